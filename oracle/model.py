@@ -106,8 +106,12 @@ class OracleTextEncoder(torch.nn.Module):
         x = F.layer_norm(x, (s.dim,), self.P("embeddings.LayerNorm.weight"),
                          self.P("embeddings.LayerNorm.bias"), s.ln_eps)
         x = F.dropout(x, self.p, self.training)
-        # additive mask: (1-mask) * finfo.min, broadcast over heads and query positions
-        bias = (1.0 - attention_mask.to(x.dtype))[:, None, None, :] * torch.finfo(x.dtype).min
+        # transformers 5.x resolves to its sdpa attention: boolean key mask, and torch's
+        # scaled_dot_product_attention returns 0 for a query row whose keys are ALL masked (a caption
+        # zeroed by modality dropout, multimodal_model.py:451-452).  Partially masked rows are
+        # identical to the eager additive finfo.min form.
+        keymask = attention_mask.to(torch.bool)[:, None, None, :]
+        row_valid = keymask.any(dim=-1, keepdim=True)
         dh = s.dim // s.heads
         for i in range(s.layers):
             K = S.text_layer_keys(s, i)
@@ -115,7 +119,8 @@ class OracleTextEncoder(torch.nn.Module):
             q = lin(x, "q").view(B, T, s.heads, dh).transpose(1, 2)
             k = lin(x, "k").view(B, T, s.heads, dh).transpose(1, 2)
             v = lin(x, "v").view(B, T, s.heads, dh).transpose(1, 2)
-            a = torch.softmax(q @ k.transpose(2, 3) * dh ** -0.5 + bias, dim=-1)
+            sc = (q @ k.transpose(2, 3) * dh ** -0.5).masked_fill(~keymask, float("-inf"))
+            a = torch.softmax(torch.where(row_valid, sc, torch.zeros_like(sc)), dim=-1) * row_valid
             a = F.dropout(a, self.p, self.training)
             ctx = (a @ v).transpose(1, 2).reshape(B, T, s.dim)
             att = F.dropout(lin(ctx, "o"), self.p, self.training) if s.name != "distilbert" else lin(ctx, "o")
