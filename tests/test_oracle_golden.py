@@ -174,7 +174,7 @@ def test_text_encoders_match_transformers(name):
         pre = f"enc_{name}_gnorm/"
         if k.startswith(pre) and "pooler" not in k:
             gn = np.linalg.norm(enc.P(k[len(pre):]).grad.numpy().astype(np.float64))
-            np.testing.assert_allclose(gn, float(g[k]), rtol=3e-3, atol=1e-6)
+            np.testing.assert_allclose(gn, float(g[k]), rtol=3e-3, atol=2e-5)  # key-bias grads are 0 up to noise
             checked += 1
     assert checked >= 90
 
