@@ -201,21 +201,21 @@ def O_hf_vit_state(vs):
           "encoder.pos_embedding": P("embeddings.position_embeddings", (1, vs.tokens, d)),
           "encoder.ln.weight": P("layernorm.weight", (d,)), "encoder.ln.bias": P("layernorm.bias", (d,))}
     for i in range(vs.layers):
-        H, L = f"encoder.layer.{i}.", f"encoder.layers.encoder_layer_{i}."
-        qkv_w = [P(H + f"attention.attention.{n}.weight", (d, d)) for n in ("query", "key", "value")]
-        qkv_b = [P(H + f"attention.attention.{n}.bias", (d,)) for n in ("query", "key", "value")]
+        H, L = f"layers.{i}.", f"encoder.layers.encoder_layer_{i}."
+        qkv_w = [P(H + f"attention.{n}.weight", (d, d)) for n in ("q_proj", "k_proj", "v_proj")]
+        qkv_b = [P(H + f"attention.{n}.bias", (d,)) for n in ("q_proj", "k_proj", "v_proj")]
         sd[L + "self_attention.in_proj_weight"] = np.concatenate(qkv_w, 0)
         sd[L + "self_attention.in_proj_bias"] = np.concatenate(qkv_b, 0)
-        sd[L + "self_attention.out_proj.weight"] = P(H + "attention.output.dense.weight", (d, d))
-        sd[L + "self_attention.out_proj.bias"] = P(H + "attention.output.dense.bias", (d,))
+        sd[L + "self_attention.out_proj.weight"] = P(H + "attention.o_proj.weight", (d, d))
+        sd[L + "self_attention.out_proj.bias"] = P(H + "attention.o_proj.bias", (d,))
         sd[L + "ln_1.weight"] = P(H + "layernorm_before.weight", (d,))
         sd[L + "ln_1.bias"] = P(H + "layernorm_before.bias", (d,))
         sd[L + "ln_2.weight"] = P(H + "layernorm_after.weight", (d,))
         sd[L + "ln_2.bias"] = P(H + "layernorm_after.bias", (d,))
-        sd[L + "mlp.0.weight"] = P(H + "intermediate.dense.weight", (f, d))
-        sd[L + "mlp.0.bias"] = P(H + "intermediate.dense.bias", (f,))
-        sd[L + "mlp.3.weight"] = P(H + "output.dense.weight", (d, f))
-        sd[L + "mlp.3.bias"] = P(H + "output.dense.bias", (d,))
+        sd[L + "mlp.0.weight"] = P(H + "mlp.fc1.weight", (f, d))
+        sd[L + "mlp.0.bias"] = P(H + "mlp.fc1.bias", (f,))
+        sd[L + "mlp.3.weight"] = P(H + "mlp.fc2.weight", (d, f))
+        sd[L + "mlp.3.bias"] = P(H + "mlp.fc2.bias", (d,))
     return sd
 
 
