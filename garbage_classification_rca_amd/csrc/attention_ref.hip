@@ -1,0 +1,178 @@
+// K3 (reference-grade): multi-head attention forward / backward on a fused QKV buffer, any dtype, fp32 math.
+// One wave per query row (forward, dQ) or per key row (dK, dV): lanes own keys (resp. queries) for the score
+// phase and head-dim channels for the value phase; probabilities cross over through LDS.  This is the fp32
+// "parity mode" kernel and the checker for the MFMA kernel in attention_mfma.hip; it is not the fast path.
+#include "common.h"
+
+#define ATT_MAX_S 1024
+#define ATT_MAX_DH 128
+
+template <typename T>
+__device__ __forceinline__ float dot_row(const T* __restrict__ row, const float* __restrict__ vec_lds, int dh) {
+  float a = 0.f;
+  for (int d = 0; d < dh; d += 4) {
+    Vec4<T> v = Vec4<T>::load(row + d);
+    a += v.v[0] * vec_lds[d] + v.v[1] * vec_lds[d + 1] + v.v[2] * vec_lds[d + 2] + v.v[3] * vec_lds[d + 3];
+  }
+  return a;
+}
+
+// grid (ceil(S/4), B*H), block 256 (4 waves = 4 query rows)
+template <typename T>
+__global__ void __launch_bounds__(256)
+mha_fwd_ref_k(const T* __restrict__ qkv, const int32_t* __restrict__ key_mask, T* __restrict__ out, float* __restrict__ lse,
+              int B, int H, int S, int dh, float scale) {
+  extern __shared__ float sm[];     // per wave: q[dh] | p[S]
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int b = blockIdx.y / H, h = blockIdx.y % H;
+  const int i = blockIdx.x * 4 + wave;
+  float* qv = sm + wave * (ATT_MAX_DH + S);
+  float* p = qv + ATT_MAX_DH;
+  const int64_t ld = 3LL * H * dh;
+  const T* Q = qkv + (int64_t)b * S * ld + h * dh;
+  const T* Kp = Q + H * dh;
+  const T* Vp = Kp + H * dh;
+  if (i >= S) return;                      // whole wave exits together (i is wave-uniform); no block barrier below
+  for (int d = lane; d < dh; d += 64) qv[d] = to_f(Q[(int64_t)i * ld + d]);
+  __builtin_amdgcn_wave_barrier();
+  float m = -INFINITY;
+  for (int j = lane; j < S; j += 64) {
+    float s = -INFINITY;
+    if (!key_mask || key_mask[b * S + j] != 0) s = dot_row(Kp + (int64_t)j * ld, qv, dh) * scale;
+    p[j] = s;
+    m = fmaxf(m, s);
+  }
+  m = wave_max(m);
+  float l = 0.f;
+  if (m > -INFINITY) {
+    for (int j = lane; j < S; j += 64) { const float e = __expf(p[j] - m); p[j] = e; l += e; }
+  } else {
+    for (int j = lane; j < S; j += 64) p[j] = 0.f;
+  }
+  l = wave_sum(l);
+  const float inv = l > 0.f ? 1.f / l : 0.f;
+  __builtin_amdgcn_wave_barrier();
+  for (int d = lane; d < dh; d += 64) {
+    float o = 0.f;
+    for (int j = 0; j < S; ++j) o += p[j] * to_f(Vp[(int64_t)j * ld + d]);
+    out[((int64_t)b * S + i) * (H * dh) + h * dh + d] = from_f<T>(o * inv);
+  }
+  if (lane == 0) lse[((int64_t)b * H + h) * S + i] = l > 0.f ? m + __logf(l) : INFINITY;
+}
+
+// dQ: one wave per query row
+template <typename T>
+__global__ void __launch_bounds__(256)
+mha_bwd_dq_ref_k(const T* __restrict__ qkv, const int32_t* __restrict__ key_mask, const T* __restrict__ out,
+                 const T* __restrict__ dout, const float* __restrict__ lse, T* __restrict__ dqkv,
+                 int B, int H, int S, int dh, float scale) {
+  extern __shared__ float sm[];     // per wave: q[dh] | do[dh] | ds[S]
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int b = blockIdx.y / H, h = blockIdx.y % H;
+  const int i = blockIdx.x * 4 + wave;
+  float* qv = sm + wave * (2 * ATT_MAX_DH + S);
+  float* dov = qv + ATT_MAX_DH;
+  float* ds = dov + ATT_MAX_DH;
+  const int64_t ld = 3LL * H * dh, ldo = (int64_t)H * dh;
+  const T* Q = qkv + (int64_t)b * S * ld + h * dh;
+  const T* Kp = Q + H * dh;
+  const T* Vp = Kp + H * dh;
+  if (i >= S) return;
+  float dsum = 0.f;
+  for (int d = lane; d < dh; d += 64) {
+    qv[d] = to_f(Q[(int64_t)i * ld + d]);
+    const float g = to_f(dout[((int64_t)b * S + i) * ldo + h * dh + d]);
+    dov[d] = g;
+    dsum += g * to_f(out[((int64_t)b * S + i) * ldo + h * dh + d]);
+  }
+  dsum = wave_sum(dsum);
+  __builtin_amdgcn_wave_barrier();
+  const float L = lse[((int64_t)b * H + h) * S + i];
+  for (int j = lane; j < S; j += 64) {
+    float v = 0.f;
+    if (!key_mask || key_mask[b * S + j] != 0) {
+      const float s = dot_row(Kp + (int64_t)j * ld, qv, dh) * scale;
+      const float pj = __expf(s - L);
+      const float dp = dot_row(Vp + (int64_t)j * ld, dov, dh);
+      v = pj * (dp - dsum) * scale;
+    }
+    ds[j] = v;
+  }
+  __builtin_amdgcn_wave_barrier();
+  for (int d = lane; d < dh; d += 64) {
+    float a = 0.f;
+    for (int j = 0; j < S; ++j) a += ds[j] * to_f(Kp[(int64_t)j * ld + d]);
+    dqkv[((int64_t)b * S + i) * ld + h * dh + d] = from_f<T>(a);
+  }
+}
+
+// dK, dV: one wave per key row
+template <typename T>
+__global__ void __launch_bounds__(256)
+mha_bwd_dkv_ref_k(const T* __restrict__ qkv, const int32_t* __restrict__ key_mask, const T* __restrict__ out,
+                  const T* __restrict__ dout, const float* __restrict__ lse, T* __restrict__ dqkv,
+                  int B, int H, int S, int dh, float scale) {
+  extern __shared__ float sm[];     // per wave: k[dh] | v[dh] | p[S] | ds[S]
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int b = blockIdx.y / H, h = blockIdx.y % H;
+  const int j = blockIdx.x * 4 + wave;
+  float* kv = sm + wave * (2 * ATT_MAX_DH + 2 * S);
+  float* vv = kv + ATT_MAX_DH;
+  float* p = vv + ATT_MAX_DH;
+  float* ds = p + S;
+  const int64_t ld = 3LL * H * dh, ldo = (int64_t)H * dh;
+  const T* Q = qkv + (int64_t)b * S * ld + h * dh;
+  const T* Kp = Q + H * dh;
+  const T* Vp = Kp + H * dh;
+  if (j >= S) return;
+  const bool masked = key_mask && key_mask[b * S + j] == 0;
+  for (int d = lane; d < dh; d += 64) { kv[d] = to_f(Kp[(int64_t)j * ld + d]); vv[d] = to_f(Vp[(int64_t)j * ld + d]); }
+  __builtin_amdgcn_wave_barrier();
+  for (int i = lane; i < S; i += 64) {
+    float pi = 0.f, dsi = 0.f;
+    if (!masked) {
+      const T* dorow = dout + ((int64_t)b * S + i) * ldo + h * dh;
+      const T* orow = out + ((int64_t)b * S + i) * ldo + h * dh;
+      const float s = dot_row(Q + (int64_t)i * ld, kv, dh) * scale;
+      pi = __expf(s - lse[((int64_t)b * H + h) * S + i]);
+      const float dp = dot_row(dorow, vv, dh);
+      float dsum = 0.f;
+      for (int d = 0; d < dh; ++d) dsum += to_f(dorow[d]) * to_f(orow[d]);
+      dsi = pi * (dp - dsum) * scale;
+    }
+    p[i] = pi; ds[i] = dsi;
+  }
+  __builtin_amdgcn_wave_barrier();
+  for (int d = lane; d < dh; d += 64) {
+    float ak = 0.f, av = 0.f;
+    for (int i = 0; i < S; ++i) {
+      ak += ds[i] * to_f(Q[(int64_t)i * ld + d]);
+      av += p[i] * to_f(dout[((int64_t)b * S + i) * ldo + h * dh + d]);
+    }
+    dqkv[((int64_t)b * S + j) * ld + (int64_t)H * dh + h * dh + d] = from_f<T>(ak);
+    dqkv[((int64_t)b * S + j) * ld + 2LL * H * dh + h * dh + d] = from_f<T>(av);
+  }
+}
+
+int mmrca_mha_fwd_ref(const void* qkv, const int32_t* key_mask, void* out, float* lse, int B, int H, int S, int dh,
+                      float scale, int dtype, hipStream_t st) {
+  MMRCA_REQUIRE(S <= ATT_MAX_S && dh <= ATT_MAX_DH && dh % 4 == 0, "mha_fwd(ref): S=%d dh=%d unsupported", S, dh);
+  dim3 grid((S + 3) / 4, B * H);
+  const size_t lds = 4 * (ATT_MAX_DH + S) * sizeof(float);
+  MMRCA_DISPATCH_DTYPE(dtype, "mha_fwd",
+    hipLaunchKernelGGL(mha_fwd_ref_k<T>, grid, dim3(256), lds, st, (const T*)qkv, key_mask, (T*)out, lse, B, H, S, dh, scale);)
+  MMRCA_CHECK_LAUNCH("mha_fwd(ref)");
+  return 0;
+}
+
+int mmrca_mha_bwd_ref(const void* qkv, const int32_t* key_mask, const void* out, const void* dout, const float* lse,
+                      void* dqkv, int B, int H, int S, int dh, float scale, int dtype, hipStream_t st) {
+  MMRCA_REQUIRE(S <= ATT_MAX_S && dh <= ATT_MAX_DH && dh % 4 == 0, "mha_bwd(ref): S=%d dh=%d unsupported", S, dh);
+  dim3 grid((S + 3) / 4, B * H);
+  const size_t lds1 = 4 * (2 * ATT_MAX_DH + S) * sizeof(float), lds2 = 4 * (2 * ATT_MAX_DH + 2 * S) * sizeof(float);
+  MMRCA_DISPATCH_DTYPE(dtype, "mha_bwd",
+    hipLaunchKernelGGL(mha_bwd_dq_ref_k<T>, grid, dim3(256), lds1, st, (const T*)qkv, key_mask, (const T*)out, (const T*)dout, lse, (T*)dqkv, B, H, S, dh, scale);
+    hipLaunchKernelGGL(mha_bwd_dkv_ref_k<T>, grid, dim3(256), lds2, st, (const T*)qkv, key_mask, (const T*)out, (const T*)dout, lse, (T*)dqkv, B, H, S, dh, scale);)
+  MMRCA_CHECK_LAUNCH("mha_bwd(ref)");
+  return 0;
+}

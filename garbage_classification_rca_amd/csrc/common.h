@@ -1,0 +1,81 @@
+// Shared helpers for the libmmrca HIP sources (gfx950 only; wave = 64 lanes).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdarg.h>
+#include <stdio.h>
+#include "../../include/mmrca.h"
+
+typedef __bf16 bf16_t;
+
+int mmrca_fail(int code, const char* fmt, ...);   // records the message, returns code (api.cpp)
+
+#define MMRCA_CHECK_LAUNCH(name)                                                         \
+  do {                                                                                   \
+    hipError_t e_ = hipGetLastError();                                                   \
+    if (e_ != hipSuccess) return mmrca_fail(-10, "%s: launch failed: %s", name, hipGetErrorString(e_)); \
+  } while (0)
+
+#define MMRCA_REQUIRE(cond, ...)                         \
+  do {                                                   \
+    if (!(cond)) return mmrca_fail(-1, __VA_ARGS__);     \
+  } while (0)
+
+__device__ __forceinline__ float to_f(float x) { return x; }
+__device__ __forceinline__ float to_f(bf16_t x) { return (float)x; }
+template <typename T> __device__ __forceinline__ T from_f(float x);
+template <> __device__ __forceinline__ float from_f<float>(float x) { return x; }
+template <> __device__ __forceinline__ bf16_t from_f<bf16_t>(float x) { return (bf16_t)x; }
+
+// 4-element vector access (16 B for f32, 8 B for bf16); pointers must be aligned accordingly.
+template <typename T> struct Vec4;
+template <> struct Vec4<float> {
+  float v[4];
+  __device__ __forceinline__ static Vec4 load(const float* p) {
+    Vec4 r; float4 t = *reinterpret_cast<const float4*>(p); r.v[0] = t.x; r.v[1] = t.y; r.v[2] = t.z; r.v[3] = t.w; return r;
+  }
+  __device__ __forceinline__ void store(float* p) const { *reinterpret_cast<float4*>(p) = make_float4(v[0], v[1], v[2], v[3]); }
+};
+template <> struct Vec4<bf16_t> {
+  float v[4];
+  __device__ __forceinline__ static Vec4 load(const bf16_t* p) {
+    typedef __attribute__((ext_vector_type(4))) __bf16 b4;
+    b4 t = *reinterpret_cast<const b4*>(p);
+    Vec4 r; r.v[0] = (float)t[0]; r.v[1] = (float)t[1]; r.v[2] = (float)t[2]; r.v[3] = (float)t[3]; return r;
+  }
+  __device__ __forceinline__ void store(bf16_t* p) const {
+    typedef __attribute__((ext_vector_type(4))) __bf16 b4;
+    b4 t; t[0] = (bf16_t)v[0]; t[1] = (bf16_t)v[1]; t[2] = (bf16_t)v[2]; t[3] = (bf16_t)v[3];
+    *reinterpret_cast<b4*>(p) = t;
+  }
+};
+
+__device__ __forceinline__ float wave_sum(float x) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) x += __shfl_xor(x, o, 64);
+  return x;
+}
+__device__ __forceinline__ float wave_max(float x) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) x = fmaxf(x, __shfl_xor(x, o, 64));
+  return x;
+}
+
+// counter-based uniform in [0,1): splitmix64 of (seed, index)
+__device__ __forceinline__ float mmrca_uniform(uint64_t seed, uint64_t idx) {
+  uint64_t z = seed + 0x9E3779B97F4A7C15ull * (idx + 1);
+  z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+  z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+  z = z ^ (z >> 31);
+  return (float)(z >> 40) * (1.0f / 16777216.0f);
+}
+
+__device__ __forceinline__ float gelu_f(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752f)); }
+__device__ __forceinline__ float gelu_grad_f(float x) {
+  return 0.5f * (1.0f + erff(x * 0.70710678118654752f)) + x * 0.3989422804014327f * __expf(-0.5f * x * x);
+}
+
+#define MMRCA_DISPATCH_DTYPE(dtype, NAME, ...)                               \
+  if ((dtype) == MMRCA_F32) { typedef float T; __VA_ARGS__ }                 \
+  else if ((dtype) == MMRCA_BF16) { typedef bf16_t T; __VA_ARGS__ }          \
+  else return mmrca_fail(-2, "%s: bad dtype %d", NAME, (int)(dtype));

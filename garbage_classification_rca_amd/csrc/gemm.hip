@@ -1,0 +1,329 @@
+// K2: C[M,N] = act(A (.) B + bias) + addend  -- every nn.Linear forward, input-gradient and weight-gradient
+// on the MM-RCA path (see include/mmrca.h).
+//
+// Two implementations behind one entry point:
+//   * gemm_ref_k   : fp32-accumulating VALU tile kernel, any dtype / layout / shape.  It is the fp32 "parity mode"
+//                    and the fallback for shapes the MFMA kernel does not take (e.g. the 4-class logits).
+//   * gemm_mfma_k  : bf16 v_mfma_f32_16x16x32_bf16 kernel, 128x128x64 tiles, 4 waves (2x2, 64x64 per wave),
+//                    operands staged HBM->LDS with global_load_lds (16 B/lane, no VGPR round trip), double-buffered.
+//                    Both operand layouts are handled in LDS, so no transposed copies of weights or activations
+//                    ever exist in HBM:
+//                      ROWK [rows][k]  : 128-B LDS rows, 16-B chunks XOR-swizzled by (row>>1)&7 -> conflict-free
+//                                        ds_read_b128 fragment reads (swizzle applied on the global source address,
+//                                        because global_load_lds writes lane-linear).
+//                      KROW [k][rows]  : 256-B LDS rows, 32-B granules XOR-swizzled by (k&3)|((k>>3)&1)<<2, read
+//                                        with ds_read_b64_tr_b16 (hardware transpose) -> conflict-free.
+//                    XCD-aware block->tile map (8 XCDs, private L2s) with grouped-M rastering.
+//                    Weight gradients (fp32, +=) split the long contraction over blockIdx.y and combine with
+//                    fp32 atomics shaped as 64-B row segments.
+#include "common.h"
+
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+
+// ======================================================================================================
+// reference kernel
+// ======================================================================================================
+template <typename T>
+__global__ void __launch_bounds__(256)
+gemm_ref_k(const T* __restrict__ A, const T* __restrict__ B, void* __restrict__ Cv, const T* __restrict__ bias,
+           const T* __restrict__ addend, T* __restrict__ preact, int64_t M, int64_t N, int64_t K,
+           int64_t sam, int64_t sak, int64_t sbn, int64_t sbk, int64_t ldc, int act, int accum) {
+  __shared__ float As[16][65], Bs[16][65];
+  const int tx = threadIdx.x & 15, ty = threadIdx.x >> 4;
+  const int64_t m0 = (int64_t)blockIdx.y * 64, n0 = (int64_t)blockIdx.x * 64;
+  float acc[4][4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = 0.f;
+  for (int64_t k0 = 0; k0 < K; k0 += 16) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int idx = threadIdx.x + i * 256;
+      int mm, kk;
+      if (sak == 1) { mm = idx >> 4; kk = idx & 15; } else { kk = idx >> 6; mm = idx & 63; }
+      const int64_t gm = m0 + mm, gk = k0 + kk;
+      As[kk][mm] = (gm < M && gk < K) ? to_f(A[gm * sam + gk * sak]) : 0.f;
+      int nn, k2;
+      if (sbk == 1) { nn = idx >> 4; k2 = idx & 15; } else { k2 = idx >> 6; nn = idx & 63; }
+      const int64_t gn = n0 + nn, gk2 = k0 + k2;
+      Bs[k2][nn] = (gn < N && gk2 < K) ? to_f(B[gn * sbn + gk2 * sbk]) : 0.f;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int kk = 0; kk < 16; ++kk) {
+      float a[4], b[4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) { a[i] = As[kk][ty * 4 + i]; b[i] = Bs[kk][tx * 4 + i]; }
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = fmaf(a[i], b[j], acc[i][j]);
+    }
+    __syncthreads();
+  }
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int64_t m = m0 + ty * 4 + i;
+    if (m >= M) continue;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int64_t n = n0 + tx * 4 + j;
+      if (n >= N) continue;
+      float v = acc[i][j];
+      if (bias) v += to_f(bias[n]);
+      if (preact) preact[m * ldc + n] = from_f<T>(v);
+      if (act == MMRCA_ACT_GELU) v = gelu_f(v);
+      if (addend) v += to_f(addend[m * ldc + n]);
+      if (accum) ((float*)Cv)[m * ldc + n] += v;
+      else ((T*)Cv)[m * ldc + n] = from_f<T>(v);
+    }
+  }
+}
+
+// ======================================================================================================
+// MFMA kernel
+// ======================================================================================================
+#define GBM 128
+#define GBN 128
+#define GBK 64
+#define TILE_BYTES (128 * 64 * 2)    // one operand tile: 16 KiB in either layout
+
+typedef __attribute__((address_space(3))) void lds_void;
+typedef const __attribute__((address_space(1))) void gbl_void;
+
+__device__ __forceinline__ int krow_f(int row) { return (row & 3) | (((row >> 3) & 1) << 2); }
+
+// stage one 128x64 operand tile (16 x 1-KiB wave instructions; this wave issues 4 of them)
+template <bool KROW>
+__device__ __forceinline__ void stage_tile(const bf16_t* __restrict__ base, int64_t ld, int64_t row0, int64_t rows_total,
+                                           int64_t k0, char* lds_tile, int wave, int lane) {
+#pragma unroll
+  for (int ii = 0; ii < 4; ++ii) {
+    const int i = wave * 4 + ii;
+    const bf16_t* src;
+    if (!KROW) {
+      const int r = 8 * i + (lane >> 3);
+      const int c = (lane & 7) ^ ((r >> 1) & 7);
+      int64_t gr = row0 + r;
+      if (gr > rows_total - 1) gr = rows_total - 1;        // edge rows: read a valid row, results are never stored
+      src = base + gr * ld + k0 + c * 8;
+    } else {
+      const int kr = 4 * i + (lane >> 4);
+      const int chp = lane & 15;
+      const int c = ((((chp >> 1) ^ krow_f(kr))) << 1) | (chp & 1);
+      src = base + (k0 + kr) * ld + row0 + c * 8;
+    }
+    __builtin_amdgcn_global_load_lds((gbl_void*)src, (lds_void*)(lds_tile + i * 1024), 16, 0, 0);
+  }
+}
+
+// fragment of the 16 rows starting at tile-row `rb` (multiple of 16), k-step ks (32 contraction elements)
+template <bool KROW>
+__device__ __forceinline__ bf16x8 load_frag(const char* lds_tile, int rb, int ks, int lane) {
+  if (!KROW) {
+    const int r = rb + (lane & 15);
+    const int ch = 4 * ks + (lane >> 4);
+    return *reinterpret_cast<const bf16x8*>(lds_tile + r * 128 + ((ch ^ ((r >> 1) & 7)) << 4));
+  } else {
+    const int g = lane >> 4, i = lane & 15, q = i >> 2, p = i & 3;
+    const int row = 32 * ks + 8 * g + q;
+    const int off0 = row * 256 + ((((rb >> 4) ^ krow_f(row))) << 5) + p * 8;
+    const int row1 = row + 4;
+    const int off1 = row1 * 256 + ((((rb >> 4) ^ krow_f(row1))) << 5) + p * 8;
+    bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((__attribute__((address_space(3))) bf16x4*)(lds_tile + off0));
+    bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((__attribute__((address_space(3))) bf16x4*)(lds_tile + off1));
+    bf16x8 r;
+    r[0] = lo[0]; r[1] = lo[1]; r[2] = lo[2]; r[3] = lo[3]; r[4] = hi[0]; r[5] = hi[1]; r[6] = hi[2]; r[7] = hi[3];
+    return r;
+  }
+}
+
+template <bool A_KROW, bool B_KROW, bool ATOMIC_F32>
+__global__ void __launch_bounds__(256)
+gemm_mfma_k(const bf16_t* __restrict__ A, const bf16_t* __restrict__ B, void* __restrict__ Cv, const bf16_t* __restrict__ bias,
+            const bf16_t* __restrict__ addend, bf16_t* __restrict__ preact, int64_t M, int64_t N, int64_t K,
+            int64_t lda, int64_t ldb, int64_t ldc, int act, int tiles_m, int tiles_n, int64_t ksplit_len) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];   // [2 buffers][A tile | B tile]
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int wr = wave >> 1, wc = wave & 1;
+
+  // XCD-aware remap (blocks b and b+8 share an XCD under round-robin dispatch; speed only), then grouped-M raster
+  const int nwg = tiles_m * tiles_n;
+  const int orig = blockIdx.x;
+  const int q8 = nwg >> 3, r8 = nwg & 7, xcd = orig & 7;
+  const int wgid = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (orig >> 3);
+  const int GROUP = 8;
+  const int group = wgid / (GROUP * tiles_n);
+  const int first_m = group * GROUP;
+  const int gsize = (tiles_m - first_m) < GROUP ? (tiles_m - first_m) : GROUP;
+  const int tm = first_m + (wgid % (GROUP * tiles_n)) % gsize;
+  const int tn = (wgid % (GROUP * tiles_n)) / gsize;
+  const int64_t m_blk = (int64_t)tm * GBM, n_blk = (int64_t)tn * GBN;
+
+  const int64_t kbeg = (int64_t)blockIdx.y * ksplit_len;
+  int64_t kend = kbeg + ksplit_len; if (kend > K) kend = K;
+  const int nt = (int)((kend - kbeg + GBK - 1) / GBK);
+
+  f32x4 acc[4][4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+  if (nt > 0) {
+    stage_tile<A_KROW>(A, lda, m_blk, M, kbeg, smem, wave, lane);
+    stage_tile<B_KROW>(B, ldb, n_blk, N, kbeg, smem + TILE_BYTES, wave, lane);
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+
+  for (int t = 0; t < nt; ++t) {
+    char* cur = smem + (t & 1) * 2 * TILE_BYTES;
+    char* nxt = smem + ((t + 1) & 1) * 2 * TILE_BYTES;
+    if (t + 1 < nt) {
+      stage_tile<A_KROW>(A, lda, m_blk, M, kbeg + (int64_t)(t + 1) * GBK, nxt, wave, lane);
+      stage_tile<B_KROW>(B, ldb, n_blk, N, kbeg + (int64_t)(t + 1) * GBK, nxt + TILE_BYTES, wave, lane);
+    }
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+      bf16x8 af[4], bfr[4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) af[i] = load_frag<A_KROW>(cur, wr * 64 + i * 16, ks, lane);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) bfr[j] = load_frag<B_KROW>(cur + TILE_BYTES, wc * 64 + j * 16, ks, lane);
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          if (ATOMIC_F32) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i], bfr[j], acc[i][j], 0, 0, 0);  // D[m][n]
+          else            acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr[j], af[i], acc[i][j], 0, 0, 0);  // D[n][m]
+        }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+  }
+
+  const int g = lane >> 4, l16 = lane & 15;
+  if (ATOMIC_F32) {
+    float* C = (float*)Cv;
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int64_t n = n_blk + wc * 64 + j * 16 + l16;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int64_t m = m_blk + wr * 64 + i * 16 + 4 * g + r;
+          if (m < M && n < N) atomicAdd(C + m * ldc + n, acc[i][j][r]);
+        }
+      }
+  } else {
+    bf16_t* C = (bf16_t*)Cv;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int64_t m = m_blk + wr * 64 + i * 16 + l16;
+      if (m >= M) continue;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int64_t n0 = n_blk + wc * 64 + j * 16 + 4 * g;
+        float v[4] = {acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]};
+        if (bias) {
+          bf16x4 b4 = *reinterpret_cast<const bf16x4*>(bias + n0);
+#pragma unroll
+          for (int r = 0; r < 4; ++r) v[r] += (float)b4[r];
+        }
+        if (preact) {
+          bf16x4 o;
+#pragma unroll
+          for (int r = 0; r < 4; ++r) o[r] = (bf16_t)v[r];
+          *reinterpret_cast<bf16x4*>(preact + m * ldc + n0) = o;
+        }
+        if (act == MMRCA_ACT_GELU) {
+#pragma unroll
+          for (int r = 0; r < 4; ++r) v[r] = gelu_f(v[r]);
+        }
+        if (addend) {
+          bf16x4 a4 = *reinterpret_cast<const bf16x4*>(addend + m * ldc + n0);
+#pragma unroll
+          for (int r = 0; r < 4; ++r) v[r] += (float)a4[r];
+        }
+        bf16x4 o;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) o[r] = (bf16_t)v[r];
+        *reinterpret_cast<bf16x4*>(C + m * ldc + n0) = o;
+      }
+    }
+  }
+}
+
+static bool aligned16(const void* p) { return (((uintptr_t)p) & 15) == 0; }
+
+template <bool AK, bool BK2, bool AT>
+static void launch_mfma(const void* A, const void* B, void* C, const void* bias, const void* addend, void* preact,
+                        int64_t M, int64_t N, int64_t K, int64_t lda, int64_t ldb, int64_t ldc, int act, int tiles_m,
+                        int tiles_n, int ksplits, int64_t ksplit_len, hipStream_t st) {
+  hipLaunchKernelGGL((gemm_mfma_k<AK, BK2, AT>), dim3(tiles_m * tiles_n, ksplits), dim3(256), 4 * TILE_BYTES, st,
+                     (const bf16_t*)A, (const bf16_t*)B, C, (const bf16_t*)bias, (const bf16_t*)addend, (bf16_t*)preact,
+                     M, N, K, lda, ldb, ldc, act, tiles_m, tiles_n, ksplit_len);
+}
+
+extern "C" int mmrca_gemm(const void* A, const void* B, void* C, const void* bias, const void* addend, void* preact,
+                          int64_t M, int64_t N, int64_t K, int64_t lda, int64_t ldb, int64_t ldc,
+                          int a_layout, int b_layout, int act, int out_f32_accum, int dtype, int impl, void* stream) {
+  MMRCA_REQUIRE(A && B && C, "gemm: null operand");
+  MMRCA_REQUIRE(M > 0 && N > 0 && K > 0, "gemm: bad shape M=%lld N=%lld K=%lld", (long long)M, (long long)N, (long long)K);
+  MMRCA_REQUIRE((a_layout == MMRCA_ROWK || a_layout == MMRCA_KROW) && (b_layout == MMRCA_ROWK || b_layout == MMRCA_KROW), "gemm: bad layout");
+  MMRCA_REQUIRE(act == MMRCA_ACT_NONE || act == MMRCA_ACT_GELU, "gemm: bad activation");
+  MMRCA_REQUIRE(lda >= (a_layout == MMRCA_ROWK ? K : M) && ldb >= (b_layout == MMRCA_ROWK ? K : N) && ldc >= N, "gemm: leading dimension too small");
+  MMRCA_REQUIRE(!(out_f32_accum && (bias || addend || preact || act != MMRCA_ACT_NONE)), "gemm: accumulate mode takes no epilogue");
+  hipStream_t st = (hipStream_t)stream;
+
+  bool ok_mfma = (dtype == MMRCA_BF16) && (N % GBN == 0) && (K % GBK == 0) && (lda % 8 == 0) && (ldb % 8 == 0) &&
+                 (ldc % 4 == 0) && aligned16(A) && aligned16(B) && aligned16(C) && (!bias || aligned16(bias)) &&
+                 (!addend || aligned16(addend)) && (!preact || aligned16(preact)) &&
+                 (a_layout == MMRCA_ROWK || M % GBM == 0);
+  if (impl == MMRCA_GEMM_MFMA && !ok_mfma)
+    return mmrca_fail(-3, "gemm: shape M=%lld N=%lld K=%lld dtype=%d does not qualify for the MFMA kernel", (long long)M, (long long)N, (long long)K, dtype);
+  const bool use_mfma = ok_mfma && impl != MMRCA_GEMM_REF;
+
+  if (use_mfma) {
+    const int tiles_m = (int)((M + GBM - 1) / GBM), tiles_n = (int)(N / GBN);
+    int ksplits = 1;
+    int64_t ksplit_len = K;
+    if (out_f32_accum) {
+      const int64_t ksteps = K / GBK;
+      int64_t want = 768 / ((int64_t)tiles_m * tiles_n);
+      if (want < 1) want = 1;
+      if (want > ksteps / 4) want = ksteps / 4 > 0 ? ksteps / 4 : 1;
+      const int64_t steps_per = (ksteps + want - 1) / want;
+      ksplit_len = steps_per * GBK;
+      ksplits = (int)((ksteps + steps_per - 1) / steps_per);
+    }
+    const bool ak = a_layout == MMRCA_KROW, bk = b_layout == MMRCA_KROW, at = out_f32_accum != 0;
+#define L(AK_, BK_, AT_) launch_mfma<AK_, BK_, AT_>(A, B, C, bias, addend, preact, M, N, K, lda, ldb, ldc, act, tiles_m, tiles_n, ksplits, ksplit_len, st)
+    if (!ak && !bk && !at) L(false, false, false);
+    else if (!ak && bk && !at) L(false, true, false);
+    else if (ak && !bk && !at) L(true, false, false);
+    else if (ak && bk && !at) L(true, true, false);
+    else if (!ak && !bk && at) L(false, false, true);
+    else if (!ak && bk && at) L(false, true, true);
+    else if (ak && !bk && at) L(true, false, true);
+    else L(true, true, true);
+#undef L
+    MMRCA_CHECK_LAUNCH("gemm(mfma)");
+    return 0;
+  }
+
+  const int64_t sam = a_layout == MMRCA_ROWK ? lda : 1, sak = a_layout == MMRCA_ROWK ? 1 : lda;
+  const int64_t sbn = b_layout == MMRCA_ROWK ? ldb : 1, sbk = b_layout == MMRCA_ROWK ? 1 : ldb;
+  dim3 grid((unsigned)((N + 63) / 64), (unsigned)((M + 63) / 64));
+  MMRCA_REQUIRE(grid.y <= 65535, "gemm(ref): M too large for the reference kernel grid");
+  MMRCA_DISPATCH_DTYPE(dtype, "gemm",
+    hipLaunchKernelGGL(gemm_ref_k<T>, grid, dim3(256), 0, st, (const T*)A, (const T*)B, C, (const T*)bias, (const T*)addend,
+                       (T*)preact, M, N, K, sam, sak, sbn, sbk, ldc, act, out_f32_accum);)
+  MMRCA_CHECK_LAUNCH("gemm(ref)");
+  return 0;
+}

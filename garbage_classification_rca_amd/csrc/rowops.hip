@@ -1,0 +1,533 @@
+// Row-wise and elementwise kernels of the MM-RCA path: LayerNorm (+residual) fwd/bwd, GELU backward, bias
+// (column) gradient, text embeddings, ViT patchify/assemble, loss, optimizers.  All are HBM-bound: one wave
+// per row, 8- or 16-byte accesses per lane, fp32 statistics, wave-shuffle reductions.
+#include "common.h"
+
+#define LN_MAXV 8   // row kept in registers: D <= 256 * LN_MAXV
+
+// --------------------------------------------------------------------------------------------------------
+// s = x (+res); y = LN(s)*gamma+beta
+// --------------------------------------------------------------------------------------------------------
+template <typename T>
+__global__ void __launch_bounds__(256)
+add_ln_fwd_k(const T* __restrict__ x, const T* __restrict__ res, const T* __restrict__ gamma, const T* __restrict__ beta,
+             T* __restrict__ sum_out, T* __restrict__ y, float* __restrict__ mean, float* __restrict__ rstd,
+             int64_t rows, int D, int64_t ld_x, int64_t ld_y, float eps) {
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  for (int64_t row = (int64_t)blockIdx.x * 4 + wave; row < rows; row += (int64_t)gridDim.x * 4) {
+    float v[LN_MAXV][4];
+    float s = 0.f;
+#pragma unroll
+    for (int it = 0; it < LN_MAXV; ++it) {
+      const int c = it * 256 + lane * 4;
+      if (c < D) {
+        Vec4<T> a = Vec4<T>::load(x + row * ld_x + c);
+        if (res) {
+          Vec4<T> r = Vec4<T>::load(res + row * ld_x + c);
+#pragma unroll
+          for (int j = 0; j < 4; ++j) a.v[j] += r.v[j];
+        }
+        if (sum_out) {
+          // the stored sum is what the backward re-reads: round once, then normalise the rounded values
+#pragma unroll
+          for (int j = 0; j < 4; ++j) a.v[j] = to_f(from_f<T>(a.v[j]));
+          a.store(sum_out + row * ld_x + c);
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { v[it][j] = a.v[j]; s += a.v[j]; }
+      }
+    }
+    const float mu = wave_sum(s) / (float)D;
+    float q = 0.f;
+#pragma unroll
+    for (int it = 0; it < LN_MAXV; ++it) {
+      const int c = it * 256 + lane * 4;
+      if (c < D) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { const float d = v[it][j] - mu; q += d * d; }
+      }
+    }
+    const float rs = rsqrtf(wave_sum(q) / (float)D + eps);
+    if (lane == 0) { if (mean) mean[row] = mu; if (rstd) rstd[row] = rs; }
+#pragma unroll
+    for (int it = 0; it < LN_MAXV; ++it) {
+      const int c = it * 256 + lane * 4;
+      if (c < D) {
+        Vec4<T> g = Vec4<T>::load(gamma + c), b = Vec4<T>::load(beta + c), o;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) o.v[j] = (v[it][j] - mu) * rs * g.v[j] + b.v[j];
+        o.store(y + row * ld_y + c);
+      }
+    }
+  }
+}
+
+extern "C" int mmrca_add_layernorm_fwd(const void* x, const void* res, const void* gamma, const void* beta,
+                                       void* sum_out, void* y, float* mean, float* rstd, int64_t rows, int D,
+                                       int64_t ld_x, int64_t ld_y, float eps, int dtype, void* stream) {
+  MMRCA_REQUIRE(x && gamma && beta && y, "add_layernorm_fwd: null pointer");
+  MMRCA_REQUIRE(D > 0 && D % 4 == 0 && D <= 256 * LN_MAXV, "add_layernorm_fwd: D=%d unsupported (multiple of 4, <= %d)", D, 256 * LN_MAXV);
+  MMRCA_REQUIRE(ld_x >= D && ld_y >= D && ld_x % 4 == 0 && ld_y % 4 == 0, "add_layernorm_fwd: bad leading dims");
+  if (rows <= 0) return 0;
+  const int grid = (int)((rows + 3) / 4 < 4096 ? (rows + 3) / 4 : 4096);
+  MMRCA_DISPATCH_DTYPE(dtype, "add_layernorm_fwd",
+    hipLaunchKernelGGL(add_ln_fwd_k<T>, dim3(grid), dim3(256), 0, (hipStream_t)stream, (const T*)x, (const T*)res,
+                       (const T*)gamma, (const T*)beta, (T*)sum_out, (T*)y, mean, rstd, rows, D, ld_x, ld_y, eps);)
+  MMRCA_CHECK_LAUNCH("add_layernorm_fwd");
+  return 0;
+}
+
+// --------------------------------------------------------------------------------------------------------
+// LayerNorm backward: ds = rstd*(g - mean(g) - xhat*mean(g*xhat)) (+dres), g = dy*gamma;
+// dgamma += sum_rows dy*xhat, dbeta += sum_rows dy (per-lane register partials -> LDS -> one atomic per column/block)
+// --------------------------------------------------------------------------------------------------------
+template <typename T>
+__global__ void __launch_bounds__(256)
+ln_bwd_k(const T* __restrict__ dy, const T* __restrict__ s, const T* __restrict__ gamma, const float* __restrict__ mean,
+         const float* __restrict__ rstd, const T* __restrict__ dres, T* __restrict__ ds, float* __restrict__ dgamma,
+         float* __restrict__ dbeta, int64_t rows, int D, int64_t ld_dy, int64_t ld_s, int64_t ld_ds) {
+  __shared__ float red[2][4][256 * 4 + 4];   // [dgamma|dbeta][wave][col chunk]; reduced one `it` slab at a time
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  float adg[LN_MAXV][4], adb[LN_MAXV][4];
+#pragma unroll
+  for (int it = 0; it < LN_MAXV; ++it)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) { adg[it][j] = 0.f; adb[it][j] = 0.f; }
+  for (int64_t row = (int64_t)blockIdx.x * 4 + wave; row < rows; row += (int64_t)gridDim.x * 4) {
+    const float mu = mean[row], rs = rstd[row];
+    float g[LN_MAXV][4], xh[LN_MAXV][4];
+    float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+    for (int it = 0; it < LN_MAXV; ++it) {
+      const int c = it * 256 + lane * 4;
+      if (c < D) {
+        Vec4<T> d = Vec4<T>::load(dy + row * ld_dy + c), sv = Vec4<T>::load(s + row * ld_s + c), gm = Vec4<T>::load(gamma + c);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const float xhat = (sv.v[j] - mu) * rs;
+          const float gg = d.v[j] * gm.v[j];
+          xh[it][j] = xhat; g[it][j] = gg;
+          s1 += gg; s2 += gg * xhat;
+          adg[it][j] += d.v[j] * xhat; adb[it][j] += d.v[j];
+        }
+      }
+    }
+    s1 = wave_sum(s1) / (float)D; s2 = wave_sum(s2) / (float)D;
+#pragma unroll
+    for (int it = 0; it < LN_MAXV; ++it) {
+      const int c = it * 256 + lane * 4;
+      if (c < D) {
+        Vec4<T> o;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) o.v[j] = rs * (g[it][j] - s1 - xh[it][j] * s2);
+        if (dres) {
+          Vec4<T> r = Vec4<T>::load(dres + row * ld_ds + c);
+#pragma unroll
+          for (int j = 0; j < 4; ++j) o.v[j] += r.v[j];
+        }
+        o.store(ds + row * ld_ds + c);
+      }
+    }
+  }
+  // cross-wave reduction of the parameter gradients, one 256-column slab at a time
+#pragma unroll
+  for (int it = 0; it < LN_MAXV; ++it) {
+    if (it * 256 >= D) break;
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < 4; ++j) { red[0][wave][lane * 4 + j] = adg[it][j]; red[1][wave][lane * 4 + j] = adb[it][j]; }
+    __syncthreads();
+    const int c = it * 256 + threadIdx.x;
+    if (c < D) {
+      const float a = red[0][0][threadIdx.x] + red[0][1][threadIdx.x] + red[0][2][threadIdx.x] + red[0][3][threadIdx.x];
+      const float b = red[1][0][threadIdx.x] + red[1][1][threadIdx.x] + red[1][2][threadIdx.x] + red[1][3][threadIdx.x];
+      if (dgamma) atomicAdd(dgamma + c, a);
+      if (dbeta) atomicAdd(dbeta + c, b);
+    }
+  }
+}
+
+extern "C" int mmrca_layernorm_bwd(const void* dy, const void* s, const void* gamma, const float* mean, const float* rstd,
+                                   const void* dres, void* ds, float* dgamma, float* dbeta, int64_t rows, int D,
+                                   int64_t ld_dy, int64_t ld_s, int64_t ld_ds, int dtype, void* stream) {
+  MMRCA_REQUIRE(dy && s && gamma && mean && rstd && ds, "layernorm_bwd: null pointer");
+  MMRCA_REQUIRE(D > 0 && D % 4 == 0 && D <= 256 * LN_MAXV, "layernorm_bwd: D=%d unsupported", D);
+  MMRCA_REQUIRE(ld_dy >= D && ld_s >= D && ld_ds >= D && ld_dy % 4 == 0 && ld_s % 4 == 0 && ld_ds % 4 == 0, "layernorm_bwd: bad leading dims");
+  if (rows <= 0) return 0;
+  int64_t want = (rows + 3) / 4;
+  const int grid = (int)(want < 1024 ? want : 1024);
+  MMRCA_DISPATCH_DTYPE(dtype, "layernorm_bwd",
+    hipLaunchKernelGGL(ln_bwd_k<T>, dim3(grid), dim3(256), 0, (hipStream_t)stream, (const T*)dy, (const T*)s, (const T*)gamma,
+                       mean, rstd, (const T*)dres, (T*)ds, dgamma, dbeta, rows, D, ld_dy, ld_s, ld_ds);)
+  MMRCA_CHECK_LAUNCH("layernorm_bwd");
+  return 0;
+}
+
+// --------------------------------------------------------------------------------------------------------
+// GELU backward, bias gradient
+// --------------------------------------------------------------------------------------------------------
+template <typename T>
+__global__ void __launch_bounds__(256) gelu_bwd_k(const T* __restrict__ dg, const T* __restrict__ h, T* __restrict__ dh, int64_t n4) {
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (int64_t)gridDim.x * blockDim.x) {
+    Vec4<T> a = Vec4<T>::load(dg + i * 4), b = Vec4<T>::load(h + i * 4), o;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) o.v[j] = a.v[j] * gelu_grad_f(b.v[j]);
+    o.store(dh + i * 4);
+  }
+}
+
+extern "C" int mmrca_gelu_bwd(const void* dG, const void* H, void* dH, int64_t n, int dtype, void* stream) {
+  MMRCA_REQUIRE(dG && H && dH, "gelu_bwd: null pointer");
+  MMRCA_REQUIRE(n % 4 == 0, "gelu_bwd: n must be a multiple of 4");
+  if (n <= 0) return 0;
+  const int64_t n4 = n / 4;
+  const int grid = (int)((n4 + 255) / 256 < 8192 ? (n4 + 255) / 256 : 8192);
+  MMRCA_DISPATCH_DTYPE(dtype, "gelu_bwd",
+    hipLaunchKernelGGL(gelu_bwd_k<T>, dim3(grid), dim3(256), 0, (hipStream_t)stream, (const T*)dG, (const T*)H, (T*)dH, n4);)
+  MMRCA_CHECK_LAUNCH("gelu_bwd");
+  return 0;
+}
+
+// db[c] += sum_m dY[m][c].  Block = 4 waves x 64 lanes; a block owns 256 columns (4 per lane) and a slab of rows;
+// waves stride the rows, partials meet in LDS, one atomic per column per block.
+template <typename T>
+__global__ void __launch_bounds__(256) colsum_k(const T* __restrict__ dY, float* __restrict__ db, int64_t M, int64_t N, int64_t ld, int rows_per_block) {
+  __shared__ float red[4][256];
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int64_t c = (int64_t)blockIdx.x * 256 + lane * 4;
+  const int64_t r0 = (int64_t)blockIdx.y * rows_per_block;
+  int64_t r1 = r0 + rows_per_block; if (r1 > M) r1 = M;
+  float a[4] = {0.f, 0.f, 0.f, 0.f};
+  if (c < N) {
+    for (int64_t r = r0 + wave; r < r1; r += 4) {
+      Vec4<T> v = Vec4<T>::load(dY + r * ld + c);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) a[j] += v.v[j];
+    }
+  }
+#pragma unroll
+  for (int j = 0; j < 4; ++j) red[wave][lane * 4 + j] = a[j];
+  __syncthreads();
+  const int64_t cc = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (cc < N) atomicAdd(db + cc, red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x]);
+}
+
+extern "C" int mmrca_colsum_accum(const void* dY, float* db, int64_t M, int64_t N, int64_t ld, int dtype, void* stream) {
+  MMRCA_REQUIRE(dY && db, "colsum_accum: null pointer");
+  MMRCA_REQUIRE(N % 4 == 0 && ld % 4 == 0 && ld >= N, "colsum_accum: N and ld must be multiples of 4");
+  if (M <= 0 || N <= 0) return 0;
+  const int gx = (int)((N + 255) / 256);
+  int rows_per_block = 256;
+  int64_t gy = (M + rows_per_block - 1) / rows_per_block;
+  while (gy * gx > 4096) { rows_per_block *= 2; gy = (M + rows_per_block - 1) / rows_per_block; }
+  MMRCA_DISPATCH_DTYPE(dtype, "colsum_accum",
+    hipLaunchKernelGGL(colsum_k<T>, dim3(gx, (unsigned)gy), dim3(256), 0, (hipStream_t)stream, (const T*)dY, db, M, N, ld, rows_per_block);)
+  MMRCA_CHECK_LAUNCH("colsum_accum");
+  return 0;
+}
+
+// --------------------------------------------------------------------------------------------------------
+// text embeddings
+// --------------------------------------------------------------------------------------------------------
+template <typename T>
+__global__ void __launch_bounds__(256)
+embed_fwd_k(const int32_t* __restrict__ ids, const int32_t* __restrict__ pos_ids, const T* __restrict__ word,
+            const T* __restrict__ pos, const T* __restrict__ type_row, T* __restrict__ out, int64_t rows, int D) {
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  for (int64_t row = (int64_t)blockIdx.x * 4 + wave; row < rows; row += (int64_t)gridDim.x * 4) {
+    const int64_t id = ids[row], p = pos_ids[row];
+    for (int c = lane * 4; c < D; c += 256) {
+      Vec4<T> a = Vec4<T>::load(word + id * D + c), b = Vec4<T>::load(pos + p * D + c);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) a.v[j] += b.v[j];
+      if (type_row) {
+        Vec4<T> t = Vec4<T>::load(type_row + c);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) a.v[j] += t.v[j];
+      }
+      a.store(out + row * D + c);
+    }
+  }
+}
+
+template <typename T>
+__global__ void __launch_bounds__(256)
+embed_bwd_k(const T* __restrict__ dout, const int32_t* __restrict__ ids, const int32_t* __restrict__ pos_ids,
+            float* __restrict__ dword, float* __restrict__ dpos, float* __restrict__ dtype_row, int64_t rows, int D) {
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  for (int64_t row = (int64_t)blockIdx.x * 4 + wave; row < rows; row += (int64_t)gridDim.x * 4) {
+    const int64_t id = ids[row], p = pos_ids[row];
+    for (int c = lane * 4; c < D; c += 256) {
+      Vec4<T> d = Vec4<T>::load(dout + row * D + c);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        if (dword) atomicAdd(dword + id * D + c + j, d.v[j]);
+        if (dpos) atomicAdd(dpos + p * D + c + j, d.v[j]);
+        if (dtype_row) atomicAdd(dtype_row + c + j, d.v[j]);
+      }
+    }
+  }
+}
+
+extern "C" int mmrca_embed_fwd(const int32_t* ids, const int32_t* pos_ids, const void* word, const void* pos,
+                               const void* type_row, void* out, int64_t rows, int D, int dtype, void* stream) {
+  MMRCA_REQUIRE(ids && pos_ids && word && pos && out, "embed_fwd: null pointer");
+  MMRCA_REQUIRE(D % 4 == 0, "embed_fwd: D must be a multiple of 4");
+  if (rows <= 0) return 0;
+  const int grid = (int)((rows + 3) / 4 < 4096 ? (rows + 3) / 4 : 4096);
+  MMRCA_DISPATCH_DTYPE(dtype, "embed_fwd",
+    hipLaunchKernelGGL(embed_fwd_k<T>, dim3(grid), dim3(256), 0, (hipStream_t)stream, ids, pos_ids, (const T*)word,
+                       (const T*)pos, (const T*)type_row, (T*)out, rows, D);)
+  MMRCA_CHECK_LAUNCH("embed_fwd");
+  return 0;
+}
+
+extern "C" int mmrca_embed_bwd(const void* dout, const int32_t* ids, const int32_t* pos_ids, float* dword, float* dpos,
+                               float* dtype_row, int64_t rows, int D, int dtype, void* stream) {
+  MMRCA_REQUIRE(dout && ids && pos_ids, "embed_bwd: null pointer");
+  MMRCA_REQUIRE(D % 4 == 0, "embed_bwd: D must be a multiple of 4");
+  if (rows <= 0) return 0;
+  const int grid = (int)((rows + 3) / 4 < 4096 ? (rows + 3) / 4 : 4096);
+  MMRCA_DISPATCH_DTYPE(dtype, "embed_bwd",
+    hipLaunchKernelGGL(embed_bwd_k<T>, dim3(grid), dim3(256), 0, (hipStream_t)stream, (const T*)dout, ids, pos_ids,
+                       dword, dpos, dtype_row, rows, D);)
+  MMRCA_CHECK_LAUNCH("embed_bwd");
+  return 0;
+}
+
+// --------------------------------------------------------------------------------------------------------
+// ViT patch embedding glue
+// --------------------------------------------------------------------------------------------------------
+template <typename T>
+__global__ void __launch_bounds__(256)
+patchify_k(const float* __restrict__ img, T* __restrict__ out, int B, int C, int Himg, int Wimg, int P, int64_t total4) {
+  const int nPw = Wimg / P, nPh = Himg / P, Kp = C * P * P;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total4; i += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t e = i * 4;
+    const int k = (int)(e % Kp);
+    const int64_t row = e / Kp;
+    const int pw = (int)(row % nPw), ph = (int)((row / nPw) % nPh), b = (int)(row / ((int64_t)nPw * nPh));
+    const int px = k % P, py = (k / P) % P, c = k / (P * P);
+    const float* src = img + (((int64_t)b * C + c) * Himg + (ph * P + py)) * Wimg + pw * P + px;
+    Vec4<float> v = Vec4<float>::load(src);
+    Vec4<T> o;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) o.v[j] = v.v[j];
+    o.store(out + e);
+  }
+}
+
+extern "C" int mmrca_patchify_fwd(const float* images, void* patches, int B, int C, int Himg, int Wimg, int P, int dtype, void* stream) {
+  MMRCA_REQUIRE(images && patches, "patchify_fwd: null pointer");
+  MMRCA_REQUIRE(P % 4 == 0 && Himg % P == 0 && Wimg % P == 0 && Wimg % 4 == 0, "patchify_fwd: unsupported geometry");
+  const int64_t total4 = (int64_t)B * C * Himg * Wimg / 4;
+  if (total4 <= 0) return 0;
+  const int grid = (int)((total4 + 255) / 256 < 8192 ? (total4 + 255) / 256 : 8192);
+  MMRCA_DISPATCH_DTYPE(dtype, "patchify_fwd",
+    hipLaunchKernelGGL(patchify_k<T>, dim3(grid), dim3(256), 0, (hipStream_t)stream, images, (T*)patches, B, C, Himg, Wimg, P, total4);)
+  MMRCA_CHECK_LAUNCH("patchify_fwd");
+  return 0;
+}
+
+template <typename T>
+__global__ void __launch_bounds__(256)
+vit_assemble_fwd_k(const T* __restrict__ proj, const T* __restrict__ cls, const T* __restrict__ pos, T* __restrict__ x, int B, int nP, int D, int64_t total4) {
+  const int Tn = nP + 1;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total4; i += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t e = i * 4;
+    const int d = (int)(e % D);
+    const int64_t row = e / D;
+    const int t = (int)(row % Tn);
+    const int64_t b = row / Tn;
+    Vec4<T> a = (t == 0) ? Vec4<T>::load(cls + d) : Vec4<T>::load(proj + (b * nP + (t - 1)) * (int64_t)D + d);
+    Vec4<T> p = Vec4<T>::load(pos + (int64_t)t * D + d);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) a.v[j] += p.v[j];
+    a.store(x + e);
+  }
+}
+
+// dproj = dx rows 1..; dpos[t,d] += sum_b dx[b,t,d]; dcls[d] += sum_b dx[b,0,d].  One thread per 4 columns of one token.
+template <typename T>
+__global__ void __launch_bounds__(256)
+vit_assemble_bwd_k(const T* __restrict__ dx, T* __restrict__ dproj, float* __restrict__ dcls, float* __restrict__ dpos, int B, int nP, int D) {
+  const int Tn = nP + 1;
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= (int64_t)Tn * D / 4) return;
+  const int64_t e = i * 4;
+  const int d = (int)(e % D), t = (int)(e / D);
+  float acc[4] = {0.f, 0.f, 0.f, 0.f};
+  for (int b = 0; b < B; ++b) {
+    Vec4<T> v = Vec4<T>::load(dx + ((int64_t)b * Tn + t) * D + d);
+    if (t > 0) v.store(dproj + ((int64_t)b * nP + (t - 1)) * D + d);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[j] += v.v[j];
+  }
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    if (dpos) atomicAdd(dpos + (int64_t)t * D + d + j, acc[j]);
+    if (t == 0 && dcls) atomicAdd(dcls + d + j, acc[j]);
+  }
+}
+
+extern "C" int mmrca_vit_assemble_fwd(const void* proj, const void* cls, const void* pos, void* x, int B, int nP, int D, int dtype, void* stream) {
+  MMRCA_REQUIRE(proj && cls && pos && x, "vit_assemble_fwd: null pointer");
+  MMRCA_REQUIRE(D % 4 == 0, "vit_assemble_fwd: D must be a multiple of 4");
+  const int64_t total4 = (int64_t)B * (nP + 1) * D / 4;
+  if (total4 <= 0) return 0;
+  const int grid = (int)((total4 + 255) / 256 < 8192 ? (total4 + 255) / 256 : 8192);
+  MMRCA_DISPATCH_DTYPE(dtype, "vit_assemble_fwd",
+    hipLaunchKernelGGL(vit_assemble_fwd_k<T>, dim3(grid), dim3(256), 0, (hipStream_t)stream, (const T*)proj, (const T*)cls,
+                       (const T*)pos, (T*)x, B, nP, D, total4);)
+  MMRCA_CHECK_LAUNCH("vit_assemble_fwd");
+  return 0;
+}
+
+extern "C" int mmrca_vit_assemble_bwd(const void* dx, void* dproj, float* dcls, float* dpos, int B, int nP, int D, int dtype, void* stream) {
+  MMRCA_REQUIRE(dx && dproj, "vit_assemble_bwd: null pointer");
+  MMRCA_REQUIRE(D % 4 == 0, "vit_assemble_bwd: D must be a multiple of 4");
+  const int64_t n = (int64_t)(nP + 1) * D / 4;
+  if (n <= 0 || B <= 0) return 0;
+  MMRCA_DISPATCH_DTYPE(dtype, "vit_assemble_bwd",
+    hipLaunchKernelGGL(vit_assemble_bwd_k<T>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, (const T*)dx,
+                       (T*)dproj, dcls, dpos, B, nP, D);)
+  MMRCA_CHECK_LAUNCH("vit_assemble_bwd");
+  return 0;
+}
+
+// --------------------------------------------------------------------------------------------------------
+// loss: CrossEntropyLoss(weight, label_smoothing), mean over the weighted denominator (main_both.py:87-93)
+// single block; B*C is tiny (batch x 4)
+// --------------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256)
+xent_k(const float* __restrict__ logits, const int32_t* __restrict__ labels, const float* __restrict__ cw, float eps,
+       float* __restrict__ loss, float* __restrict__ dlogits, int B, int C, float grad_scale) {
+  __shared__ float s_num[256], s_den[256];
+  float num = 0.f, den = 0.f;
+  for (int i = threadIdx.x; i < B; i += 256) {
+    const float* z = logits + (int64_t)i * C;
+    float m = -INFINITY;
+    for (int c = 0; c < C; ++c) m = fmaxf(m, z[c]);
+    float se = 0.f;
+    for (int c = 0; c < C; ++c) se += expf(z[c] - m);
+    const float lse = m + logf(se);
+    const int y = labels[i];
+    const float wy = cw ? cw[y] : 1.f;
+    float smooth = 0.f;
+    for (int c = 0; c < C; ++c) smooth += (cw ? cw[c] : 1.f) * (lse - z[c]);
+    num += (1.f - eps) * wy * (lse - z[y]) + (eps / (float)C) * smooth;
+    den += wy;
+  }
+  s_num[threadIdx.x] = num; s_den[threadIdx.x] = den;
+  __syncthreads();
+  for (int o = 128; o > 0; o >>= 1) {
+    if ((int)threadIdx.x < o) { s_num[threadIdx.x] += s_num[threadIdx.x + o]; s_den[threadIdx.x] += s_den[threadIdx.x + o]; }
+    __syncthreads();
+  }
+  const float D = s_den[0];
+  if (threadIdx.x == 0 && loss) loss[0] = s_num[0] / D;
+  if (dlogits) {
+    for (int i = threadIdx.x; i < B; i += 256) {
+      const float* z = logits + (int64_t)i * C;
+      float m = -INFINITY;
+      for (int c = 0; c < C; ++c) m = fmaxf(m, z[c]);
+      float se = 0.f;
+      for (int c = 0; c < C; ++c) se += expf(z[c] - m);
+      const int y = labels[i];
+      const float wy = cw ? cw[y] : 1.f;
+      float wsum = 0.f;
+      for (int c = 0; c < C; ++c) wsum += cw ? cw[c] : 1.f;
+      for (int c = 0; c < C; ++c) {
+        const float p = expf(z[c] - m) / se;
+        const float wc = cw ? cw[c] : 1.f;
+        // d/dz_c of (1-eps)*wy*(lse - z_y) + eps/C * sum_k w_k (lse - z_k)
+        const float g = (1.f - eps) * wy * (p - (c == y ? 1.f : 0.f)) + (eps / (float)C) * (wsum * p - wc);
+        dlogits[(int64_t)i * C + c] = g / D * grad_scale;
+      }
+    }
+  }
+}
+
+extern "C" int mmrca_xent_fwd_bwd(const float* logits, const int32_t* labels, const float* class_w, float smoothing,
+                                  float* loss, float* dlogits, int B, int C, float grad_scale, void* stream) {
+  MMRCA_REQUIRE(logits && labels, "xent: null pointer");
+  MMRCA_REQUIRE(B > 0 && C > 0 && C <= 1024, "xent: bad shape B=%d C=%d", B, C);
+  hipLaunchKernelGGL(xent_k, dim3(1), dim3(256), 0, (hipStream_t)stream, logits, labels, class_w, smoothing, loss, dlogits, B, C, grad_scale);
+  MMRCA_CHECK_LAUNCH("xent");
+  return 0;
+}
+
+// --------------------------------------------------------------------------------------------------------
+// optimizers on the flat arenas (+ refresh of the bf16 working copy)
+// --------------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256)
+sgd_k(float* __restrict__ p, const float* __restrict__ g, bf16_t* __restrict__ lp, int64_t n4, float lr, float wd, float gs) {
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (int64_t)gridDim.x * blockDim.x) {
+    Vec4<float> pv = Vec4<float>::load(p + i * 4), gv = Vec4<float>::load(g + i * 4);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) pv.v[j] -= lr * (gv.v[j] * gs + wd * pv.v[j]);
+    pv.store(p + i * 4);
+    if (lp) { Vec4<bf16_t> o; for (int j = 0; j < 4; ++j) o.v[j] = pv.v[j]; o.store(lp + i * 4); }
+  }
+}
+
+__global__ void __launch_bounds__(256)
+adamw_k(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m, float* __restrict__ v, bf16_t* __restrict__ lp,
+        int64_t n4, float lr, float b1, float b2, float eps, float wd, float bc1, float bc2, float gs) {
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (int64_t)gridDim.x * blockDim.x) {
+    Vec4<float> pv = Vec4<float>::load(p + i * 4), gv = Vec4<float>::load(g + i * 4), mv = Vec4<float>::load(m + i * 4), vv = Vec4<float>::load(v + i * 4);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const float gg = gv.v[j] * gs;
+      pv.v[j] *= (1.f - lr * wd);
+      mv.v[j] = b1 * mv.v[j] + (1.f - b1) * gg;
+      vv.v[j] = b2 * vv.v[j] + (1.f - b2) * gg * gg;
+      const float denom = sqrtf(vv.v[j]) / sqrtf(bc2) + eps;
+      pv.v[j] -= (lr / bc1) * mv.v[j] / denom;
+    }
+    pv.store(p + i * 4); mv.store(m + i * 4); vv.store(v + i * 4);
+    if (lp) { Vec4<bf16_t> o; for (int j = 0; j < 4; ++j) o.v[j] = pv.v[j]; o.store(lp + i * 4); }
+  }
+}
+
+__global__ void __launch_bounds__(256) cast_k(const float* __restrict__ s, bf16_t* __restrict__ d, int64_t n4) {
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (int64_t)gridDim.x * blockDim.x) {
+    Vec4<float> a = Vec4<float>::load(s + i * 4);
+    Vec4<bf16_t> o;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) o.v[j] = a.v[j];
+    o.store(d + i * 4);
+  }
+}
+
+static inline int ew_grid(int64_t n4) { int64_t g = (n4 + 255) / 256; return (int)(g < 8192 ? g : 8192); }
+
+extern "C" int mmrca_sgd_step(float* p, const float* g, void* lp, int64_t n, float lr, float wd, float grad_scale, void* stream) {
+  MMRCA_REQUIRE(p && g, "sgd_step: null pointer");
+  MMRCA_REQUIRE(n % 4 == 0, "sgd_step: arena length must be a multiple of 4");
+  if (n <= 0) return 0;
+  hipLaunchKernelGGL(sgd_k, dim3(ew_grid(n / 4)), dim3(256), 0, (hipStream_t)stream, p, g, (bf16_t*)lp, n / 4, lr, wd, grad_scale);
+  MMRCA_CHECK_LAUNCH("sgd_step");
+  return 0;
+}
+
+extern "C" int mmrca_adamw_step(float* p, const float* g, float* m, float* v, void* lp, int64_t n, float lr, float beta1,
+                                float beta2, float eps, float wd, int step, float grad_scale, void* stream) {
+  MMRCA_REQUIRE(p && g && m && v, "adamw_step: null pointer");
+  MMRCA_REQUIRE(n % 4 == 0 && step >= 1, "adamw_step: bad arguments");
+  if (n <= 0) return 0;
+  const float bc1 = 1.f - powf(beta1, (float)step), bc2 = 1.f - powf(beta2, (float)step);
+  hipLaunchKernelGGL(adamw_k, dim3(ew_grid(n / 4)), dim3(256), 0, (hipStream_t)stream, p, g, m, v, (bf16_t*)lp, n / 4, lr, beta1,
+                     beta2, eps, wd, bc1, bc2, grad_scale);
+  MMRCA_CHECK_LAUNCH("adamw_step");
+  return 0;
+}
+
+extern "C" int mmrca_cast_f32_to_bf16(const float* src, void* dst, int64_t n, void* stream) {
+  MMRCA_REQUIRE(src && dst, "cast: null pointer");
+  MMRCA_REQUIRE(n % 4 == 0, "cast: n must be a multiple of 4");
+  if (n <= 0) return 0;
+  hipLaunchKernelGGL(cast_k, dim3(ew_grid(n / 4)), dim3(256), 0, (hipStream_t)stream, src, (bf16_t*)dst, n / 4);
+  MMRCA_CHECK_LAUNCH("cast");
+  return 0;
+}

@@ -1,0 +1,414 @@
+"""Host-side sequencing of the MM-RCA hot path over libmmrca (HIP).
+
+Data layout in HBM (sized for 288 GB: nothing is recomputed, every saved activation stays resident):
+
+* ONE flat fp32 parameter arena (master weights) in the order  text encoder | vision encoder | fusion head,
+  ONE flat fp32 gradient arena with the same offsets (data-parallel all-reduce runs over contiguous slices of
+  it, no bucket copies) and, in bf16 mode, ONE bf16 working copy refreshed by the fused optimizer kernel.
+  q/k/v projection weights of the text encoders sit adjacently, so the fused [3D, D] QKV GEMM needs no copy.
+* activations: row-major [rows, features] in the compute dtype, rows padded to a multiple of 128 with zeros that
+  no kernel ever writes (the weight-gradient GEMM contracts over rows through transposed LDS reads and needs
+  whole 64-row steps).
+* no torch autograd inside: forward() saves what backward() needs; backward() accumulates (+=) into the gradient
+  arena, which is exactly the reference's gradient-accumulation semantic (main_both.py:112-124).
+
+PyTorch is used for memory, streams and a few index copies only; every arithmetic op is a libmmrca call.
+"""
+from __future__ import annotations
+
+import math
+from typing import Dict, List, Optional, Tuple
+
+import torch
+
+from . import lib as L
+from . import spec as S
+
+ALIGN = 64          # arena entries start on 256-byte boundaries
+ROWPAD = 128
+
+
+def _round_up(x: int, m: int) -> int:
+    return (x + m - 1) // m * m
+
+
+class Arena:
+    def __init__(self, entries: List[Tuple[str, Tuple[int, ...]]], device, with_lp: bool):
+        self.offsets: Dict[str, Tuple[int, Tuple[int, ...], int]] = {}
+        off = 0
+        for k, shp in entries:
+            n = 1
+            for s in shp:
+                n *= s
+            off = _round_up(off, ALIGN)
+            self.offsets[k] = (off, tuple(shp), n)
+            off += n
+        self.total = _round_up(off, ALIGN)
+        self.p = torch.zeros(self.total, dtype=torch.float32, device=device)
+        self.g = torch.zeros(self.total, dtype=torch.float32, device=device)
+        self.lp = torch.zeros(self.total, dtype=torch.bfloat16, device=device) if with_lp else None
+        self.lp_valid = False
+
+    def view(self, key, which="p"):
+        off, shp, n = self.offsets[key]
+        return getattr(self, which)[off:off + n].view(shp)
+
+    def span(self, first_key, last_key):
+        a = self.offsets[first_key][0]
+        off, _, n = self.offsets[last_key]
+        return a, off + n
+
+
+class MMRCAEngine:
+    """Owns parameters, gradients and activations of one MM-RCA replica on one GPU."""
+
+    def __init__(self, text_model: str, image_model: str, n_classes: int = 4, reverse: bool = True, mode: int = 0,
+                 dtype: torch.dtype = torch.bfloat16, device="cuda", gemm_impl: int = L.IMPL_AUTO,
+                 attn_impl: int = L.IMPL_AUTO):
+        L.load()
+        if text_model not in S.TEXT_SPECS:
+            raise ValueError(f"Wrong text model: {text_model}")
+        if image_model not in S.VISION_SPECS:
+            raise NotImplementedError(
+                f"image model {image_model!r}: only the ViT backbones {sorted(S.VISION_SPECS)} are HIP kernels so far; "
+                "EfficientNetV2 / ShuffleNetV2 are SURVEY.md section 8 f3 (next)")
+        self.ts, self.vs = S.TEXT_SPECS[text_model], S.VISION_SPECS[image_model]
+        self.n_classes, self.reverse, self.mode = n_classes, bool(reverse), int(mode)
+        self.dtype, self.device = dtype, torch.device(device)
+        self.dt = L.dtype_code(dtype)
+        self.gemm_impl, self.attn_impl = gemm_impl, attn_impl
+        self.d_txt, self.d_img = self.ts.dim, self.vs.dim
+        ents = [("text_model." + k, s) for k, s in S.text_params(self.ts)]
+        ents += [("image_model." + k, s) for k, s in S.vision_params(self.vs)]
+        self.head_keys = S.head_used_params(self.d_img, self.d_txt, n_classes, mode == 1, mode == 2)
+        ents += self.head_keys
+        self.arena = Arena(ents, self.device, with_lp=(dtype == torch.bfloat16))
+        self.param_keys = [k for k, _ in ents]
+        self.text_span = self.arena.span(ents[0][0], "text_model." + S.text_params(self.ts)[-1][0])
+        self.image_span = self.arena.span("image_model." + S.vision_params(self.vs)[0][0],
+                                          "image_model." + S.vision_params(self.vs)[-1][0])
+        self.head_span = self.arena.span(self.head_keys[0][0], self.head_keys[-1][0])
+        self._bufs: Dict[Tuple, torch.Tensor] = {}
+        self._saved = None
+        self._head_w = self._head_struct("p")
+        self._head_g = self._head_struct("g")
+        # fused QKV views of the text encoder must be contiguous in the arena
+        for i in range(self.ts.layers):
+            K = S.text_layer_keys(self.ts, i)
+            o = [self.arena.offsets["text_model." + K[n] + ".weight"] for n in ("q", "k", "v")]
+            assert o[1][0] == o[0][0] + o[0][2] and o[2][0] == o[1][0] + o[1][2], "qkv weights not adjacent"
+            o = [self.arena.offsets["text_model." + K[n] + ".bias"] for n in ("q", "k", "v")]
+            assert o[1][0] == o[0][0] + o[0][2] and o[2][0] == o[1][0] + o[1][2], "qkv biases not adjacent"
+
+    # ------------------------------------------------------------------ parameters
+    def _head_struct(self, which) -> L.HeadPtrs:
+        names = {"sai": "self_attention_image", "sat": "self_attention_text", "c1": "cross_attention_1", "c2": "cross_attention_2"}
+        leaf = {"wq": "W_query.weight", "bq": "W_query.bias", "wk": "W_key.weight", "bk": "W_key.bias",
+                "wv": "W_value.weight", "bv": "W_value.bias", "g": "norm.weight", "b": "norm.bias"}
+        fin = ["final_with_everything", "final_features_only_linear", "cross_attention_only_linear"][self.mode]
+        st = L.HeadPtrs()
+        for b, nm in names.items():
+            for l, suffix in leaf.items():
+                setattr(st, f"{b}_{l}", self.arena.view(f"{nm}.{suffix}", which).data_ptr())
+        st.fin_w = self.arena.view(fin + ".weight", which).data_ptr()
+        st.fin_b = self.arena.view(fin + ".bias", which).data_ptr()
+        return st
+
+    def W(self, key):
+        """parameter view in the compute dtype"""
+        return self.arena.view(key, "lp" if self.dtype == torch.bfloat16 else "p")
+
+    def Wflat(self, key, numel):
+        off = self.arena.offsets[key][0]
+        src = self.arena.lp if self.dtype == torch.bfloat16 else self.arena.p
+        return src[off:off + numel]
+
+    def G(self, key):
+        return self.arena.view(key, "g")
+
+    def Gflat(self, key, numel):
+        off = self.arena.offsets[key][0]
+        return self.arena.g[off:off + numel]
+
+    def refresh_working_copy(self, force=False):
+        if self.arena.lp is not None and (force or not self.arena.lp_valid):
+            L.cast_f32_to_bf16(self.arena.p, self.arena.lp, self.arena.total)
+            self.arena.lp_valid = True
+
+    def init_parameters(self, seed: int = 0):
+        """Random init (no pretrained weights offline): encoders N(0, 0.02) / LayerNorm (1, 0) as BERT/ViT do;
+        head layers with torch's nn.Linear / nn.LayerNorm defaults (the reference's init, multimodal_model.py:199-292)."""
+        g = torch.Generator(device="cpu").manual_seed(seed)
+        with torch.no_grad():
+            for k in self.param_keys:
+                v = self.arena.view(k)
+                leaf = k.rsplit(".", 1)[-1]
+                is_head = not k.startswith(("text_model.", "image_model."))
+                lname = k.lower()
+                is_norm = ("norm" in lname) or (".ln_" in lname) or lname.endswith(("encoder.ln.weight", "encoder.ln.bias"))
+                if is_norm:
+                    v.fill_(1.0 if leaf == "weight" else 0.0)
+                elif is_head:
+                    if v.dim() == 2:
+                        bound = 1.0 / math.sqrt(v.shape[1])
+                        v.copy_((torch.rand(v.shape, generator=g) * 2 - 1) * bound)
+                        self._last_fan_in = v.shape[1]
+                    else:
+                        bound = 1.0 / math.sqrt(self._last_fan_in)
+                        v.copy_((torch.rand(v.shape, generator=g) * 2 - 1) * bound)
+                elif leaf == "bias" or leaf.endswith("_bias"):
+                    v.zero_()
+                else:
+                    v.copy_(torch.randn(v.shape, generator=g) * 0.02)
+        self.arena.lp_valid = False
+
+    def load_arrays(self, sd: Dict[str, "torch.Tensor"], strict=True):
+        with torch.no_grad():
+            for k in self.param_keys:
+                if k in sd:
+                    self.arena.view(k).copy_(torch.as_tensor(sd[k]).to(self.device, torch.float32).view(self.arena.offsets[k][1]))
+                elif strict:
+                    raise KeyError(k)
+        self.arena.lp_valid = False
+
+    # ------------------------------------------------------------------ buffers
+    def buf(self, name, rows, cols, dtype=None, layer=0):
+        dtype = dtype or self.dtype
+        key = (name, layer, rows, cols, dtype)
+        t = self._bufs.get(key)
+        if t is None:
+            t = torch.zeros(_round_up(max(rows, 1), ROWPAD), cols, dtype=dtype, device=self.device)
+            self._bufs[key] = t
+        return t
+
+    def release_buffers(self):
+        self._bufs.clear()
+        self._saved = None
+
+    # ------------------------------------------------------------------ op helpers
+    def _lin_fwd(self, x, wkey, bkey, out, M, N, K, act=L.ACT_NONE, preact=None, addend=None, wnumel=None):
+        w = self.W(wkey) if wnumel is None else self.Wflat(wkey, wnumel)
+        b = self.W(bkey) if wnumel is None else self.Wflat(bkey, N)
+        L.gemm(x, w, out, bias=b, addend=addend, preact=preact, M=M, N=N, K=K, lda=K, ldb=K, ldc=N,
+               a_layout=L.ROWK, b_layout=L.ROWK, act=act, dtype=self.dt, impl=self.gemm_impl)
+
+    def _lin_bwd(self, dy, x, wkey, bkey, dx, M, N, K, addend=None, wnumel=None):
+        """dy [M,N], x [M,K], weight [N,K]:  dW += dy^T x ; db += colsum(dy) ; dx = dy W (+ addend)."""
+        Mk = _round_up(M, 64)
+        gw = self.G(wkey) if wnumel is None else self.Gflat(wkey, wnumel)
+        gb = self.G(bkey) if wnumel is None else self.Gflat(bkey, N)
+        L.gemm(dy, x, gw, M=N, N=K, K=Mk, lda=N, ldb=K, ldc=K, a_layout=L.KROW, b_layout=L.KROW, accum=True,
+               dtype=self.dt, impl=self.gemm_impl)
+        L.colsum_accum(dy, gb, M, N, N, self.dt)
+        if dx is not None:
+            w = self.W(wkey) if wnumel is None else self.Wflat(wkey, wnumel)
+            L.gemm(dy, w, dx, addend=addend, M=M, N=K, K=N, lda=N, ldb=K, ldc=K, a_layout=L.ROWK, b_layout=L.KROW,
+                   dtype=self.dt, impl=self.gemm_impl)
+
+    def _ln_fwd(self, x, res, pfx, sum_out, y, mean, rstd, rows, D, eps, ld_x=None, ld_y=None):
+        L.add_layernorm_fwd(x, res, self.W(pfx + ".weight"), self.W(pfx + ".bias"), sum_out, y, mean, rstd, rows, D,
+                            ld_x or D, ld_y or D, eps, self.dt)
+
+    def _ln_bwd(self, dy, s, pfx, mean, rstd, dres, ds, rows, D, ld_dy=None, ld_s=None, ld_ds=None):
+        L.layernorm_bwd(dy, s, self.W(pfx + ".weight"), mean, rstd, dres, ds, self.G(pfx + ".weight"), self.G(pfx + ".bias"),
+                        rows, D, ld_dy or D, ld_s or D, ld_ds or D, self.dt)
+
+    # ------------------------------------------------------------------ text encoder
+    def _text_forward(self, ids, mask, save):
+        s, P = self.ts, "text_model."
+        B, T = ids.shape
+        M, D, Fd, H = B * T, s.dim, s.ffn, s.heads
+        dh = D // H
+        ids32 = ids.to(torch.int32).contiguous().view(-1)
+        if s.pos_offset:
+            nonpad = (ids != s.pad_id).to(torch.int64)
+            pos = (torch.cumsum(nonpad, dim=1) * nonpad + s.pad_id).to(torch.int32).contiguous().view(-1)
+        else:
+            pos = torch.arange(T, device=ids.device, dtype=torch.int32).repeat(B)
+        mask32 = mask.to(torch.int32).contiguous()
+        fb = lambda name, cols, l=0, dt=None: self.buf("t_" + name, M, cols, dt, l if save else 0)
+        stat = lambda name, l=0: self.buf("t_" + name, 1, _round_up(M, ROWPAD), torch.float32, l if save else 0)
+        emb = fb("emb", D)
+        type_row = self.Wflat(P + "embeddings.token_type_embeddings.weight", D) if s.type_vocab else None
+        L.embed_fwd(ids32, pos, self.W(P + "embeddings.word_embeddings.weight"), self.W(P + "embeddings.position_embeddings.weight"),
+                    type_row, emb, M, D, self.dt)
+        x = fb("x", D, 0)
+        mean0, rstd0 = stat("mean0"), stat("rstd0")
+        self._ln_fwd(emb, None, P + "embeddings.LayerNorm", None, x, mean0, rstd0, M, D, s.ln_eps)
+        layers = []
+        for i in range(s.layers):
+            K = S.text_layer_keys(s, i)
+            qkv, ctx, lse = fb("qkv", 3 * D, i), fb("ctx", D, i), self.buf("t_lse", 1, _round_up(B * H * T, ROWPAD), torch.float32, i if save else 0)
+            self._lin_fwd(x, P + K["q"] + ".weight", P + K["q"] + ".bias", qkv, M, 3 * D, D, wnumel=3 * D * D)
+            L.mha_fwd(qkv, mask32, ctx, lse, B, H, T, dh, dh ** -0.5, self.dt, self.attn_impl)
+            att = fb("tmpD", D)
+            self._lin_fwd(ctx, P + K["o"] + ".weight", P + K["o"] + ".bias", att, M, D, D)
+            s1, x1 = fb("s1", D, i), fb("x1", D, i)
+            m1, r1 = stat("m1", i), stat("r1", i)
+            self._ln_fwd(att, x, P + K["ln1"], s1, x1, m1, r1, M, D, s.ln_eps)
+            h, g = fb("h", Fd, i), fb("g", Fd, i)
+            self._lin_fwd(x1, P + K["f1"] + ".weight", P + K["f1"] + ".bias", g, M, Fd, D, act=L.ACT_GELU, preact=h)
+            f = fb("tmpD", D)
+            self._lin_fwd(g, P + K["f2"] + ".weight", P + K["f2"] + ".bias", f, M, D, Fd)
+            s2, xn = fb("s2", D, i), fb("x", D, i + 1)
+            m2, r2 = stat("m2", i), stat("r2", i)
+            self._ln_fwd(f, x1, P + K["ln2"], s2, xn, m2, r2, M, D, s.ln_eps)
+            layers.append(dict(x=x, qkv=qkv, ctx=ctx, lse=lse, s1=s1, x1=x1, m1=m1, r1=r1, h=h, g=g, s2=s2, m2=m2, r2=r2))
+            x = xn
+        cls = x[:M].view(B, T, D)[:, 0].contiguous()
+        return cls, dict(B=B, T=T, ids32=ids32, pos=pos, mask32=mask32, emb=emb, mean0=mean0, rstd0=rstd0, layers=layers)
+
+    def _text_backward(self, dcls, sv):
+        s, P = self.ts, "text_model."
+        B, T = sv["B"], sv["T"]
+        M, D, Fd, H = B * T, s.dim, s.ffn, s.heads
+        dh = D // H
+        gb = lambda name, cols: self.buf("tg_" + name, M, cols)
+        dx = gb("dxA", D)
+        dx[:M].zero_()
+        dx[:M].view(B, T, D)[:, 0] = dcls
+        for i in reversed(range(s.layers)):
+            K, a = S.text_layer_keys(s, i), sv["layers"][i]
+            ds2 = gb("ds2", D)
+            self._ln_bwd(dx, a["s2"], P + K["ln2"], a["m2"], a["r2"], None, ds2, M, D)
+            dg = gb("dF", Fd)
+            self._lin_bwd(ds2, a["g"], P + K["f2"] + ".weight", P + K["f2"] + ".bias", dg, M, D, Fd)
+            L.gelu_bwd(dg, a["h"], dg, M * Fd, self.dt)
+            dx1 = gb("dxB", D)
+            self._lin_bwd(dg, a["x1"], P + K["f1"] + ".weight", P + K["f1"] + ".bias", dx1, M, Fd, D, addend=ds2)
+            ds1 = gb("ds1", D)
+            self._ln_bwd(dx1, a["s1"], P + K["ln1"], a["m1"], a["r1"], None, ds1, M, D)
+            dctx = gb("dctx", D)
+            self._lin_bwd(ds1, a["ctx"], P + K["o"] + ".weight", P + K["o"] + ".bias", dctx, M, D, D)
+            dqkv = gb("dqkv", 3 * D)
+            L.mha_bwd(a["qkv"], sv["mask32"], a["ctx"], dctx, a["lse"], dqkv, B, H, T, dh, dh ** -0.5, self.dt, self.attn_impl)
+            self._lin_bwd(dqkv, a["x"], P + K["q"] + ".weight", P + K["q"] + ".bias", dx, M, 3 * D, D, addend=ds1, wnumel=3 * D * D)
+        ds0 = gb("ds2", D)
+        self._ln_bwd(dx, sv["emb"], P + "embeddings.LayerNorm", sv["mean0"], sv["rstd0"], None, ds0, M, D)
+        dtype_row = self.Gflat(P + "embeddings.token_type_embeddings.weight", D) if s.type_vocab else None
+        L.embed_bwd(ds0, sv["ids32"], sv["pos"], self.G(P + "embeddings.word_embeddings.weight"),
+                    self.G(P + "embeddings.position_embeddings.weight"), dtype_row, M, D, self.dt)
+
+    # ------------------------------------------------------------------ vision encoder
+    def _vision_forward(self, images, save):
+        s, P = self.vs, "image_model."
+        B = images.shape[0]
+        if tuple(images.shape[1:]) != (3, s.image, s.image):
+            raise ValueError(f"images must be [B,3,{s.image},{s.image}], got {tuple(images.shape)}")
+        nP, Tn, D, Fd, H = s.tokens - 1, s.tokens, s.dim, s.ffn, s.heads
+        dh, M, Kp = D // H, B * Tn, 3 * s.patch * s.patch
+        fb = lambda name, rows, cols, l=0, dt=None: self.buf("v_" + name, rows, cols, dt, l if save else 0)
+        stat = lambda name, l=0: self.buf("v_" + name, 1, _round_up(M, ROWPAD), torch.float32, l if save else 0)
+        images = images.to(torch.float32).contiguous()
+        patches = fb("patches", B * nP, Kp)
+        L.patchify_fwd(images, patches, B, 3, s.image, s.image, s.patch, self.dt)
+        proj = fb("proj", B * nP, D)
+        self._lin_fwd(patches, P + "conv_proj.weight", P + "conv_proj.bias", proj, B * nP, D, Kp, wnumel=D * Kp)
+        x = fb("x", M, D, 0)
+        L.vit_assemble_fwd(proj, self.W(P + "class_token"), self.W(P + "encoder.pos_embedding"), x, B, nP, D, self.dt)
+        layers = []
+        for i in range(s.layers):
+            Lk = P + f"encoder.layers.encoder_layer_{i}."
+            y1, m1, r1 = fb("y1", M, D, i), stat("m1", i), stat("r1", i)
+            self._ln_fwd(x, None, Lk + "ln_1", None, y1, m1, r1, M, D, s.ln_eps)
+            qkv, ctx = fb("qkv", M, 3 * D, i), fb("ctx", M, D, i)
+            lse = self.buf("v_lse", 1, _round_up(B * H * Tn, ROWPAD), torch.float32, i if save else 0)
+            self._lin_fwd(y1, Lk + "self_attention.in_proj_weight", Lk + "self_attention.in_proj_bias", qkv, M, 3 * D, D)
+            L.mha_fwd(qkv, None, ctx, lse, B, H, Tn, dh, dh ** -0.5, self.dt, self.attn_impl)
+            x1 = fb("x1", M, D, i)
+            self._lin_fwd(ctx, Lk + "self_attention.out_proj.weight", Lk + "self_attention.out_proj.bias", x1, M, D, D, addend=x)
+            y2, m2, r2 = fb("y2", M, D, i), stat("m2", i), stat("r2", i)
+            self._ln_fwd(x1, None, Lk + "ln_2", None, y2, m2, r2, M, D, s.ln_eps)
+            h, g = fb("h", M, Fd, i), fb("g", M, Fd, i)
+            self._lin_fwd(y2, Lk + "mlp.0.weight", Lk + "mlp.0.bias", g, M, Fd, D, act=L.ACT_GELU, preact=h)
+            xn = fb("x", M, D, i + 1)
+            self._lin_fwd(g, Lk + "mlp.3.weight", Lk + "mlp.3.bias", xn, M, D, Fd, addend=x1)
+            layers.append(dict(x=x, y1=y1, m1=m1, r1=r1, qkv=qkv, ctx=ctx, lse=lse, x1=x1, y2=y2, m2=m2, r2=r2, h=h, g=g))
+            x = xn
+        feat = self.buf("v_feat", B, D)
+        mf, rf = stat("mf"), stat("rf")
+        self._ln_fwd(x, None, P + "encoder.ln", None, feat, mf, rf, B, D, s.ln_eps, ld_x=Tn * D, ld_y=D)
+        return feat[:B], dict(B=B, patches=patches, xL=x, mf=mf, rf=rf, layers=layers)
+
+    def _vision_backward(self, dfeat, sv):
+        s, P = self.vs, "image_model."
+        B = sv["B"]
+        nP, Tn, D, Fd, H = s.tokens - 1, s.tokens, s.dim, s.ffn, s.heads
+        dh, M, Kp = D // H, B * Tn, 3 * s.patch * s.patch
+        gb = lambda name, rows, cols: self.buf("vg_" + name, rows, cols)
+        dx = gb("dxA", M, D)
+        dx[:M].zero_()
+        dfe = self.buf("vg_dfeat", B, D)
+        dfe[:B].copy_(dfeat)
+        self._ln_bwd(dfe, sv["xL"], P + "encoder.ln", sv["mf"], sv["rf"], None, dx, B, D, ld_dy=D, ld_s=Tn * D, ld_ds=Tn * D)
+        for i in reversed(range(s.layers)):
+            Lk, a = P + f"encoder.layers.encoder_layer_{i}.", sv["layers"][i]
+            dg = gb("dF", M, Fd)
+            self._lin_bwd(dx, a["g"], Lk + "mlp.3.weight", Lk + "mlp.3.bias", dg, M, D, Fd)
+            L.gelu_bwd(dg, a["h"], dg, M * Fd, self.dt)
+            dy2 = gb("dy", M, D)
+            self._lin_bwd(dg, a["y2"], Lk + "mlp.0.weight", Lk + "mlp.0.bias", dy2, M, Fd, D)
+            dx1 = gb("dxB", M, D)
+            self._ln_bwd(dy2, a["x1"], Lk + "ln_2", a["m2"], a["r2"], dx, dx1, M, D)
+            dctx = gb("dctx", M, D)
+            self._lin_bwd(dx1, a["ctx"], Lk + "self_attention.out_proj.weight", Lk + "self_attention.out_proj.bias", dctx, M, D, D)
+            dqkv = gb("dqkv", M, 3 * D)
+            L.mha_bwd(a["qkv"], None, a["ctx"], dctx, a["lse"], dqkv, B, H, Tn, dh, dh ** -0.5, self.dt, self.attn_impl)
+            dy1 = gb("dy", M, D)
+            self._lin_bwd(dqkv, a["y1"], Lk + "self_attention.in_proj_weight", Lk + "self_attention.in_proj_bias", dy1, M, 3 * D, D)
+            self._ln_bwd(dy1, a["x"], Lk + "ln_1", a["m1"], a["r1"], dx1, dx, M, D)
+        dproj = gb("dproj", B * nP, D)
+        L.vit_assemble_bwd(dx, dproj, self.Gflat(P + "class_token", D), self.Gflat(P + "encoder.pos_embedding", Tn * D), B, nP, D, self.dt)
+        self._lin_bwd(dproj, sv["patches"], P + "conv_proj.weight", P + "conv_proj.bias", None, B * nP, D, Kp, wnumel=D * Kp)
+
+    # ------------------------------------------------------------------ whole model
+    def forward(self, ids, mask, images, drop_p: float = 0.0, seed: int = 0, save: bool = True):
+        """ids/mask int64 [B,S] and images fp32 [B,3,H,W] in HBM -> logits fp32 [B, n_classes]."""
+        for t, nm in ((ids, "input ids"), (mask, "attention mask"), (images, "images")):
+            if not t.is_cuda:
+                raise L.MmrcaError(f"{nm} must be in HBM; the MM-RCA product path has no CPU fallback")
+        self.refresh_working_copy()
+        B = ids.shape[0]
+        cls, tsv = self._text_forward(ids, mask, save)
+        feat, vsv = self._vision_forward(images, save)
+        logits = torch.empty(B, self.n_classes, dtype=torch.float32, device=self.device)
+        L.head_fwd(feat, cls, self._head_w, logits, B, self.d_img, self.d_txt, self.n_classes, self.reverse, self.mode,
+                   float(drop_p), int(seed), self.dt)
+        self._saved = dict(B=B, cls=cls, feat=feat, text=tsv, vision=vsv, drop_p=float(drop_p), seed=int(seed), full=save)
+        return logits
+
+    def backward(self, dlogits, train_text: bool = True, train_image: bool = True):
+        sv = self._saved
+        if sv is None:
+            raise L.MmrcaError("backward() without a forward()")
+        if (train_text or train_image) and not sv["full"]:
+            raise L.MmrcaError("backward through the encoders needs forward(save=True)")
+        B = sv["B"]
+        dl = dlogits.to(torch.float32).contiguous()
+        dimg = torch.empty(B, self.d_img, dtype=self.dtype, device=self.device) if train_image else None
+        dtxt = torch.empty(B, self.d_txt, dtype=self.dtype, device=self.device) if train_text else None
+        L.head_bwd(dl, sv["feat"], sv["cls"], self._head_w, self._head_g, dimg, dtxt, B, self.d_img, self.d_txt,
+                   self.n_classes, self.reverse, self.mode, sv["drop_p"], sv["seed"], self.dt)
+        if train_image:
+            self._vision_backward(dimg, sv["vision"])
+        if train_text:
+            self._text_backward(dtxt, sv["text"])
+        self.arena.lp_valid = False        # an optimizer step normally follows
+
+    # ------------------------------------------------------------------ flat-arena optimizer steps
+    def trainable_spans(self, train_text: bool, train_image: bool):
+        spans = []
+        if train_text:
+            spans.append(self.text_span)
+        if train_image:
+            spans.append(self.image_span)
+        spans.append(self.head_span)
+        # merge adjacent
+        spans.sort()
+        out = [list(spans[0])]
+        for a, b in spans[1:]:
+            if a <= _round_up(out[-1][1], ALIGN):
+                out[-1][1] = b
+            else:
+                out.append([a, b])
+        return [(a, _round_up(b, 4)) for a, b in out]

@@ -1,0 +1,209 @@
+"""ctypes binding of libmmrca.so (the C ABI declared in include/mmrca.h).
+
+The product path has no CPU fallback: if the shared library is missing or a call fails this module raises.
+Build with ``python -c "import __graft_entry__ as g; g.build()"`` (or ``make -C garbage_classification_rca_amd/csrc``).
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import subprocess
+from typing import Optional
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libmmrca.so")
+
+F32, BF16 = 0, 1
+ACT_NONE, ACT_GELU = 0, 1
+ROWK, KROW = 0, 1
+IMPL_AUTO, IMPL_REF, IMPL_MFMA = 0, 1, 2
+
+HEAD_FIELDS = [f"{blk}_{leaf}" for blk in ("sai", "sat", "c1", "c2")
+               for leaf in ("wq", "bq", "wk", "bk", "wv", "bv", "g", "b")] + ["fin_w", "fin_b"]
+
+
+class HeadPtrs(C.Structure):
+    _fields_ = [(n, C.c_void_p) for n in HEAD_FIELDS]
+
+
+class MmrcaError(RuntimeError):
+    pass
+
+
+def build_library(force: bool = False) -> str:
+    """Compile every HIP source for gfx950 into libmmrca.so (hipcc cross-compiles without a GPU)."""
+    src_dir = os.path.join(_HERE, "csrc")
+    cmd = ["make", "-C", src_dir, "-j8"]
+    if force:
+        subprocess.run(["make", "-C", src_dir, "clean"], check=True, capture_output=True)
+    r = subprocess.run(cmd, capture_output=True, text=True)
+    if r.returncode != 0 or not os.path.exists(LIB_PATH):
+        raise MmrcaError("building libmmrca.so failed:\n" + r.stdout[-4000:] + r.stderr[-4000:])
+    return LIB_PATH
+
+
+_lib = None
+
+_i64, _i32, _f32, _vp, _u64 = C.c_int64, C.c_int, C.c_float, C.c_void_p, C.c_uint64
+_SIGS = {
+    "mmrca_gemm": [_vp] * 6 + [_i64] * 6 + [_i32] * 6 + [_vp],
+    "mmrca_colsum_accum": [_vp, _vp, _i64, _i64, _i64, _i32, _vp],
+    "mmrca_gelu_bwd": [_vp, _vp, _vp, _i64, _i32, _vp],
+    "mmrca_mha_fwd": [_vp] * 4 + [_i32] * 4 + [_f32, _i32, _i32, _vp],
+    "mmrca_mha_bwd": [_vp] * 6 + [_i32] * 4 + [_f32, _i32, _i32, _vp],
+    "mmrca_add_layernorm_fwd": [_vp] * 8 + [_i64, _i32, _i64, _i64, _f32, _i32, _vp],
+    "mmrca_layernorm_bwd": [_vp] * 9 + [_i64, _i32, _i64, _i64, _i64, _i32, _vp],
+    "mmrca_embed_fwd": [_vp] * 6 + [_i64, _i32, _i32, _vp],
+    "mmrca_embed_bwd": [_vp] * 6 + [_i64, _i32, _i32, _vp],
+    "mmrca_patchify_fwd": [_vp, _vp] + [_i32] * 6 + [_vp],
+    "mmrca_vit_assemble_fwd": [_vp] * 4 + [_i32] * 4 + [_vp],
+    "mmrca_vit_assemble_bwd": [_vp] * 4 + [_i32] * 4 + [_vp],
+    "mmrca_head_fwd": [_vp, _vp, C.POINTER(HeadPtrs), _vp] + [_i32] * 6 + [_f32, _u64, _i32, _vp],
+    "mmrca_head_bwd": [_vp, _vp, _vp, C.POINTER(HeadPtrs), C.POINTER(HeadPtrs), _vp, _vp] + [_i32] * 6 + [_f32, _u64, _i32, _vp],
+    "mmrca_xent_fwd_bwd": [_vp, _vp, _vp, _f32, _vp, _vp, _i32, _i32, _f32, _vp],
+    "mmrca_sgd_step": [_vp, _vp, _vp, _i64, _f32, _f32, _f32, _vp],
+    "mmrca_adamw_step": [_vp] * 5 + [_i64] + [_f32] * 5 + [_i32, _f32, _vp],
+    "mmrca_cast_f32_to_bf16": [_vp, _vp, _i64, _vp],
+}
+EXPORTS = sorted(list(_SIGS) + ["mmrca_last_error", "mmrca_version"])
+
+
+def load(build_if_missing: bool = False):
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        if build_if_missing:
+            build_library()
+        else:
+            raise MmrcaError(f"{LIB_PATH} not found: the HIP extension is required (run __graft_entry__.build()); "
+                             "there is no CPU fallback")
+    lib = C.CDLL(LIB_PATH)
+    for name, args in _SIGS.items():
+        fn = getattr(lib, name)
+        fn.argtypes = args
+        fn.restype = C.c_int
+    lib.mmrca_last_error.restype = C.c_char_p
+    lib.mmrca_version.restype = C.c_int
+    _lib = lib
+    return lib
+
+
+def _check(rc: int, what: str):
+    if rc != 0:
+        raise MmrcaError(f"{what} failed ({rc}): {load().mmrca_last_error().decode()}")
+
+
+def dtype_code(dt: torch.dtype) -> int:
+    if dt == torch.float32:
+        return F32
+    if dt == torch.bfloat16:
+        return BF16
+    raise MmrcaError(f"unsupported dtype {dt}")
+
+
+def ptr(t: Optional[torch.Tensor]):
+    return None if t is None else t.data_ptr()
+
+
+def stream_ptr() -> int:
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _dev(t: torch.Tensor, name: str):
+    if not t.is_cuda:
+        raise MmrcaError(f"{name}: tensor must live in HBM (got device {t.device}); the product path has no CPU fallback")
+
+
+# ---------------------------------------------------------------------------------------------------------
+# thin typed wrappers (raw pointers in, nothing allocated)
+# ---------------------------------------------------------------------------------------------------------
+def gemm(A, B, Cout, *, bias=None, addend=None, preact=None, M, N, K, lda, ldb, ldc, a_layout=ROWK, b_layout=ROWK,
+         act=ACT_NONE, accum=False, dtype, impl=IMPL_AUTO):
+    _dev(A, "gemm A")
+    _check(load().mmrca_gemm(ptr(A), ptr(B), ptr(Cout), ptr(bias), ptr(addend), ptr(preact), M, N, K, lda, ldb, ldc,
+                             a_layout, b_layout, act, int(accum), dtype, impl, stream_ptr()), "mmrca_gemm")
+
+
+def colsum_accum(dY, db, M, N, ld, dtype):
+    _check(load().mmrca_colsum_accum(ptr(dY), ptr(db), M, N, ld, dtype, stream_ptr()), "mmrca_colsum_accum")
+
+
+def gelu_bwd(dG, H, dH, n, dtype):
+    _check(load().mmrca_gelu_bwd(ptr(dG), ptr(H), ptr(dH), n, dtype, stream_ptr()), "mmrca_gelu_bwd")
+
+
+def mha_fwd(qkv, key_mask, out, lse, B, H, S, dh, scale, dtype, impl=IMPL_AUTO):
+    _dev(qkv, "mha qkv")
+    _check(load().mmrca_mha_fwd(ptr(qkv), ptr(key_mask), ptr(out), ptr(lse), B, H, S, dh, scale, dtype, impl, stream_ptr()), "mmrca_mha_fwd")
+
+
+def mha_bwd(qkv, key_mask, out, dout, lse, dqkv, B, H, S, dh, scale, dtype, impl=IMPL_AUTO):
+    _check(load().mmrca_mha_bwd(ptr(qkv), ptr(key_mask), ptr(out), ptr(dout), ptr(lse), ptr(dqkv), B, H, S, dh, scale, dtype,
+                                impl, stream_ptr()), "mmrca_mha_bwd")
+
+
+def add_layernorm_fwd(x, res, gamma, beta, sum_out, y, mean, rstd, rows, D, ld_x, ld_y, eps, dtype):
+    _dev(x, "layernorm x")
+    _check(load().mmrca_add_layernorm_fwd(ptr(x), ptr(res), ptr(gamma), ptr(beta), ptr(sum_out), ptr(y), ptr(mean), ptr(rstd),
+                                          rows, D, ld_x, ld_y, eps, dtype, stream_ptr()), "mmrca_add_layernorm_fwd")
+
+
+def layernorm_bwd(dy, s, gamma, mean, rstd, dres, ds, dgamma, dbeta, rows, D, ld_dy, ld_s, ld_ds, dtype):
+    _check(load().mmrca_layernorm_bwd(ptr(dy), ptr(s), ptr(gamma), ptr(mean), ptr(rstd), ptr(dres), ptr(ds), ptr(dgamma),
+                                      ptr(dbeta), rows, D, ld_dy, ld_s, ld_ds, dtype, stream_ptr()), "mmrca_layernorm_bwd")
+
+
+def embed_fwd(ids, pos_ids, word, pos, type_row, out, rows, D, dtype):
+    _dev(ids, "embed ids")
+    _check(load().mmrca_embed_fwd(ptr(ids), ptr(pos_ids), ptr(word), ptr(pos), ptr(type_row), ptr(out), rows, D, dtype, stream_ptr()), "mmrca_embed_fwd")
+
+
+def embed_bwd(dout, ids, pos_ids, dword, dpos, dtype_row, rows, D, dtype):
+    _check(load().mmrca_embed_bwd(ptr(dout), ptr(ids), ptr(pos_ids), ptr(dword), ptr(dpos), ptr(dtype_row), rows, D, dtype, stream_ptr()), "mmrca_embed_bwd")
+
+
+def patchify_fwd(images, patches, B, Cc, Himg, Wimg, P, dtype):
+    _dev(images, "patchify images")
+    _check(load().mmrca_patchify_fwd(ptr(images), ptr(patches), B, Cc, Himg, Wimg, P, dtype, stream_ptr()), "mmrca_patchify_fwd")
+
+
+def vit_assemble_fwd(proj, cls, pos, x, B, nP, D, dtype):
+    _check(load().mmrca_vit_assemble_fwd(ptr(proj), ptr(cls), ptr(pos), ptr(x), B, nP, D, dtype, stream_ptr()), "mmrca_vit_assemble_fwd")
+
+
+def vit_assemble_bwd(dx, dproj, dcls, dpos, B, nP, D, dtype):
+    _check(load().mmrca_vit_assemble_bwd(ptr(dx), ptr(dproj), ptr(dcls), ptr(dpos), B, nP, D, dtype, stream_ptr()), "mmrca_vit_assemble_bwd")
+
+
+def head_fwd(img, txt, w: HeadPtrs, logits, B, d_img, d_txt, n_classes, reverse, mode, drop_p, seed, dtype):
+    _dev(img, "head img")
+    _check(load().mmrca_head_fwd(ptr(img), ptr(txt), C.byref(w), ptr(logits), B, d_img, d_txt, n_classes, int(reverse), mode,
+                                 drop_p, seed, dtype, stream_ptr()), "mmrca_head_fwd")
+
+
+def head_bwd(dlogits, img, txt, w: HeadPtrs, g: HeadPtrs, dimg, dtxt, B, d_img, d_txt, n_classes, reverse, mode, drop_p, seed, dtype):
+    _check(load().mmrca_head_bwd(ptr(dlogits), ptr(img), ptr(txt), C.byref(w), C.byref(g), ptr(dimg), ptr(dtxt), B, d_img, d_txt,
+                                 n_classes, int(reverse), mode, drop_p, seed, dtype, stream_ptr()), "mmrca_head_bwd")
+
+
+def xent_fwd_bwd(logits, labels, class_w, smoothing, loss, dlogits, B, Cc, grad_scale=1.0):
+    _dev(logits, "xent logits")
+    _check(load().mmrca_xent_fwd_bwd(ptr(logits), ptr(labels), ptr(class_w), smoothing, ptr(loss), ptr(dlogits), B, Cc, grad_scale, stream_ptr()), "mmrca_xent_fwd_bwd")
+
+
+def sgd_step(p, g, lp, n, lr, wd, grad_scale=1.0):
+    _dev(p, "sgd params")
+    _check(load().mmrca_sgd_step(ptr(p), ptr(g), ptr(lp), n, lr, wd, grad_scale, stream_ptr()), "mmrca_sgd_step")
+
+
+def adamw_step(p, g, m, v, lp, n, lr, b1, b2, eps, wd, step, grad_scale=1.0):
+    _dev(p, "adamw params")
+    _check(load().mmrca_adamw_step(ptr(p), ptr(g), ptr(m), ptr(v), ptr(lp), n, lr, b1, b2, eps, wd, step, grad_scale, stream_ptr()), "mmrca_adamw_step")
+
+
+def cast_f32_to_bf16(src, dst, n):
+    _dev(src, "cast src")
+    _check(load().mmrca_cast_f32_to_bf16(ptr(src), ptr(dst), n, stream_ptr()), "mmrca_cast_f32_to_bf16")

@@ -1,0 +1,134 @@
+/*
+ * mmrca.h -- C ABI of libmmrca.so: the MI355X (gfx950) kernels of the MM-RCA training hot path.
+ *
+ * The reference (espiriki/Garbage_Classification_RCA) has no FFI of its own: its seam is the Python
+ * nn.Module contract of MM_RCA.  Each entry point below names the reference code whose arithmetic it
+ * replaces (paths relative to the reference checkout).  Python binds these with ctypes (see
+ * INTEGRATION.md); nothing in a signature is a torch type.
+ *
+ * Conventions
+ *   - every function returns 0 on success, a negative code on error; mmrca_last_error() gives the text
+ *     (thread-local).  Arguments are validated on the host before any launch.
+ *   - the caller owns all buffers; the library allocates nothing and never synchronises the device.
+ *     All work is enqueued on `stream` (a hipStream_t passed as void*; NULL = default stream).
+ *   - tensors are row-major and contiguous unless a leading dimension is given (in elements).
+ *   - dtype: MMRCA_F32 = fp32 storage and math ("parity mode"); MMRCA_BF16 = bf16 storage, fp32
+ *     accumulation and fp32 softmax/LayerNorm statistics (the benchmarked mode).
+ *   - parameter gradients are always fp32 and are ACCUMULATED (+=) into the caller's gradient arena,
+ *     which is what main_both.py:112-124 relies on for its sum-not-mean gradient accumulation.
+ */
+#ifndef MMRCA_H
+#define MMRCA_H
+#include <stdint.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+enum { MMRCA_F32 = 0, MMRCA_BF16 = 1 };
+enum { MMRCA_ACT_NONE = 0, MMRCA_ACT_GELU = 1 };
+/* operand layouts of mmrca_gemm: ROWK = [rows][contraction] (contraction contiguous),
+ * KROW = [contraction][rows] (rows contiguous) */
+enum { MMRCA_ROWK = 0, MMRCA_KROW = 1 };
+enum { MMRCA_GEMM_AUTO = 0, MMRCA_GEMM_REF = 1, MMRCA_GEMM_MFMA = 2 };
+
+const char* mmrca_last_error(void);
+int mmrca_version(void);
+
+/* K2. C[M,N] = act(A (.) B + bias[N]) + addend[M,N]      (torch.nn.Linear fwd / dgrad / wgrad:
+ * transformers modeling_distilbert.py q_lin/k_lin/v_lin/out_lin/ffn.lin1/lin2, torchvision ViT in_proj/
+ * out_proj/mlp, and their autograd; head linears go through mmrca_head_*).
+ *   A: M rows, contraction K; layout a_layout, leading dimension lda.   B: N rows, contraction K.
+ *   out_f32_accum != 0: C is fp32 and C += result (wgrad); otherwise C has `dtype`.
+ *   preact (optional, `dtype`): receives A(.)B + bias before the activation.
+ *   For a_layout==KROW the contraction runs over rows of A and B; rows K..round_up(K,64) of both
+ *   buffers must exist and hold zeros (the engine pads its activation buffers so).
+ *   impl: AUTO picks the MFMA kernel when dtype==BF16 and the shape qualifies. */
+int mmrca_gemm(const void* A, const void* B, void* C, const void* bias, const void* addend, void* preact,
+               int64_t M, int64_t N, int64_t K, int64_t lda, int64_t ldb, int64_t ldc,
+               int a_layout, int b_layout, int act, int out_f32_accum, int dtype, int impl, void* stream);
+
+/* db[N] (fp32) += column sums of dY[M,N]  (bias gradients of every nn.Linear on the path). */
+int mmrca_colsum_accum(const void* dY, float* db, int64_t M, int64_t N, int64_t ld, int dtype, void* stream);
+
+/* dH = dG * gelu'(H)   (exact erf GELU: transformers activations "gelu", torchvision MLPBlock nn.GELU). */
+int mmrca_gelu_bwd(const void* dG, const void* H, void* dH, int64_t n, int dtype, void* stream);
+
+/* K3. Multi-head attention over a fused QKV buffer [B*S, 3*H*dh] (q | k | v column blocks; head h at
+ * columns h*dh).  out[B*S, H*dh].  key_mask (optional): int32 [B,S], 0 = masked key; a query row whose
+ * keys are all masked yields zeros (torch SDPA semantics used by transformers 5.x).  lse: fp32 [B,H,S].
+ * Replaces modeling_distilbert.py:122-203 / torchvision MultiheadAttention (QK^T*scale, softmax, PV). */
+int mmrca_mha_fwd(const void* qkv, const int32_t* key_mask, void* out, float* lse,
+                  int B, int H, int S, int dh, float scale, int dtype, int impl, void* stream);
+int mmrca_mha_bwd(const void* qkv, const int32_t* key_mask, const void* out, const void* dout, const float* lse,
+                  void* dqkv, int B, int H, int S, int dh, float scale, int dtype, int impl, void* stream);
+
+/* K4. s = x (+ res);  y = LayerNorm(s) * gamma + beta.  sum_out (optional) receives s.  mean/rstd fp32 [rows].
+ * Row r of x/res/sum_out/y starts at r*ld_* elements (lets the ViT final norm run on class tokens only).
+ * nn.LayerNorm at modeling_distilbert.py:98,240,247 (eps 1e-12), torchvision ln_1/ln_2/encoder.ln (1e-6). */
+int mmrca_add_layernorm_fwd(const void* x, const void* res, const void* gamma, const void* beta,
+                            void* sum_out, void* y, float* mean, float* rstd,
+                            int64_t rows, int D, int64_t ld_x, int64_t ld_y, float eps, int dtype, void* stream);
+/* ds = LN'(dy) (+ dres);  dgamma/dbeta (fp32) += .   s is the saved LayerNorm input. */
+int mmrca_layernorm_bwd(const void* dy, const void* s, const void* gamma, const float* mean, const float* rstd,
+                        const void* dres, void* ds, float* dgamma, float* dbeta,
+                        int64_t rows, int D, int64_t ld_dy, int64_t ld_s, int64_t ld_ds, int dtype, void* stream);
+
+/* K5a. text embeddings: out[r] = word[ids[r]] + pos[pos_ids[r]] (+ type_row)   (modeling_distilbert.py:82-118,
+ * BertEmbeddings; LayerNorm follows via mmrca_add_layernorm_fwd).  ids/pos_ids int32 [rows]. */
+int mmrca_embed_fwd(const int32_t* ids, const int32_t* pos_ids, const void* word, const void* pos,
+                    const void* type_row, void* out, int64_t rows, int D, int dtype, void* stream);
+int mmrca_embed_bwd(const void* dout, const int32_t* ids, const int32_t* pos_ids, float* dword, float* dpos,
+                    float* dtype_row, int64_t rows, int D, int dtype, void* stream);
+
+/* K5b. ViT patch embedding (torchvision conv_proj 16x16/16 + class token + pos embedding).
+ * patchify: images fp32 NCHW [B,3,H,W] -> rows [B*nP, 3*P*P] (k = c*P*P + py*P + px), nP=(H/P)*(W/P).
+ * assemble: x[b,0] = cls + pos[0]; x[b,1+i] = proj[b*nP+i] + pos[1+i]. */
+int mmrca_patchify_fwd(const float* images, void* patches, int B, int C, int Himg, int Wimg, int P, int dtype, void* stream);
+int mmrca_vit_assemble_fwd(const void* proj, const void* cls, const void* pos, void* x, int B, int nP, int D, int dtype, void* stream);
+int mmrca_vit_assemble_bwd(const void* dx, void* dproj, float* dcls, float* dpos, int B, int nP, int D, int dtype, void* stream);
+
+/* K1. fused MM-RCA fusion head (CVPR_code/multimodal_model.py:662-726 with SelfAttention :39-68 and
+ * ReverseCrossAttention :71-108): L2-normalise, reshape to 16 pseudo-patches, 2x self-attention, 2x (reverse)
+ * cross-attention, LayerNorm+ReLU, concat by mode, dropout, final linear.  One workgroup per sample.
+ * weights: fp32 pointers in the order of MmrcaHeadWeights.  mode: 0 default, 1 features_only, 2 cross_attention_only.
+ * drop_p>0 applies inverted dropout to the concatenated features with a counter-based mask (seed, sample, column).
+ * The backward takes the same feature pointers and recomputes the (tiny) forward in LDS: nothing is saved in HBM.
+ * dimg/dtxt (optional): gradients wrt the un-normalised backbone features, in `dtype`. */
+typedef struct {
+  const float *sai_wq, *sai_bq, *sai_wk, *sai_bk, *sai_wv, *sai_bv, *sai_g, *sai_b;   /* self_attention_image */
+  const float *sat_wq, *sat_bq, *sat_wk, *sat_bk, *sat_wv, *sat_bv, *sat_g, *sat_b;   /* self_attention_text  */
+  const float *c1_wq, *c1_bq, *c1_wk, *c1_bk, *c1_wv, *c1_bv, *c1_g, *c1_b;           /* cross_attention_1    */
+  const float *c2_wq, *c2_bq, *c2_wk, *c2_bk, *c2_wv, *c2_bv, *c2_g, *c2_b;           /* cross_attention_2    */
+  const float *fin_w, *fin_b;                                                         /* active final linear  */
+} MmrcaHeadWeights;
+typedef struct {
+  float *sai_wq, *sai_bq, *sai_wk, *sai_bk, *sai_wv, *sai_bv, *sai_g, *sai_b;
+  float *sat_wq, *sat_bq, *sat_wk, *sat_bk, *sat_wv, *sat_bv, *sat_g, *sat_b;
+  float *c1_wq, *c1_bq, *c1_wk, *c1_bk, *c1_wv, *c1_bv, *c1_g, *c1_b;
+  float *c2_wq, *c2_bq, *c2_wk, *c2_bk, *c2_wv, *c2_bv, *c2_g, *c2_b;
+  float *fin_w, *fin_b;
+} MmrcaHeadGrads;
+int mmrca_head_fwd(const void* img, const void* txt, const MmrcaHeadWeights* w, float* logits,
+                   int B, int d_img, int d_txt, int n_classes, int reverse, int mode,
+                   float drop_p, uint64_t seed, int dtype, void* stream);
+int mmrca_head_bwd(const float* dlogits, const void* img, const void* txt, const MmrcaHeadWeights* w,
+                   const MmrcaHeadGrads* g, void* dimg, void* dtxt, int B, int d_img, int d_txt, int n_classes,
+                   int reverse, int mode, float drop_p, uint64_t seed, int dtype, void* stream);
+
+/* K6. weighted, label-smoothed cross entropy (torch.nn.CrossEntropyLoss as built at main_both.py:87-93), mean
+ * reduction with the weighted denominator.  loss: fp32[1]; dlogits (optional): fp32 [B,C] scaled by grad_scale. */
+int mmrca_xent_fwd_bwd(const float* logits, const int32_t* labels, const float* class_w, float smoothing,
+                       float* loss, float* dlogits, int B, int C, float grad_scale, void* stream);
+
+/* optimizers over the flat fp32 arenas (torch.optim.SGD / AdamW as constructed at main_both.py:544-549:
+ * SGD: g += wd*p; p -= lr*g.   AdamW: p *= 1-lr*wd; Adam step with bias correction, eps 1e-8).
+ * lp (optional): bf16 working copy of p, refreshed in the same pass. */
+int mmrca_sgd_step(float* p, const float* g, void* lp, int64_t n, float lr, float wd, float grad_scale, void* stream);
+int mmrca_adamw_step(float* p, const float* g, float* m, float* v, void* lp, int64_t n, float lr, float beta1,
+                     float beta2, float eps, float wd, int step, float grad_scale, void* stream);
+int mmrca_cast_f32_to_bf16(const float* src, void* dst, int64_t n, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

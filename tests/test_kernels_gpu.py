@@ -1,0 +1,386 @@
+"""Kernel-level parity: every libmmrca entry point, called through the C ABI, against a plain PyTorch fp32
+statement of the same op (and the oracle for the fused head).  Needs an MI355X."""
+import math
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+from garbage_classification_rca_amd import lib as L   # noqa: E402
+
+
+@pytest.fixture(scope="module", autouse=True)
+def _gpu():
+    assert torch.cuda.is_available(), "these tests need a GPU"
+    L.load()
+    torch.manual_seed(0)
+
+
+def dev(x, dt=torch.float32):
+    return x.to("cuda", dt).contiguous()
+
+
+def rel_err(a, b):
+    a, b = a.float(), b.float()
+    return ((a - b).abs().max() / (b.abs().max() + 1e-30)).item()
+
+
+TOL = {torch.float32: 2e-5, torch.bfloat16: 2e-2}
+
+
+# ------------------------------------------------------------------------------------------------------
+# GEMM
+# ------------------------------------------------------------------------------------------------------
+def _gemm_case(M, N, K, a_layout, b_layout, dt, impl, act=L.ACT_NONE, bias=False, addend=False, preact=False, accum=False):
+    g = torch.Generator().manual_seed(M * 7 + N * 3 + K)
+    Kp = (K + 63) // 64 * 64 if a_layout == L.KROW or b_layout == L.KROW else K
+    A = torch.randn(M, K, generator=g) * 0.5
+    Bm = torch.randn(N, K, generator=g) * 0.5
+    Ad = dev(A, dt) if a_layout == L.ROWK else dev(F.pad(A.t(), (0, 0, 0, Kp - K)), dt)      # [Kp, M]
+    Bd = dev(Bm, dt) if b_layout == L.ROWK else dev(F.pad(Bm.t(), (0, 0, 0, Kp - K)), dt)    # [Kp, N]
+    Af = (Ad if a_layout == L.ROWK else Ad[:K].t()).float()
+    Bf = (Bd if b_layout == L.ROWK else Bd[:K].t()).float()
+    bias_d = dev(torch.randn(N, generator=g), dt) if bias else None
+    add_d = dev(torch.randn(M, N, generator=g), dt) if addend else None
+    pre_d = torch.empty(M, N, device="cuda", dtype=dt) if preact else None
+    ref = Af.double() @ Bf.double().t()
+    if bias:
+        ref = ref + bias_d.double()
+    ref_pre = ref.clone()
+    if act == L.ACT_GELU:
+        ref = F.gelu(ref)
+    if addend:
+        ref = ref + add_d.double()
+    if accum:
+        Cd = dev(torch.randn(M, N, generator=g))
+        ref = ref + Cd.double()
+    else:
+        Cd = torch.empty(M, N, device="cuda", dtype=dt)
+    Kcall = Kp if (a_layout == L.KROW or b_layout == L.KROW) else K
+    if a_layout == L.ROWK and Kcall != K:
+        Ad = dev(F.pad(A, (0, Kcall - K)), dt)
+    if b_layout == L.ROWK and Kcall != K:
+        Bd = dev(F.pad(Bm, (0, Kcall - K)), dt)
+    L.gemm(Ad, Bd, Cd, bias=bias_d, addend=add_d, preact=pre_d, M=M, N=N, K=Kcall,
+           lda=Ad.shape[1], ldb=Bd.shape[1], ldc=N, a_layout=a_layout, b_layout=b_layout, act=act, accum=accum,
+           dtype=L.dtype_code(dt), impl=impl)
+    torch.cuda.synchronize()
+    tol = TOL[dt] * (1 if dt == torch.float32 else 1.0)
+    assert rel_err(Cd, ref) < tol, (M, N, K, a_layout, b_layout, dt, impl)
+    if preact:
+        assert rel_err(pre_d, ref_pre) < tol
+
+
+@pytest.mark.parametrize("dt", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("layouts", [(0, 0), (0, 1), (1, 1), (1, 0)])
+def test_gemm_ref_layouts(dt, layouts):
+    _gemm_case(100, 72, 52, layouts[0], layouts[1], dt, L.IMPL_REF, bias=True)
+    _gemm_case(64, 4, 3072, layouts[0], layouts[1], dt, L.IMPL_REF)
+
+
+@pytest.mark.parametrize("dt", [torch.float32, torch.bfloat16])
+def test_gemm_ref_epilogues(dt):
+    _gemm_case(70, 68, 64, 0, 0, dt, L.IMPL_REF, act=L.ACT_GELU, bias=True, addend=True, preact=True)
+    _gemm_case(70, 68, 128, 1, 1, dt, L.IMPL_REF, accum=True)
+
+
+def test_gemm_mfma_exact_integers():
+    """A = I-like / asymmetric small integers: catches swapped fragment maps exactly (no rounding)."""
+    M, N, K = 256, 256, 128
+    A = torch.zeros(M, K); A[torch.arange(M), torch.arange(M) % K] = 1.0; A[:, 3] += 2.0
+    B = (torch.arange(N)[:, None] * 3 + torch.arange(K)[None, :] * 5) % 7 - 3.0
+    for (al, bl) in [(0, 0), (0, 1), (1, 1), (1, 0)]:
+        Ad = dev(A if al == 0 else A.t(), torch.bfloat16)
+        Bd = dev(B if bl == 0 else B.t(), torch.bfloat16)
+        Cd = torch.empty(M, N, device="cuda", dtype=torch.bfloat16)
+        L.gemm(Ad, Bd, Cd, M=M, N=N, K=K, lda=Ad.shape[1], ldb=Bd.shape[1], ldc=N, a_layout=al, b_layout=bl,
+               dtype=L.BF16, impl=L.IMPL_MFMA)
+        torch.cuda.synchronize()
+        assert torch.equal(Cd.float().cpu(), A @ B.t()), (al, bl)
+
+
+@pytest.mark.parametrize("layouts", [(0, 0), (0, 1), (1, 1), (1, 0)])
+def test_gemm_mfma_layouts(layouts):
+    al, bl = layouts
+    M = 384 if al == L.KROW else 300          # ragged M only for a row-major A (the forward / dgrad cases)
+    _gemm_case(M, 256, 192, al, bl, torch.bfloat16, L.IMPL_MFMA, bias=True)
+    _gemm_case(M, 128, 64, al, bl, torch.bfloat16, L.IMPL_MFMA)
+
+
+def test_gemm_mfma_epilogues_and_wgrad():
+    _gemm_case(200, 384, 256, 0, 0, torch.bfloat16, L.IMPL_MFMA, act=L.ACT_GELU, bias=True, addend=True, preact=True)
+    _gemm_case(788, 768, 768, 0, 1, torch.bfloat16, L.IMPL_MFMA, addend=True)      # dgrad, ViT rows at B=4
+    # wgrad: dW[N,K] += dY^T X, contraction over 788 rows padded to 832 with zeros; split-K + fp32 atomics
+    _gemm_case(768, 768, 788, 1, 1, torch.bfloat16, L.IMPL_MFMA, accum=True)
+    _gemm_case(256, 128, 5000, 1, 1, torch.bfloat16, L.IMPL_MFMA, accum=True)
+
+
+def test_gemm_rejects_bad_arguments():
+    a = torch.zeros(4, 4, device="cuda")
+    with pytest.raises(L.MmrcaError):
+        L.gemm(a, a, a, M=4, N=4, K=4, lda=2, ldb=4, ldc=4, dtype=L.F32)
+    with pytest.raises(L.MmrcaError):
+        L.gemm(a, a, a, M=4, N=4, K=4, lda=4, ldb=4, ldc=4, dtype=L.BF16, impl=L.IMPL_MFMA)
+    with pytest.raises(L.MmrcaError):
+        L.gemm(torch.zeros(4, 4), a, a, M=4, N=4, K=4, lda=4, ldb=4, ldc=4, dtype=L.F32)     # host tensor
+
+
+# ------------------------------------------------------------------------------------------------------
+# LayerNorm, GELU', column sums
+# ------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("dt", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("D", [768, 1024, 96])
+def test_layernorm_fwd_bwd(dt, D):
+    rows, eps = 37, 1e-6
+    x, r = dev(torch.randn(rows, D), dt), dev(torch.randn(rows, D), dt)
+    g, b = dev(1 + 0.1 * torch.randn(D), dt), dev(0.1 * torch.randn(D), dt)
+    s_out, y = torch.empty_like(x), torch.empty_like(x)
+    mean, rstd = torch.empty(rows, device="cuda"), torch.empty(rows, device="cuda")
+    L.add_layernorm_fwd(x, r, g, b, s_out, y, mean, rstd, rows, D, D, D, eps, L.dtype_code(dt))
+    s_ref = (x.float() + r.float())
+    if dt == torch.bfloat16:
+        s_ref = s_ref.bfloat16().float()
+    sr = s_ref.clone().requires_grad_(True)
+    gr, br = g.float().clone().requires_grad_(True), b.float().clone().requires_grad_(True)
+    y_ref = F.layer_norm(sr, (D,), gr, br, eps)
+    assert rel_err(s_out, s_ref) < TOL[dt] and rel_err(y, y_ref) < TOL[dt]
+    dy, dres = dev(torch.randn(rows, D), dt), dev(torch.randn(rows, D), dt)
+    ds = torch.empty_like(x)
+    dg, db = torch.zeros(D, device="cuda"), torch.zeros(D, device="cuda")
+    L.layernorm_bwd(dy, s_out, g, mean, rstd, dres, ds, dg, db, rows, D, D, D, D, L.dtype_code(dt))
+    y_ref.backward(dy.float())
+    assert rel_err(ds, sr.grad + dres.float()) < TOL[dt]
+    assert rel_err(dg, gr.grad) < TOL[dt] and rel_err(db, br.grad) < TOL[dt]
+
+
+def test_layernorm_strided_rows_class_token_only():
+    B, Tn, D = 3, 5, 768
+    x = dev(torch.randn(B * Tn, D))
+    g, b = dev(torch.ones(D)), dev(torch.zeros(D))
+    y = torch.empty(B, D, device="cuda")
+    mean, rstd = torch.empty(B, device="cuda"), torch.empty(B, device="cuda")
+    L.add_layernorm_fwd(x, None, g, b, None, y, mean, rstd, B, D, Tn * D, D, 1e-6, L.F32)
+    assert rel_err(y, F.layer_norm(x.view(B, Tn, D)[:, 0], (D,), g, b, 1e-6)) < 1e-5
+
+
+@pytest.mark.parametrize("dt", [torch.float32, torch.bfloat16])
+def test_gelu_bwd_and_colsum(dt):
+    n = 64 * 772
+    h, dg = dev(torch.randn(n) * 2, dt), dev(torch.randn(n), dt)
+    dh = torch.empty_like(h)
+    L.gelu_bwd(dg, h, dh, n, L.dtype_code(dt))
+    hr = h.float().clone().requires_grad_(True)
+    F.gelu(hr).backward(dg.float())
+    assert rel_err(dh, hr.grad) < TOL[dt]
+    M, N = 1003, 772
+    dY = dev(torch.randn(M, N), dt)
+    db = dev(torch.randn(N))
+    ref = db + dY.float().sum(0)
+    L.colsum_accum(dY, db, M, N, N, L.dtype_code(dt))
+    assert rel_err(db, ref) < 1e-4
+
+
+# ------------------------------------------------------------------------------------------------------
+# embeddings, patchify, assemble
+# ------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("dt", [torch.float32, torch.bfloat16])
+def test_embed_fwd_bwd(dt):
+    V, Pn, D, rows = 1000, 66, 768, 50
+    word, pos, typ = dev(torch.randn(V, D), dt), dev(torch.randn(Pn, D), dt), dev(torch.randn(D), dt)
+    ids = torch.randint(0, V, (rows,), dtype=torch.int32, device="cuda"); ids[:5] = 7
+    pid = torch.randint(0, Pn, (rows,), dtype=torch.int32, device="cuda")
+    out = torch.empty(rows, D, device="cuda", dtype=dt)
+    L.embed_fwd(ids, pid, word, pos, typ, out, rows, D, L.dtype_code(dt))
+    ref = word.float()[ids.long()] + pos.float()[pid.long()] + typ.float()
+    assert rel_err(out, ref) < TOL[dt]
+    dout = dev(torch.randn(rows, D), dt)
+    dw, dp, dty = torch.zeros(V, D, device="cuda"), torch.zeros(Pn, D, device="cuda"), torch.zeros(D, device="cuda")
+    L.embed_bwd(dout, ids, pid, dw, dp, dty, rows, D, L.dtype_code(dt))
+    rw = torch.zeros(V, D, device="cuda").index_add_(0, ids.long(), dout.float())
+    rp = torch.zeros(Pn, D, device="cuda").index_add_(0, pid.long(), dout.float())
+    assert rel_err(dw, rw) < 1e-5 and rel_err(dp, rp) < 1e-5 and rel_err(dty, dout.float().sum(0)) < 1e-5
+
+
+@pytest.mark.parametrize("dt", [torch.float32, torch.bfloat16])
+def test_patchify_matches_conv_and_assemble(dt):
+    B, P, Himg, D = 2, 16, 64, 768
+    nP = (Himg // P) ** 2
+    img = dev(torch.randn(B, 3, Himg, Himg))
+    patches = torch.empty(B * nP, 3 * P * P, device="cuda", dtype=dt)
+    L.patchify_fwd(img, patches, B, 3, Himg, Himg, P, L.dtype_code(dt))
+    w = dev(torch.randn(D, 3, P, P) * 0.05)
+    ref = F.conv2d(img, w, stride=P).reshape(B, D, nP).permute(0, 2, 1).reshape(B * nP, D)
+    got = patches.float() @ w.reshape(D, -1).t()
+    assert rel_err(got, ref) < (1e-4 if dt == torch.float32 else 2e-2)
+    proj, cls, pos = dev(torch.randn(B * nP, D), dt), dev(torch.randn(D), dt), dev(torch.randn(nP + 1, D), dt)
+    x = torch.empty(B * (nP + 1), D, device="cuda", dtype=dt)
+    L.vit_assemble_fwd(proj, cls, pos, x, B, nP, D, L.dtype_code(dt))
+    xr = torch.cat([cls.float().expand(B, 1, D), proj.float().view(B, nP, D)], 1) + pos.float()
+    assert rel_err(x, xr.reshape(-1, D)) < TOL[dt]
+    dx = dev(torch.randn(B * (nP + 1), D), dt)
+    dproj = torch.empty_like(proj)
+    dcls, dpos = torch.zeros(D, device="cuda"), torch.zeros(nP + 1, D, device="cuda")
+    L.vit_assemble_bwd(dx, dproj, dcls, dpos, B, nP, D, L.dtype_code(dt))
+    d3 = dx.float().view(B, nP + 1, D)
+    assert rel_err(dproj, d3[:, 1:].reshape(-1, D)) < 1e-6
+    assert rel_err(dpos, d3.sum(0)) < 1e-5 and rel_err(dcls, d3[:, 0].sum(0)) < 1e-5
+
+
+# ------------------------------------------------------------------------------------------------------
+# attention
+# ------------------------------------------------------------------------------------------------------
+def _attn_ref(qkv, mask, B, H, S, dh, dout=None):
+    qkv = qkv.float().clone().requires_grad_(True)
+    q, k, v = (t.view(B, S, H, dh).transpose(1, 2) for t in qkv.view(B, S, 3 * H * dh).split(H * dh, dim=-1))
+    sc = q @ k.transpose(2, 3) / math.sqrt(dh)
+    if mask is not None:
+        km = mask.bool()[:, None, None, :]
+        valid = km.any(-1, keepdim=True)
+        sc = sc.masked_fill(~km, float("-inf"))
+        a = torch.softmax(torch.where(valid, sc, torch.zeros_like(sc)), -1) * valid
+    else:
+        a = torch.softmax(sc, -1)
+    out = (a @ v).transpose(1, 2).reshape(B * S, H * dh)
+    if dout is None:
+        return out, None
+    out.backward(dout.float())
+    return out, qkv.grad
+
+
+@pytest.mark.parametrize("dt,impl", [(torch.float32, L.IMPL_REF), (torch.bfloat16, L.IMPL_REF), (torch.bfloat16, L.IMPL_AUTO)])
+@pytest.mark.parametrize("S,masked", [(64, True), (197, False), (40, True)])
+def test_mha_fwd_bwd(dt, impl, S, masked):
+    B, H, dh = 3, 4, 64
+    qkv = dev(torch.randn(B * S, 3 * H * dh), dt)
+    mask = None
+    if masked:
+        mask = torch.ones(B, S, dtype=torch.int32)
+        mask[0, S // 2:] = 0
+        mask[2, :] = 0            # fully masked caption (modality dropout)
+        mask = mask.cuda()
+    out = torch.empty(B * S, H * dh, device="cuda", dtype=dt)
+    lse = torch.empty(B, H, S, device="cuda")
+    L.mha_fwd(qkv, mask, out, lse, B, H, S, dh, 1 / math.sqrt(dh), L.dtype_code(dt), impl)
+    dout = dev(torch.randn(B * S, H * dh), dt)
+    ref, dref = _attn_ref(qkv, mask, B, H, S, dh, dout)
+    tol = 1e-4 if dt == torch.float32 else 2e-2
+    assert torch.isfinite(out.float()).all()
+    assert rel_err(out, ref) < tol
+    dqkv = torch.zeros_like(qkv)
+    L.mha_bwd(qkv, mask, out, dout, lse, dqkv, B, H, S, dh, 1 / math.sqrt(dh), L.dtype_code(dt), impl)
+    assert torch.isfinite(dqkv.float()).all()
+    assert rel_err(dqkv, dref) < (2e-4 if dt == torch.float32 else 3e-2)
+
+
+# ------------------------------------------------------------------------------------------------------
+# fused head vs the oracle, loss, optimizers
+# ------------------------------------------------------------------------------------------------------
+def _head_setup(d_img, d_txt, mode, reverse, n_classes=4):
+    from oracle import model as O
+    from garbage_classification_rca_amd import spec as S
+    from garbage_classification_rca_amd.procedural import proc_tensor
+    m = O.OracleMMRCA(n_classes, 0.0, 0.0, 0.7, torch.nn.Identity(), torch.nn.Identity(), d_img, d_txt, reverse,
+                      mode == 1, mode == 2)
+    sd = {k: torch.from_numpy(proc_tensor(k, tuple(v.shape))) for k, v in m.state_dict().items()}
+    m.load_state_dict(sd)
+    names = {"sai": "self_attention_image", "sat": "self_attention_text", "c1": "cross_attention_1", "c2": "cross_attention_2"}
+    leaf = {"wq": "W_query.weight", "bq": "W_query.bias", "wk": "W_key.weight", "bk": "W_key.bias",
+            "wv": "W_value.weight", "bv": "W_value.bias", "g": "norm.weight", "b": "norm.bias"}
+    fin = ["final_with_everything", "final_features_only_linear", "cross_attention_only_linear"][mode]
+    keys = {f"{b}_{l}": f"{names[b]}.{leaf[l]}" for b in names for l in leaf}
+    keys["fin_w"], keys["fin_b"] = fin + ".weight", fin + ".bias"
+    wt = {f: sd[k].cuda().contiguous() for f, k in keys.items()}
+    gt = {f: torch.zeros_like(t) for f, t in wt.items()}
+    W, G = L.HeadPtrs(), L.HeadPtrs()
+    for f in L.HEAD_FIELDS:
+        setattr(W, f, wt[f].data_ptr()); setattr(G, f, gt[f].data_ptr())
+    return m, keys, wt, gt, W, G
+
+
+@pytest.mark.parametrize("mode", [0, 1, 2])
+@pytest.mark.parametrize("reverse", [True, False])
+@pytest.mark.parametrize("dims", [(1280, 768), (768, 768), (2048, 768)])
+def test_head_fwd_bwd_vs_oracle(mode, reverse, dims):
+    d_img, d_txt = dims
+    B = 5
+    m, keys, wt, gt, W, G = _head_setup(d_img, d_txt, mode, reverse)
+    g = torch.Generator().manual_seed(5)
+    img, txt = torch.randn(B, d_img, generator=g), torch.randn(B, d_txt, generator=g)
+    imgd, txtd = img.cuda(), txt.cuda()
+    logits = torch.empty(B, 4, device="cuda")
+    L.head_fwd(imgd, txtd, W, logits, B, d_img, d_txt, 4, reverse, mode, 0.0, 0, L.F32)
+    ir, tr = img.clone().requires_grad_(True), txt.clone().requires_grad_(True)
+    for p in m.parameters():
+        p.requires_grad_(True)
+    ref = m.head(tr, ir)
+    assert rel_err(logits.cpu(), ref.detach()) < 1e-4
+    dl = torch.randn(B, 4, generator=g)
+    ref.backward(dl)
+    dimg, dtxt = torch.empty_like(imgd), torch.empty_like(txtd)
+    L.head_bwd(dl.cuda(), imgd, txtd, W, G, dimg, dtxt, B, d_img, d_txt, 4, reverse, mode, 0.0, 0, L.F32)
+    assert rel_err(dimg.cpu(), ir.grad) < 2e-4 and rel_err(dtxt.cpu(), tr.grad) < 2e-4
+    named = dict(m.named_parameters())
+    for f, k in keys.items():
+        gref = named[k].grad
+        if gref is None:
+            assert float(gt[f].abs().max()) == 0.0, f
+        else:
+            assert rel_err(gt[f].cpu(), gref) < 3e-4, f
+
+
+def test_head_dropout_is_consistent_between_fwd_and_bwd():
+    """With dropout the forward is linear in the kept columns; check d logits / d fin_b and the mask's keep rate."""
+    d_img, d_txt, B = 768, 768, 64
+    m, keys, wt, gt, W, G = _head_setup(d_img, d_txt, 1, True)
+    wt["fin_w"].fill_(1.0); wt["fin_b"].zero_()
+    img, txt = torch.rand(B, d_img).cuda() + 0.5, torch.rand(B, d_txt).cuda() + 0.5
+    lg0, lg1 = torch.empty(B, 4, device="cuda"), torch.empty(B, 4, device="cuda")
+    L.head_fwd(img, txt, W, lg0, B, d_img, d_txt, 4, True, 1, 0.0, 11, L.F32)
+    L.head_fwd(img, txt, W, lg1, B, d_img, d_txt, 4, True, 1, 0.6, 11, L.F32)
+    # E[dropout(x)] = x: with 1536 columns per sample the means agree to a few percent
+    assert abs((lg1.mean() / lg0.mean()).item() - 1.0) < 0.05
+    lg2 = torch.empty_like(lg1)
+    L.head_fwd(img, txt, W, lg2, B, d_img, d_txt, 4, True, 1, 0.6, 11, L.F32)
+    assert torch.equal(lg1, lg2)                      # counter-based mask: same seed, same mask
+    dl = torch.ones(B, 4, device="cuda")
+    L.head_bwd(dl, img, txt, W, G, None, None, B, d_img, d_txt, 4, True, 1, 0.6, 11, L.F32)
+    # sum over classes/columns of dW = sum_b sum_col dropped(x)[b,col] * 1 = sum of logits of one class
+    assert rel_err(gt["fin_w"][0].sum(), lg1[:, 0].sum()) < 1e-4
+
+
+def test_xent_matches_torch():
+    B, C = 37, 4
+    z = torch.randn(B, C) * 2
+    y = torch.randint(0, C, (B,))
+    w = torch.tensor([0.5, 2.0, 1.0, 1.5])
+    for eps in (0.0, 0.1):
+        for cw in (None, w):
+            zr = z.clone().requires_grad_(True)
+            ref = torch.nn.CrossEntropyLoss(weight=cw, label_smoothing=eps)(zr, y)
+            ref.backward()
+            loss, dz = torch.empty(1, device="cuda"), torch.empty(B, C, device="cuda")
+            L.xent_fwd_bwd(z.cuda(), y.int().cuda(), None if cw is None else cw.cuda(), eps, loss, dz, B, C)
+            assert abs(loss.item() - ref.item()) < 1e-5 * max(1, abs(ref.item()))
+            assert rel_err(dz.cpu(), zr.grad) < 1e-5
+
+
+def test_optimizers_match_torch():
+    n = 4096 + 64
+    p0, g = torch.randn(n), torch.randn(n)
+    for kind in ("sgd", "adamw"):
+        pt = p0.clone().requires_grad_(True)
+        opt = torch.optim.SGD([pt], lr=0.01, weight_decay=0.01) if kind == "sgd" else torch.optim.AdamW([pt], lr=0.01, weight_decay=0.01)
+        pd, lp = p0.clone().cuda(), torch.empty(n, device="cuda", dtype=torch.bfloat16)
+        mom, var = torch.zeros(n, device="cuda"), torch.zeros(n, device="cuda")
+        for step in range(1, 4):
+            pt.grad = g.clone() * step
+            opt.step()
+            if kind == "sgd":
+                L.sgd_step(pd, (g * step).cuda(), lp, n, 0.01, 0.01)
+            else:
+                L.adamw_step(pd, (g * step).cuda(), mom, var, lp, n, 0.01, 0.9, 0.999, 1e-8, 0.01, step)
+        assert rel_err(pd.cpu(), pt.detach()) < 1e-5
+        assert torch.equal(lp.cpu(), pd.cpu().bfloat16())
