@@ -1,0 +1,118 @@
+"""Data parallelism for the MM-RCA training loop: one process per GPU, RCCL (torch.distributed backend "nccl" on
+ROCm; "gloo" on CPU for tests).  Replaces the reference's single-process ``nn.DataParallel`` (main_both.py:386-388).
+
+* samples shard by rank with a shared per-epoch permutation (``ShardedSampler``) -- no data-path collective;
+* the one exchange step is the gradient all-reduce.  The gradient arena is flat and ordered
+  text | vision | head, and the backward finishes spans in the order head, vision layers (last to first), text layers
+  (last to first): ``GradSync`` issues one asynchronous all-reduce (average) per finished span on RCCL's own stream, so
+  the exchange of layer i overlaps the backward of layers < i; ``finish()`` waits before the optimizer step.
+  With gradient accumulation only the stepping micro-batch synchronises (main_both.py:116-124 semantics).
+"""
+from __future__ import annotations
+
+import math
+import os
+from typing import Iterator, List, Optional
+
+import torch
+import torch.distributed as dist
+
+
+def init_from_env(backend: Optional[str] = None):
+    """RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* from torchrun; returns (rank, local_rank, world)."""
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1 and not dist.is_initialized():
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29500")
+        if backend is None:
+            backend = "nccl" if torch.cuda.is_available() else "gloo"
+        if backend == "nccl":
+            torch.cuda.set_device(local)
+            dist.init_process_group(backend, rank=rank, world_size=world, device_id=torch.device("cuda", local))
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
+    return rank, local, world
+
+
+class ShardedSampler(torch.utils.data.Sampler):
+    """idx = perm(seed + epoch)[rank::world], padded (by wrapping) so that every rank draws the same count."""
+
+    def __init__(self, n: int, rank: int, world: int, shuffle: bool = True, seed: int = 0):
+        self.n, self.rank, self.world, self.shuffle, self.seed, self.epoch = n, rank, world, shuffle, seed, 0
+        self.per_rank = math.ceil(n / world) if n else 0
+
+    def set_epoch(self, epoch: int):
+        self.epoch = epoch
+
+    def indices(self) -> List[int]:
+        if self.shuffle:
+            g = torch.Generator().manual_seed(self.seed + self.epoch)
+            order = torch.randperm(self.n, generator=g).tolist()
+        else:
+            order = list(range(self.n))
+        total = self.per_rank * self.world
+        if total > self.n and self.n:
+            order = order + order[: total - self.n]
+        return order[self.rank: total: self.world]
+
+    def __iter__(self) -> Iterator[int]:
+        return iter(self.indices())
+
+    def __len__(self) -> int:
+        return self.per_rank
+
+
+class GradSync:
+    """Overlapped gradient averaging over contiguous slices of a flat gradient buffer."""
+
+    def __init__(self, flat_grads: torch.Tensor, world: Optional[int] = None, bucket_bytes: int = 32 << 20):
+        self.g = flat_grads
+        self.world = world if world is not None else (dist.get_world_size() if dist.is_initialized() else 1)
+        self.bucket_elems = max(1, bucket_bytes // flat_grads.element_size())
+        self.pending = []
+        self.enabled = True
+        self._acc_lo, self._acc_hi = None, None
+        self.bytes_reduced = 0
+
+    def span_ready(self, lo: int, hi: int, flush: bool = False):
+        """Called by the engine when grads in [lo, hi) are final.  Adjacent ready spans are merged until a bucket is
+        full (spans arrive in descending address order within an encoder)."""
+        if not self.enabled or self.world == 1 or hi <= lo:
+            return
+        if self._acc_lo is not None and hi == self._acc_lo:
+            self._acc_lo = lo
+        elif self._acc_lo is not None and lo == self._acc_hi:
+            self._acc_hi = hi
+        else:
+            self._flush()
+            self._acc_lo, self._acc_hi = lo, hi
+        if flush or (self._acc_hi - self._acc_lo) >= self.bucket_elems:
+            self._flush()
+
+    def _flush(self):
+        if self._acc_lo is None:
+            return
+        view = self.g[self._acc_lo:self._acc_hi]
+        op = dist.ReduceOp.AVG if dist.get_backend() == "nccl" else dist.ReduceOp.SUM
+        work = dist.all_reduce(view, op=op, async_op=True)
+        self.pending.append((work, view, op))
+        self.bytes_reduced += view.numel() * view.element_size()
+        self._acc_lo = self._acc_hi = None
+
+    def finish(self):
+        self._flush()
+        for work, view, op in self.pending:
+            work.wait()
+            if op == dist.ReduceOp.SUM:
+                view.div_(self.world)
+        self.pending.clear()
+
+
+def all_reduce_counts(correct: int, count: int, device) -> tuple:
+    if not dist.is_initialized() or dist.get_world_size() == 1:
+        return correct, count
+    t = torch.tensor([correct, count], dtype=torch.float64, device=device)
+    dist.all_reduce(t)
+    return int(t[0].item()), int(t[1].item())

@@ -90,6 +90,17 @@ class MMRCAEngine:
         self.head_span = self.arena.span(self.head_keys[0][0], self.head_keys[-1][0])
         self._bufs: Dict[Tuple, torch.Tensor] = {}
         self._saved = None
+        # parameter groups that become final together during backward; they tile the arena exactly (padding included)
+        self.groups: Dict[str, Tuple[int, int]] = {}
+        starts = []
+        for k in self.param_keys:
+            gname = self._group_of(k)
+            if not starts or starts[-1][0] != gname:
+                starts.append((gname, self.arena.offsets[k][0]))
+        for j, (gname, lo) in enumerate(starts):
+            hi = starts[j + 1][1] if j + 1 < len(starts) else self.arena.total
+            self.groups[gname] = (lo, hi)
+        self.grad_sync = None          # distributed.GradSync, set by the training driver
         self._head_w = self._head_struct("p")
         self._head_g = self._head_struct("g")
         # fused QKV views of the text encoder must be contiguous in the arena
@@ -99,6 +110,30 @@ class MMRCAEngine:
             assert o[1][0] == o[0][0] + o[0][2] and o[2][0] == o[1][0] + o[1][2], "qkv weights not adjacent"
             o = [self.arena.offsets["text_model." + K[n] + ".bias"] for n in ("q", "k", "v")]
             assert o[1][0] == o[0][0] + o[0][2] and o[2][0] == o[1][0] + o[1][2], "qkv biases not adjacent"
+
+    @staticmethod
+    def _group_of(key: str) -> str:
+        import re
+        m = re.match(r"text_model\.(?:transformer|encoder)\.layer\.(\d+)\.", key)
+        if m:
+            return f"text_layer_{int(m.group(1))}"
+        if key.startswith("text_model.pooler"):
+            return "text_tail"
+        if key.startswith("text_model."):
+            return "text_emb"
+        m = re.match(r"image_model\.encoder\.layers\.encoder_layer_(\d+)\.", key)
+        if m:
+            return f"image_layer_{int(m.group(1))}"
+        if key.startswith("image_model.encoder.ln"):
+            return "image_ln"
+        if key.startswith("image_model."):
+            return "image_emb"
+        return "head"
+
+    def _ready(self, group: str, flush: bool = False):
+        if self.grad_sync is not None and group in self.groups:
+            lo, hi = self.groups[group]
+            self.grad_sync.span_ready(lo, hi, flush)
 
     # ------------------------------------------------------------------ parameters
     def _head_struct(self, which) -> L.HeadPtrs:
@@ -283,11 +318,13 @@ class MMRCAEngine:
             dqkv = gb("dqkv", 3 * D)
             L.mha_bwd(a["qkv"], sv["mask32"], a["ctx"], dctx, a["lse"], dqkv, B, H, T, dh, dh ** -0.5, self.dt, self.attn_impl)
             self._lin_bwd(dqkv, a["x"], P + K["q"] + ".weight", P + K["q"] + ".bias", dx, M, 3 * D, D, addend=ds1, wnumel=3 * D * D)
+            self._ready(f"text_layer_{i}")
         ds0 = gb("ds2", D)
         self._ln_bwd(dx, sv["emb"], P + "embeddings.LayerNorm", sv["mean0"], sv["rstd0"], None, ds0, M, D)
         dtype_row = self.Gflat(P + "embeddings.token_type_embeddings.weight", D) if s.type_vocab else None
         L.embed_bwd(ds0, sv["ids32"], sv["pos"], self.G(P + "embeddings.word_embeddings.weight"),
                     self.G(P + "embeddings.position_embeddings.weight"), dtype_row, M, D, self.dt)
+        self._ready("text_emb", flush=True)
 
     # ------------------------------------------------------------------ vision encoder
     def _vision_forward(self, images, save):
@@ -341,6 +378,7 @@ class MMRCAEngine:
         dfe = self.buf("vg_dfeat", B, D)
         dfe[:B].copy_(dfeat)
         self._ln_bwd(dfe, sv["xL"], P + "encoder.ln", sv["mf"], sv["rf"], None, dx, B, D, ld_dy=D, ld_s=Tn * D, ld_ds=Tn * D)
+        self._ready("image_ln")
         for i in reversed(range(s.layers)):
             Lk, a = P + f"encoder.layers.encoder_layer_{i}.", sv["layers"][i]
             dg = gb("dF", M, Fd)
@@ -357,9 +395,11 @@ class MMRCAEngine:
             dy1 = gb("dy", M, D)
             self._lin_bwd(dqkv, a["y1"], Lk + "self_attention.in_proj_weight", Lk + "self_attention.in_proj_bias", dy1, M, 3 * D, D)
             self._ln_bwd(dy1, a["x"], Lk + "ln_1", a["m1"], a["r1"], dx1, dx, M, D)
+            self._ready(f"image_layer_{i}")
         dproj = gb("dproj", B * nP, D)
         L.vit_assemble_bwd(dx, dproj, self.Gflat(P + "class_token", D), self.Gflat(P + "encoder.pos_embedding", Tn * D), B, nP, D, self.dt)
         self._lin_bwd(dproj, sv["patches"], P + "conv_proj.weight", P + "conv_proj.bias", None, B * nP, D, Kp, wnumel=D * Kp)
+        self._ready("image_emb", flush=True)
 
     # ------------------------------------------------------------------ whole model
     def forward(self, ids, mask, images, drop_p: float = 0.0, seed: int = 0, save: bool = True):
@@ -389,6 +429,7 @@ class MMRCAEngine:
         dtxt = torch.empty(B, self.d_txt, dtype=self.dtype, device=self.device) if train_text else None
         L.head_bwd(dl, sv["feat"], sv["cls"], self._head_w, self._head_g, dimg, dtxt, B, self.d_img, self.d_txt,
                    self.n_classes, self.reverse, self.mode, sv["drop_p"], sv["seed"], self.dt)
+        self._ready("head", flush=not (train_image or train_text))
         if train_image:
             self._vision_backward(dimg, sv["vision"])
         if train_text:
@@ -397,18 +438,18 @@ class MMRCAEngine:
 
     # ------------------------------------------------------------------ flat-arena optimizer steps
     def trainable_spans(self, train_text: bool, train_image: bool):
+        """Contiguous [lo, hi) slices of the arenas that an optimizer step / all-reduce must cover."""
+        t0, i0, h0 = 0, self.groups["image_emb"][0], self.groups["head"][0]
         spans = []
         if train_text:
-            spans.append(self.text_span)
+            spans.append([t0, i0])
         if train_image:
-            spans.append(self.image_span)
-        spans.append(self.head_span)
-        # merge adjacent
-        spans.sort()
-        out = [list(spans[0])]
-        for a, b in spans[1:]:
-            if a <= _round_up(out[-1][1], ALIGN):
-                out[-1][1] = b
+            if spans and spans[-1][1] == i0:
+                spans[-1][1] = h0
             else:
-                out.append([a, b])
-        return [(a, _round_up(b, 4)) for a, b in out]
+                spans.append([i0, h0])
+        if spans and spans[-1][1] == h0:
+            spans[-1][1] = self.arena.total
+        else:
+            spans.append([h0, self.arena.total])
+        return [tuple(x) for x in spans]

@@ -1,0 +1,244 @@
+"""Drop-in ``MM_RCA`` module (mirrors CVPR_code/multimodal_model.py:156-328, 636-728 of the reference).
+
+Same constructor argument order as the reference's call at main_both.py:306-317, same
+``forward(_input_ids, _attention_mask, _images, eval=False, remove_image=False, remove_text=False)``, same
+``get_tokenizer() / get_image_size() / get_max_token_size()``, same ``.text_model`` / ``.image_model``
+attributes and the same ``state_dict()`` key names -- but the arithmetic runs in libmmrca (HIP) through
+:class:`~garbage_classification_rca_amd.engine.MMRCAEngine`.  ``loss.backward()`` works: the whole model is one
+autograd node whose backward runs the HIP backward and accumulates into ``param.grad`` (views of the flat
+gradient arena).
+
+Differences from the reference, all additive:
+* ``image_model_name`` (11th argument; the reference ignores ``--image_model`` and hard-codes EfficientNetV2-M,
+  main_both.py:259).  HIP backbones today: ``transformer_B16`` and ``transformer_L16``.
+* ``dtype`` (torch.bfloat16 default; torch.float32 = parity mode).
+* encoder dropout (0.1 inside DistilBERT in train mode) is not applied yet -- see DESIGN.md "known gaps".
+"""
+from __future__ import annotations
+
+import sys
+from typing import Dict, Optional
+
+import numpy as np
+import torch
+
+from . import lib as L
+from . import spec as S
+from .engine import MMRCAEngine
+
+
+def decision(probability):
+    """multimodal_model.py:110-111 -- one draw of the global numpy RNG."""
+    return np.random.rand(1)[0] < probability
+
+
+class ParamTree(torch.nn.Module):
+    """Registers arena views as nn.Parameters under nested sub-modules so that ``state_dict()`` keys are the
+    reference's dotted names."""
+
+    def __init__(self):
+        super().__init__()
+
+    def add(self, dotted: str, p: torch.nn.Parameter):
+        node = self
+        parts = dotted.split(".")
+        for name in parts[:-1]:
+            if name not in node._modules:
+                node.add_module(name, ParamTree())
+            node = node._modules[name]
+        node.register_parameter(parts[-1], p)
+
+
+class HashingTokenizer:
+    """Offline stand-in used only when the HuggingFace vocabulary files cannot be fetched (no network):
+    whitespace words hashed into the vocabulary, [CLS]/[SEP]/pad ids of bert-base-uncased.  Same call contract
+    as the tokenizer call in CustomImageTextFolder.py:305-333."""
+
+    def __init__(self, vocab_size=30522, cls_id=101, sep_id=102, pad_id=0, model_max_length=512):
+        self.vocab_size, self.cls_id, self.sep_id, self.pad_id = vocab_size, cls_id, sep_id, pad_id
+        self.model_max_length = model_max_length
+
+    def __call__(self, text, max_length=None, truncation=True, padding="max_length", return_attention_mask=True,
+                 return_token_type_ids=False, return_tensors="pt", **kw):
+        import zlib
+        max_length = max_length or self.model_max_length
+        ids = [self.cls_id] + [1000 + zlib.crc32(w.encode()) % (self.vocab_size - 1000) for w in str(text).split()]
+        ids = ids[: max_length - 1] + [self.sep_id]
+        mask = [1] * len(ids)
+        if padding == "max_length":
+            ids, mask = ids + [self.pad_id] * (max_length - len(ids)), mask + [0] * (max_length - len(mask))
+        out = {"input_ids": torch.tensor([ids], dtype=torch.int64)}
+        if return_attention_mask:
+            out["attention_mask"] = torch.tensor([mask], dtype=torch.int64)
+        return out
+
+    encode_plus = __call__
+
+
+class _EngineFunction(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, anchor, module, ids, mask, images, drop_p, seed, save):
+        ctx.module = module
+        return module.engine.forward(ids, mask, images, drop_p, seed, save=save)
+
+    @staticmethod
+    def backward(ctx, dlogits):
+        ctx.module._engine_backward(dlogits)
+        return (None,) * 8
+
+
+class EffV2MediumAndDistilbertGated(torch.nn.Module):
+    """Base class name kept from the reference (multimodal_model.py:156); only the MM_RCA forward is built."""
+
+    def __init__(self, n_classes, drop_ratio, image_or_text_dropout_chance, img_prob_dropout, num_neurons_fc,
+                 text_model_name, batch_size, reverse, features_only, cross_attention_only,
+                 image_model_name: str = "transformer_B16", dtype: torch.dtype = torch.bfloat16,
+                 device="cuda", init_seed: int = 0, build_unused_parameters: bool = True):
+        super().__init__()
+        self.text_model_name = text_model_name
+        self.image_model_name = image_model_name
+        self.features_only, self.cross_attention_only = bool(features_only), bool(cross_attention_only)
+        print("Only features:", self.features_only)
+        print("Only cross attention:", self.cross_attention_only)
+        if text_model_name not in S.TEXT_SPECS:
+            print("Wrong text model:", text_model_name)          # multimodal_model.py:184-186
+            sys.exit(1)
+        mode = 1 if self.features_only else (2 if self.cross_attention_only else 0)
+        self.engine = MMRCAEngine(text_model_name, image_model_name, n_classes, reverse, mode, dtype, device)
+        self.engine.init_parameters(init_seed)
+        self.drop_ratio = float(drop_ratio)
+        self.image_or_text_dropout_chance = image_or_text_dropout_chance
+        self.img_dropout_prob = img_prob_dropout
+        self.fc_layer_neurons, self.batch_size, self.n_classes = num_neurons_fc, batch_size, n_classes
+        self.num_patches = S.NUM_PATCHES
+        self.txt_patch_size, self.img_patch_size = self.engine.d_txt // 16, self.engine.d_img // 16
+        print("txt patch size: ", self.txt_patch_size)
+        print("img patch size: ", self.img_patch_size)
+        self._fwd_count = 0
+        self._drop_seed = 0x5EED
+
+        # parameters = views of the flat arena; gradients = views of the gradient arena
+        ar = self.engine.arena
+        self.text_model, self.image_model = ParamTree(), ParamTree()
+        self._arena_params: Dict[str, torch.nn.Parameter] = {}
+        for k in self.engine.param_keys:
+            p = torch.nn.Parameter(ar.view(k))
+            self._arena_params[k] = p
+            if k.startswith("text_model."):
+                self.text_model.add(k[len("text_model."):], p)
+                p.requires_grad = False                      # frozen at construction (multimodal_model.py:132-133)
+            elif k.startswith("image_model."):
+                self.image_model.add(k[len("image_model."):], p)
+                p.requires_grad = False                      # :117-118
+            else:
+                self._add_head_param(k, p)
+        self._attach_grads()
+        if build_unused_parameters:
+            # present-but-unused keys of the reference constructor (:199-328): kept for checkpoint interchange
+            g = torch.Generator().manual_seed(init_seed + 1)
+            for k, shp in S.head_unused_params(self.engine.d_img, self.engine.d_txt, n_classes, num_neurons_fc,
+                                               batch_size, self.features_only, self.cross_attention_only):
+                if k in self._arena_params:
+                    continue
+                t = torch.randn(shp, generator=g) * 0.02 if len(shp) else torch.tensor(float(np.log(1 / 0.07)))
+                self._add_head_param(k, torch.nn.Parameter(t.to(device)))
+        self._anchor = torch.zeros(1, device=device, requires_grad=True)
+        self.config_hidden_size = self.engine.d_txt
+
+    def _add_head_param(self, dotted, p):
+        node = self
+        parts = dotted.split(".")
+        for name in parts[:-1]:
+            if name not in node._modules:
+                node.add_module(name, ParamTree())
+            node = node._modules[name]
+        node.register_parameter(parts[-1], p)
+
+    def _attach_grads(self):
+        for k, p in self._arena_params.items():
+            p.grad = self.engine.arena.view(k, "g")
+
+    # ------------------------------------------------------------------ reference API
+    def get_tokenizer(self):
+        """multimodal_model.py:397-405.  Falls back to an offline hashing tokenizer when the HF files are absent."""
+        names = {"bert": "bert-base-uncased", "distilbert": "distilbert-base-uncased", "roberta": "roberta-base"}
+        try:
+            from transformers import AutoTokenizer
+            self.tokenizer = AutoTokenizer.from_pretrained(names[self.text_model_name], local_files_only=True)
+        except Exception as e:      # no network / no cache
+            print(f"[mmrca] tokenizer files for {names[self.text_model_name]} unavailable ({type(e).__name__}); "
+                  "using the offline HashingTokenizer")
+            ts = self.engine.ts
+            self.tokenizer = HashingTokenizer(ts.vocab, model_max_length=self.get_max_token_size())
+        return self.tokenizer
+
+    def get_image_size(self):
+        """(W, H) the image backbone expects (reference: (480, 480) for EfficientNetV2-M, :407-408)."""
+        return (self.engine.vs.image, self.engine.vs.image)
+
+    def get_max_token_size(self):
+        """multimodal_model.py:410-418: the text backbone's max_position_embeddings."""
+        ts = self.engine.ts
+        return ts.max_pos - ts.pos_offset if ts.pos_offset else ts.max_pos
+
+    def drop_modalities(self, _eval, remove_image, remove_text):
+        """multimodal_model.py:420-455 incl. its numpy-RNG draw pattern (1 draw, 2 if the first succeeds)."""
+        if _eval:
+            if remove_image:
+                print("    Eval: zero image")
+                self._images = torch.zeros_like(self._images)
+            if remove_text:
+                print("    Eval: zero text")
+                self._input_ids = torch.zeros_like(self._input_ids)
+                self._attention_mask = torch.zeros_like(self._attention_mask)
+        else:
+            if decision(self.image_or_text_dropout_chance):
+                if decision(self.img_dropout_prob):
+                    print("    Train: zeroing image\n")
+                    self._images = torch.zeros_like(self._images)
+                else:
+                    print("    Train: zeroing text\n")
+                    self._input_ids = torch.zeros_like(self._input_ids)
+                    self._attention_mask = torch.zeros_like(self._attention_mask)
+
+    # ------------------------------------------------------------------ autograd glue
+    def _train_flags(self):
+        tt = next(iter(self.text_model.parameters())).requires_grad
+        ti = next(iter(self.image_model.parameters())).requires_grad
+        return tt, ti
+
+    def _engine_backward(self, dlogits):
+        if any(p.grad is None for p in self._arena_params.values()):
+            # optimizer.zero_grad(set_to_none=True) (torch's default, used at main_both.py:120,124) dropped the views
+            self.engine.arena.g.zero_()
+            self._attach_grads()
+        tt, ti = self._train_flags()
+        self.engine.backward(dlogits, train_text=tt, train_image=ti)
+
+    def load_state_dict(self, state_dict, strict=True, **kw):
+        r = super().load_state_dict(state_dict, strict=strict, **kw)
+        self.engine.arena.lp_valid = False
+        return r
+
+    def _apply(self, fn, *a, **kw):
+        # parameters live in the engine's arenas; .to()/.cuda()/.cpu() would detach them (save_model_weights'
+        # model.to("cpu") round trip at main_both.py:223-226 becomes a no-op: state_dict() tensors are copied out instead)
+        return self
+
+    def forward(self, _input_ids, _attention_mask, _images, eval=False, remove_image=False, remove_text=False):
+        raise NotImplementedError("only the MM_RCA forward is built (other fusion forwards are unconstructible in the reference)")
+
+
+class MM_RCA(EffV2MediumAndDistilbertGated):
+    """multimodal_model.py:636-728."""
+
+    def forward(self, _input_ids, _attention_mask, _images, eval=False, remove_image=False, remove_text=False):
+        self._images, self._input_ids, self._attention_mask = _images, _input_ids, _attention_mask
+        self.drop_modalities(eval, remove_image, remove_text)
+        drop_p = self.drop_ratio if self.training else 0.0           # nn.Dropout(p=drop_ratio) at :719
+        self._fwd_count += 1
+        need_grad = torch.is_grad_enabled()
+        tt, ti = self._train_flags()
+        logits = _EngineFunction.apply(self._anchor, self, self._input_ids, self._attention_mask, self._images,
+                                       drop_p, self._drop_seed + self._fwd_count, bool(need_grad and (tt or ti)))
+        return logits
