@@ -1,0 +1,179 @@
+#!/usr/bin/env python
+"""Headline benchmark: train samples/s (image+text pairs) of MM-RCA, ViT-B/16 + DistilBERT, bf16, per-GPU batch 256
+(BASELINE.json configs[1]), on N GPUs of one node (weak scaling, one process per GPU over RCCL).
+
+    python bench.py --gpus 1 --steps 10 --warmup 3
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
+
+A step = one pass of the hot path over one batch of synthetic pairs already resident in HBM: forward (text encoder,
+vision encoder, fused RCA head), weighted/smoothed cross entropy, full backward (fine-tuning phase: every parameter
+trainable, main_both.py:690-697), gradient all-reduce (N>1), SGD step (lr 1e-3, weight decay 1e-2: the reference
+defaults, options.py) and gradient zeroing.  Rank 0 prints ONE JSON line.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+PEAK_BF16_TFLOPS = 2500.0      # MI355X dense bf16 MFMA peak (MI355X_MICROARCH.md, chip-level parameters)
+# forward matmul FLOPs per sample: DistilBERT S=64 5.51 G + ViT-B/16 35.1 G + head 2.9 M
+FWD_GFLOP_PER_SAMPLE = 40.6
+
+
+def cpu_baseline(batch=8, steps=2, seq_len=64):
+    """The oracle (CPU restatement of the reference's model + run_one_epoch step) on this box's host cores, same
+    synthetic tensors, fp32 eager, fine-tuning phase.  A reported baseline, not the optimisation target."""
+    from oracle import model as O
+    from garbage_classification_rca_amd.procedural import synth_captions
+    n = os.cpu_count() or 1
+    torch.set_num_threads(n)
+    m = O.build_oracle("distilbert", "transformer_B16", True, drop_ratio=0.6, enc_dropout=0.1).train()
+    g = torch.Generator().manual_seed(0)
+    with torch.no_grad():
+        for name, p in m.named_parameters():
+            if p.dim() >= 2:
+                p.copy_(torch.randn(p.shape, generator=g) * 0.02)
+            elif name.endswith("weight"):
+                p.fill_(1.0)          # every 1-D "weight" on this path is a LayerNorm scale
+            else:
+                p.zero_()
+    opt = torch.optim.SGD(m.parameters(), lr=1e-3, weight_decay=1e-2)
+    ids, mask = (torch.from_numpy(a) for a in synth_captions(batch, seq_len, seed=4321))
+    images = torch.randn(batch, 3, 224, 224, generator=torch.Generator().manual_seed(1234))
+    labels = torch.arange(batch) % 4
+
+    def step():
+        out = m(ids, mask, images)
+        loss = O.cross_entropy(out, labels)
+        loss.backward()
+        opt.step()
+        opt.zero_grad()
+    step()
+    t0 = time.time()
+    for _ in range(steps):
+        step()
+    dt = time.time() - t0
+    return {"value": round(batch * steps / dt, 3), "unit": "samples/s", "cores": n, "kind": "port",
+            "sample": f"oracle (PyTorch CPU fp32 eager restatement of MM_RCA + run_one_epoch step), ViT-B/16 + DistilBERT, "
+                      f"batch {batch}, S={seq_len}, {steps} timed steps after 1 warm-up, {n} threads"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=8)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--batch", type=int, default=256, help="per-GPU batch (BASELINE config: 256)")
+    ap.add_argument("--seq_len", type=int, default=64)
+    ap.add_argument("--no_cpu_baseline", action="store_true")
+    ap.add_argument("--frozen", action="store_true", help="time the frozen-backbone phase instead (reported separately)")
+    args = ap.parse_args()
+
+    from garbage_classification_rca_amd import lib as L
+    from garbage_classification_rca_amd import distributed as D
+    from garbage_classification_rca_amd.multimodal_model import MM_RCA
+    from garbage_classification_rca_amd.optim import FlatSGD
+    from garbage_classification_rca_amd.procedural import synth_captions
+    from garbage_classification_rca_amd.training import FusedCrossEntropy, hip_train_step
+    import torch.distributed as dist
+
+    rank, local, world = D.init_from_env("nccl")
+    assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
+    assert torch.cuda.is_available(), "bench.py needs a GPU: the MM-RCA product path has no CPU fallback"
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    L.load()
+    B, S = args.batch, args.seq_len
+
+    import contextlib
+    import io
+    with contextlib.redirect_stdout(io.StringIO()):
+        model = MM_RCA(4, 0.6, 0.0, 0.7, 256, "distilbert", B, True, False, False, image_model_name="transformer_B16",
+                       dtype=torch.bfloat16, device=dev, init_seed=0)
+    model.train()
+    if not args.frozen:
+        for p in model.parameters():
+            p.requires_grad = True
+    opt = FlatSGD(model, lr=1e-3, weight_decay=1e-2)
+    crit = FusedCrossEntropy(None, 0.0)
+    sync = D.GradSync(model.engine.arena.g, world) if world > 1 else None
+
+    # synthetic pairs, resident in HBM before the timed region; a few distinct batches
+    nb = 2
+    ids, mask = synth_captions(B * nb, S, seed=4321 + rank)
+    ids, mask = torch.from_numpy(ids).to(dev), torch.from_numpy(mask).to(dev)
+    gen = torch.Generator(device=dev).manual_seed(1234 + rank)
+    images = torch.randn(B * nb, 3, 224, 224, device=dev, generator=gen)
+    labels = (torch.arange(B * nb, device=dev) % 4).to(torch.int32)
+
+    def step(i):
+        j = (i % nb) * B
+        return hip_train_step(model, ids[j:j + B], mask[j:j + B], images[j:j + B], labels[j:j + B], crit, opt, sync)
+
+    with contextlib.redirect_stdout(io.StringIO()):
+        for i in range(args.warmup):
+            step(i)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    L.GEMM_PROFILE = []
+    t0 = time.perf_counter()
+    with contextlib.redirect_stdout(io.StringIO()):
+        for i in range(args.steps):
+            loss = step(i)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    prof, L.GEMM_PROFILE = L.GEMM_PROFILE, None
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    final_loss = float(loss.item())
+
+    if rank == 0:
+        flops = sum(p[0] for p in prof)
+        ms = sum(p[2].elapsed_time(p[3]) for p in prof)
+        by_kind = {}
+        for f, kind, e0, e1 in prof:
+            d = by_kind.setdefault(kind, [0.0, 0.0, 0])
+            d[0] += f; d[1] += e0.elapsed_time(e1); d[2] += 1
+        achieved = flops / (ms * 1e-3) / 1e12 if ms > 0 else 0.0
+        value = B * world * args.steps / elapsed
+        train_flop_per_sample = (FWD_GFLOP_PER_SAMPLE * (1.0 if args.frozen else 3.0)) * 1e9
+        out = {
+            "metric": "train samples/sec (image+text pairs), MM-RCA ViT-B16+DistilBERT", "value": round(value, 2),
+            "unit": "samples/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(elapsed / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
+            "config": {"workload": "MM_RCA --reverse ViT-B/16 + DistilBERT, " + ("frozen-backbone" if args.frozen else "fine-tune")
+                       + " train step (fwd+loss+bwd+allreduce+SGD), 224x224 images, 64-token captions",
+                       "per_gpu_batch": B, "global_batch": B * world, "seq_len": S, "image": 224, "parallelism": f"dp{world}",
+                       "optimizer": "sgd lr=1e-3 wd=1e-2", "random_init": True, "final_loss": round(final_loss, 4)},
+            "roofline": {"bound": "mfma", "achieved": round(achieved, 2), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
+                         "frac": round(achieved / PEAK_BF16_TFLOPS, 4), "traffic": None,
+                         "kernel": "gemm_mfma_k (bf16 16x16x32 MFMA GEMM; all nn.Linear fwd/dgrad/wgrad)",
+                         "launches": len(prof), "gemm_ms_per_step": round(ms / args.steps, 3),
+                         "by_layout_TFLOPs": {f"a{k[0]}b{k[1]}acc{k[2]}": round(v[0] / (v[1] * 1e-3) / 1e12, 1) for k, v in by_kind.items() if v[1] > 0},
+                         "whole_step_model_TFLOPs": round(value / world * train_flop_per_sample / 1e12, 2),
+                         "whole_step_frac": round(value / world * train_flop_per_sample / 1e12 / PEAK_BF16_TFLOPS, 4)},
+        }
+        if not args.no_cpu_baseline and world == 1:
+            out["cpu_baseline"] = cpu_baseline()
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

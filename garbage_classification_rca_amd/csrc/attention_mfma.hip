@@ -1,6 +1,372 @@
-// K3 (fast path): fused multi-head attention with MFMA.  Placeholder until the kernel lands: reports "not qualified"
-// so that the dispatcher uses the reference-grade kernels.
+// K3 (fast path): fused multi-head attention on v_mfma_f32_16x16x32_bf16, head dim 64, bf16 in/out, fp32 softmax.
+//
+// One workgroup (4 waves) per (batch, head).  The two [S,64] operands that every wave re-reads are staged once in
+// LDS (128-B rows); scores, probabilities and their gradients never leave registers:
+//   * the score tile is computed TRANSPOSED, S^T = K Q^T (keys on MFMA rows, queries on lanes), so a query's whole row
+//     of the softmax lives in one lane column: the row max / sum are register reductions plus two lane shuffles, and
+//     the fp32 accumulator registers ARE the next MFMA's B operand (P^T for O^T = V^T P^T) after a bf16 pack --
+//     no LDS round trip for P.  The contraction order inside a 32-key step is permuted by that reuse
+//     (key = 32u + 16(j>>2) + 4g + (j&3) for element j of lane group g); the V^T operand is fetched in the same order
+//     with ds_read_b64_tr_b16 (hardware-transposed LDS read of row-major V).
+//   * LDS images: "ROW" = 16-B chunks XOR (row>>1)&7 (conflict-free ds_read_b128 fragment reads);
+//                 "TR"  = 32-B granules XOR (row>>1)&3 (conflict-free transposed reads, 2-way on row reads).
+//   * backward = two kernels that recompute P from the saved log-sum-exp: dQ (a wave owns 16 queries, sweeps keys) and
+//     dK/dV (a wave owns 16 keys, sweeps queries); no atomics, no fp32 scratch in HBM.
+// Masked keys get -inf; a query whose keys are all masked outputs zeros and lse=+inf (torch SDPA semantics).
 #include "common.h"
-bool mmrca_mha_mfma_ok(int S, int dh, int dtype) { (void)S; (void)dh; (void)dtype; return false; }
-int mmrca_mha_fwd_mfma(const void*, const int32_t*, void*, float*, int, int, int, int, float, hipStream_t) { return mmrca_fail(-3, "mha mfma: not built"); }
-int mmrca_mha_bwd_mfma(const void*, const int32_t*, const void*, const void*, const float*, void*, int, int, int, int, float, hipStream_t) { return mmrca_fail(-3, "mha mfma: not built"); }
+
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+typedef __attribute__((address_space(3))) bf16x4 lds_bf16x4;
+
+#define AT_DH 64
+#define AT_MAX_S 512
+#define AT_MAXKT (AT_MAX_S / 16)
+
+enum { IMG_ROW = 0, IMG_TR = 1 };
+
+__device__ __forceinline__ int img_off(int mode, int row, int c /*16-B chunk 0..7*/) {
+  if (mode == IMG_ROW) return row * 128 + ((c ^ ((row >> 1) & 7)) << 4);
+  return row * 128 + ((((c >> 1) ^ ((row >> 1) & 3)) << 5) | ((c & 1) << 4));
+}
+
+// stage rows [0,S) of a [S, ld] slice (64 bf16 per row) into an LDS image, zero-filling rows [S, Spad)
+__device__ __forceinline__ void stage_rows(char* img, int mode, const bf16_t* __restrict__ src, int64_t ld, int S, int Spad) {
+  for (int idx = threadIdx.x; idx < Spad * 8; idx += blockDim.x) {
+    const int row = idx >> 3, c = idx & 7;
+    uint4 v = make_uint4(0, 0, 0, 0);
+    if (row < S) v = *reinterpret_cast<const uint4*>(src + (int64_t)row * ld + c * 8);
+    *reinterpret_cast<uint4*>(img + img_off(mode, row, c)) = v;
+  }
+}
+
+// A-role fragment, rows rb..rb+15 of an image, contraction = the 64 columns (k-step ks of 32)
+__device__ __forceinline__ bf16x8 frag_rows(const char* img, int mode, int rb, int ks, int lane) {
+  const int r = rb + (lane & 15), c = 4 * ks + (lane >> 4);
+  return *reinterpret_cast<const bf16x8*>(img + img_off(mode, r, c));
+}
+
+// A-role fragment of the TRANSPOSED image: D-rows = columns 16dt..16dt+15, contraction = image rows in the permuted
+// order  row(j) = 32u + 16(j>>2) + 4g + (j&3)
+__device__ __forceinline__ bf16x8 frag_cols_tr(const char* img, int u, int dt, int lane) {
+  const int g = lane >> 4, i = lane & 15, q = i >> 2, p = i & 3;
+  const int r0 = 32 * u + 4 * g + q, r1 = r0 + 16;
+  const int o0 = r0 * 128 + ((dt ^ ((r0 >> 1) & 3)) << 5) + 8 * p;
+  const int o1 = r1 * 128 + ((dt ^ ((r1 >> 1) & 3)) << 5) + 8 * p;
+  bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4*)(img + o0));
+  bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4*)(img + o1));
+  bf16x8 r;
+  r[0] = lo[0]; r[1] = lo[1]; r[2] = lo[2]; r[3] = lo[3]; r[4] = hi[0]; r[5] = hi[1]; r[6] = hi[2]; r[7] = hi[3];
+  return r;
+}
+
+// B-role fragment straight from HBM: lane (i = lane&15, g) holds row (row0+i) columns 32ks+8g .. +7
+__device__ __forceinline__ bf16x8 frag_global(const bf16_t* __restrict__ base, int64_t ld, int row0, int S, int ks, int lane) {
+  int r = row0 + (lane & 15);
+  if (r > S - 1) r = S - 1;
+  return *reinterpret_cast<const bf16x8*>(base + (int64_t)r * ld + 32 * ks + 8 * (lane >> 4));
+}
+
+__device__ __forceinline__ bf16x8 pack_pair(const f32x4& a, const f32x4& b) {
+  bf16x8 r;
+  r[0] = (bf16_t)a[0]; r[1] = (bf16_t)a[1]; r[2] = (bf16_t)a[2]; r[3] = (bf16_t)a[3];
+  r[4] = (bf16_t)b[0]; r[5] = (bf16_t)b[1]; r[6] = (bf16_t)b[2]; r[7] = (bf16_t)b[3];
+  return r;
+}
+
+__device__ __forceinline__ float colgroup_max(float x) { x = fmaxf(x, __shfl_xor(x, 16, 64)); return fmaxf(x, __shfl_xor(x, 32, 64)); }
+__device__ __forceinline__ float colgroup_sum(float x) { x += __shfl_xor(x, 16, 64); return x + __shfl_xor(x, 32, 64); }
+
+// ------------------------------------------------------------------------------------------------------
+// forward
+// ------------------------------------------------------------------------------------------------------
+template <int NKT>     // key tiles of 16 (Spad = 16*NKT, NKT even)
+__global__ void __launch_bounds__(256)
+mha_fwd_mfma_k(const bf16_t* __restrict__ qkv, const int32_t* __restrict__ key_mask, bf16_t* __restrict__ out,
+               float* __restrict__ lse, int H, int S, float scale) {
+  extern __shared__ __attribute__((aligned(16))) char sm[];
+  constexpr int Spad = NKT * 16;
+  char* Kimg = sm; char* Vimg = sm + Spad * 128;
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, g = lane >> 4, l16 = lane & 15;
+  const int b = blockIdx.x / H, h = blockIdx.x % H;
+  const int64_t ld = 3LL * H * AT_DH;
+  const bf16_t* Q = qkv + (int64_t)b * S * ld + h * AT_DH;
+  const bf16_t* Kp = Q + H * AT_DH;
+  const bf16_t* Vp = Kp + H * AT_DH;
+  stage_rows(Kimg, IMG_ROW, Kp, ld, S, Spad);
+  stage_rows(Vimg, IMG_TR, Vp, ld, S, Spad);
+  __syncthreads();
+  // per-lane key validity bits for keys 16kt + 4g + r
+  const int nqt = (S + 15) / 16;
+  for (int qt = wave; qt < nqt; qt += 4) {
+    const int q0 = qt * 16;
+    bf16x8 qf0 = frag_global(Q, ld, q0, S, 0, lane), qf1 = frag_global(Q, ld, q0, S, 1, lane);
+    f32x4 s[NKT];
+#pragma unroll
+    for (int kt = 0; kt < NKT; ++kt) {
+      f32x4 a = {0.f, 0.f, 0.f, 0.f};
+      a = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_rows(Kimg, IMG_ROW, kt * 16, 0, lane), qf0, a, 0, 0, 0);
+      a = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_rows(Kimg, IMG_ROW, kt * 16, 1, lane), qf1, a, 0, 0, 0);
+      s[kt] = a;
+    }
+    float m = -INFINITY;
+#pragma unroll
+    for (int kt = 0; kt < NKT; ++kt) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int key = kt * 16 + 4 * g + r;
+        const bool ok = key < S && (!key_mask || key_mask[b * S + key] != 0);
+        const float v = ok ? s[kt][r] * scale : -INFINITY;
+        s[kt][r] = v;
+        m = fmaxf(m, v);
+      }
+    }
+    m = colgroup_max(m);
+    float l = 0.f;
+    const float msafe = m > -INFINITY ? m : 0.f;
+#pragma unroll
+    for (int kt = 0; kt < NKT; ++kt)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) { const float e = __expf(s[kt][r] - msafe); s[kt][r] = e; l += e; }
+    l = colgroup_sum(l);
+    f32x4 o[4];
+#pragma unroll
+    for (int dt = 0; dt < 4; ++dt) o[dt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int u = 0; u < NKT / 2; ++u) {
+      const bf16x8 pf = pack_pair(s[2 * u], s[2 * u + 1]);
+#pragma unroll
+      for (int dt = 0; dt < 4; ++dt)
+        o[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_cols_tr(Vimg, u, dt, lane), pf, o[dt], 0, 0, 0);   // O^T[d][q]
+    }
+    const int q = q0 + l16;
+    if (q < S) {
+      const float inv = l > 0.f ? 1.f / l : 0.f;
+      bf16_t* orow = out + ((int64_t)b * S + q) * (H * AT_DH) + h * AT_DH;
+#pragma unroll
+      for (int dt = 0; dt < 4; ++dt) {
+        bf16x4 v;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) v[r] = (bf16_t)(o[dt][r] * inv);
+        *reinterpret_cast<bf16x4*>(orow + dt * 16 + 4 * g) = v;
+      }
+      if (g == 0) lse[((int64_t)b * H + h) * S + q] = l > 0.f ? m + __logf(l) : INFINITY;
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------------
+// backward, dQ: a wave owns 16 queries
+// ------------------------------------------------------------------------------------------------------
+template <int NKT>
+__global__ void __launch_bounds__(256)
+mha_bwd_dq_mfma_k(const bf16_t* __restrict__ qkv, const int32_t* __restrict__ key_mask, const bf16_t* __restrict__ out,
+                  const bf16_t* __restrict__ dout, const float* __restrict__ lse, bf16_t* __restrict__ dqkv,
+                  int H, int S, float scale) {
+  extern __shared__ __attribute__((aligned(16))) char sm[];
+  constexpr int Spad = NKT * 16;
+  char* Kimg = sm; char* Vimg = sm + Spad * 128;
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, g = lane >> 4, l16 = lane & 15;
+  const int b = blockIdx.x / H, h = blockIdx.x % H;
+  const int64_t ld = 3LL * H * AT_DH, ldo = (int64_t)H * AT_DH;
+  const bf16_t* Q = qkv + (int64_t)b * S * ld + h * AT_DH;
+  const bf16_t* Kp = Q + H * AT_DH;
+  const bf16_t* Vp = Kp + H * AT_DH;
+  const bf16_t* O = out + (int64_t)b * S * ldo + h * AT_DH;
+  const bf16_t* dO = dout + (int64_t)b * S * ldo + h * AT_DH;
+  stage_rows(Kimg, IMG_TR, Kp, ld, S, Spad);      // row reads for S^T (2-way), transposed reads for dQ^T
+  stage_rows(Vimg, IMG_ROW, Vp, ld, S, Spad);     // row reads for dP^T
+  __syncthreads();
+  const int nqt = (S + 15) / 16;
+  for (int qt = wave; qt < nqt; qt += 4) {
+    const int q0 = qt * 16;
+    const int q = q0 + l16;
+    const bf16x8 qf0 = frag_global(Q, ld, q0, S, 0, lane), qf1 = frag_global(Q, ld, q0, S, 1, lane);
+    const bf16x8 df0 = frag_global(dO, ldo, q0, S, 0, lane), df1 = frag_global(dO, ldo, q0, S, 1, lane);
+    const bf16x8 of0 = frag_global(O, ldo, q0, S, 0, lane), of1 = frag_global(O, ldo, q0, S, 1, lane);
+    float dsum = 0.f;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) dsum += (float)df0[j] * (float)of0[j] + (float)df1[j] * (float)of1[j];
+    dsum = colgroup_sum(dsum);                       // D_q = rowsum(dO * O)
+    const float L = lse[((int64_t)b * H + h) * S + (q < S ? q : S - 1)];
+    f32x4 dq[4];
+#pragma unroll
+    for (int dt = 0; dt < 4; ++dt) dq[dt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int u = 0; u < NKT / 2; ++u) {
+      f32x4 ds2[2];
+#pragma unroll
+      for (int hh = 0; hh < 2; ++hh) {
+        const int kt = 2 * u + hh;
+        f32x4 s = {0.f, 0.f, 0.f, 0.f}, dp = {0.f, 0.f, 0.f, 0.f};
+        s = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_rows(Kimg, IMG_TR, kt * 16, 0, lane), qf0, s, 0, 0, 0);
+        s = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_rows(Kimg, IMG_TR, kt * 16, 1, lane), qf1, s, 0, 0, 0);
+        dp = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_rows(Vimg, IMG_ROW, kt * 16, 0, lane), df0, dp, 0, 0, 0);
+        dp = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_rows(Vimg, IMG_ROW, kt * 16, 1, lane), df1, dp, 0, 0, 0);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int key = kt * 16 + 4 * g + r;
+          const bool ok = key < S && (!key_mask || key_mask[b * S + key] != 0);
+          const float p = ok ? __expf(s[r] * scale - L) : 0.f;
+          ds2[hh][r] = p * (dp[r] - dsum) * scale;
+        }
+      }
+      const bf16x8 dsf = pack_pair(ds2[0], ds2[1]);
+#pragma unroll
+      for (int dt = 0; dt < 4; ++dt)
+        dq[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_cols_tr(Kimg, u, dt, lane), dsf, dq[dt], 0, 0, 0);   // dQ^T[d][q]
+    }
+    if (q < S) {
+      bf16_t* drow = dqkv + ((int64_t)b * S + q) * ld + h * AT_DH;
+#pragma unroll
+      for (int dt = 0; dt < 4; ++dt) {
+        bf16x4 v;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) v[r] = (bf16_t)dq[dt][r];
+        *reinterpret_cast<bf16x4*>(drow + dt * 16 + 4 * g) = v;
+      }
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------------
+// backward, dK/dV: a wave owns 16 keys
+// ------------------------------------------------------------------------------------------------------
+template <int NKT>
+__global__ void __launch_bounds__(256)
+mha_bwd_dkv_mfma_k(const bf16_t* __restrict__ qkv, const int32_t* __restrict__ key_mask, const bf16_t* __restrict__ out,
+                   const bf16_t* __restrict__ dout, const float* __restrict__ lse, bf16_t* __restrict__ dqkv,
+                   int H, int S, float scale) {
+  extern __shared__ __attribute__((aligned(16))) char sm[];
+  constexpr int Spad = NKT * 16;
+  char* Qimg = sm; char* Dimg = sm + Spad * 128;
+  float* lse_s = reinterpret_cast<float*>(sm + 2 * Spad * 128);
+  float* dsum_s = lse_s + Spad;
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, g = lane >> 4, l16 = lane & 15;
+  const int b = blockIdx.x / H, h = blockIdx.x % H;
+  const int64_t ld = 3LL * H * AT_DH, ldo = (int64_t)H * AT_DH;
+  const bf16_t* Q = qkv + (int64_t)b * S * ld + h * AT_DH;
+  const bf16_t* Kp = Q + H * AT_DH;
+  const bf16_t* Vp = Kp + H * AT_DH;
+  const bf16_t* O = out + (int64_t)b * S * ldo + h * AT_DH;
+  const bf16_t* dO = dout + (int64_t)b * S * ldo + h * AT_DH;
+  stage_rows(Qimg, IMG_TR, Q, ld, S, Spad);
+  stage_rows(Dimg, IMG_TR, dO, ldo, S, Spad);
+  for (int q = threadIdx.x; q < Spad; q += blockDim.x) {
+    float a = 0.f, L = INFINITY;                 // padded query rows: lse=+inf -> P = 0
+    if (q < S) {
+      L = lse[((int64_t)b * H + h) * S + q];
+#pragma unroll
+      for (int c = 0; c < 8; ++c) {
+        const bf16x8 x = *reinterpret_cast<const bf16x8*>(dO + (int64_t)q * ldo + c * 8);
+        const bf16x8 y = *reinterpret_cast<const bf16x8*>(O + (int64_t)q * ldo + c * 8);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) a += (float)x[j] * (float)y[j];
+      }
+    }
+    lse_s[q] = L; dsum_s[q] = a;
+  }
+  __syncthreads();
+  const int nkt = (S + 15) / 16;
+  for (int kt = wave; kt < nkt; kt += 4) {
+    const int k0 = kt * 16;
+    const int key = k0 + l16;
+    const bool key_ok = key < S && (!key_mask || key_mask[b * S + key] != 0);
+    const bf16x8 kf0 = frag_global(Kp, ld, k0, S, 0, lane), kf1 = frag_global(Kp, ld, k0, S, 1, lane);
+    const bf16x8 vf0 = frag_global(Vp, ld, k0, S, 0, lane), vf1 = frag_global(Vp, ld, k0, S, 1, lane);
+    f32x4 dk[4], dv[4];
+#pragma unroll
+    for (int dt = 0; dt < 4; ++dt) { dk[dt] = (f32x4){0.f, 0.f, 0.f, 0.f}; dv[dt] = (f32x4){0.f, 0.f, 0.f, 0.f}; }
+#pragma unroll
+    for (int u = 0; u < NKT / 2; ++u) {
+      f32x4 p2[2], ds2[2];
+#pragma unroll
+      for (int hh = 0; hh < 2; ++hh) {
+        const int qt = 2 * u + hh;
+        f32x4 s = {0.f, 0.f, 0.f, 0.f}, dp = {0.f, 0.f, 0.f, 0.f};
+        s = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_rows(Qimg, IMG_TR, qt * 16, 0, lane), kf0, s, 0, 0, 0);    // S[q][key]
+        s = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_rows(Qimg, IMG_TR, qt * 16, 1, lane), kf1, s, 0, 0, 0);
+        dp = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_rows(Dimg, IMG_TR, qt * 16, 0, lane), vf0, dp, 0, 0, 0);  // dP[q][key]
+        dp = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_rows(Dimg, IMG_TR, qt * 16, 1, lane), vf1, dp, 0, 0, 0);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int q = qt * 16 + 4 * g + r;
+          const float p = key_ok ? __expf(s[r] * scale - lse_s[q]) : 0.f;
+          p2[hh][r] = p;
+          ds2[hh][r] = p * (dp[r] - dsum_s[q]) * scale;
+        }
+      }
+      const bf16x8 pf = pack_pair(p2[0], p2[1]), dsf = pack_pair(ds2[0], ds2[1]);
+#pragma unroll
+      for (int dt = 0; dt < 4; ++dt) {
+        dv[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_cols_tr(Dimg, u, dt, lane), pf, dv[dt], 0, 0, 0);    // dV^T[d][key]
+        dk[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_cols_tr(Qimg, u, dt, lane), dsf, dk[dt], 0, 0, 0);   // dK^T[d][key]
+      }
+    }
+    if (key < S) {
+      bf16_t* krow = dqkv + ((int64_t)b * S + key) * ld + (int64_t)H * AT_DH + h * AT_DH;
+      bf16_t* vrow = krow + (int64_t)H * AT_DH;
+#pragma unroll
+      for (int dt = 0; dt < 4; ++dt) {
+        bf16x4 a, c;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) { a[r] = (bf16_t)dk[dt][r]; c[r] = (bf16_t)dv[dt][r]; }
+        *reinterpret_cast<bf16x4*>(krow + dt * 16 + 4 * g) = a;
+        *reinterpret_cast<bf16x4*>(vrow + dt * 16 + 4 * g) = c;
+      }
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------------
+// host side
+// ------------------------------------------------------------------------------------------------------
+bool mmrca_mha_mfma_ok(int S, int dh, int dtype) { return dtype == MMRCA_BF16 && dh == AT_DH && S >= 1 && S <= AT_MAX_S; }
+
+static int pick_nkt(int S) {
+  const int need = (S + 31) / 32 * 2;            // key tiles, even
+  const int opts[] = {2, 4, 8, 14, 16, 32};
+  for (int o : opts) if (o >= need) return o;
+  return 32;
+}
+
+#define AT_LAUNCH(KERNEL, NKT, LDSBYTES, ...)                                                                        \
+  do {                                                                                                               \
+    (void)hipFuncSetAttribute((const void*)KERNEL<NKT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(LDSBYTES)); \
+    hipLaunchKernelGGL(KERNEL<NKT>, dim3(B * H), dim3(256), LDSBYTES, st, __VA_ARGS__);                               \
+  } while (0)
+
+#define AT_SWITCH(KERNEL, EXTRA, ...)                                                     \
+  switch (nkt) {                                                                           \
+    case 2: AT_LAUNCH(KERNEL, 2, 2 * 2 * 16 * 128 + EXTRA(2), __VA_ARGS__); break;         \
+    case 4: AT_LAUNCH(KERNEL, 4, 2 * 4 * 16 * 128 + EXTRA(4), __VA_ARGS__); break;         \
+    case 8: AT_LAUNCH(KERNEL, 8, 2 * 8 * 16 * 128 + EXTRA(8), __VA_ARGS__); break;         \
+    case 14: AT_LAUNCH(KERNEL, 14, 2 * 14 * 16 * 128 + EXTRA(14), __VA_ARGS__); break;     \
+    case 16: AT_LAUNCH(KERNEL, 16, 2 * 16 * 16 * 128 + EXTRA(16), __VA_ARGS__); break;     \
+    default: AT_LAUNCH(KERNEL, 32, 2 * 32 * 16 * 128 + EXTRA(32), __VA_ARGS__); break;     \
+  }
+#define NO_EXTRA(n) 0
+#define STAT_EXTRA(n) (2 * (n) * 16 * 4)
+
+int mmrca_mha_fwd_mfma(const void* qkv, const int32_t* key_mask, void* out, float* lse, int B, int H, int S, int dh,
+                       float scale, hipStream_t st) {
+  (void)dh;
+  MMRCA_REQUIRE((((uintptr_t)qkv) & 15) == 0 && (((uintptr_t)out) & 7) == 0, "mha_fwd: qkv must be 16-byte aligned");
+  const int nkt = pick_nkt(S);
+  AT_SWITCH(mha_fwd_mfma_k, NO_EXTRA, (const bf16_t*)qkv, key_mask, (bf16_t*)out, lse, H, S, scale);
+  MMRCA_CHECK_LAUNCH("mha_fwd(mfma)");
+  return 0;
+}
+
+int mmrca_mha_bwd_mfma(const void* qkv, const int32_t* key_mask, const void* out, const void* dout, const float* lse,
+                       void* dqkv, int B, int H, int S, int dh, float scale, hipStream_t st) {
+  (void)dh;
+  MMRCA_REQUIRE((((uintptr_t)qkv) & 15) == 0 && (((uintptr_t)out) & 15) == 0 && (((uintptr_t)dout) & 15) == 0 && (((uintptr_t)dqkv) & 7) == 0,
+                "mha_bwd: buffers must be 16-byte aligned");
+  const int nkt = pick_nkt(S);
+  AT_SWITCH(mha_bwd_dq_mfma_k, NO_EXTRA, (const bf16_t*)qkv, key_mask, (const bf16_t*)out, (const bf16_t*)dout, lse, (bf16_t*)dqkv, H, S, scale);
+  AT_SWITCH(mha_bwd_dkv_mfma_k, STAT_EXTRA, (const bf16_t*)qkv, key_mask, (const bf16_t*)out, (const bf16_t*)dout, lse, (bf16_t*)dqkv, H, S, scale);
+  MMRCA_CHECK_LAUNCH("mha_bwd(mfma)");
+  return 0;
+}

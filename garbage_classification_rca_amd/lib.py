@@ -120,11 +120,25 @@ def _dev(t: torch.Tensor, name: str):
 # ---------------------------------------------------------------------------------------------------------
 # thin typed wrappers (raw pointers in, nothing allocated)
 # ---------------------------------------------------------------------------------------------------------
+GEMM_PROFILE = None     # bench.py sets this to a list: every MFMA-qualified GEMM launch is bracketed by HIP events
+
+
+def gemm_is_mfma(M, N, K, a_layout, dtype, impl):
+    return dtype == BF16 and impl != IMPL_REF and N % 128 == 0 and K % 64 == 0 and (a_layout == ROWK or M % 128 == 0)
+
+
 def gemm(A, B, Cout, *, bias=None, addend=None, preact=None, M, N, K, lda, ldb, ldc, a_layout=ROWK, b_layout=ROWK,
          act=ACT_NONE, accum=False, dtype, impl=IMPL_AUTO):
     _dev(A, "gemm A")
+    prof = GEMM_PROFILE is not None and gemm_is_mfma(M, N, K, a_layout, dtype, impl)
+    if prof:
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
     _check(load().mmrca_gemm(ptr(A), ptr(B), ptr(Cout), ptr(bias), ptr(addend), ptr(preact), M, N, K, lda, ldb, ldc,
                              a_layout, b_layout, act, int(accum), dtype, impl, stream_ptr()), "mmrca_gemm")
+    if prof:
+        e1.record()
+        GEMM_PROFILE.append((2.0 * M * N * K, (a_layout, b_layout, int(accum)), e0, e1))
 
 
 def colsum_accum(dY, db, M, N, ld, dtype):

@@ -1,0 +1,150 @@
+"""The training hot loop: restatement of ``run_one_epoch`` / ``calculate_set_accuracy`` (main_both.py:81-198) over the
+HIP module, plus the fused single-step form the benchmark times.
+
+Quirks of the reference that change results and are reproduced on purpose:
+  (i)  ``loss.backward()`` runs BEFORE ``loss = loss / acc_steps`` (main_both.py:112-114): gradients of the
+       ``acc_steps`` micro-batches are SUMMED, only the logged loss is scaled;
+  (ii) the optimizer steps every ``acc_steps`` batches or on the last batch; ``acc_steps == 0`` steps every batch;
+  (iii) the per-batch loss is brought to the host every batch (``loss.cpu()``, :128).
+"""
+from __future__ import annotations
+
+import math
+from typing import List, Optional, Sequence
+
+import torch
+
+from . import lib as L
+
+mode_config_dict = {      # main_both.py:43-47
+    'image_only': {"remove_text": True, "remove_image": False},
+    'text_only': {"remove_text": False, "remove_image": True},
+    'both': {"remove_text": False, "remove_image": False},
+}
+
+
+def get_class_weights_from_counts(counts: Sequence[int]) -> List[float]:
+    """w_c = N_total / (n_classes * n_c)   (main_both.py:61-78)."""
+    total = float(sum(counts))
+    return [total / (len(counts) * c) for c in counts]
+
+
+class FusedCrossEntropy:
+    """torch.nn.CrossEntropyLoss(weight, label_smoothing) (main_both.py:87-93) as one HIP kernel that also emits
+    d loss / d logits, so the step needs no autograd graph."""
+
+    def __init__(self, weight: Optional[torch.Tensor] = None, label_smoothing: float = 0.0):
+        self.weight, self.label_smoothing = weight, float(label_smoothing)
+
+    def __call__(self, logits: torch.Tensor, labels: torch.Tensor):
+        B, C = logits.shape
+        loss = torch.empty(1, dtype=torch.float32, device=logits.device)
+        dlogits = torch.empty_like(logits)
+        L.xent_fwd_bwd(logits, labels.to(torch.int32), self.weight, self.label_smoothing, loss, dlogits, B, C, 1.0)
+        return loss, dlogits
+
+
+def hip_train_step(model, ids, mask, images, labels, criterion: FusedCrossEntropy, optimizer=None, grad_sync=None,
+                   do_step: bool = True):
+    """forward -> loss -> backward (-> gradient all-reduce) -> optimizer step -> zero grads, all on the current
+    stream without a host sync.  Returns the device loss tensor."""
+    eng = model.engine
+    model._images, model._input_ids, model._attention_mask = images, ids, mask
+    model.drop_modalities(False, False, False)
+    tt, ti = model._train_flags()
+    model._fwd_count += 1
+    logits = eng.forward(model._input_ids, model._attention_mask, model._images,
+                         model.drop_ratio if model.training else 0.0, model._drop_seed + model._fwd_count, save=(tt or ti))
+    loss, dlogits = criterion(logits, labels)
+    if grad_sync is not None:
+        grad_sync.enabled = bool(do_step)
+    eng.grad_sync = grad_sync
+    eng.backward(dlogits, train_text=tt, train_image=ti)
+    if do_step and optimizer is not None:
+        if grad_sync is not None:
+            grad_sync.finish()
+        optimizer.step()
+        optimizer.zero_grad()
+    return loss
+
+
+def run_one_epoch(epoch_num, model, data_loader, len_train_data, hw_device, batch_size, train_optimizer, weights,
+                  use_class_weights, acc_steps, smoothing, grad_sync=None, verbose=True):
+    """main_both.py:81-134 (same argument order).  Works with any model exposing the MM_RCA forward; with the HIP
+    module the criterion is the fused kernel and the backward is the engine's."""
+    batch_loss = []
+    n_batches = math.ceil(len_train_data / batch_size)
+    fused = hasattr(model, "engine")
+    if use_class_weights:
+        opt_weights = torch.tensor(weights, dtype=torch.float32, device=hw_device)     # (.cuda() in the reference, :89)
+    else:
+        opt_weights = None
+    if fused:
+        criterion = FusedCrossEntropy(opt_weights, smoothing)
+    else:
+        criterion = torch.nn.CrossEntropyLoss(weight=opt_weights, label_smoothing=smoothing).to(hw_device)
+    n_loader = len(data_loader)
+    for batch_idx, (data, labels) in enumerate(data_loader):
+        images = data['image']['raw_image'].to(hw_device, non_blocking=True)
+        texts = data['text']
+        ids = texts['tokens'].to(hw_device, non_blocking=True)
+        mask = texts['attention_mask'].to(hw_device, non_blocking=True)
+        labels = labels.to(hw_device, non_blocking=True)
+        if acc_steps != 0:
+            do_step = ((batch_idx + 1) % acc_steps == 0) or (batch_idx + 1 == n_loader)
+        else:
+            do_step = True
+        if fused:
+            loss = hip_train_step(model, ids, mask, images, labels, criterion, train_optimizer, grad_sync, do_step)[0]
+        else:
+            out = model(_input_ids=ids, _attention_mask=mask, _images=images)
+            loss = criterion(out, labels)
+            loss.backward()
+            if do_step:
+                train_optimizer.step()
+                train_optimizer.zero_grad()
+        if acc_steps != 0:
+            loss = loss / acc_steps            # logged value only (:114)
+        if verbose:
+            if do_step and acc_steps != 0:
+                print("Optimizer step on batch idx: {}".format(batch_idx))
+            print("Batch {}/{} on epoch {}".format(batch_idx, n_batches, epoch_num))
+        batch_loss.append(loss.detach().cpu())
+    return n_batches, batch_loss
+
+
+def calculate_set_accuracy(model, data_loader, len_data, device, batch_size, mode, eval_mode, verbose=True,
+                           all_reduce=None):
+    """main_both.py:141-198.  Returns (accuracy %, sklearn classification report dict)."""
+    n_batches = math.ceil(len_data / batch_size)
+    all_labels, all_predictions = [], []
+    correct = 0
+    with torch.no_grad():
+        for batch_idx, (data, labels) in enumerate(data_loader):
+            images = data['image']['raw_image'].to(device)
+            texts = data['text']
+            ids, mask = texts['tokens'].to(device), texts['attention_mask'].to(device)
+            labels = labels.to(device)
+            outputs = model(_input_ids=ids, _attention_mask=mask, _images=images, eval=eval_mode,
+                            remove_text=mode["remove_text"], remove_image=mode["remove_image"])
+            pred = torch.max(outputs, 1)[1].view(-1)
+            correct += torch.sum(torch.eq(pred, labels)).item()
+            if verbose:
+                print("Batches {}/{} ".format(batch_idx, n_batches))
+            all_labels.append(labels.cpu())
+            all_predictions.append(pred.cpu())
+    labels_flat = [int(x) for t in all_labels for x in t]
+    preds_flat = [int(x) for t in all_predictions for x in t]
+    count = len_data
+    if all_reduce is not None:
+        correct, count = all_reduce(correct, len(labels_flat), device)
+    try:
+        from sklearn.metrics import classification_report
+        report = classification_report(labels_flat, preds_flat, labels=[0, 1, 2, 3],
+                                       target_names=["black", "blue", "green", "ttr"], output_dict=True, zero_division=0)
+    except Exception:
+        report = {}
+    acc = 100 * (correct / max(count, 1))
+    if verbose:
+        print("Set acc: ", acc)
+    return acc, report
