@@ -1,0 +1,298 @@
+"""Host-side logic on CPU: CLI, dataset, training-loop semantics, sharding, gradient sync (gloo, world_size 2), and
+that the C-ABI library loads and exports every symbol include/mmrca.h declares.  No GPU compute here."""
+import ast
+import ctypes
+import json
+import os
+import re
+import sys
+import tempfile
+
+import numpy as np
+import pytest
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+G = os.path.join(ROOT, "tests", "golden")
+
+from garbage_classification_rca_amd import lib as L                                   # noqa: E402
+from garbage_classification_rca_amd import spec as S                                  # noqa: E402
+from garbage_classification_rca_amd.options import args_parser                        # noqa: E402
+from garbage_classification_rca_amd import CustomImageTextFolder as DS                # noqa: E402
+from garbage_classification_rca_amd import distributed as D                           # noqa: E402
+from garbage_classification_rca_amd.training import run_one_epoch, get_class_weights_from_counts, calculate_set_accuracy, mode_config_dict  # noqa: E402
+
+
+# ------------------------------------------------------------------------------------------------ C ABI
+def test_library_builds_loads_and_exports_every_declared_symbol():
+    if not os.path.exists(L.LIB_PATH):
+        L.build_library()
+    lib = ctypes.CDLL(L.LIB_PATH)
+    hdr = open(os.path.join(ROOT, "include", "mmrca.h")).read()
+    declared = set(re.findall(r"\b(mmrca_[a-z0-9_]+)\s*\(", hdr))
+    assert len(declared) >= 20
+    for name in declared:
+        assert hasattr(lib, name), f"{name} declared in include/mmrca.h but not exported"
+    assert declared == set(L.EXPORTS), declared ^ set(L.EXPORTS)
+    assert L.load().mmrca_version() >= 1
+
+
+def test_product_path_fails_loudly_without_gpu_tensors():
+    L.load()
+    a = torch.zeros(4, 4)
+    with pytest.raises(L.MmrcaError):
+        L.gemm(a, a, a, M=4, N=4, K=4, lda=4, ldb=4, ldc=4, dtype=L.F32)
+    with pytest.raises(L.MmrcaError):
+        L.add_layernorm_fwd(a, None, a, a, None, a, None, None, 4, 4, 4, 4, 1e-5, L.F32)
+    if not torch.cuda.is_available():
+        from garbage_classification_rca_amd.engine import MMRCAEngine
+        with pytest.raises(Exception):
+            MMRCAEngine("distilbert", "transformer_B16")        # no device, no fallback
+
+
+def test_no_product_module_imports_the_oracle():
+    pkg = os.path.join(ROOT, "garbage_classification_rca_amd")
+    for fn in os.listdir(pkg):
+        if fn.endswith(".py"):
+            tree = ast.parse(open(os.path.join(pkg, fn)).read())
+            for node in ast.walk(tree):
+                names = []
+                if isinstance(node, ast.Import):
+                    names = [a.name for a in node.names]
+                elif isinstance(node, ast.ImportFrom):
+                    names = [node.module or ""]
+                assert not any(n == "oracle" or n.startswith("oracle.") for n in names), fn
+
+
+# ------------------------------------------------------------------------------------------------ CLI
+def test_cli_defaults_match_reference_parser():
+    gold = json.load(open(os.path.join(G, "options_goldens.json")))
+    mine = vars(args_parser([]))
+    for k, v in gold["defaults"].items():
+        assert k in mine, k
+        assert mine[k] == v, (k, mine[k], v)
+    ex = vars(args_parser(["--late_fusion=MM_RCA", "--reverse", "--no-tl", "--features_only", "--acc_steps", "3"]))
+    for k, v in gold["example"].items():
+        assert ex[k] == v
+    extra = set(mine) - set(gold["defaults"])
+    assert extra == {"tokens_max_len", "dtype", "synthetic", "num_workers", "seed"}     # additive flags only
+
+
+# ------------------------------------------------------------------------------------------------ dataset
+def _golden_lines():
+    out = {}
+    for ln in open(os.path.join(G, "dataset_goldens.txt")).read().splitlines():
+        parts = ln.split("\t")
+        out.setdefault(parts[0], []).append(parts[1:])
+    return out
+
+
+def _make_tree(td):
+    from PIL import Image
+    files = {"Black": ["chip_bag_12.png", "styrofoam cup.jpg", "notes.txt"], "Blue": ["Pizza_Box_3.png"],
+             "Green": ["banana-peel_001.jpeg", "sub/coffee_grounds.png"], "TTR": ["AA batteries_7.bmp"]}
+    for c, fs in files.items():
+        for f in fs:
+            p = os.path.join(td, c, f)
+            os.makedirs(os.path.dirname(p), exist_ok=True)
+            if f.endswith(".txt"):
+                open(p, "w").write("x")
+            else:
+                Image.new("RGB", (5, 4), (10, 20, 30)).save(p)
+    csvp = os.path.join(td, "desc.csv")
+    open(csvp, "w").write("filename,description\nBlack/chip_bag_12.png,an empty bag of chips\nsub/coffee_grounds.png,used coffee grounds\n")
+    return csvp
+
+
+def test_pre_process_text_known_answers():
+    for src, want in _golden_lines()["KAT"]:
+        assert repr(DS.pre_process_text(ast.literal_eval(src))) == want
+
+
+def test_dataset_listing_matches_reference():
+    gold = _golden_lines()
+    with tempfile.TemporaryDirectory() as td:
+        csvp = _make_tree(td)
+        d = DS.CustomImageTextFolder(td)
+        assert repr(d.classes) == gold["CLASSES"][0][0]
+        assert repr(d.targets) == gold["TARGETS"][0][0]
+        assert repr([len(x) for x in d.per_class]) == gold["PER_CLASS"][0][0]
+        assert len(d) == int(gold["LEN"][0][0]) and d.imgs is d.samples
+        for (s, t), g in zip(d.samples, gold["SAMPLE"]):
+            assert [os.path.relpath(s["image"], td), repr(s["text"]), repr(s["long_text"]), str(t)] == g
+        item, tgt = d[0]
+        assert [repr(sorted(item.keys())), repr(sorted(item["image"].keys())), repr(sorted(item["text"].keys())), str(tgt)] == gold["ITEM0"][0]
+        d2 = DS.CustomImageTextFolder(td, extended_desc=csvp)
+        for (s, t), g in zip(d2.samples, gold["SAMPLE_EXT"]):
+            assert [os.path.relpath(s["image"], td), repr(s["long_text"])] == g
+        assert repr(d2[0][0]["text"]["original_text"]) == gold["ITEM0_EXT"][0][0]
+        # tokenised items and collation
+        from garbage_classification_rca_amd.multimodal_model import HashingTokenizer
+        d3 = DS.CustomImageTextFolder(td, tokens_max_len=12, tokenizer_text=HashingTokenizer(),
+                                      transform=lambda im: torch.zeros(3, 8, 8))
+        batch, labels = next(iter(torch.utils.data.DataLoader(d3, batch_size=3)))
+        assert batch["text"]["tokens"].shape == (3, 12) and batch["text"]["tokens"].dtype == torch.int64
+        assert batch["text"]["attention_mask"].sum(1).tolist() == [4, 4, 4]      # [CLS] w w [SEP]
+        assert batch["image"]["raw_image"].shape == (3, 3, 8, 8) and labels.tolist() == [0, 0, 1]
+        ids, mask = d3.get_tokens("pizza box")
+        assert ids[0] == 101 and ids[3] == 102 and mask.sum() == 4
+
+
+def test_dataset_errors_like_reference():
+    with tempfile.TemporaryDirectory() as td:
+        with pytest.raises(FileNotFoundError):
+            DS.CustomImageTextFolder(td)                      # no class folders
+        os.makedirs(os.path.join(td, "Black"))
+        with pytest.raises(FileNotFoundError):
+            DS.CustomImageTextFolder(td)                      # class without a valid file
+
+
+def test_class_weights_and_synthetic_dataset():
+    assert get_class_weights_from_counts([2, 1, 2, 1]) == [6 / 8, 6 / 4, 6 / 8, 6 / 4]
+    ds = DS.SyntheticImageTextDataset(10, 32, 16)
+    item, t = ds[3]
+    assert item["image"]["raw_image"].shape == (3, 32, 32) and t == 3
+    assert item["text"]["tokens"][0] == 101 and int(item["text"]["attention_mask"].sum()) >= 8
+    assert torch.equal(ds[3][0]["image"]["raw_image"], item["image"]["raw_image"])
+
+
+# ------------------------------------------------------------------------------------------------ training loop
+class _Tiny(torch.nn.Module):
+    def __init__(self):
+        super().__init__()
+        self.fc = torch.nn.Linear(6, 4)
+
+    def forward(self, _input_ids, _attention_mask, _images, eval=False, remove_image=False, remove_text=False):
+        x = _images.flatten(1)[:, :6]
+        if remove_image:
+            x = torch.zeros_like(x)
+        return self.fc(x)
+
+
+def _loader(n, bs):
+    g = torch.Generator().manual_seed(0)
+    xs, ys = torch.randn(n, 3, 2, 1, generator=g), torch.arange(n) % 4
+    items = [({"image": {"raw_image": xs[i], "image_path": str(i)},
+               "text": {"original_text": "", "tokens": torch.zeros(4, dtype=torch.int64), "attention_mask": torch.ones(4, dtype=torch.int64)}}, int(ys[i]))
+             for i in range(n)]
+    return torch.utils.data.DataLoader(items, batch_size=bs), xs, ys
+
+
+@pytest.mark.parametrize("acc_steps", [0, 2, 3])
+def test_run_one_epoch_accumulation_semantics(acc_steps):
+    """Gradients of the micro-batches are SUMMED (backward before the /acc_steps), the step happens every acc_steps
+    batches or on the last one; the logged loss is scaled (main_both.py:112-124)."""
+    torch.manual_seed(0)
+    m, ref = _Tiny(), _Tiny()
+    ref.load_state_dict(m.state_dict())
+    dl, xs, ys = _loader(10, 2)          # 5 batches
+    opt = torch.optim.SGD(m.parameters(), lr=0.1, weight_decay=0.01)
+    nb, losses = run_one_epoch(0, m, dl, 10, "cpu", 2, opt, [1, 1, 1, 1], False, acc_steps, 0.1, verbose=False)
+    assert nb == 5 and len(losses) == 5
+    ropt = torch.optim.SGD(ref.parameters(), lr=0.1, weight_decay=0.01)
+    crit = torch.nn.CrossEntropyLoss(label_smoothing=0.1)
+    logged = []
+    for b in range(5):
+        out = ref(None, None, xs[2 * b:2 * b + 2])
+        loss = crit(out, ys[2 * b:2 * b + 2])
+        loss.backward()
+        step = True if acc_steps == 0 else ((b + 1) % acc_steps == 0 or b == 4)
+        logged.append(loss.item() / (acc_steps if acc_steps else 1))
+        if step:
+            ropt.step(); ropt.zero_grad()
+    for a, b in zip(m.parameters(), ref.parameters()):
+        assert torch.allclose(a, b, atol=1e-6)
+    assert np.allclose([float(l) for l in losses], logged, atol=1e-6)
+
+
+def test_run_one_epoch_class_weights_and_accuracy():
+    torch.manual_seed(1)
+    m = _Tiny()
+    dl, xs, ys = _loader(8, 4)
+    opt = torch.optim.SGD(m.parameters(), lr=0.0)
+    _, losses = run_one_epoch(0, m, dl, 8, "cpu", 4, opt, [0.5, 2.0, 1.0, 1.5], True, 0, 0.0, verbose=False)
+    want = torch.nn.CrossEntropyLoss(weight=torch.tensor([0.5, 2.0, 1.0, 1.5]))(m(None, None, xs[:4]), ys[:4])
+    assert abs(float(losses[0]) - want.item()) < 1e-6
+    acc, rep = calculate_set_accuracy(m, dl, 8, "cpu", 4, mode_config_dict["both"], True, verbose=False)
+    pred = m(None, None, xs).argmax(1)
+    assert abs(acc - 100.0 * float((pred == ys).float().mean())) < 1e-9
+    acc0, _ = calculate_set_accuracy(m, dl, 8, "cpu", 4, mode_config_dict["text_only"], True, verbose=False)
+    assert 0.0 <= acc0 <= 100.0
+
+
+# ------------------------------------------------------------------------------------------------ sharding + gradient sync
+def test_sharded_sampler_partitions_every_index_once():
+    for n, world in [(10, 2), (17, 4), (8, 8), (5, 8)]:
+        seen = []
+        for r in range(world):
+            s = D.ShardedSampler(n, r, world, shuffle=True, seed=3)
+            s.set_epoch(2)
+            idx = s.indices()
+            assert len(idx) == len(s) == -(-n // world)
+            seen += idx
+        assert set(seen) == set(range(n))                     # every sample visited
+        assert len(seen) - n < world                          # padding only to equalise ranks
+    a, b = D.ShardedSampler(10, 0, 2, seed=1), D.ShardedSampler(10, 0, 2, seed=1)
+    a.set_epoch(0); b.set_epoch(1)
+    assert a.indices() != b.indices()
+
+
+def _ddp_worker(rank, world, port, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank))
+    import torch.distributed as dist
+    r, _, w = D.init_from_env("gloo")
+    torch.manual_seed(0)
+    W = torch.randn(4, 6)
+    X, Y = torch.randn(8, 6), torch.arange(8) % 4
+    sampler = D.ShardedSampler(8, r, w, shuffle=False)
+    idx = sampler.indices()
+    Wp = W.clone().requires_grad_(True)
+    torch.nn.functional.cross_entropy(X[idx] @ Wp.t(), Y[idx]).backward()
+    flat = torch.zeros(64)
+    flat[8:32] = Wp.grad.flatten()
+    flat[40:44] = float(r + 1)
+    sync = D.GradSync(flat, w, bucket_bytes=64)
+    # spans become ready from high to low addresses, as during backward; adjacent ones merge into one all-reduce
+    sync.span_ready(40, 64)
+    sync.span_ready(32, 40)
+    sync.span_ready(0, 32, flush=True)
+    sync.finish()
+    q.put((r, flat.clone(), len(sync.pending), sync.bytes_reduced))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_gradient_sync_world2_equals_full_batch_gradient():
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 29600 + os.getpid() % 300
+    procs = [ctx.Process(target=_ddp_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted([q.get(timeout=120) for _ in range(2)], key=lambda t: t[0])
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    torch.manual_seed(0)
+    W = torch.randn(4, 6)
+    X, Y = torch.randn(8, 6), torch.arange(8) % 4
+    Wp = W.clone().requires_grad_(True)
+    torch.nn.functional.cross_entropy(X @ Wp.t(), Y).backward()        # gradient of the mean loss over the global batch
+    for r, flat, pending, nbytes in res:
+        assert torch.allclose(flat[8:32], Wp.grad.flatten(), atol=1e-6)
+        assert torch.allclose(flat[40:44], torch.full((4,), 1.5))
+        assert pending == 0 and nbytes == 64 * 4
+
+
+# ------------------------------------------------------------------------------------------------ inventories
+def test_parameter_inventories():
+    used = S.head_used_params(1280, 768, 4, False, False)
+    assert sum(int(np.prod(s)) for _, s in used) == 94820
+    n_txt = sum(int(np.prod(s)) for _, s in S.text_params(S.TEXT_SPECS["distilbert"]))
+    assert n_txt == 66362880                                               # DistilBertModel parameters
+    n_vit = sum(int(np.prod(s)) for _, s in S.vision_params(S.VISION_SPECS["transformer_B16"]))
+    assert n_vit == 85798656                                               # vit_b_16 without the classification head
+    keys = [k for k, _ in S.head_unused_params(1280, 768, 4, 256, 16, False, False)]
+    for k in ("clip_fc_layer.weight", "logit_scale", "gru_text.weight_ih_l0", "fusion.kernel1", "classifier.bias", "final.weight"):
+        assert k in keys
