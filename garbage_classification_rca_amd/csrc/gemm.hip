@@ -90,6 +90,7 @@ gemm_ref_k(const T* __restrict__ A, const T* __restrict__ B, void* __restrict__ 
 #define GBN 128
 #define GBK 64
 #define TILE_BYTES (128 * 64 * 2)    // one operand tile: 16 KiB in either layout
+#define LDS128_BYTES (128 * (128 * 4 + 16))   // max(2 x (A,B) tiles = 64 KiB, epilogue staging 66 KiB)
 
 typedef __attribute__((address_space(3))) void lds_void;
 typedef const __attribute__((address_space(1))) void gbl_void;
@@ -221,39 +222,52 @@ gemm_mfma_k(const bf16_t* __restrict__ A, const bf16_t* __restrict__ B, void* __
         }
       }
   } else {
+    // bf16 output through LDS (see gemm256.hip): fp32 tile [128][128] with rows padded by 16 B, read back two whole
+    // rows per wave instruction so that every global access is a contiguous 256-byte row segment
     bf16_t* C = (bf16_t*)Cv;
+    constexpr int EP_STRIDE = 128 * 4 + 16;
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      const int64_t m = m_blk + wr * 64 + i * 16 + l16;
-      if (m >= M) continue;
+    for (int i = 0; i < 4; ++i)
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
-        const int64_t n0 = n_blk + wc * 64 + j * 16 + 4 * g;
-        float v[4] = {acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]};
-        if (bias) {
-          bf16x4 b4 = *reinterpret_cast<const bf16x4*>(bias + n0);
+        const int row = wr * 64 + i * 16 + l16, col = wc * 64 + j * 16 + 4 * g;
+        *reinterpret_cast<f32x4*>(smem + row * EP_STRIDE + col * 4) = acc[i][j];
+      }
+    __syncthreads();
+    const int half = lane >> 5, l32 = lane & 31;
+    const int64_t ncol = n_blk + l32 * 4;
+    float bv[4] = {0.f, 0.f, 0.f, 0.f};
+    if (bias) {
+      bf16x4 b4 = *reinterpret_cast<const bf16x4*>(bias + ncol);
 #pragma unroll
-          for (int r = 0; r < 4; ++r) v[r] += (float)b4[r];
-        }
+      for (int r = 0; r < 4; ++r) bv[r] = (float)b4[r];
+    }
+#pragma unroll 4
+    for (int rr = 0; rr < 16; ++rr) {
+      const int row = wave * 32 + rr * 2 + half;
+      const int64_t m = m_blk + row;
+      if (m < M) {
+        const f32x4 c = *reinterpret_cast<const f32x4*>(smem + row * EP_STRIDE + l32 * 16);
+        float v[4] = {c[0] + bv[0], c[1] + bv[1], c[2] + bv[2], c[3] + bv[3]};
         if (preact) {
           bf16x4 o;
 #pragma unroll
           for (int r = 0; r < 4; ++r) o[r] = (bf16_t)v[r];
-          *reinterpret_cast<bf16x4*>(preact + m * ldc + n0) = o;
+          *reinterpret_cast<bf16x4*>(preact + m * ldc + ncol) = o;
         }
         if (act == MMRCA_ACT_GELU) {
 #pragma unroll
           for (int r = 0; r < 4; ++r) v[r] = gelu_f(v[r]);
         }
         if (addend) {
-          bf16x4 a4 = *reinterpret_cast<const bf16x4*>(addend + m * ldc + n0);
+          bf16x4 a4 = *reinterpret_cast<const bf16x4*>(addend + m * ldc + ncol);
 #pragma unroll
           for (int r = 0; r < 4; ++r) v[r] += (float)a4[r];
         }
         bf16x4 o;
 #pragma unroll
         for (int r = 0; r < 4; ++r) o[r] = (bf16_t)v[r];
-        *reinterpret_cast<bf16x4*>(C + m * ldc + n0) = o;
+        *reinterpret_cast<bf16x4*>(C + m * ldc + ncol) = o;
       }
     }
   }
@@ -261,11 +275,17 @@ gemm_mfma_k(const bf16_t* __restrict__ A, const bf16_t* __restrict__ B, void* __
 
 static bool aligned16(const void* p) { return (((uintptr_t)p) & 15) == 0; }
 
+bool mmrca_gemm256_ok(int64_t M, int64_t N, int64_t K, int a_layout);
+int mmrca_gemm256(const void* A, const void* B, void* C, const void* bias, const void* addend, void* preact, int64_t M,
+                  int64_t N, int64_t K, int64_t lda, int64_t ldb, int64_t ldc, int a_layout, int b_layout, int act,
+                  hipStream_t st);
+
 template <bool AK, bool BK2, bool AT>
 static void launch_mfma(const void* A, const void* B, void* C, const void* bias, const void* addend, void* preact,
                         int64_t M, int64_t N, int64_t K, int64_t lda, int64_t ldb, int64_t ldc, int act, int tiles_m,
                         int tiles_n, int ksplits, int64_t ksplit_len, hipStream_t st) {
-  hipLaunchKernelGGL((gemm_mfma_k<AK, BK2, AT>), dim3(tiles_m * tiles_n, ksplits), dim3(256), 4 * TILE_BYTES, st,
+  (void)hipFuncSetAttribute((const void*)gemm_mfma_k<AK, BK2, AT>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS128_BYTES);
+  hipLaunchKernelGGL((gemm_mfma_k<AK, BK2, AT>), dim3(tiles_m * tiles_n, ksplits), dim3(256), LDS128_BYTES, st,
                      (const bf16_t*)A, (const bf16_t*)B, C, (const bf16_t*)bias, (const bf16_t*)addend, (bf16_t*)preact,
                      M, N, K, lda, ldb, ldc, act, tiles_m, tiles_n, ksplit_len);
 }
@@ -285,9 +305,14 @@ extern "C" int mmrca_gemm(const void* A, const void* B, void* C, const void* bia
                  (ldc % 4 == 0) && aligned16(A) && aligned16(B) && aligned16(C) && (!bias || aligned16(bias)) &&
                  (!addend || aligned16(addend)) && (!preact || aligned16(preact)) &&
                  (a_layout == MMRCA_ROWK || M % GBM == 0);
+  const bool ok256 = ok_mfma && !out_f32_accum && mmrca_gemm256_ok(M, N, K, a_layout);
+  if (impl == MMRCA_GEMM_MFMA256 && !ok256)
+    return mmrca_fail(-3, "gemm: shape M=%lld N=%lld K=%lld does not qualify for the 256x256 MFMA kernel", (long long)M, (long long)N, (long long)K);
+  if (ok256 && (impl == MMRCA_GEMM_MFMA256 || (impl == MMRCA_GEMM_AUTO && b_layout == MMRCA_ROWK && N >= 1536 && K <= 1536 && ((M + 255) / 256) * (N / 256) >= 512)))
+    return mmrca_gemm256(A, B, C, bias, addend, preact, M, N, K, lda, ldb, ldc, a_layout, b_layout, act, st);
   if (impl == MMRCA_GEMM_MFMA && !ok_mfma)
     return mmrca_fail(-3, "gemm: shape M=%lld N=%lld K=%lld dtype=%d does not qualify for the MFMA kernel", (long long)M, (long long)N, (long long)K, dtype);
-  const bool use_mfma = ok_mfma && impl != MMRCA_GEMM_REF;
+  const bool use_mfma = ok_mfma && impl != MMRCA_GEMM_REF;   // 128x128 kernel
 
   if (use_mfma) {
     const int tiles_m = (int)((M + GBM - 1) / GBM), tiles_n = (int)(N / GBN);

@@ -18,7 +18,7 @@ LIB_PATH = os.path.join(_HERE, "libmmrca.so")
 F32, BF16 = 0, 1
 ACT_NONE, ACT_GELU = 0, 1
 ROWK, KROW = 0, 1
-IMPL_AUTO, IMPL_REF, IMPL_MFMA = 0, 1, 2
+IMPL_AUTO, IMPL_REF, IMPL_MFMA, IMPL_MFMA256 = 0, 1, 2, 3
 
 HEAD_FIELDS = [f"{blk}_{leaf}" for blk in ("sai", "sat", "c1", "c2")
                for leaf in ("wq", "bq", "wk", "bk", "wv", "bv", "g", "b")] + ["fin_w", "fin_b"]
@@ -67,7 +67,7 @@ _SIGS = {
     "mmrca_adamw_step": [_vp] * 5 + [_i64] + [_f32] * 5 + [_i32, _f32, _vp],
     "mmrca_cast_f32_to_bf16": [_vp, _vp, _i64, _vp],
 }
-EXPORTS = sorted(list(_SIGS) + ["mmrca_last_error", "mmrca_version"])
+EXPORTS = sorted(list(_SIGS) + ["mmrca_last_error", "mmrca_version", "mmrca_debug_set"])
 
 
 def load(build_if_missing: bool = False):

@@ -29,10 +29,12 @@ enum { MMRCA_ACT_NONE = 0, MMRCA_ACT_GELU = 1 };
 /* operand layouts of mmrca_gemm: ROWK = [rows][contraction] (contraction contiguous),
  * KROW = [contraction][rows] (rows contiguous) */
 enum { MMRCA_ROWK = 0, MMRCA_KROW = 1 };
-enum { MMRCA_GEMM_AUTO = 0, MMRCA_GEMM_REF = 1, MMRCA_GEMM_MFMA = 2 };
+enum { MMRCA_GEMM_AUTO = 0, MMRCA_GEMM_REF = 1, MMRCA_GEMM_MFMA = 2 /* 128x128 tiles */, MMRCA_GEMM_MFMA256 = 3 /* 256x256 tiles */ };
 
 const char* mmrca_last_error(void);
 int mmrca_version(void);
+/* timing-only ablation switches for kernel development (0 = normal operation; results are WRONG otherwise) */
+int mmrca_debug_set(int flags);
 
 /* K2. C[M,N] = act(A (.) B + bias[N]) + addend[M,N]      (torch.nn.Linear fwd / dgrad / wgrad:
  * transformers modeling_distilbert.py q_lin/k_lin/v_lin/out_lin/ffn.lin1/lin2, torchvision ViT in_proj/

@@ -118,6 +118,26 @@ def test_gemm_mfma_epilogues_and_wgrad():
     _gemm_case(256, 128, 5000, 1, 1, torch.bfloat16, L.IMPL_MFMA, accum=True)
 
 
+@pytest.mark.parametrize("layouts", [(0, 0), (0, 1), (1, 1), (1, 0)])
+def test_gemm_mfma256_layouts_and_epilogues(layouts):
+    """256x256 tile kernel with loads kept in flight across barriers: exact integers first, then random data with
+    every K-tile count from 1 (tail-only path) upward and a ragged M."""
+    al, bl = layouts
+    M, N, K = 512, 256, 192
+    A = ((torch.arange(M)[:, None] * 7 + torch.arange(K)[None, :] * 3) % 5 - 2.0)
+    B = ((torch.arange(N)[:, None] * 3 + torch.arange(K)[None, :] * 5) % 7 - 3.0)
+    Ad, Bd = dev(A if al == 0 else A.t(), torch.bfloat16), dev(B if bl == 0 else B.t(), torch.bfloat16)
+    Cd = torch.empty(M, N, device="cuda", dtype=torch.bfloat16)
+    L.gemm(Ad, Bd, Cd, M=M, N=N, K=K, lda=Ad.shape[1], ldb=Bd.shape[1], ldc=N, a_layout=al, b_layout=bl, dtype=L.BF16, impl=L.IMPL_MFMA256)
+    torch.cuda.synchronize()
+    assert torch.equal(Cd.float().cpu(), (A @ B.t()).bfloat16().float()), (al, bl)
+    for K in (64, 128, 320, 768):
+        Mr = 768 if al == L.KROW else 700
+        _gemm_case(Mr, 512, K, al, bl, torch.bfloat16, L.IMPL_MFMA256, bias=True)
+    Mr = 768 if al == L.KROW else 1000
+    _gemm_case(Mr, 256, 256, al, bl, torch.bfloat16, L.IMPL_MFMA256, act=L.ACT_GELU, bias=True, addend=True, preact=True)
+
+
 def test_gemm_rejects_bad_arguments():
     a = torch.zeros(4, 4, device="cuda")
     with pytest.raises(L.MmrcaError):

@@ -1,0 +1,57 @@
+#!/usr/bin/env python
+"""Per-shape timing of the MFMA GEMM kernels on the encoder shapes of BASELINE configs[1] (B=256).
+Random operands (zero-filled data reads 15-20% high on this chip), interleaved rounds in one process."""
+import sys, os, json
+import torch
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from garbage_classification_rca_amd import lib as L
+
+M = 50432
+SHAPES = [  # (name, M, N, K, a_layout, b_layout, accum)
+    ("fwd qkv", M, 2304, 768, 0, 0, 0), ("fwd out", M, 768, 768, 0, 0, 0), ("fwd ffn1", M, 3072, 768, 0, 0, 0), ("fwd ffn2", M, 768, 3072, 0, 0, 0),
+    ("dgrad qkv", M, 768, 2304, 0, 1, 0), ("dgrad ffn1", M, 768, 3072, 0, 1, 0), ("dgrad ffn2", M, 3072, 768, 0, 1, 0),
+    ("wgrad qkv", 2304, 768, M, 1, 1, 1), ("wgrad out", 768, 768, M, 1, 1, 1), ("wgrad ffn1", 3072, 768, M, 1, 1, 1), ("wgrad ffn2", 768, 3072, M, 1, 1, 1),
+    ("epi K64", M, 3072, 64, 0, 0, 0), ("epi K128", M, 3072, 128, 0, 0, 0), ("epi K1536", M, 3072, 1536, 0, 0, 0),
+    ("text fwd qkv", 16384, 2304, 768, 0, 0, 0), ("text fwd out", 16384, 768, 768, 0, 0, 0),
+]
+impls = {"mfma128": L.IMPL_MFMA, "mfma256": L.IMPL_MFMA256}
+DBG = [int(x) for x in os.environ.get("MMRCA_DBG", "0").split(",")]
+only = sys.argv[1:] 
+L.load()
+dev = "cuda"
+res = {}
+for name, m, n, k, al, bl, acc in SHAPES:
+    if only and not any(o in name for o in only):
+        continue
+    Mp = (m + 127) // 128 * 128
+    if al == 0:
+        A = torch.randn(Mp, k, device=dev).bfloat16(); lda = k
+    else:
+        A = torch.randn(k, m, device=dev).bfloat16(); lda = m
+    if bl == 0:
+        B = torch.randn(n, k, device=dev).bfloat16(); ldb = k
+    else:
+        B = torch.randn(k, n, device=dev).bfloat16(); ldb = n
+    C = torch.zeros(Mp, n, device=dev, dtype=torch.float32 if acc else torch.bfloat16)
+    bias = None if acc else torch.randn(n, device=dev).bfloat16()
+    row = {}
+    for iname, impl, dbg in [(a, b, 0) for a, b in impls.items()] + [(f"256dbg{d}", L.IMPL_MFMA256, d) for d in DBG if d]:
+        if impl == L.IMPL_MFMA256 and (acc or n % 256 or (al == 1 and m % 256)):
+            continue
+        L.load().mmrca_debug_set(dbg)
+        def run():
+            L.gemm(A, B, C, bias=bias, M=m, N=n, K=k, lda=lda, ldb=ldb, ldc=n, a_layout=al, b_layout=bl, accum=bool(acc), dtype=L.BF16, impl=impl)
+        for _ in range(3):
+            run()
+        torch.cuda.synchronize()
+        best = 1e9
+        for rnd in range(3):
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(10):
+                run()
+            e1.record(); torch.cuda.synchronize()
+            best = min(best, e0.elapsed_time(e1) / 10)
+        row[iname] = round(2.0 * m * n * k / (best * 1e-3) / 1e12, 1)
+    res[name] = row
+    print(f"{name:14s} M={m:6d} N={n:5d} K={k:6d}  " + "  ".join(f"{a}={b:7.1f} TF ({2.0*m*n*k/b/1e6:.0f}us)" for a, b in row.items()), flush=True)
