@@ -82,7 +82,7 @@ __device__ __forceinline__ float colgroup_sum(float x) { x += __shfl_xor(x, 16, 
 // forward
 // ------------------------------------------------------------------------------------------------------
 template <int NKT>     // key tiles of 16 (Spad = 16*NKT, NKT even)
-__global__ void __launch_bounds__(256)
+__global__ void __launch_bounds__(256, 2)
 mha_fwd_mfma_k(const bf16_t* __restrict__ qkv, const int32_t* __restrict__ key_mask, bf16_t* __restrict__ out,
                float* __restrict__ lse, int H, int S, float scale) {
   extern __shared__ __attribute__((aligned(16))) char sm[];
@@ -160,7 +160,7 @@ mha_fwd_mfma_k(const bf16_t* __restrict__ qkv, const int32_t* __restrict__ key_m
 // backward, dQ: a wave owns 16 queries
 // ------------------------------------------------------------------------------------------------------
 template <int NKT>
-__global__ void __launch_bounds__(256)
+__global__ void __launch_bounds__(256, 2)
 mha_bwd_dq_mfma_k(const bf16_t* __restrict__ qkv, const int32_t* __restrict__ key_mask, const bf16_t* __restrict__ out,
                   const bf16_t* __restrict__ dout, const float* __restrict__ lse, bf16_t* __restrict__ dqkv,
                   int H, int S, float scale) {
@@ -193,8 +193,8 @@ mha_bwd_dq_mfma_k(const bf16_t* __restrict__ qkv, const int32_t* __restrict__ ke
     f32x4 dq[4];
 #pragma unroll
     for (int dt = 0; dt < 4; ++dt) dq[dt] = (f32x4){0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-    for (int u = 0; u < NKT / 2; ++u) {
+#pragma unroll 1
+    for (int u = 0; u < NKT / 2; ++u) {      // rolled: keeps the live set small enough for 2 blocks per CU
       f32x4 ds2[2];
 #pragma unroll
       for (int hh = 0; hh < 2; ++hh) {
@@ -234,7 +234,7 @@ mha_bwd_dq_mfma_k(const bf16_t* __restrict__ qkv, const int32_t* __restrict__ ke
 // backward, dK/dV: a wave owns 16 keys
 // ------------------------------------------------------------------------------------------------------
 template <int NKT>
-__global__ void __launch_bounds__(256)
+__global__ void __launch_bounds__(256, 2)
 mha_bwd_dkv_mfma_k(const bf16_t* __restrict__ qkv, const int32_t* __restrict__ key_mask, const bf16_t* __restrict__ out,
                    const bf16_t* __restrict__ dout, const float* __restrict__ lse, bf16_t* __restrict__ dqkv,
                    int H, int S, float scale) {
@@ -278,7 +278,7 @@ mha_bwd_dkv_mfma_k(const bf16_t* __restrict__ qkv, const int32_t* __restrict__ k
     f32x4 dk[4], dv[4];
 #pragma unroll
     for (int dt = 0; dt < 4; ++dt) { dk[dt] = (f32x4){0.f, 0.f, 0.f, 0.f}; dv[dt] = (f32x4){0.f, 0.f, 0.f, 0.f}; }
-#pragma unroll
+#pragma unroll 1
     for (int u = 0; u < NKT / 2; ++u) {
       f32x4 p2[2], ds2[2];
 #pragma unroll

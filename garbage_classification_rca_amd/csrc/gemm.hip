@@ -320,7 +320,10 @@ extern "C" int mmrca_gemm(const void* A, const void* B, void* C, const void* bia
     int64_t ksplit_len = K;
     if (out_f32_accum) {
       const int64_t ksteps = K / GBK;
-      int64_t want = 768 / ((int64_t)tiles_m * tiles_n);
+      extern int g_mmrca_dbg;
+      // resident slots = 256 CUs x 2 blocks: aim for one (few tiles) or two (many tiles) full rounds
+      const int64_t target = (g_mmrca_dbg >> 8) > 0 ? (g_mmrca_dbg >> 8) : ((int64_t)tiles_m * tiles_n >= 64 ? 1024 : 512);
+      int64_t want = target / ((int64_t)tiles_m * tiles_n);
       if (want < 1) want = 1;
       if (want > ksteps / 4) want = ksteps / 4 > 0 ? ksteps / 4 : 1;
       const int64_t steps_per = (ksteps + want - 1) / want;

@@ -35,7 +35,9 @@ for name, m, n, k, al, bl, acc in SHAPES:
     C = torch.zeros(Mp, n, device=dev, dtype=torch.float32 if acc else torch.bfloat16)
     bias = None if acc else torch.randn(n, device=dev).bfloat16()
     row = {}
-    for iname, impl, dbg in [(a, b, 0) for a, b in impls.items()] + [(f"256dbg{d}", L.IMPL_MFMA256, d) for d in DBG if d]:
+    variants = [(a, b, 0) for a, b in impls.items()] + [(f"256dbg{d}", L.IMPL_MFMA256, d) for d in DBG if d and d < 256]
+    variants += [(f"128tgt{d >> 8}", L.IMPL_MFMA, d) for d in DBG if d >= 256]
+    for iname, impl, dbg in variants:
         if impl == L.IMPL_MFMA256 and (acc or n % 256 or (al == 1 and m % 256)):
             continue
         L.load().mmrca_debug_set(dbg)
