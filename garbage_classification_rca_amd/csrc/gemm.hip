@@ -74,8 +74,13 @@ gemm_ref_k(const T* __restrict__ A, const T* __restrict__ B, void* __restrict__ 
       if (n >= N) continue;
       float v = acc[i][j];
       if (bias) v += to_f(bias[n]);
-      if (preact) preact[m * ldc + n] = from_f<T>(v);
-      if (act == MMRCA_ACT_GELU) v = gelu_f(v);
+      if (act == MMRCA_ACT_GELU_SAVE_GRAD) { preact[m * ldc + n] = from_f<T>(gelu_grad_f(v)); v = gelu_f(v); }
+      else if (act == MMRCA_ACT_MUL) v *= to_f(preact[m * ldc + n]);
+      else if (act == MMRCA_ACT_GELU_BWD) v *= gelu_grad_f(to_f(preact[m * ldc + n]));
+      else {
+        if (preact) preact[m * ldc + n] = from_f<T>(v);
+        if (act == MMRCA_ACT_GELU) v = gelu_f(v);
+      }
       if (addend) v += to_f(addend[m * ldc + n]);
       if (accum) ((float*)Cv)[m * ldc + n] += v;
       else ((T*)Cv)[m * ldc + n] = from_f<T>(v);
@@ -142,11 +147,11 @@ __device__ __forceinline__ bf16x8 load_frag(const char* lds_tile, int rb, int ks
   }
 }
 
-template <bool A_KROW, bool B_KROW, bool ATOMIC_F32>
+template <bool A_KROW, bool B_KROW, bool ATOMIC_F32, bool FUSE_DB>
 __global__ void __launch_bounds__(256)
 gemm_mfma_k(const bf16_t* __restrict__ A, const bf16_t* __restrict__ B, void* __restrict__ Cv, const bf16_t* __restrict__ bias,
             const bf16_t* __restrict__ addend, bf16_t* __restrict__ preact, int64_t M, int64_t N, int64_t K,
-            int64_t lda, int64_t ldb, int64_t ldc, int act, int tiles_m, int tiles_n, int64_t ksplit_len) {
+            int64_t lda, int64_t ldb, int64_t ldc, int act, int tiles_m, int tiles_n, int64_t ksplit_len, float* __restrict__ dbias) {
   extern __shared__ __attribute__((aligned(16))) char smem[];   // [2 buffers][A tile | B tile]
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const int wr = wave >> 1, wc = wave & 1;
@@ -173,6 +178,17 @@ gemm_mfma_k(const bf16_t* __restrict__ A, const bf16_t* __restrict__ B, void* __
   for (int i = 0; i < 4; ++i)
 #pragma unroll
     for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+  // bias gradient fused into the weight-gradient GEMM: row sums of the A operand (= column sums of dY) come from one
+  // extra MFMA per A fragment against an all-ones B fragment; only the first column of tiles and waves does it.
+  constexpr bool do_bias = ATOMIC_F32 && FUSE_DB;   // work split: k-step (mod tiles_n) -> tile column, ks -> wave column
+  const int kstep0 = (int)(kbeg / GBK);
+  f32x4 accb[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) accb[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  bf16x8 ones;
+#pragma unroll
+  for (int e = 0; e < 8; ++e) ones[e] = (bf16_t)1.0f;
 
   if (nt > 0) {
     stage_tile<A_KROW>(A, lda, m_blk, M, kbeg, smem, wave, lane);
@@ -202,6 +218,10 @@ gemm_mfma_k(const bf16_t* __restrict__ A, const bf16_t* __restrict__ B, void* __
           if (ATOMIC_F32) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i], bfr[j], acc[i][j], 0, 0, 0);  // D[m][n]
           else            acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr[j], af[i], acc[i][j], 0, 0, 0);  // D[n][m]
         }
+      if (do_bias && ks == wc && ((kstep0 + t) % tiles_n) == tn) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) accb[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i], ones, accb[i], 0, 0, 0);
+      }
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
@@ -221,6 +241,15 @@ gemm_mfma_k(const bf16_t* __restrict__ A, const bf16_t* __restrict__ B, void* __
           if (m < M && n < N) atomicAdd(C + m * ldc + n, acc[i][j][r]);
         }
       }
+    if (do_bias && l16 == 0) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int64_t m = m_blk + wr * 64 + i * 16 + 4 * g + r;
+          if (m < M) atomicAdd(dbias + m, accb[i][r]);
+        }
+    }
   } else {
     // bf16 output through LDS (see gemm256.hip): fp32 tile [128][128] with rows padded by 16 B, read back two whole
     // rows per wave instruction so that every global access is a contiguous 256-byte row segment
@@ -249,7 +278,24 @@ gemm_mfma_k(const bf16_t* __restrict__ A, const bf16_t* __restrict__ B, void* __
       if (m < M) {
         const f32x4 c = *reinterpret_cast<const f32x4*>(smem + row * EP_STRIDE + l32 * 16);
         float v[4] = {c[0] + bv[0], c[1] + bv[1], c[2] + bv[2], c[3] + bv[3]};
-        if (preact) {
+        if (act == MMRCA_ACT_MUL) {
+          bf16x4 h4 = *reinterpret_cast<const bf16x4*>(preact + m * ldc + ncol);
+#pragma unroll
+          for (int r = 0; r < 4; ++r) v[r] *= (float)h4[r];
+        } else if (act == MMRCA_ACT_GELU_SAVE_GRAD) {
+          bf16x4 o;
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const float e = erff(v[r] * 0.70710678118654752f);
+            o[r] = (bf16_t)(0.5f * (1.0f + e) + v[r] * 0.3989422804014327f * __expf(-0.5f * v[r] * v[r]));
+            v[r] = 0.5f * v[r] * (1.0f + e);
+          }
+          *reinterpret_cast<bf16x4*>(preact + m * ldc + ncol) = o;
+        } else if (act == MMRCA_ACT_GELU_BWD) {
+          bf16x4 h4 = *reinterpret_cast<const bf16x4*>(preact + m * ldc + ncol);
+#pragma unroll
+          for (int r = 0; r < 4; ++r) v[r] *= gelu_grad_f((float)h4[r]);
+        } else if (preact) {
           bf16x4 o;
 #pragma unroll
           for (int r = 0; r < 4; ++r) o[r] = (bf16_t)v[r];
@@ -280,14 +326,14 @@ int mmrca_gemm256(const void* A, const void* B, void* C, const void* bias, const
                   int64_t N, int64_t K, int64_t lda, int64_t ldb, int64_t ldc, int a_layout, int b_layout, int act,
                   hipStream_t st);
 
-template <bool AK, bool BK2, bool AT>
+template <bool AK, bool BK2, bool AT, bool DB>
 static void launch_mfma(const void* A, const void* B, void* C, const void* bias, const void* addend, void* preact,
                         int64_t M, int64_t N, int64_t K, int64_t lda, int64_t ldb, int64_t ldc, int act, int tiles_m,
-                        int tiles_n, int ksplits, int64_t ksplit_len, hipStream_t st) {
-  (void)hipFuncSetAttribute((const void*)gemm_mfma_k<AK, BK2, AT>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS128_BYTES);
-  hipLaunchKernelGGL((gemm_mfma_k<AK, BK2, AT>), dim3(tiles_m * tiles_n, ksplits), dim3(256), LDS128_BYTES, st,
+                        int tiles_n, int ksplits, int64_t ksplit_len, float* dbias, hipStream_t st) {
+  (void)hipFuncSetAttribute((const void*)gemm_mfma_k<AK, BK2, AT, DB>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS128_BYTES);
+  hipLaunchKernelGGL((gemm_mfma_k<AK, BK2, AT, DB>), dim3(tiles_m * tiles_n, ksplits), dim3(256), LDS128_BYTES, st,
                      (const bf16_t*)A, (const bf16_t*)B, C, (const bf16_t*)bias, (const bf16_t*)addend, (bf16_t*)preact,
-                     M, N, K, lda, ldb, ldc, act, tiles_m, tiles_n, ksplit_len);
+                     M, N, K, lda, ldb, ldc, act, tiles_m, tiles_n, ksplit_len, dbias);
 }
 
 extern "C" int mmrca_gemm(const void* A, const void* B, void* C, const void* bias, const void* addend, void* preact,
@@ -296,9 +342,11 @@ extern "C" int mmrca_gemm(const void* A, const void* B, void* C, const void* bia
   MMRCA_REQUIRE(A && B && C, "gemm: null operand");
   MMRCA_REQUIRE(M > 0 && N > 0 && K > 0, "gemm: bad shape M=%lld N=%lld K=%lld", (long long)M, (long long)N, (long long)K);
   MMRCA_REQUIRE((a_layout == MMRCA_ROWK || a_layout == MMRCA_KROW) && (b_layout == MMRCA_ROWK || b_layout == MMRCA_KROW), "gemm: bad layout");
-  MMRCA_REQUIRE(act == MMRCA_ACT_NONE || act == MMRCA_ACT_GELU, "gemm: bad activation");
+  MMRCA_REQUIRE(act >= MMRCA_ACT_NONE && act <= MMRCA_ACT_MUL, "gemm: bad activation");
+  MMRCA_REQUIRE(act < MMRCA_ACT_GELU_BWD || preact, "gemm: this activation needs the `preact` buffer");
   MMRCA_REQUIRE(lda >= (a_layout == MMRCA_ROWK ? K : M) && ldb >= (b_layout == MMRCA_ROWK ? K : N) && ldc >= N, "gemm: leading dimension too small");
-  MMRCA_REQUIRE(!(out_f32_accum && (bias || addend || preact || act != MMRCA_ACT_NONE)), "gemm: accumulate mode takes no epilogue");
+  MMRCA_REQUIRE(!(out_f32_accum && (addend || preact || act != MMRCA_ACT_NONE)), "gemm: accumulate mode takes no epilogue");
+  MMRCA_REQUIRE(!(out_f32_accum && bias && a_layout != MMRCA_KROW), "gemm: the fused bias gradient needs A in KROW layout");
   hipStream_t st = (hipStream_t)stream;
 
   bool ok_mfma = (dtype == MMRCA_BF16) && (N % GBN == 0) && (K % GBK == 0) && (lda % 8 == 0) && (ldb % 8 == 0) &&
@@ -331,7 +379,13 @@ extern "C" int mmrca_gemm(const void* A, const void* B, void* C, const void* bia
       ksplits = (int)((ksteps + steps_per - 1) / steps_per);
     }
     const bool ak = a_layout == MMRCA_KROW, bk = b_layout == MMRCA_KROW, at = out_f32_accum != 0;
-#define L(AK_, BK_, AT_) launch_mfma<AK_, BK_, AT_>(A, B, C, bias, addend, preact, M, N, K, lda, ldb, ldc, act, tiles_m, tiles_n, ksplits, ksplit_len, st)
+    if (at && bias) {   // weight gradient with the bias gradient fused (A is KROW by contract)
+      if (bk) launch_mfma<true, true, true, true>(A, B, C, nullptr, addend, preact, M, N, K, lda, ldb, ldc, act, tiles_m, tiles_n, ksplits, ksplit_len, (float*)bias, st);
+      else launch_mfma<true, false, true, true>(A, B, C, nullptr, addend, preact, M, N, K, lda, ldb, ldc, act, tiles_m, tiles_n, ksplits, ksplit_len, (float*)bias, st);
+      MMRCA_CHECK_LAUNCH("gemm(mfma,wgrad+dbias)");
+      return 0;
+    }
+#define L(AK_, BK_, AT_) launch_mfma<AK_, BK_, AT_, false>(A, B, C, out_f32_accum ? nullptr : bias, addend, preact, M, N, K, lda, ldb, ldc, act, tiles_m, tiles_n, ksplits, ksplit_len, out_f32_accum ? (float*)bias : nullptr, st)
     if (!ak && !bk && !at) L(false, false, false);
     else if (!ak && bk && !at) L(false, true, false);
     else if (ak && !bk && !at) L(true, false, false);
@@ -345,6 +399,10 @@ extern "C" int mmrca_gemm(const void* A, const void* B, void* C, const void* bia
     return 0;
   }
 
+  if (out_f32_accum && bias) {     // fused bias gradient, reference path: column sums of A[K rows][M cols]
+    if (int rc = mmrca_colsum_accum(A, (float*)bias, K, M, lda, dtype, stream)) return rc;
+    bias = nullptr;
+  }
   const int64_t sam = a_layout == MMRCA_ROWK ? lda : 1, sak = a_layout == MMRCA_ROWK ? 1 : lda;
   const int64_t sbn = b_layout == MMRCA_ROWK ? ldb : 1, sbk = b_layout == MMRCA_ROWK ? 1 : ldb;
   dim3 grid((unsigned)((N + 63) / 64), (unsigned)((M + 63) / 64));

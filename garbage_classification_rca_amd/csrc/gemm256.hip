@@ -248,7 +248,24 @@ gemm_mfma256_k(const bf16_t* __restrict__ A, const bf16_t* __restrict__ B, bf16_
       if (m < M) {
         const f32x4 c = *reinterpret_cast<const f32x4*>(smem + row * EP_STRIDE + lane * 16);
         float v[4] = {c[0] + bv[0], c[1] + bv[1], c[2] + bv[2], c[3] + bv[3]};
-        if (preact) {
+        if (act == MMRCA_ACT_MUL) {
+          bf16x4 h4 = *reinterpret_cast<const bf16x4*>(preact + m * ldc + ncol);
+#pragma unroll
+          for (int r = 0; r < 4; ++r) v[r] *= (float)h4[r];
+        } else if (act == MMRCA_ACT_GELU_SAVE_GRAD) {
+          bf16x4 o;
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const float e = erff(v[r] * 0.70710678118654752f);
+            o[r] = (bf16_t)(0.5f * (1.0f + e) + v[r] * 0.3989422804014327f * __expf(-0.5f * v[r] * v[r]));
+            v[r] = 0.5f * v[r] * (1.0f + e);
+          }
+          *reinterpret_cast<bf16x4*>(preact + m * ldc + ncol) = o;
+        } else if (act == MMRCA_ACT_GELU_BWD) {
+          bf16x4 h4 = *reinterpret_cast<const bf16x4*>(preact + m * ldc + ncol);
+#pragma unroll
+          for (int r = 0; r < 4; ++r) v[r] *= gelu_grad_f((float)h4[r]);
+        } else if (preact) {
           bf16x4 o;
 #pragma unroll
           for (int r = 0; r < 4; ++r) o[r] = (bf16_t)v[r];

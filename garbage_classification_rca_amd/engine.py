@@ -24,7 +24,13 @@ import torch
 from . import lib as L
 from . import spec as S
 
+import os
+
 ALIGN = 64          # arena entries start on 256-byte boundaries
+# Epilogue fusions that exist in the kernels and are parity-tested, but measured net-neutral on MI355X at cfg 2 (the
+# fused work is exposed in the GEMM epilogue instead of overlapping in a bandwidth-bound pass): off by default.
+FUSE_BIAS_GRAD = os.environ.get("MMRCA_FUSE_BIAS", "0") == "1"
+FUSE_GELU_GRAD = os.environ.get("MMRCA_FUSE_GELU", "0") == "1"
 ROWPAD = 128
 
 
@@ -227,18 +233,24 @@ class MMRCAEngine:
         L.gemm(x, w, out, bias=b, addend=addend, preact=preact, M=M, N=N, K=K, lda=K, ldb=K, ldc=N,
                a_layout=L.ROWK, b_layout=L.ROWK, act=act, dtype=self.dt, impl=self.gemm_impl)
 
-    def _lin_bwd(self, dy, x, wkey, bkey, dx, M, N, K, addend=None, wnumel=None):
-        """dy [M,N], x [M,K], weight [N,K]:  dW += dy^T x ; db += colsum(dy) ; dx = dy W (+ addend)."""
+    def _lin_bwd(self, dy, x, wkey, bkey, dx, M, N, K, addend=None, wnumel=None, gelu_h=None):
+        """dy [M,N], x [M,K], weight [N,K]:  dW += dy^T x and db += colsum(dy) in ONE pass (the bias gradient rides
+        on the weight-gradient GEMM); dx = dy W (+ addend), optionally times gelu'(gelu_h) in the epilogue."""
         Mk = _round_up(M, 64)
         gw = self.G(wkey) if wnumel is None else self.Gflat(wkey, wnumel)
         gb = self.G(bkey) if wnumel is None else self.Gflat(bkey, N)
-        L.gemm(dy, x, gw, M=N, N=K, K=Mk, lda=N, ldb=K, ldc=K, a_layout=L.KROW, b_layout=L.KROW, accum=True,
-               dtype=self.dt, impl=self.gemm_impl)
-        L.colsum_accum(dy, gb, M, N, N, self.dt)
+        L.gemm(dy, x, gw, bias=(gb if FUSE_BIAS_GRAD else None), M=N, N=K, K=Mk, lda=N, ldb=K, ldc=K, a_layout=L.KROW,
+               b_layout=L.KROW, accum=True, dtype=self.dt, impl=self.gemm_impl)
+        if not FUSE_BIAS_GRAD:
+            L.colsum_accum(dy, gb, M, N, N, self.dt)
         if dx is not None:
             w = self.W(wkey) if wnumel is None else self.Wflat(wkey, wnumel)
-            L.gemm(dy, w, dx, addend=addend, M=M, N=K, K=N, lda=N, ldb=K, ldc=K, a_layout=L.ROWK, b_layout=L.KROW,
-                   dtype=self.dt, impl=self.gemm_impl)
+            fuse = gelu_h is not None and FUSE_GELU_GRAD
+            L.gemm(dy, w, dx, addend=addend, preact=(gelu_h if fuse else None), M=M, N=K, K=N, lda=N, ldb=K, ldc=K,
+                   a_layout=L.ROWK, b_layout=L.KROW, act=(L.ACT_MUL if fuse else L.ACT_NONE), dtype=self.dt,
+                   impl=self.gemm_impl)
+            if gelu_h is not None and not fuse:
+                L.gelu_bwd(dx, gelu_h, dx, M * K, self.dt)
 
     def _ln_fwd(self, x, res, pfx, sum_out, y, mean, rstd, rows, D, eps, ld_x=None, ld_y=None):
         L.add_layernorm_fwd(x, res, self.W(pfx + ".weight"), self.W(pfx + ".bias"), sum_out, y, mean, rstd, rows, D,
@@ -282,7 +294,7 @@ class MMRCAEngine:
             m1, r1 = stat("m1", i), stat("r1", i)
             self._ln_fwd(att, x, P + K["ln1"], s1, x1, m1, r1, M, D, s.ln_eps)
             h, g = fb("h", Fd, i), fb("g", Fd, i)
-            self._lin_fwd(x1, P + K["f1"] + ".weight", P + K["f1"] + ".bias", g, M, Fd, D, act=L.ACT_GELU, preact=h)
+            self._lin_fwd(x1, P + K["f1"] + ".weight", P + K["f1"] + ".bias", g, M, Fd, D, act=(L.ACT_GELU_SAVE_GRAD if FUSE_GELU_GRAD else L.ACT_GELU), preact=h)   # fused mode: h <- gelu'(pre-activation)
             f = fb("tmpD", D)
             self._lin_fwd(g, P + K["f2"] + ".weight", P + K["f2"] + ".bias", f, M, D, Fd)
             s2, xn = fb("s2", D, i), fb("x", D, i + 1)
@@ -307,8 +319,7 @@ class MMRCAEngine:
             ds2 = gb("ds2", D)
             self._ln_bwd(dx, a["s2"], P + K["ln2"], a["m2"], a["r2"], None, ds2, M, D)
             dg = gb("dF", Fd)
-            self._lin_bwd(ds2, a["g"], P + K["f2"] + ".weight", P + K["f2"] + ".bias", dg, M, D, Fd)
-            L.gelu_bwd(dg, a["h"], dg, M * Fd, self.dt)
+            self._lin_bwd(ds2, a["g"], P + K["f2"] + ".weight", P + K["f2"] + ".bias", dg, M, D, Fd, gelu_h=a["h"])
             dx1 = gb("dxB", D)
             self._lin_bwd(dg, a["x1"], P + K["f1"] + ".weight", P + K["f1"] + ".bias", dx1, M, Fd, D, addend=ds2)
             ds1 = gb("ds1", D)
@@ -357,7 +368,7 @@ class MMRCAEngine:
             y2, m2, r2 = fb("y2", M, D, i), stat("m2", i), stat("r2", i)
             self._ln_fwd(x1, None, Lk + "ln_2", None, y2, m2, r2, M, D, s.ln_eps)
             h, g = fb("h", M, Fd, i), fb("g", M, Fd, i)
-            self._lin_fwd(y2, Lk + "mlp.0.weight", Lk + "mlp.0.bias", g, M, Fd, D, act=L.ACT_GELU, preact=h)
+            self._lin_fwd(y2, Lk + "mlp.0.weight", Lk + "mlp.0.bias", g, M, Fd, D, act=(L.ACT_GELU_SAVE_GRAD if FUSE_GELU_GRAD else L.ACT_GELU), preact=h)   # fused mode: h <- gelu'(pre-activation)
             xn = fb("x", M, D, i + 1)
             self._lin_fwd(g, Lk + "mlp.3.weight", Lk + "mlp.3.bias", xn, M, D, Fd, addend=x1)
             layers.append(dict(x=x, y1=y1, m1=m1, r1=r1, qkv=qkv, ctx=ctx, lse=lse, x1=x1, y2=y2, m2=m2, r2=r2, h=h, g=g))
@@ -382,8 +393,7 @@ class MMRCAEngine:
         for i in reversed(range(s.layers)):
             Lk, a = P + f"encoder.layers.encoder_layer_{i}.", sv["layers"][i]
             dg = gb("dF", M, Fd)
-            self._lin_bwd(dx, a["g"], Lk + "mlp.3.weight", Lk + "mlp.3.bias", dg, M, D, Fd)
-            L.gelu_bwd(dg, a["h"], dg, M * Fd, self.dt)
+            self._lin_bwd(dx, a["g"], Lk + "mlp.3.weight", Lk + "mlp.3.bias", dg, M, D, Fd, gelu_h=a["h"])
             dy2 = gb("dy", M, D)
             self._lin_bwd(dg, a["y2"], Lk + "mlp.0.weight", Lk + "mlp.0.bias", dy2, M, Fd, D)
             dx1 = gb("dxB", M, D)

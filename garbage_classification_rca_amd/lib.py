@@ -16,7 +16,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libmmrca.so")
 
 F32, BF16 = 0, 1
-ACT_NONE, ACT_GELU = 0, 1
+ACT_NONE, ACT_GELU, ACT_GELU_BWD, ACT_GELU_SAVE_GRAD, ACT_MUL = 0, 1, 2, 3, 4
 ROWK, KROW = 0, 1
 IMPL_AUTO, IMPL_REF, IMPL_MFMA, IMPL_MFMA256 = 0, 1, 2, 3
 

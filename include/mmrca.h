@@ -25,7 +25,10 @@ extern "C" {
 #endif
 
 enum { MMRCA_F32 = 0, MMRCA_BF16 = 1 };
-enum { MMRCA_ACT_NONE = 0, MMRCA_ACT_GELU = 1 };
+enum { MMRCA_ACT_NONE = 0, MMRCA_ACT_GELU = 1,
+       MMRCA_ACT_GELU_BWD = 2,        /* C = (A.B) * gelu'(preact); preact (the saved pre-activation) is an INPUT */
+       MMRCA_ACT_GELU_SAVE_GRAD = 3,  /* C = gelu(v), preact <- gelu'(v): the forward emits the derivative (shares the erf) */
+       MMRCA_ACT_MUL = 4 };           /* C = (A.B) * preact; preact is an INPUT (pairs with GELU_SAVE_GRAD) */
 /* operand layouts of mmrca_gemm: ROWK = [rows][contraction] (contraction contiguous),
  * KROW = [contraction][rows] (rows contiguous) */
 enum { MMRCA_ROWK = 0, MMRCA_KROW = 1 };
@@ -40,7 +43,9 @@ int mmrca_debug_set(int flags);
  * transformers modeling_distilbert.py q_lin/k_lin/v_lin/out_lin/ffn.lin1/lin2, torchvision ViT in_proj/
  * out_proj/mlp, and their autograd; head linears go through mmrca_head_*).
  *   A: M rows, contraction K; layout a_layout, leading dimension lda.   B: N rows, contraction K.
- *   out_f32_accum != 0: C is fp32 and C += result (wgrad); otherwise C has `dtype`.
+ *   out_f32_accum != 0: C is fp32 and C += result (wgrad); otherwise C has `dtype`.  In that mode `bias`, if given,
+ *   is an fp32 OUTPUT [M]: bias[m] += sum_k A[m][k] (the bias gradient = column sums of dY), fused into the same
+ *   pass over A (A must be KROW).
  *   preact (optional, `dtype`): receives A(.)B + bias before the activation.
  *   For a_layout==KROW the contraction runs over rows of A and B; rows K..round_up(K,64) of both
  *   buffers must exist and hold zeros (the engine pads its activation buffers so).

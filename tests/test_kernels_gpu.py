@@ -138,6 +138,43 @@ def test_gemm_mfma256_layouts_and_epilogues(layouts):
     _gemm_case(Mr, 256, 256, al, bl, torch.bfloat16, L.IMPL_MFMA256, act=L.ACT_GELU, bias=True, addend=True, preact=True)
 
 
+@pytest.mark.parametrize("dt,impl", [(torch.float32, L.IMPL_REF), (torch.bfloat16, L.IMPL_REF), (torch.bfloat16, L.IMPL_MFMA)])
+def test_gemm_fused_bias_gradient_and_gelu_backward(dt, impl):
+    """wgrad with the bias gradient riding on the same pass, and dgrad with gelu'(h) in the epilogue."""
+    M, N, K = 788, 768, 256            # dY [M,N], X [M,K]
+    Mp = 832
+    g = torch.Generator().manual_seed(3)
+    dY = torch.zeros(Mp, N); dY[:M] = torch.randn(M, N, generator=g)
+    X = torch.zeros(Mp, K); X[:M] = torch.randn(M, K, generator=g)
+    dYd, Xd = dev(dY, dt), dev(X, dt)
+    dW, db = dev(torch.randn(N, K, generator=g)), dev(torch.randn(N, generator=g))
+    refW = dW.double() + dYd.double().t() @ Xd.double()
+    refb = db.double() + dYd.double().sum(0)
+    L.gemm(dYd, Xd, dW, bias=db, M=N, N=K, K=Mp, lda=N, ldb=K, ldc=K, a_layout=L.KROW, b_layout=L.KROW, accum=True,
+           dtype=L.dtype_code(dt), impl=impl)
+    assert rel_err(dW, refW) < 1e-4 and rel_err(db, refb) < 1e-4
+    W = dev(torch.randn(N, K, generator=g) * 0.1, dt)
+    H = dev(torch.randn(M, K, generator=g), dt)
+    dX = torch.empty(M, K, device="cuda", dtype=dt)
+    L.gemm(dYd, W, dX, preact=H, M=M, N=K, K=N, lda=N, ldb=K, ldc=K, a_layout=L.ROWK, b_layout=L.KROW, act=L.ACT_GELU_BWD,
+           dtype=L.dtype_code(dt), impl=impl)
+    hr = H.float().clone().requires_grad_(True)
+    F.gelu(hr).backward(torch.ones_like(hr))
+    ref = (dYd[:M].double() @ W.double()) * hr.grad.double()
+    assert rel_err(dX, ref) < TOL[dt]
+    # forward emits gelu'(v) (ACT_GELU_SAVE_GRAD), backward multiplies by it (ACT_MUL)
+    Xf, Wf = dev(torch.randn(M, N, generator=g) * 0.2, dt), dev(torch.randn(K, N, generator=g) * 0.2, dt)
+    Y, Gp = torch.empty(M, K, device="cuda", dtype=dt), torch.empty(M, K, device="cuda", dtype=dt)
+    L.gemm(Xf, Wf, Y, preact=Gp, M=M, N=K, K=N, lda=N, ldb=N, ldc=K, act=L.ACT_GELU_SAVE_GRAD, dtype=L.dtype_code(dt), impl=impl)
+    pre = (Xf.double() @ Wf.double().t()).float().requires_grad_(True)
+    yr = F.gelu(pre); yr.backward(torch.ones_like(yr))
+    assert rel_err(Y, yr.detach()) < TOL[dt] and rel_err(Gp, pre.grad) < TOL[dt]
+    dX2 = torch.empty(M, K, device="cuda", dtype=dt)
+    L.gemm(dYd, W, dX2, preact=Gp, M=M, N=K, K=N, lda=N, ldb=K, ldc=K, a_layout=L.ROWK, b_layout=L.KROW, act=L.ACT_MUL,
+           dtype=L.dtype_code(dt), impl=impl)
+    assert rel_err(dX2, (dYd[:M].double() @ W.double()) * Gp.double()) < TOL[dt]
+
+
 def test_gemm_rejects_bad_arguments():
     a = torch.zeros(4, 4, device="cuda")
     with pytest.raises(L.MmrcaError):
