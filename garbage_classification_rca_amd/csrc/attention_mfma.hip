@@ -75,6 +75,11 @@ __device__ __forceinline__ bf16x8 pack_pair(const f32x4& a, const f32x4& b) {
   return r;
 }
 
+// attention-probability dropout: keep-scale of element (row q, key) of head bh
+__device__ __forceinline__ float attn_keep(float p, float sc, uint64_t seed, int64_t bh, int S, int q, int key) {
+  return mmrca_uniform(seed, ((uint64_t)bh * S + q) * S + key) >= p ? sc : 0.f;
+}
+
 __device__ __forceinline__ float colgroup_max(float x) { x = fmaxf(x, __shfl_xor(x, 16, 64)); return fmaxf(x, __shfl_xor(x, 32, 64)); }
 __device__ __forceinline__ float colgroup_sum(float x) { x += __shfl_xor(x, 16, 64); return x + __shfl_xor(x, 32, 64); }
 
@@ -84,7 +89,8 @@ __device__ __forceinline__ float colgroup_sum(float x) { x += __shfl_xor(x, 16, 
 template <int NKT>     // key tiles of 16 (Spad = 16*NKT, NKT even)
 __global__ void __launch_bounds__(256, 2)
 mha_fwd_mfma_k(const bf16_t* __restrict__ qkv, const int32_t* __restrict__ key_mask, bf16_t* __restrict__ out,
-               float* __restrict__ lse, int H, int S, float scale) {
+               float* __restrict__ lse, int H, int S, float scale, float drop_p, uint64_t drop_seed) {
+  const float drop_sc = drop_p > 0.f ? 1.f / (1.f - drop_p) : 1.f;
   extern __shared__ __attribute__((aligned(16))) char sm[];
   constexpr int Spad = NKT * 16;
   char* Kimg = sm; char* Vimg = sm + Spad * 128;
@@ -130,6 +136,12 @@ mha_fwd_mfma_k(const bf16_t* __restrict__ qkv, const int32_t* __restrict__ key_m
 #pragma unroll
       for (int r = 0; r < 4; ++r) { const float e = __expf(s[kt][r] - msafe); s[kt][r] = e; l += e; }
     l = colgroup_sum(l);
+    if (drop_p > 0.f) {      // dropout acts on the normalised probabilities: mask the numerators, keep the denominator
+#pragma unroll
+      for (int kt = 0; kt < NKT; ++kt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) s[kt][r] *= attn_keep(drop_p, drop_sc, drop_seed, blockIdx.x, S, q0 + l16, kt * 16 + 4 * g + r);
+    }
     f32x4 o[4];
 #pragma unroll
     for (int dt = 0; dt < 4; ++dt) o[dt] = (f32x4){0.f, 0.f, 0.f, 0.f};
@@ -163,7 +175,8 @@ template <int NKT>
 __global__ void __launch_bounds__(256, 2)
 mha_bwd_dq_mfma_k(const bf16_t* __restrict__ qkv, const int32_t* __restrict__ key_mask, const bf16_t* __restrict__ out,
                   const bf16_t* __restrict__ dout, const float* __restrict__ lse, bf16_t* __restrict__ dqkv,
-                  int H, int S, float scale) {
+                  int H, int S, float scale, float drop_p, uint64_t drop_seed) {
+  const float drop_sc = drop_p > 0.f ? 1.f / (1.f - drop_p) : 1.f;
   extern __shared__ __attribute__((aligned(16))) char sm[];
   constexpr int Spad = NKT * 16;
   char* Kimg = sm; char* Vimg = sm + Spad * 128;
@@ -209,7 +222,8 @@ mha_bwd_dq_mfma_k(const bf16_t* __restrict__ qkv, const int32_t* __restrict__ ke
           const int key = kt * 16 + 4 * g + r;
           const bool ok = key < S && (!key_mask || key_mask[b * S + key] != 0);
           const float p = ok ? __expf(s[r] * scale - L) : 0.f;
-          ds2[hh][r] = p * (dp[r] - dsum) * scale;
+          const float keep = drop_p > 0.f ? attn_keep(drop_p, drop_sc, drop_seed, blockIdx.x, S, q, key) : 1.f;
+          ds2[hh][r] = p * (dp[r] * keep - dsum) * scale;
         }
       }
       const bf16x8 dsf = pack_pair(ds2[0], ds2[1]);
@@ -237,7 +251,8 @@ template <int NKT>
 __global__ void __launch_bounds__(256, 2)
 mha_bwd_dkv_mfma_k(const bf16_t* __restrict__ qkv, const int32_t* __restrict__ key_mask, const bf16_t* __restrict__ out,
                    const bf16_t* __restrict__ dout, const float* __restrict__ lse, bf16_t* __restrict__ dqkv,
-                   int H, int S, float scale) {
+                   int H, int S, float scale, float drop_p, uint64_t drop_seed) {
+  const float drop_sc = drop_p > 0.f ? 1.f / (1.f - drop_p) : 1.f;
   extern __shared__ __attribute__((aligned(16))) char sm[];
   constexpr int Spad = NKT * 16;
   char* Qimg = sm; char* Dimg = sm + Spad * 128;
@@ -293,8 +308,9 @@ mha_bwd_dkv_mfma_k(const bf16_t* __restrict__ qkv, const int32_t* __restrict__ k
         for (int r = 0; r < 4; ++r) {
           const int q = qt * 16 + 4 * g + r;
           const float p = key_ok ? __expf(s[r] * scale - lse_s[q]) : 0.f;
-          p2[hh][r] = p;
-          ds2[hh][r] = p * (dp[r] - dsum_s[q]) * scale;
+          const float keep = drop_p > 0.f ? attn_keep(drop_p, drop_sc, drop_seed, blockIdx.x, S, q, key) : 1.f;
+          p2[hh][r] = p * keep;
+          ds2[hh][r] = p * (dp[r] * keep - dsum_s[q]) * scale;
         }
       }
       const bf16x8 pf = pack_pair(p2[0], p2[1]), dsf = pack_pair(ds2[0], ds2[1]);
@@ -350,23 +366,23 @@ static int pick_nkt(int S) {
 #define STAT_EXTRA(n) (2 * (n) * 16 * 4)
 
 int mmrca_mha_fwd_mfma(const void* qkv, const int32_t* key_mask, void* out, float* lse, int B, int H, int S, int dh,
-                       float scale, hipStream_t st) {
+                       float scale, float drop_p, uint64_t drop_seed, hipStream_t st) {
   (void)dh;
   MMRCA_REQUIRE((((uintptr_t)qkv) & 15) == 0 && (((uintptr_t)out) & 7) == 0, "mha_fwd: qkv must be 16-byte aligned");
   const int nkt = pick_nkt(S);
-  AT_SWITCH(mha_fwd_mfma_k, NO_EXTRA, (const bf16_t*)qkv, key_mask, (bf16_t*)out, lse, H, S, scale);
+  AT_SWITCH(mha_fwd_mfma_k, NO_EXTRA, (const bf16_t*)qkv, key_mask, (bf16_t*)out, lse, H, S, scale, drop_p, drop_seed);
   MMRCA_CHECK_LAUNCH("mha_fwd(mfma)");
   return 0;
 }
 
 int mmrca_mha_bwd_mfma(const void* qkv, const int32_t* key_mask, const void* out, const void* dout, const float* lse,
-                       void* dqkv, int B, int H, int S, int dh, float scale, hipStream_t st) {
+                       void* dqkv, int B, int H, int S, int dh, float scale, float drop_p, uint64_t drop_seed, hipStream_t st) {
   (void)dh;
   MMRCA_REQUIRE((((uintptr_t)qkv) & 15) == 0 && (((uintptr_t)out) & 15) == 0 && (((uintptr_t)dout) & 15) == 0 && (((uintptr_t)dqkv) & 7) == 0,
                 "mha_bwd: buffers must be 16-byte aligned");
   const int nkt = pick_nkt(S);
-  AT_SWITCH(mha_bwd_dq_mfma_k, NO_EXTRA, (const bf16_t*)qkv, key_mask, (const bf16_t*)out, (const bf16_t*)dout, lse, (bf16_t*)dqkv, H, S, scale);
-  AT_SWITCH(mha_bwd_dkv_mfma_k, STAT_EXTRA, (const bf16_t*)qkv, key_mask, (const bf16_t*)out, (const bf16_t*)dout, lse, (bf16_t*)dqkv, H, S, scale);
+  AT_SWITCH(mha_bwd_dq_mfma_k, NO_EXTRA, (const bf16_t*)qkv, key_mask, (const bf16_t*)out, (const bf16_t*)dout, lse, (bf16_t*)dqkv, H, S, scale, drop_p, drop_seed);
+  AT_SWITCH(mha_bwd_dkv_mfma_k, STAT_EXTRA, (const bf16_t*)qkv, key_mask, (const bf16_t*)out, (const bf16_t*)dout, lse, (bf16_t*)dqkv, H, S, scale, drop_p, drop_seed);
   MMRCA_CHECK_LAUNCH("mha_bwd(mfma)");
   return 0;
 }

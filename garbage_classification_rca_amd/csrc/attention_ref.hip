@@ -21,7 +21,8 @@ __device__ __forceinline__ float dot_row(const T* __restrict__ row, const float*
 template <typename T>
 __global__ void __launch_bounds__(256)
 mha_fwd_ref_k(const T* __restrict__ qkv, const int32_t* __restrict__ key_mask, T* __restrict__ out, float* __restrict__ lse,
-              int B, int H, int S, int dh, float scale) {
+              int B, int H, int S, int dh, float scale, float drop_p, uint64_t drop_seed) {
+  const float drop_sc = drop_p > 0.f ? 1.f / (1.f - drop_p) : 1.f;
   extern __shared__ float sm[];     // per wave: q[dh] | p[S]
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const int b = blockIdx.y / H, h = blockIdx.y % H;
@@ -51,6 +52,9 @@ mha_fwd_ref_k(const T* __restrict__ qkv, const int32_t* __restrict__ key_mask, T
   }
   l = wave_sum(l);
   const float inv = l > 0.f ? 1.f / l : 0.f;
+  if (drop_p > 0.f)
+    for (int j = lane; j < S; j += 64)
+      p[j] *= mmrca_uniform(drop_seed, ((uint64_t)blockIdx.y * S + i) * S + j) >= drop_p ? drop_sc : 0.f;
   __builtin_amdgcn_wave_barrier();
   for (int d = lane; d < dh; d += 64) {
     float o = 0.f;
@@ -65,7 +69,8 @@ template <typename T>
 __global__ void __launch_bounds__(256)
 mha_bwd_dq_ref_k(const T* __restrict__ qkv, const int32_t* __restrict__ key_mask, const T* __restrict__ out,
                  const T* __restrict__ dout, const float* __restrict__ lse, T* __restrict__ dqkv,
-                 int B, int H, int S, int dh, float scale) {
+                 int B, int H, int S, int dh, float scale, float drop_p, uint64_t drop_seed) {
+  const float drop_sc = drop_p > 0.f ? 1.f / (1.f - drop_p) : 1.f;
   extern __shared__ float sm[];     // per wave: q[dh] | do[dh] | ds[S]
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const int b = blockIdx.y / H, h = blockIdx.y % H;
@@ -93,7 +98,8 @@ mha_bwd_dq_ref_k(const T* __restrict__ qkv, const int32_t* __restrict__ key_mask
     if (!key_mask || key_mask[b * S + j] != 0) {
       const float s = dot_row(Kp + (int64_t)j * ld, qv, dh) * scale;
       const float pj = __expf(s - L);
-      const float dp = dot_row(Vp + (int64_t)j * ld, dov, dh);
+      float dp = dot_row(Vp + (int64_t)j * ld, dov, dh);
+      if (drop_p > 0.f) dp *= mmrca_uniform(drop_seed, ((uint64_t)blockIdx.y * S + i) * S + j) >= drop_p ? drop_sc : 0.f;
       v = pj * (dp - dsum) * scale;
     }
     ds[j] = v;
@@ -111,7 +117,8 @@ template <typename T>
 __global__ void __launch_bounds__(256)
 mha_bwd_dkv_ref_k(const T* __restrict__ qkv, const int32_t* __restrict__ key_mask, const T* __restrict__ out,
                   const T* __restrict__ dout, const float* __restrict__ lse, T* __restrict__ dqkv,
-                  int B, int H, int S, int dh, float scale) {
+                  int B, int H, int S, int dh, float scale, float drop_p, uint64_t drop_seed) {
+  const float drop_sc = drop_p > 0.f ? 1.f / (1.f - drop_p) : 1.f;
   extern __shared__ float sm[];     // per wave: k[dh] | v[dh] | p[S] | ds[S]
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const int b = blockIdx.y / H, h = blockIdx.y % H;
@@ -135,10 +142,12 @@ mha_bwd_dkv_ref_k(const T* __restrict__ qkv, const int32_t* __restrict__ key_mas
       const T* orow = out + ((int64_t)b * S + i) * ldo + h * dh;
       const float s = dot_row(Q + (int64_t)i * ld, kv, dh) * scale;
       pi = __expf(s - lse[((int64_t)b * H + h) * S + i]);
-      const float dp = dot_row(dorow, vv, dh);
+      float dp = dot_row(dorow, vv, dh);
       float dsum = 0.f;
       for (int d = 0; d < dh; ++d) dsum += to_f(dorow[d]) * to_f(orow[d]);
-      dsi = pi * (dp - dsum) * scale;
+      const float keep = drop_p > 0.f ? (mmrca_uniform(drop_seed, ((uint64_t)blockIdx.y * S + i) * S + j) >= drop_p ? drop_sc : 0.f) : 1.f;
+      dsi = pi * (dp * keep - dsum) * scale;
+      pi *= keep;
     }
     p[i] = pi; ds[i] = dsi;
   }
@@ -155,24 +164,24 @@ mha_bwd_dkv_ref_k(const T* __restrict__ qkv, const int32_t* __restrict__ key_mas
 }
 
 int mmrca_mha_fwd_ref(const void* qkv, const int32_t* key_mask, void* out, float* lse, int B, int H, int S, int dh,
-                      float scale, int dtype, hipStream_t st) {
+                      float scale, float drop_p, uint64_t drop_seed, int dtype, hipStream_t st) {
   MMRCA_REQUIRE(S <= ATT_MAX_S && dh <= ATT_MAX_DH && dh % 4 == 0, "mha_fwd(ref): S=%d dh=%d unsupported", S, dh);
   dim3 grid((S + 3) / 4, B * H);
   const size_t lds = 4 * (ATT_MAX_DH + S) * sizeof(float);
   MMRCA_DISPATCH_DTYPE(dtype, "mha_fwd",
-    hipLaunchKernelGGL(mha_fwd_ref_k<T>, grid, dim3(256), lds, st, (const T*)qkv, key_mask, (T*)out, lse, B, H, S, dh, scale);)
+    hipLaunchKernelGGL(mha_fwd_ref_k<T>, grid, dim3(256), lds, st, (const T*)qkv, key_mask, (T*)out, lse, B, H, S, dh, scale, drop_p, drop_seed);)
   MMRCA_CHECK_LAUNCH("mha_fwd(ref)");
   return 0;
 }
 
 int mmrca_mha_bwd_ref(const void* qkv, const int32_t* key_mask, const void* out, const void* dout, const float* lse,
-                      void* dqkv, int B, int H, int S, int dh, float scale, int dtype, hipStream_t st) {
+                      void* dqkv, int B, int H, int S, int dh, float scale, float drop_p, uint64_t drop_seed, int dtype, hipStream_t st) {
   MMRCA_REQUIRE(S <= ATT_MAX_S && dh <= ATT_MAX_DH && dh % 4 == 0, "mha_bwd(ref): S=%d dh=%d unsupported", S, dh);
   dim3 grid((S + 3) / 4, B * H);
   const size_t lds1 = 4 * (2 * ATT_MAX_DH + S) * sizeof(float), lds2 = 4 * (2 * ATT_MAX_DH + 2 * S) * sizeof(float);
   MMRCA_DISPATCH_DTYPE(dtype, "mha_bwd",
-    hipLaunchKernelGGL(mha_bwd_dq_ref_k<T>, grid, dim3(256), lds1, st, (const T*)qkv, key_mask, (const T*)out, (const T*)dout, lse, (T*)dqkv, B, H, S, dh, scale);
-    hipLaunchKernelGGL(mha_bwd_dkv_ref_k<T>, grid, dim3(256), lds2, st, (const T*)qkv, key_mask, (const T*)out, (const T*)dout, lse, (T*)dqkv, B, H, S, dh, scale);)
+    hipLaunchKernelGGL(mha_bwd_dq_ref_k<T>, grid, dim3(256), lds1, st, (const T*)qkv, key_mask, (const T*)out, (const T*)dout, lse, (T*)dqkv, B, H, S, dh, scale, drop_p, drop_seed);
+    hipLaunchKernelGGL(mha_bwd_dkv_ref_k<T>, grid, dim3(256), lds2, st, (const T*)qkv, key_mask, (const T*)out, (const T*)dout, lse, (T*)dqkv, B, H, S, dh, scale, drop_p, drop_seed);)
   MMRCA_CHECK_LAUNCH("mha_bwd(ref)");
   return 0;
 }

@@ -12,7 +12,9 @@ template <typename T>
 __global__ void __launch_bounds__(256)
 add_ln_fwd_k(const T* __restrict__ x, const T* __restrict__ res, const T* __restrict__ gamma, const T* __restrict__ beta,
              T* __restrict__ sum_out, T* __restrict__ y, float* __restrict__ mean, float* __restrict__ rstd,
-             int64_t rows, int D, int64_t ld_x, int64_t ld_y, float eps) {
+             int64_t rows, int D, int64_t ld_x, int64_t ld_y, float eps, float in_p, uint64_t in_seed, float out_p,
+             uint64_t out_seed) {
+  const float in_sc = in_p > 0.f ? 1.f / (1.f - in_p) : 1.f, out_sc = out_p > 0.f ? 1.f / (1.f - out_p) : 1.f;
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   for (int64_t row = (int64_t)blockIdx.x * 4 + wave; row < rows; row += (int64_t)gridDim.x * 4) {
     float v[LN_MAXV][4];
@@ -22,6 +24,10 @@ add_ln_fwd_k(const T* __restrict__ x, const T* __restrict__ res, const T* __rest
       const int c = it * 256 + lane * 4;
       if (c < D) {
         Vec4<T> a = Vec4<T>::load(x + row * ld_x + c);
+        if (in_p > 0.f) {      // dropout on the branch before the residual add (FFN / attention output dropout)
+#pragma unroll
+          for (int j = 0; j < 4; ++j) a.v[j] = mmrca_uniform(in_seed, (uint64_t)row * D + c + j) >= in_p ? a.v[j] * in_sc : 0.f;
+        }
         if (res) {
           Vec4<T> r = Vec4<T>::load(res + row * ld_x + c);
 #pragma unroll
@@ -56,6 +62,10 @@ add_ln_fwd_k(const T* __restrict__ x, const T* __restrict__ res, const T* __rest
         Vec4<T> g = Vec4<T>::load(gamma + c), b = Vec4<T>::load(beta + c), o;
 #pragma unroll
         for (int j = 0; j < 4; ++j) o.v[j] = (v[it][j] - mu) * rs * g.v[j] + b.v[j];
+        if (out_p > 0.f) {     // dropout on the normalised output (embedding dropout)
+#pragma unroll
+          for (int j = 0; j < 4; ++j) o.v[j] = mmrca_uniform(out_seed, (uint64_t)row * D + c + j) >= out_p ? o.v[j] * out_sc : 0.f;
+        }
         o.store(y + row * ld_y + c);
       }
     }
@@ -64,7 +74,9 @@ add_ln_fwd_k(const T* __restrict__ x, const T* __restrict__ res, const T* __rest
 
 extern "C" int mmrca_add_layernorm_fwd(const void* x, const void* res, const void* gamma, const void* beta,
                                        void* sum_out, void* y, float* mean, float* rstd, int64_t rows, int D,
-                                       int64_t ld_x, int64_t ld_y, float eps, int dtype, void* stream) {
+                                       int64_t ld_x, int64_t ld_y, float eps, float in_drop_p, uint64_t in_drop_seed,
+                                       float out_drop_p, uint64_t out_drop_seed, int dtype, void* stream) {
+  MMRCA_REQUIRE(in_drop_p >= 0.f && in_drop_p < 1.f && out_drop_p >= 0.f && out_drop_p < 1.f, "add_layernorm_fwd: dropout p must be in [0,1)");
   MMRCA_REQUIRE(x && gamma && beta && y, "add_layernorm_fwd: null pointer");
   MMRCA_REQUIRE(D > 0 && D % 4 == 0 && D <= 256 * LN_MAXV, "add_layernorm_fwd: D=%d unsupported (multiple of 4, <= %d)", D, 256 * LN_MAXV);
   MMRCA_REQUIRE(ld_x >= D && ld_y >= D && ld_x % 4 == 0 && ld_y % 4 == 0, "add_layernorm_fwd: bad leading dims");
@@ -72,7 +84,8 @@ extern "C" int mmrca_add_layernorm_fwd(const void* x, const void* res, const voi
   const int grid = (int)((rows + 3) / 4 < 4096 ? (rows + 3) / 4 : 4096);
   MMRCA_DISPATCH_DTYPE(dtype, "add_layernorm_fwd",
     hipLaunchKernelGGL(add_ln_fwd_k<T>, dim3(grid), dim3(256), 0, (hipStream_t)stream, (const T*)x, (const T*)res,
-                       (const T*)gamma, (const T*)beta, (T*)sum_out, (T*)y, mean, rstd, rows, D, ld_x, ld_y, eps);)
+                       (const T*)gamma, (const T*)beta, (T*)sum_out, (T*)y, mean, rstd, rows, D, ld_x, ld_y, eps, in_drop_p, in_drop_seed,
+                       out_drop_p, out_drop_seed);)
   MMRCA_CHECK_LAUNCH("add_layernorm_fwd");
   return 0;
 }
@@ -85,7 +98,9 @@ template <typename T>
 __global__ void __launch_bounds__(256)
 ln_bwd_k(const T* __restrict__ dy, const T* __restrict__ s, const T* __restrict__ gamma, const float* __restrict__ mean,
          const float* __restrict__ rstd, const T* __restrict__ dres, T* __restrict__ ds, float* __restrict__ dgamma,
-         float* __restrict__ dbeta, int64_t rows, int D, int64_t ld_dy, int64_t ld_s, int64_t ld_ds) {
+         float* __restrict__ dbeta, int64_t rows, int D, int64_t ld_dy, int64_t ld_s, int64_t ld_ds, float dy_p,
+         uint64_t dy_seed, float br_p, uint64_t br_seed, T* __restrict__ dbranch) {
+  const float dy_sc = dy_p > 0.f ? 1.f / (1.f - dy_p) : 1.f, br_sc = br_p > 0.f ? 1.f / (1.f - br_p) : 1.f;
   __shared__ float red[2][4][256 * 4 + 4];   // [dgamma|dbeta][wave][col chunk]; reduced one `it` slab at a time
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   float adg[LN_MAXV][4], adb[LN_MAXV][4];
@@ -102,6 +117,10 @@ ln_bwd_k(const T* __restrict__ dy, const T* __restrict__ s, const T* __restrict_
       const int c = it * 256 + lane * 4;
       if (c < D) {
         Vec4<T> d = Vec4<T>::load(dy + row * ld_dy + c), sv = Vec4<T>::load(s + row * ld_s + c), gm = Vec4<T>::load(gamma + c);
+        if (dy_p > 0.f) {      // the forward dropped the normalised output: mask the incoming gradient the same way
+#pragma unroll
+          for (int j = 0; j < 4; ++j) d.v[j] = mmrca_uniform(dy_seed, (uint64_t)row * D + c + j) >= dy_p ? d.v[j] * dy_sc : 0.f;
+        }
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
           const float xhat = (sv.v[j] - mu) * rs;
@@ -120,6 +139,13 @@ ln_bwd_k(const T* __restrict__ dy, const T* __restrict__ s, const T* __restrict_
         Vec4<T> o;
 #pragma unroll
         for (int j = 0; j < 4; ++j) o.v[j] = rs * (g[it][j] - s1 - xh[it][j] * s2);
+        if (dbranch) {         // gradient of the dropped branch (before the residual-stream gradient is added)
+          Vec4<T> ob;
+#pragma unroll
+          for (int j = 0; j < 4; ++j)
+            ob.v[j] = (br_p > 0.f && mmrca_uniform(br_seed, (uint64_t)row * D + c + j) < br_p) ? 0.f : o.v[j] * br_sc;
+          ob.store(dbranch + row * ld_ds + c);
+        }
         if (dres) {
           Vec4<T> r = Vec4<T>::load(dres + row * ld_ds + c);
 #pragma unroll
@@ -149,7 +175,9 @@ ln_bwd_k(const T* __restrict__ dy, const T* __restrict__ s, const T* __restrict_
 
 extern "C" int mmrca_layernorm_bwd(const void* dy, const void* s, const void* gamma, const float* mean, const float* rstd,
                                    const void* dres, void* ds, float* dgamma, float* dbeta, int64_t rows, int D,
-                                   int64_t ld_dy, int64_t ld_s, int64_t ld_ds, int dtype, void* stream) {
+                                   int64_t ld_dy, int64_t ld_s, int64_t ld_ds, float dy_drop_p, uint64_t dy_drop_seed,
+                                   float branch_drop_p, uint64_t branch_drop_seed, void* dbranch, int dtype, void* stream) {
+  MMRCA_REQUIRE(dy_drop_p >= 0.f && dy_drop_p < 1.f && branch_drop_p >= 0.f && branch_drop_p < 1.f, "layernorm_bwd: dropout p must be in [0,1)");
   MMRCA_REQUIRE(dy && s && gamma && mean && rstd && ds, "layernorm_bwd: null pointer");
   MMRCA_REQUIRE(D > 0 && D % 4 == 0 && D <= 256 * LN_MAXV, "layernorm_bwd: D=%d unsupported", D);
   MMRCA_REQUIRE(ld_dy >= D && ld_s >= D && ld_ds >= D && ld_dy % 4 == 0 && ld_s % 4 == 0 && ld_ds % 4 == 0, "layernorm_bwd: bad leading dims");
@@ -158,7 +186,8 @@ extern "C" int mmrca_layernorm_bwd(const void* dy, const void* s, const void* ga
   const int grid = (int)(want < 1024 ? want : 1024);
   MMRCA_DISPATCH_DTYPE(dtype, "layernorm_bwd",
     hipLaunchKernelGGL(ln_bwd_k<T>, dim3(grid), dim3(256), 0, (hipStream_t)stream, (const T*)dy, (const T*)s, (const T*)gamma,
-                       mean, rstd, (const T*)dres, (T*)ds, dgamma, dbeta, rows, D, ld_dy, ld_s, ld_ds);)
+                       mean, rstd, (const T*)dres, (T*)ds, dgamma, dbeta, rows, D, ld_dy, ld_s, ld_ds, dy_drop_p, dy_drop_seed,
+                       branch_drop_p, branch_drop_seed, (T*)dbranch);)
   MMRCA_CHECK_LAUNCH("layernorm_bwd");
   return 0;
 }

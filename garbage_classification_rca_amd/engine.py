@@ -252,16 +252,21 @@ class MMRCAEngine:
             if gelu_h is not None and not fuse:
                 L.gelu_bwd(dx, gelu_h, dx, M * K, self.dt)
 
-    def _ln_fwd(self, x, res, pfx, sum_out, y, mean, rstd, rows, D, eps, ld_x=None, ld_y=None):
+    def _ln_fwd(self, x, res, pfx, sum_out, y, mean, rstd, rows, D, eps, ld_x=None, ld_y=None, in_drop=(0.0, 0), out_drop=(0.0, 0)):
         L.add_layernorm_fwd(x, res, self.W(pfx + ".weight"), self.W(pfx + ".bias"), sum_out, y, mean, rstd, rows, D,
-                            ld_x or D, ld_y or D, eps, self.dt)
+                            ld_x or D, ld_y or D, eps, self.dt, in_drop=in_drop, out_drop=out_drop)
 
-    def _ln_bwd(self, dy, s, pfx, mean, rstd, dres, ds, rows, D, ld_dy=None, ld_s=None, ld_ds=None):
+    def _ln_bwd(self, dy, s, pfx, mean, rstd, dres, ds, rows, D, ld_dy=None, ld_s=None, ld_ds=None, dy_drop=(0.0, 0),
+                branch_drop=(0.0, 0), dbranch=None):
         L.layernorm_bwd(dy, s, self.W(pfx + ".weight"), mean, rstd, dres, ds, self.G(pfx + ".weight"), self.G(pfx + ".bias"),
-                        rows, D, ld_dy or D, ld_s or D, ld_ds or D, self.dt)
+                        rows, D, ld_dy or D, ld_s or D, ld_ds or D, self.dt, dy_drop=dy_drop, branch_drop=branch_drop, dbranch=dbranch)
+
+    @staticmethod
+    def _site_seed(base: int, layer: int, site: int) -> int:
+        return (base * 1000003 + layer * 16 + site + 0x9E3779B97F4A7C15) & 0xFFFFFFFFFFFFFFFF
 
     # ------------------------------------------------------------------ text encoder
-    def _text_forward(self, ids, mask, save):
+    def _text_forward(self, ids, mask, save, drop_p: float = 0.0, drop_seed: int = 0):
         s, P = self.ts, "text_model."
         B, T = ids.shape
         M, D, Fd, H = B * T, s.dim, s.ffn, s.heads
@@ -281,29 +286,33 @@ class MMRCAEngine:
                     type_row, emb, M, D, self.dt)
         x = fb("x", D, 0)
         mean0, rstd0 = stat("mean0"), stat("rstd0")
-        self._ln_fwd(emb, None, P + "embeddings.LayerNorm", None, x, mean0, rstd0, M, D, s.ln_eps)
+        dp = float(drop_p)
+        sd = lambda layer, site: self._site_seed(drop_seed, layer, site)
+        post_attn_drop = dp if s.name != "distilbert" else 0.0     # BertSelfOutput drops the attention output, DistilBERT does not
+        self._ln_fwd(emb, None, P + "embeddings.LayerNorm", None, x, mean0, rstd0, M, D, s.ln_eps, out_drop=(dp, sd(0, 0)))
         layers = []
         for i in range(s.layers):
             K = S.text_layer_keys(s, i)
             qkv, ctx, lse = fb("qkv", 3 * D, i), fb("ctx", D, i), self.buf("t_lse", 1, _round_up(B * H * T, ROWPAD), torch.float32, i if save else 0)
             self._lin_fwd(x, P + K["q"] + ".weight", P + K["q"] + ".bias", qkv, M, 3 * D, D, wnumel=3 * D * D)
-            L.mha_fwd(qkv, mask32, ctx, lse, B, H, T, dh, dh ** -0.5, self.dt, self.attn_impl)
+            L.mha_fwd(qkv, mask32, ctx, lse, B, H, T, dh, dh ** -0.5, self.dt, self.attn_impl, drop_p=dp, drop_seed=sd(i, 1))
             att = fb("tmpD", D)
             self._lin_fwd(ctx, P + K["o"] + ".weight", P + K["o"] + ".bias", att, M, D, D)
             s1, x1 = fb("s1", D, i), fb("x1", D, i)
             m1, r1 = stat("m1", i), stat("r1", i)
-            self._ln_fwd(att, x, P + K["ln1"], s1, x1, m1, r1, M, D, s.ln_eps)
+            self._ln_fwd(att, x, P + K["ln1"], s1, x1, m1, r1, M, D, s.ln_eps, in_drop=(post_attn_drop, sd(i, 2)))
             h, g = fb("h", Fd, i), fb("g", Fd, i)
             self._lin_fwd(x1, P + K["f1"] + ".weight", P + K["f1"] + ".bias", g, M, Fd, D, act=(L.ACT_GELU_SAVE_GRAD if FUSE_GELU_GRAD else L.ACT_GELU), preact=h)   # fused mode: h <- gelu'(pre-activation)
             f = fb("tmpD", D)
             self._lin_fwd(g, P + K["f2"] + ".weight", P + K["f2"] + ".bias", f, M, D, Fd)
             s2, xn = fb("s2", D, i), fb("x", D, i + 1)
             m2, r2 = stat("m2", i), stat("r2", i)
-            self._ln_fwd(f, x1, P + K["ln2"], s2, xn, m2, r2, M, D, s.ln_eps)
+            self._ln_fwd(f, x1, P + K["ln2"], s2, xn, m2, r2, M, D, s.ln_eps, in_drop=(dp, sd(i, 3)))
             layers.append(dict(x=x, qkv=qkv, ctx=ctx, lse=lse, s1=s1, x1=x1, m1=m1, r1=r1, h=h, g=g, s2=s2, m2=m2, r2=r2))
             x = xn
         cls = x[:M].view(B, T, D)[:, 0].contiguous()
-        return cls, dict(B=B, T=T, ids32=ids32, pos=pos, mask32=mask32, emb=emb, mean0=mean0, rstd0=rstd0, layers=layers)
+        return cls, dict(B=B, T=T, ids32=ids32, pos=pos, mask32=mask32, emb=emb, mean0=mean0, rstd0=rstd0, layers=layers,
+                         drop_p=dp, drop_seed=drop_seed)
 
     def _text_backward(self, dcls, sv):
         s, P = self.ts, "text_model."
@@ -317,21 +326,27 @@ class MMRCAEngine:
         for i in reversed(range(s.layers)):
             K, a = S.text_layer_keys(s, i), sv["layers"][i]
             ds2 = gb("ds2", D)
-            self._ln_bwd(dx, a["s2"], P + K["ln2"], a["m2"], a["r2"], None, ds2, M, D)
+            dp, sd = sv["drop_p"], (lambda layer, site: self._site_seed(sv["drop_seed"], layer, site))
+            post_attn_drop = dp if s.name != "distilbert" else 0.0
+            df = gb("dbr", D) if dp > 0 else None          # gradient of the dropped FFN branch
+            self._ln_bwd(dx, a["s2"], P + K["ln2"], a["m2"], a["r2"], None, ds2, M, D, branch_drop=(dp, sd(i, 3)), dbranch=df)
             dg = gb("dF", Fd)
-            self._lin_bwd(ds2, a["g"], P + K["f2"] + ".weight", P + K["f2"] + ".bias", dg, M, D, Fd, gelu_h=a["h"])
+            self._lin_bwd(df if df is not None else ds2, a["g"], P + K["f2"] + ".weight", P + K["f2"] + ".bias", dg, M, D, Fd, gelu_h=a["h"])
             dx1 = gb("dxB", D)
             self._lin_bwd(dg, a["x1"], P + K["f1"] + ".weight", P + K["f1"] + ".bias", dx1, M, Fd, D, addend=ds2)
             ds1 = gb("ds1", D)
-            self._ln_bwd(dx1, a["s1"], P + K["ln1"], a["m1"], a["r1"], None, ds1, M, D)
+            datt = gb("dbr", D) if post_attn_drop > 0 else None
+            self._ln_bwd(dx1, a["s1"], P + K["ln1"], a["m1"], a["r1"], None, ds1, M, D, branch_drop=(post_attn_drop, sd(i, 2)), dbranch=datt)
             dctx = gb("dctx", D)
-            self._lin_bwd(ds1, a["ctx"], P + K["o"] + ".weight", P + K["o"] + ".bias", dctx, M, D, D)
+            self._lin_bwd(datt if datt is not None else ds1, a["ctx"], P + K["o"] + ".weight", P + K["o"] + ".bias", dctx, M, D, D)
             dqkv = gb("dqkv", 3 * D)
-            L.mha_bwd(a["qkv"], sv["mask32"], a["ctx"], dctx, a["lse"], dqkv, B, H, T, dh, dh ** -0.5, self.dt, self.attn_impl)
+            L.mha_bwd(a["qkv"], sv["mask32"], a["ctx"], dctx, a["lse"], dqkv, B, H, T, dh, dh ** -0.5, self.dt, self.attn_impl,
+                      drop_p=dp, drop_seed=sd(i, 1))
             self._lin_bwd(dqkv, a["x"], P + K["q"] + ".weight", P + K["q"] + ".bias", dx, M, 3 * D, D, addend=ds1, wnumel=3 * D * D)
             self._ready(f"text_layer_{i}")
         ds0 = gb("ds2", D)
-        self._ln_bwd(dx, sv["emb"], P + "embeddings.LayerNorm", sv["mean0"], sv["rstd0"], None, ds0, M, D)
+        self._ln_bwd(dx, sv["emb"], P + "embeddings.LayerNorm", sv["mean0"], sv["rstd0"], None, ds0, M, D,
+                     dy_drop=(sv["drop_p"], self._site_seed(sv["drop_seed"], 0, 0)))
         dtype_row = self.Gflat(P + "embeddings.token_type_embeddings.weight", D) if s.type_vocab else None
         L.embed_bwd(ds0, sv["ids32"], sv["pos"], self.G(P + "embeddings.word_embeddings.weight"),
                     self.G(P + "embeddings.position_embeddings.weight"), dtype_row, M, D, self.dt)
@@ -412,14 +427,14 @@ class MMRCAEngine:
         self._ready("image_emb", flush=True)
 
     # ------------------------------------------------------------------ whole model
-    def forward(self, ids, mask, images, drop_p: float = 0.0, seed: int = 0, save: bool = True):
+    def forward(self, ids, mask, images, drop_p: float = 0.0, seed: int = 0, save: bool = True, enc_drop_p: float = 0.0):
         """ids/mask int64 [B,S] and images fp32 [B,3,H,W] in HBM -> logits fp32 [B, n_classes]."""
         for t, nm in ((ids, "input ids"), (mask, "attention mask"), (images, "images")):
             if not t.is_cuda:
                 raise L.MmrcaError(f"{nm} must be in HBM; the MM-RCA product path has no CPU fallback")
         self.refresh_working_copy()
         B = ids.shape[0]
-        cls, tsv = self._text_forward(ids, mask, save)
+        cls, tsv = self._text_forward(ids, mask, save, enc_drop_p, int(seed))
         feat, vsv = self._vision_forward(images, save)
         logits = torch.empty(B, self.n_classes, dtype=torch.float32, device=self.device)
         L.head_fwd(feat, cls, self._head_w, logits, B, self.d_img, self.d_txt, self.n_classes, self.reverse, self.mode,

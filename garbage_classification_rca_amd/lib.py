@@ -51,10 +51,10 @@ _SIGS = {
     "mmrca_gemm": [_vp] * 6 + [_i64] * 6 + [_i32] * 6 + [_vp],
     "mmrca_colsum_accum": [_vp, _vp, _i64, _i64, _i64, _i32, _vp],
     "mmrca_gelu_bwd": [_vp, _vp, _vp, _i64, _i32, _vp],
-    "mmrca_mha_fwd": [_vp] * 4 + [_i32] * 4 + [_f32, _i32, _i32, _vp],
-    "mmrca_mha_bwd": [_vp] * 6 + [_i32] * 4 + [_f32, _i32, _i32, _vp],
-    "mmrca_add_layernorm_fwd": [_vp] * 8 + [_i64, _i32, _i64, _i64, _f32, _i32, _vp],
-    "mmrca_layernorm_bwd": [_vp] * 9 + [_i64, _i32, _i64, _i64, _i64, _i32, _vp],
+    "mmrca_mha_fwd": [_vp] * 4 + [_i32] * 4 + [_f32, _f32, _u64, _i32, _i32, _vp],
+    "mmrca_mha_bwd": [_vp] * 6 + [_i32] * 4 + [_f32, _f32, _u64, _i32, _i32, _vp],
+    "mmrca_add_layernorm_fwd": [_vp] * 8 + [_i64, _i32, _i64, _i64, _f32, _f32, _u64, _f32, _u64, _i32, _vp],
+    "mmrca_layernorm_bwd": [_vp] * 9 + [_i64, _i32, _i64, _i64, _i64, _f32, _u64, _f32, _u64, _vp, _i32, _vp],
     "mmrca_embed_fwd": [_vp] * 6 + [_i64, _i32, _i32, _vp],
     "mmrca_embed_bwd": [_vp] * 6 + [_i64, _i32, _i32, _vp],
     "mmrca_patchify_fwd": [_vp, _vp] + [_i32] * 6 + [_vp],
@@ -149,25 +149,30 @@ def gelu_bwd(dG, H, dH, n, dtype):
     _check(load().mmrca_gelu_bwd(ptr(dG), ptr(H), ptr(dH), n, dtype, stream_ptr()), "mmrca_gelu_bwd")
 
 
-def mha_fwd(qkv, key_mask, out, lse, B, H, S, dh, scale, dtype, impl=IMPL_AUTO):
+def mha_fwd(qkv, key_mask, out, lse, B, H, S, dh, scale, dtype, impl=IMPL_AUTO, drop_p=0.0, drop_seed=0):
     _dev(qkv, "mha qkv")
-    _check(load().mmrca_mha_fwd(ptr(qkv), ptr(key_mask), ptr(out), ptr(lse), B, H, S, dh, scale, dtype, impl, stream_ptr()), "mmrca_mha_fwd")
+    _check(load().mmrca_mha_fwd(ptr(qkv), ptr(key_mask), ptr(out), ptr(lse), B, H, S, dh, scale, drop_p, drop_seed, dtype,
+                                impl, stream_ptr()), "mmrca_mha_fwd")
 
 
-def mha_bwd(qkv, key_mask, out, dout, lse, dqkv, B, H, S, dh, scale, dtype, impl=IMPL_AUTO):
-    _check(load().mmrca_mha_bwd(ptr(qkv), ptr(key_mask), ptr(out), ptr(dout), ptr(lse), ptr(dqkv), B, H, S, dh, scale, dtype,
-                                impl, stream_ptr()), "mmrca_mha_bwd")
+def mha_bwd(qkv, key_mask, out, dout, lse, dqkv, B, H, S, dh, scale, dtype, impl=IMPL_AUTO, drop_p=0.0, drop_seed=0):
+    _check(load().mmrca_mha_bwd(ptr(qkv), ptr(key_mask), ptr(out), ptr(dout), ptr(lse), ptr(dqkv), B, H, S, dh, scale,
+                                drop_p, drop_seed, dtype, impl, stream_ptr()), "mmrca_mha_bwd")
 
 
-def add_layernorm_fwd(x, res, gamma, beta, sum_out, y, mean, rstd, rows, D, ld_x, ld_y, eps, dtype):
+def add_layernorm_fwd(x, res, gamma, beta, sum_out, y, mean, rstd, rows, D, ld_x, ld_y, eps, dtype,
+                      in_drop=(0.0, 0), out_drop=(0.0, 0)):
     _dev(x, "layernorm x")
     _check(load().mmrca_add_layernorm_fwd(ptr(x), ptr(res), ptr(gamma), ptr(beta), ptr(sum_out), ptr(y), ptr(mean), ptr(rstd),
-                                          rows, D, ld_x, ld_y, eps, dtype, stream_ptr()), "mmrca_add_layernorm_fwd")
+                                          rows, D, ld_x, ld_y, eps, in_drop[0], in_drop[1], out_drop[0], out_drop[1],
+                                          dtype, stream_ptr()), "mmrca_add_layernorm_fwd")
 
 
-def layernorm_bwd(dy, s, gamma, mean, rstd, dres, ds, dgamma, dbeta, rows, D, ld_dy, ld_s, ld_ds, dtype):
+def layernorm_bwd(dy, s, gamma, mean, rstd, dres, ds, dgamma, dbeta, rows, D, ld_dy, ld_s, ld_ds, dtype,
+                  dy_drop=(0.0, 0), branch_drop=(0.0, 0), dbranch=None):
     _check(load().mmrca_layernorm_bwd(ptr(dy), ptr(s), ptr(gamma), ptr(mean), ptr(rstd), ptr(dres), ptr(ds), ptr(dgamma),
-                                      ptr(dbeta), rows, D, ld_dy, ld_s, ld_ds, dtype, stream_ptr()), "mmrca_layernorm_bwd")
+                                      ptr(dbeta), rows, D, ld_dy, ld_s, ld_ds, dy_drop[0], dy_drop[1], branch_drop[0],
+                                      branch_drop[1], ptr(dbranch), dtype, stream_ptr()), "mmrca_layernorm_bwd")
 
 
 def embed_fwd(ids, pos_ids, word, pos, type_row, out, rows, D, dtype):

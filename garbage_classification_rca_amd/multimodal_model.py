@@ -12,7 +12,8 @@ Differences from the reference, all additive:
 * ``image_model_name`` (11th argument; the reference ignores ``--image_model`` and hard-codes EfficientNetV2-M,
   main_both.py:259).  HIP backbones today: ``transformer_B16`` and ``transformer_L16``.
 * ``dtype`` (torch.bfloat16 default; torch.float32 = parity mode).
-* encoder dropout (0.1 inside DistilBERT in train mode) is not applied yet -- see DESIGN.md "known gaps".
+* train-mode dropout (head p=model_dropout; text encoder p=0.1 on embeddings / attention probabilities / FFN output)
+  uses counter-based masks instead of torch's Philox stream: same distribution, different random bits.
 """
 from __future__ import annotations
 
@@ -77,14 +78,14 @@ class HashingTokenizer:
 
 class _EngineFunction(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, anchor, module, ids, mask, images, drop_p, seed, save):
+    def forward(ctx, anchor, module, ids, mask, images, drop_p, seed, save, enc_p):
         ctx.module = module
-        return module.engine.forward(ids, mask, images, drop_p, seed, save=save)
+        return module.engine.forward(ids, mask, images, drop_p, seed, save=save, enc_drop_p=enc_p)
 
     @staticmethod
     def backward(ctx, dlogits):
         ctx.module._engine_backward(dlogits)
-        return (None,) * 8
+        return (None,) * 9
 
 
 class EffV2MediumAndDistilbertGated(torch.nn.Module):
@@ -107,6 +108,9 @@ class EffV2MediumAndDistilbertGated(torch.nn.Module):
         self.engine = MMRCAEngine(text_model_name, image_model_name, n_classes, reverse, mode, dtype, device)
         self.engine.init_parameters(init_seed)
         self.drop_ratio = float(drop_ratio)
+        # train-mode dropout inside the HF text encoders (DistilBertConfig.dropout = attention_dropout = 0.1; torchvision's
+        # ViT defaults are 0.0, so the image encoder has none)
+        self.enc_dropout = 0.1
         self.image_or_text_dropout_chance = image_or_text_dropout_chance
         self.img_dropout_prob = img_prob_dropout
         self.fc_layer_neurons, self.batch_size, self.n_classes = num_neurons_fc, batch_size, n_classes
@@ -240,5 +244,6 @@ class MM_RCA(EffV2MediumAndDistilbertGated):
         need_grad = torch.is_grad_enabled()
         tt, ti = self._train_flags()
         logits = _EngineFunction.apply(self._anchor, self, self._input_ids, self._attention_mask, self._images,
-                                       drop_p, self._drop_seed + self._fwd_count, bool(need_grad and (tt or ti)))
+                                       drop_p, self._drop_seed + self._fwd_count, bool(need_grad and (tt or ti)),
+                                       self.enc_dropout if self.training else 0.0)
         return logits

@@ -79,3 +79,15 @@ def synth_captions(n: int, seq_len: int, seed: int, vocab_lo: int = 1000, vocab_
         ids[i, L - 1] = sep_id
         mask[i, :L] = 1
     return ids, mask
+
+
+def counter_uniform(seed: int, idx: np.ndarray) -> np.ndarray:
+    """Host mirror of the device's counter-based uniform (csrc/common.h::mmrca_uniform, splitmix64): lets tests rebuild
+    the exact dropout masks of the kernels."""
+    idx = np.asarray(idx, dtype=np.uint64)
+    with np.errstate(over="ignore"):
+        z = np.uint64(seed & 0xFFFFFFFFFFFFFFFF) + np.uint64(0x9E3779B97F4A7C15) * (idx + np.uint64(1))
+        z = (z ^ (z >> np.uint64(30))) * np.uint64(0xBF58476D1CE4E5B9)
+        z = (z ^ (z >> np.uint64(27))) * np.uint64(0x94D049BB133111EB)
+        z = z ^ (z >> np.uint64(31))
+    return (z >> np.uint64(40)).astype(np.float32) * np.float32(1.0 / 16777216.0)

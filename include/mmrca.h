@@ -63,22 +63,34 @@ int mmrca_gelu_bwd(const void* dG, const void* H, void* dH, int64_t n, int dtype
 /* K3. Multi-head attention over a fused QKV buffer [B*S, 3*H*dh] (q | k | v column blocks; head h at
  * columns h*dh).  out[B*S, H*dh].  key_mask (optional): int32 [B,S], 0 = masked key; a query row whose
  * keys are all masked yields zeros (torch SDPA semantics used by transformers 5.x).  lse: fp32 [B,H,S].
- * Replaces modeling_distilbert.py:122-203 / torchvision MultiheadAttention (QK^T*scale, softmax, PV). */
+ * Replaces modeling_distilbert.py:122-203 / torchvision MultiheadAttention (QK^T*scale, softmax, PV).
+ * drop_p > 0: attention-probability dropout (modeling_distilbert.py:146), mask from (seed, ((b*H+h)*S+q)*S+key). */
 int mmrca_mha_fwd(const void* qkv, const int32_t* key_mask, void* out, float* lse,
-                  int B, int H, int S, int dh, float scale, int dtype, int impl, void* stream);
+                  int B, int H, int S, int dh, float scale, float drop_p, uint64_t drop_seed,
+                  int dtype, int impl, void* stream);
 int mmrca_mha_bwd(const void* qkv, const int32_t* key_mask, const void* out, const void* dout, const float* lse,
-                  void* dqkv, int B, int H, int S, int dh, float scale, int dtype, int impl, void* stream);
+                  void* dqkv, int B, int H, int S, int dh, float scale, float drop_p, uint64_t drop_seed,
+                  int dtype, int impl, void* stream);
 
 /* K4. s = x (+ res);  y = LayerNorm(s) * gamma + beta.  sum_out (optional) receives s.  mean/rstd fp32 [rows].
  * Row r of x/res/sum_out/y starts at r*ld_* elements (lets the ViT final norm run on class tokens only).
- * nn.LayerNorm at modeling_distilbert.py:98,240,247 (eps 1e-12), torchvision ln_1/ln_2/encoder.ln (1e-6). */
+ * nn.LayerNorm at modeling_distilbert.py:98,240,247 (eps 1e-12), torchvision ln_1/ln_2/encoder.ln (1e-6).
+ * Train-mode dropout of the HF encoders is fused here with counter-based masks (seed, row*D+col), inverted scaling:
+ *   in_drop  : s = dropout(x) + res   (FFN-output / attention-output dropout, modeling_distilbert.py:222)
+ *   out_drop : y = dropout(LayerNorm(s))   (embedding dropout, modeling_distilbert.py:117) */
 int mmrca_add_layernorm_fwd(const void* x, const void* res, const void* gamma, const void* beta,
                             void* sum_out, void* y, float* mean, float* rstd,
-                            int64_t rows, int D, int64_t ld_x, int64_t ld_y, float eps, int dtype, void* stream);
-/* ds = LN'(dy) (+ dres);  dgamma/dbeta (fp32) += .   s is the saved LayerNorm input. */
+                            int64_t rows, int D, int64_t ld_x, int64_t ld_y, float eps,
+                            float in_drop_p, uint64_t in_drop_seed, float out_drop_p, uint64_t out_drop_seed,
+                            int dtype, void* stream);
+/* ds = LN'(dy) (+ dres);  dgamma/dbeta (fp32) += .   s is the saved LayerNorm input.
+ * dy_drop: mask dy like the forward's out_drop.  dbranch (optional) = dropout-mask(LN'(dy)) with (branch_drop_p, seed):
+ * the gradient of the branch that the forward's in_drop dropped (ds itself stays the residual-stream gradient). */
 int mmrca_layernorm_bwd(const void* dy, const void* s, const void* gamma, const float* mean, const float* rstd,
                         const void* dres, void* ds, float* dgamma, float* dbeta,
-                        int64_t rows, int D, int64_t ld_dy, int64_t ld_s, int64_t ld_ds, int dtype, void* stream);
+                        int64_t rows, int D, int64_t ld_dy, int64_t ld_s, int64_t ld_ds,
+                        float dy_drop_p, uint64_t dy_drop_seed, float branch_drop_p, uint64_t branch_drop_seed,
+                        void* dbranch, int dtype, void* stream);
 
 /* K5a. text embeddings: out[r] = word[ids[r]] + pos[pos_ids[r]] (+ type_row)   (modeling_distilbert.py:82-118,
  * BertEmbeddings; LayerNorm follows via mmrca_add_layernorm_fwd).  ids/pos_ids int32 [rows]. */

@@ -195,6 +195,7 @@ def test_module_facade_state_dict_and_autograd():
     ids, mask, images = _inputs(2, 16)
     ids, mask, images = ids.cuda(), mask.cuda(), images.cuda()
     m.train()
+    m.enc_dropout = 0.0          # exact 2x accumulation check below needs identical forwards
     crit = torch.nn.CrossEntropyLoss()
     labels = torch.tensor([1, 3]).cuda()
     out = m(_input_ids=ids, _attention_mask=mask, _images=images)
@@ -220,3 +221,25 @@ def test_module_facade_state_dict_and_autograd():
         a = m(ids, mask, images, eval=True, remove_image=True)
         b = m(ids, mask, torch.zeros_like(images), eval=True)
     assert torch.equal(a, b)
+
+
+def test_encoder_dropout_runs_and_is_seed_deterministic():
+    """Text-encoder dropout (p=0.1 in train mode): same seed -> identical logits and gradients, different seed -> different;
+    expectation over seeds approaches the no-dropout logits."""
+    eng = MMRCAEngine("distilbert", "transformer_B16", 4, True, 0, torch.bfloat16)
+    eng.load_arrays(proc_state_for(eng))
+    ids, mask, images = _inputs(4, 32)
+    ids, mask, images = ids.cuda(), mask.cuda(), images.cuda()
+    l0 = eng.forward(ids, mask, images).clone()
+    la = eng.forward(ids, mask, images, enc_drop_p=0.1, seed=5).clone()
+    dl = torch.randn(4, 4, device="cuda") * 0.1
+    eng.arena.g.zero_(); eng.backward(dl); ga = eng.arena.g.clone()
+    lb = eng.forward(ids, mask, images, enc_drop_p=0.1, seed=5).clone()
+    eng.arena.g.zero_(); eng.backward(dl); gb = eng.arena.g.clone()
+    lc = eng.forward(ids, mask, images, enc_drop_p=0.1, seed=6).clone()
+    assert torch.equal(la, lb) and not torch.equal(la, lc) and not torch.equal(la, l0)
+    text_hi = eng.groups["image_emb"][0]
+    cos = torch.nn.functional.cosine_similarity(ga[:text_hi], gb[:text_hi], dim=0).item()
+    assert cos > 0.999            # identical masks in forward and backward (atomics reorder the fp32 sums only)
+    assert torch.isfinite(ga).all() and float(ga[:text_hi].abs().max()) > 0
+    eng.release_buffers()

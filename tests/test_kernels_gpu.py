@@ -333,6 +333,71 @@ def test_mha_fwd_bwd(dt, impl, S, masked):
 
 
 # ------------------------------------------------------------------------------------------------------
+# train-mode dropout of the text encoder (counter-based masks shared by forward and backward)
+# ------------------------------------------------------------------------------------------------------
+def _keep(seed, shape, p):
+    from garbage_classification_rca_amd.procedural import counter_uniform
+    idx = np.arange(int(np.prod(shape)), dtype=np.uint64).reshape(shape)
+    return torch.from_numpy((counter_uniform(seed, idx) >= p).astype(np.float32) / (1.0 - p)).cuda()
+
+
+def test_layernorm_dropout_fwd_bwd_match_masked_reference():
+    rows, D, eps, p = 33, 768, 1e-12, 0.1
+    x, r = dev(torch.randn(rows, D)), dev(torch.randn(rows, D))
+    g, b = dev(1 + 0.1 * torch.randn(D)), dev(0.1 * torch.randn(D))
+    s_out, y = torch.empty_like(x), torch.empty_like(x)
+    mean, rstd = torch.empty(rows, device="cuda"), torch.empty(rows, device="cuda")
+    L.add_layernorm_fwd(x, r, g, b, s_out, y, mean, rstd, rows, D, D, D, eps, L.F32, in_drop=(p, 11), out_drop=(p, 22))
+    k_in, k_out = _keep(11, (rows, D), p), _keep(22, (rows, D), p)
+    assert abs(float((k_in > 0).float().mean()) - 0.9) < 0.01
+    xr = x.clone().requires_grad_(True)
+    s_ref = xr * k_in + r
+    y_ref = F.layer_norm(s_ref, (D,), g, b, eps) * k_out
+    assert rel_err(s_out, s_ref.detach()) < 1e-5 and rel_err(y, y_ref.detach()) < 1e-5
+    dy = dev(torch.randn(rows, D))
+    y_ref.backward(dy)
+    # backward: ds (residual-stream gradient), dbranch (gradient of the dropped branch)
+    ds, dbr = torch.empty_like(x), torch.empty_like(x)
+    dg, db = torch.zeros(D, device="cuda"), torch.zeros(D, device="cuda")
+    L.layernorm_bwd(dy, s_out, g, mean, rstd, None, ds, dg, db, rows, D, D, D, D, L.F32, dy_drop=(p, 22), branch_drop=(p, 11), dbranch=dbr)
+    assert rel_err(dbr, xr.grad) < 1e-4
+    assert rel_err(ds * k_in, xr.grad) < 1e-4
+
+
+@pytest.mark.parametrize("S,masked", [(64, True), (197, False)])
+def test_attention_dropout_mfma_matches_reference_kernel_and_torch(S, masked):
+    B, H, dh, p, seed = 2, 3, 64, 0.1, 77
+    qkv = dev(torch.randn(B * S, 3 * H * dh), torch.bfloat16)
+    mask = None
+    if masked:
+        mask = torch.ones(B, S, dtype=torch.int32); mask[1, S // 3:] = 0; mask = mask.cuda()
+    sc = 1 / math.sqrt(dh)
+    outs = {}
+    for impl in (L.IMPL_REF, L.IMPL_AUTO):
+        out = torch.empty(B * S, H * dh, device="cuda", dtype=torch.bfloat16)
+        lse = torch.empty(B, H, S, device="cuda")
+        L.mha_fwd(qkv, mask, out, lse, B, H, S, dh, sc, L.BF16, impl, drop_p=p, drop_seed=seed)
+        dout = dev(torch.randn(B * S, H * dh, generator=torch.Generator().manual_seed(1)), torch.bfloat16)
+        dqkv = torch.zeros_like(qkv)
+        L.mha_bwd(qkv, mask, out, dout, lse, dqkv, B, H, S, dh, sc, L.BF16, impl, drop_p=p, drop_seed=seed)
+        outs[impl] = (out.float(), dqkv.float())
+    assert rel_err(outs[L.IMPL_AUTO][0], outs[L.IMPL_REF][0]) < 2e-2
+    assert rel_err(outs[L.IMPL_AUTO][1], outs[L.IMPL_REF][1]) < 3e-2
+    # torch statement with the same mask
+    keep = _keep(seed, (B * H, S, S), p).view(B, H, S, S)
+    q3 = qkv.float().clone().requires_grad_(True)
+    q, k, v = (t.view(B, S, H, dh).transpose(1, 2) for t in q3.view(B, S, 3 * H * dh).split(H * dh, dim=-1))
+    s_ = q @ k.transpose(2, 3) * sc
+    if mask is not None:
+        s_ = s_.masked_fill(~mask.bool()[:, None, None, :], float("-inf"))
+    a = torch.softmax(s_, -1) * keep
+    o = (a @ v).transpose(1, 2).reshape(B * S, H * dh)
+    o.backward(dout.float())
+    assert rel_err(outs[L.IMPL_REF][0], o.detach()) < 2e-2
+    assert rel_err(outs[L.IMPL_REF][1], q3.grad) < 3e-2
+
+
+# ------------------------------------------------------------------------------------------------------
 # fused head vs the oracle, loss, optimizers
 # ------------------------------------------------------------------------------------------------------
 def _head_setup(d_img, d_txt, mode, reverse, n_classes=4):
