@@ -31,6 +31,10 @@ ALIGN = 64          # arena entries start on 256-byte boundaries
 # fused work is exposed in the GEMM epilogue instead of overlapping in a bandwidth-bound pass): off by default.
 FUSE_BIAS_GRAD = os.environ.get("MMRCA_FUSE_BIAS", "0") == "1"
 FUSE_GELU_GRAD = os.environ.get("MMRCA_FUSE_GELU", "0") == "1"
+# weight-gradient GEMMs on a second HIP stream, concurrent with the input-gradient chain of the same layer
+SIDE_STREAM_WGRAD = os.environ.get("MMRCA_SIDE_STREAM", "1") == "1"
+# text encoder and vision encoder are independent until the fusion head: run them on two streams
+CONCURRENT_ENCODERS = os.environ.get("MMRCA_CONCURRENT_ENCODERS", "1") == "1"
 ROWPAD = 128
 
 
@@ -107,6 +111,12 @@ class MMRCAEngine:
             hi = starts[j + 1][1] if j + 1 < len(starts) else self.arena.total
             self.groups[gname] = (lo, hi)
         self.grad_sync = None          # distributed.GradSync, set by the training driver
+        on_gpu = self.device.type == "cuda"
+        self._side_v = torch.cuda.Stream(device=self.device) if (SIDE_STREAM_WGRAD and on_gpu) else None
+        self._side_t = torch.cuda.Stream(device=self.device) if (SIDE_STREAM_WGRAD and on_gpu) else None
+        self._side = self._side_v          # the side stream of the encoder whose backward is being queued
+        self._text_stream = torch.cuda.Stream(device=self.device) if (CONCURRENT_ENCODERS and on_gpu) else None
+        self._first_wgrad_ev = None
         self._head_w = self._head_struct("p")
         self._head_g = self._head_struct("g")
         # fused QKV views of the text encoder must be contiguous in the arena
@@ -239,10 +249,26 @@ class MMRCAEngine:
         Mk = _round_up(M, 64)
         gw = self.G(wkey) if wnumel is None else self.Gflat(wkey, wnumel)
         gb = self.G(bkey) if wnumel is None else self.Gflat(bkey, N)
-        L.gemm(dy, x, gw, bias=(gb if FUSE_BIAS_GRAD else None), M=N, N=K, K=Mk, lda=N, ldb=K, ldc=K, a_layout=L.KROW,
-               b_layout=L.KROW, accum=True, dtype=self.dt, impl=self.gemm_impl)
-        if not FUSE_BIAS_GRAD:
-            L.colsum_accum(dy, gb, M, N, N, self.dt)
+
+        def wgrad():
+            L.gemm(dy, x, gw, bias=(gb if FUSE_BIAS_GRAD else None), M=N, N=K, K=Mk, lda=N, ldb=K, ldc=K, a_layout=L.KROW,
+                   b_layout=L.KROW, accum=True, dtype=self.dt, impl=self.gemm_impl)
+            if not FUSE_BIAS_GRAD:
+                L.colsum_accum(dy, gb, M, N, N, self.dt)
+
+        if self._side is None:
+            wgrad()
+        else:
+            # dy and x are complete on the main stream here; the side stream reads them while the main stream goes on
+            # with the input-gradient chain.  Buffers are only re-written in the next layer (after _layer_boundary) or,
+            # for the incoming-gradient buffer, after _wait_first_wgrad().
+            main = torch.cuda.current_stream()
+            self._side.wait_stream(main)
+            with torch.cuda.stream(self._side):
+                wgrad()
+                if self._first_wgrad_ev is None:
+                    self._first_wgrad_ev = torch.cuda.Event()
+                    self._first_wgrad_ev.record(self._side)
         if dx is not None:
             w = self.W(wkey) if wnumel is None else self.Wflat(wkey, wnumel)
             fuse = gelu_h is not None and FUSE_GELU_GRAD
@@ -260,6 +286,19 @@ class MMRCAEngine:
                 branch_drop=(0.0, 0), dbranch=None):
         L.layernorm_bwd(dy, s, self.W(pfx + ".weight"), mean, rstd, dres, ds, self.G(pfx + ".weight"), self.G(pfx + ".bias"),
                         rows, D, ld_dy or D, ld_s or D, ld_ds or D, self.dt, dy_drop=dy_drop, branch_drop=branch_drop, dbranch=dbranch)
+
+    def _layer_boundary(self):
+        """All side-stream weight-gradient work of the finished layer must be done before the next layer re-writes the
+        gradient buffers it read (and before its parameter group is handed to the gradient all-reduce)."""
+        if self._side is not None:
+            torch.cuda.current_stream().wait_stream(self._side)
+            self._first_wgrad_ev = None
+
+    def _wait_first_wgrad(self):
+        """The first weight-gradient GEMM of a layer reads the incoming-gradient buffer that the layer's last op
+        overwrites with the outgoing gradient."""
+        if self._side is not None and self._first_wgrad_ev is not None:
+            torch.cuda.current_stream().wait_event(self._first_wgrad_ev)
 
     @staticmethod
     def _site_seed(base: int, layer: int, site: int) -> int:
@@ -328,21 +367,23 @@ class MMRCAEngine:
             ds2 = gb("ds2", D)
             dp, sd = sv["drop_p"], (lambda layer, site: self._site_seed(sv["drop_seed"], layer, site))
             post_attn_drop = dp if s.name != "distilbert" else 0.0
-            df = gb("dbr", D) if dp > 0 else None          # gradient of the dropped FFN branch
+            df = gb("dbr_ffn", D) if dp > 0 else None      # gradient of the dropped FFN branch
             self._ln_bwd(dx, a["s2"], P + K["ln2"], a["m2"], a["r2"], None, ds2, M, D, branch_drop=(dp, sd(i, 3)), dbranch=df)
             dg = gb("dF", Fd)
             self._lin_bwd(df if df is not None else ds2, a["g"], P + K["f2"] + ".weight", P + K["f2"] + ".bias", dg, M, D, Fd, gelu_h=a["h"])
             dx1 = gb("dxB", D)
             self._lin_bwd(dg, a["x1"], P + K["f1"] + ".weight", P + K["f1"] + ".bias", dx1, M, Fd, D, addend=ds2)
             ds1 = gb("ds1", D)
-            datt = gb("dbr", D) if post_attn_drop > 0 else None
+            datt = gb("dbr_att", D) if post_attn_drop > 0 else None
             self._ln_bwd(dx1, a["s1"], P + K["ln1"], a["m1"], a["r1"], None, ds1, M, D, branch_drop=(post_attn_drop, sd(i, 2)), dbranch=datt)
             dctx = gb("dctx", D)
             self._lin_bwd(datt if datt is not None else ds1, a["ctx"], P + K["o"] + ".weight", P + K["o"] + ".bias", dctx, M, D, D)
             dqkv = gb("dqkv", 3 * D)
             L.mha_bwd(a["qkv"], sv["mask32"], a["ctx"], dctx, a["lse"], dqkv, B, H, T, dh, dh ** -0.5, self.dt, self.attn_impl,
                       drop_p=dp, drop_seed=sd(i, 1))
+            self._wait_first_wgrad()       # (the FFN2 weight gradient does not read dx in the post-LN layout; harmless)
             self._lin_bwd(dqkv, a["x"], P + K["q"] + ".weight", P + K["q"] + ".bias", dx, M, 3 * D, D, addend=ds1, wnumel=3 * D * D)
+            self._layer_boundary()
             self._ready(f"text_layer_{i}")
         ds0 = gb("ds2", D)
         self._ln_bwd(dx, sv["emb"], P + "embeddings.LayerNorm", sv["mean0"], sv["rstd0"], None, ds0, M, D,
@@ -350,6 +391,7 @@ class MMRCAEngine:
         dtype_row = self.Gflat(P + "embeddings.token_type_embeddings.weight", D) if s.type_vocab else None
         L.embed_bwd(ds0, sv["ids32"], sv["pos"], self.G(P + "embeddings.word_embeddings.weight"),
                     self.G(P + "embeddings.position_embeddings.weight"), dtype_row, M, D, self.dt)
+        self._layer_boundary()
         self._ready("text_emb", flush=True)
 
     # ------------------------------------------------------------------ vision encoder
@@ -419,11 +461,14 @@ class MMRCAEngine:
             L.mha_bwd(a["qkv"], None, a["ctx"], dctx, a["lse"], dqkv, B, H, Tn, dh, dh ** -0.5, self.dt, self.attn_impl)
             dy1 = gb("dy", M, D)
             self._lin_bwd(dqkv, a["y1"], Lk + "self_attention.in_proj_weight", Lk + "self_attention.in_proj_bias", dy1, M, 3 * D, D)
+            self._wait_first_wgrad()       # mlp.3's weight gradient (side stream) reads dx; this op overwrites it
             self._ln_bwd(dy1, a["x"], Lk + "ln_1", a["m1"], a["r1"], dx1, dx, M, D)
+            self._layer_boundary()
             self._ready(f"image_layer_{i}")
         dproj = gb("dproj", B * nP, D)
         L.vit_assemble_bwd(dx, dproj, self.Gflat(P + "class_token", D), self.Gflat(P + "encoder.pos_embedding", Tn * D), B, nP, D, self.dt)
         self._lin_bwd(dproj, sv["patches"], P + "conv_proj.weight", P + "conv_proj.bias", None, B * nP, D, Kp, wnumel=D * Kp)
+        self._layer_boundary()
         self._ready("image_emb", flush=True)
 
     # ------------------------------------------------------------------ whole model
@@ -434,8 +479,17 @@ class MMRCAEngine:
                 raise L.MmrcaError(f"{nm} must be in HBM; the MM-RCA product path has no CPU fallback")
         self.refresh_working_copy()
         B = ids.shape[0]
-        cls, tsv = self._text_forward(ids, mask, save, enc_drop_p, int(seed))
-        feat, vsv = self._vision_forward(images, save)
+        main = torch.cuda.current_stream()
+        if self._text_stream is not None:
+            self._text_stream.wait_stream(main)
+            with torch.cuda.stream(self._text_stream):
+                cls, tsv = self._text_forward(ids, mask, save, enc_drop_p, int(seed))
+            feat, vsv = self._vision_forward(images, save)
+            main.wait_stream(self._text_stream)
+            cls.record_stream(main)
+        else:
+            cls, tsv = self._text_forward(ids, mask, save, enc_drop_p, int(seed))
+            feat, vsv = self._vision_forward(images, save)
         logits = torch.empty(B, self.n_classes, dtype=torch.float32, device=self.device)
         L.head_fwd(feat, cls, self._head_w, logits, B, self.d_img, self.d_txt, self.n_classes, self.reverse, self.mode,
                    float(drop_p), int(seed), self.dt)
@@ -455,10 +509,27 @@ class MMRCAEngine:
         L.head_bwd(dl, sv["feat"], sv["cls"], self._head_w, self._head_g, dimg, dtxt, B, self.d_img, self.d_txt,
                    self.n_classes, self.reverse, self.mode, sv["drop_p"], sv["seed"], self.dt)
         self._ready("head", flush=not (train_image or train_text))
-        if train_image:
-            self._vision_backward(dimg, sv["vision"])
-        if train_text:
-            self._text_backward(dtxt, sv["text"])
+        main = torch.cuda.current_stream()
+        if train_text and self._text_stream is not None:
+            # the host queues the text backward first (it is short) on its own stream, then the vision backward on the
+            # main stream; the gradient all-reduce hooks see image groups and text groups on their own streams
+            self._text_stream.wait_stream(main)
+            dtxt.record_stream(self._text_stream)
+            if train_image:
+                self._side = self._side_v
+                self._vision_backward(dimg, sv["vision"])
+            with torch.cuda.stream(self._text_stream):
+                self._side = self._side_t
+                self._text_backward(dtxt, sv["text"])
+            main.wait_stream(self._text_stream)
+        else:
+            if train_image:
+                self._side = self._side_v
+                self._vision_backward(dimg, sv["vision"])
+            if train_text:
+                self._side = self._side_t
+                self._text_backward(dtxt, sv["text"])
+        self._side = self._side_v
         self.arena.lp_valid = False        # an optimizer step normally follows
 
     # ------------------------------------------------------------------ flat-arena optimizer steps
