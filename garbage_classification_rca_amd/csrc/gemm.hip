@@ -326,6 +326,8 @@ int mmrca_gemm256(const void* A, const void* B, void* C, const void* bias, const
                   int64_t N, int64_t K, int64_t lda, int64_t ldb, int64_t ldc, int a_layout, int b_layout, int act,
                   hipStream_t st);
 
+extern int g_mmrca_dbg;
+
 template <bool AK, bool BK2, bool AT, bool DB>
 static void launch_mfma(const void* A, const void* B, void* C, const void* bias, const void* addend, void* preact,
                         int64_t M, int64_t N, int64_t K, int64_t lda, int64_t ldb, int64_t ldc, int act, int tiles_m,
@@ -356,7 +358,9 @@ extern "C" int mmrca_gemm(const void* A, const void* B, void* C, const void* bia
   const bool ok256 = ok_mfma && !out_f32_accum && mmrca_gemm256_ok(M, N, K, a_layout);
   if (impl == MMRCA_GEMM_MFMA256 && !ok256)
     return mmrca_fail(-3, "gemm: shape M=%lld N=%lld K=%lld does not qualify for the 256x256 MFMA kernel", (long long)M, (long long)N, (long long)K);
-  if (ok256 && (impl == MMRCA_GEMM_MFMA256 || (impl == MMRCA_GEMM_AUTO && b_layout == MMRCA_ROWK && N >= 1536 && K <= 1536 && ((M + 255) / 256) * (N / 256) >= 512)))
+  // measured (tools/gemm_bench.py, interleaved rounds): with the row-contiguous epilogue the 128x128 kernel at two blocks
+  // per CU is faster than the 256x256 kernel on every encoder shape, so AUTO never picks the large tile
+  if (ok256 && impl == MMRCA_GEMM_MFMA256)
     return mmrca_gemm256(A, B, C, bias, addend, preact, M, N, K, lda, ldb, ldc, a_layout, b_layout, act, st);
   if (impl == MMRCA_GEMM_MFMA && !ok_mfma)
     return mmrca_fail(-3, "gemm: shape M=%lld N=%lld K=%lld dtype=%d does not qualify for the MFMA kernel", (long long)M, (long long)N, (long long)K, dtype);
@@ -368,7 +372,6 @@ extern "C" int mmrca_gemm(const void* A, const void* B, void* C, const void* bia
     int64_t ksplit_len = K;
     if (out_f32_accum) {
       const int64_t ksteps = K / GBK;
-      extern int g_mmrca_dbg;
       // resident slots = 256 CUs x 2 blocks: aim for one (few tiles) or two (many tiles) full rounds
       const int64_t target = (g_mmrca_dbg >> 8) > 0 ? (g_mmrca_dbg >> 8) : ((int64_t)tiles_m * tiles_n >= 64 ? 1024 : 512);
       int64_t want = target / ((int64_t)tiles_m * tiles_n);

@@ -37,23 +37,30 @@ for name, m, n, k, al, bl, acc in SHAPES:
     row = {}
     variants = [(a, b, 0) for a, b in impls.items()] + [(f"256dbg{d}", L.IMPL_MFMA256, d) for d in DBG if d and d < 256]
     variants += [(f"128tgt{d >> 8}", L.IMPL_MFMA, d) for d in DBG if d >= 256]
+    variants += [(f"128dbg{d}", L.IMPL_MFMA, d) for d in DBG if d == 16]
+    runs = {}
     for iname, impl, dbg in variants:
         if impl == L.IMPL_MFMA256 and (acc or n % 256 or (al == 1 and m % 256)):
             continue
-        L.load().mmrca_debug_set(dbg)
-        def run():
+        def run(impl=impl, dbg=dbg):
+            L.load().mmrca_debug_set(dbg)
             L.gemm(A, B, C, bias=bias, M=m, N=n, K=k, lda=lda, ldb=ldb, ldc=n, a_layout=al, b_layout=bl, accum=bool(acc), dtype=L.BF16, impl=impl)
+        runs[iname] = run
+    best = {k2: 1e9 for k2 in runs}
+    for k2, fn in runs.items():
         for _ in range(3):
-            run()
-        torch.cuda.synchronize()
-        best = 1e9
-        for rnd in range(3):
+            fn()
+    torch.cuda.synchronize()
+    for rnd in range(5):                       # interleaved rounds: every variant sees the same cache / clock state
+        for k2, fn in runs.items():
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
-            for _ in range(10):
-                run()
+            for _ in range(5):
+                fn()
             e1.record(); torch.cuda.synchronize()
-            best = min(best, e0.elapsed_time(e1) / 10)
-        row[iname] = round(2.0 * m * n * k / (best * 1e-3) / 1e12, 1)
+            best[k2] = min(best[k2], e0.elapsed_time(e1) / 5)
+    for k2 in runs:
+        row[k2] = round(2.0 * m * n * k / (best[k2] * 1e-3) / 1e12, 1)
+    L.load().mmrca_debug_set(0)
     res[name] = row
     print(f"{name:14s} M={m:6d} N={n:5d} K={k:6d}  " + "  ".join(f"{a}={b:7.1f} TF ({2.0*m*n*k/b/1e6:.0f}us)" for a, b in row.items()), flush=True)
