@@ -143,6 +143,7 @@ def main():
     with contextlib.redirect_stdout(io.StringIO()):
         for i in range(args.steps):
             loss = step(i)
+    host_enqueue = time.perf_counter() - t0          # host time to enqueue the steps (the GPU runs behind it)
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
@@ -193,7 +194,8 @@ def main():
             "config": {"workload": "MM_RCA --reverse ViT-B/16 + DistilBERT, " + ("frozen-backbone" if args.frozen else "fine-tune")
                        + " train step (fwd+loss+bwd+allreduce+SGD), 224x224 images, 64-token captions",
                        "per_gpu_batch": B, "global_batch": B * world, "seq_len": S, "image": 224, "parallelism": f"dp{world}",
-                       "optimizer": "sgd lr=1e-3 wd=1e-2", "random_init": True, "final_loss": round(final_loss, 4)},
+                       "optimizer": "sgd lr=1e-3 wd=1e-2", "random_init": True, "final_loss": round(final_loss, 4),
+                       "host_enqueue_ms_per_step": round(host_enqueue / args.steps * 1e3, 2)},
             "roofline": {"bound": "mfma", "achieved": round(achieved, 2), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
                          "frac": round(achieved / PEAK_BF16_TFLOPS, 4), "traffic": None,
                          "kernel": "gemm_mfma_k (bf16 16x16x32 MFMA GEMM; all nn.Linear fwd/dgrad/wgrad)",

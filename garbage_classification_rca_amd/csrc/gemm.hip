@@ -319,6 +319,195 @@ gemm_mfma_k(const bf16_t* __restrict__ A, const bf16_t* __restrict__ B, void* __
   }
 }
 
+// ======================================================================================================
+// persistent variant: grid = 2 blocks per CU; every block walks work items (tile, k-split) it, it+G, it+2G, ... and the
+// two-buffer K pipeline never stops at an item boundary: the first K-tile of the NEXT item is issued before the last
+// MFMAs of the current one, so its HBM latency hides behind those MFMAs and the epilogue (which stages through the
+// LDS buffer that is idle at that moment, 32 rows at a time).
+// ======================================================================================================
+template <bool A_KROW, bool B_KROW, bool ATOMIC_F32>
+__global__ void __launch_bounds__(256)
+gemm_mfma_p_k(const bf16_t* __restrict__ A, const bf16_t* __restrict__ B, void* __restrict__ Cv, const bf16_t* __restrict__ bias,
+              const bf16_t* __restrict__ addend, bf16_t* __restrict__ preact, int64_t M, int64_t N, int64_t K,
+              int64_t lda, int64_t ldb, int64_t ldc, int act, int tiles_m, int tiles_n, int ksplits, int64_t ksplit_len) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];   // [2 buffers][A tile | B tile]
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
+  const int wr = wave >> 1, wc = wave & 1;
+  const int g = lane >> 4, l16 = lane & 15;
+  const int nwg = tiles_m * tiles_n;
+  const int total = nwg * ksplits;
+
+  auto decode = [&](int it, int64_t& m_blk, int64_t& n_blk, int64_t& kbeg, int& nt) {
+    const int orig = it % nwg, split = it / nwg;
+    const int q8 = nwg >> 3, r8 = nwg & 7, xcd = orig & 7;
+    const int wgid = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (orig >> 3);
+    const int GROUP = 8;
+    const int group = wgid / (GROUP * tiles_n);
+    const int first_m = group * GROUP;
+    const int gsize = (tiles_m - first_m) < GROUP ? (tiles_m - first_m) : GROUP;
+    m_blk = (int64_t)(first_m + (wgid % (GROUP * tiles_n)) % gsize) * GBM;
+    n_blk = (int64_t)((wgid % (GROUP * tiles_n)) / gsize) * GBN;
+    kbeg = (int64_t)split * ksplit_len;
+    int64_t kend = kbeg + ksplit_len; if (kend > K) kend = K;
+    nt = (int)((kend - kbeg + GBK - 1) / GBK);
+  };
+
+  int it = blockIdx.x;
+  if (it >= total) return;
+  int64_t m_blk, n_blk, kbeg; int nt;
+  decode(it, m_blk, n_blk, kbeg, nt);
+  int gstep = 0;                                   // global K-step counter: buffer = gstep & 1
+  stage_tile<A_KROW>(A, lda, m_blk, M, kbeg, smem, wave, lane);
+  stage_tile<B_KROW>(B, ldb, n_blk, N, kbeg, smem + TILE_BYTES, wave, lane);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+
+  while (true) {
+    const int it_next = it + gridDim.x;
+    const bool has_next = it_next < total;
+    int64_t m_n = 0, n_n = 0, k_n = 0; int nt_n = 0;
+    if (has_next) decode(it_next, m_n, n_n, k_n, nt_n);
+
+    f32x4 acc[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    // bias is fetched BEFORE the K loop: vmcnt retires in order, so a bias load issued in the epilogue would make its
+    // wait cover the run-ahead loads of the next item as well
+    float bv[4] = {0.f, 0.f, 0.f, 0.f};
+    if (!ATOMIC_F32 && bias) {
+      bf16x4 b4 = *reinterpret_cast<const bf16x4*>(bias + n_blk + (lane & 31) * 4);
+#pragma unroll
+      for (int r = 0; r < 4; ++r) bv[r] = (float)b4[r];
+    }
+
+    for (int t = 0; t < nt; ++t, ++gstep) {
+      char* cur = smem + (gstep & 1) * 2 * TILE_BYTES;
+      char* nxt = smem + ((gstep + 1) & 1) * 2 * TILE_BYTES;
+      const bool last = (t + 1 == nt);
+      if (!last) {
+        stage_tile<A_KROW>(A, lda, m_blk, M, kbeg + (int64_t)(t + 1) * GBK, nxt, wave, lane);
+        stage_tile<B_KROW>(B, ldb, n_blk, N, kbeg + (int64_t)(t + 1) * GBK, nxt + TILE_BYTES, wave, lane);
+      } else if (has_next) {                       // run ahead into the next work item
+        stage_tile<A_KROW>(A, lda, m_n, M, k_n, nxt, wave, lane);
+        stage_tile<B_KROW>(B, ldb, n_n, N, k_n, nxt + TILE_BYTES, wave, lane);
+      }
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks) {
+        bf16x8 af[4], bfr[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) af[i] = load_frag<A_KROW>(cur, wr * 64 + i * 16, ks, lane);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) bfr[j] = load_frag<B_KROW>(cur + TILE_BYTES, wc * 64 + j * 16, ks, lane);
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            if (ATOMIC_F32) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i], bfr[j], acc[i][j], 0, 0, 0);
+            else            acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr[j], af[i], acc[i][j], 0, 0, 0);
+          }
+      }
+      if (!last) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+      } else {
+        asm volatile("s_barrier" ::: "memory");    // every wave is done reading `cur`; the run-ahead loads stay in flight
+      }
+    }
+    // ---------------- epilogue of the finished item; `ep` = the buffer just consumed (idle now)
+    char* ep = smem + ((gstep - 1) & 1) * 2 * TILE_BYTES;
+    if (ATOMIC_F32) {
+      float* C = (float*)Cv;
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const int64_t n = n_blk + wc * 64 + j * 16 + l16;
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const int64_t m = m_blk + wr * 64 + i * 16 + 4 * g + r;
+            if (m < M && n < N) atomicAdd(C + m * ldc + n, acc[i][j][r]);
+          }
+        }
+    } else {
+      bf16_t* C = (bf16_t*)Cv;
+      constexpr int EP_STRIDE = 128 * 4 + 16;      // 32 rows x 528 B = 16.5 KiB per pass
+      const int half = lane >> 5, l32 = lane & 31;
+      const int64_t ncol = n_blk + l32 * 4;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {                // pass i: tile rows wr*64 + i*16 + [0,16) of both wave rows
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+          *reinterpret_cast<f32x4*>(ep + (wr * 16 + l16) * EP_STRIDE + (wc * 64 + j * 16 + 4 * g) * 4) = acc[i][j];
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+#pragma unroll
+        for (int rr = 0; rr < 4; ++rr) {
+          const int lrow = wave * 8 + rr * 2 + half;               // 0..31 within the pass
+          const int64_t m = m_blk + (lrow >> 4) * 64 + i * 16 + (lrow & 15);
+          if (m < M) {
+            const f32x4 c = *reinterpret_cast<const f32x4*>(ep + lrow * EP_STRIDE + l32 * 16);
+            float v[4] = {c[0] + bv[0], c[1] + bv[1], c[2] + bv[2], c[3] + bv[3]};
+            if (act == MMRCA_ACT_MUL) {
+              bf16x4 h4 = *reinterpret_cast<const bf16x4*>(preact + m * ldc + ncol);
+#pragma unroll
+              for (int r = 0; r < 4; ++r) v[r] *= (float)h4[r];
+            } else if (act == MMRCA_ACT_GELU_SAVE_GRAD) {
+              bf16x4 o;
+#pragma unroll
+              for (int r = 0; r < 4; ++r) {
+                const float e = erff(v[r] * 0.70710678118654752f);
+                o[r] = (bf16_t)(0.5f * (1.0f + e) + v[r] * 0.3989422804014327f * __expf(-0.5f * v[r] * v[r]));
+                v[r] = 0.5f * v[r] * (1.0f + e);
+              }
+              *reinterpret_cast<bf16x4*>(preact + m * ldc + ncol) = o;
+            } else if (act == MMRCA_ACT_GELU_BWD) {
+              bf16x4 h4 = *reinterpret_cast<const bf16x4*>(preact + m * ldc + ncol);
+#pragma unroll
+              for (int r = 0; r < 4; ++r) v[r] *= gelu_grad_f((float)h4[r]);
+            } else if (preact) {
+              bf16x4 o;
+#pragma unroll
+              for (int r = 0; r < 4; ++r) o[r] = (bf16_t)v[r];
+              *reinterpret_cast<bf16x4*>(preact + m * ldc + ncol) = o;
+            }
+            if (act == MMRCA_ACT_GELU) {
+#pragma unroll
+              for (int r = 0; r < 4; ++r) v[r] = gelu_f(v[r]);
+            }
+            if (addend) {
+              bf16x4 a4 = *reinterpret_cast<const bf16x4*>(addend + m * ldc + ncol);
+#pragma unroll
+              for (int r = 0; r < 4; ++r) v[r] += (float)a4[r];
+            }
+            bf16x4 o;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) o[r] = (bf16_t)v[r];
+            *reinterpret_cast<bf16x4*>(C + m * ldc + ncol) = o;
+          }
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");   // the pass buffer is re-written by the next pass
+      }
+    }
+    if (!has_next) break;
+    // the run-ahead K-tile of the next item must have landed before anyone reads it
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    it = it_next; m_blk = m_n; n_blk = n_n; kbeg = k_n; nt = nt_n;
+  }
+}
+
+template <bool AK, bool BK2, bool AT>
+static void launch_mfma_p(const void* A, const void* B, void* C, const void* bias, const void* addend, void* preact,
+                          int64_t M, int64_t N, int64_t K, int64_t lda, int64_t ldb, int64_t ldc, int act, int tiles_m,
+                          int tiles_n, int ksplits, int64_t ksplit_len, hipStream_t st) {
+  const int total = tiles_m * tiles_n * ksplits;
+  const int grid = total < 512 ? total : 512;            // 256 CUs x 2 resident blocks (64 KiB LDS each)
+  hipLaunchKernelGGL((gemm_mfma_p_k<AK, BK2, AT>), dim3(grid), dim3(256), 4 * TILE_BYTES, st, (const bf16_t*)A, (const bf16_t*)B,
+                     C, (const bf16_t*)bias, (const bf16_t*)addend, (bf16_t*)preact, M, N, K, lda, ldb, ldc, act, tiles_m,
+                     tiles_n, ksplits, ksplit_len);
+}
+
 static bool aligned16(const void* p) { return (((uintptr_t)p) & 15) == 0; }
 
 bool mmrca_gemm256_ok(int64_t M, int64_t N, int64_t K, int a_layout);
@@ -362,7 +551,7 @@ extern "C" int mmrca_gemm(const void* A, const void* B, void* C, const void* bia
   // per CU is faster than the 256x256 kernel on every encoder shape, so AUTO never picks the large tile
   if (ok256 && impl == MMRCA_GEMM_MFMA256)
     return mmrca_gemm256(A, B, C, bias, addend, preact, M, N, K, lda, ldb, ldc, a_layout, b_layout, act, st);
-  if (impl == MMRCA_GEMM_MFMA && !ok_mfma)
+  if ((impl == MMRCA_GEMM_MFMA || impl == MMRCA_GEMM_MFMA_PERSIST) && !ok_mfma)
     return mmrca_fail(-3, "gemm: shape M=%lld N=%lld K=%lld dtype=%d does not qualify for the MFMA kernel", (long long)M, (long long)N, (long long)K, dtype);
   const bool use_mfma = ok_mfma && impl != MMRCA_GEMM_REF;   // 128x128 kernel
 
@@ -382,6 +571,20 @@ extern "C" int mmrca_gemm(const void* A, const void* B, void* C, const void* bia
       ksplits = (int)((ksteps + steps_per - 1) / steps_per);
     }
     const bool ak = a_layout == MMRCA_KROW, bk = b_layout == MMRCA_KROW, at = out_f32_accum != 0;
+    if (impl == MMRCA_GEMM_MFMA_PERSIST && !(at && bias)) {
+#define LP(AK_, BK_, AT_) launch_mfma_p<AK_, BK_, AT_>(A, B, C, bias, addend, preact, M, N, K, lda, ldb, ldc, act, tiles_m, tiles_n, ksplits, ksplit_len, st)
+      if (!ak && !bk && !at) LP(false, false, false);
+      else if (!ak && bk && !at) LP(false, true, false);
+      else if (ak && !bk && !at) LP(true, false, false);
+      else if (ak && bk && !at) LP(true, true, false);
+      else if (!ak && !bk && at) LP(false, false, true);
+      else if (!ak && bk && at) LP(false, true, true);
+      else if (ak && !bk && at) LP(true, false, true);
+      else LP(true, true, true);
+#undef LP
+      MMRCA_CHECK_LAUNCH("gemm(mfma,persistent)");
+      return 0;
+    }
     if (at && bias) {   // weight gradient with the bias gradient fused (A is KROW by contract)
       if (bk) launch_mfma<true, true, true, true>(A, B, C, nullptr, addend, preact, M, N, K, lda, ldb, ldc, act, tiles_m, tiles_n, ksplits, ksplit_len, (float*)bias, st);
       else launch_mfma<true, false, true, true>(A, B, C, nullptr, addend, preact, M, N, K, lda, ldb, ldc, act, tiles_m, tiles_n, ksplits, ksplit_len, (float*)bias, st);

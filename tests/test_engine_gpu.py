@@ -243,3 +243,28 @@ def test_encoder_dropout_runs_and_is_seed_deterministic():
     assert cos > 0.999            # identical masks in forward and backward (atomics reorder the fp32 sums only)
     assert torch.isfinite(ga).all() and float(ga[:text_hi].abs().max()) > 0
     eng.release_buffers()
+
+
+def test_cfg4_vit_l16_bert_cross_attention_only_fp32_logits():
+    """BASELINE.json configs[3] at test size: MM_RCA --cross_attention_only, ViT-L/16 + BERT-base, 128-token captions."""
+    eng, orc, sd = _build_pair(torch.float32, text="bert", image="transformer_L16", mode=2)
+    ids, mask, images = _inputs(2, 128)
+    logits = eng.forward(ids.cuda(), mask.cuda(), images.cuda(), save=False)
+    with torch.no_grad():
+        ref = orc(ids, mask, images, eval=True)
+    assert rel(logits, ref) < 1e-3
+    eng.release_buffers()
+
+
+def test_cfg3_text_side_roberta_bf16_step_runs():
+    """configs[2] pairs RoBERTa-base with EfficientNetV2-L; the conv backbone is not built, the
+    RoBERTa text path is: one bf16 train step with ViT-B/16 standing in for the image encoder."""
+    eng = MMRCAEngine("roberta", "transformer_B16", 4, True, 0, torch.bfloat16)
+    eng.init_parameters(0)
+    ids, mask, images = _inputs(2, 32)
+    ids = ids.clone(); ids[ids == 0] = 1          # RoBERTa pads with id 1
+    logits = eng.forward(ids.cuda(), mask.cuda(), images.cuda(), enc_drop_p=0.1, seed=3)
+    eng.backward(torch.randn(2, 4, device="cuda") * 0.1)
+    torch.cuda.synchronize()
+    assert torch.isfinite(logits).all() and torch.isfinite(eng.arena.g).all()
+    eng.release_buffers()

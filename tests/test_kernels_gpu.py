@@ -119,6 +119,19 @@ def test_gemm_mfma_epilogues_and_wgrad():
 
 
 @pytest.mark.parametrize("layouts", [(0, 0), (0, 1), (1, 1), (1, 0)])
+def test_gemm_persistent_kernel(layouts):
+    """Persistent 128x128 kernel (pipeline runs across tile boundaries): many more tiles than resident blocks, ragged M,
+    single-K-step items, epilogues, and the split-K fp32 accumulate path."""
+    al, bl = layouts
+    M = 9 * 128 * 8 if al == L.KROW else 9000           # > 512 work items with N = 1024
+    for K in (64, 192):
+        _gemm_case(M, 1024, K, al, bl, torch.bfloat16, L.IMPL_MFMA_PERSIST, bias=True)
+    Ms = 768 if al == L.KROW else 700
+    _gemm_case(Ms, 256, 256, al, bl, torch.bfloat16, L.IMPL_MFMA_PERSIST, act=L.ACT_GELU, bias=True, addend=True, preact=True)
+    _gemm_case(768, 768, 5000, 1, 1, torch.bfloat16, L.IMPL_MFMA_PERSIST, accum=True)
+
+
+@pytest.mark.parametrize("layouts", [(0, 0), (0, 1), (1, 1), (1, 0)])
 def test_gemm_mfma256_layouts_and_epilogues(layouts):
     """256x256 tile kernel with loads kept in flight across barriers: exact integers first, then random data with
     every K-tile count from 1 (tail-only path) upward and a ragged M."""
