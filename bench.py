@@ -169,6 +169,15 @@ def main():
         serial_ms = (time.perf_counter() - ts0) / replay * 1e3
     prof, L.GEMM_PROFILE = L.GEMM_PROFILE, None
     eng._side_v, eng._side_t, eng._side, eng._text_stream = saved_streams
+    if world > 1 and os.environ.get("MMRCA_CHECK_REPLICAS") == "1":
+        # data-parallel invariant: every rank applied the same averaged gradient, so the replicas are bit-identical
+        chk = eng.arena.p.double().sum().view(1)
+        lo, hi = chk.clone(), chk.clone()
+        dist.all_reduce(lo, op=dist.ReduceOp.MIN); dist.all_reduce(hi, op=dist.ReduceOp.MAX)
+        assert float(hi - lo) == 0.0, f"replicas diverged: {float(lo)} vs {float(hi)}"
+        if rank == 0:
+            print(f"[bench] replicas identical after {args.warmup + args.steps + replay + 1} steps (param checksum {float(chk):.6f}); "
+                  f"all-reduced {sync.bytes_reduced / 1e6:.1f} MB in total", file=sys.stderr, flush=True)
     if world > 1:
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)

@@ -26,13 +26,18 @@ def init_from_env(backend: Optional[str] = None):
     if world > 1 and not dist.is_initialized():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29500")
+        backend = os.environ.get("MMRCA_DIST_BACKEND", backend)      # rehearsal override (e.g. gloo on a one-GPU box)
         if backend is None:
             backend = "nccl" if torch.cuda.is_available() else "gloo"
+        if torch.cuda.is_available():
+            local = local % max(torch.cuda.device_count(), 1)         # several ranks may share a card in a rehearsal
         if backend == "nccl":
             torch.cuda.set_device(local)
             dist.init_process_group(backend, rank=rank, world_size=world, device_id=torch.device("cuda", local))
         else:
             dist.init_process_group(backend, rank=rank, world_size=world)
+    if torch.cuda.is_available():
+        local = local % max(torch.cuda.device_count(), 1)
     return rank, local, world
 
 

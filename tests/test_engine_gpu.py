@@ -268,3 +268,23 @@ def test_cfg3_text_side_roberta_bf16_step_runs():
     torch.cuda.synchronize()
     assert torch.isfinite(logits).all() and torch.isfinite(eng.arena.g).all()
     eng.release_buffers()
+
+
+def test_two_rank_data_parallel_rehearsal_keeps_replicas_identical():
+    """N>1 path of bench.py (sharded synthetic data, overlapped gradient all-reduce over the flat arena, fused SGD) with
+    two ranks sharing this one GPU and gloo standing in for RCCL: after several steps both replicas hold bit-identical
+    parameters and exactly one arena's worth of gradients was reduced per step."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, MMRCA_DIST_BACKEND="gloo", MMRCA_CHECK_REPLICAS="1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", "29533", os.path.join(root, "bench.py"), "--gpus", "2", "--batch", "8", "--steps", "2", "--warmup", "1",
+           "--no_cpu_baseline"]
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600, cwd=root)
+    assert r.returncode == 0, r.stderr[-2000:]
+    assert "replicas identical" in r.stderr
+    line = [l for l in r.stdout.splitlines() if l.startswith("{")][-1]
+    import json
+    d = json.loads(line)
+    assert d["n_gpus"] == 2 and d["config"]["global_batch"] == 16 and d["scaling"] == "weak"
