@@ -320,6 +320,196 @@ gemm_mfma_k(const bf16_t* __restrict__ A, const bf16_t* __restrict__ B, void* __
 }
 
 // ======================================================================================================
+// BK = 32 variant: 128x128x32 tiles, 2 x 16 KiB of LDS per block (epilogue staged 32 rows at a time inside it), so FOUR
+// blocks (16 waves) are resident per CU instead of two.  Calibration (tools/probes/mfma_peak.hip): one wave per SIMD can
+// only drive the matrix pipe to 57 %, two reach 72-90 %; with loads, waits and barriers in the way, a SIMD that holds two
+// waves is often down to one issuing wave.  Four waves per SIMD trade a barrier every 16 MFMAs for that thread-level cover.
+//   ROWK image: 64-B rows, 16-B chunk index XOR ((4 - (row>>2)) & 3): the 16 lanes of every ds_read_b128 group land on 16
+//   distinct slots of the 256-B bank row.   KROW image: the 256-B-row image of the BK=64 kernel with 32 k-rows.
+// ======================================================================================================
+#define TILE32_BYTES (128 * 32 * 2)
+
+template <bool KROW>
+__device__ __forceinline__ void stage_tile32(const bf16_t* __restrict__ base, int64_t ld, int64_t row0, int64_t rows_total,
+                                             int64_t k0, char* lds_tile, int wave, int lane) {
+#pragma unroll
+  for (int ii = 0; ii < 2; ++ii) {
+    const int i = wave * 2 + ii;                  // 8 wave-instructions of 1 KiB per operand tile
+    const bf16_t* src;
+    if (!KROW) {
+      const int r = 16 * i + (lane >> 2);
+      const int c = (lane & 3) ^ ((4 - (r >> 2)) & 3);
+      int64_t gr = row0 + r;
+      if (gr > rows_total - 1) gr = rows_total - 1;
+      src = base + gr * ld + k0 + c * 8;
+    } else {
+      const int kr = 4 * i + (lane >> 4);
+      const int chp = lane & 15;
+      const int c = ((((chp >> 1) ^ krow_f(kr))) << 1) | (chp & 1);
+      src = base + (k0 + kr) * ld + row0 + c * 8;
+    }
+    __builtin_amdgcn_global_load_lds((gbl_void*)src, (lds_void*)(lds_tile + i * 1024), 16, 0, 0);
+  }
+}
+
+template <bool KROW>
+__device__ __forceinline__ bf16x8 load_frag32(const char* lds_tile, int rb, int lane) {
+  if (!KROW) {
+    const int r = rb + (lane & 15);
+    const int ch = lane >> 4;
+    return *reinterpret_cast<const bf16x8*>(lds_tile + r * 64 + ((ch ^ ((4 - (r >> 2)) & 3)) << 4));
+  } else {
+    return load_frag<true>(lds_tile, rb, 0, lane);
+  }
+}
+
+template <bool A_KROW, bool B_KROW, bool ATOMIC_F32>
+__global__ void __launch_bounds__(256, 4)
+gemm_mfma_k32(const bf16_t* __restrict__ A, const bf16_t* __restrict__ B, void* __restrict__ Cv, const bf16_t* __restrict__ bias,
+              const bf16_t* __restrict__ addend, bf16_t* __restrict__ preact, int64_t M, int64_t N, int64_t K,
+              int64_t lda, int64_t ldb, int64_t ldc, int act, int tiles_m, int tiles_n, int64_t ksplit_len) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];   // [2 buffers][A tile 8 KiB | B tile 8 KiB]
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
+  const int wr = wave >> 1, wc = wave & 1;
+  const int nwg = tiles_m * tiles_n;
+  const int orig = blockIdx.x;
+  const int q8 = nwg >> 3, r8 = nwg & 7, xcd = orig & 7;
+  const int wgid = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (orig >> 3);
+  const int GROUP = 8;
+  const int group = wgid / (GROUP * tiles_n);
+  const int first_m = group * GROUP;
+  const int gsize = (tiles_m - first_m) < GROUP ? (tiles_m - first_m) : GROUP;
+  const int tm = first_m + (wgid % (GROUP * tiles_n)) % gsize;
+  const int tn = (wgid % (GROUP * tiles_n)) / gsize;
+  const int64_t m_blk = (int64_t)tm * GBM, n_blk = (int64_t)tn * GBN;
+  const int64_t kbeg = (int64_t)blockIdx.y * ksplit_len;
+  int64_t kend = kbeg + ksplit_len; if (kend > K) kend = K;
+  const int nt = (int)((kend - kbeg + 31) / 32);
+
+  f32x4 acc[4][4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  if (nt > 0) {
+    stage_tile32<A_KROW>(A, lda, m_blk, M, kbeg, smem, wave, lane);
+    stage_tile32<B_KROW>(B, ldb, n_blk, N, kbeg, smem + TILE32_BYTES, wave, lane);
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  for (int t = 0; t < nt; ++t) {
+    char* cur = smem + (t & 1) * 2 * TILE32_BYTES;
+    char* nxt = smem + ((t + 1) & 1) * 2 * TILE32_BYTES;
+    if (t + 1 < nt) {
+      stage_tile32<A_KROW>(A, lda, m_blk, M, kbeg + (int64_t)(t + 1) * 32, nxt, wave, lane);
+      stage_tile32<B_KROW>(B, ldb, n_blk, N, kbeg + (int64_t)(t + 1) * 32, nxt + TILE32_BYTES, wave, lane);
+    }
+    bf16x8 af[4], bfr[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) af[i] = load_frag32<A_KROW>(cur, wr * 64 + i * 16, lane);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) bfr[j] = load_frag32<B_KROW>(cur + TILE32_BYTES, wc * 64 + j * 16, lane);
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        if (ATOMIC_F32) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i], bfr[j], acc[i][j], 0, 0, 0);
+        else            acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr[j], af[i], acc[i][j], 0, 0, 0);
+      }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+  }
+  const int g = lane >> 4, l16 = lane & 15;
+  if (ATOMIC_F32) {
+    float* C = (float*)Cv;
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int64_t n = n_blk + wc * 64 + j * 16 + l16;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int64_t m = m_blk + wr * 64 + i * 16 + 4 * g + r;
+          if (m < M && n < N) atomicAdd(C + m * ldc + n, acc[i][j][r]);
+        }
+      }
+  } else {
+    bf16_t* C = (bf16_t*)Cv;
+    constexpr int EP_STRIDE = 128 * 4 + 16;
+    const int half = lane >> 5, l32 = lane & 31;
+    const int64_t ncol = n_blk + l32 * 4;
+    float bv[4] = {0.f, 0.f, 0.f, 0.f};
+    if (bias) {
+      bf16x4 b4 = *reinterpret_cast<const bf16x4*>(bias + ncol);
+#pragma unroll
+      for (int r = 0; r < 4; ++r) bv[r] = (float)b4[r];
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+        *reinterpret_cast<f32x4*>(smem + (wr * 16 + l16) * EP_STRIDE + (wc * 64 + j * 16 + 4 * g) * 4) = acc[i][j];
+      __syncthreads();
+#pragma unroll
+      for (int rr = 0; rr < 4; ++rr) {
+        const int lrow = wave * 8 + rr * 2 + half;
+        const int64_t m = m_blk + (lrow >> 4) * 64 + i * 16 + (lrow & 15);
+        if (m < M) {
+          const f32x4 c = *reinterpret_cast<const f32x4*>(smem + lrow * EP_STRIDE + l32 * 16);
+          float v[4] = {c[0] + bv[0], c[1] + bv[1], c[2] + bv[2], c[3] + bv[3]};
+          if (act == MMRCA_ACT_MUL) {
+            bf16x4 h4 = *reinterpret_cast<const bf16x4*>(preact + m * ldc + ncol);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) v[r] *= (float)h4[r];
+          } else if (act == MMRCA_ACT_GELU_SAVE_GRAD) {
+            bf16x4 o;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+              const float e = erff(v[r] * 0.70710678118654752f);
+              o[r] = (bf16_t)(0.5f * (1.0f + e) + v[r] * 0.3989422804014327f * __expf(-0.5f * v[r] * v[r]));
+              v[r] = 0.5f * v[r] * (1.0f + e);
+            }
+            *reinterpret_cast<bf16x4*>(preact + m * ldc + ncol) = o;
+          } else if (act == MMRCA_ACT_GELU_BWD) {
+            bf16x4 h4 = *reinterpret_cast<const bf16x4*>(preact + m * ldc + ncol);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) v[r] *= gelu_grad_f((float)h4[r]);
+          } else if (preact) {
+            bf16x4 o;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) o[r] = (bf16_t)v[r];
+            *reinterpret_cast<bf16x4*>(preact + m * ldc + ncol) = o;
+          }
+          if (act == MMRCA_ACT_GELU) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) v[r] = gelu_f(v[r]);
+          }
+          if (addend) {
+            bf16x4 a4 = *reinterpret_cast<const bf16x4*>(addend + m * ldc + ncol);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) v[r] += (float)a4[r];
+          }
+          bf16x4 o;
+#pragma unroll
+          for (int r = 0; r < 4; ++r) o[r] = (bf16_t)v[r];
+          *reinterpret_cast<bf16x4*>(C + m * ldc + ncol) = o;
+        }
+      }
+      __syncthreads();
+    }
+  }
+}
+
+template <bool AK, bool BK2, bool AT>
+static void launch_mfma32(const void* A, const void* B, void* C, const void* bias, const void* addend, void* preact,
+                          int64_t M, int64_t N, int64_t K, int64_t lda, int64_t ldb, int64_t ldc, int act, int tiles_m,
+                          int tiles_n, int ksplits, int64_t ksplit_len, hipStream_t st) {
+  hipLaunchKernelGGL((gemm_mfma_k32<AK, BK2, AT>), dim3(tiles_m * tiles_n, ksplits), dim3(256), 4 * TILE32_BYTES, st,
+                     (const bf16_t*)A, (const bf16_t*)B, C, (const bf16_t*)bias, (const bf16_t*)addend, (bf16_t*)preact,
+                     M, N, K, lda, ldb, ldc, act, tiles_m, tiles_n, ksplit_len);
+}
+
+// ======================================================================================================
 // persistent variant: grid = 2 blocks per CU; every block walks work items (tile, k-split) it, it+G, it+2G, ... and the
 // two-buffer K pipeline never stops at an item boundary: the first K-tile of the NEXT item is issued before the last
 // MFMAs of the current one, so its HBM latency hides behind those MFMAs and the epilogue (which stages through the
@@ -551,7 +741,7 @@ extern "C" int mmrca_gemm(const void* A, const void* B, void* C, const void* bia
   // per CU is faster than the 256x256 kernel on every encoder shape, so AUTO never picks the large tile
   if (ok256 && impl == MMRCA_GEMM_MFMA256)
     return mmrca_gemm256(A, B, C, bias, addend, preact, M, N, K, lda, ldb, ldc, a_layout, b_layout, act, st);
-  if ((impl == MMRCA_GEMM_MFMA || impl == MMRCA_GEMM_MFMA_PERSIST) && !ok_mfma)
+  if ((impl == MMRCA_GEMM_MFMA || impl == MMRCA_GEMM_MFMA_PERSIST || impl == MMRCA_GEMM_MFMA_BK32) && !ok_mfma)
     return mmrca_fail(-3, "gemm: shape M=%lld N=%lld K=%lld dtype=%d does not qualify for the MFMA kernel", (long long)M, (long long)N, (long long)K, dtype);
   const bool use_mfma = ok_mfma && impl != MMRCA_GEMM_REF;   // 128x128 kernel
 
@@ -562,7 +752,7 @@ extern "C" int mmrca_gemm(const void* A, const void* B, void* C, const void* bia
     if (out_f32_accum) {
       const int64_t ksteps = K / GBK;
       // resident slots = 256 CUs x 2 blocks: aim for one (few tiles) or two (many tiles) full rounds
-      const int64_t target = (g_mmrca_dbg >> 8) > 0 ? (g_mmrca_dbg >> 8) : ((int64_t)tiles_m * tiles_n >= 64 ? 1024 : 512);
+      const int64_t target = (g_mmrca_dbg >> 8) > 0 ? (g_mmrca_dbg >> 8) : ((int64_t)tiles_m * tiles_n >= 64 ? 1024 : 512);   // see below: 1024 = one round of 4 blocks/CU (BK=32 kernel) or two rounds of 2 (BK=64)
       int64_t want = target / ((int64_t)tiles_m * tiles_n);
       if (want < 1) want = 1;
       if (want > ksteps / 4) want = ksteps / 4 > 0 ? ksteps / 4 : 1;
@@ -571,6 +761,24 @@ extern "C" int mmrca_gemm(const void* A, const void* B, void* C, const void* bia
       ksplits = (int)((ksteps + steps_per - 1) / steps_per);
     }
     const bool ak = a_layout == MMRCA_KROW, bk = b_layout == MMRCA_KROW, at = out_f32_accum != 0;
+    // AUTO: the 128x128x32 kernel (four blocks per CU) wherever an operand is read through the transposed LDS path
+    // (dgrad, wgrad): +17-25 % there; the 128x128x64 kernel for the all-ROWK forward GEMMs (long-K shapes lose 10-16 %
+    // with 32-deep steps) and for weight gradients with too few tiles to fill four blocks per CU.
+    const bool auto32 = impl == MMRCA_GEMM_AUTO && (ak || bk) && !(at && (int64_t)tiles_m * tiles_n < 64);
+    if ((impl == MMRCA_GEMM_MFMA_BK32 || auto32) && !(at && bias)) {
+#define L32(AK_, BK_, AT_) launch_mfma32<AK_, BK_, AT_>(A, B, C, bias, addend, preact, M, N, K, lda, ldb, ldc, act, tiles_m, tiles_n, ksplits, ksplit_len, st)
+      if (!ak && !bk && !at) L32(false, false, false);
+      else if (!ak && bk && !at) L32(false, true, false);
+      else if (ak && !bk && !at) L32(true, false, false);
+      else if (ak && bk && !at) L32(true, true, false);
+      else if (!ak && !bk && at) L32(false, false, true);
+      else if (!ak && bk && at) L32(false, true, true);
+      else if (ak && !bk && at) L32(true, false, true);
+      else L32(true, true, true);
+#undef L32
+      MMRCA_CHECK_LAUNCH("gemm(mfma,bk32)");
+      return 0;
+    }
     if (impl == MMRCA_GEMM_MFMA_PERSIST && !(at && bias)) {
 #define LP(AK_, BK_, AT_) launch_mfma_p<AK_, BK_, AT_>(A, B, C, bias, addend, preact, M, N, K, lda, ldb, ldc, act, tiles_m, tiles_n, ksplits, ksplit_len, st)
       if (!ak && !bk && !at) LP(false, false, false);

@@ -119,6 +119,27 @@ def test_gemm_mfma_epilogues_and_wgrad():
 
 
 @pytest.mark.parametrize("layouts", [(0, 0), (0, 1), (1, 1), (1, 0)])
+def test_gemm_bk32_kernel(layouts):
+    """128x128x32 kernel (four blocks per CU): exact integers first (new 64-byte-row LDS image), then random data, ragged M,
+    odd number of 32-deep K steps, epilogues, split-K accumulate."""
+    al, bl = layouts
+    M, N, K = 256, 256, 96
+    A = ((torch.arange(M)[:, None] * 7 + torch.arange(K)[None, :] * 3) % 5 - 2.0)
+    B = ((torch.arange(N)[:, None] * 3 + torch.arange(K)[None, :] * 5) % 7 - 3.0)
+    Kp = 128
+    Ap, Bp = F.pad(A, (0, Kp - K)), F.pad(B, (0, Kp - K))
+    Ad, Bd = dev(Ap if al == 0 else Ap.t(), torch.bfloat16), dev(Bp if bl == 0 else Bp.t(), torch.bfloat16)
+    Cd = torch.empty(M, N, device="cuda", dtype=torch.bfloat16)
+    L.gemm(Ad, Bd, Cd, M=M, N=N, K=Kp, lda=Ad.shape[1], ldb=Bd.shape[1], ldc=N, a_layout=al, b_layout=bl, dtype=L.BF16, impl=L.IMPL_MFMA_BK32)
+    torch.cuda.synchronize()
+    assert torch.equal(Cd.float().cpu(), (A @ B.t()).bfloat16().float()), (al, bl)
+    Mr = 384 if al == L.KROW else 300
+    _gemm_case(Mr, 256, 192, al, bl, torch.bfloat16, L.IMPL_MFMA_BK32, bias=True)
+    _gemm_case(Mr, 384, 256, al, bl, torch.bfloat16, L.IMPL_MFMA_BK32, act=L.ACT_GELU, bias=True, addend=True, preact=True)
+    _gemm_case(768, 768, 788, 1, 1, torch.bfloat16, L.IMPL_MFMA_BK32, accum=True)
+
+
+@pytest.mark.parametrize("layouts", [(0, 0), (0, 1), (1, 1), (1, 0)])
 def test_gemm_persistent_kernel(layouts):
     """Persistent 128x128 kernel (pipeline runs across tile boundaries): many more tiles than resident blocks, ragged M,
     single-K-step items, epilogues, and the split-K fp32 accumulate path."""

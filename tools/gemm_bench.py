@@ -14,7 +14,7 @@ SHAPES = [  # (name, M, N, K, a_layout, b_layout, accum)
     ("epi K64", M, 3072, 64, 0, 0, 0), ("epi K128", M, 3072, 128, 0, 0, 0), ("epi K1536", M, 3072, 1536, 0, 0, 0),
     ("text fwd qkv", 16384, 2304, 768, 0, 0, 0), ("text fwd out", 16384, 768, 768, 0, 0, 0),
 ]
-impls = {"mfma128": L.IMPL_MFMA, "persist": L.IMPL_MFMA_PERSIST}
+impls = {"mfma128": L.IMPL_MFMA, "bk32": L.IMPL_MFMA_BK32}
 DBG = [int(x) for x in os.environ.get("MMRCA_DBG", "0").split(",")]
 only = sys.argv[1:] 
 L.load()
@@ -38,6 +38,7 @@ for name, m, n, k, al, bl, acc in SHAPES:
     variants = [(a, b, 0) for a, b in impls.items()] + [(f"256dbg{d}", L.IMPL_MFMA256, d) for d in DBG if d and d < 256]
     variants += [(f"128tgt{d >> 8}", L.IMPL_MFMA, d) for d in DBG if d >= 256]
     variants += [(f"128dbg{d}", L.IMPL_MFMA, d) for d in DBG if d == 16]
+    variants += [(f"bk32tgt{d >> 8}", L.IMPL_MFMA_BK32, d) for d in DBG if d >= 256]
     runs = {}
     for iname, impl, dbg in variants:
         if impl == L.IMPL_MFMA256 and (acc or n % 256 or (al == 1 and m % 256)):
