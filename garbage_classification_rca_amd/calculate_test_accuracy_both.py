@@ -1,0 +1,133 @@
+"""Test-split evaluator: the reference's ``calculate_test_accuracy_both.py`` on the HIP module.
+
+    python calculate_test_accuracy_both.py --late_fusion=MM_RCA --reverse --image_model=transformer_B16 \
+        --text_model=distilbert --model_path=<checkpoint.pth> --dataset_folder_name=<Test folder>
+
+Kept: ``calculate_test_accuracy`` (:52-117: argmax, running accuracy, confusion matrix, sklearn classification report with
+the class names Black/Blue/Green/TTR), the CSV report and confusion-matrix image file names (:119-141), seeds 42
+(:151-157), batch 16, eval with both modalities.  Fixed: the reference passes 9 arguments to ``MM_RCA`` here (:162-171,
+``cross_attention_only`` missing) and cannot construct the model; this script passes all ten.  The confusion matrix is
+computed with numpy (torchmetrics / seaborn are optional).
+"""
+from __future__ import annotations
+
+import math
+import os
+import sys
+
+import numpy as np
+import torch
+
+from .CustomImageTextFolder import CustomImageTextFolder
+from .main_both import Transforms
+from .multimodal_model import MM_RCA
+from .options import args_parser
+from .training import mode_config_dict
+
+_num_classes = 4
+BASE_PATH = os.getcwd() + os.sep
+classes = ["Black", "Blue", "Green", "TTR"]
+
+
+def confusion_matrix(labels, preds, n=_num_classes) -> np.ndarray:
+    cm = np.zeros((n, n), dtype=np.int64)
+    for t, p in zip(labels, preds):
+        cm[int(t), int(p)] += 1
+    return cm
+
+
+def calculate_test_accuracy(model, data_loader, len_test_data, hw_device, batch_size, mode, eval_mode, verbose=True):
+    """Reference :52-117.  Returns (accuracy %, text report, report dict, confusion matrix)."""
+    correct = 0
+    n_batches = math.ceil(len_test_data / batch_size)
+    all_preds, all_labels = [], []
+    with torch.no_grad():
+        for batch_idx, (data, labels) in enumerate(data_loader):
+            texts = data['text']
+            images = data['image']['raw_image'].to(hw_device)
+            ids, mask = texts['tokens'].to(hw_device), texts['attention_mask'].to(hw_device)
+            labels = labels.to(hw_device)
+            outputs = model(_input_ids=ids, _attention_mask=mask, _images=images, eval=eval_mode,
+                            remove_text=mode["remove_text"], remove_image=mode["remove_image"])
+            pred = torch.max(outputs, 1)[1].view(-1)
+            all_preds += pred.cpu().tolist()
+            all_labels += labels.cpu().tolist()
+            correct += torch.sum(torch.eq(pred, labels)).item()
+            if verbose:
+                print("Test batches {}/{} ".format(batch_idx, n_batches))
+                print("Running test accuracy: {:.3f} %".format(100 * (correct / len_test_data)))
+    test_acc = 100 * (correct / max(len_test_data, 1))
+    cm = confusion_matrix(all_labels, all_preds)
+    try:
+        from sklearn.metrics import classification_report
+        kw = dict(labels=list(range(_num_classes)), target_names=classes, zero_division=0)
+        report = classification_report(all_labels, all_preds, **kw)
+        report_dict = classification_report(all_labels, all_preds, output_dict=True, **kw)
+    except Exception:
+        report, report_dict = "", {}
+    return test_acc, report, report_dict, cm
+
+
+def generate_report_and_image(test_report_dict, test_accuracy, conf_matrix, mode, out_dir=None):
+    """Reference :119-141 (same file names)."""
+    out_dir = out_dir or BASE_PATH
+    import pandas as pd
+    csv_path = os.path.join(out_dir, "multimodal_model_report_test_set_acc_{:.2f}_{}.csv".format(test_accuracy, mode))
+    pd.DataFrame.from_dict(test_report_dict).to_csv(csv_path, index=True)
+    png_path = os.path.join(out_dir, 'conf_matrix_multimodal_model_test_set_acc_{:.2f}_{}.png'.format(test_accuracy, mode))
+    try:
+        import matplotlib
+        matplotlib.use("Agg")
+        import matplotlib.pyplot as plt
+        plt.rcParams.update({'font.size': 16})
+        fig, ax = plt.subplots(figsize=(10, 5))
+        im = ax.imshow(conf_matrix, cmap='viridis')
+        ax.set_xticks(range(_num_classes)); ax.set_yticks(range(_num_classes))
+        ax.set_xticklabels(classes); ax.set_yticklabels(classes)
+        for i in range(_num_classes):
+            for j in range(_num_classes):
+                ax.text(j, i, str(int(conf_matrix[i, j])), ha="center", va="center", color="w")
+        fig.colorbar(im)
+        fig.savefig(png_path)
+        plt.close(fig)
+    except Exception as e:      # plotting is optional
+        print(f"[mmrca] confusion-matrix image skipped ({type(e).__name__}: {e})")
+        png_path = None
+    return csv_path, png_path
+
+
+def main(argv=None):
+    args = args_parser(argv)
+    if not torch.cuda.is_available():
+        print("GPU not available!!!!  The MM-RCA HIP path has no CPU fallback.")
+        sys.exit(1)
+    device = torch.device("cuda:0")
+    torch.manual_seed(42)
+    np.random.seed(42)
+    _batch_size = 16
+    if args.late_fusion != "MM_RCA":
+        print("Wrong late fusion strategy: ", args.late_fusion)
+        sys.exit(1)
+    image_model = args.image_model if args.image_model not in ("b4",) else "transformer_B16"
+    model = MM_RCA(_num_classes, args.model_dropout, args.image_text_dropout, args.image_prob_dropout, args.num_neurons_FC,
+                   args.text_model, _batch_size, args.reverse, args.features_only, args.cross_attention_only,
+                   image_model_name=image_model, dtype=torch.bfloat16 if args.dtype == "bf16" else torch.float32, device=device)
+    model.load_state_dict(torch.load(args.model_path, map_location=device))
+    model.eval()
+    WIDTH, HEIGHT = model.get_image_size()
+    test_data = CustomImageTextFolder(root=args.dataset_folder_name, tokens_max_len=args.tokens_max_len or model.get_max_token_size(),
+                                      tokenizer_text=model.get_tokenizer(), transform=Transforms(WIDTH, HEIGHT))
+    print("Num of test samples: {}".format(len(test_data)))
+    loader = torch.utils.data.DataLoader(dataset=test_data, batch_size=_batch_size, shuffle=True, num_workers=min(8, args.num_workers),
+                                         pin_memory=True)
+    acc, report, report_dict, cm = calculate_test_accuracy(model, loader, len(test_data), device, _batch_size,
+                                                           mode_config_dict['both'], True)
+    generate_report_and_image(report_dict, acc, cm, "always_both")
+    print(test_data.class_to_idx)
+    print("Test accuracy random both: {:.2f} %".format(acc))
+    print("Test Report:")
+    print(report)
+
+
+if __name__ == '__main__':
+    main()

@@ -220,6 +220,16 @@ class EffV2MediumAndDistilbertGated(torch.nn.Module):
         self.engine.backward(dlogits, train_text=tt, train_image=ti)
 
     def load_state_dict(self, state_dict, strict=True, **kw):
+        """Present-but-unused head layers can differ in shape between runs (``clip_fc_layer`` is ``Linear(batch_size, 4)``,
+        multimodal_model.py:237, so a checkpoint trained at another --batch_size does not fit): such keys are skipped
+        with a note instead of failing the load; every parameter the MM_RCA forward uses must match."""
+        own = super().state_dict()
+        state_dict = dict(state_dict)
+        for k in list(state_dict):
+            if k in own and k not in self._arena_params and tuple(own[k].shape) != tuple(state_dict[k].shape):
+                print(f"[mmrca] skipping unused parameter {k}: checkpoint {tuple(state_dict[k].shape)} vs model {tuple(own[k].shape)}")
+                del state_dict[k]
+                strict = False
         r = super().load_state_dict(state_dict, strict=strict, **kw)
         self.engine.arena.lp_valid = False
         return r

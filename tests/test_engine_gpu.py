@@ -288,3 +288,42 @@ def test_two_rank_data_parallel_rehearsal_keeps_replicas_identical():
     import json
     d = json.loads(line)
     assert d["n_gpus"] == 2 and d["config"]["global_batch"] == 16 and d["scaling"] == "weak"
+
+
+def test_end_to_end_training_driver_and_evaluator_on_a_tiny_folder(tmp_path):
+    """Drop-in plumbing on real files (the shape of BASELINE configs[0], with ViT-B/16 for the image side):
+    folder dataset -> main_both.py two-phase loop (frozen epoch, fine-tune epoch, four accuracy passes, best-val
+    checkpoint with the reference's file-name pattern) -> calculate_test_accuracy_both.py on that checkpoint."""
+    import glob
+    import subprocess
+    import sys
+    from PIL import Image
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    rng = np.random.default_rng(0)
+    for split in ("Train", "Val"):
+        for ci, c in enumerate(["Black", "Blue", "Green", "TTR"]):
+            d = tmp_path / split / c
+            d.mkdir(parents=True)
+            for k in range(2 if split == "Train" else 1):
+                arr = (rng.random((40, 56, 3)) * 255).astype(np.uint8)
+                arr[:, :, ci % 3] = 255 - 40 * ci
+                Image.fromarray(arr).save(d / f"{['chip_bag','pizza_box','banana_peel','aa_batteries'][ci]}_{k}.png")
+    env = dict(os.environ, PYTHONPATH=root)
+    common = ["--late_fusion=MM_RCA", "--reverse", "--image_model=transformer_B16", "--text_model=distilbert",
+              "--tokens_max_len", "16", "--num_workers", "0", "--dtype", "bf16"]
+    r = subprocess.run([sys.executable, os.path.join(root, "main_both.py"), *common, "--dataset_folder_name=Train",
+                        "--dataset_folder_name_val=Val", "--epochs", "1", "--ft_epochs", "1", "--batch_size", "4",
+                        "--batch_size_FT", "4", "--acc_steps_FT", "2", "--balance_weights", "--label_smoothing", "0.1", "--seed", "1"],
+                       cwd=tmp_path, env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-1500:] + r.stderr[-3000:]
+    assert "Starting Fine tuning!!" in r.stdout and "Optimizer step on batch idx" in r.stdout
+    ckpts = glob.glob(str(tmp_path / "model_weights" / "distilbert_transformer_B16" / "BEST_model_*_MM_RCA_*.pth"))
+    assert ckpts, r.stdout[-2000:]
+    sd = torch.load(ckpts[0], map_location="cpu")
+    assert "cross_attention_1.W_query.weight" in sd and "text_model.embeddings.word_embeddings.weight" in sd
+    r2 = subprocess.run([sys.executable, os.path.join(root, "calculate_test_accuracy_both.py"), *common,
+                         "--dataset_folder_name", str(tmp_path / "Val"), "--model_path", ckpts[0]],
+                        cwd=tmp_path, env=env, capture_output=True, text=True, timeout=600)
+    assert r2.returncode == 0, r2.stdout[-1500:] + r2.stderr[-3000:]
+    assert "Test accuracy random both" in r2.stdout
+    assert glob.glob(str(tmp_path / "multimodal_model_report_test_set_acc_*_always_both.csv"))

@@ -296,3 +296,22 @@ def test_parameter_inventories():
     keys = [k for k, _ in S.head_unused_params(1280, 768, 4, 256, 16, False, False)]
     for k in ("clip_fc_layer.weight", "logit_scale", "gru_text.weight_ih_l0", "fusion.kernel1", "classifier.bias", "final.weight"):
         assert k in keys
+
+
+def test_test_split_evaluator_logic_on_cpu():
+    """calculate_test_accuracy (reference calculate_test_accuracy_both.py:52-117) with a stand-in model: accuracy,
+    confusion matrix, sklearn report, CSV / image file names."""
+    from garbage_classification_rca_amd import calculate_test_accuracy_both as E
+    m = _Tiny()
+    dl, xs, ys = _loader(12, 4)
+    acc, report, rd, cm = E.calculate_test_accuracy(m, dl, 12, "cpu", 4, mode_config_dict["both"], True, verbose=False)
+    pred = m(None, None, xs).argmax(1)
+    assert abs(acc - 100.0 * float((pred == ys).float().mean())) < 1e-9
+    assert cm.shape == (4, 4) and cm.sum() == 12 and int(np.trace(cm)) == int((pred == ys).sum())
+    for i in range(12):
+        pass
+    assert set(rd.keys()) >= {"Black", "Blue", "Green", "TTR", "accuracy"}
+    with tempfile.TemporaryDirectory() as td:
+        csvp, pngp = E.generate_report_and_image(rd, acc, cm, "always_both", out_dir=td)
+        assert os.path.basename(csvp) == "multimodal_model_report_test_set_acc_{:.2f}_always_both.csv".format(acc)
+        assert os.path.exists(csvp)
