@@ -8,7 +8,7 @@
 // --------------------------------------------------------------------------------------------------------
 // s = x (+res); y = LN(s)*gamma+beta
 // --------------------------------------------------------------------------------------------------------
-template <typename T>
+template <typename T, int NV>
 __global__ void __launch_bounds__(256)
 add_ln_fwd_k(const T* __restrict__ x, const T* __restrict__ res, const T* __restrict__ gamma, const T* __restrict__ beta,
              T* __restrict__ sum_out, T* __restrict__ y, float* __restrict__ mean, float* __restrict__ rstd,
@@ -17,10 +17,10 @@ add_ln_fwd_k(const T* __restrict__ x, const T* __restrict__ res, const T* __rest
   const float in_sc = in_p > 0.f ? 1.f / (1.f - in_p) : 1.f, out_sc = out_p > 0.f ? 1.f / (1.f - out_p) : 1.f;
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   for (int64_t row = (int64_t)blockIdx.x * 4 + wave; row < rows; row += (int64_t)gridDim.x * 4) {
-    float v[LN_MAXV][4];
+    float v[NV][4];
     float s = 0.f;
 #pragma unroll
-    for (int it = 0; it < LN_MAXV; ++it) {
+    for (int it = 0; it < NV; ++it) {
       const int c = it * 256 + lane * 4;
       if (c < D) {
         Vec4<T> a = Vec4<T>::load(x + row * ld_x + c);
@@ -46,7 +46,7 @@ add_ln_fwd_k(const T* __restrict__ x, const T* __restrict__ res, const T* __rest
     const float mu = wave_sum(s) / (float)D;
     float q = 0.f;
 #pragma unroll
-    for (int it = 0; it < LN_MAXV; ++it) {
+    for (int it = 0; it < NV; ++it) {
       const int c = it * 256 + lane * 4;
       if (c < D) {
 #pragma unroll
@@ -56,7 +56,7 @@ add_ln_fwd_k(const T* __restrict__ x, const T* __restrict__ res, const T* __rest
     const float rs = rsqrtf(wave_sum(q) / (float)D + eps);
     if (lane == 0) { if (mean) mean[row] = mu; if (rstd) rstd[row] = rs; }
 #pragma unroll
-    for (int it = 0; it < LN_MAXV; ++it) {
+    for (int it = 0; it < NV; ++it) {
       const int c = it * 256 + lane * 4;
       if (c < D) {
         Vec4<T> g = Vec4<T>::load(gamma + c), b = Vec4<T>::load(beta + c), o;
@@ -82,10 +82,15 @@ extern "C" int mmrca_add_layernorm_fwd(const void* x, const void* res, const voi
   MMRCA_REQUIRE(ld_x >= D && ld_y >= D && ld_x % 4 == 0 && ld_y % 4 == 0, "add_layernorm_fwd: bad leading dims");
   if (rows <= 0) return 0;
   const int grid = (int)((rows + 3) / 4 < 4096 ? (rows + 3) / 4 : 4096);
+#define LN_FWD_LAUNCH(NV_)                                                                                             \
+  hipLaunchKernelGGL((add_ln_fwd_k<T, NV_>), dim3(grid), dim3(256), 0, (hipStream_t)stream, (const T*)x, (const T*)res,  \
+                     (const T*)gamma, (const T*)beta, (T*)sum_out, (T*)y, mean, rstd, rows, D, ld_x, ld_y, eps, in_drop_p,  \
+                     in_drop_seed, out_drop_p, out_drop_seed)
+  const int nv = (D + 255) / 256;        // register slabs of 256 columns actually needed (3 for D=768)
   MMRCA_DISPATCH_DTYPE(dtype, "add_layernorm_fwd",
-    hipLaunchKernelGGL(add_ln_fwd_k<T>, dim3(grid), dim3(256), 0, (hipStream_t)stream, (const T*)x, (const T*)res,
-                       (const T*)gamma, (const T*)beta, (T*)sum_out, (T*)y, mean, rstd, rows, D, ld_x, ld_y, eps, in_drop_p, in_drop_seed,
-                       out_drop_p, out_drop_seed);)
+    if (nv <= 1) LN_FWD_LAUNCH(1); else if (nv <= 2) LN_FWD_LAUNCH(2); else if (nv <= 3) LN_FWD_LAUNCH(3);
+    else if (nv <= 4) LN_FWD_LAUNCH(4); else LN_FWD_LAUNCH(8);)
+#undef LN_FWD_LAUNCH
   MMRCA_CHECK_LAUNCH("add_layernorm_fwd");
   return 0;
 }
@@ -94,26 +99,27 @@ extern "C" int mmrca_add_layernorm_fwd(const void* x, const void* res, const voi
 // LayerNorm backward: ds = rstd*(g - mean(g) - xhat*mean(g*xhat)) (+dres), g = dy*gamma;
 // dgamma += sum_rows dy*xhat, dbeta += sum_rows dy (per-lane register partials -> LDS -> one atomic per column/block)
 // --------------------------------------------------------------------------------------------------------
-template <typename T>
+template <typename T, int NV>
 __global__ void __launch_bounds__(256)
 ln_bwd_k(const T* __restrict__ dy, const T* __restrict__ s, const T* __restrict__ gamma, const float* __restrict__ mean,
          const float* __restrict__ rstd, const T* __restrict__ dres, T* __restrict__ ds, float* __restrict__ dgamma,
          float* __restrict__ dbeta, int64_t rows, int D, int64_t ld_dy, int64_t ld_s, int64_t ld_ds, float dy_p,
-         uint64_t dy_seed, float br_p, uint64_t br_seed, T* __restrict__ dbranch) {
+         uint64_t dy_seed, float br_p, uint64_t br_seed, T* __restrict__ dbranch, float* __restrict__ dcol,
+         float* __restrict__ dcol_branch) {
   const float dy_sc = dy_p > 0.f ? 1.f / (1.f - dy_p) : 1.f, br_sc = br_p > 0.f ? 1.f / (1.f - br_p) : 1.f;
-  __shared__ float red[2][4][256 * 4 + 4];   // [dgamma|dbeta][wave][col chunk]; reduced one `it` slab at a time
+  __shared__ float red[4][4][256];   // [dgamma|dbeta|colsum(ds)|colsum(dbranch)][wave][column of the slab]
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-  float adg[LN_MAXV][4], adb[LN_MAXV][4];
+  float adg[NV][4], adb[NV][4], adc[NV][4], adcb[NV][4];
 #pragma unroll
-  for (int it = 0; it < LN_MAXV; ++it)
+  for (int it = 0; it < NV; ++it)
 #pragma unroll
-    for (int j = 0; j < 4; ++j) { adg[it][j] = 0.f; adb[it][j] = 0.f; }
+    for (int j = 0; j < 4; ++j) { adg[it][j] = 0.f; adb[it][j] = 0.f; adc[it][j] = 0.f; adcb[it][j] = 0.f; }
   for (int64_t row = (int64_t)blockIdx.x * 4 + wave; row < rows; row += (int64_t)gridDim.x * 4) {
     const float mu = mean[row], rs = rstd[row];
-    float g[LN_MAXV][4], xh[LN_MAXV][4];
+    float g[NV][4], xh[NV][4];
     float s1 = 0.f, s2 = 0.f;
 #pragma unroll
-    for (int it = 0; it < LN_MAXV; ++it) {
+    for (int it = 0; it < NV; ++it) {
       const int c = it * 256 + lane * 4;
       if (c < D) {
         Vec4<T> d = Vec4<T>::load(dy + row * ld_dy + c), sv = Vec4<T>::load(s + row * ld_s + c), gm = Vec4<T>::load(gamma + c);
@@ -133,7 +139,7 @@ ln_bwd_k(const T* __restrict__ dy, const T* __restrict__ s, const T* __restrict_
     }
     s1 = wave_sum(s1) / (float)D; s2 = wave_sum(s2) / (float)D;
 #pragma unroll
-    for (int it = 0; it < LN_MAXV; ++it) {
+    for (int it = 0; it < NV; ++it) {
       const int c = it * 256 + lane * 4;
       if (c < D) {
         Vec4<T> o;
@@ -145,11 +151,19 @@ ln_bwd_k(const T* __restrict__ dy, const T* __restrict__ s, const T* __restrict_
           for (int j = 0; j < 4; ++j)
             ob.v[j] = (br_p > 0.f && mmrca_uniform(br_seed, (uint64_t)row * D + c + j) < br_p) ? 0.f : o.v[j] * br_sc;
           ob.store(dbranch + row * ld_ds + c);
+          if (dcol_branch) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) adcb[it][j] += ob.v[j];
+          }
         }
         if (dres) {
           Vec4<T> r = Vec4<T>::load(dres + row * ld_ds + c);
 #pragma unroll
           for (int j = 0; j < 4; ++j) o.v[j] += r.v[j];
+        }
+        if (dcol) {            // column sums of the OUTPUT = bias gradient of the linear layer that produced this stream
+#pragma unroll
+          for (int j = 0; j < 4; ++j) adc[it][j] += o.v[j];
         }
         o.store(ds + row * ld_ds + c);
       }
@@ -157,18 +171,21 @@ ln_bwd_k(const T* __restrict__ dy, const T* __restrict__ s, const T* __restrict_
   }
   // cross-wave reduction of the parameter gradients, one 256-column slab at a time
 #pragma unroll
-  for (int it = 0; it < LN_MAXV; ++it) {
+  for (int it = 0; it < NV; ++it) {
     if (it * 256 >= D) break;
     __syncthreads();
 #pragma unroll
-    for (int j = 0; j < 4; ++j) { red[0][wave][lane * 4 + j] = adg[it][j]; red[1][wave][lane * 4 + j] = adb[it][j]; }
+    for (int j = 0; j < 4; ++j) {
+      red[0][wave][lane * 4 + j] = adg[it][j]; red[1][wave][lane * 4 + j] = adb[it][j];
+      red[2][wave][lane * 4 + j] = adc[it][j]; red[3][wave][lane * 4 + j] = adcb[it][j];
+    }
     __syncthreads();
     const int c = it * 256 + threadIdx.x;
     if (c < D) {
-      const float a = red[0][0][threadIdx.x] + red[0][1][threadIdx.x] + red[0][2][threadIdx.x] + red[0][3][threadIdx.x];
-      const float b = red[1][0][threadIdx.x] + red[1][1][threadIdx.x] + red[1][2][threadIdx.x] + red[1][3][threadIdx.x];
-      if (dgamma) atomicAdd(dgamma + c, a);
-      if (dbeta) atomicAdd(dbeta + c, b);
+      float* dst[4] = {dgamma, dbeta, dcol, dcol_branch};
+#pragma unroll
+      for (int q = 0; q < 4; ++q)
+        if (dst[q]) atomicAdd(dst[q] + c, red[q][0][threadIdx.x] + red[q][1][threadIdx.x] + red[q][2][threadIdx.x] + red[q][3][threadIdx.x]);
     }
   }
 }
@@ -176,7 +193,8 @@ ln_bwd_k(const T* __restrict__ dy, const T* __restrict__ s, const T* __restrict_
 extern "C" int mmrca_layernorm_bwd(const void* dy, const void* s, const void* gamma, const float* mean, const float* rstd,
                                    const void* dres, void* ds, float* dgamma, float* dbeta, int64_t rows, int D,
                                    int64_t ld_dy, int64_t ld_s, int64_t ld_ds, float dy_drop_p, uint64_t dy_drop_seed,
-                                   float branch_drop_p, uint64_t branch_drop_seed, void* dbranch, int dtype, void* stream) {
+                                   float branch_drop_p, uint64_t branch_drop_seed, void* dbranch, float* dcol, float* dcol_branch,
+                                   int dtype, void* stream) {
   MMRCA_REQUIRE(dy_drop_p >= 0.f && dy_drop_p < 1.f && branch_drop_p >= 0.f && branch_drop_p < 1.f, "layernorm_bwd: dropout p must be in [0,1)");
   MMRCA_REQUIRE(dy && s && gamma && mean && rstd && ds, "layernorm_bwd: null pointer");
   MMRCA_REQUIRE(D > 0 && D % 4 == 0 && D <= 256 * LN_MAXV, "layernorm_bwd: D=%d unsupported", D);
@@ -184,10 +202,16 @@ extern "C" int mmrca_layernorm_bwd(const void* dy, const void* s, const void* ga
   if (rows <= 0) return 0;
   int64_t want = (rows + 3) / 4;
   const int grid = (int)(want < 1024 ? want : 1024);
+  MMRCA_REQUIRE(!(dcol_branch && !dbranch), "layernorm_bwd: dcol_branch needs dbranch");
+#define LN_BWD_LAUNCH(NV_)                                                                                                  \
+  hipLaunchKernelGGL((ln_bwd_k<T, NV_>), dim3(grid), dim3(256), 0, (hipStream_t)stream, (const T*)dy, (const T*)s,           \
+                     (const T*)gamma, mean, rstd, (const T*)dres, (T*)ds, dgamma, dbeta, rows, D, ld_dy, ld_s, ld_ds, dy_drop_p, \
+                     dy_drop_seed, branch_drop_p, branch_drop_seed, (T*)dbranch, dcol, dcol_branch)
+  const int nv = (D + 255) / 256;
   MMRCA_DISPATCH_DTYPE(dtype, "layernorm_bwd",
-    hipLaunchKernelGGL(ln_bwd_k<T>, dim3(grid), dim3(256), 0, (hipStream_t)stream, (const T*)dy, (const T*)s, (const T*)gamma,
-                       mean, rstd, (const T*)dres, (T*)ds, dgamma, dbeta, rows, D, ld_dy, ld_s, ld_ds, dy_drop_p, dy_drop_seed,
-                       branch_drop_p, branch_drop_seed, (T*)dbranch);)
+    if (nv <= 1) LN_BWD_LAUNCH(1); else if (nv <= 2) LN_BWD_LAUNCH(2); else if (nv <= 3) LN_BWD_LAUNCH(3);
+    else if (nv <= 4) LN_BWD_LAUNCH(4); else LN_BWD_LAUNCH(8);)
+#undef LN_BWD_LAUNCH
   MMRCA_CHECK_LAUNCH("layernorm_bwd");
   return 0;
 }

@@ -243,7 +243,7 @@ class MMRCAEngine:
         L.gemm(x, w, out, bias=b, addend=addend, preact=preact, M=M, N=N, K=K, lda=K, ldb=K, ldc=N,
                a_layout=L.ROWK, b_layout=L.ROWK, act=act, dtype=self.dt, impl=self.gemm_impl)
 
-    def _lin_bwd(self, dy, x, wkey, bkey, dx, M, N, K, addend=None, wnumel=None, gelu_h=None):
+    def _lin_bwd(self, dy, x, wkey, bkey, dx, M, N, K, addend=None, wnumel=None, gelu_h=None, bias_done=False):
         """dy [M,N], x [M,K], weight [N,K]:  dW += dy^T x and db += colsum(dy) in ONE pass (the bias gradient rides
         on the weight-gradient GEMM); dx = dy W (+ addend), optionally times gelu'(gelu_h) in the epilogue."""
         Mk = _round_up(M, 64)
@@ -253,7 +253,7 @@ class MMRCAEngine:
         def wgrad():
             L.gemm(dy, x, gw, bias=(gb if FUSE_BIAS_GRAD else None), M=N, N=K, K=Mk, lda=N, ldb=K, ldc=K, a_layout=L.KROW,
                    b_layout=L.KROW, accum=True, dtype=self.dt, impl=self.gemm_impl)
-            if not FUSE_BIAS_GRAD:
+            if not FUSE_BIAS_GRAD and not bias_done:     # bias_done: the producer of dy already accumulated its column sums
                 L.colsum_accum(dy, gb, M, N, N, self.dt)
 
         if self._side is None:
@@ -283,9 +283,10 @@ class MMRCAEngine:
                             ld_x or D, ld_y or D, eps, self.dt, in_drop=in_drop, out_drop=out_drop)
 
     def _ln_bwd(self, dy, s, pfx, mean, rstd, dres, ds, rows, D, ld_dy=None, ld_s=None, ld_ds=None, dy_drop=(0.0, 0),
-                branch_drop=(0.0, 0), dbranch=None):
+                branch_drop=(0.0, 0), dbranch=None, dcol=None, dcol_branch=None):
         L.layernorm_bwd(dy, s, self.W(pfx + ".weight"), mean, rstd, dres, ds, self.G(pfx + ".weight"), self.G(pfx + ".bias"),
-                        rows, D, ld_dy or D, ld_s or D, ld_ds or D, self.dt, dy_drop=dy_drop, branch_drop=branch_drop, dbranch=dbranch)
+                        rows, D, ld_dy or D, ld_s or D, ld_ds or D, self.dt, dy_drop=dy_drop, branch_drop=branch_drop, dbranch=dbranch,
+                        dcol=dcol, dcol_branch=dcol_branch)
 
     def _layer_boundary(self):
         """All side-stream weight-gradient work of the finished layer must be done before the next layer re-writes the
@@ -368,16 +369,22 @@ class MMRCAEngine:
             dp, sd = sv["drop_p"], (lambda layer, site: self._site_seed(sv["drop_seed"], layer, site))
             post_attn_drop = dp if s.name != "distilbert" else 0.0
             df = gb("dbr_ffn", D) if dp > 0 else None      # gradient of the dropped FFN branch
-            self._ln_bwd(dx, a["s2"], P + K["ln2"], a["m2"], a["r2"], None, ds2, M, D, branch_drop=(dp, sd(i, 3)), dbranch=df)
+            gb_f2, gb_o = self.G(P + K["f2"] + ".bias"), self.G(P + K["o"] + ".bias")
+            # the LayerNorm backward also emits the column sums of its output = bias gradient of the linear that fed it
+            self._ln_bwd(dx, a["s2"], P + K["ln2"], a["m2"], a["r2"], None, ds2, M, D, branch_drop=(dp, sd(i, 3)), dbranch=df,
+                         dcol=(None if df is not None else gb_f2), dcol_branch=(gb_f2 if df is not None else None))
             dg = gb("dF", Fd)
-            self._lin_bwd(df if df is not None else ds2, a["g"], P + K["f2"] + ".weight", P + K["f2"] + ".bias", dg, M, D, Fd, gelu_h=a["h"])
+            self._lin_bwd(df if df is not None else ds2, a["g"], P + K["f2"] + ".weight", P + K["f2"] + ".bias", dg, M, D, Fd,
+                          gelu_h=a["h"], bias_done=True)
             dx1 = gb("dxB", D)
             self._lin_bwd(dg, a["x1"], P + K["f1"] + ".weight", P + K["f1"] + ".bias", dx1, M, Fd, D, addend=ds2)
             ds1 = gb("ds1", D)
             datt = gb("dbr_att", D) if post_attn_drop > 0 else None
-            self._ln_bwd(dx1, a["s1"], P + K["ln1"], a["m1"], a["r1"], None, ds1, M, D, branch_drop=(post_attn_drop, sd(i, 2)), dbranch=datt)
+            self._ln_bwd(dx1, a["s1"], P + K["ln1"], a["m1"], a["r1"], None, ds1, M, D, branch_drop=(post_attn_drop, sd(i, 2)), dbranch=datt,
+                         dcol=(None if datt is not None else gb_o), dcol_branch=(gb_o if datt is not None else None))
             dctx = gb("dctx", D)
-            self._lin_bwd(datt if datt is not None else ds1, a["ctx"], P + K["o"] + ".weight", P + K["o"] + ".bias", dctx, M, D, D)
+            self._lin_bwd(datt if datt is not None else ds1, a["ctx"], P + K["o"] + ".weight", P + K["o"] + ".bias", dctx, M, D, D,
+                          bias_done=True)
             dqkv = gb("dqkv", 3 * D)
             L.mha_bwd(a["qkv"], sv["mask32"], a["ctx"], dctx, a["lse"], dqkv, B, H, T, dh, dh ** -0.5, self.dt, self.attn_impl,
                       drop_p=dp, drop_seed=sd(i, 1))
@@ -445,24 +452,29 @@ class MMRCAEngine:
         dx[:M].zero_()
         dfe = self.buf("vg_dfeat", B, D)
         dfe[:B].copy_(dfeat)
-        self._ln_bwd(dfe, sv["xL"], P + "encoder.ln", sv["mf"], sv["rf"], None, dx, B, D, ld_dy=D, ld_s=Tn * D, ld_ds=Tn * D)
+        top = P + f"encoder.layers.encoder_layer_{s.layers - 1}."
+        # dx is zero except the class-token rows written here, so their column sums are the top layer's mlp.3 bias gradient
+        self._ln_bwd(dfe, sv["xL"], P + "encoder.ln", sv["mf"], sv["rf"], None, dx, B, D, ld_dy=D, ld_s=Tn * D, ld_ds=Tn * D,
+                     dcol=self.G(top + "mlp.3.bias"))
         self._ready("image_ln")
         for i in reversed(range(s.layers)):
             Lk, a = P + f"encoder.layers.encoder_layer_{i}.", sv["layers"][i]
             dg = gb("dF", M, Fd)
-            self._lin_bwd(dx, a["g"], Lk + "mlp.3.weight", Lk + "mlp.3.bias", dg, M, D, Fd, gelu_h=a["h"])
+            self._lin_bwd(dx, a["g"], Lk + "mlp.3.weight", Lk + "mlp.3.bias", dg, M, D, Fd, gelu_h=a["h"], bias_done=True)
             dy2 = gb("dy", M, D)
             self._lin_bwd(dg, a["y2"], Lk + "mlp.0.weight", Lk + "mlp.0.bias", dy2, M, Fd, D)
             dx1 = gb("dxB", M, D)
-            self._ln_bwd(dy2, a["x1"], Lk + "ln_2", a["m2"], a["r2"], dx, dx1, M, D)
+            self._ln_bwd(dy2, a["x1"], Lk + "ln_2", a["m2"], a["r2"], dx, dx1, M, D, dcol=self.G(Lk + "self_attention.out_proj.bias"))
             dctx = gb("dctx", M, D)
-            self._lin_bwd(dx1, a["ctx"], Lk + "self_attention.out_proj.weight", Lk + "self_attention.out_proj.bias", dctx, M, D, D)
+            self._lin_bwd(dx1, a["ctx"], Lk + "self_attention.out_proj.weight", Lk + "self_attention.out_proj.bias", dctx, M, D, D,
+                          bias_done=True)
             dqkv = gb("dqkv", M, 3 * D)
             L.mha_bwd(a["qkv"], None, a["ctx"], dctx, a["lse"], dqkv, B, H, Tn, dh, dh ** -0.5, self.dt, self.attn_impl)
             dy1 = gb("dy", M, D)
             self._lin_bwd(dqkv, a["y1"], Lk + "self_attention.in_proj_weight", Lk + "self_attention.in_proj_bias", dy1, M, 3 * D, D)
             self._wait_first_wgrad()       # mlp.3's weight gradient (side stream) reads dx; this op overwrites it
-            self._ln_bwd(dy1, a["x"], Lk + "ln_1", a["m1"], a["r1"], dx1, dx, M, D)
+            below = P + f"encoder.layers.encoder_layer_{i - 1}.mlp.3.bias"
+            self._ln_bwd(dy1, a["x"], Lk + "ln_1", a["m1"], a["r1"], dx1, dx, M, D, dcol=(self.G(below) if i > 0 else None))
             self._layer_boundary()
             self._ready(f"image_layer_{i}")
         dproj = gb("dproj", B * nP, D)

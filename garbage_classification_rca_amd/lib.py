@@ -54,7 +54,7 @@ _SIGS = {
     "mmrca_mha_fwd": [_vp] * 4 + [_i32] * 4 + [_f32, _f32, _u64, _i32, _i32, _vp],
     "mmrca_mha_bwd": [_vp] * 6 + [_i32] * 4 + [_f32, _f32, _u64, _i32, _i32, _vp],
     "mmrca_add_layernorm_fwd": [_vp] * 8 + [_i64, _i32, _i64, _i64, _f32, _f32, _u64, _f32, _u64, _i32, _vp],
-    "mmrca_layernorm_bwd": [_vp] * 9 + [_i64, _i32, _i64, _i64, _i64, _f32, _u64, _f32, _u64, _vp, _i32, _vp],
+    "mmrca_layernorm_bwd": [_vp] * 9 + [_i64, _i32, _i64, _i64, _i64, _f32, _u64, _f32, _u64, _vp, _vp, _vp, _i32, _vp],
     "mmrca_embed_fwd": [_vp] * 6 + [_i64, _i32, _i32, _vp],
     "mmrca_embed_bwd": [_vp] * 6 + [_i64, _i32, _i32, _vp],
     "mmrca_patchify_fwd": [_vp, _vp] + [_i32] * 6 + [_vp],
@@ -169,10 +169,10 @@ def add_layernorm_fwd(x, res, gamma, beta, sum_out, y, mean, rstd, rows, D, ld_x
 
 
 def layernorm_bwd(dy, s, gamma, mean, rstd, dres, ds, dgamma, dbeta, rows, D, ld_dy, ld_s, ld_ds, dtype,
-                  dy_drop=(0.0, 0), branch_drop=(0.0, 0), dbranch=None):
+                  dy_drop=(0.0, 0), branch_drop=(0.0, 0), dbranch=None, dcol=None, dcol_branch=None):
     _check(load().mmrca_layernorm_bwd(ptr(dy), ptr(s), ptr(gamma), ptr(mean), ptr(rstd), ptr(dres), ptr(ds), ptr(dgamma),
                                       ptr(dbeta), rows, D, ld_dy, ld_s, ld_ds, dy_drop[0], dy_drop[1], branch_drop[0],
-                                      branch_drop[1], ptr(dbranch), dtype, stream_ptr()), "mmrca_layernorm_bwd")
+                                      branch_drop[1], ptr(dbranch), ptr(dcol), ptr(dcol_branch), dtype, stream_ptr()), "mmrca_layernorm_bwd")
 
 
 def embed_fwd(ids, pos_ids, word, pos, type_row, out, rows, D, dtype):

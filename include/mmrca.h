@@ -87,12 +87,14 @@ int mmrca_add_layernorm_fwd(const void* x, const void* res, const void* gamma, c
                             int dtype, void* stream);
 /* ds = LN'(dy) (+ dres);  dgamma/dbeta (fp32) += .   s is the saved LayerNorm input.
  * dy_drop: mask dy like the forward's out_drop.  dbranch (optional) = dropout-mask(LN'(dy)) with (branch_drop_p, seed):
- * the gradient of the branch that the forward's in_drop dropped (ds itself stays the residual-stream gradient). */
+ * the gradient of the branch that the forward's in_drop dropped (ds itself stays the residual-stream gradient).
+ * dcol / dcol_branch (optional, fp32 [D], +=): column sums of ds / of dbranch = the bias gradient of the linear layer whose
+ * output fed this LayerNorm (saves a separate pass over the gradient). */
 int mmrca_layernorm_bwd(const void* dy, const void* s, const void* gamma, const float* mean, const float* rstd,
                         const void* dres, void* ds, float* dgamma, float* dbeta,
                         int64_t rows, int D, int64_t ld_dy, int64_t ld_s, int64_t ld_ds,
                         float dy_drop_p, uint64_t dy_drop_seed, float branch_drop_p, uint64_t branch_drop_seed,
-                        void* dbranch, int dtype, void* stream);
+                        void* dbranch, float* dcol, float* dcol_branch, int dtype, void* stream);
 
 /* K5a. text embeddings: out[r] = word[ids[r]] + pos[pos_ids[r]] (+ type_row)   (modeling_distilbert.py:82-118,
  * BertEmbeddings; LayerNorm follows via mmrca_add_layernorm_fwd).  ids/pos_ids int32 [rows]. */
