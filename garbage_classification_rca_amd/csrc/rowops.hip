@@ -241,6 +241,60 @@ extern "C" int mmrca_gelu_bwd(const void* dG, const void* H, void* dH, int64_t n
   return 0;
 }
 
+// dH = dG * gelu'(H) and, in the same pass, db[c] += sum_m dH[m][c] (the FFN1 bias gradient): a thread owns 4 columns and
+// walks a slab of rows, so the column sums stay in registers; one atomic per column per block.
+template <typename T>
+__global__ void __launch_bounds__(256)
+gelu_bwd_colsum_k(const T* __restrict__ dg, const T* __restrict__ h, T* __restrict__ dh, float* __restrict__ db, int64_t M,
+                  int64_t N, int64_t ld, int rows_per_block) {
+  const int64_t c = ((int64_t)blockIdx.x * 256 + threadIdx.x) * 4;
+  if (c >= N) return;
+  const int64_t r0 = (int64_t)blockIdx.y * rows_per_block;
+  int64_t r1 = r0 + rows_per_block; if (r1 > M) r1 = M;
+  float acc[4] = {0.f, 0.f, 0.f, 0.f};
+  int64_t r = r0;
+  for (; r + 3 < r1; r += 4) {                     // four rows in flight per thread
+    Vec4<T> a[4], b[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) { a[u] = Vec4<T>::load(dg + (r + u) * ld + c); b[u] = Vec4<T>::load(h + (r + u) * ld + c); }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      Vec4<T> o;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) { o.v[j] = a[u].v[j] * gelu_grad_f(b[u].v[j]); }
+      o.store(dh + (r + u) * ld + c);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) acc[j] += to_f(from_f<T>(o.v[j]));      // sum what was stored (rounded), as colsum_k would
+    }
+  }
+  for (; r < r1; ++r) {
+    Vec4<T> a = Vec4<T>::load(dg + r * ld + c), b = Vec4<T>::load(h + r * ld + c), o;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) o.v[j] = a.v[j] * gelu_grad_f(b.v[j]);
+    o.store(dh + r * ld + c);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[j] += to_f(from_f<T>(o.v[j]));
+  }
+#pragma unroll
+  for (int j = 0; j < 4; ++j) atomicAdd(db + c + j, acc[j]);
+}
+
+extern "C" int mmrca_gelu_bwd_colsum(const void* dG, const void* H, void* dH, float* db, int64_t M, int64_t N, int64_t ld,
+                                     int dtype, void* stream) {
+  MMRCA_REQUIRE(dG && H && dH && db, "gelu_bwd_colsum: null pointer");
+  MMRCA_REQUIRE(N % 4 == 0 && ld % 4 == 0 && ld >= N, "gelu_bwd_colsum: N and ld must be multiples of 4");
+  if (M <= 0 || N <= 0) return 0;
+  const int gx = (int)((N / 4 + 255) / 256);
+  int rows_per_block = 64;
+  int64_t gy = (M + rows_per_block - 1) / rows_per_block;
+  while (gy * gx > 8192) { rows_per_block *= 2; gy = (M + rows_per_block - 1) / rows_per_block; }
+  MMRCA_DISPATCH_DTYPE(dtype, "gelu_bwd_colsum",
+    hipLaunchKernelGGL(gelu_bwd_colsum_k<T>, dim3(gx, (unsigned)gy), dim3(256), 0, (hipStream_t)stream, (const T*)dG, (const T*)H,
+                       (T*)dH, db, M, N, ld, rows_per_block);)
+  MMRCA_CHECK_LAUNCH("gelu_bwd_colsum");
+  return 0;
+}
+
 // db[c] += sum_m dY[m][c].  Block = 4 waves x 64 lanes; a block owns 256 columns (4 per lane) and a slab of rows;
 // waves stride the rows, partials meet in LDS, one atomic per column per block.
 template <typename T>

@@ -243,7 +243,7 @@ class MMRCAEngine:
         L.gemm(x, w, out, bias=b, addend=addend, preact=preact, M=M, N=N, K=K, lda=K, ldb=K, ldc=N,
                a_layout=L.ROWK, b_layout=L.ROWK, act=act, dtype=self.dt, impl=self.gemm_impl)
 
-    def _lin_bwd(self, dy, x, wkey, bkey, dx, M, N, K, addend=None, wnumel=None, gelu_h=None, bias_done=False):
+    def _lin_bwd(self, dy, x, wkey, bkey, dx, M, N, K, addend=None, wnumel=None, gelu_h=None, bias_done=False, gelu_db=None):
         """dy [M,N], x [M,K], weight [N,K]:  dW += dy^T x and db += colsum(dy) in ONE pass (the bias gradient rides
         on the weight-gradient GEMM); dx = dy W (+ addend), optionally times gelu'(gelu_h) in the epilogue."""
         Mk = _round_up(M, 64)
@@ -276,7 +276,10 @@ class MMRCAEngine:
                    a_layout=L.ROWK, b_layout=L.KROW, act=(L.ACT_MUL if fuse else L.ACT_NONE), dtype=self.dt,
                    impl=self.gemm_impl)
             if gelu_h is not None and not fuse:
-                L.gelu_bwd(dx, gelu_h, dx, M * K, self.dt)
+                if gelu_db is not None:     # dh = dg * gelu'(h) and the FFN1 bias gradient (column sums of dh) in one pass
+                    L.gelu_bwd_colsum(dx, gelu_h, dx, gelu_db, M, K, K, self.dt)
+                else:
+                    L.gelu_bwd(dx, gelu_h, dx, M * K, self.dt)
 
     def _ln_fwd(self, x, res, pfx, sum_out, y, mean, rstd, rows, D, eps, ld_x=None, ld_y=None, in_drop=(0.0, 0), out_drop=(0.0, 0)):
         L.add_layernorm_fwd(x, res, self.W(pfx + ".weight"), self.W(pfx + ".bias"), sum_out, y, mean, rstd, rows, D,
@@ -375,9 +378,9 @@ class MMRCAEngine:
                          dcol=(None if df is not None else gb_f2), dcol_branch=(gb_f2 if df is not None else None))
             dg = gb("dF", Fd)
             self._lin_bwd(df if df is not None else ds2, a["g"], P + K["f2"] + ".weight", P + K["f2"] + ".bias", dg, M, D, Fd,
-                          gelu_h=a["h"], bias_done=True)
+                          gelu_h=a["h"], bias_done=True, gelu_db=(None if FUSE_GELU_GRAD else self.G(P + K["f1"] + ".bias")))
             dx1 = gb("dxB", D)
-            self._lin_bwd(dg, a["x1"], P + K["f1"] + ".weight", P + K["f1"] + ".bias", dx1, M, Fd, D, addend=ds2)
+            self._lin_bwd(dg, a["x1"], P + K["f1"] + ".weight", P + K["f1"] + ".bias", dx1, M, Fd, D, addend=ds2, bias_done=not FUSE_GELU_GRAD)
             ds1 = gb("ds1", D)
             datt = gb("dbr_att", D) if post_attn_drop > 0 else None
             self._ln_bwd(dx1, a["s1"], P + K["ln1"], a["m1"], a["r1"], None, ds1, M, D, branch_drop=(post_attn_drop, sd(i, 2)), dbranch=datt,
@@ -460,9 +463,10 @@ class MMRCAEngine:
         for i in reversed(range(s.layers)):
             Lk, a = P + f"encoder.layers.encoder_layer_{i}.", sv["layers"][i]
             dg = gb("dF", M, Fd)
-            self._lin_bwd(dx, a["g"], Lk + "mlp.3.weight", Lk + "mlp.3.bias", dg, M, D, Fd, gelu_h=a["h"], bias_done=True)
+            self._lin_bwd(dx, a["g"], Lk + "mlp.3.weight", Lk + "mlp.3.bias", dg, M, D, Fd, gelu_h=a["h"], bias_done=True,
+                          gelu_db=(None if FUSE_GELU_GRAD else self.G(Lk + "mlp.0.bias")))
             dy2 = gb("dy", M, D)
-            self._lin_bwd(dg, a["y2"], Lk + "mlp.0.weight", Lk + "mlp.0.bias", dy2, M, Fd, D)
+            self._lin_bwd(dg, a["y2"], Lk + "mlp.0.weight", Lk + "mlp.0.bias", dy2, M, Fd, D, bias_done=not FUSE_GELU_GRAD)
             dx1 = gb("dxB", M, D)
             self._ln_bwd(dy2, a["x1"], Lk + "ln_2", a["m2"], a["r2"], dx, dx1, M, D, dcol=self.G(Lk + "self_attention.out_proj.bias"))
             dctx = gb("dctx", M, D)

@@ -51,6 +51,7 @@ _SIGS = {
     "mmrca_gemm": [_vp] * 6 + [_i64] * 6 + [_i32] * 6 + [_vp],
     "mmrca_colsum_accum": [_vp, _vp, _i64, _i64, _i64, _i32, _vp],
     "mmrca_gelu_bwd": [_vp, _vp, _vp, _i64, _i32, _vp],
+    "mmrca_gelu_bwd_colsum": [_vp, _vp, _vp, _vp, _i64, _i64, _i64, _i32, _vp],
     "mmrca_mha_fwd": [_vp] * 4 + [_i32] * 4 + [_f32, _f32, _u64, _i32, _i32, _vp],
     "mmrca_mha_bwd": [_vp] * 6 + [_i32] * 4 + [_f32, _f32, _u64, _i32, _i32, _vp],
     "mmrca_add_layernorm_fwd": [_vp] * 8 + [_i64, _i32, _i64, _i64, _f32, _f32, _u64, _f32, _u64, _i32, _vp],
@@ -147,6 +148,10 @@ def colsum_accum(dY, db, M, N, ld, dtype):
 
 def gelu_bwd(dG, H, dH, n, dtype):
     _check(load().mmrca_gelu_bwd(ptr(dG), ptr(H), ptr(dH), n, dtype, stream_ptr()), "mmrca_gelu_bwd")
+
+
+def gelu_bwd_colsum(dG, H, dH, db, M, N, ld, dtype):
+    _check(load().mmrca_gelu_bwd_colsum(ptr(dG), ptr(H), ptr(dH), ptr(db), M, N, ld, dtype, stream_ptr()), "mmrca_gelu_bwd_colsum")
 
 
 def mha_fwd(qkv, key_mask, out, lse, B, H, S, dh, scale, dtype, impl=IMPL_AUTO, drop_p=0.0, drop_seed=0):

@@ -61,6 +61,9 @@ int mmrca_colsum_accum(const void* dY, float* db, int64_t M, int64_t N, int64_t 
 
 /* dH = dG * gelu'(H)   (exact erf GELU: transformers activations "gelu", torchvision MLPBlock nn.GELU). */
 int mmrca_gelu_bwd(const void* dG, const void* H, void* dH, int64_t n, int dtype, void* stream);
+/* the same on a [M,N] matrix plus db[N] (fp32) += column sums of dH: the FFN1 / mlp.0 bias gradient in the same pass */
+int mmrca_gelu_bwd_colsum(const void* dG, const void* H, void* dH, float* db, int64_t M, int64_t N, int64_t ld,
+                          int dtype, void* stream);
 
 /* K3. Multi-head attention over a fused QKV buffer [B*S, 3*H*dh] (q | k | v column blocks; head h at
  * columns h*dh).  out[B*S, H*dh].  key_mask (optional): int32 [B,S], 0 = masked key; a query row whose

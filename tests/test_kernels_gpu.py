@@ -266,6 +266,14 @@ def test_gelu_bwd_and_colsum(dt):
     hr = h.float().clone().requires_grad_(True)
     F.gelu(hr).backward(dg.float())
     assert rel_err(dh, hr.grad) < TOL[dt]
+    Mg, Ng = 1003, 3072
+    hg, dgg = dev(torch.randn(Mg, Ng) * 2, dt), dev(torch.randn(Mg, Ng), dt)
+    dhg, dbg = torch.empty_like(hg), dev(torch.randn(Ng))
+    hr2 = hg.float().clone().requires_grad_(True)
+    F.gelu(hr2).backward(dgg.float())
+    refb = dbg + hr2.grad.sum(0)
+    L.gelu_bwd_colsum(dgg, hg, dhg, dbg, Mg, Ng, Ng, L.dtype_code(dt))
+    assert rel_err(dhg, hr2.grad) < TOL[dt] and rel_err(dbg, refb) < (1e-4 if dt == torch.float32 else 3e-3)
     M, N = 1003, 772
     dY = dev(torch.randn(M, N), dt)
     db = dev(torch.randn(N))
