@@ -509,6 +509,149 @@ static void launch_mfma32(const void* A, const void* B, void* C, const void* bia
                      M, N, K, lda, ldb, ldc, act, tiles_m, tiles_n, ksplit_len);
 }
 
+// single-stage 128x128x64 variant (32 KiB LDS, four to five blocks per CU): full 128-byte lines for ROWK operands
+template <bool A_KROW, bool B_KROW, bool ATOMIC_F32>
+__global__ void __launch_bounds__(256, 4)
+gemm_mfma_k1s(const bf16_t* __restrict__ A, const bf16_t* __restrict__ B, void* __restrict__ Cv, const bf16_t* __restrict__ bias,
+              const bf16_t* __restrict__ addend, bf16_t* __restrict__ preact, int64_t M, int64_t N, int64_t K,
+              int64_t lda, int64_t ldb, int64_t ldc, int act, int tiles_m, int tiles_n, int64_t ksplit_len) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];   // ONE buffer: [A tile 16 KiB | B tile 16 KiB]
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
+  const int wr = wave >> 1, wc = wave & 1;
+  const int nwg = tiles_m * tiles_n;
+  const int orig = blockIdx.x;
+  const int q8 = nwg >> 3, r8 = nwg & 7, xcd = orig & 7;
+  const int wgid = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (orig >> 3);
+  const int GROUP = 8;
+  const int group = wgid / (GROUP * tiles_n);
+  const int first_m = group * GROUP;
+  const int gsize = (tiles_m - first_m) < GROUP ? (tiles_m - first_m) : GROUP;
+  const int tm = first_m + (wgid % (GROUP * tiles_n)) % gsize;
+  const int tn = (wgid % (GROUP * tiles_n)) / gsize;
+  const int64_t m_blk = (int64_t)tm * GBM, n_blk = (int64_t)tn * GBN;
+  const int64_t kbeg = (int64_t)blockIdx.y * ksplit_len;
+  int64_t kend = kbeg + ksplit_len; if (kend > K) kend = K;
+  const int nt = (int)((kend - kbeg + GBK - 1) / GBK);
+
+  f32x4 acc[4][4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  for (int t = 0; t < nt; ++t) {
+    // single LDS stage: load -> wait -> barrier -> 32 MFMAs -> barrier; the load latency of this block is covered by the
+    // other three or four blocks resident on the CU (32 KiB of LDS each) instead of by software prefetch
+    stage_tile<A_KROW>(A, lda, m_blk, M, kbeg + (int64_t)t * GBK, smem, wave, lane);
+    stage_tile<B_KROW>(B, ldb, n_blk, N, kbeg + (int64_t)t * GBK, smem + TILE_BYTES, wave, lane);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+      bf16x8 af[4], bfr[4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) af[i] = load_frag<A_KROW>(smem, wr * 64 + i * 16, ks, lane);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) bfr[j] = load_frag<B_KROW>(smem + TILE_BYTES, wc * 64 + j * 16, ks, lane);
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          if (ATOMIC_F32) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i], bfr[j], acc[i][j], 0, 0, 0);
+          else            acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr[j], af[i], acc[i][j], 0, 0, 0);
+        }
+    }
+    __syncthreads();
+  }
+  const int g = lane >> 4, l16 = lane & 15;
+  if (ATOMIC_F32) {
+    float* C = (float*)Cv;
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int64_t n = n_blk + wc * 64 + j * 16 + l16;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int64_t m = m_blk + wr * 64 + i * 16 + 4 * g + r;
+          if (m < M && n < N) atomicAdd(C + m * ldc + n, acc[i][j][r]);
+        }
+      }
+  } else {
+    bf16_t* C = (bf16_t*)Cv;
+    constexpr int EP_STRIDE = 128 * 4 + 16;
+    const int half = lane >> 5, l32 = lane & 31;
+    const int64_t ncol = n_blk + l32 * 4;
+    float bv[4] = {0.f, 0.f, 0.f, 0.f};
+    if (bias) {
+      bf16x4 b4 = *reinterpret_cast<const bf16x4*>(bias + ncol);
+#pragma unroll
+      for (int r = 0; r < 4; ++r) bv[r] = (float)b4[r];
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+        *reinterpret_cast<f32x4*>(smem + (wr * 16 + l16) * EP_STRIDE + (wc * 64 + j * 16 + 4 * g) * 4) = acc[i][j];
+      __syncthreads();
+#pragma unroll
+      for (int rr = 0; rr < 4; ++rr) {
+        const int lrow = wave * 8 + rr * 2 + half;
+        const int64_t m = m_blk + (lrow >> 4) * 64 + i * 16 + (lrow & 15);
+        if (m < M) {
+          const f32x4 c = *reinterpret_cast<const f32x4*>(smem + lrow * EP_STRIDE + l32 * 16);
+          float v[4] = {c[0] + bv[0], c[1] + bv[1], c[2] + bv[2], c[3] + bv[3]};
+          if (act == MMRCA_ACT_MUL) {
+            bf16x4 h4 = *reinterpret_cast<const bf16x4*>(preact + m * ldc + ncol);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) v[r] *= (float)h4[r];
+          } else if (act == MMRCA_ACT_GELU_SAVE_GRAD) {
+            bf16x4 o;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+              const float e = erff(v[r] * 0.70710678118654752f);
+              o[r] = (bf16_t)(0.5f * (1.0f + e) + v[r] * 0.3989422804014327f * __expf(-0.5f * v[r] * v[r]));
+              v[r] = 0.5f * v[r] * (1.0f + e);
+            }
+            *reinterpret_cast<bf16x4*>(preact + m * ldc + ncol) = o;
+          } else if (act == MMRCA_ACT_GELU_BWD) {
+            bf16x4 h4 = *reinterpret_cast<const bf16x4*>(preact + m * ldc + ncol);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) v[r] *= gelu_grad_f((float)h4[r]);
+          } else if (preact) {
+            bf16x4 o;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) o[r] = (bf16_t)v[r];
+            *reinterpret_cast<bf16x4*>(preact + m * ldc + ncol) = o;
+          }
+          if (act == MMRCA_ACT_GELU) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) v[r] = gelu_f(v[r]);
+          }
+          if (addend) {
+            bf16x4 a4 = *reinterpret_cast<const bf16x4*>(addend + m * ldc + ncol);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) v[r] += (float)a4[r];
+          }
+          bf16x4 o;
+#pragma unroll
+          for (int r = 0; r < 4; ++r) o[r] = (bf16_t)v[r];
+          *reinterpret_cast<bf16x4*>(C + m * ldc + ncol) = o;
+        }
+      }
+      __syncthreads();
+    }
+  }
+}
+
+template <bool AK, bool BK2, bool AT>
+static void launch_mfma1s(const void* A, const void* B, void* C, const void* bias, const void* addend, void* preact,
+                          int64_t M, int64_t N, int64_t K, int64_t lda, int64_t ldb, int64_t ldc, int act, int tiles_m,
+                          int tiles_n, int ksplits, int64_t ksplit_len, hipStream_t st) {
+  hipLaunchKernelGGL((gemm_mfma_k1s<AK, BK2, AT>), dim3(tiles_m * tiles_n, ksplits), dim3(256), 2 * TILE_BYTES, st,
+                     (const bf16_t*)A, (const bf16_t*)B, C, (const bf16_t*)bias, (const bf16_t*)addend, (bf16_t*)preact,
+                     M, N, K, lda, ldb, ldc, act, tiles_m, tiles_n, ksplit_len);
+}
+
 // ======================================================================================================
 // persistent variant: grid = 2 blocks per CU; every block walks work items (tile, k-split) it, it+G, it+2G, ... and the
 // two-buffer K pipeline never stops at an item boundary: the first K-tile of the NEXT item is issued before the last
@@ -741,7 +884,7 @@ extern "C" int mmrca_gemm(const void* A, const void* B, void* C, const void* bia
   // per CU is faster than the 256x256 kernel on every encoder shape, so AUTO never picks the large tile
   if (ok256 && impl == MMRCA_GEMM_MFMA256)
     return mmrca_gemm256(A, B, C, bias, addend, preact, M, N, K, lda, ldb, ldc, a_layout, b_layout, act, st);
-  if ((impl == MMRCA_GEMM_MFMA || impl == MMRCA_GEMM_MFMA_PERSIST || impl == MMRCA_GEMM_MFMA_BK32) && !ok_mfma)
+  if ((impl == MMRCA_GEMM_MFMA || impl == MMRCA_GEMM_MFMA_PERSIST || impl == MMRCA_GEMM_MFMA_BK32 || impl == MMRCA_GEMM_MFMA_1STAGE) && !ok_mfma)
     return mmrca_fail(-3, "gemm: shape M=%lld N=%lld K=%lld dtype=%d does not qualify for the MFMA kernel", (long long)M, (long long)N, (long long)K, dtype);
   const bool use_mfma = ok_mfma && impl != MMRCA_GEMM_REF;   // 128x128 kernel
 
@@ -761,10 +904,13 @@ extern "C" int mmrca_gemm(const void* A, const void* B, void* C, const void* bia
       ksplits = (int)((ksteps + steps_per - 1) / steps_per);
     }
     const bool ak = a_layout == MMRCA_KROW, bk = b_layout == MMRCA_KROW, at = out_f32_accum != 0;
-    // AUTO: the 128x128x32 kernel (four blocks per CU) wherever an operand is read through the transposed LDS path
-    // (dgrad, wgrad): +17-25 % there; the 128x128x64 kernel for the all-ROWK forward GEMMs (long-K shapes lose 10-16 %
-    // with 32-deep steps) and for weight gradients with too few tiles to fill four blocks per CU.
-    const bool auto32 = impl == MMRCA_GEMM_AUTO && (ak || bk) && !(at && (int64_t)tiles_m * tiles_n < 64);
+    // AUTO (tools/gemm_bench.py, interleaved A/B on the encoder shapes): thread-level parallelism beats software prefetch on
+    // this chip -- the kernels with 32 KiB of LDS per block (four to five resident blocks per CU) win everywhere:
+    //   forward (ROWK,ROWK) and dgrad (ROWK,KROW): single-stage 128x128x64 (790-910 TFLOP/s vs 680-875 for the two-stage
+    //     kernel at two blocks per CU); 64-deep steps keep the ROWK operands' HBM reads in full 128-byte lines;
+    //   wgrad (KROW,KROW, fp32 atomics): two-stage 128x128x32 (800-870 vs 680-740), unless there are too few tiles.
+    const bool auto1s = impl == MMRCA_GEMM_AUTO && !at;
+    const bool auto32 = impl == MMRCA_GEMM_AUTO && at && (int64_t)tiles_m * tiles_n >= 64;
     if ((impl == MMRCA_GEMM_MFMA_BK32 || auto32) && !(at && bias)) {
 #define L32(AK_, BK_, AT_) launch_mfma32<AK_, BK_, AT_>(A, B, C, bias, addend, preact, M, N, K, lda, ldb, ldc, act, tiles_m, tiles_n, ksplits, ksplit_len, st)
       if (!ak && !bk && !at) L32(false, false, false);
@@ -777,6 +923,20 @@ extern "C" int mmrca_gemm(const void* A, const void* B, void* C, const void* bia
       else L32(true, true, true);
 #undef L32
       MMRCA_CHECK_LAUNCH("gemm(mfma,bk32)");
+      return 0;
+    }
+    if ((impl == MMRCA_GEMM_MFMA_1STAGE || auto1s) && !(at && bias)) {
+#define L1S(AK_, BK_, AT_) launch_mfma1s<AK_, BK_, AT_>(A, B, C, bias, addend, preact, M, N, K, lda, ldb, ldc, act, tiles_m, tiles_n, ksplits, ksplit_len, st)
+      if (!ak && !bk && !at) L1S(false, false, false);
+      else if (!ak && bk && !at) L1S(false, true, false);
+      else if (ak && !bk && !at) L1S(true, false, false);
+      else if (ak && bk && !at) L1S(true, true, false);
+      else if (!ak && !bk && at) L1S(false, false, true);
+      else if (!ak && bk && at) L1S(false, true, true);
+      else if (ak && !bk && at) L1S(true, false, true);
+      else L1S(true, true, true);
+#undef L1S
+      MMRCA_CHECK_LAUNCH("gemm(mfma,1stage)");
       return 0;
     }
     if (impl == MMRCA_GEMM_MFMA_PERSIST && !(at && bias)) {

@@ -140,6 +140,15 @@ def test_gemm_bk32_kernel(layouts):
 
 
 @pytest.mark.parametrize("layouts", [(0, 0), (0, 1), (1, 1), (1, 0)])
+def test_gemm_single_stage_kernel(layouts):
+    al, bl = layouts
+    Mr = 384 if al == L.KROW else 300
+    _gemm_case(Mr, 256, 192, al, bl, torch.bfloat16, L.IMPL_MFMA_1STAGE, bias=True)
+    _gemm_case(Mr, 384, 256, al, bl, torch.bfloat16, L.IMPL_MFMA_1STAGE, act=L.ACT_GELU, bias=True, addend=True, preact=True)
+    _gemm_case(768, 768, 788, 1, 1, torch.bfloat16, L.IMPL_MFMA_1STAGE, accum=True)
+
+
+@pytest.mark.parametrize("layouts", [(0, 0), (0, 1), (1, 1), (1, 0)])
 def test_gemm_persistent_kernel(layouts):
     """Persistent 128x128 kernel (pipeline runs across tile boundaries): many more tiles than resident blocks, ragged M,
     single-K-step items, epilogues, and the split-K fp32 accumulate path."""

@@ -14,7 +14,7 @@ SHAPES = [  # (name, M, N, K, a_layout, b_layout, accum)
     ("epi K64", M, 3072, 64, 0, 0, 0), ("epi K128", M, 3072, 128, 0, 0, 0), ("epi K1536", M, 3072, 1536, 0, 0, 0),
     ("text fwd qkv", 16384, 2304, 768, 0, 0, 0), ("text fwd out", 16384, 768, 768, 0, 0, 0),
 ]
-impls = {"mfma128": L.IMPL_MFMA, "bk32": L.IMPL_MFMA_BK32}
+impls = {"mfma128": L.IMPL_MFMA, "bk32": L.IMPL_MFMA_BK32, "1stage": L.IMPL_MFMA_1STAGE}
 DBG = [int(x) for x in os.environ.get("MMRCA_DBG", "0").split(",")]
 only = sys.argv[1:] 
 L.load()
