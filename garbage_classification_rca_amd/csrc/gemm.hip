@@ -510,8 +510,8 @@ static void launch_mfma32(const void* A, const void* B, void* C, const void* bia
 }
 
 // single-stage 128x128x64 variant (32 KiB LDS, four to five blocks per CU): full 128-byte lines for ROWK operands
-template <bool A_KROW, bool B_KROW, bool ATOMIC_F32>
-__global__ void __launch_bounds__(256, 4)
+template <bool A_KROW, bool B_KROW, bool ATOMIC_F32, int WPE>
+__global__ void __launch_bounds__(256, WPE)
 gemm_mfma_k1s(const bf16_t* __restrict__ A, const bf16_t* __restrict__ B, void* __restrict__ Cv, const bf16_t* __restrict__ bias,
               const bf16_t* __restrict__ addend, bf16_t* __restrict__ preact, int64_t M, int64_t N, int64_t K,
               int64_t lda, int64_t ldb, int64_t ldc, int act, int tiles_m, int tiles_n, int64_t ksplit_len) {
@@ -643,11 +643,11 @@ gemm_mfma_k1s(const bf16_t* __restrict__ A, const bf16_t* __restrict__ B, void* 
   }
 }
 
-template <bool AK, bool BK2, bool AT>
+template <bool AK, bool BK2, bool AT, int WPE>
 static void launch_mfma1s(const void* A, const void* B, void* C, const void* bias, const void* addend, void* preact,
                           int64_t M, int64_t N, int64_t K, int64_t lda, int64_t ldb, int64_t ldc, int act, int tiles_m,
                           int tiles_n, int ksplits, int64_t ksplit_len, hipStream_t st) {
-  hipLaunchKernelGGL((gemm_mfma_k1s<AK, BK2, AT>), dim3(tiles_m * tiles_n, ksplits), dim3(256), 2 * TILE_BYTES, st,
+  hipLaunchKernelGGL((gemm_mfma_k1s<AK, BK2, AT, WPE>), dim3(tiles_m * tiles_n, ksplits), dim3(256), 2 * TILE_BYTES, st,
                      (const bf16_t*)A, (const bf16_t*)B, C, (const bf16_t*)bias, (const bf16_t*)addend, (bf16_t*)preact,
                      M, N, K, lda, ldb, ldc, act, tiles_m, tiles_n, ksplit_len);
 }
@@ -925,8 +925,9 @@ extern "C" int mmrca_gemm(const void* A, const void* B, void* C, const void* bia
       MMRCA_CHECK_LAUNCH("gemm(mfma,bk32)");
       return 0;
     }
+    // (compiled for five waves per SIMD, <= 96 VGPRs, this kernel spills and runs 2-5x slower: four is the sweet spot)
     if ((impl == MMRCA_GEMM_MFMA_1STAGE || auto1s) && !(at && bias)) {
-#define L1S(AK_, BK_, AT_) launch_mfma1s<AK_, BK_, AT_>(A, B, C, bias, addend, preact, M, N, K, lda, ldb, ldc, act, tiles_m, tiles_n, ksplits, ksplit_len, st)
+#define L1S(AK_, BK_, AT_) launch_mfma1s<AK_, BK_, AT_, 4>(A, B, C, bias, addend, preact, M, N, K, lda, ldb, ldc, act, tiles_m, tiles_n, ksplits, ksplit_len, st)
       if (!ak && !bk && !at) L1S(false, false, false);
       else if (!ak && bk && !at) L1S(false, true, false);
       else if (ak && !bk && !at) L1S(true, false, false);
