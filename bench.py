@@ -189,10 +189,18 @@ def main():
         flops = sum(p[0] for p in prof)
         ms = sum(p[2].elapsed_time(p[3]) for p in prof)
         by_kind = {}
-        for f, kind, e0, e1 in prof:
+        for f, kind, e0, e1, _shape in prof:
             d = by_kind.setdefault(kind, [0.0, 0.0, 0])
             d[0] += f; d[1] += e0.elapsed_time(e1); d[2] += 1
         achieved = flops / (ms * 1e-3) / 1e12 if ms > 0 else 0.0
+        if os.environ.get("MMRCA_BENCH_SHAPES") == "1":       # in-situ per-shape table (stderr), for kernel tuning
+            by_shape = {}
+            for f, kind, e0, e1, shp in prof:
+                d = by_shape.setdefault((kind, shp), [0.0, 0.0, 0])
+                d[0] += f; d[1] += e0.elapsed_time(e1); d[2] += 1
+            for (kind, shp), v in sorted(by_shape.items(), key=lambda kv: -kv[1][1]):
+                print(f"[bench] gemm a{kind[0]}b{kind[1]}acc{kind[2]} M={shp[0]} N={shp[1]} K={shp[2]} act={shp[3]}: {v[2] // replay}/step, "
+                      f"{v[1] / v[2] * 1e3:.0f} us, {v[0] / (v[1] * 1e-3) / 1e12:.0f} TF, {v[1] / replay:.2f} ms/step", file=sys.stderr, flush=True)
         value = B * world * args.steps / elapsed
         train_flop_per_sample = (FWD_GFLOP_PER_SAMPLE * (1.0 if args.frozen else 3.0)) * 1e9
         out = {

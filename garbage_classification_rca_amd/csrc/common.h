@@ -75,6 +75,20 @@ __device__ __forceinline__ float gelu_grad_f(float x) {
   return 0.5f * (1.0f + erff(x * 0.70710678118654752f)) + x * 0.3989422804014327f * __expf(-0.5f * x * x);
 }
 
+// GELU of the bf16 MFMA epilogues: 0.5 erfc(|x|/sqrt 2) by Abramowitz-Stegun 7.1.26 (|err| <= 1.5e-7 in erf, far below
+// bf16 resolution) on the hardware reciprocal and exp2 -- ~14 VALU ops per element instead of erff()'s ~40, which made
+// the FFN1 epilogue VALU-bound (64 elements per lane per tile against 6k cycles of MFMA).  fp32 parity mode keeps erff.
+__device__ __forceinline__ float gelu_fast_f(float x) {
+  const float z = fabsf(x) * 0.70710678118654752f;
+  const float t = __builtin_amdgcn_rcpf(fmaf(0.3275911f, z, 1.0f));
+  float p = fmaf(t, 1.061405429f, -1.453152027f);
+  p = fmaf(p, t, 1.421413741f);
+  p = fmaf(p, t, -0.284496736f);
+  p = fmaf(p, t, 0.254829592f);
+  const float q = 0.5f * p * t * __builtin_amdgcn_exp2f(-1.4426950408889634f * z * z);
+  return x >= 0.f ? fmaf(-x, q, x) : x * q;
+}
+
 #define MMRCA_DISPATCH_DTYPE(dtype, NAME, ...)                               \
   if ((dtype) == MMRCA_F32) { typedef float T; __VA_ARGS__ }                 \
   else if ((dtype) == MMRCA_BF16) { typedef bf16_t T; __VA_ARGS__ }          \

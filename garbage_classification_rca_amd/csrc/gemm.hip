@@ -303,7 +303,7 @@ gemm_mfma_k(const bf16_t* __restrict__ A, const bf16_t* __restrict__ B, void* __
         }
         if (act == MMRCA_ACT_GELU) {
 #pragma unroll
-          for (int r = 0; r < 4; ++r) v[r] = gelu_f(v[r]);
+          for (int r = 0; r < 4; ++r) v[r] = gelu_fast_f(v[r]);
         }
         if (addend) {
           bf16x4 a4 = *reinterpret_cast<const bf16x4*>(addend + m * ldc + ncol);
@@ -482,7 +482,7 @@ gemm_mfma_k32(const bf16_t* __restrict__ A, const bf16_t* __restrict__ B, void* 
           }
           if (act == MMRCA_ACT_GELU) {
 #pragma unroll
-            for (int r = 0; r < 4; ++r) v[r] = gelu_f(v[r]);
+            for (int r = 0; r < 4; ++r) v[r] = gelu_fast_f(v[r]);
           }
           if (addend) {
             bf16x4 a4 = *reinterpret_cast<const bf16x4*>(addend + m * ldc + ncol);
@@ -587,6 +587,21 @@ gemm_mfma_k1s(const bf16_t* __restrict__ A, const bf16_t* __restrict__ B, void* 
 #pragma unroll
       for (int r = 0; r < 4; ++r) bv[r] = (float)b4[r];
     }
+    // the residual addend is fetched for the whole tile up front (16 x 8 B per lane, in the registers the operand
+    // fragments just vacated): in the model it is the residual stream, long evicted from L2/MALL by the time this GEMM
+    // runs, and loading it row by row inside the staged loop exposed one HBM round trip per pass
+    bf16x4 add4[4][4];
+    if (addend) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int rr = 0; rr < 4; ++rr) {
+          const int lrow = wave * 8 + rr * 2 + half;
+          int64_t m = m_blk + (lrow >> 4) * 64 + i * 16 + (lrow & 15);
+          if (m > M - 1) m = M - 1;
+          add4[i][rr] = *reinterpret_cast<const bf16x4*>(addend + m * ldc + ncol);
+        }
+    }
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
 #pragma unroll
@@ -625,12 +640,11 @@ gemm_mfma_k1s(const bf16_t* __restrict__ A, const bf16_t* __restrict__ B, void* 
           }
           if (act == MMRCA_ACT_GELU) {
 #pragma unroll
-            for (int r = 0; r < 4; ++r) v[r] = gelu_f(v[r]);
+            for (int r = 0; r < 4; ++r) v[r] = gelu_fast_f(v[r]);
           }
           if (addend) {
-            bf16x4 a4 = *reinterpret_cast<const bf16x4*>(addend + m * ldc + ncol);
 #pragma unroll
-            for (int r = 0; r < 4; ++r) v[r] += (float)a4[r];
+            for (int r = 0; r < 4; ++r) v[r] += (float)add4[i][rr][r];
           }
           bf16x4 o;
 #pragma unroll
@@ -806,7 +820,7 @@ gemm_mfma_p_k(const bf16_t* __restrict__ A, const bf16_t* __restrict__ B, void* 
             }
             if (act == MMRCA_ACT_GELU) {
 #pragma unroll
-              for (int r = 0; r < 4; ++r) v[r] = gelu_f(v[r]);
+              for (int r = 0; r < 4; ++r) v[r] = gelu_fast_f(v[r]);
             }
             if (addend) {
               bf16x4 a4 = *reinterpret_cast<const bf16x4*>(addend + m * ldc + ncol);

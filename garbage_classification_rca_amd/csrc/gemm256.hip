@@ -273,7 +273,7 @@ gemm_mfma256_k(const bf16_t* __restrict__ A, const bf16_t* __restrict__ B, bf16_
         }
         if (act == MMRCA_ACT_GELU) {
 #pragma unroll
-          for (int r = 0; r < 4; ++r) v[r] = gelu_f(v[r]);
+          for (int r = 0; r < 4; ++r) v[r] = gelu_fast_f(v[r]);
         }
         if (addend) {
           bf16x4 a4 = *reinterpret_cast<const bf16x4*>(addend + m * ldc + ncol);

@@ -139,7 +139,7 @@ def gemm(A, B, Cout, *, bias=None, addend=None, preact=None, M, N, K, lda, ldb, 
                              a_layout, b_layout, act, int(accum), dtype, impl, stream_ptr()), "mmrca_gemm")
     if prof:
         e1.record()
-        GEMM_PROFILE.append((2.0 * M * N * K, (a_layout, b_layout, int(accum)), e0, e1))
+        GEMM_PROFILE.append((2.0 * M * N * K, (a_layout, b_layout, int(accum)), e0, e1, (M, N, K, act)))
 
 
 def colsum_accum(dY, db, M, N, ld, dtype):

@@ -12,6 +12,8 @@ SHAPES = [  # (name, M, N, K, a_layout, b_layout, accum)
     ("dgrad qkv", M, 768, 2304, 0, 1, 0), ("dgrad ffn1", M, 768, 3072, 0, 1, 0), ("dgrad ffn2", M, 3072, 768, 0, 1, 0),
     ("wgrad qkv", 2304, 768, M, 1, 1, 1), ("wgrad out", 768, 768, M, 1, 1, 1), ("wgrad ffn1", 3072, 768, M, 1, 1, 1), ("wgrad ffn2", 768, 3072, M, 1, 1, 1),
     ("epi K64", M, 3072, 64, 0, 0, 0), ("epi K128", M, 3072, 128, 0, 0, 0), ("epi K1536", M, 3072, 1536, 0, 0, 0),
+    ("epi ffn1 preact", M, 3072, 768, 0, 0, 0), ("epi ffn1 gelu", M, 3072, 768, 0, 0, 0), ("epi ffn1 gelu preact", M, 3072, 768, 0, 0, 0),
+    ("epi out addend", M, 768, 768, 0, 0, 0), ("epi ffn2 addend", M, 768, 3072, 0, 0, 0),
     ("text fwd qkv", 16384, 2304, 768, 0, 0, 0), ("text fwd out", 16384, 768, 768, 0, 0, 0),
 ]
 impls = {"mfma128": L.IMPL_MFMA, "bk32": L.IMPL_MFMA_BK32, "1stage": L.IMPL_MFMA_1STAGE}
@@ -35,6 +37,9 @@ for name, m, n, k, al, bl, acc in SHAPES:
     C = torch.zeros(Mp, n, device=dev, dtype=torch.float32 if acc else torch.bfloat16)
     bias = None if acc else torch.randn(n, device=dev).bfloat16()
     row = {}
+    epi = dict(preact=torch.empty(Mp, n, device=dev, dtype=torch.bfloat16) if "preact" in name else None,
+               addend=torch.randn(Mp, n, device=dev).bfloat16() if "addend" in name else None,
+               act=L.ACT_GELU if "gelu" in name else L.ACT_NONE)
     variants = [(a, b, 0) for a, b in impls.items()] + [(f"256dbg{d}", L.IMPL_MFMA256, d) for d in DBG if d and d < 256]
     variants += [(f"128tgt{d >> 8}", L.IMPL_MFMA, d) for d in DBG if d >= 256]
     variants += [(f"128dbg{d}", L.IMPL_MFMA, d) for d in DBG if d == 16]
@@ -45,8 +50,13 @@ for name, m, n, k, al, bl, acc in SHAPES:
             continue
         def run(impl=impl, dbg=dbg):
             L.load().mmrca_debug_set(dbg)
-            L.gemm(A, B, C, bias=bias, M=m, N=n, K=k, lda=lda, ldb=ldb, ldc=n, a_layout=al, b_layout=bl, accum=bool(acc), dtype=L.BF16, impl=impl)
+            L.gemm(A, B, C, bias=bias, M=m, N=n, K=k, lda=lda, ldb=ldb, ldc=n, a_layout=al, b_layout=bl, accum=bool(acc), dtype=L.BF16, impl=impl, **epi)
         runs[iname] = run
+    if os.environ.get("MMRCA_YARDSTICK"):      # calibration only: the vendor library (hipBLASLt through torch.matmul) on the same operands
+        At = A[:m] if al == 0 else A.t()
+        Bt = B.t() if bl == 0 else B
+        Cy = torch.empty(m, n, device=dev, dtype=torch.bfloat16)
+        runs["hipblaslt"] = lambda At=At, Bt=Bt, Cy=Cy: torch.matmul(At, Bt, out=Cy)
     best = {k2: 1e9 for k2 in runs}
     for k2, fn in runs.items():
         for _ in range(3):

@@ -1,7 +1,7 @@
 #!/usr/bin/env python
 """Summarise a rocprofv3 kernel_stats.csv: ms per step per kernel.  usage: prof_summary.py <dir> <steps_in_run> [rows]"""
 import csv, glob, sys
-f = glob.glob(sys.argv[1] + "/*/*kernel_stats.csv")[0]
+f = sys.argv[1] if sys.argv[1].endswith(".csv") else (glob.glob(sys.argv[1] + "/*kernel_stats.csv") + glob.glob(sys.argv[1] + "/*/*kernel_stats.csv"))[0]
 n = int(sys.argv[2])
 rows = list(csv.DictReader(open(f)))
 tot = sum(int(r["TotalDurationNs"]) for r in rows)
