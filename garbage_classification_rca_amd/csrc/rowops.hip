@@ -77,76 +77,101 @@ add_ln_fwd_k(const T* __restrict__ x, const T* __restrict__ res, const T* __rest
 // loads in flight (the plain kernel above reached 3.0 TB/s at 50432 x 768; HBM-bound work wants ~2x the bytes in flight)
 typedef __attribute__((ext_vector_type(8))) __bf16 raw8;
 
-template <int NV2>
+template <int NV2, int RP>
 __global__ void __launch_bounds__(256)
 add_ln_fwd_bf16_k(const bf16_t* __restrict__ x, const bf16_t* __restrict__ res, const bf16_t* __restrict__ gamma,
                   const bf16_t* __restrict__ beta, bf16_t* __restrict__ sum_out, bf16_t* __restrict__ y,
                   float* __restrict__ mean, float* __restrict__ rstd, int64_t rows, int D, int64_t ld_x, int64_t ld_y,
                   float eps, float in_p, uint64_t in_seed, float out_p, uint64_t out_seed) {
+  // RP rows per wave per iteration (rows row, row + stride, ...): their loads, reductions and stores interleave
   const float in_sc = in_p > 0.f ? 1.f / (1.f - in_p) : 1.f, out_sc = out_p > 0.f ? 1.f / (1.f - out_p) : 1.f;
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const int64_t stride = (int64_t)gridDim.x * 4;
   int64_t row = (int64_t)blockIdx.x * 4 + wave;
-  raw8 gm[NV2], bt[NV2], nx[NV2], nr[NV2];
+  raw8 gm[NV2], bt[NV2], nx[RP][NV2], nr[RP][NV2];
 #pragma unroll
   for (int it = 0; it < NV2; ++it) {
     const int c = it * 512 + lane * 8;
     if (c < D) { gm[it] = *reinterpret_cast<const raw8*>(gamma + c); bt[it] = *reinterpret_cast<const raw8*>(beta + c); }
   }
-#define LNF_FETCH(r_)                                                                            \
-  _Pragma("unroll") for (int it = 0; it < NV2; ++it) {                                           \
-    const int c = it * 512 + lane * 8;                                                           \
-    if (c < D) {                                                                                 \
-      nx[it] = *reinterpret_cast<const raw8*>(x + (r_) * ld_x + c);                              \
-      if (res) nr[it] = *reinterpret_cast<const raw8*>(res + (r_) * ld_x + c);                   \
+#define LNF_FETCH(r0_)                                                                           \
+  _Pragma("unroll") for (int p = 0; p < RP; ++p) {                                               \
+    const int64_t r_ = (r0_) + p * stride;                                                       \
+    if (r_ < rows) {                                                                             \
+      _Pragma("unroll") for (int it = 0; it < NV2; ++it) {                                       \
+        const int c = it * 512 + lane * 8;                                                       \
+        if (c < D) {                                                                             \
+          nx[p][it] = *reinterpret_cast<const raw8*>(x + r_ * ld_x + c);                         \
+          if (res) nr[p][it] = *reinterpret_cast<const raw8*>(res + r_ * ld_x + c);              \
+        }                                                                                        \
+      }                                                                                          \
     }                                                                                            \
   }
-  if (row < rows) { LNF_FETCH(row) }
-  for (; row < rows; row += stride) {
-    float v[NV2][8];
-    float s = 0.f;
+  LNF_FETCH(row)
+  for (; row < rows; row += RP * stride) {
+    float v[RP][NV2][8];
+    float s[RP], q[RP], mu[RP], rs[RP];
 #pragma unroll
-    for (int it = 0; it < NV2; ++it) {
-      const int c = it * 512 + lane * 8;
-      if (c < D) {
-        raw8 so;
+    for (int p = 0; p < RP; ++p) {
+      const int64_t r = row + p * stride;
+      s[p] = 0.f;
+      if (r < rows) {
 #pragma unroll
-        for (int j = 0; j < 8; ++j) {
-          float a = (float)nx[it][j];
-          if (in_p > 0.f) a = mmrca_uniform(in_seed, (uint64_t)row * D + c + j) >= in_p ? a * in_sc : 0.f;
-          if (res) a += (float)nr[it][j];
-          if (sum_out) { so[j] = (bf16_t)a; a = (float)so[j]; }   // the stored sum is what the backward re-reads
-          v[it][j] = a; s += a;
+        for (int it = 0; it < NV2; ++it) {
+          const int c = it * 512 + lane * 8;
+          if (c < D) {
+            raw8 so;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+              float a = (float)nx[p][it][j];
+              if (in_p > 0.f) a = mmrca_uniform(in_seed, (uint64_t)r * D + c + j) >= in_p ? a * in_sc : 0.f;
+              if (res) a += (float)nr[p][it][j];
+              if (sum_out) { so[j] = (bf16_t)a; a = (float)so[j]; }   // the stored sum is what the backward re-reads
+              v[p][it][j] = a; s[p] += a;
+            }
+            if (sum_out) *reinterpret_cast<raw8*>(sum_out + r * ld_x + c) = so;
+          }
         }
-        if (sum_out) *reinterpret_cast<raw8*>(sum_out + row * ld_x + c) = so;
       }
     }
-    const int64_t nxt = row + stride;
-    if (nxt < rows) { LNF_FETCH(nxt) }
-    const float mu = wave_sum(s) / (float)D;
-    float q = 0.f;
+    LNF_FETCH(row + RP * stride)
 #pragma unroll
-    for (int it = 0; it < NV2; ++it) {
-      const int c = it * 512 + lane * 8;
-      if (c < D) {
+    for (int p = 0; p < RP; ++p) mu[p] = wave_sum(s[p]) / (float)D;
 #pragma unroll
-        for (int j = 0; j < 8; ++j) { const float d = v[it][j] - mu; q += d * d; }
+    for (int p = 0; p < RP; ++p) {
+      q[p] = 0.f;
+      if (row + p * stride < rows) {
+#pragma unroll
+        for (int it = 0; it < NV2; ++it) {
+          const int c = it * 512 + lane * 8;
+          if (c < D) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) { const float d = v[p][it][j] - mu[p]; q[p] += d * d; }
+          }
+        }
       }
     }
-    const float rs = rsqrtf(wave_sum(q) / (float)D + eps);
-    if (lane == 0) { if (mean) mean[row] = mu; if (rstd) rstd[row] = rs; }
 #pragma unroll
-    for (int it = 0; it < NV2; ++it) {
-      const int c = it * 512 + lane * 8;
-      if (c < D) {
-        raw8 o;
+    for (int p = 0; p < RP; ++p) rs[p] = rsqrtf(wave_sum(q[p]) / (float)D + eps);
 #pragma unroll
-        for (int j = 0; j < 8; ++j) {
-          float t = (v[it][j] - mu) * rs * (float)gm[it][j] + (float)bt[it][j];
-          if (out_p > 0.f) t = mmrca_uniform(out_seed, (uint64_t)row * D + c + j) >= out_p ? t * out_sc : 0.f;
-          o[j] = (bf16_t)t;
+    for (int p = 0; p < RP; ++p) {
+      const int64_t r = row + p * stride;
+      if (r < rows) {
+        if (lane == 0) { if (mean) mean[r] = mu[p]; if (rstd) rstd[r] = rs[p]; }
+#pragma unroll
+        for (int it = 0; it < NV2; ++it) {
+          const int c = it * 512 + lane * 8;
+          if (c < D) {
+            raw8 o;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+              float t = (v[p][it][j] - mu[p]) * rs[p] * (float)gm[it][j] + (float)bt[it][j];
+              if (out_p > 0.f) t = mmrca_uniform(out_seed, (uint64_t)r * D + c + j) >= out_p ? t * out_sc : 0.f;
+              o[j] = (bf16_t)t;
+            }
+            *reinterpret_cast<raw8*>(y + r * ld_y + c) = o;
+          }
         }
-        *reinterpret_cast<raw8*>(y + row * ld_y + c) = o;
       }
     }
   }
@@ -166,9 +191,9 @@ extern "C" int mmrca_add_layernorm_fwd(const void* x, const void* res, const voi
   if (rows <= 0) return 0;
   if (dtype == MMRCA_BF16 && D % 8 == 0 && D <= 1024 && ld_x % 8 == 0 && ld_y % 8 == 0 && aligned16p(x) && aligned16p(y) &&
       aligned16p(gamma) && aligned16p(beta) && (!res || aligned16p(res)) && (!sum_out || aligned16p(sum_out))) {
-    const int g2 = (int)((rows + 3) / 4 < 2048 ? (rows + 3) / 4 : 2048);
+    const int g2 = (int)((rows + 7) / 8 < 1024 ? (rows + 7) / 8 : 1024);
 #define LN_FWD16(NV2_)                                                                                                       \
-    hipLaunchKernelGGL((add_ln_fwd_bf16_k<NV2_>), dim3(g2), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)x,              \
+    hipLaunchKernelGGL((add_ln_fwd_bf16_k<NV2_, 2>), dim3(g2), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)x,              \
                        (const bf16_t*)res, (const bf16_t*)gamma, (const bf16_t*)beta, (bf16_t*)sum_out, (bf16_t*)y, mean, rstd, \
                        rows, D, ld_x, ld_y, eps, in_drop_p, in_drop_seed, out_drop_p, out_drop_seed)
     const int nv2 = (D + 511) / 512;
@@ -612,6 +637,62 @@ embed_bwd_k(const T* __restrict__ dout, const int32_t* __restrict__ ids, const i
   }
 }
 
+// D <= 1024: the token-type row (one address per column for ALL rows) and the position rows (one per position for the
+// whole batch) were 16k-way and 256-way contended atomics, 1 ms per step.  A wave now keeps both sums in registers
+// across the rows it walks -- its row stride is a multiple of any power-of-two sequence length, so its position id
+// normally never changes -- and flushes them with one atomic per column (on a position change, and at the end).
+template <typename T>
+__global__ void __launch_bounds__(256)
+embed_bwd_acc_k(const T* __restrict__ dout, const int32_t* __restrict__ ids, const int32_t* __restrict__ pos_ids,
+                float* __restrict__ dword, float* __restrict__ dpos, float* __restrict__ dtype_row, int64_t rows, int D) {
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  float at[4][4], ap[4][4];
+#pragma unroll
+  for (int k = 0; k < 4; ++k)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) { at[k][j] = 0.f; ap[k][j] = 0.f; }
+  int64_t cur_p = -1;
+  for (int64_t row = (int64_t)blockIdx.x * 4 + wave; row < rows; row += (int64_t)gridDim.x * 4) {
+    const int64_t id = ids[row], p = pos_ids[row];
+    if (dpos && p != cur_p) {                  // wave-uniform
+      if (cur_p >= 0) {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          const int c = lane * 4 + 256 * k;
+          if (c < D) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) { atomicAdd(dpos + cur_p * D + c + j, ap[k][j]); ap[k][j] = 0.f; }
+          }
+        }
+      }
+      cur_p = p;
+    }
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const int c = lane * 4 + 256 * k;
+      if (c < D) {
+        Vec4<T> d = Vec4<T>::load(dout + row * D + c);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          if (dword) atomicAdd(dword + id * D + c + j, d.v[j]);
+          ap[k][j] += d.v[j]; at[k][j] += d.v[j];
+        }
+      }
+    }
+  }
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    const int c = lane * 4 + 256 * k;
+    if (c < D) {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        if (dpos && cur_p >= 0) atomicAdd(dpos + cur_p * D + c + j, ap[k][j]);
+        if (dtype_row) atomicAdd(dtype_row + c + j, at[k][j]);
+      }
+    }
+  }
+}
+
 extern "C" int mmrca_embed_fwd(const int32_t* ids, const int32_t* pos_ids, const void* word, const void* pos,
                                const void* type_row, void* out, int64_t rows, int D, int dtype, void* stream) {
   MMRCA_REQUIRE(ids && pos_ids && word && pos && out, "embed_fwd: null pointer");
@@ -630,6 +711,14 @@ extern "C" int mmrca_embed_bwd(const void* dout, const int32_t* ids, const int32
   MMRCA_REQUIRE(dout && ids && pos_ids, "embed_bwd: null pointer");
   MMRCA_REQUIRE(D % 4 == 0, "embed_bwd: D must be a multiple of 4");
   if (rows <= 0) return 0;
+  if (D <= 1024) {
+    const int g2 = (int)((rows + 3) / 4 < 256 ? (rows + 3) / 4 : 256);     // 1024 waves: row stride 1024
+    MMRCA_DISPATCH_DTYPE(dtype, "embed_bwd",
+      hipLaunchKernelGGL(embed_bwd_acc_k<T>, dim3(g2), dim3(256), 0, (hipStream_t)stream, (const T*)dout, ids, pos_ids,
+                         dword, dpos, dtype_row, rows, D);)
+    MMRCA_CHECK_LAUNCH("embed_bwd");
+    return 0;
+  }
   const int grid = (int)((rows + 3) / 4 < 4096 ? (rows + 3) / 4 : 4096);
   MMRCA_DISPATCH_DTYPE(dtype, "embed_bwd",
     hipLaunchKernelGGL(embed_bwd_k<T>, dim3(grid), dim3(256), 0, (hipStream_t)stream, (const T*)dout, ids, pos_ids,

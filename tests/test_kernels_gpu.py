@@ -294,12 +294,16 @@ def test_gelu_bwd_and_colsum(dt):
 # ------------------------------------------------------------------------------------------------------
 # embeddings, patchify, assemble
 # ------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("rows,structured", [(50, False), (4100, False), (64 * 70, True)])
 @pytest.mark.parametrize("dt", [torch.float32, torch.bfloat16])
-def test_embed_fwd_bwd(dt):
-    V, Pn, D, rows = 1000, 66, 768, 50
+def test_embed_fwd_bwd(dt, rows, structured):
+    # rows > 1024: a wave of embed_bwd walks several rows, keeping position / token-type sums in registers
+    V, Pn, D = 1000, 66, 768
     word, pos, typ = dev(torch.randn(V, D), dt), dev(torch.randn(Pn, D), dt), dev(torch.randn(D), dt)
     ids = torch.randint(0, V, (rows,), dtype=torch.int32, device="cuda"); ids[:5] = 7
     pid = torch.randint(0, Pn, (rows,), dtype=torch.int32, device="cuda")
+    if structured:
+        pid = (torch.arange(rows, device="cuda") % 64).int()
     out = torch.empty(rows, D, device="cuda", dtype=dt)
     L.embed_fwd(ids, pid, word, pos, typ, out, rows, D, L.dtype_code(dt))
     ref = word.float()[ids.long()] + pos.float()[pid.long()] + typ.float()
