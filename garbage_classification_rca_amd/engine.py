@@ -35,6 +35,11 @@ FUSE_GELU_GRAD = os.environ.get("MMRCA_FUSE_GELU", "0") == "1"
 SIDE_STREAM_WGRAD = os.environ.get("MMRCA_SIDE_STREAM", "1") == "1"
 # text encoder and vision encoder are independent until the fusion head: run them on two streams
 CONCURRENT_ENCODERS = os.environ.get("MMRCA_CONCURRENT_ENCODERS", "1") == "1"
+# Only the class-token row of each encoder's LAST layer reaches the head (reference: hidden_state[:, 0] /
+# torchvision's x[:, 0]), so everything of that layer after the attention mix -- out-proj, residual, LayerNorms, the
+# FFN, and their backward -- runs on B rows instead of B*S.  Same logits and same gradients for every parameter (the
+# pruned rows' outputs were never read; their gradients are exact zeros); "0" restores the full-row top layer.
+CLS_TAIL = os.environ.get("MMRCA_CLS_TAIL", "1") == "1"
 ROWPAD = 128
 
 
@@ -339,6 +344,28 @@ class MMRCAEngine:
             qkv, ctx, lse = fb("qkv", 3 * D, i), fb("ctx", D, i), self.buf("t_lse", 1, _round_up(B * H * T, ROWPAD), torch.float32, i if save else 0)
             self._lin_fwd(x, P + K["q"] + ".weight", P + K["q"] + ".bias", qkv, M, 3 * D, D, wnumel=3 * D * D)
             L.mha_fwd(qkv, mask32, ctx, lse, B, H, T, dh, dh ** -0.5, self.dt, self.attn_impl, drop_p=dp, drop_seed=sd(i, 1))
+            if CLS_TAIL and i == s.layers - 1:
+                # class-token tail: rows b*T of ctx / x only (see CLS_TAIL above)
+                cb = lambda name, cols, dt=None: self.buf("t_" + name + "_c", B, cols, dt, i if save else 0)
+                ctx_c, x_c = cb("ctx", D), cb("xin", D)
+                ctx_c[:B].copy_(ctx[:M].view(B, T, D)[:, 0]); x_c[:B].copy_(x[:M].view(B, T, D)[:, 0])
+                att = cb("att", D)
+                self._lin_fwd(ctx_c, P + K["o"] + ".weight", P + K["o"] + ".bias", att, B, D, D)
+                s1, x1 = cb("s1", D), cb("x1", D)
+                m1, r1 = stat("m1c", i), stat("r1c", i)
+                self._ln_fwd(att, x_c, P + K["ln1"], s1, x1, m1, r1, B, D, s.ln_eps, in_drop=(post_attn_drop, sd(i, 2)))
+                h, g = cb("h", Fd), cb("g", Fd)
+                self._lin_fwd(x1, P + K["f1"] + ".weight", P + K["f1"] + ".bias", g, B, Fd, D, act=(L.ACT_GELU_SAVE_GRAD if FUSE_GELU_GRAD else L.ACT_GELU), preact=h)
+                f = cb("f", D)
+                self._lin_fwd(g, P + K["f2"] + ".weight", P + K["f2"] + ".bias", f, B, D, Fd)
+                s2, xn = cb("s2", D), cb("xout", D)
+                m2, r2 = stat("m2c", i), stat("r2c", i)
+                self._ln_fwd(f, x1, P + K["ln2"], s2, xn, m2, r2, B, D, s.ln_eps, in_drop=(dp, sd(i, 3)))
+                layers.append(dict(x=x, qkv=qkv, ctx=ctx, lse=lse, s1=s1, x1=x1, m1=m1, r1=r1, h=h, g=g, s2=s2, m2=m2, r2=r2,
+                                   ctx_c=ctx_c, tail=True))
+                cls = xn[:B].clone()
+                return cls, dict(B=B, T=T, ids32=ids32, pos=pos, mask32=mask32, emb=emb, mean0=mean0, rstd0=rstd0, layers=layers,
+                                 drop_p=dp, drop_seed=drop_seed)
             att = fb("tmpD", D)
             self._lin_fwd(ctx, P + K["o"] + ".weight", P + K["o"] + ".bias", att, M, D, D)
             s1, x1 = fb("s1", D, i), fb("x1", D, i)
@@ -364,9 +391,14 @@ class MMRCAEngine:
         dh = D // H
         gb = lambda name, cols: self.buf("tg_" + name, M, cols)
         dx = gb("dxA", D)
-        dx[:M].zero_()
-        dx[:M].view(B, T, D)[:, 0] = dcls
+        tail = bool(sv["layers"][-1].get("tail"))
+        if not tail:
+            dx[:M].zero_()
+            dx[:M].view(B, T, D)[:, 0] = dcls
         for i in reversed(range(s.layers)):
+            if tail and i == s.layers - 1:
+                self._text_backward_tail(dcls, sv, dx)
+                continue
             K, a = S.text_layer_keys(s, i), sv["layers"][i]
             ds2 = gb("ds2", D)
             dp, sd = sv["drop_p"], (lambda layer, site: self._site_seed(sv["drop_seed"], layer, site))
@@ -404,6 +436,48 @@ class MMRCAEngine:
         self._layer_boundary()
         self._ready("text_emb", flush=True)
 
+    def _text_backward_tail(self, dcls, sv, dx):
+        """Backward of the LAST text layer when its post-attention part ran on the class-token rows only (CLS_TAIL)."""
+        s, P = self.ts, "text_model."
+        B, T = sv["B"], sv["T"]
+        M, D, Fd, H = B * T, s.dim, s.ffn, s.heads
+        dh, i = D // H, s.layers - 1
+        K, a = S.text_layer_keys(s, i), sv["layers"][i]
+        gb = lambda name, cols: self.buf("tg_" + name, M, cols)
+        gc = lambda name, cols: self.buf("tg_" + name + "_c", B, cols)
+        dp, sd = sv["drop_p"], (lambda layer, site: self._site_seed(sv["drop_seed"], layer, site))
+        post_attn_drop = dp if s.name != "distilbert" else 0.0
+        dxc = gc("dx", D)
+        dxc[:B].copy_(dcls)
+        ds2 = gc("ds2", D)
+        df = gc("dbr_ffn", D) if dp > 0 else None
+        gb_f2, gb_o = self.G(P + K["f2"] + ".bias"), self.G(P + K["o"] + ".bias")
+        self._ln_bwd(dxc, a["s2"], P + K["ln2"], a["m2"], a["r2"], None, ds2, B, D, branch_drop=(dp, sd(i, 3)), dbranch=df,
+                     dcol=(None if df is not None else gb_f2), dcol_branch=(gb_f2 if df is not None else None))
+        dg = gc("dF", Fd)
+        self._lin_bwd(df if df is not None else ds2, a["g"], P + K["f2"] + ".weight", P + K["f2"] + ".bias", dg, B, D, Fd,
+                      gelu_h=a["h"], bias_done=True, gelu_db=(None if FUSE_GELU_GRAD else self.G(P + K["f1"] + ".bias")))
+        dx1 = gc("dxB", D)
+        self._lin_bwd(dg, a["x1"], P + K["f1"] + ".weight", P + K["f1"] + ".bias", dx1, B, Fd, D, addend=ds2, bias_done=not FUSE_GELU_GRAD)
+        ds1 = gc("ds1", D)
+        datt = gc("dbr_att", D) if post_attn_drop > 0 else None
+        self._ln_bwd(dx1, a["s1"], P + K["ln1"], a["m1"], a["r1"], None, ds1, B, D, branch_drop=(post_attn_drop, sd(i, 2)), dbranch=datt,
+                     dcol=(None if datt is not None else gb_o), dcol_branch=(gb_o if datt is not None else None))
+        dctx_c = gc("dctx", D)
+        self._lin_bwd(datt if datt is not None else ds1, a["ctx_c"], P + K["o"] + ".weight", P + K["o"] + ".bias", dctx_c, B, D, D,
+                      bias_done=True)
+        # back to all rows: the attention mixes the class-token gradient into every key / value row
+        dctx, ds1_full = gb("dctx", D), gb("ds1", D)
+        dctx[:M].zero_(); ds1_full[:M].zero_()
+        dctx[:M].view(B, T, D)[:, 0] = dctx_c[:B]
+        ds1_full[:M].view(B, T, D)[:, 0] = ds1[:B]
+        dqkv = gb("dqkv", 3 * D)
+        L.mha_bwd(a["qkv"], sv["mask32"], a["ctx"], dctx, a["lse"], dqkv, B, H, T, dh, dh ** -0.5, self.dt, self.attn_impl,
+                  drop_p=dp, drop_seed=sd(i, 1))
+        self._lin_bwd(dqkv, a["x"], P + K["q"] + ".weight", P + K["q"] + ".bias", dx, M, 3 * D, D, addend=ds1_full, wnumel=3 * D * D)
+        self._layer_boundary()
+        self._ready(f"text_layer_{i}")
+
     # ------------------------------------------------------------------ vision encoder
     def _vision_forward(self, images, save):
         s, P = self.vs, "image_model."
@@ -430,6 +504,25 @@ class MMRCAEngine:
             lse = self.buf("v_lse", 1, _round_up(B * H * Tn, ROWPAD), torch.float32, i if save else 0)
             self._lin_fwd(y1, Lk + "self_attention.in_proj_weight", Lk + "self_attention.in_proj_bias", qkv, M, 3 * D, D)
             L.mha_fwd(qkv, None, ctx, lse, B, H, Tn, dh, dh ** -0.5, self.dt, self.attn_impl)
+            if CLS_TAIL and i == s.layers - 1:
+                # class-token tail: rows b*Tn of ctx / x only (see CLS_TAIL above)
+                cb = lambda name, cols: fb(name + "_c", B, cols, i)
+                ctx_c, x_c = cb("ctx", D), cb("xin", D)
+                ctx_c[:B].copy_(ctx[:M].view(B, Tn, D)[:, 0]); x_c[:B].copy_(x[:M].view(B, Tn, D)[:, 0])
+                x1 = cb("x1", D)
+                self._lin_fwd(ctx_c, Lk + "self_attention.out_proj.weight", Lk + "self_attention.out_proj.bias", x1, B, D, D, addend=x_c)
+                y2, m2, r2 = cb("y2", D), stat("m2c", i), stat("r2c", i)
+                self._ln_fwd(x1, None, Lk + "ln_2", None, y2, m2, r2, B, D, s.ln_eps)
+                h, g = cb("h", Fd), cb("g", Fd)
+                self._lin_fwd(y2, Lk + "mlp.0.weight", Lk + "mlp.0.bias", g, B, Fd, D, act=(L.ACT_GELU_SAVE_GRAD if FUSE_GELU_GRAD else L.ACT_GELU), preact=h)
+                xn = cb("xout", D)
+                self._lin_fwd(g, Lk + "mlp.3.weight", Lk + "mlp.3.bias", xn, B, D, Fd, addend=x1)
+                layers.append(dict(x=x, y1=y1, m1=m1, r1=r1, qkv=qkv, ctx=ctx, lse=lse, x1=x1, y2=y2, m2=m2, r2=r2, h=h, g=g,
+                                   ctx_c=ctx_c, tail=True))
+                feat = self.buf("v_feat", B, D)
+                mf, rf = stat("mf"), stat("rf")
+                self._ln_fwd(xn, None, P + "encoder.ln", None, feat, mf, rf, B, D, s.ln_eps)
+                return feat[:B], dict(B=B, patches=patches, xL=xn, mf=mf, rf=rf, layers=layers)
             x1 = fb("x1", M, D, i)
             self._lin_fwd(ctx, Lk + "self_attention.out_proj.weight", Lk + "self_attention.out_proj.bias", x1, M, D, D, addend=x)
             y2, m2, r2 = fb("y2", M, D, i), stat("m2", i), stat("r2", i)
@@ -452,15 +545,23 @@ class MMRCAEngine:
         dh, M, Kp = D // H, B * Tn, 3 * s.patch * s.patch
         gb = lambda name, rows, cols: self.buf("vg_" + name, rows, cols)
         dx = gb("dxA", M, D)
-        dx[:M].zero_()
         dfe = self.buf("vg_dfeat", B, D)
         dfe[:B].copy_(dfeat)
         top = P + f"encoder.layers.encoder_layer_{s.layers - 1}."
-        # dx is zero except the class-token rows written here, so their column sums are the top layer's mlp.3 bias gradient
-        self._ln_bwd(dfe, sv["xL"], P + "encoder.ln", sv["mf"], sv["rf"], None, dx, B, D, ld_dy=D, ld_s=Tn * D, ld_ds=Tn * D,
-                     dcol=self.G(top + "mlp.3.bias"))
+        tail = bool(sv["layers"][-1].get("tail"))
+        if tail:
+            dxc = self.buf("vg_dx_c", B, D)
+            self._ln_bwd(dfe, sv["xL"], P + "encoder.ln", sv["mf"], sv["rf"], None, dxc, B, D, dcol=self.G(top + "mlp.3.bias"))
+        else:
+            dx[:M].zero_()
+            # dx is zero except the class-token rows written here, so their column sums are the top layer's mlp.3 bias gradient
+            self._ln_bwd(dfe, sv["xL"], P + "encoder.ln", sv["mf"], sv["rf"], None, dx, B, D, ld_dy=D, ld_s=Tn * D, ld_ds=Tn * D,
+                         dcol=self.G(top + "mlp.3.bias"))
         self._ready("image_ln")
         for i in reversed(range(s.layers)):
+            if tail and i == s.layers - 1:
+                self._vision_backward_tail(dxc, sv, dx)
+                continue
             Lk, a = P + f"encoder.layers.encoder_layer_{i}.", sv["layers"][i]
             dg = gb("dF", M, Fd)
             self._lin_bwd(dx, a["g"], Lk + "mlp.3.weight", Lk + "mlp.3.bias", dg, M, D, Fd, gelu_h=a["h"], bias_done=True,
@@ -486,6 +587,41 @@ class MMRCAEngine:
         self._lin_bwd(dproj, sv["patches"], P + "conv_proj.weight", P + "conv_proj.bias", None, B * nP, D, Kp, wnumel=D * Kp)
         self._layer_boundary()
         self._ready("image_emb", flush=True)
+
+    def _vision_backward_tail(self, dxc, sv, dx):
+        """Backward of the LAST ViT layer when its post-attention part ran on the class-token rows only (CLS_TAIL);
+        dxc [B, D] is the gradient at the layer's class-token output, dx [B*Tn, D] receives the gradient at its input."""
+        s, P = self.vs, "image_model."
+        B = sv["B"]
+        Tn, D, Fd, H = s.tokens, s.dim, s.ffn, s.heads
+        dh, M, i = D // H, B * Tn, s.layers - 1
+        Lk, a = P + f"encoder.layers.encoder_layer_{i}.", sv["layers"][i]
+        gb = lambda name, rows, cols: self.buf("vg_" + name, rows, cols)
+        gc = lambda name, cols: self.buf("vg_" + name + "_c", B, cols)
+        dg = gc("dF", Fd)
+        self._lin_bwd(dxc, a["g"], Lk + "mlp.3.weight", Lk + "mlp.3.bias", dg, B, D, Fd, gelu_h=a["h"], bias_done=True,
+                      gelu_db=(None if FUSE_GELU_GRAD else self.G(Lk + "mlp.0.bias")))
+        dy2 = gc("dy", D)
+        self._lin_bwd(dg, a["y2"], Lk + "mlp.0.weight", Lk + "mlp.0.bias", dy2, B, Fd, D, bias_done=not FUSE_GELU_GRAD)
+        dx1c = gc("dxB", D)
+        self._ln_bwd(dy2, a["x1"], Lk + "ln_2", a["m2"], a["r2"], dxc, dx1c, B, D, dcol=self.G(Lk + "self_attention.out_proj.bias"))
+        dctx_c = gc("dctx", D)
+        self._lin_bwd(dx1c, a["ctx_c"], Lk + "self_attention.out_proj.weight", Lk + "self_attention.out_proj.bias", dctx_c, B, D, D,
+                      bias_done=True)
+        # back to all rows: the attention mixes the class-token gradient into every key / value row, and the residual
+        # stream carries it straight down at the class-token rows
+        dctx, dx1 = gb("dctx", M, D), gb("dxB", M, D)
+        dctx[:M].zero_(); dx1[:M].zero_()
+        dctx[:M].view(B, Tn, D)[:, 0] = dctx_c[:B]
+        dx1[:M].view(B, Tn, D)[:, 0] = dx1c[:B]
+        dqkv = gb("dqkv", M, 3 * D)
+        L.mha_bwd(a["qkv"], None, a["ctx"], dctx, a["lse"], dqkv, B, H, Tn, dh, dh ** -0.5, self.dt, self.attn_impl)
+        dy1 = gb("dy", M, D)
+        self._lin_bwd(dqkv, a["y1"], Lk + "self_attention.in_proj_weight", Lk + "self_attention.in_proj_bias", dy1, M, 3 * D, D)
+        below = P + f"encoder.layers.encoder_layer_{i - 1}.mlp.3.bias"
+        self._ln_bwd(dy1, a["x"], Lk + "ln_1", a["m1"], a["r1"], dx1, dx, M, D, dcol=(self.G(below) if i > 0 else None))
+        self._layer_boundary()
+        self._ready(f"image_layer_{i}")
 
     # ------------------------------------------------------------------ whole model
     def forward(self, ids, mask, images, drop_p: float = 0.0, seed: int = 0, save: bool = True, enc_drop_p: float = 0.0):

@@ -101,6 +101,31 @@ def _inputs(B, S_len):
     return torch.from_numpy(ids), torch.from_numpy(mask), torch.from_numpy(images)
 
 
+@pytest.mark.parametrize("dtype,tol", [(torch.float32, 2e-5), (torch.bfloat16, 2e-2)])
+def test_class_token_tail_equals_full_top_layer(dtype, tol, monkeypatch):
+    """CLS_TAIL prunes rows whose outputs are never read: logits and every parameter gradient must be unchanged."""
+    from garbage_classification_rca_amd import engine as E
+    B, S_len = 3, 24
+    ids, mask, images = _inputs(B, S_len)
+    labels, cw = torch.tensor([0, 1, 2]).int().cuda(), torch.tensor([0.7, 1.3, 0.9, 1.1]).cuda()
+    out = {}
+    for tail in (True, False):
+        monkeypatch.setattr(E, "CLS_TAIL", tail)
+        eng = MMRCAEngine("distilbert", "transformer_B16", 4, True, 0, dtype)
+        eng.load_arrays(proc_state_for(eng))
+        logits = eng.forward(ids.cuda(), mask.cuda(), images.cuda(), enc_drop_p=0.0)
+        loss, dl = torch.empty(1, device="cuda"), torch.empty(B, 4, device="cuda")
+        L.xent_fwd_bwd(logits, labels, cw, 0.1, loss, dl, B, 4)
+        eng.arena.g.zero_()
+        eng.backward(dl)
+        torch.cuda.synchronize()
+        out[tail] = (logits.float().clone(), eng.arena.g.clone())
+    assert rel(out[True][0], out[False][0]) < tol
+    ga, gb = out[True][1], out[False][1]
+    assert float((ga - gb).abs().max()) <= tol * float(gb.abs().max())
+    assert float(torch.nn.functional.cosine_similarity(ga, gb, dim=0)) > 1 - tol
+
+
 @pytest.mark.parametrize("mode", [0, 2])
 def test_fp32_logits_and_gradients_match_oracle(mode):
     B, S_len = 3, 24
