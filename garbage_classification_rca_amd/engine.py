@@ -343,12 +343,13 @@ class MMRCAEngine:
             K = S.text_layer_keys(s, i)
             qkv, ctx, lse = fb("qkv", 3 * D, i), fb("ctx", D, i), self.buf("t_lse", 1, _round_up(B * H * T, ROWPAD), torch.float32, i if save else 0)
             self._lin_fwd(x, P + K["q"] + ".weight", P + K["q"] + ".bias", qkv, M, 3 * D, D, wnumel=3 * D * D)
-            L.mha_fwd(qkv, mask32, ctx, lse, B, H, T, dh, dh ** -0.5, self.dt, self.attn_impl, drop_p=dp, drop_seed=sd(i, 1))
             if CLS_TAIL and i == s.layers - 1:
-                # class-token tail: rows b*T of ctx / x only (see CLS_TAIL above)
+                # class-token tail: the class-token query's attention, then rows b*T only (see CLS_TAIL above)
                 cb = lambda name, cols, dt=None: self.buf("t_" + name + "_c", B, cols, dt, i if save else 0)
                 ctx_c, x_c = cb("ctx", D), cb("xin", D)
-                ctx_c[:B].copy_(ctx[:M].view(B, T, D)[:, 0]); x_c[:B].copy_(x[:M].view(B, T, D)[:, 0])
+                lse = self.buf("t_lse_c", 1, _round_up(B * H, ROWPAD), torch.float32, i if save else 0)
+                L.mha_cls_fwd(qkv, mask32, ctx_c, lse, B, H, T, dh, dh ** -0.5, self.dt, drop_p=dp, drop_seed=sd(i, 1))
+                x_c[:B].copy_(x[:M].view(B, T, D)[:, 0])
                 att = cb("att", D)
                 self._lin_fwd(ctx_c, P + K["o"] + ".weight", P + K["o"] + ".bias", att, B, D, D)
                 s1, x1 = cb("s1", D), cb("x1", D)
@@ -366,6 +367,7 @@ class MMRCAEngine:
                 cls = xn[:B].clone()
                 return cls, dict(B=B, T=T, ids32=ids32, pos=pos, mask32=mask32, emb=emb, mean0=mean0, rstd0=rstd0, layers=layers,
                                  drop_p=dp, drop_seed=drop_seed)
+            L.mha_fwd(qkv, mask32, ctx, lse, B, H, T, dh, dh ** -0.5, self.dt, self.attn_impl, drop_p=dp, drop_seed=sd(i, 1))
             att = fb("tmpD", D)
             self._lin_fwd(ctx, P + K["o"] + ".weight", P + K["o"] + ".bias", att, M, D, D)
             s1, x1 = fb("s1", D, i), fb("x1", D, i)
@@ -467,13 +469,12 @@ class MMRCAEngine:
         self._lin_bwd(datt if datt is not None else ds1, a["ctx_c"], P + K["o"] + ".weight", P + K["o"] + ".bias", dctx_c, B, D, D,
                       bias_done=True)
         # back to all rows: the attention mixes the class-token gradient into every key / value row
-        dctx, ds1_full = gb("dctx", D), gb("ds1", D)
-        dctx[:M].zero_(); ds1_full[:M].zero_()
-        dctx[:M].view(B, T, D)[:, 0] = dctx_c[:B]
+        ds1_full = gb("ds1", D)
+        ds1_full[:M].zero_()
         ds1_full[:M].view(B, T, D)[:, 0] = ds1[:B]
         dqkv = gb("dqkv", 3 * D)
-        L.mha_bwd(a["qkv"], sv["mask32"], a["ctx"], dctx, a["lse"], dqkv, B, H, T, dh, dh ** -0.5, self.dt, self.attn_impl,
-                  drop_p=dp, drop_seed=sd(i, 1))
+        L.mha_cls_bwd(a["qkv"], sv["mask32"], a["ctx_c"], dctx_c, a["lse"], dqkv, B, H, T, dh, dh ** -0.5, self.dt,
+                      drop_p=dp, drop_seed=sd(i, 1))
         self._lin_bwd(dqkv, a["x"], P + K["q"] + ".weight", P + K["q"] + ".bias", dx, M, 3 * D, D, addend=ds1_full, wnumel=3 * D * D)
         self._layer_boundary()
         self._ready(f"text_layer_{i}")
@@ -503,12 +504,13 @@ class MMRCAEngine:
             qkv, ctx = fb("qkv", M, 3 * D, i), fb("ctx", M, D, i)
             lse = self.buf("v_lse", 1, _round_up(B * H * Tn, ROWPAD), torch.float32, i if save else 0)
             self._lin_fwd(y1, Lk + "self_attention.in_proj_weight", Lk + "self_attention.in_proj_bias", qkv, M, 3 * D, D)
-            L.mha_fwd(qkv, None, ctx, lse, B, H, Tn, dh, dh ** -0.5, self.dt, self.attn_impl)
             if CLS_TAIL and i == s.layers - 1:
-                # class-token tail: rows b*Tn of ctx / x only (see CLS_TAIL above)
+                # class-token tail: the class-token query's attention, then rows b*Tn only (see CLS_TAIL above)
                 cb = lambda name, cols: fb(name + "_c", B, cols, i)
                 ctx_c, x_c = cb("ctx", D), cb("xin", D)
-                ctx_c[:B].copy_(ctx[:M].view(B, Tn, D)[:, 0]); x_c[:B].copy_(x[:M].view(B, Tn, D)[:, 0])
+                lse = self.buf("v_lse_c", 1, _round_up(B * H, ROWPAD), torch.float32, i if save else 0)
+                L.mha_cls_fwd(qkv, None, ctx_c, lse, B, H, Tn, dh, dh ** -0.5, self.dt)
+                x_c[:B].copy_(x[:M].view(B, Tn, D)[:, 0])
                 x1 = cb("x1", D)
                 self._lin_fwd(ctx_c, Lk + "self_attention.out_proj.weight", Lk + "self_attention.out_proj.bias", x1, B, D, D, addend=x_c)
                 y2, m2, r2 = cb("y2", D), stat("m2c", i), stat("r2c", i)
@@ -523,6 +525,7 @@ class MMRCAEngine:
                 mf, rf = stat("mf"), stat("rf")
                 self._ln_fwd(xn, None, P + "encoder.ln", None, feat, mf, rf, B, D, s.ln_eps)
                 return feat[:B], dict(B=B, patches=patches, xL=xn, mf=mf, rf=rf, layers=layers)
+            L.mha_fwd(qkv, None, ctx, lse, B, H, Tn, dh, dh ** -0.5, self.dt, self.attn_impl)
             x1 = fb("x1", M, D, i)
             self._lin_fwd(ctx, Lk + "self_attention.out_proj.weight", Lk + "self_attention.out_proj.bias", x1, M, D, D, addend=x)
             y2, m2, r2 = fb("y2", M, D, i), stat("m2", i), stat("r2", i)
@@ -610,12 +613,11 @@ class MMRCAEngine:
                       bias_done=True)
         # back to all rows: the attention mixes the class-token gradient into every key / value row, and the residual
         # stream carries it straight down at the class-token rows
-        dctx, dx1 = gb("dctx", M, D), gb("dxB", M, D)
-        dctx[:M].zero_(); dx1[:M].zero_()
-        dctx[:M].view(B, Tn, D)[:, 0] = dctx_c[:B]
+        dx1 = gb("dxB", M, D)
+        dx1[:M].zero_()
         dx1[:M].view(B, Tn, D)[:, 0] = dx1c[:B]
         dqkv = gb("dqkv", M, 3 * D)
-        L.mha_bwd(a["qkv"], None, a["ctx"], dctx, a["lse"], dqkv, B, H, Tn, dh, dh ** -0.5, self.dt, self.attn_impl)
+        L.mha_cls_bwd(a["qkv"], None, a["ctx_c"], dctx_c, a["lse"], dqkv, B, H, Tn, dh, dh ** -0.5, self.dt)
         dy1 = gb("dy", M, D)
         self._lin_bwd(dqkv, a["y1"], Lk + "self_attention.in_proj_weight", Lk + "self_attention.in_proj_bias", dy1, M, 3 * D, D)
         below = P + f"encoder.layers.encoder_layer_{i - 1}.mlp.3.bias"

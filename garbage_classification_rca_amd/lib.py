@@ -54,6 +54,8 @@ _SIGS = {
     "mmrca_gelu_bwd_colsum": [_vp, _vp, _vp, _vp, _i64, _i64, _i64, _i32, _vp],
     "mmrca_mha_fwd": [_vp] * 4 + [_i32] * 4 + [_f32, _f32, _u64, _i32, _i32, _vp],
     "mmrca_mha_bwd": [_vp] * 6 + [_i32] * 4 + [_f32, _f32, _u64, _i32, _i32, _vp],
+    "mmrca_mha_cls_fwd": [_vp] * 4 + [_i32] * 4 + [_f32, _f32, _u64, _i32, _vp],
+    "mmrca_mha_cls_bwd": [_vp] * 6 + [_i32] * 4 + [_f32, _f32, _u64, _i32, _vp],
     "mmrca_add_layernorm_fwd": [_vp] * 8 + [_i64, _i32, _i64, _i64, _f32, _f32, _u64, _f32, _u64, _i32, _vp],
     "mmrca_layernorm_bwd": [_vp] * 9 + [_i64, _i32, _i64, _i64, _i64, _f32, _u64, _f32, _u64, _vp, _vp, _vp, _i32, _vp],
     "mmrca_embed_fwd": [_vp] * 6 + [_i64, _i32, _i32, _vp],
@@ -163,6 +165,18 @@ def mha_fwd(qkv, key_mask, out, lse, B, H, S, dh, scale, dtype, impl=IMPL_AUTO, 
 def mha_bwd(qkv, key_mask, out, dout, lse, dqkv, B, H, S, dh, scale, dtype, impl=IMPL_AUTO, drop_p=0.0, drop_seed=0):
     _check(load().mmrca_mha_bwd(ptr(qkv), ptr(key_mask), ptr(out), ptr(dout), ptr(lse), ptr(dqkv), B, H, S, dh, scale,
                                 drop_p, drop_seed, dtype, impl, stream_ptr()), "mmrca_mha_bwd")
+
+
+def mha_cls_fwd(qkv, key_mask, out, lse, B, H, S, dh, scale, dtype, drop_p=0.0, drop_seed=0):
+    """attention of the class-token query (row 0) only: out [B, H*dh], lse [B, H]"""
+    _dev(qkv, "mha_cls qkv")
+    _check(load().mmrca_mha_cls_fwd(ptr(qkv), ptr(key_mask), ptr(out), ptr(lse), B, H, S, dh, scale, drop_p, drop_seed, dtype,
+                                    stream_ptr()), "mmrca_mha_cls_fwd")
+
+
+def mha_cls_bwd(qkv, key_mask, out, dout, lse, dqkv, B, H, S, dh, scale, dtype, drop_p=0.0, drop_seed=0):
+    _check(load().mmrca_mha_cls_bwd(ptr(qkv), ptr(key_mask), ptr(out), ptr(dout), ptr(lse), ptr(dqkv), B, H, S, dh, scale,
+                                    drop_p, drop_seed, dtype, stream_ptr()), "mmrca_mha_cls_bwd")
 
 
 def add_layernorm_fwd(x, res, gamma, beta, sum_out, y, mean, rstd, rows, D, ld_x, ld_y, eps, dtype,

@@ -77,6 +77,16 @@ int mmrca_mha_fwd(const void* qkv, const int32_t* key_mask, void* out, float* ls
 int mmrca_mha_bwd(const void* qkv, const int32_t* key_mask, const void* out, const void* dout, const float* lse,
                   void* dqkv, int B, int H, int S, int dh, float scale, float drop_p, uint64_t drop_seed,
                   int dtype, int impl, void* stream);
+/* K3c. The same attention for the class-token query only (row 0 of every sequence): what the LAST encoder layer needs,
+ * because the reference reads hidden_state[:, 0] (multimodal_model.py:352,517) / torchvision reads x[:, 0] and nothing else
+ * of that layer's output.  out / dout: [B, H*dh] (compact), lse: fp32 [B,H].  The backward fills the WHOLE fused dqkv
+ * buffer: dQ row 0, dK / dV of every key row, zeros in dQ rows >= 1.  Equal to row 0 of mmrca_mha_fwd, and to
+ * mmrca_mha_bwd with dout zero outside row 0 (same mask and dropout-counter semantics). */
+int mmrca_mha_cls_fwd(const void* qkv, const int32_t* key_mask, void* out, float* lse,
+                      int B, int H, int S, int dh, float scale, float drop_p, uint64_t drop_seed, int dtype, void* stream);
+int mmrca_mha_cls_bwd(const void* qkv, const int32_t* key_mask, const void* out, const void* dout, const float* lse,
+                      void* dqkv, int B, int H, int S, int dh, float scale, float drop_p, uint64_t drop_seed,
+                      int dtype, void* stream);
 
 /* K4. s = x (+ res);  y = LayerNorm(s) * gamma + beta.  sum_out (optional) receives s.  mean/rstd fp32 [rows].
  * Row r of x/res/sum_out/y starts at r*ld_* elements (lets the ViT final norm run on class tokens only).

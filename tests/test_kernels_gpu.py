@@ -387,6 +387,42 @@ def test_mha_fwd_bwd(dt, impl, S, masked):
     assert rel_err(dqkv, dref) < (2e-4 if dt == torch.float32 else 3e-2)
 
 
+@pytest.mark.parametrize("dt", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("S,dh,masked,p", [(64, 64, True, 0.0), (197, 64, False, 0.0), (40, 64, True, 0.1), (300, 32, False, 0.1)])
+def test_class_token_attention_equals_row0_of_full_attention(dt, S, dh, masked, p):
+    """mmrca_mha_cls_* = row 0 of the full kernels (forward), and the full backward fed a gradient that is zero
+    outside row 0 -- same masks, same dropout counters."""
+    B, H, seed = 3, 4, 99
+    qkv = dev(torch.randn(B * S, 3 * H * dh), dt)
+    mask = None
+    if masked:
+        mask = torch.ones(B, S, dtype=torch.int32)
+        mask[0, S // 2:] = 0
+        mask[2, :] = 0
+        mask = mask.cuda()
+    sc, code = 1 / math.sqrt(dh), L.dtype_code(dt)
+    out = torch.empty(B * S, H * dh, device="cuda", dtype=dt)
+    lse = torch.empty(B, H, S, device="cuda")
+    L.mha_fwd(qkv, mask, out, lse, B, H, S, dh, sc, code, L.IMPL_REF, drop_p=p, drop_seed=seed)
+    out_c = torch.empty(B, H * dh, device="cuda", dtype=dt)
+    lse_c = torch.empty(B, H, device="cuda")
+    L.mha_cls_fwd(qkv, mask, out_c, lse_c, B, H, S, dh, sc, code, drop_p=p, drop_seed=seed)
+    tol = 1e-5 if dt == torch.float32 else 1e-2
+    assert rel_err(out_c, out.view(B, S, H * dh)[:, 0]) < tol
+    fin = torch.isfinite(lse[:, :, 0])
+    assert torch.equal(fin, torch.isfinite(lse_c)) and rel_err(lse_c[fin], lse[:, :, 0][fin]) < 1e-5
+    dout_c = dev(torch.randn(B, H * dh), dt)
+    dout = torch.zeros(B * S, H * dh, device="cuda", dtype=dt)
+    dout.view(B, S, H * dh)[:, 0] = dout_c
+    dqkv = torch.zeros_like(qkv)
+    L.mha_bwd(qkv, mask, out, dout, lse, dqkv, B, H, S, dh, sc, code, L.IMPL_REF, drop_p=p, drop_seed=seed)
+    dqkv_c = torch.full_like(qkv, float("nan"))          # the class-token backward must write every element
+    L.mha_cls_bwd(qkv, mask, out_c, dout_c, lse_c, dqkv_c, B, H, S, dh, sc, code, drop_p=p, drop_seed=seed)
+    assert torch.isfinite(dqkv_c.float()).all()
+    assert rel_err(dqkv_c, dqkv) < (1e-4 if dt == torch.float32 else 2e-2)
+    assert float(dqkv_c.view(B, S, 3, H * dh)[:, 1:, 0].abs().max()) == 0.0
+
+
 # ------------------------------------------------------------------------------------------------------
 # train-mode dropout of the text encoder (counter-based masks shared by forward and backward)
 # ------------------------------------------------------------------------------------------------------
