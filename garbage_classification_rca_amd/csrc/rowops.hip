@@ -621,7 +621,8 @@ embed_fwd_k(const int32_t* __restrict__ ids, const int32_t* __restrict__ pos_ids
 template <typename T>
 __global__ void __launch_bounds__(256)
 embed_bwd_k(const T* __restrict__ dout, const int32_t* __restrict__ ids, const int32_t* __restrict__ pos_ids,
-            float* __restrict__ dword, float* __restrict__ dpos, float* __restrict__ dtype_row, int64_t rows, int D) {
+            float* __restrict__ dword, float* __restrict__ dpos, float* __restrict__ dtype_row, int64_t rows, int D,
+            int pad_id, int pos_pad_id) {
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   for (int64_t row = (int64_t)blockIdx.x * 4 + wave; row < rows; row += (int64_t)gridDim.x * 4) {
     const int64_t id = ids[row], p = pos_ids[row];
@@ -629,8 +630,8 @@ embed_bwd_k(const T* __restrict__ dout, const int32_t* __restrict__ ids, const i
       Vec4<T> d = Vec4<T>::load(dout + row * D + c);
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
-        if (dword) atomicAdd(dword + id * D + c + j, d.v[j]);
-        if (dpos) atomicAdd(dpos + p * D + c + j, d.v[j]);
+        if (dword && id != pad_id) atomicAdd(dword + id * D + c + j, d.v[j]);
+        if (dpos && p != pos_pad_id) atomicAdd(dpos + p * D + c + j, d.v[j]);
         if (dtype_row) atomicAdd(dtype_row + c + j, d.v[j]);
       }
     }
@@ -644,7 +645,8 @@ embed_bwd_k(const T* __restrict__ dout, const int32_t* __restrict__ ids, const i
 template <typename T>
 __global__ void __launch_bounds__(256)
 embed_bwd_acc_k(const T* __restrict__ dout, const int32_t* __restrict__ ids, const int32_t* __restrict__ pos_ids,
-                float* __restrict__ dword, float* __restrict__ dpos, float* __restrict__ dtype_row, int64_t rows, int D) {
+                float* __restrict__ dword, float* __restrict__ dpos, float* __restrict__ dtype_row, int64_t rows, int D,
+                int pad_id, int pos_pad_id) {
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   float at[4][4], ap[4][4];
 #pragma unroll
@@ -653,7 +655,9 @@ embed_bwd_acc_k(const T* __restrict__ dout, const int32_t* __restrict__ ids, con
     for (int j = 0; j < 4; ++j) { at[k][j] = 0.f; ap[k][j] = 0.f; }
   int64_t cur_p = -1;
   for (int64_t row = (int64_t)blockIdx.x * 4 + wave; row < rows; row += (int64_t)gridDim.x * 4) {
-    const int64_t id = ids[row], p = pos_ids[row];
+    const int64_t id = ids[row];
+    int64_t p = pos_ids[row];
+    if (p == pos_pad_id) p = -1;               // padding_idx of the position table (RoBERTa): that row takes no gradient
     if (dpos && p != cur_p) {                  // wave-uniform
       if (cur_p >= 0) {
 #pragma unroll
@@ -667,15 +671,29 @@ embed_bwd_acc_k(const T* __restrict__ dout, const int32_t* __restrict__ ids, con
       }
       cur_p = p;
     }
+    Vec4<T> d[4];
+    bool nz = false;
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
       const int c = lane * 4 + 256 * k;
       if (c < D) {
-        Vec4<T> d = Vec4<T>::load(dout + row * D + c);
+        d[k] = Vec4<T>::load(dout + row * D + c);
+        nz = nz || d[k].v[0] != 0.f || d[k].v[1] != 0.f || d[k].v[2] != 0.f || d[k].v[3] != 0.f;
+      }
+    }
+    // a row whose gradient is all zeros (masked positions under class-token pooling: most of a padded batch) adds
+    // nothing anywhere; skipping it also removes the worst same-address contention (thousands of [PAD] rows -> one row)
+    if (!__any(nz)) continue;
+    const bool word_on = dword && id != pad_id;  // nn.Embedding(padding_idx=pad_token_id): the pad row stays zero
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const int c = lane * 4 + 256 * k;
+      if (c < D) {
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-          if (dword) atomicAdd(dword + id * D + c + j, d.v[j]);
-          ap[k][j] += d.v[j]; at[k][j] += d.v[j];
+          if (word_on) atomicAdd(dword + id * D + c + j, d[k].v[j]);
+          if (cur_p >= 0) ap[k][j] += d[k].v[j];
+          at[k][j] += d[k].v[j];
         }
       }
     }
@@ -707,7 +725,7 @@ extern "C" int mmrca_embed_fwd(const int32_t* ids, const int32_t* pos_ids, const
 }
 
 extern "C" int mmrca_embed_bwd(const void* dout, const int32_t* ids, const int32_t* pos_ids, float* dword, float* dpos,
-                               float* dtype_row, int64_t rows, int D, int dtype, void* stream) {
+                               float* dtype_row, int64_t rows, int D, int pad_id, int pos_pad_id, int dtype, void* stream) {
   MMRCA_REQUIRE(dout && ids && pos_ids, "embed_bwd: null pointer");
   MMRCA_REQUIRE(D % 4 == 0, "embed_bwd: D must be a multiple of 4");
   if (rows <= 0) return 0;
@@ -715,14 +733,14 @@ extern "C" int mmrca_embed_bwd(const void* dout, const int32_t* ids, const int32
     const int g2 = (int)((rows + 3) / 4 < 256 ? (rows + 3) / 4 : 256);     // 1024 waves: row stride 1024
     MMRCA_DISPATCH_DTYPE(dtype, "embed_bwd",
       hipLaunchKernelGGL(embed_bwd_acc_k<T>, dim3(g2), dim3(256), 0, (hipStream_t)stream, (const T*)dout, ids, pos_ids,
-                         dword, dpos, dtype_row, rows, D);)
+                         dword, dpos, dtype_row, rows, D, pad_id, pos_pad_id);)
     MMRCA_CHECK_LAUNCH("embed_bwd");
     return 0;
   }
   const int grid = (int)((rows + 3) / 4 < 4096 ? (rows + 3) / 4 : 4096);
   MMRCA_DISPATCH_DTYPE(dtype, "embed_bwd",
     hipLaunchKernelGGL(embed_bwd_k<T>, dim3(grid), dim3(256), 0, (hipStream_t)stream, (const T*)dout, ids, pos_ids,
-                       dword, dpos, dtype_row, rows, D);)
+                       dword, dpos, dtype_row, rows, D, pad_id, pos_pad_id);)
   MMRCA_CHECK_LAUNCH("embed_bwd");
   return 0;
 }

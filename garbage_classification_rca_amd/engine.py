@@ -434,7 +434,8 @@ class MMRCAEngine:
                      dy_drop=(sv["drop_p"], self._site_seed(sv["drop_seed"], 0, 0)))
         dtype_row = self.Gflat(P + "embeddings.token_type_embeddings.weight", D) if s.type_vocab else None
         L.embed_bwd(ds0, sv["ids32"], sv["pos"], self.G(P + "embeddings.word_embeddings.weight"),
-                    self.G(P + "embeddings.position_embeddings.weight"), dtype_row, M, D, self.dt)
+                    self.G(P + "embeddings.position_embeddings.weight"), dtype_row, M, D, self.dt,
+                    pad_id=s.pad_id, pos_pad_id=(s.pad_id if s.pos_offset else -1))
         self._layer_boundary()
         self._ready("text_emb", flush=True)
 

@@ -59,7 +59,7 @@ _SIGS = {
     "mmrca_add_layernorm_fwd": [_vp] * 8 + [_i64, _i32, _i64, _i64, _f32, _f32, _u64, _f32, _u64, _i32, _vp],
     "mmrca_layernorm_bwd": [_vp] * 9 + [_i64, _i32, _i64, _i64, _i64, _f32, _u64, _f32, _u64, _vp, _vp, _vp, _i32, _vp],
     "mmrca_embed_fwd": [_vp] * 6 + [_i64, _i32, _i32, _vp],
-    "mmrca_embed_bwd": [_vp] * 6 + [_i64, _i32, _i32, _vp],
+    "mmrca_embed_bwd": [_vp] * 6 + [_i64, _i32, _i32, _i32, _i32, _vp],
     "mmrca_patchify_fwd": [_vp, _vp] + [_i32] * 6 + [_vp],
     "mmrca_vit_assemble_fwd": [_vp] * 4 + [_i32] * 4 + [_vp],
     "mmrca_vit_assemble_bwd": [_vp] * 4 + [_i32] * 4 + [_vp],
@@ -199,8 +199,9 @@ def embed_fwd(ids, pos_ids, word, pos, type_row, out, rows, D, dtype):
     _check(load().mmrca_embed_fwd(ptr(ids), ptr(pos_ids), ptr(word), ptr(pos), ptr(type_row), ptr(out), rows, D, dtype, stream_ptr()), "mmrca_embed_fwd")
 
 
-def embed_bwd(dout, ids, pos_ids, dword, dpos, dtype_row, rows, D, dtype):
-    _check(load().mmrca_embed_bwd(ptr(dout), ptr(ids), ptr(pos_ids), ptr(dword), ptr(dpos), ptr(dtype_row), rows, D, dtype, stream_ptr()), "mmrca_embed_bwd")
+def embed_bwd(dout, ids, pos_ids, dword, dpos, dtype_row, rows, D, dtype, pad_id=-1, pos_pad_id=-1):
+    _check(load().mmrca_embed_bwd(ptr(dout), ptr(ids), ptr(pos_ids), ptr(dword), ptr(dpos), ptr(dtype_row), rows, D,
+                                  pad_id, pos_pad_id, dtype, stream_ptr()), "mmrca_embed_bwd")
 
 
 def patchify_fwd(images, patches, B, Cc, Himg, Wimg, P, dtype):

@@ -114,8 +114,10 @@ int mmrca_layernorm_bwd(const void* dy, const void* s, const void* gamma, const 
  * BertEmbeddings; LayerNorm follows via mmrca_add_layernorm_fwd).  ids/pos_ids int32 [rows]. */
 int mmrca_embed_fwd(const int32_t* ids, const int32_t* pos_ids, const void* word, const void* pos,
                     const void* type_row, void* out, int64_t rows, int D, int dtype, void* stream);
+/* backward (fp32 tables, +=).  pad_id / pos_pad_id: nn.Embedding(padding_idx=pad_token_id) -- rows with ids[r] == pad_id add
+ * nothing to dword (all three HF encoders), rows with pos_ids[r] == pos_pad_id nothing to dpos (RoBERTa only); -1 = none. */
 int mmrca_embed_bwd(const void* dout, const int32_t* ids, const int32_t* pos_ids, float* dword, float* dpos,
-                    float* dtype_row, int64_t rows, int D, int dtype, void* stream);
+                    float* dtype_row, int64_t rows, int D, int pad_id, int pos_pad_id, int dtype, void* stream);
 
 /* K5b. ViT patch embedding (torchvision conv_proj 16x16/16 + class token + pos embedding).
  * patchify: images fp32 NCHW [B,3,H,W] -> rows [B*nP, 3*P*P] (k = c*P*P + py*P + px), nP=(H/P)*(W/P).

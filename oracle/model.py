@@ -99,8 +99,10 @@ class OracleTextEncoder(torch.nn.Module):
             pos = torch.cumsum(nonpad, dim=1) * nonpad + s.pad_id
         else:
             pos = torch.arange(T).unsqueeze(0).expand(B, T)
-        x = F.embedding(input_ids, self.P("embeddings.word_embeddings.weight")) + \
-            F.embedding(pos, self.P("embeddings.position_embeddings.weight"))
+        # nn.Embedding(..., padding_idx=pad_token_id) (modeling_distilbert.py Embeddings / BertEmbeddings / RobertaEmbeddings):
+        # the pad row never receives a gradient; RoBERTa's position table has the same padding_idx
+        x = F.embedding(input_ids, self.P("embeddings.word_embeddings.weight"), padding_idx=s.pad_id) + \
+            F.embedding(pos, self.P("embeddings.position_embeddings.weight"), padding_idx=(s.pad_id if s.pos_offset else None))
         if s.type_vocab:
             x = x + self.P("embeddings.token_type_embeddings.weight")[0]
         x = F.layer_norm(x, (s.dim,), self.P("embeddings.LayerNorm.weight"),

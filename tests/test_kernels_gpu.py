@@ -310,9 +310,16 @@ def test_embed_fwd_bwd(dt, rows, structured):
     assert rel_err(out, ref) < TOL[dt]
     dout = dev(torch.randn(rows, D), dt)
     dw, dp, dty = torch.zeros(V, D, device="cuda"), torch.zeros(Pn, D, device="cuda"), torch.zeros(D, device="cuda")
+    dout[3::7] = 0                      # all-zero gradient rows (masked positions) are skipped inside the kernel
     L.embed_bwd(dout, ids, pid, dw, dp, dty, rows, D, L.dtype_code(dt))
     rw = torch.zeros(V, D, device="cuda").index_add_(0, ids.long(), dout.float())
     rp = torch.zeros(Pn, D, device="cuda").index_add_(0, pid.long(), dout.float())
+    assert rel_err(dw, rw) < 1e-5 and rel_err(dp, rp) < 1e-5 and rel_err(dty, dout.float().sum(0)) < 1e-5
+    # padding_idx: the pad row of the word table (id 7 here) / of the position table (position 1) takes no gradient
+    dw.zero_(); dp.zero_(); dty.zero_()
+    L.embed_bwd(dout, ids, pid, dw, dp, dty, rows, D, L.dtype_code(dt), pad_id=7, pos_pad_id=1)
+    rw[7] = 0; rp[1] = 0
+    assert float(dw[7].abs().max()) == 0.0 and float(dp[1].abs().max()) == 0.0
     assert rel_err(dw, rw) < 1e-5 and rel_err(dp, rp) < 1e-5 and rel_err(dty, dout.float().sum(0)) < 1e-5
 
 

@@ -177,6 +177,13 @@ def test_text_encoders_match_transformers(name):
             np.testing.assert_allclose(gn, float(g[k]), rtol=3e-3, atol=2e-5)  # key-bias grads are 0 up to noise
             checked += 1
     assert checked >= 90
+    # padding_idx: with an all-ones mask the pad positions get a gradient, the pad ROW of the table must not
+    enc.zero_grad()
+    (enc(ids[:3], torch.ones_like(mask[:3]))[:, 0] * v[:3]).sum().backward()
+    for leaf in ("embeddings.word_embeddings.weight", "embeddings.position_embeddings.weight"):
+        gr = enc.P(leaf).grad.numpy().astype(np.float64)
+        np.testing.assert_allclose(np.linalg.norm(gr), float(g[f"enc_{name}_allones_gnorm/{leaf}"]), rtol=3e-3)
+        np.testing.assert_allclose(np.linalg.norm(gr[ts.pad_id]), float(g[f"enc_{name}_allones_padrow_gnorm/{leaf}"]), rtol=3e-3, atol=1e-9)
 
 
 def test_vit_matches_transformers_vit():
