@@ -89,6 +89,21 @@ __device__ __forceinline__ float gelu_fast_f(float x) {
   return x >= 0.f ? fmaf(-x, q, x) : x * q;
 }
 
+// the same, also returning gelu'(x) = Phi(x) + x phi(x) (shares the exponential)
+__device__ __forceinline__ float gelu_and_grad_fast_f(float x, float* grad) {
+  const float z = fabsf(x) * 0.70710678118654752f;
+  const float t = __builtin_amdgcn_rcpf(fmaf(0.3275911f, z, 1.0f));
+  float p = fmaf(t, 1.061405429f, -1.453152027f);
+  p = fmaf(p, t, 1.421413741f);
+  p = fmaf(p, t, -0.284496736f);
+  p = fmaf(p, t, 0.254829592f);
+  const float e = __builtin_amdgcn_exp2f(-1.4426950408889634f * z * z);     // exp(-x^2 / 2)
+  const float q = 0.5f * p * t * e;
+  const float Phi = x >= 0.f ? 1.0f - q : q;
+  *grad = fmaf(x * 0.3989422804014327f, e, Phi);
+  return x * Phi;
+}
+
 #define MMRCA_DISPATCH_DTYPE(dtype, NAME, ...)                               \
   if ((dtype) == MMRCA_F32) { typedef float T; __VA_ARGS__ }                 \
   else if ((dtype) == MMRCA_BF16) { typedef bf16_t T; __VA_ARGS__ }          \

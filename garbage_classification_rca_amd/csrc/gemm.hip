@@ -514,7 +514,7 @@ template <bool A_KROW, bool B_KROW, bool ATOMIC_F32, int WPE>
 __global__ void __launch_bounds__(256, WPE)
 gemm_mfma_k1s(const bf16_t* __restrict__ A, const bf16_t* __restrict__ B, void* __restrict__ Cv, const bf16_t* __restrict__ bias,
               const bf16_t* __restrict__ addend, bf16_t* __restrict__ preact, int64_t M, int64_t N, int64_t K,
-              int64_t lda, int64_t ldb, int64_t ldc, int act, int tiles_m, int tiles_n, int64_t ksplit_len) {
+              int64_t lda, int64_t ldb, int64_t ldc, int act, int tiles_m, int tiles_n, int64_t ksplit_len, float* __restrict__ colsum) {
   extern __shared__ __attribute__((aligned(16))) char smem[];   // ONE buffer: [A tile 16 KiB | B tile 16 KiB]
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
   const int wr = wave >> 1, wc = wave & 1;
@@ -587,11 +587,13 @@ gemm_mfma_k1s(const bf16_t* __restrict__ A, const bf16_t* __restrict__ B, void* 
 #pragma unroll
       for (int r = 0; r < 4; ++r) bv[r] = (float)b4[r];
     }
-    // the residual addend is fetched for the whole tile up front (16 x 8 B per lane, in the registers the operand
-    // fragments just vacated): in the model it is the residual stream, long evicted from L2/MALL by the time this GEMM
-    // runs, and loading it row by row inside the staged loop exposed one HBM round trip per pass
+    // the side operand of the epilogue -- the residual addend, or the saved gelu'(h) that ACT_MUL multiplies by -- is
+    // fetched for the whole tile up front (16 x 8 B per lane, in the registers the operand fragments just vacated): in
+    // the model it was written many kernels ago and is long gone from L2/MALL, and loading it row by row inside the
+    // staged loop exposed one HBM round trip per pass
     bf16x4 add4[4][4];
-    if (addend) {
+    const bf16_t* side = act == MMRCA_ACT_MUL ? preact : addend;
+    if (side) {
 #pragma unroll
       for (int i = 0; i < 4; ++i)
 #pragma unroll
@@ -599,9 +601,10 @@ gemm_mfma_k1s(const bf16_t* __restrict__ A, const bf16_t* __restrict__ B, void* 
           const int lrow = wave * 8 + rr * 2 + half;
           int64_t m = m_blk + (lrow >> 4) * 64 + i * 16 + (lrow & 15);
           if (m > M - 1) m = M - 1;
-          add4[i][rr] = *reinterpret_cast<const bf16x4*>(addend + m * ldc + ncol);
+          add4[i][rr] = *reinterpret_cast<const bf16x4*>(side + m * ldc + ncol);
         }
     }
+    float cs[4] = {0.f, 0.f, 0.f, 0.f};      // column sums of what this lane stores (colsum != nullptr)
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
 #pragma unroll
@@ -616,16 +619,15 @@ gemm_mfma_k1s(const bf16_t* __restrict__ A, const bf16_t* __restrict__ B, void* 
           const f32x4 c = *reinterpret_cast<const f32x4*>(smem + lrow * EP_STRIDE + l32 * 16);
           float v[4] = {c[0] + bv[0], c[1] + bv[1], c[2] + bv[2], c[3] + bv[3]};
           if (act == MMRCA_ACT_MUL) {
-            bf16x4 h4 = *reinterpret_cast<const bf16x4*>(preact + m * ldc + ncol);
 #pragma unroll
-            for (int r = 0; r < 4; ++r) v[r] *= (float)h4[r];
+            for (int r = 0; r < 4; ++r) v[r] *= (float)add4[i][rr][r];
           } else if (act == MMRCA_ACT_GELU_SAVE_GRAD) {
             bf16x4 o;
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-              const float e = erff(v[r] * 0.70710678118654752f);
-              o[r] = (bf16_t)(0.5f * (1.0f + e) + v[r] * 0.3989422804014327f * __expf(-0.5f * v[r] * v[r]));
-              v[r] = 0.5f * v[r] * (1.0f + e);
+              float dg;
+              v[r] = gelu_and_grad_fast_f(v[r], &dg);
+              o[r] = (bf16_t)dg;
             }
             *reinterpret_cast<bf16x4*>(preact + m * ldc + ncol) = o;
           } else if (act == MMRCA_ACT_GELU_BWD) {
@@ -643,16 +645,36 @@ gemm_mfma_k1s(const bf16_t* __restrict__ A, const bf16_t* __restrict__ B, void* 
             for (int r = 0; r < 4; ++r) v[r] = gelu_fast_f(v[r]);
           }
           if (addend) {
+            if (act == MMRCA_ACT_MUL) {       // (both side operands at once: the addend is read in place)
+              bf16x4 a4 = *reinterpret_cast<const bf16x4*>(addend + m * ldc + ncol);
 #pragma unroll
-            for (int r = 0; r < 4; ++r) v[r] += (float)add4[i][rr][r];
+              for (int r = 0; r < 4; ++r) v[r] += (float)a4[r];
+            } else {
+#pragma unroll
+              for (int r = 0; r < 4; ++r) v[r] += (float)add4[i][rr][r];
+            }
           }
           bf16x4 o;
 #pragma unroll
-          for (int r = 0; r < 4; ++r) o[r] = (bf16_t)v[r];
+          for (int r = 0; r < 4; ++r) { o[r] = (bf16_t)v[r]; cs[r] += (float)o[r]; }
           *reinterpret_cast<bf16x4*>(C + m * ldc + ncol) = o;
         }
       }
       __syncthreads();
+    }
+    if (colsum) {
+      // column sums of the stored tile (the bias gradient of the layer below, when this GEMM is its input gradient):
+      // 8 row groups (4 waves x 2 half-waves) -> LDS -> one atomic per column per block
+      float* red = reinterpret_cast<float*>(smem);
+#pragma unroll
+      for (int r = 0; r < 4; ++r) red[(wave * 2 + half) * 128 + l32 * 4 + r] = cs[r];
+      __syncthreads();
+      if (threadIdx.x < 128) {
+        float t = 0.f;
+#pragma unroll
+        for (int q = 0; q < 8; ++q) t += red[q * 128 + threadIdx.x];
+        atomicAdd(colsum + n_blk + threadIdx.x, t);
+      }
     }
   }
 }
@@ -660,10 +682,10 @@ gemm_mfma_k1s(const bf16_t* __restrict__ A, const bf16_t* __restrict__ B, void* 
 template <bool AK, bool BK2, bool AT, int WPE>
 static void launch_mfma1s(const void* A, const void* B, void* C, const void* bias, const void* addend, void* preact,
                           int64_t M, int64_t N, int64_t K, int64_t lda, int64_t ldb, int64_t ldc, int act, int tiles_m,
-                          int tiles_n, int ksplits, int64_t ksplit_len, hipStream_t st) {
+                          int tiles_n, int ksplits, int64_t ksplit_len, float* colsum, hipStream_t st) {
   hipLaunchKernelGGL((gemm_mfma_k1s<AK, BK2, AT, WPE>), dim3(tiles_m * tiles_n, ksplits), dim3(256), 2 * TILE_BYTES, st,
                      (const bf16_t*)A, (const bf16_t*)B, C, (const bf16_t*)bias, (const bf16_t*)addend, (bf16_t*)preact,
-                     M, N, K, lda, ldb, ldc, act, tiles_m, tiles_n, ksplit_len);
+                     M, N, K, lda, ldb, ldc, act, tiles_m, tiles_n, ksplit_len, colsum);
 }
 
 // ======================================================================================================
@@ -874,9 +896,11 @@ static void launch_mfma(const void* A, const void* B, void* C, const void* bias,
                      M, N, K, lda, ldb, ldc, act, tiles_m, tiles_n, ksplit_len, dbias);
 }
 
-extern "C" int mmrca_gemm(const void* A, const void* B, void* C, const void* bias, const void* addend, void* preact,
-                          int64_t M, int64_t N, int64_t K, int64_t lda, int64_t ldb, int64_t ldc,
-                          int a_layout, int b_layout, int act, int out_f32_accum, int dtype, int impl, void* stream) {
+// colsum_fused: honoured by the single-stage kernel only; *fused_done tells the caller whether it was
+static int gemm_dispatch(const void* A, const void* B, void* C, const void* bias, const void* addend, void* preact,
+                         int64_t M, int64_t N, int64_t K, int64_t lda, int64_t ldb, int64_t ldc,
+                         int a_layout, int b_layout, int act, int out_f32_accum, int dtype, int impl, void* stream,
+                         float* colsum_fused, bool* fused_done) {
   MMRCA_REQUIRE(A && B && C, "gemm: null operand");
   MMRCA_REQUIRE(M > 0 && N > 0 && K > 0, "gemm: bad shape M=%lld N=%lld K=%lld", (long long)M, (long long)N, (long long)K);
   MMRCA_REQUIRE((a_layout == MMRCA_ROWK || a_layout == MMRCA_KROW) && (b_layout == MMRCA_ROWK || b_layout == MMRCA_KROW), "gemm: bad layout");
@@ -941,7 +965,9 @@ extern "C" int mmrca_gemm(const void* A, const void* B, void* C, const void* bia
     }
     // (compiled for five waves per SIMD, <= 96 VGPRs, this kernel spills and runs 2-5x slower: four is the sweet spot)
     if ((impl == MMRCA_GEMM_MFMA_1STAGE || auto1s) && !(at && bias)) {
-#define L1S(AK_, BK_, AT_) launch_mfma1s<AK_, BK_, AT_, 4>(A, B, C, bias, addend, preact, M, N, K, lda, ldb, ldc, act, tiles_m, tiles_n, ksplits, ksplit_len, st)
+      float* cs1 = at ? nullptr : colsum_fused;
+      if (cs1 && fused_done) *fused_done = true;
+#define L1S(AK_, BK_, AT_) launch_mfma1s<AK_, BK_, AT_, 4>(A, B, C, bias, addend, preact, M, N, K, lda, ldb, ldc, act, tiles_m, tiles_n, ksplits, ksplit_len, cs1, st)
       if (!ak && !bk && !at) L1S(false, false, false);
       else if (!ak && bk && !at) L1S(false, true, false);
       else if (ak && !bk && !at) L1S(true, false, false);
@@ -1000,5 +1026,24 @@ extern "C" int mmrca_gemm(const void* A, const void* B, void* C, const void* bia
     hipLaunchKernelGGL(gemm_ref_k<T>, grid, dim3(256), 0, st, (const T*)A, (const T*)B, C, (const T*)bias, (const T*)addend,
                        (T*)preact, M, N, K, sam, sak, sbn, sbk, ldc, act, out_f32_accum);)
   MMRCA_CHECK_LAUNCH("gemm(ref)");
+  return 0;
+}
+
+extern "C" int mmrca_gemm(const void* A, const void* B, void* C, const void* bias, const void* addend, void* preact,
+                          int64_t M, int64_t N, int64_t K, int64_t lda, int64_t ldb, int64_t ldc,
+                          int a_layout, int b_layout, int act, int out_f32_accum, int dtype, int impl, void* stream) {
+  return gemm_dispatch(A, B, C, bias, addend, preact, M, N, K, lda, ldb, ldc, a_layout, b_layout, act, out_f32_accum, dtype,
+                       impl, stream, nullptr, nullptr);
+}
+
+extern "C" int mmrca_gemm_colsum(const void* A, const void* B, void* C, const void* bias, const void* addend, void* preact,
+                                 float* colsum, int64_t M, int64_t N, int64_t K, int64_t lda, int64_t ldb, int64_t ldc,
+                                 int a_layout, int b_layout, int act, int dtype, int impl, void* stream) {
+  MMRCA_REQUIRE(colsum, "gemm_colsum: null colsum");
+  bool done = false;
+  if (int rc = gemm_dispatch(A, B, C, bias, addend, preact, M, N, K, lda, ldb, ldc, a_layout, b_layout, act, 0, dtype, impl,
+                             stream, colsum, &done))
+    return rc;
+  if (!done) return mmrca_colsum_accum(C, colsum, M, N, ldc, dtype, stream);    // kernels without the fused sums: one more pass
   return 0;
 }

@@ -30,7 +30,7 @@ ALIGN = 64          # arena entries start on 256-byte boundaries
 # Epilogue fusions that exist in the kernels and are parity-tested, but measured net-neutral on MI355X at cfg 2 (the
 # fused work is exposed in the GEMM epilogue instead of overlapping in a bandwidth-bound pass): off by default.
 FUSE_BIAS_GRAD = os.environ.get("MMRCA_FUSE_BIAS", "0") == "1"
-FUSE_GELU_GRAD = os.environ.get("MMRCA_FUSE_GELU", "0") == "1"
+FUSE_GELU_GRAD = os.environ.get("MMRCA_FUSE_GELU", "1") == "1"
 # weight-gradient GEMMs on a second HIP stream, concurrent with the input-gradient chain of the same layer
 SIDE_STREAM_WGRAD = os.environ.get("MMRCA_SIDE_STREAM", "1") == "1"
 # text encoder and vision encoder are independent until the fusion head: run them on two streams
@@ -277,9 +277,10 @@ class MMRCAEngine:
         if dx is not None:
             w = self.W(wkey) if wnumel is None else self.Wflat(wkey, wnumel)
             fuse = gelu_h is not None and FUSE_GELU_GRAD
+            # fused: dh = (dy W) * gelu'(h) in the epilogue (h holds gelu' then) and the FFN1 bias gradient = its column sums
             L.gemm(dy, w, dx, addend=addend, preact=(gelu_h if fuse else None), M=M, N=K, K=N, lda=N, ldb=K, ldc=K,
                    a_layout=L.ROWK, b_layout=L.KROW, act=(L.ACT_MUL if fuse else L.ACT_NONE), dtype=self.dt,
-                   impl=self.gemm_impl)
+                   impl=self.gemm_impl, colsum=(gelu_db if fuse else None))
             if gelu_h is not None and not fuse:
                 if gelu_db is not None:     # dh = dg * gelu'(h) and the FFN1 bias gradient (column sums of dh) in one pass
                     L.gelu_bwd_colsum(dx, gelu_h, dx, gelu_db, M, K, K, self.dt)
@@ -412,9 +413,9 @@ class MMRCAEngine:
                          dcol=(None if df is not None else gb_f2), dcol_branch=(gb_f2 if df is not None else None))
             dg = gb("dF", Fd)
             self._lin_bwd(df if df is not None else ds2, a["g"], P + K["f2"] + ".weight", P + K["f2"] + ".bias", dg, M, D, Fd,
-                          gelu_h=a["h"], bias_done=True, gelu_db=(None if FUSE_GELU_GRAD else self.G(P + K["f1"] + ".bias")))
+                          gelu_h=a["h"], bias_done=True, gelu_db=self.G(P + K["f1"] + ".bias"))
             dx1 = gb("dxB", D)
-            self._lin_bwd(dg, a["x1"], P + K["f1"] + ".weight", P + K["f1"] + ".bias", dx1, M, Fd, D, addend=ds2, bias_done=not FUSE_GELU_GRAD)
+            self._lin_bwd(dg, a["x1"], P + K["f1"] + ".weight", P + K["f1"] + ".bias", dx1, M, Fd, D, addend=ds2, bias_done=True)
             ds1 = gb("ds1", D)
             datt = gb("dbr_att", D) if post_attn_drop > 0 else None
             self._ln_bwd(dx1, a["s1"], P + K["ln1"], a["m1"], a["r1"], None, ds1, M, D, branch_drop=(post_attn_drop, sd(i, 2)), dbranch=datt,
@@ -459,9 +460,9 @@ class MMRCAEngine:
                      dcol=(None if df is not None else gb_f2), dcol_branch=(gb_f2 if df is not None else None))
         dg = gc("dF", Fd)
         self._lin_bwd(df if df is not None else ds2, a["g"], P + K["f2"] + ".weight", P + K["f2"] + ".bias", dg, B, D, Fd,
-                      gelu_h=a["h"], bias_done=True, gelu_db=(None if FUSE_GELU_GRAD else self.G(P + K["f1"] + ".bias")))
+                      gelu_h=a["h"], bias_done=True, gelu_db=self.G(P + K["f1"] + ".bias"))
         dx1 = gc("dxB", D)
-        self._lin_bwd(dg, a["x1"], P + K["f1"] + ".weight", P + K["f1"] + ".bias", dx1, B, Fd, D, addend=ds2, bias_done=not FUSE_GELU_GRAD)
+        self._lin_bwd(dg, a["x1"], P + K["f1"] + ".weight", P + K["f1"] + ".bias", dx1, B, Fd, D, addend=ds2, bias_done=True)
         ds1 = gc("ds1", D)
         datt = gc("dbr_att", D) if post_attn_drop > 0 else None
         self._ln_bwd(dx1, a["s1"], P + K["ln1"], a["m1"], a["r1"], None, ds1, B, D, branch_drop=(post_attn_drop, sd(i, 2)), dbranch=datt,
@@ -569,9 +570,9 @@ class MMRCAEngine:
             Lk, a = P + f"encoder.layers.encoder_layer_{i}.", sv["layers"][i]
             dg = gb("dF", M, Fd)
             self._lin_bwd(dx, a["g"], Lk + "mlp.3.weight", Lk + "mlp.3.bias", dg, M, D, Fd, gelu_h=a["h"], bias_done=True,
-                          gelu_db=(None if FUSE_GELU_GRAD else self.G(Lk + "mlp.0.bias")))
+                          gelu_db=self.G(Lk + "mlp.0.bias"))
             dy2 = gb("dy", M, D)
-            self._lin_bwd(dg, a["y2"], Lk + "mlp.0.weight", Lk + "mlp.0.bias", dy2, M, Fd, D, bias_done=not FUSE_GELU_GRAD)
+            self._lin_bwd(dg, a["y2"], Lk + "mlp.0.weight", Lk + "mlp.0.bias", dy2, M, Fd, D, bias_done=True)
             dx1 = gb("dxB", M, D)
             self._ln_bwd(dy2, a["x1"], Lk + "ln_2", a["m2"], a["r2"], dx, dx1, M, D, dcol=self.G(Lk + "self_attention.out_proj.bias"))
             dctx = gb("dctx", M, D)
@@ -604,9 +605,9 @@ class MMRCAEngine:
         gc = lambda name, cols: self.buf("vg_" + name + "_c", B, cols)
         dg = gc("dF", Fd)
         self._lin_bwd(dxc, a["g"], Lk + "mlp.3.weight", Lk + "mlp.3.bias", dg, B, D, Fd, gelu_h=a["h"], bias_done=True,
-                      gelu_db=(None if FUSE_GELU_GRAD else self.G(Lk + "mlp.0.bias")))
+                      gelu_db=self.G(Lk + "mlp.0.bias"))
         dy2 = gc("dy", D)
-        self._lin_bwd(dg, a["y2"], Lk + "mlp.0.weight", Lk + "mlp.0.bias", dy2, B, Fd, D, bias_done=not FUSE_GELU_GRAD)
+        self._lin_bwd(dg, a["y2"], Lk + "mlp.0.weight", Lk + "mlp.0.bias", dy2, B, Fd, D, bias_done=True)
         dx1c = gc("dxB", D)
         self._ln_bwd(dy2, a["x1"], Lk + "ln_2", a["m2"], a["r2"], dxc, dx1c, B, D, dcol=self.G(Lk + "self_attention.out_proj.bias"))
         dctx_c = gc("dctx", D)

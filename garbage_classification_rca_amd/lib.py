@@ -49,6 +49,7 @@ _lib = None
 _i64, _i32, _f32, _vp, _u64 = C.c_int64, C.c_int, C.c_float, C.c_void_p, C.c_uint64
 _SIGS = {
     "mmrca_gemm": [_vp] * 6 + [_i64] * 6 + [_i32] * 6 + [_vp],
+    "mmrca_gemm_colsum": [_vp] * 7 + [_i64] * 6 + [_i32] * 5 + [_vp],
     "mmrca_colsum_accum": [_vp, _vp, _i64, _i64, _i64, _i32, _vp],
     "mmrca_gelu_bwd": [_vp, _vp, _vp, _i64, _i32, _vp],
     "mmrca_gelu_bwd_colsum": [_vp, _vp, _vp, _vp, _i64, _i64, _i64, _i32, _vp],
@@ -131,14 +132,21 @@ def gemm_is_mfma(M, N, K, a_layout, dtype, impl):
 
 
 def gemm(A, B, Cout, *, bias=None, addend=None, preact=None, M, N, K, lda, ldb, ldc, a_layout=ROWK, b_layout=ROWK,
-         act=ACT_NONE, accum=False, dtype, impl=IMPL_AUTO):
+         act=ACT_NONE, accum=False, dtype, impl=IMPL_AUTO, colsum=None):
+    """colsum (fp32 [N], +=): column sums of the stored C ride on the GEMM epilogue (mmrca_gemm_colsum)"""
     _dev(A, "gemm A")
     prof = GEMM_PROFILE is not None and gemm_is_mfma(M, N, K, a_layout, dtype, impl)
     if prof:
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
-    _check(load().mmrca_gemm(ptr(A), ptr(B), ptr(Cout), ptr(bias), ptr(addend), ptr(preact), M, N, K, lda, ldb, ldc,
-                             a_layout, b_layout, act, int(accum), dtype, impl, stream_ptr()), "mmrca_gemm")
+    if colsum is not None:
+        if accum:
+            raise MmrcaError("gemm: colsum is not available in accumulate mode")
+        _check(load().mmrca_gemm_colsum(ptr(A), ptr(B), ptr(Cout), ptr(bias), ptr(addend), ptr(preact), ptr(colsum), M, N, K,
+                                        lda, ldb, ldc, a_layout, b_layout, act, dtype, impl, stream_ptr()), "mmrca_gemm_colsum")
+    else:
+        _check(load().mmrca_gemm(ptr(A), ptr(B), ptr(Cout), ptr(bias), ptr(addend), ptr(preact), M, N, K, lda, ldb, ldc,
+                                 a_layout, b_layout, act, int(accum), dtype, impl, stream_ptr()), "mmrca_gemm")
     if prof:
         e1.record()
         GEMM_PROFILE.append((2.0 * M * N * K, (a_layout, b_layout, int(accum)), e0, e1, (M, N, K, act)))

@@ -56,6 +56,12 @@ int mmrca_debug_set(int flags);
 int mmrca_gemm(const void* A, const void* B, void* C, const void* bias, const void* addend, void* preact,
                int64_t M, int64_t N, int64_t K, int64_t lda, int64_t ldb, int64_t ldc,
                int a_layout, int b_layout, int act, int out_f32_accum, int dtype, int impl, void* stream);
+/* The same product (no accumulate mode) that also adds the column sums of the stored C to colsum[N] (fp32, +=): when C is an
+ * input gradient dX = dY W, these are the bias gradient of the layer that produced X (with act = MMRCA_ACT_MUL and
+ * preact = gelu'(h): the FFN1 bias gradient, so GELU backward and its bias reduction need no pass of their own). */
+int mmrca_gemm_colsum(const void* A, const void* B, void* C, const void* bias, const void* addend, void* preact,
+                      float* colsum, int64_t M, int64_t N, int64_t K, int64_t lda, int64_t ldb, int64_t ldc,
+                      int a_layout, int b_layout, int act, int dtype, int impl, void* stream);
 
 /* db[N] (fp32) += column sums of dY[M,N]  (bias gradients of every nn.Linear on the path). */
 int mmrca_colsum_accum(const void* dY, float* db, int64_t M, int64_t N, int64_t ld, int dtype, void* stream);

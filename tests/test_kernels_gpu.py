@@ -218,6 +218,29 @@ def test_gemm_fused_bias_gradient_and_gelu_backward(dt, impl):
     assert rel_err(dX2, (dYd[:M].double() @ W.double()) * Gp.double()) < TOL[dt]
 
 
+@pytest.mark.parametrize("dt,impl", [(torch.float32, L.IMPL_REF), (torch.bfloat16, L.IMPL_AUTO), (torch.bfloat16, L.IMPL_MFMA),
+                                     (torch.bfloat16, L.IMPL_MFMA_1STAGE)])
+def test_gemm_colsum_rides_on_the_input_gradient(dt, impl):
+    """mmrca_gemm_colsum: dH = (dY W) * gelu'(h) and db += column sums of the stored dH (ragged M, several row tiles)."""
+    M, N, K = 788, 384, 256            # dY [M,K], W [K,N] (KROW), C [M,N]
+    g = torch.Generator().manual_seed(5)
+    dY, W = dev(torch.randn(M, K, generator=g), dt), dev(torch.randn(K, N, generator=g) * 0.1, dt)
+    Gp, add = dev(torch.rand(M, N, generator=g), dt), dev(torch.randn(M, N, generator=g), dt)
+    for act, pre, addend in ((L.ACT_MUL, Gp, None), (L.ACT_NONE, None, add), (L.ACT_MUL, Gp, add)):
+        C = torch.empty(M, N, device="cuda", dtype=dt)
+        db = dev(torch.randn(N, generator=g))
+        db0 = db.clone()
+        L.gemm(dY, W, C, preact=pre, addend=addend, M=M, N=N, K=K, lda=K, ldb=N, ldc=N, a_layout=L.ROWK, b_layout=L.KROW,
+               act=act, dtype=L.dtype_code(dt), impl=impl, colsum=db)
+        ref = dY.double() @ W.double()
+        if act == L.ACT_MUL:
+            ref = ref * Gp.double()
+        if addend is not None:
+            ref = ref + add.double()
+        assert rel_err(C, ref) < TOL[dt]
+        assert rel_err(db - db0, C.float().sum(0)) < 1e-4          # sums of what was stored
+
+
 def test_gemm_rejects_bad_arguments():
     a = torch.zeros(4, 4, device="cuda")
     with pytest.raises(L.MmrcaError):
