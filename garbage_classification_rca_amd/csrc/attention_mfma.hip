@@ -83,17 +83,32 @@ __device__ __forceinline__ float attn_keep(float p, float sc, uint64_t seed, int
 __device__ __forceinline__ float colgroup_max(float x) { x = fmaxf(x, __shfl_xor(x, 16, 64)); return fmaxf(x, __shfl_xor(x, 32, 64)); }
 __device__ __forceinline__ float colgroup_sum(float x) { x += __shfl_xor(x, 16, 64); return x + __shfl_xor(x, 32, 64); }
 
+// key validity as an additive score bias in LDS: 0 for a live key, -inf for a masked or padded one.  (Testing
+// key_mask[] per score element cost a branch and a global load per element per query tile; the bias is one broadcast
+// ds_read_b128 per key tile and folds into the scale multiply as an fma.)
+__device__ __forceinline__ void stage_key_bias(float* kb, const int32_t* __restrict__ key_mask, int b, int S, int Spad) {
+  for (int key = threadIdx.x; key < Spad; key += blockDim.x)
+    kb[key] = (key < S && (!key_mask || key_mask[b * S + key] != 0)) ? 0.f : -INFINITY;
+}
+
+#define LOG2E 1.4426950408889634f
+#define LN2 0.6931471805599453f
+
 // ------------------------------------------------------------------------------------------------------
 // forward
 // ------------------------------------------------------------------------------------------------------
-template <int NKT>     // key tiles of 16 (Spad = 16*NKT, NKT even)
-__global__ void __launch_bounds__(256, 2)
+// NW waves per block share the two LDS images: LDS (2 x 28 KiB at S=197) allows two blocks per CU, so NW = 8 is what puts
+// four waves on every SIMD (the kernels are latency-bound on LDS reads between dependent MFMAs) and halves the number of
+// tiles a wave walks.
+template <int NKT, bool DROP, int NW>     // key tiles of 16 (Spad = 16*NKT, NKT even); DROP: attention-probability dropout compiled in
+__global__ void __launch_bounds__(64 * NW, NW / 2)
 mha_fwd_mfma_k(const bf16_t* __restrict__ qkv, const int32_t* __restrict__ key_mask, bf16_t* __restrict__ out,
                float* __restrict__ lse, int H, int S, float scale, float drop_p, uint64_t drop_seed) {
-  const float drop_sc = drop_p > 0.f ? 1.f / (1.f - drop_p) : 1.f;
+  const float drop_sc = DROP ? 1.f / (1.f - drop_p) : 1.f;
   extern __shared__ __attribute__((aligned(16))) char sm[];
   constexpr int Spad = NKT * 16;
   char* Kimg = sm; char* Vimg = sm + Spad * 128;
+  float* kb = reinterpret_cast<float*>(sm + 2 * Spad * 128);
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, g = lane >> 4, l16 = lane & 15;
   const int b = blockIdx.x / H, h = blockIdx.x % H;
   const int64_t ld = 3LL * H * AT_DH;
@@ -102,10 +117,11 @@ mha_fwd_mfma_k(const bf16_t* __restrict__ qkv, const int32_t* __restrict__ key_m
   const bf16_t* Vp = Kp + H * AT_DH;
   stage_rows(Kimg, IMG_ROW, Kp, ld, S, Spad);
   stage_rows(Vimg, IMG_TR, Vp, ld, S, Spad);
+  stage_key_bias(kb, key_mask, b, S, Spad);
   __syncthreads();
-  // per-lane key validity bits for keys 16kt + 4g + r
+  const float c1 = scale * LOG2E;                    // scores live in the exp2 domain
   const int nqt = (S + 15) / 16;
-  for (int qt = wave; qt < nqt; qt += 4) {
+  for (int qt = wave; qt < nqt; qt += NW) {
     const int q0 = qt * 16;
     bf16x8 qf0 = frag_global(Q, ld, q0, S, 0, lane), qf1 = frag_global(Q, ld, q0, S, 1, lane);
     f32x4 s[NKT];
@@ -115,15 +131,17 @@ mha_fwd_mfma_k(const bf16_t* __restrict__ qkv, const int32_t* __restrict__ key_m
       a = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_rows(Kimg, IMG_ROW, kt * 16, 0, lane), qf0, a, 0, 0, 0);
       a = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_rows(Kimg, IMG_ROW, kt * 16, 1, lane), qf1, a, 0, 0, 0);
       s[kt] = a;
+      // keep the scheduler from hoisting every K fragment of the row up front (it then needs > 128 VGPRs and spills);
+      // with four waves per SIMD the other waves cover this tile's LDS latency
+      if (NW > 4 && (kt & 1)) __builtin_amdgcn_sched_barrier(0);
     }
     float m = -INFINITY;
 #pragma unroll
     for (int kt = 0; kt < NKT; ++kt) {
+      const f32x4 bias = *reinterpret_cast<const f32x4*>(kb + kt * 16 + 4 * g);     // keys 16kt + 4g + r
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
-        const int key = kt * 16 + 4 * g + r;
-        const bool ok = key < S && (!key_mask || key_mask[b * S + key] != 0);
-        const float v = ok ? s[kt][r] * scale : -INFINITY;
+        const float v = fmaf(s[kt][r], c1, bias[r]);
         s[kt][r] = v;
         m = fmaxf(m, v);
       }
@@ -134,9 +152,9 @@ mha_fwd_mfma_k(const bf16_t* __restrict__ qkv, const int32_t* __restrict__ key_m
 #pragma unroll
     for (int kt = 0; kt < NKT; ++kt)
 #pragma unroll
-      for (int r = 0; r < 4; ++r) { const float e = __expf(s[kt][r] - msafe); s[kt][r] = e; l += e; }
+      for (int r = 0; r < 4; ++r) { const float e = __builtin_amdgcn_exp2f(s[kt][r] - msafe); s[kt][r] = e; l += e; }
     l = colgroup_sum(l);
-    if (drop_p > 0.f) {      // dropout acts on the normalised probabilities: mask the numerators, keep the denominator
+    if (DROP) {      // dropout acts on the normalised probabilities: mask the numerators, keep the denominator
 #pragma unroll
       for (int kt = 0; kt < NKT; ++kt)
 #pragma unroll
@@ -151,6 +169,7 @@ mha_fwd_mfma_k(const bf16_t* __restrict__ qkv, const int32_t* __restrict__ key_m
 #pragma unroll
       for (int dt = 0; dt < 4; ++dt)
         o[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_cols_tr(Vimg, u, dt, lane), pf, o[dt], 0, 0, 0);   // O^T[d][q]
+      if (NW > 4) __builtin_amdgcn_sched_barrier(0);
     }
     const int q = q0 + l16;
     if (q < S) {
@@ -163,7 +182,7 @@ mha_fwd_mfma_k(const bf16_t* __restrict__ qkv, const int32_t* __restrict__ key_m
         for (int r = 0; r < 4; ++r) v[r] = (bf16_t)(o[dt][r] * inv);
         *reinterpret_cast<bf16x4*>(orow + dt * 16 + 4 * g) = v;
       }
-      if (g == 0) lse[((int64_t)b * H + h) * S + q] = l > 0.f ? m + __logf(l) : INFINITY;
+      if (g == 0) lse[((int64_t)b * H + h) * S + q] = l > 0.f ? m * LN2 + __logf(l) : INFINITY;
     }
   }
 }
@@ -171,15 +190,16 @@ mha_fwd_mfma_k(const bf16_t* __restrict__ qkv, const int32_t* __restrict__ key_m
 // ------------------------------------------------------------------------------------------------------
 // backward, dQ: a wave owns 16 queries
 // ------------------------------------------------------------------------------------------------------
-template <int NKT>
-__global__ void __launch_bounds__(256, 2)
+template <int NKT, bool DROP, int NW>
+__global__ void __launch_bounds__(64 * NW, NW / 2)
 mha_bwd_dq_mfma_k(const bf16_t* __restrict__ qkv, const int32_t* __restrict__ key_mask, const bf16_t* __restrict__ out,
                   const bf16_t* __restrict__ dout, const float* __restrict__ lse, bf16_t* __restrict__ dqkv,
                   int H, int S, float scale, float drop_p, uint64_t drop_seed) {
-  const float drop_sc = drop_p > 0.f ? 1.f / (1.f - drop_p) : 1.f;
+  const float drop_sc = DROP ? 1.f / (1.f - drop_p) : 1.f;
   extern __shared__ __attribute__((aligned(16))) char sm[];
   constexpr int Spad = NKT * 16;
   char* Kimg = sm; char* Vimg = sm + Spad * 128;
+  float* kb = reinterpret_cast<float*>(sm + 2 * Spad * 128);
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, g = lane >> 4, l16 = lane & 15;
   const int b = blockIdx.x / H, h = blockIdx.x % H;
   const int64_t ld = 3LL * H * AT_DH, ldo = (int64_t)H * AT_DH;
@@ -190,9 +210,11 @@ mha_bwd_dq_mfma_k(const bf16_t* __restrict__ qkv, const int32_t* __restrict__ ke
   const bf16_t* dO = dout + (int64_t)b * S * ldo + h * AT_DH;
   stage_rows(Kimg, IMG_TR, Kp, ld, S, Spad);      // row reads for S^T (2-way), transposed reads for dQ^T
   stage_rows(Vimg, IMG_ROW, Vp, ld, S, Spad);     // row reads for dP^T
+  stage_key_bias(kb, key_mask, b, S, Spad);
   __syncthreads();
+  const float c1 = scale * LOG2E;
   const int nqt = (S + 15) / 16;
-  for (int qt = wave; qt < nqt; qt += 4) {
+  for (int qt = wave; qt < nqt; qt += NW) {
     const int q0 = qt * 16;
     const int q = q0 + l16;
     const bf16x8 qf0 = frag_global(Q, ld, q0, S, 0, lane), qf1 = frag_global(Q, ld, q0, S, 1, lane);
@@ -202,7 +224,7 @@ mha_bwd_dq_mfma_k(const bf16_t* __restrict__ qkv, const int32_t* __restrict__ ke
 #pragma unroll
     for (int j = 0; j < 8; ++j) dsum += (float)df0[j] * (float)of0[j] + (float)df1[j] * (float)of1[j];
     dsum = colgroup_sum(dsum);                       // D_q = rowsum(dO * O)
-    const float L = lse[((int64_t)b * H + h) * S + (q < S ? q : S - 1)];
+    const float L2 = lse[((int64_t)b * H + h) * S + (q < S ? q : S - 1)] * LOG2E;      // +inf for a fully masked query
     f32x4 dq[4];
 #pragma unroll
     for (int dt = 0; dt < 4; ++dt) dq[dt] = (f32x4){0.f, 0.f, 0.f, 0.f};
@@ -217,13 +239,12 @@ mha_bwd_dq_mfma_k(const bf16_t* __restrict__ qkv, const int32_t* __restrict__ ke
         s = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_rows(Kimg, IMG_TR, kt * 16, 1, lane), qf1, s, 0, 0, 0);
         dp = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_rows(Vimg, IMG_ROW, kt * 16, 0, lane), df0, dp, 0, 0, 0);
         dp = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_rows(Vimg, IMG_ROW, kt * 16, 1, lane), df1, dp, 0, 0, 0);
+        const f32x4 bias = *reinterpret_cast<const f32x4*>(kb + kt * 16 + 4 * g);
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-          const int key = kt * 16 + 4 * g + r;
-          const bool ok = key < S && (!key_mask || key_mask[b * S + key] != 0);
-          const float p = ok ? __expf(s[r] * scale - L) : 0.f;
-          const float keep = drop_p > 0.f ? attn_keep(drop_p, drop_sc, drop_seed, blockIdx.x, S, q, key) : 1.f;
-          ds2[hh][r] = p * (dp[r] * keep - dsum) * scale;
+          const float p = __builtin_amdgcn_exp2f(fmaf(s[r], c1, bias[r]) - L2);          // 0 for masked keys / queries
+          const float keep = DROP ? attn_keep(drop_p, drop_sc, drop_seed, blockIdx.x, S, q, kt * 16 + 4 * g + r) : 1.f;
+          ds2[hh][r] = p * (DROP ? dp[r] * keep - dsum : dp[r] - dsum);                   // (the score scale is applied to dQ below)
         }
       }
       const bf16x8 dsf = pack_pair(ds2[0], ds2[1]);
@@ -237,7 +258,7 @@ mha_bwd_dq_mfma_k(const bf16_t* __restrict__ qkv, const int32_t* __restrict__ ke
       for (int dt = 0; dt < 4; ++dt) {
         bf16x4 v;
 #pragma unroll
-        for (int r = 0; r < 4; ++r) v[r] = (bf16_t)dq[dt][r];
+        for (int r = 0; r < 4; ++r) v[r] = (bf16_t)(dq[dt][r] * scale);
         *reinterpret_cast<bf16x4*>(drow + dt * 16 + 4 * g) = v;
       }
     }
@@ -247,16 +268,16 @@ mha_bwd_dq_mfma_k(const bf16_t* __restrict__ qkv, const int32_t* __restrict__ ke
 // ------------------------------------------------------------------------------------------------------
 // backward, dK/dV: a wave owns 16 keys
 // ------------------------------------------------------------------------------------------------------
-template <int NKT>
-__global__ void __launch_bounds__(256, 2)
+template <int NKT, bool DROP, int NW>
+__global__ void __launch_bounds__(64 * NW, NW / 2)
 mha_bwd_dkv_mfma_k(const bf16_t* __restrict__ qkv, const int32_t* __restrict__ key_mask, const bf16_t* __restrict__ out,
                    const bf16_t* __restrict__ dout, const float* __restrict__ lse, bf16_t* __restrict__ dqkv,
                    int H, int S, float scale, float drop_p, uint64_t drop_seed) {
-  const float drop_sc = drop_p > 0.f ? 1.f / (1.f - drop_p) : 1.f;
+  const float drop_sc = DROP ? 1.f / (1.f - drop_p) : 1.f;
   extern __shared__ __attribute__((aligned(16))) char sm[];
   constexpr int Spad = NKT * 16;
   char* Qimg = sm; char* Dimg = sm + Spad * 128;
-  float* lse_s = reinterpret_cast<float*>(sm + 2 * Spad * 128);
+  float* lse_s = reinterpret_cast<float*>(sm + 2 * Spad * 128);     // log-sum-exp in the exp2 domain
   float* dsum_s = lse_s + Spad;
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, g = lane >> 4, l16 = lane & 15;
   const int b = blockIdx.x / H, h = blockIdx.x % H;
@@ -271,7 +292,7 @@ mha_bwd_dkv_mfma_k(const bf16_t* __restrict__ qkv, const int32_t* __restrict__ k
   for (int q = threadIdx.x; q < Spad; q += blockDim.x) {
     float a = 0.f, L = INFINITY;                 // padded query rows: lse=+inf -> P = 0
     if (q < S) {
-      L = lse[((int64_t)b * H + h) * S + q];
+      L = lse[((int64_t)b * H + h) * S + q] * LOG2E;
 #pragma unroll
       for (int c = 0; c < 8; ++c) {
         const bf16x8 x = *reinterpret_cast<const bf16x8*>(dO + (int64_t)q * ldo + c * 8);
@@ -283,11 +304,12 @@ mha_bwd_dkv_mfma_k(const bf16_t* __restrict__ qkv, const int32_t* __restrict__ k
     lse_s[q] = L; dsum_s[q] = a;
   }
   __syncthreads();
+  const float c1 = scale * LOG2E;
   const int nkt = (S + 15) / 16;
-  for (int kt = wave; kt < nkt; kt += 4) {
+  for (int kt = wave; kt < nkt; kt += NW) {
     const int k0 = kt * 16;
     const int key = k0 + l16;
-    const bool key_ok = key < S && (!key_mask || key_mask[b * S + key] != 0);
+    const float kbias = (key < S && (!key_mask || key_mask[b * S + key] != 0)) ? 0.f : -INFINITY;    // this lane's key
     const bf16x8 kf0 = frag_global(Kp, ld, k0, S, 0, lane), kf1 = frag_global(Kp, ld, k0, S, 1, lane);
     const bf16x8 vf0 = frag_global(Vp, ld, k0, S, 0, lane), vf1 = frag_global(Vp, ld, k0, S, 1, lane);
     f32x4 dk[4], dv[4];
@@ -304,13 +326,19 @@ mha_bwd_dkv_mfma_k(const bf16_t* __restrict__ qkv, const int32_t* __restrict__ k
         s = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_rows(Qimg, IMG_TR, qt * 16, 1, lane), kf1, s, 0, 0, 0);
         dp = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_rows(Dimg, IMG_TR, qt * 16, 0, lane), vf0, dp, 0, 0, 0);  // dP[q][key]
         dp = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_rows(Dimg, IMG_TR, qt * 16, 1, lane), vf1, dp, 0, 0, 0);
+        const f32x4 Lq = *reinterpret_cast<const f32x4*>(lse_s + qt * 16 + 4 * g);       // queries 16qt + 4g + r
+        const f32x4 Dq = *reinterpret_cast<const f32x4*>(dsum_s + qt * 16 + 4 * g);
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-          const int q = qt * 16 + 4 * g + r;
-          const float p = key_ok ? __expf(s[r] * scale - lse_s[q]) : 0.f;
-          const float keep = drop_p > 0.f ? attn_keep(drop_p, drop_sc, drop_seed, blockIdx.x, S, q, key) : 1.f;
-          p2[hh][r] = p * keep;
-          ds2[hh][r] = p * (dp[r] * keep - dsum_s[q]) * scale;
+          const float p = __builtin_amdgcn_exp2f(fmaf(s[r], c1, kbias) - Lq[r]);
+          if (DROP) {
+            const float keep = attn_keep(drop_p, drop_sc, drop_seed, blockIdx.x, S, qt * 16 + 4 * g + r, key);
+            p2[hh][r] = p * keep;
+            ds2[hh][r] = p * (dp[r] * keep - Dq[r]);
+          } else {
+            p2[hh][r] = p;
+            ds2[hh][r] = p * (dp[r] - Dq[r]);                                            // (score scale applied to dK below)
+          }
         }
       }
       const bf16x8 pf = pack_pair(p2[0], p2[1]), dsf = pack_pair(ds2[0], ds2[1]);
@@ -327,7 +355,7 @@ mha_bwd_dkv_mfma_k(const bf16_t* __restrict__ qkv, const int32_t* __restrict__ k
       for (int dt = 0; dt < 4; ++dt) {
         bf16x4 a, c;
 #pragma unroll
-        for (int r = 0; r < 4; ++r) { a[r] = (bf16_t)dk[dt][r]; c[r] = (bf16_t)dv[dt][r]; }
+        for (int r = 0; r < 4; ++r) { a[r] = (bf16_t)(dk[dt][r] * scale); c[r] = (bf16_t)dv[dt][r]; }
         *reinterpret_cast<bf16x4*>(krow + dt * 16 + 4 * g) = a;
         *reinterpret_cast<bf16x4*>(vrow + dt * 16 + 4 * g) = c;
       }
@@ -347,22 +375,38 @@ static int pick_nkt(int S) {
   return 32;
 }
 
-#define AT_LAUNCH(KERNEL, NKT, LDSBYTES, ...)                                                                        \
-  do {                                                                                                               \
-    (void)hipFuncSetAttribute((const void*)KERNEL<NKT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(LDSBYTES)); \
-    hipLaunchKernelGGL(KERNEL<NKT>, dim3(B * H), dim3(256), LDSBYTES, st, __VA_ARGS__);                               \
+#define AT_LAUNCH1(KERNEL, NKT, DROP, NW, LDSBYTES, ...)                                                                        \
+  do {                                                                                                                         \
+    (void)hipFuncSetAttribute((const void*)KERNEL<NKT, DROP, NW>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(LDSBYTES)); \
+    hipLaunchKernelGGL((KERNEL<NKT, DROP, NW>), dim3(B * H), dim3(64 * NW), LDSBYTES, st, __VA_ARGS__);                         \
+  } while (0)
+// small S: 4 waves.  S > 128: 8 waves when the kernel fits 128 VGPRs without spilling (W8_PLAIN / W8_DROP, per kernel)
+#define AT_LAUNCH4(KERNEL, NKT, LDSBYTES, ...)                                          \
+  do {                                                                                  \
+    if (drop_p > 0.f) AT_LAUNCH1(KERNEL, NKT, true, 4, LDSBYTES, __VA_ARGS__);          \
+    else AT_LAUNCH1(KERNEL, NKT, false, 4, LDSBYTES, __VA_ARGS__);                      \
+  } while (0)
+#define AT_LAUNCH8(KERNEL, NKT, W8_PLAIN, W8_DROP, LDSBYTES, ...)                       \
+  do {                                                                                  \
+    if (drop_p > 0.f) {                                                                 \
+      if (W8_DROP) AT_LAUNCH1(KERNEL, NKT, true, 8, LDSBYTES, __VA_ARGS__);             \
+      else AT_LAUNCH1(KERNEL, NKT, true, 4, LDSBYTES, __VA_ARGS__);                     \
+    } else {                                                                            \
+      if (W8_PLAIN) AT_LAUNCH1(KERNEL, NKT, false, 8, LDSBYTES, __VA_ARGS__);           \
+      else AT_LAUNCH1(KERNEL, NKT, false, 4, LDSBYTES, __VA_ARGS__);                    \
+    }                                                                                   \
   } while (0)
 
-#define AT_SWITCH(KERNEL, EXTRA, ...)                                                     \
-  switch (nkt) {                                                                           \
-    case 2: AT_LAUNCH(KERNEL, 2, 2 * 2 * 16 * 128 + EXTRA(2), __VA_ARGS__); break;         \
-    case 4: AT_LAUNCH(KERNEL, 4, 2 * 4 * 16 * 128 + EXTRA(4), __VA_ARGS__); break;         \
-    case 8: AT_LAUNCH(KERNEL, 8, 2 * 8 * 16 * 128 + EXTRA(8), __VA_ARGS__); break;         \
-    case 14: AT_LAUNCH(KERNEL, 14, 2 * 14 * 16 * 128 + EXTRA(14), __VA_ARGS__); break;     \
-    case 16: AT_LAUNCH(KERNEL, 16, 2 * 16 * 16 * 128 + EXTRA(16), __VA_ARGS__); break;     \
-    default: AT_LAUNCH(KERNEL, 32, 2 * 32 * 16 * 128 + EXTRA(32), __VA_ARGS__); break;     \
+#define AT_SWITCH(KERNEL, EXTRA, W8_PLAIN, W8_DROP, W8_32, ...)                                                   \
+  switch (nkt) {                                                                                                   \
+    case 2: AT_LAUNCH4(KERNEL, 2, 2 * 2 * 16 * 128 + EXTRA(2), __VA_ARGS__); break;                                \
+    case 4: AT_LAUNCH4(KERNEL, 4, 2 * 4 * 16 * 128 + EXTRA(4), __VA_ARGS__); break;                                \
+    case 8: AT_LAUNCH4(KERNEL, 8, 2 * 8 * 16 * 128 + EXTRA(8), __VA_ARGS__); break;                                \
+    case 14: AT_LAUNCH8(KERNEL, 14, W8_PLAIN, W8_DROP, 2 * 14 * 16 * 128 + EXTRA(14), __VA_ARGS__); break;         \
+    case 16: AT_LAUNCH8(KERNEL, 16, W8_PLAIN, W8_DROP, 2 * 16 * 16 * 128 + EXTRA(16), __VA_ARGS__); break;         \
+    default: AT_LAUNCH8(KERNEL, 32, (W8_PLAIN && W8_32), (W8_DROP && W8_32), 2 * 32 * 16 * 128 + EXTRA(32), __VA_ARGS__); break; \
   }
-#define NO_EXTRA(n) 0
+#define BIAS_EXTRA(n) ((n) * 16 * 4)
 #define STAT_EXTRA(n) (2 * (n) * 16 * 4)
 
 int mmrca_mha_fwd_mfma(const void* qkv, const int32_t* key_mask, void* out, float* lse, int B, int H, int S, int dh,
@@ -370,7 +414,7 @@ int mmrca_mha_fwd_mfma(const void* qkv, const int32_t* key_mask, void* out, floa
   (void)dh;
   MMRCA_REQUIRE((((uintptr_t)qkv) & 15) == 0 && (((uintptr_t)out) & 7) == 0, "mha_fwd: qkv must be 16-byte aligned");
   const int nkt = pick_nkt(S);
-  AT_SWITCH(mha_fwd_mfma_k, NO_EXTRA, (const bf16_t*)qkv, key_mask, (bf16_t*)out, lse, H, S, scale, drop_p, drop_seed);
+  AT_SWITCH(mha_fwd_mfma_k, BIAS_EXTRA, true, false, false, (const bf16_t*)qkv, key_mask, (bf16_t*)out, lse, H, S, scale, drop_p, drop_seed);
   MMRCA_CHECK_LAUNCH("mha_fwd(mfma)");
   return 0;
 }
@@ -381,8 +425,8 @@ int mmrca_mha_bwd_mfma(const void* qkv, const int32_t* key_mask, const void* out
   MMRCA_REQUIRE((((uintptr_t)qkv) & 15) == 0 && (((uintptr_t)out) & 15) == 0 && (((uintptr_t)dout) & 15) == 0 && (((uintptr_t)dqkv) & 7) == 0,
                 "mha_bwd: buffers must be 16-byte aligned");
   const int nkt = pick_nkt(S);
-  AT_SWITCH(mha_bwd_dq_mfma_k, NO_EXTRA, (const bf16_t*)qkv, key_mask, (const bf16_t*)out, (const bf16_t*)dout, lse, (bf16_t*)dqkv, H, S, scale, drop_p, drop_seed);
-  AT_SWITCH(mha_bwd_dkv_mfma_k, STAT_EXTRA, (const bf16_t*)qkv, key_mask, (const bf16_t*)out, (const bf16_t*)dout, lse, (bf16_t*)dqkv, H, S, scale, drop_p, drop_seed);
+  AT_SWITCH(mha_bwd_dq_mfma_k, BIAS_EXTRA, true, true, true, (const bf16_t*)qkv, key_mask, (const bf16_t*)out, (const bf16_t*)dout, lse, (bf16_t*)dqkv, H, S, scale, drop_p, drop_seed);
+  AT_SWITCH(mha_bwd_dkv_mfma_k, STAT_EXTRA, true, false, true, (const bf16_t*)qkv, key_mask, (const bf16_t*)out, (const bf16_t*)dout, lse, (bf16_t*)dqkv, H, S, scale, drop_p, drop_seed);
   MMRCA_CHECK_LAUNCH("mha_bwd(mfma)");
   return 0;
 }
