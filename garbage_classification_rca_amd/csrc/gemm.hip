@@ -126,6 +126,30 @@ __device__ __forceinline__ void stage_tile(const bf16_t* __restrict__ base, int6
   }
 }
 
+// the same with NI instructions per wave (an 8-wave block stages 256 rows with NI = 4, 128 rows / 64 k-rows with NI = 2)
+template <bool KROW, int NI>
+__device__ __forceinline__ void stage_tile_n(const bf16_t* __restrict__ base, int64_t ld, int64_t row0, int64_t rows_total,
+                                             int64_t k0, char* lds_tile, int wave, int lane) {
+#pragma unroll
+  for (int ii = 0; ii < NI; ++ii) {
+    const int i = wave * NI + ii;
+    const bf16_t* src;
+    if (!KROW) {
+      const int r = 8 * i + (lane >> 3);
+      const int c = (lane & 7) ^ ((r >> 1) & 7);
+      int64_t gr = row0 + r;
+      if (gr > rows_total - 1) gr = rows_total - 1;
+      src = base + gr * ld + k0 + c * 8;
+    } else {
+      const int kr = 4 * i + (lane >> 4);
+      const int chp = lane & 15;
+      const int c = ((((chp >> 1) ^ krow_f(kr))) << 1) | (chp & 1);
+      src = base + (k0 + kr) * ld + row0 + c * 8;
+    }
+    __builtin_amdgcn_global_load_lds((gbl_void*)src, (lds_void*)(lds_tile + i * 1024), 16, 0, 0);
+  }
+}
+
 // fragment of the 16 rows starting at tile-row `rb` (multiple of 16), k-step ks (32 contraction elements)
 template <bool KROW>
 __device__ __forceinline__ bf16x8 load_frag(const char* lds_tile, int rb, int ks, int lane) {
@@ -679,6 +703,176 @@ gemm_mfma_k1s(const bf16_t* __restrict__ A, const bf16_t* __restrict__ B, void* 
   }
 }
 
+// Tall single-stage variant: 256x128x64 block tile, EIGHT waves (4 x 2, each 64x64), 48 KiB of LDS, two blocks per CU.
+// Measured on the 128x128 kernel (halving its global->LDS staging gave +33%, halving its LDS fragment reads +1%): the
+// limiter is the per-CU vector-memory path that fills LDS -- 32 KiB per 128x128x64 step is 512 cycles at 64 B/clk, the same
+// as the step's MFMA time -- so the remedy is more flops per staged byte.  256x128 stages 48 KiB for twice the flops (0.75x
+// bytes per flop) and still keeps four waves on every SIMD.  A must be ROWK (forward and input-gradient GEMMs).
+template <bool B_KROW>
+__global__ void __launch_bounds__(512, 4)
+gemm_mfma_k1s_tall(const bf16_t* __restrict__ A, const bf16_t* __restrict__ B, void* __restrict__ Cv, const bf16_t* __restrict__ bias,
+              const bf16_t* __restrict__ addend, bf16_t* __restrict__ preact, int64_t M, int64_t N, int64_t K,
+              int64_t lda, int64_t ldb, int64_t ldc, int act, int tiles_m, int tiles_n, int64_t ksplit_len, float* __restrict__ colsum) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];   // ONE buffer: [A tile 256 rows, 32 KiB | B tile 16 KiB]
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
+  const int wr = wave >> 1, wc = wave & 1;
+  const int nwg = tiles_m * tiles_n;
+  const int orig = blockIdx.x;
+  const int q8 = nwg >> 3, r8 = nwg & 7, xcd = orig & 7;
+  const int wgid = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (orig >> 3);
+  const int GROUP = 8;
+  const int group = wgid / (GROUP * tiles_n);
+  const int first_m = group * GROUP;
+  const int gsize = (tiles_m - first_m) < GROUP ? (tiles_m - first_m) : GROUP;
+  const int tm = first_m + (wgid % (GROUP * tiles_n)) % gsize;
+  const int tn = (wgid % (GROUP * tiles_n)) / gsize;
+  const int64_t m_blk = (int64_t)tm * 256, n_blk = (int64_t)tn * GBN;
+  const int64_t kbeg = (int64_t)blockIdx.y * ksplit_len;
+  int64_t kend = kbeg + ksplit_len; if (kend > K) kend = K;
+  const int nt = (int)((kend - kbeg + GBK - 1) / GBK);
+
+  f32x4 acc[4][4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  for (int t = 0; t < nt; ++t) {
+    // single LDS stage: load -> wait -> barrier -> 32 MFMAs -> barrier; the load latency of this block is covered by the
+    // other three or four blocks resident on the CU (32 KiB of LDS each) instead of by software prefetch
+    stage_tile_n<false, 4>(A, lda, m_blk, M, kbeg + (int64_t)t * GBK, smem, wave, lane);                  // 32 x 1 KiB
+    stage_tile_n<B_KROW, 2>(B, ldb, n_blk, N, kbeg + (int64_t)t * GBK, smem + 2 * TILE_BYTES, wave, lane);  // 16 x 1 KiB
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+      bf16x8 af[4], bfr[4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) af[i] = load_frag<false>(smem, wr * 64 + i * 16, ks, lane);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) bfr[j] = load_frag<B_KROW>(smem + 2 * TILE_BYTES, wc * 64 + j * 16, ks, lane);
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr[j], af[i], acc[i][j], 0, 0, 0);
+        }
+    }
+    __syncthreads();
+  }
+  const int g = lane >> 4, l16 = lane & 15;
+  {
+    bf16_t* C = (bf16_t*)Cv;
+    constexpr int EP_STRIDE = 128 * 4 + 16;
+    const int half = lane >> 5, l32 = lane & 31;
+    const int64_t ncol = n_blk + l32 * 4;
+    float bv[4] = {0.f, 0.f, 0.f, 0.f};
+    if (bias) {
+      bf16x4 b4 = *reinterpret_cast<const bf16x4*>(bias + ncol);
+#pragma unroll
+      for (int r = 0; r < 4; ++r) bv[r] = (float)b4[r];
+    }
+    // the side operand of the epilogue -- the residual addend, or the saved gelu'(h) that ACT_MUL multiplies by -- is
+    // fetched for the whole tile up front (16 x 8 B per lane, in the registers the operand fragments just vacated): in
+    // the model it was written many kernels ago and is long gone from L2/MALL, and loading it row by row inside the
+    // staged loop exposed one HBM round trip per pass
+    bf16x4 add4[4][4];
+    const bf16_t* side = act == MMRCA_ACT_MUL ? preact : addend;
+    if (side) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int rr = 0; rr < 4; ++rr) {
+          const int lrow = wave * 8 + rr * 2 + half;
+          int64_t m = m_blk + (lrow >> 4) * 64 + i * 16 + (lrow & 15);
+          if (m > M - 1) m = M - 1;
+          add4[i][rr] = *reinterpret_cast<const bf16x4*>(side + m * ldc + ncol);
+        }
+    }
+    float cs[4] = {0.f, 0.f, 0.f, 0.f};      // column sums of what this lane stores (colsum != nullptr)
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+        *reinterpret_cast<f32x4*>(smem + (wr * 16 + l16) * EP_STRIDE + (wc * 64 + j * 16 + 4 * g) * 4) = acc[i][j];
+      __syncthreads();
+#pragma unroll
+      for (int rr = 0; rr < 4; ++rr) {
+        const int lrow = wave * 8 + rr * 2 + half;
+        const int64_t m = m_blk + (lrow >> 4) * 64 + i * 16 + (lrow & 15);
+        if (m < M) {
+          const f32x4 c = *reinterpret_cast<const f32x4*>(smem + lrow * EP_STRIDE + l32 * 16);
+          float v[4] = {c[0] + bv[0], c[1] + bv[1], c[2] + bv[2], c[3] + bv[3]};
+          if (act == MMRCA_ACT_MUL) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) v[r] *= (float)add4[i][rr][r];
+          } else if (act == MMRCA_ACT_GELU_SAVE_GRAD) {
+            bf16x4 o;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+              float dg;
+              v[r] = gelu_and_grad_fast_f(v[r], &dg);
+              o[r] = (bf16_t)dg;
+            }
+            *reinterpret_cast<bf16x4*>(preact + m * ldc + ncol) = o;
+          } else if (act == MMRCA_ACT_GELU_BWD) {
+            bf16x4 h4 = *reinterpret_cast<const bf16x4*>(preact + m * ldc + ncol);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) v[r] *= gelu_grad_f((float)h4[r]);
+          } else if (preact) {
+            bf16x4 o;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) o[r] = (bf16_t)v[r];
+            *reinterpret_cast<bf16x4*>(preact + m * ldc + ncol) = o;
+          }
+          if (act == MMRCA_ACT_GELU) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) v[r] = gelu_fast_f(v[r]);
+          }
+          if (addend) {
+            if (act == MMRCA_ACT_MUL) {       // (both side operands at once: the addend is read in place)
+              bf16x4 a4 = *reinterpret_cast<const bf16x4*>(addend + m * ldc + ncol);
+#pragma unroll
+              for (int r = 0; r < 4; ++r) v[r] += (float)a4[r];
+            } else {
+#pragma unroll
+              for (int r = 0; r < 4; ++r) v[r] += (float)add4[i][rr][r];
+            }
+          }
+          bf16x4 o;
+#pragma unroll
+          for (int r = 0; r < 4; ++r) { o[r] = (bf16_t)v[r]; cs[r] += (float)o[r]; }
+          *reinterpret_cast<bf16x4*>(C + m * ldc + ncol) = o;
+        }
+      }
+      __syncthreads();
+    }
+    if (colsum) {
+      // column sums of the stored tile (the bias gradient of the layer below, when this GEMM is its input gradient):
+      // 16 row groups (8 waves x 2 half-waves) -> LDS -> one atomic per column per block
+      float* red = reinterpret_cast<float*>(smem);
+#pragma unroll
+      for (int r = 0; r < 4; ++r) red[(wave * 2 + half) * 128 + l32 * 4 + r] = cs[r];
+      __syncthreads();
+      if (threadIdx.x < 128) {
+        float t = 0.f;
+#pragma unroll
+        for (int q = 0; q < 16; ++q) t += red[q * 128 + threadIdx.x];
+        atomicAdd(colsum + n_blk + threadIdx.x, t);
+      }
+    }
+  }
+}
+
+template <bool BK2>
+static void launch_mfma1s_tall(const void* A, const void* B, void* C, const void* bias, const void* addend, void* preact,
+                               int64_t M, int64_t N, int64_t K, int64_t lda, int64_t ldb, int64_t ldc, int act, int tiles_n,
+                               float* colsum, hipStream_t st) {
+  const int tiles_m = (int)((M + 255) / 256);
+  hipLaunchKernelGGL((gemm_mfma_k1s_tall<BK2>), dim3(tiles_m * tiles_n, 1), dim3(512), 3 * TILE_BYTES, st,
+                     (const bf16_t*)A, (const bf16_t*)B, C, (const bf16_t*)bias, (const bf16_t*)addend, (bf16_t*)preact,
+                     M, N, K, lda, ldb, ldc, act, tiles_m, tiles_n, K, colsum);
+}
+
 template <bool AK, bool BK2, bool AT, int WPE>
 static void launch_mfma1s(const void* A, const void* B, void* C, const void* bias, const void* addend, void* preact,
                           int64_t M, int64_t N, int64_t K, int64_t lda, int64_t ldb, int64_t ldc, int act, int tiles_m,
@@ -885,6 +1079,7 @@ int mmrca_gemm256(const void* A, const void* B, void* C, const void* bias, const
                   hipStream_t st);
 
 extern int g_mmrca_dbg;
+#define MMRCA_TALL_MIN_M (1LL << 60)   // AUTO threshold for the 256x128 kernel (off until measured)
 
 template <bool AK, bool BK2, bool AT, bool DB>
 static void launch_mfma(const void* A, const void* B, void* C, const void* bias, const void* addend, void* preact,
@@ -922,7 +1117,7 @@ static int gemm_dispatch(const void* A, const void* B, void* C, const void* bias
   // per CU is faster than the 256x256 kernel on every encoder shape, so AUTO never picks the large tile
   if (ok256 && impl == MMRCA_GEMM_MFMA256)
     return mmrca_gemm256(A, B, C, bias, addend, preact, M, N, K, lda, ldb, ldc, a_layout, b_layout, act, st);
-  if ((impl == MMRCA_GEMM_MFMA || impl == MMRCA_GEMM_MFMA_PERSIST || impl == MMRCA_GEMM_MFMA_BK32 || impl == MMRCA_GEMM_MFMA_1STAGE) && !ok_mfma)
+  if ((impl == MMRCA_GEMM_MFMA || impl == MMRCA_GEMM_MFMA_PERSIST || impl == MMRCA_GEMM_MFMA_BK32 || impl == MMRCA_GEMM_MFMA_1STAGE || impl == MMRCA_GEMM_MFMA_TALL) && !ok_mfma)
     return mmrca_fail(-3, "gemm: shape M=%lld N=%lld K=%lld dtype=%d does not qualify for the MFMA kernel", (long long)M, (long long)N, (long long)K, dtype);
   const bool use_mfma = ok_mfma && impl != MMRCA_GEMM_REF;   // 128x128 kernel
 
@@ -961,6 +1156,15 @@ static int gemm_dispatch(const void* A, const void* B, void* C, const void* bias
       else L32(true, true, true);
 #undef L32
       MMRCA_CHECK_LAUNCH("gemm(mfma,bk32)");
+      return 0;
+    }
+    if (impl == MMRCA_GEMM_MFMA_TALL && (at || ak))
+      return mmrca_fail(-3, "gemm: the 256x128 kernel needs a ROWK A operand and no accumulate mode");
+    if (impl == MMRCA_GEMM_MFMA_TALL || (auto1s && !ak && M >= MMRCA_TALL_MIN_M)) {
+      if (colsum_fused && fused_done) *fused_done = true;
+      if (bk) launch_mfma1s_tall<true>(A, B, C, bias, addend, preact, M, N, K, lda, ldb, ldc, act, tiles_n, colsum_fused, st);
+      else launch_mfma1s_tall<false>(A, B, C, bias, addend, preact, M, N, K, lda, ldb, ldc, act, tiles_n, colsum_fused, st);
+      MMRCA_CHECK_LAUNCH("gemm(mfma,256x128)");
       return 0;
     }
     // (compiled for five waves per SIMD, <= 96 VGPRs, this kernel spills and runs 2-5x slower: four is the sweet spot)

@@ -148,6 +148,16 @@ def test_gemm_single_stage_kernel(layouts):
     _gemm_case(768, 768, 788, 1, 1, torch.bfloat16, L.IMPL_MFMA_1STAGE, accum=True)
 
 
+@pytest.mark.parametrize("bl", [0, 1])
+def test_gemm_tall_kernel(bl):
+    """256x128x64 eight-wave kernel: ragged M (partial last row tile), one and several K steps, every epilogue."""
+    for M, N, K in ((300, 256, 64), (1000, 384, 192), (513, 128, 320)):
+        _gemm_case(M, N, K, 0, bl, torch.bfloat16, L.IMPL_MFMA_TALL, bias=True)
+    _gemm_case(700, 384, 256, 0, bl, torch.bfloat16, L.IMPL_MFMA_TALL, act=L.ACT_GELU, bias=True, addend=True, preact=True)
+    with pytest.raises(L.MmrcaError):
+        _gemm_case(768, 256, 128, 1, bl, torch.bfloat16, L.IMPL_MFMA_TALL)
+
+
 @pytest.mark.parametrize("layouts", [(0, 0), (0, 1), (1, 1), (1, 0)])
 def test_gemm_persistent_kernel(layouts):
     """Persistent 128x128 kernel (pipeline runs across tile boundaries): many more tiles than resident blocks, ragged M,
@@ -219,7 +229,7 @@ def test_gemm_fused_bias_gradient_and_gelu_backward(dt, impl):
 
 
 @pytest.mark.parametrize("dt,impl", [(torch.float32, L.IMPL_REF), (torch.bfloat16, L.IMPL_AUTO), (torch.bfloat16, L.IMPL_MFMA),
-                                     (torch.bfloat16, L.IMPL_MFMA_1STAGE)])
+                                     (torch.bfloat16, L.IMPL_MFMA_1STAGE), (torch.bfloat16, L.IMPL_MFMA_TALL)])
 def test_gemm_colsum_rides_on_the_input_gradient(dt, impl):
     """mmrca_gemm_colsum: dH = (dY W) * gelu'(h) and db += column sums of the stored dH (ragged M, several row tiles)."""
     M, N, K = 788, 384, 256            # dY [M,K], W [K,N] (KROW), C [M,N]

@@ -16,7 +16,7 @@ SHAPES = [  # (name, M, N, K, a_layout, b_layout, accum)
     ("epi out addend", M, 768, 768, 0, 0, 0), ("epi ffn2 addend", M, 768, 3072, 0, 0, 0),
     ("text fwd qkv", 16384, 2304, 768, 0, 0, 0), ("text fwd out", 16384, 768, 768, 0, 0, 0),
 ]
-impls = {"mfma128": L.IMPL_MFMA, "bk32": L.IMPL_MFMA_BK32, "1stage": L.IMPL_MFMA_1STAGE}
+impls = {"bk32": L.IMPL_MFMA_BK32, "1stage": L.IMPL_MFMA_1STAGE, "tall": L.IMPL_MFMA_TALL}
 DBG = [int(x) for x in os.environ.get("MMRCA_DBG", "0").split(",")]
 only = sys.argv[1:] 
 L.load()
@@ -47,6 +47,8 @@ for name, m, n, k, al, bl, acc in SHAPES:
     runs = {}
     for iname, impl, dbg in variants:
         if impl == L.IMPL_MFMA256 and (acc or n % 256 or (al == 1 and m % 256)):
+            continue
+        if impl == L.IMPL_MFMA_TALL and (acc or al == 1):
             continue
         def run(impl=impl, dbg=dbg):
             L.load().mmrca_debug_set(dbg)
