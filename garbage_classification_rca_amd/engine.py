@@ -27,12 +27,16 @@ from . import spec as S
 import os
 
 ALIGN = 64          # arena entries start on 256-byte boundaries
-# Epilogue fusions that exist in the kernels and are parity-tested, but measured net-neutral on MI355X at cfg 2 (the
-# fused work is exposed in the GEMM epilogue instead of overlapping in a bandwidth-bound pass): off by default.
+# Bias gradient as an extra ones-operand MFMA inside the weight-gradient GEMM: parity-tested, measured net-neutral
+# (conditional MFMAs disturb the main loop), off by default.
 FUSE_BIAS_GRAD = os.environ.get("MMRCA_FUSE_BIAS", "0") == "1"
+# GELU backward fused into the GEMMs: FFN1's forward epilogue stores gelu'(h) instead of h, FFN2's input-gradient
+# epilogue multiplies by it and emits the FFN1 bias gradient (column sums): +3.8 % end to end (no separate pass).
 FUSE_GELU_GRAD = os.environ.get("MMRCA_FUSE_GELU", "1") == "1"
-# weight-gradient GEMMs on a second HIP stream, concurrent with the input-gradient chain of the same layer
-SIDE_STREAM_WGRAD = os.environ.get("MMRCA_SIDE_STREAM", "1") == "1"
+# weight-gradient GEMMs on a second HIP stream, concurrent with the input-gradient chain of the same layer.  Helped
+# (+4 %) while the GEMMs left the chip half idle; with the current kernels two concurrent GEMMs only fight over LDS
+# slots and L2 (-4 %, same-box A/B), so it is off by default.
+SIDE_STREAM_WGRAD = os.environ.get("MMRCA_SIDE_STREAM", "0") == "1"
 # text encoder and vision encoder are independent until the fusion head: run them on two streams
 CONCURRENT_ENCODERS = os.environ.get("MMRCA_CONCURRENT_ENCODERS", "1") == "1"
 # Only the class-token row of each encoder's LAST layer reaches the head (reference: hidden_state[:, 0] /
