@@ -873,6 +873,184 @@ static void launch_mfma1s_tall(const void* A, const void* B, void* C, const void
                      M, N, K, lda, ldb, ldc, act, tiles_m, tiles_n, K, colsum);
 }
 
+// ======================================================================================================
+// 256x256x64 block tile, SIXTEEN waves (4 x 4, each 64x64), two 64-KiB LDS stages, one block per CU.
+// The 128x128 kernels sit at ~73 % of the aggregate L2->CU bandwidth (32 flop per staged byte, ~28 TB/s at 900 TFLOP/s),
+// where queueing makes the staging latency ~2 us; this tile halves the staged bytes per flop (64 flop/B) and keeps a full
+// 64-KiB stage in flight behind 2,048 MFMA cycles per SIMD.  Four waves per SIMD (<= 128 VGPRs) hide the LDS read latency
+// the way the small kernels do; one barrier per K step.  A must be ROWK, no accumulate mode, N % 256 == 0.
+// Measured: 880-920 TFLOP/s on the wide-output shapes (= the 128x128 single-stage kernel), 5-12 % slower on the N = 768
+// shapes (591 tiles = 2.3 rounds of 256 CUs).  With its staging AND its LDS fragment reads halved (timing experiment) it
+// only reaches 1.0-1.23 PFLOP/s: no single limiter is left to remove, so AUTO keeps the small kernel; selectable (impl 8).
+// ======================================================================================================
+#define W256_STAGE_BYTES (4 * TILE_BYTES)      // A 256 rows x 128 B (32 KiB) | B 32 KiB
+
+template <bool B_KROW>
+__device__ __forceinline__ void stage256(const bf16_t* __restrict__ A, const bf16_t* __restrict__ B, int64_t lda, int64_t ldb,
+                                         int64_t m_blk, int64_t n_blk, int64_t M, int64_t N, int64_t k0, char* st, int wave, int lane) {
+  stage_tile_n<false, 2>(A, lda, m_blk, M, k0, st, wave, lane);                                   // 32 x 1 KiB over 16 waves
+  if (!B_KROW) stage_tile_n<false, 2>(B, ldb, n_blk, N, k0, st + 2 * TILE_BYTES, wave, lane);
+  else stage_tile_n<true, 2>(B, ldb, n_blk + (wave >> 3) * 128, N, k0, st + 2 * TILE_BYTES + (wave >> 3) * TILE_BYTES, wave & 7, lane);
+}
+
+template <bool B_KROW>
+__global__ void __launch_bounds__(1024, 4)
+gemm_mfma_k256w(const bf16_t* __restrict__ A, const bf16_t* __restrict__ B, bf16_t* __restrict__ C, const bf16_t* __restrict__ bias,
+                const bf16_t* __restrict__ addend, bf16_t* __restrict__ preact, int64_t M, int64_t N, int64_t K,
+                int64_t lda, int64_t ldb, int64_t ldc, int act, int tiles_m, int tiles_n, float* __restrict__ colsum) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];   // [2 stages][A 32 KiB | B 32 KiB]
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
+  const int wr = wave >> 2, wc = wave & 3;
+  const int nwg = tiles_m * tiles_n;
+  const int orig = blockIdx.x;
+  const int q8 = nwg >> 3, r8 = nwg & 7, xcd = orig & 7;
+  const int wgid = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (orig >> 3);
+  const int GROUP = 8;
+  const int group = wgid / (GROUP * tiles_n);
+  const int first_m = group * GROUP;
+  const int gsize = (tiles_m - first_m) < GROUP ? (tiles_m - first_m) : GROUP;
+  const int tm = first_m + (wgid % (GROUP * tiles_n)) % gsize;
+  const int tn = (wgid % (GROUP * tiles_n)) / gsize;
+  const int64_t m_blk = (int64_t)tm * 256, n_blk = (int64_t)tn * 256;
+  const int nt = (int)((K + GBK - 1) / GBK);
+  // B fragments of this wave's 64 columns: ROWK image = rows of the 256-row B tile; KROW image = two 128-column sub-tiles
+  const int boff = 2 * TILE_BYTES + (B_KROW ? (wc >> 1) * TILE_BYTES : 0);
+  const int bcol = B_KROW ? (wc & 1) * 64 : wc * 64;
+
+  f32x4 acc[4][4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  stage256<B_KROW>(A, B, lda, ldb, m_blk, n_blk, M, N, 0, smem, wave, lane);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  for (int t = 0; t < nt; ++t) {
+    char* cur = smem + (t & 1) * W256_STAGE_BYTES;
+    char* nxt = smem + ((t + 1) & 1) * W256_STAGE_BYTES;
+    if (t + 1 < nt) stage256<B_KROW>(A, B, lda, ldb, m_blk, n_blk, M, N, (int64_t)(t + 1) * GBK, nxt, wave, lane);
+    const char* bt = cur + boff;
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+      bf16x8 af[4], bfr[4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) af[i] = load_frag<false>(cur, wr * 64 + i * 16, ks, lane);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) bfr[j] = load_frag<B_KROW>(bt, bcol + j * 16, ks, lane);
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr[j], af[i], acc[i][j], 0, 0, 0);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+  }
+  // ---------------- epilogue: 64 rows x 256 columns per pass through LDS (fp32), one whole row per wave instruction
+  const int g = lane >> 4, l16 = lane & 15;
+  constexpr int EP_STRIDE = 256 * 4 + 16;
+  const int64_t ncol = n_blk + lane * 4;
+  float bv[4] = {0.f, 0.f, 0.f, 0.f};
+  if (bias) {
+    bf16x4 b4 = *reinterpret_cast<const bf16x4*>(bias + ncol);
+#pragma unroll
+    for (int r = 0; r < 4; ++r) bv[r] = (float)b4[r];
+  }
+  bf16x4 add4[4][4];
+  const bf16_t* side = act == MMRCA_ACT_MUL ? preact : addend;
+  if (side) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int rr = 0; rr < 4; ++rr) {
+        const int lrow = rr * 16 + wave;
+        int64_t m = m_blk + (lrow >> 4) * 64 + i * 16 + (lrow & 15);
+        if (m > M - 1) m = M - 1;
+        add4[i][rr] = *reinterpret_cast<const bf16x4*>(side + m * ldc + ncol);
+      }
+  }
+  float cs[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+      *reinterpret_cast<f32x4*>(smem + (wr * 16 + l16) * EP_STRIDE + (wc * 64 + j * 16 + 4 * g) * 4) = acc[i][j];
+    __syncthreads();
+#pragma unroll
+    for (int rr = 0; rr < 4; ++rr) {
+      const int lrow = rr * 16 + wave;
+      const int64_t m = m_blk + (lrow >> 4) * 64 + i * 16 + (lrow & 15);
+      if (m < M) {
+        const f32x4 c = *reinterpret_cast<const f32x4*>(smem + lrow * EP_STRIDE + lane * 16);
+        float v[4] = {c[0] + bv[0], c[1] + bv[1], c[2] + bv[2], c[3] + bv[3]};
+        if (act == MMRCA_ACT_MUL) {
+#pragma unroll
+          for (int r = 0; r < 4; ++r) v[r] *= (float)add4[i][rr][r];
+        } else if (act == MMRCA_ACT_GELU_SAVE_GRAD) {
+          bf16x4 o;
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            float dg;
+            v[r] = gelu_and_grad_fast_f(v[r], &dg);
+            o[r] = (bf16_t)dg;
+          }
+          *reinterpret_cast<bf16x4*>(preact + m * ldc + ncol) = o;
+        } else if (act == MMRCA_ACT_GELU_BWD) {
+          bf16x4 h4 = *reinterpret_cast<const bf16x4*>(preact + m * ldc + ncol);
+#pragma unroll
+          for (int r = 0; r < 4; ++r) v[r] *= gelu_grad_f((float)h4[r]);
+        } else if (preact) {
+          bf16x4 o;
+#pragma unroll
+          for (int r = 0; r < 4; ++r) o[r] = (bf16_t)v[r];
+          *reinterpret_cast<bf16x4*>(preact + m * ldc + ncol) = o;
+        }
+        if (act == MMRCA_ACT_GELU) {
+#pragma unroll
+          for (int r = 0; r < 4; ++r) v[r] = gelu_fast_f(v[r]);
+        }
+        if (addend) {
+          if (act == MMRCA_ACT_MUL) {
+            bf16x4 a4 = *reinterpret_cast<const bf16x4*>(addend + m * ldc + ncol);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) v[r] += (float)a4[r];
+          } else {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) v[r] += (float)add4[i][rr][r];
+          }
+        }
+        bf16x4 o;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) { o[r] = (bf16_t)v[r]; cs[r] += (float)o[r]; }
+        *reinterpret_cast<bf16x4*>(C + m * ldc + ncol) = o;
+      }
+    }
+    __syncthreads();
+  }
+  if (colsum) {
+    float* red = reinterpret_cast<float*>(smem);          // [16 waves][256 columns]
+#pragma unroll
+    for (int r = 0; r < 4; ++r) red[wave * 256 + lane * 4 + r] = cs[r];
+    __syncthreads();
+    if (threadIdx.x < 256) {
+      float t = 0.f;
+#pragma unroll
+      for (int q = 0; q < 16; ++q) t += red[q * 256 + threadIdx.x];
+      atomicAdd(colsum + n_blk + threadIdx.x, t);
+    }
+  }
+}
+
+template <bool BK2>
+static void launch_mfma256w(const void* A, const void* B, void* C, const void* bias, const void* addend, void* preact,
+                            int64_t M, int64_t N, int64_t K, int64_t lda, int64_t ldb, int64_t ldc, int act, float* colsum,
+                            hipStream_t st) {
+  const int tiles_m = (int)((M + 255) / 256), tiles_n = (int)(N / 256);
+  (void)hipFuncSetAttribute((const void*)gemm_mfma_k256w<BK2>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * W256_STAGE_BYTES);
+  hipLaunchKernelGGL((gemm_mfma_k256w<BK2>), dim3(tiles_m * tiles_n), dim3(1024), 2 * W256_STAGE_BYTES, st,
+                     (const bf16_t*)A, (const bf16_t*)B, (bf16_t*)C, (const bf16_t*)bias, (const bf16_t*)addend, (bf16_t*)preact,
+                     M, N, K, lda, ldb, ldc, act, tiles_m, tiles_n, colsum);
+}
+
 template <bool AK, bool BK2, bool AT, int WPE>
 static void launch_mfma1s(const void* A, const void* B, void* C, const void* bias, const void* addend, void* preact,
                           int64_t M, int64_t N, int64_t K, int64_t lda, int64_t ldb, int64_t ldc, int act, int tiles_m,
@@ -1117,7 +1295,7 @@ static int gemm_dispatch(const void* A, const void* B, void* C, const void* bias
   // per CU is faster than the 256x256 kernel on every encoder shape, so AUTO never picks the large tile
   if (ok256 && impl == MMRCA_GEMM_MFMA256)
     return mmrca_gemm256(A, B, C, bias, addend, preact, M, N, K, lda, ldb, ldc, a_layout, b_layout, act, st);
-  if ((impl == MMRCA_GEMM_MFMA || impl == MMRCA_GEMM_MFMA_PERSIST || impl == MMRCA_GEMM_MFMA_BK32 || impl == MMRCA_GEMM_MFMA_1STAGE || impl == MMRCA_GEMM_MFMA_TALL) && !ok_mfma)
+  if ((impl == MMRCA_GEMM_MFMA || impl == MMRCA_GEMM_MFMA_PERSIST || impl == MMRCA_GEMM_MFMA_BK32 || impl == MMRCA_GEMM_MFMA_1STAGE || impl == MMRCA_GEMM_MFMA_TALL || impl == MMRCA_GEMM_MFMA_256W) && !ok_mfma)
     return mmrca_fail(-3, "gemm: shape M=%lld N=%lld K=%lld dtype=%d does not qualify for the MFMA kernel", (long long)M, (long long)N, (long long)K, dtype);
   const bool use_mfma = ok_mfma && impl != MMRCA_GEMM_REF;   // 128x128 kernel
 
@@ -1156,6 +1334,15 @@ static int gemm_dispatch(const void* A, const void* B, void* C, const void* bias
       else L32(true, true, true);
 #undef L32
       MMRCA_CHECK_LAUNCH("gemm(mfma,bk32)");
+      return 0;
+    }
+    if (impl == MMRCA_GEMM_MFMA_256W && (at || ak || N % 256 != 0))
+      return mmrca_fail(-3, "gemm: the 16-wave 256x256 kernel needs a ROWK A operand, N %% 256 == 0 and no accumulate mode");
+    if (impl == MMRCA_GEMM_MFMA_256W) {
+      if (colsum_fused && fused_done) *fused_done = true;
+      if (bk) launch_mfma256w<true>(A, B, C, bias, addend, preact, M, N, K, lda, ldb, ldc, act, colsum_fused, st);
+      else launch_mfma256w<false>(A, B, C, bias, addend, preact, M, N, K, lda, ldb, ldc, act, colsum_fused, st);
+      MMRCA_CHECK_LAUNCH("gemm(mfma,256x256,16 waves)");
       return 0;
     }
     if (impl == MMRCA_GEMM_MFMA_TALL && (at || ak))

@@ -149,6 +149,16 @@ def test_gemm_single_stage_kernel(layouts):
 
 
 @pytest.mark.parametrize("bl", [0, 1])
+def test_gemm_256x256_sixteen_wave_kernel(bl):
+    """256x256x64 sixteen-wave kernel: ragged M, one / odd / many K steps, every epilogue."""
+    for M, N, K in ((300, 256, 64), (1000, 512, 192), (513, 256, 320)):
+        _gemm_case(M, N, K, 0, bl, torch.bfloat16, L.IMPL_MFMA_256W, bias=True)
+    _gemm_case(700, 512, 256, 0, bl, torch.bfloat16, L.IMPL_MFMA_256W, act=L.ACT_GELU, bias=True, addend=True, preact=True)
+    with pytest.raises(L.MmrcaError):
+        _gemm_case(512, 384, 128, 0, bl, torch.bfloat16, L.IMPL_MFMA_256W)
+
+
+@pytest.mark.parametrize("bl", [0, 1])
 def test_gemm_tall_kernel(bl):
     """256x128x64 eight-wave kernel: ragged M (partial last row tile), one and several K steps, every epilogue."""
     for M, N, K in ((300, 256, 64), (1000, 384, 192), (513, 128, 320)):
@@ -229,10 +239,10 @@ def test_gemm_fused_bias_gradient_and_gelu_backward(dt, impl):
 
 
 @pytest.mark.parametrize("dt,impl", [(torch.float32, L.IMPL_REF), (torch.bfloat16, L.IMPL_AUTO), (torch.bfloat16, L.IMPL_MFMA),
-                                     (torch.bfloat16, L.IMPL_MFMA_1STAGE), (torch.bfloat16, L.IMPL_MFMA_TALL)])
+                                     (torch.bfloat16, L.IMPL_MFMA_1STAGE), (torch.bfloat16, L.IMPL_MFMA_TALL), (torch.bfloat16, L.IMPL_MFMA_256W)])
 def test_gemm_colsum_rides_on_the_input_gradient(dt, impl):
     """mmrca_gemm_colsum: dH = (dY W) * gelu'(h) and db += column sums of the stored dH (ragged M, several row tiles)."""
-    M, N, K = 788, 384, 256            # dY [M,K], W [K,N] (KROW), C [M,N]
+    M, N, K = 788, (512 if impl == L.IMPL_MFMA_256W else 384), 256            # dY [M,K], W [K,N] (KROW), C [M,N]
     g = torch.Generator().manual_seed(5)
     dY, W = dev(torch.randn(M, K, generator=g), dt), dev(torch.randn(K, N, generator=g) * 0.1, dt)
     Gp, add = dev(torch.rand(M, N, generator=g), dt), dev(torch.randn(M, N, generator=g), dt)

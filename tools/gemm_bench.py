@@ -16,7 +16,7 @@ SHAPES = [  # (name, M, N, K, a_layout, b_layout, accum)
     ("epi out addend", M, 768, 768, 0, 0, 0), ("epi ffn2 addend", M, 768, 3072, 0, 0, 0),
     ("text fwd qkv", 16384, 2304, 768, 0, 0, 0), ("text fwd out", 16384, 768, 768, 0, 0, 0),
 ]
-impls = {"bk32": L.IMPL_MFMA_BK32, "1stage": L.IMPL_MFMA_1STAGE, "tall": L.IMPL_MFMA_TALL}
+impls = {"1stage": L.IMPL_MFMA_1STAGE, "256w": L.IMPL_MFMA_256W}
 DBG = [int(x) for x in os.environ.get("MMRCA_DBG", "0").split(",")]
 only = sys.argv[1:] 
 L.load()
@@ -40,7 +40,7 @@ for name, m, n, k, al, bl, acc in SHAPES:
     epi = dict(preact=torch.empty(Mp, n, device=dev, dtype=torch.bfloat16) if "preact" in name else None,
                addend=torch.randn(Mp, n, device=dev).bfloat16() if "addend" in name else None,
                act=L.ACT_GELU if "gelu" in name else L.ACT_NONE)
-    variants = [(a, b, 0) for a, b in impls.items()] + [(f"256dbg{d}", L.IMPL_MFMA256, d) for d in DBG if d and d < 256]
+    variants = [(a, b, 0) for a, b in impls.items()] + [(f"256dbg{d}", L.IMPL_MFMA256, d) for d in DBG if d >= 8 and d < 256 and d != 16]
     variants += [(f"128tgt{d >> 8}", L.IMPL_MFMA, d) for d in DBG if d >= 256]
     variants += [(f"128dbg{d}", L.IMPL_MFMA, d) for d in DBG if d == 16]
     variants += [(f"bk32tgt{d >> 8}", L.IMPL_MFMA_BK32, d) for d in DBG if d >= 256]
@@ -48,7 +48,7 @@ for name, m, n, k, al, bl, acc in SHAPES:
     for iname, impl, dbg in variants:
         if impl == L.IMPL_MFMA256 and (acc or n % 256 or (al == 1 and m % 256)):
             continue
-        if impl == L.IMPL_MFMA_TALL and (acc or al == 1):
+        if impl in (L.IMPL_MFMA_TALL, L.IMPL_MFMA_256W) and (acc or al == 1 or (impl == L.IMPL_MFMA_256W and n % 256)):
             continue
         def run(impl=impl, dbg=dbg):
             L.load().mmrca_debug_set(dbg)
