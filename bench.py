@@ -215,10 +215,12 @@ def main():
                        "host_enqueue_ms_per_step": round(host_enqueue / args.steps * 1e3, 2)},
             "roofline": {"bound": "mfma", "achieved": round(achieved, 2), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
                          "frac": round(achieved / PEAK_BF16_TFLOPS, 4), "traffic": None,
-                         "kernel": "gemm_mfma_k (bf16 16x16x32 MFMA GEMM; all nn.Linear fwd/dgrad/wgrad)",
+                         "kernel": "gemm_mfma_k1s / gemm_mfma_k32 (bf16 16x16x32 MFMA GEMM, 128x128 tiles; every nn.Linear fwd/dgrad/wgrad)",
                          "launches_per_step": len(prof) // replay, "gemm_ms_per_step": round(ms / replay, 3),
                          "measured_in": f"single-stream replay of {replay} steps after the timed region ({round(serial_ms, 2)} ms/step serialized)",
                          "by_layout_TFLOPs": {f"a{k[0]}b{k[1]}acc{k[2]}": round(v[0] / (v[1] * 1e-3) / 1e12, 1) for k, v in by_kind.items() if v[1] > 0},
+                         "flops_counted": "achieved = executed 2MNK of the GEMM launches; whole_step_* = nominal 3x forward model FLOPs "
+                                          "(the class-token tail executes ~5% fewer)",
                          "whole_step_model_TFLOPs": round(value / world * train_flop_per_sample / 1e12, 2),
                          "whole_step_frac": round(value / world * train_flop_per_sample / 1e12 / PEAK_BF16_TFLOPS, 4)},
         }

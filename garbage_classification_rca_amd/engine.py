@@ -428,10 +428,13 @@ class MMRCAEngine:
             self._lin_bwd(datt if datt is not None else ds1, a["ctx"], P + K["o"] + ".weight", P + K["o"] + ".bias", dctx, M, D, D,
                           bias_done=True)
             dqkv = gb("dqkv", 3 * D)
+            # the attention backward also reduces the q|k|v bias gradients (adjacent in the arena) while it has the tiles
+            qkv_db = None if FUSE_BIAS_GRAD else self.Gflat(P + K["q"] + ".bias", 3 * D)
             L.mha_bwd(a["qkv"], sv["mask32"], a["ctx"], dctx, a["lse"], dqkv, B, H, T, dh, dh ** -0.5, self.dt, self.attn_impl,
-                      drop_p=dp, drop_seed=sd(i, 1))
+                      drop_p=dp, drop_seed=sd(i, 1), colsum=qkv_db)
             self._wait_first_wgrad()       # (the FFN2 weight gradient does not read dx in the post-LN layout; harmless)
-            self._lin_bwd(dqkv, a["x"], P + K["q"] + ".weight", P + K["q"] + ".bias", dx, M, 3 * D, D, addend=ds1, wnumel=3 * D * D)
+            self._lin_bwd(dqkv, a["x"], P + K["q"] + ".weight", P + K["q"] + ".bias", dx, M, 3 * D, D, addend=ds1, wnumel=3 * D * D,
+                          bias_done=qkv_db is not None)
             self._layer_boundary()
             self._ready(f"text_layer_{i}")
         ds0 = gb("ds2", D)
@@ -583,9 +586,11 @@ class MMRCAEngine:
             self._lin_bwd(dx1, a["ctx"], Lk + "self_attention.out_proj.weight", Lk + "self_attention.out_proj.bias", dctx, M, D, D,
                           bias_done=True)
             dqkv = gb("dqkv", M, 3 * D)
-            L.mha_bwd(a["qkv"], None, a["ctx"], dctx, a["lse"], dqkv, B, H, Tn, dh, dh ** -0.5, self.dt, self.attn_impl)
+            qkv_db = None if FUSE_BIAS_GRAD else self.G(Lk + "self_attention.in_proj_bias")
+            L.mha_bwd(a["qkv"], None, a["ctx"], dctx, a["lse"], dqkv, B, H, Tn, dh, dh ** -0.5, self.dt, self.attn_impl, colsum=qkv_db)
             dy1 = gb("dy", M, D)
-            self._lin_bwd(dqkv, a["y1"], Lk + "self_attention.in_proj_weight", Lk + "self_attention.in_proj_bias", dy1, M, 3 * D, D)
+            self._lin_bwd(dqkv, a["y1"], Lk + "self_attention.in_proj_weight", Lk + "self_attention.in_proj_bias", dy1, M, 3 * D, D,
+                          bias_done=qkv_db is not None)
             self._wait_first_wgrad()       # mlp.3's weight gradient (side stream) reads dx; this op overwrites it
             below = P + f"encoder.layers.encoder_layer_{i - 1}.mlp.3.bias"
             self._ln_bwd(dy1, a["x"], Lk + "ln_1", a["m1"], a["r1"], dx1, dx, M, D, dcol=(self.G(below) if i > 0 else None))

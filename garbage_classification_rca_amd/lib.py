@@ -55,6 +55,7 @@ _SIGS = {
     "mmrca_gelu_bwd_colsum": [_vp, _vp, _vp, _vp, _i64, _i64, _i64, _i32, _vp],
     "mmrca_mha_fwd": [_vp] * 4 + [_i32] * 4 + [_f32, _f32, _u64, _i32, _i32, _vp],
     "mmrca_mha_bwd": [_vp] * 6 + [_i32] * 4 + [_f32, _f32, _u64, _i32, _i32, _vp],
+    "mmrca_mha_bwd_colsum": [_vp] * 7 + [_i32] * 4 + [_f32, _f32, _u64, _i32, _i32, _vp],
     "mmrca_mha_cls_fwd": [_vp] * 4 + [_i32] * 4 + [_f32, _f32, _u64, _i32, _vp],
     "mmrca_mha_cls_bwd": [_vp] * 6 + [_i32] * 4 + [_f32, _f32, _u64, _i32, _vp],
     "mmrca_add_layernorm_fwd": [_vp] * 8 + [_i64, _i32, _i64, _i64, _f32, _f32, _u64, _f32, _u64, _i32, _vp],
@@ -170,7 +171,12 @@ def mha_fwd(qkv, key_mask, out, lse, B, H, S, dh, scale, dtype, impl=IMPL_AUTO, 
                                 impl, stream_ptr()), "mmrca_mha_fwd")
 
 
-def mha_bwd(qkv, key_mask, out, dout, lse, dqkv, B, H, S, dh, scale, dtype, impl=IMPL_AUTO, drop_p=0.0, drop_seed=0):
+def mha_bwd(qkv, key_mask, out, dout, lse, dqkv, B, H, S, dh, scale, dtype, impl=IMPL_AUTO, drop_p=0.0, drop_seed=0, colsum=None):
+    """colsum (fp32 [3*H*dh], +=): column sums of dqkv = the in-projection bias gradient, reduced inside the kernels"""
+    if colsum is not None:
+        _check(load().mmrca_mha_bwd_colsum(ptr(qkv), ptr(key_mask), ptr(out), ptr(dout), ptr(lse), ptr(dqkv), ptr(colsum), B, H, S,
+                                           dh, scale, drop_p, drop_seed, dtype, impl, stream_ptr()), "mmrca_mha_bwd_colsum")
+        return
     _check(load().mmrca_mha_bwd(ptr(qkv), ptr(key_mask), ptr(out), ptr(dout), ptr(lse), ptr(dqkv), B, H, S, dh, scale,
                                 drop_p, drop_seed, dtype, impl, stream_ptr()), "mmrca_mha_bwd")
 

@@ -85,6 +85,11 @@ int mmrca_mha_fwd(const void* qkv, const int32_t* key_mask, void* out, float* ls
 int mmrca_mha_bwd(const void* qkv, const int32_t* key_mask, const void* out, const void* dout, const float* lse,
                   void* dqkv, int B, int H, int S, int dh, float scale, float drop_p, uint64_t drop_seed,
                   int dtype, int impl, void* stream);
+/* mmrca_mha_bwd that also adds the column sums of the stored dqkv to dqkv_colsum[3*H*dh] (fp32, +=): the bias gradient of
+ * the QKV in-projection, reduced inside the attention backward instead of by a pass of its own. */
+int mmrca_mha_bwd_colsum(const void* qkv, const int32_t* key_mask, const void* out, const void* dout, const float* lse,
+                         void* dqkv, float* dqkv_colsum, int B, int H, int S, int dh, float scale, float drop_p,
+                         uint64_t drop_seed, int dtype, int impl, void* stream);
 /* K3c. The same attention for the class-token query only (row 0 of every sequence): what the LAST encoder layer needs,
  * because the reference reads hidden_state[:, 0] (multimodal_model.py:352,517) / torchvision reads x[:, 0] and nothing else
  * of that layer's output.  out / dout: [B, H*dh] (compact), lse: fp32 [B,H].  The backward fills the WHOLE fused dqkv

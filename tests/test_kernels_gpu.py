@@ -435,6 +435,12 @@ def test_mha_fwd_bwd(dt, impl, S, masked):
     L.mha_bwd(qkv, mask, out, dout, lse, dqkv, B, H, S, dh, 1 / math.sqrt(dh), L.dtype_code(dt), impl)
     assert torch.isfinite(dqkv.float()).all()
     assert rel_err(dqkv, dref) < (2e-4 if dt == torch.float32 else 3e-2)
+    # the same backward with the in-projection bias gradient (column sums of the stored dqkv) reduced inside the kernels
+    dqkv2, db = torch.zeros_like(qkv), dev(torch.randn(3 * H * dh))
+    db0 = db.clone()
+    L.mha_bwd(qkv, mask, out, dout, lse, dqkv2, B, H, S, dh, 1 / math.sqrt(dh), L.dtype_code(dt), impl, colsum=db)
+    assert torch.equal(dqkv2, dqkv)
+    assert rel_err(db - db0, dqkv.float().sum(0)) < 1e-4
 
 
 @pytest.mark.parametrize("dt", [torch.float32, torch.bfloat16])
