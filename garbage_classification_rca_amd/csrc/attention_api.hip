@@ -2,47 +2,51 @@
 // (attention_mfma.hip).
 #include "common.h"
 
-int mmrca_mha_fwd_ref(const void*, const int32_t*, void*, float*, int, int, int, int, float, float, uint64_t, int, hipStream_t);
-int mmrca_mha_bwd_ref(const void*, const int32_t*, const void*, const void*, const float*, void*, int, int, int, int, float, float, uint64_t, int, hipStream_t);
+int mmrca_mha_fwd_ref(const void*, const int32_t*, void*, float*, int, int, int, int, float, float, uint64_t, const int32_t*, int, hipStream_t);
+int mmrca_mha_bwd_ref(const void*, const int32_t*, const void*, const void*, const float*, void*, int, int, int, int, float, float, uint64_t, const int32_t*, int, hipStream_t);
 bool mmrca_mha_mfma_ok(int S, int dh, int dtype);
-int mmrca_mha_fwd_mfma(const void*, const int32_t*, void*, float*, int, int, int, int, float, float, uint64_t, hipStream_t);
-int mmrca_mha_bwd_mfma(const void*, const int32_t*, const void*, const void*, const float*, void*, int, int, int, int, float, float, uint64_t, float*, hipStream_t);
+int mmrca_mha_fwd_mfma(const void*, const int32_t*, void*, float*, int, int, int, int, float, float, uint64_t, const int32_t*, hipStream_t);
+int mmrca_mha_bwd_mfma(const void*, const int32_t*, const void*, const void*, const float*, void*, int, int, int, int, float, float, uint64_t, float*, const int32_t*, hipStream_t);
 
 extern "C" int mmrca_mha_fwd(const void* qkv, const int32_t* key_mask, void* out, float* lse, int B, int H, int S, int dh,
-                             float scale, float drop_p, uint64_t drop_seed, int dtype, int impl, void* stream) {
+                             float scale, float drop_p, uint64_t drop_seed, const int32_t* cu_seqlens, int dtype, int impl,
+                             void* stream) {
   MMRCA_REQUIRE(qkv && out && lse, "mha_fwd: null pointer");
   MMRCA_REQUIRE(drop_p >= 0.f && drop_p < 1.f, "mha_fwd: dropout p must be in [0,1)");
   MMRCA_REQUIRE(B > 0 && H > 0 && S > 0 && dh > 0, "mha_fwd: bad shape");
   const bool ok = mmrca_mha_mfma_ok(S, dh, dtype);
   if (impl == MMRCA_GEMM_MFMA && !ok) return mmrca_fail(-3, "mha_fwd: S=%d dh=%d dtype=%d does not qualify for the MFMA kernel", S, dh, dtype);
-  if (ok && impl != MMRCA_GEMM_REF) return mmrca_mha_fwd_mfma(qkv, key_mask, out, lse, B, H, S, dh, scale, drop_p, drop_seed, (hipStream_t)stream);
-  return mmrca_mha_fwd_ref(qkv, key_mask, out, lse, B, H, S, dh, scale, drop_p, drop_seed, dtype, (hipStream_t)stream);
+  if (ok && impl != MMRCA_GEMM_REF) return mmrca_mha_fwd_mfma(qkv, key_mask, out, lse, B, H, S, dh, scale, drop_p, drop_seed, cu_seqlens, (hipStream_t)stream);
+  return mmrca_mha_fwd_ref(qkv, key_mask, out, lse, B, H, S, dh, scale, drop_p, drop_seed, cu_seqlens, dtype, (hipStream_t)stream);
 }
 
 static int mha_bwd_impl(const void* qkv, const int32_t* key_mask, const void* out, const void* dout, const float* lse,
-                        void* dqkv, float* dqkv_colsum, int B, int H, int S, int dh, float scale, float drop_p,
-                        uint64_t drop_seed, int dtype, int impl, void* stream) {
+                        void* dqkv, float* dqkv_colsum, int64_t rows, int B, int H, int S, int dh, float scale, float drop_p,
+                        uint64_t drop_seed, const int32_t* cu_seqlens, int dtype, int impl, void* stream) {
   MMRCA_REQUIRE(qkv && out && dout && lse && dqkv, "mha_bwd: null pointer");
   MMRCA_REQUIRE(drop_p >= 0.f && drop_p < 1.f, "mha_bwd: dropout p must be in [0,1)");
   MMRCA_REQUIRE(B > 0 && H > 0 && S > 0 && dh > 0, "mha_bwd: bad shape");
   const bool ok = mmrca_mha_mfma_ok(S, dh, dtype);
   if (impl == MMRCA_GEMM_MFMA && !ok) return mmrca_fail(-3, "mha_bwd: S=%d dh=%d dtype=%d does not qualify for the MFMA kernel", S, dh, dtype);
   if (ok && impl != MMRCA_GEMM_REF)
-    return mmrca_mha_bwd_mfma(qkv, key_mask, out, dout, lse, dqkv, B, H, S, dh, scale, drop_p, drop_seed, dqkv_colsum, (hipStream_t)stream);
-  if (int rc = mmrca_mha_bwd_ref(qkv, key_mask, out, dout, lse, dqkv, B, H, S, dh, scale, drop_p, drop_seed, dtype, (hipStream_t)stream)) return rc;
-  if (dqkv_colsum) return mmrca_colsum_accum(dqkv, dqkv_colsum, (int64_t)B * S, 3LL * H * dh, 3LL * H * dh, dtype, stream);
+    return mmrca_mha_bwd_mfma(qkv, key_mask, out, dout, lse, dqkv, B, H, S, dh, scale, drop_p, drop_seed, dqkv_colsum, cu_seqlens, (hipStream_t)stream);
+  if (int rc = mmrca_mha_bwd_ref(qkv, key_mask, out, dout, lse, dqkv, B, H, S, dh, scale, drop_p, drop_seed, cu_seqlens, dtype, (hipStream_t)stream)) return rc;
+  if (dqkv_colsum) return mmrca_colsum_accum(dqkv, dqkv_colsum, rows, 3LL * H * dh, 3LL * H * dh, dtype, stream);
   return 0;
 }
 
 extern "C" int mmrca_mha_bwd(const void* qkv, const int32_t* key_mask, const void* out, const void* dout, const float* lse,
-                             void* dqkv, int B, int H, int S, int dh, float scale, float drop_p, uint64_t drop_seed, int dtype,
-                             int impl, void* stream) {
-  return mha_bwd_impl(qkv, key_mask, out, dout, lse, dqkv, nullptr, B, H, S, dh, scale, drop_p, drop_seed, dtype, impl, stream);
+                             void* dqkv, int B, int H, int S, int dh, float scale, float drop_p, uint64_t drop_seed,
+                             const int32_t* cu_seqlens, int dtype, int impl, void* stream) {
+  return mha_bwd_impl(qkv, key_mask, out, dout, lse, dqkv, nullptr, 0, B, H, S, dh, scale, drop_p, drop_seed, cu_seqlens, dtype,
+                      impl, stream);
 }
 
+// total_rows: number of token rows of dqkv (B*S in the padded layout, cu_seqlens[B] in the packed one)
 extern "C" int mmrca_mha_bwd_colsum(const void* qkv, const int32_t* key_mask, const void* out, const void* dout, const float* lse,
-                                    void* dqkv, float* dqkv_colsum, int B, int H, int S, int dh, float scale, float drop_p,
-                                    uint64_t drop_seed, int dtype, int impl, void* stream) {
-  MMRCA_REQUIRE(dqkv_colsum, "mha_bwd_colsum: null dqkv_colsum");
-  return mha_bwd_impl(qkv, key_mask, out, dout, lse, dqkv, dqkv_colsum, B, H, S, dh, scale, drop_p, drop_seed, dtype, impl, stream);
+                                    void* dqkv, float* dqkv_colsum, int64_t total_rows, int B, int H, int S, int dh, float scale,
+                                    float drop_p, uint64_t drop_seed, const int32_t* cu_seqlens, int dtype, int impl, void* stream) {
+  MMRCA_REQUIRE(dqkv_colsum && total_rows > 0, "mha_bwd_colsum: null dqkv_colsum / bad total_rows");
+  return mha_bwd_impl(qkv, key_mask, out, dout, lse, dqkv, dqkv_colsum, total_rows, B, H, S, dh, scale, drop_p, drop_seed,
+                      cu_seqlens, dtype, impl, stream);
 }

@@ -34,12 +34,14 @@ __device__ __forceinline__ float block_reduce(float x, float* red, bool is_max) 
 template <typename T>
 __global__ void __launch_bounds__(256)
 mha_cls_fwd_k(const T* __restrict__ qkv, const int32_t* __restrict__ key_mask, T* __restrict__ out, float* __restrict__ lse,
-              int B, int H, int S, int dh, float scale, float drop_p, uint64_t drop_seed) {
+              int B, int H, int Smax, int dh, float scale, float drop_p, uint64_t drop_seed, const int32_t* __restrict__ cu) {
   __shared__ float qv[CLS_MAX_DH], p[CLS_MAX_S], red[4], part[4][CLS_MAX_DH];
   const float drop_sc = drop_p > 0.f ? 1.f / (1.f - drop_p) : 1.f;
   const int b = blockIdx.x / H, h = blockIdx.x % H, tid = threadIdx.x;
+  const int row0 = cu ? cu[b] : b * Smax, S = cu ? cu[b + 1] - cu[b] : Smax;     // packed / padded layout (see mmrca.h)
+  if (S <= 0) return;
   const int64_t ld = 3LL * H * dh;
-  const T* Q = qkv + (int64_t)b * S * ld + h * dh;
+  const T* Q = qkv + (int64_t)row0 * ld + h * dh;
   const T* Kp = Q + H * dh;
   const T* Vp = Kp + H * dh;
   for (int d = tid; d < dh; d += 256) qv[d] = to_f(Q[d]);
@@ -47,7 +49,7 @@ mha_cls_fwd_k(const T* __restrict__ qkv, const int32_t* __restrict__ key_mask, T
   float m = -INFINITY;
   for (int j = tid; j < S; j += 256) {
     float s = -INFINITY;
-    if (!key_mask || key_mask[b * S + j] != 0) s = dot_lds(Kp + (int64_t)j * ld, qv, dh) * scale;
+    if (!key_mask || key_mask[row0 + j] != 0) s = dot_lds(Kp + (int64_t)j * ld, qv, dh) * scale;
     p[j] = s;
     m = fmaxf(m, s);
   }
@@ -56,7 +58,7 @@ mha_cls_fwd_k(const T* __restrict__ qkv, const int32_t* __restrict__ key_mask, T
   for (int j = tid; j < S; j += 256) {
     const float e = m > -INFINITY ? __expf(p[j] - m) : 0.f;
     l += e;
-    p[j] = (drop_p > 0.f && mmrca_uniform(drop_seed, ((uint64_t)blockIdx.x * S + 0) * S + j) < drop_p) ? 0.f : e * drop_sc;
+    p[j] = (drop_p > 0.f && mmrca_uniform(drop_seed, ((uint64_t)blockIdx.x * Smax + 0) * Smax + j) < drop_p) ? 0.f : e * drop_sc;
   }
   l = block_reduce(l, red, false);       // (its barriers also publish p[])
   const float inv = l > 0.f ? 1.f / l : 0.f;
@@ -93,15 +95,17 @@ template <typename T>
 __global__ void __launch_bounds__(256)
 mha_cls_bwd_k(const T* __restrict__ qkv, const int32_t* __restrict__ key_mask, const T* __restrict__ out,
               const T* __restrict__ dout, const float* __restrict__ lse, T* __restrict__ dqkv,
-              int B, int H, int S, int dh, float scale, float drop_p, uint64_t drop_seed) {
+              int B, int H, int Smax, int dh, float scale, float drop_p, uint64_t drop_seed, const int32_t* __restrict__ cu) {
   __shared__ float qv[CLS_MAX_DH], dov[CLS_MAX_DH], pk[CLS_MAX_S], ds[CLS_MAX_S], red[4], part[4][CLS_MAX_DH];
   const float drop_sc = drop_p > 0.f ? 1.f / (1.f - drop_p) : 1.f;
   const int b = blockIdx.x / H, h = blockIdx.x % H, tid = threadIdx.x;
+  const int row0 = cu ? cu[b] : b * Smax, S = cu ? cu[b + 1] - cu[b] : Smax;
+  if (S <= 0) return;
   const int64_t ld = 3LL * H * dh;
-  const T* Q = qkv + (int64_t)b * S * ld + h * dh;
+  const T* Q = qkv + (int64_t)row0 * ld + h * dh;
   const T* Kp = Q + H * dh;
   const T* Vp = Kp + H * dh;
-  T* dQ = dqkv + (int64_t)b * S * ld + h * dh;
+  T* dQ = dqkv + (int64_t)row0 * ld + h * dh;
   T* dK = dQ + H * dh;
   T* dV = dK + H * dh;
   float dsum = 0.f;
@@ -115,11 +119,11 @@ mha_cls_bwd_k(const T* __restrict__ qkv, const int32_t* __restrict__ key_mask, c
   const float Lse = lse[blockIdx.x];
   for (int j = tid; j < S; j += 256) {
     float pkj = 0.f, dsj = 0.f;
-    if (!key_mask || key_mask[b * S + j] != 0) {
+    if (!key_mask || key_mask[row0 + j] != 0) {
       const float s = dot_lds(Kp + (int64_t)j * ld, qv, dh) * scale;
       const float pj = __expf(s - Lse);
       const float dp = dot_lds(Vp + (int64_t)j * ld, dov, dh);
-      const float keep = drop_p > 0.f ? (mmrca_uniform(drop_seed, ((uint64_t)blockIdx.x * S + 0) * S + j) >= drop_p ? drop_sc : 0.f) : 1.f;
+      const float keep = drop_p > 0.f ? (mmrca_uniform(drop_seed, ((uint64_t)blockIdx.x * Smax + 0) * Smax + j) >= drop_p ? drop_sc : 0.f) : 1.f;
       dsj = pj * (dp * keep - dsum) * scale;
       pkj = pj * keep;
     }
@@ -164,26 +168,26 @@ static bool cls_shape_ok(int S, int dh) {
 }
 
 extern "C" int mmrca_mha_cls_fwd(const void* qkv, const int32_t* key_mask, void* out, float* lse, int B, int H, int S, int dh,
-                                 float scale, float drop_p, uint64_t drop_seed, int dtype, void* stream) {
+                                 float scale, float drop_p, uint64_t drop_seed, const int32_t* cu_seqlens, int dtype, void* stream) {
   MMRCA_REQUIRE(qkv && out && lse, "mha_cls_fwd: null pointer");
   MMRCA_REQUIRE(drop_p >= 0.f && drop_p < 1.f, "mha_cls_fwd: dropout p must be in [0,1)");
   MMRCA_REQUIRE(B > 0 && H > 0 && S > 0 && cls_shape_ok(S, dh), "mha_cls_fwd: B=%d H=%d S=%d dh=%d unsupported", B, H, S, dh);
   MMRCA_DISPATCH_DTYPE(dtype, "mha_cls_fwd",
     hipLaunchKernelGGL(mha_cls_fwd_k<T>, dim3(B * H), dim3(256), 0, (hipStream_t)stream, (const T*)qkv, key_mask, (T*)out, lse,
-                       B, H, S, dh, scale, drop_p, drop_seed);)
+                       B, H, S, dh, scale, drop_p, drop_seed, cu_seqlens);)
   MMRCA_CHECK_LAUNCH("mha_cls_fwd");
   return 0;
 }
 
 extern "C" int mmrca_mha_cls_bwd(const void* qkv, const int32_t* key_mask, const void* out, const void* dout, const float* lse,
                                  void* dqkv, int B, int H, int S, int dh, float scale, float drop_p, uint64_t drop_seed,
-                                 int dtype, void* stream) {
+                                 const int32_t* cu_seqlens, int dtype, void* stream) {
   MMRCA_REQUIRE(qkv && out && dout && lse && dqkv, "mha_cls_bwd: null pointer");
   MMRCA_REQUIRE(drop_p >= 0.f && drop_p < 1.f, "mha_cls_bwd: dropout p must be in [0,1)");
   MMRCA_REQUIRE(B > 0 && H > 0 && S > 0 && cls_shape_ok(S, dh), "mha_cls_bwd: B=%d H=%d S=%d dh=%d unsupported", B, H, S, dh);
   MMRCA_DISPATCH_DTYPE(dtype, "mha_cls_bwd",
     hipLaunchKernelGGL(mha_cls_bwd_k<T>, dim3(B * H), dim3(256), 0, (hipStream_t)stream, (const T*)qkv, key_mask, (const T*)out,
-                       (const T*)dout, lse, (T*)dqkv, B, H, S, dh, scale, drop_p, drop_seed);)
+                       (const T*)dout, lse, (T*)dqkv, B, H, S, dh, scale, drop_p, drop_seed, cu_seqlens);)
   MMRCA_CHECK_LAUNCH("mha_cls_bwd");
   return 0;
 }

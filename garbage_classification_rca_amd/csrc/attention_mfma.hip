@@ -86,10 +86,18 @@ __device__ __forceinline__ float colgroup_sum(float x) { x += __shfl_xor(x, 16, 
 // key validity as an additive score bias in LDS: 0 for a live key, -inf for a masked or padded one.  (Testing
 // key_mask[] per score element cost a branch and a global load per element per query tile; the bias is one broadcast
 // ds_read_b128 per key tile and folds into the scale multiply as an fma.)
-__device__ __forceinline__ void stage_key_bias(float* kb, const int32_t* __restrict__ key_mask, int b, int S, int Spad) {
+__device__ __forceinline__ void stage_key_bias(float* kb, const int32_t* __restrict__ seq_mask, int S, int Spad) {
   for (int key = threadIdx.x; key < Spad; key += blockDim.x)
-    kb[key] = (key < S && (!key_mask || key_mask[b * S + key] != 0)) ? 0.f : -INFINITY;
+    kb[key] = (key < S && (!seq_mask || seq_mask[key] != 0)) ? 0.f : -INFINITY;
 }
+
+// Sequence b of the batch: rows [row0, row0 + S) of the token-major buffers.  Padded layout (cu == nullptr): row0 = b*Smax,
+// S = Smax.  Packed layout: cu[B+1] are the cumulative sequence lengths (captions stored back to back without their
+// padding), Smax only strides the lse / dropout-counter index spaces, which stay those of the padded layout.
+#define AT_SEQ(b_, Smax_, cu_)                                      \
+  const int row0 = (cu_) ? (cu_)[b_] : (b_) * (Smax_);              \
+  const int S = (cu_) ? (cu_)[(b_) + 1] - (cu_)[b_] : (Smax_);      \
+  if (S <= 0) return;
 
 // column sums of a stored 16x16 output tile in the D^T layout (lane = (row group g, column l16); v = the 4 rows 4g..4g+3
 // of this lane's column): sum over the 16 columns (queries / keys) that are valid, accumulate into 4 LDS floats
@@ -114,7 +122,8 @@ __device__ __forceinline__ void tile_colsum_to_lds(const bf16x4& v, bool valid, 
 template <int NKT, bool DROP, int NW>     // key tiles of 16 (Spad = 16*NKT, NKT even); DROP: attention-probability dropout compiled in
 __global__ void __launch_bounds__(64 * NW, NW / 2)
 mha_fwd_mfma_k(const bf16_t* __restrict__ qkv, const int32_t* __restrict__ key_mask, bf16_t* __restrict__ out,
-               float* __restrict__ lse, int H, int S, float scale, float drop_p, uint64_t drop_seed) {
+               float* __restrict__ lse, int H, int Smax, float scale, float drop_p, uint64_t drop_seed,
+               const int32_t* __restrict__ cu) {
   const float drop_sc = DROP ? 1.f / (1.f - drop_p) : 1.f;
   extern __shared__ __attribute__((aligned(16))) char sm[];
   constexpr int Spad = NKT * 16;
@@ -122,13 +131,14 @@ mha_fwd_mfma_k(const bf16_t* __restrict__ qkv, const int32_t* __restrict__ key_m
   float* kb = reinterpret_cast<float*>(sm + 2 * Spad * 128);
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, g = lane >> 4, l16 = lane & 15;
   const int b = blockIdx.x / H, h = blockIdx.x % H;
+  AT_SEQ(b, Smax, cu)
   const int64_t ld = 3LL * H * AT_DH;
-  const bf16_t* Q = qkv + (int64_t)b * S * ld + h * AT_DH;
+  const bf16_t* Q = qkv + (int64_t)row0 * ld + h * AT_DH;
   const bf16_t* Kp = Q + H * AT_DH;
   const bf16_t* Vp = Kp + H * AT_DH;
   stage_rows(Kimg, IMG_ROW, Kp, ld, S, Spad);
   stage_rows(Vimg, IMG_TR, Vp, ld, S, Spad);
-  stage_key_bias(kb, key_mask, b, S, Spad);
+  stage_key_bias(kb, key_mask ? key_mask + row0 : nullptr, S, Spad);
   __syncthreads();
   const float c1 = scale * LOG2E;                    // scores live in the exp2 domain
   const int nqt = (S + 15) / 16;
@@ -169,7 +179,7 @@ mha_fwd_mfma_k(const bf16_t* __restrict__ qkv, const int32_t* __restrict__ key_m
 #pragma unroll
       for (int kt = 0; kt < NKT; ++kt)
 #pragma unroll
-        for (int r = 0; r < 4; ++r) s[kt][r] *= attn_keep(drop_p, drop_sc, drop_seed, blockIdx.x, S, q0 + l16, kt * 16 + 4 * g + r);
+        for (int r = 0; r < 4; ++r) s[kt][r] *= attn_keep(drop_p, drop_sc, drop_seed, blockIdx.x, Smax, q0 + l16, kt * 16 + 4 * g + r);
     }
     f32x4 o[4];
 #pragma unroll
@@ -185,7 +195,7 @@ mha_fwd_mfma_k(const bf16_t* __restrict__ qkv, const int32_t* __restrict__ key_m
     const int q = q0 + l16;
     if (q < S) {
       const float inv = l > 0.f ? 1.f / l : 0.f;
-      bf16_t* orow = out + ((int64_t)b * S + q) * (H * AT_DH) + h * AT_DH;
+      bf16_t* orow = out + ((int64_t)row0 + q) * (H * AT_DH) + h * AT_DH;
 #pragma unroll
       for (int dt = 0; dt < 4; ++dt) {
         bf16x4 v;
@@ -193,7 +203,7 @@ mha_fwd_mfma_k(const bf16_t* __restrict__ qkv, const int32_t* __restrict__ key_m
         for (int r = 0; r < 4; ++r) v[r] = (bf16_t)(o[dt][r] * inv);
         *reinterpret_cast<bf16x4*>(orow + dt * 16 + 4 * g) = v;
       }
-      if (g == 0) lse[((int64_t)b * H + h) * S + q] = l > 0.f ? m * LN2 + __logf(l) : INFINITY;
+      if (g == 0) lse[((int64_t)b * H + h) * Smax + q] = l > 0.f ? m * LN2 + __logf(l) : INFINITY;
     }
   }
 }
@@ -205,7 +215,8 @@ template <int NKT, bool DROP, int NW>
 __global__ void __launch_bounds__(64 * NW, NW / 2)
 mha_bwd_dq_mfma_k(const bf16_t* __restrict__ qkv, const int32_t* __restrict__ key_mask, const bf16_t* __restrict__ out,
                   const bf16_t* __restrict__ dout, const float* __restrict__ lse, bf16_t* __restrict__ dqkv,
-                  int H, int S, float scale, float drop_p, uint64_t drop_seed, float* __restrict__ dbias) {
+                  int H, int Smax, float scale, float drop_p, uint64_t drop_seed, float* __restrict__ dbias,
+                  const int32_t* __restrict__ cu) {
   const float drop_sc = DROP ? 1.f / (1.f - drop_p) : 1.f;
   extern __shared__ __attribute__((aligned(16))) char sm[];
   constexpr int Spad = NKT * 16;
@@ -215,15 +226,16 @@ mha_bwd_dq_mfma_k(const bf16_t* __restrict__ qkv, const int32_t* __restrict__ ke
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, g = lane >> 4, l16 = lane & 15;
   if (threadIdx.x < 64) cs_lds[threadIdx.x] = 0.f;
   const int b = blockIdx.x / H, h = blockIdx.x % H;
+  AT_SEQ(b, Smax, cu)
   const int64_t ld = 3LL * H * AT_DH, ldo = (int64_t)H * AT_DH;
-  const bf16_t* Q = qkv + (int64_t)b * S * ld + h * AT_DH;
+  const bf16_t* Q = qkv + (int64_t)row0 * ld + h * AT_DH;
   const bf16_t* Kp = Q + H * AT_DH;
   const bf16_t* Vp = Kp + H * AT_DH;
-  const bf16_t* O = out + (int64_t)b * S * ldo + h * AT_DH;
-  const bf16_t* dO = dout + (int64_t)b * S * ldo + h * AT_DH;
+  const bf16_t* O = out + (int64_t)row0 * ldo + h * AT_DH;
+  const bf16_t* dO = dout + (int64_t)row0 * ldo + h * AT_DH;
   stage_rows(Kimg, IMG_TR, Kp, ld, S, Spad);      // row reads for S^T (2-way), transposed reads for dQ^T
   stage_rows(Vimg, IMG_ROW, Vp, ld, S, Spad);     // row reads for dP^T
-  stage_key_bias(kb, key_mask, b, S, Spad);
+  stage_key_bias(kb, key_mask ? key_mask + row0 : nullptr, S, Spad);
   __syncthreads();
   const float c1 = scale * LOG2E;
   const int nqt = (S + 15) / 16;
@@ -237,7 +249,7 @@ mha_bwd_dq_mfma_k(const bf16_t* __restrict__ qkv, const int32_t* __restrict__ ke
 #pragma unroll
     for (int j = 0; j < 8; ++j) dsum += (float)df0[j] * (float)of0[j] + (float)df1[j] * (float)of1[j];
     dsum = colgroup_sum(dsum);                       // D_q = rowsum(dO * O)
-    const float L2 = lse[((int64_t)b * H + h) * S + (q < S ? q : S - 1)] * LOG2E;      // +inf for a fully masked query
+    const float L2 = lse[((int64_t)b * H + h) * Smax + (q < S ? q : S - 1)] * LOG2E;      // +inf for a fully masked query
     f32x4 dq[4];
 #pragma unroll
     for (int dt = 0; dt < 4; ++dt) dq[dt] = (f32x4){0.f, 0.f, 0.f, 0.f};
@@ -256,7 +268,7 @@ mha_bwd_dq_mfma_k(const bf16_t* __restrict__ qkv, const int32_t* __restrict__ ke
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
           const float p = __builtin_amdgcn_exp2f(fmaf(s[r], c1, bias[r]) - L2);          // 0 for masked keys / queries
-          const float keep = DROP ? attn_keep(drop_p, drop_sc, drop_seed, blockIdx.x, S, q, kt * 16 + 4 * g + r) : 1.f;
+          const float keep = DROP ? attn_keep(drop_p, drop_sc, drop_seed, blockIdx.x, Smax, q, kt * 16 + 4 * g + r) : 1.f;
           ds2[hh][r] = p * (DROP ? dp[r] * keep - dsum : dp[r] - dsum);                   // (the score scale is applied to dQ below)
         }
       }
@@ -265,7 +277,7 @@ mha_bwd_dq_mfma_k(const bf16_t* __restrict__ qkv, const int32_t* __restrict__ ke
       for (int dt = 0; dt < 4; ++dt)
         dq[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_cols_tr(Kimg, u, dt, lane), dsf, dq[dt], 0, 0, 0);   // dQ^T[d][q]
     }
-    bf16_t* drow = dqkv + ((int64_t)b * S + (q < S ? q : S - 1)) * ld + h * AT_DH;
+    bf16_t* drow = dqkv + ((int64_t)row0 + (q < S ? q : S - 1)) * ld + h * AT_DH;
 #pragma unroll
     for (int dt = 0; dt < 4; ++dt) {
       bf16x4 v;
@@ -288,7 +300,8 @@ template <int NKT, bool DROP, int NW>
 __global__ void __launch_bounds__(64 * NW, NW / 2)
 mha_bwd_dkv_mfma_k(const bf16_t* __restrict__ qkv, const int32_t* __restrict__ key_mask, const bf16_t* __restrict__ out,
                    const bf16_t* __restrict__ dout, const float* __restrict__ lse, bf16_t* __restrict__ dqkv,
-                   int H, int S, float scale, float drop_p, uint64_t drop_seed, float* __restrict__ dbias) {
+                   int H, int Smax, float scale, float drop_p, uint64_t drop_seed, float* __restrict__ dbias,
+                   const int32_t* __restrict__ cu) {
   const float drop_sc = DROP ? 1.f / (1.f - drop_p) : 1.f;
   extern __shared__ __attribute__((aligned(16))) char sm[];
   constexpr int Spad = NKT * 16;
@@ -299,18 +312,19 @@ mha_bwd_dkv_mfma_k(const bf16_t* __restrict__ qkv, const int32_t* __restrict__ k
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, g = lane >> 4, l16 = lane & 15;
   if (threadIdx.x < 128) cs_lds[threadIdx.x] = 0.f;
   const int b = blockIdx.x / H, h = blockIdx.x % H;
+  AT_SEQ(b, Smax, cu)
   const int64_t ld = 3LL * H * AT_DH, ldo = (int64_t)H * AT_DH;
-  const bf16_t* Q = qkv + (int64_t)b * S * ld + h * AT_DH;
+  const bf16_t* Q = qkv + (int64_t)row0 * ld + h * AT_DH;
   const bf16_t* Kp = Q + H * AT_DH;
   const bf16_t* Vp = Kp + H * AT_DH;
-  const bf16_t* O = out + (int64_t)b * S * ldo + h * AT_DH;
-  const bf16_t* dO = dout + (int64_t)b * S * ldo + h * AT_DH;
+  const bf16_t* O = out + (int64_t)row0 * ldo + h * AT_DH;
+  const bf16_t* dO = dout + (int64_t)row0 * ldo + h * AT_DH;
   stage_rows(Qimg, IMG_TR, Q, ld, S, Spad);
   stage_rows(Dimg, IMG_TR, dO, ldo, S, Spad);
   for (int q = threadIdx.x; q < Spad; q += blockDim.x) {
     float a = 0.f, L = INFINITY;                 // padded query rows: lse=+inf -> P = 0
     if (q < S) {
-      L = lse[((int64_t)b * H + h) * S + q] * LOG2E;
+      L = lse[((int64_t)b * H + h) * Smax + q] * LOG2E;
 #pragma unroll
       for (int c = 0; c < 8; ++c) {
         const bf16x8 x = *reinterpret_cast<const bf16x8*>(dO + (int64_t)q * ldo + c * 8);
@@ -327,7 +341,7 @@ mha_bwd_dkv_mfma_k(const bf16_t* __restrict__ qkv, const int32_t* __restrict__ k
   for (int kt = wave; kt < nkt; kt += NW) {
     const int k0 = kt * 16;
     const int key = k0 + l16;
-    const float kbias = (key < S && (!key_mask || key_mask[b * S + key] != 0)) ? 0.f : -INFINITY;    // this lane's key
+    const float kbias = (key < S && (!key_mask || key_mask[row0 + key] != 0)) ? 0.f : -INFINITY;    // this lane's key
     const bf16x8 kf0 = frag_global(Kp, ld, k0, S, 0, lane), kf1 = frag_global(Kp, ld, k0, S, 1, lane);
     const bf16x8 vf0 = frag_global(Vp, ld, k0, S, 0, lane), vf1 = frag_global(Vp, ld, k0, S, 1, lane);
     f32x4 dk[4], dv[4];
@@ -350,7 +364,7 @@ mha_bwd_dkv_mfma_k(const bf16_t* __restrict__ qkv, const int32_t* __restrict__ k
         for (int r = 0; r < 4; ++r) {
           const float p = __builtin_amdgcn_exp2f(fmaf(s[r], c1, kbias) - Lq[r]);
           if (DROP) {
-            const float keep = attn_keep(drop_p, drop_sc, drop_seed, blockIdx.x, S, qt * 16 + 4 * g + r, key);
+            const float keep = attn_keep(drop_p, drop_sc, drop_seed, blockIdx.x, Smax, qt * 16 + 4 * g + r, key);
             p2[hh][r] = p * keep;
             ds2[hh][r] = p * (dp[r] * keep - Dq[r]);
           } else {
@@ -366,7 +380,7 @@ mha_bwd_dkv_mfma_k(const bf16_t* __restrict__ qkv, const int32_t* __restrict__ k
         dk[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_cols_tr(Qimg, u, dt, lane), dsf, dk[dt], 0, 0, 0);   // dK^T[d][key]
       }
     }
-    bf16_t* krow = dqkv + ((int64_t)b * S + (key < S ? key : S - 1)) * ld + (int64_t)H * AT_DH + h * AT_DH;
+    bf16_t* krow = dqkv + ((int64_t)row0 + (key < S ? key : S - 1)) * ld + (int64_t)H * AT_DH + h * AT_DH;
     bf16_t* vrow = krow + (int64_t)H * AT_DH;
 #pragma unroll
     for (int dt = 0; dt < 4; ++dt) {
@@ -437,24 +451,24 @@ static int pick_nkt(int S) {
 #define STAT_EXTRA(n) (2 * (n) * 16 * 4 + 128 * 4)
 
 int mmrca_mha_fwd_mfma(const void* qkv, const int32_t* key_mask, void* out, float* lse, int B, int H, int S, int dh,
-                       float scale, float drop_p, uint64_t drop_seed, hipStream_t st) {
+                       float scale, float drop_p, uint64_t drop_seed, const int32_t* cu, hipStream_t st) {
   (void)dh;
   MMRCA_REQUIRE((((uintptr_t)qkv) & 15) == 0 && (((uintptr_t)out) & 7) == 0, "mha_fwd: qkv must be 16-byte aligned");
   const int nkt = pick_nkt(S);
-  AT_SWITCH(mha_fwd_mfma_k, BIAS_EXTRA, true, false, false, (const bf16_t*)qkv, key_mask, (bf16_t*)out, lse, H, S, scale, drop_p, drop_seed);
+  AT_SWITCH(mha_fwd_mfma_k, BIAS_EXTRA, true, false, false, (const bf16_t*)qkv, key_mask, (bf16_t*)out, lse, H, S, scale, drop_p, drop_seed, cu);
   MMRCA_CHECK_LAUNCH("mha_fwd(mfma)");
   return 0;
 }
 
 int mmrca_mha_bwd_mfma(const void* qkv, const int32_t* key_mask, const void* out, const void* dout, const float* lse,
                        void* dqkv, int B, int H, int S, int dh, float scale, float drop_p, uint64_t drop_seed, float* dbias,
-                       hipStream_t st) {
+                       const int32_t* cu, hipStream_t st) {
   (void)dh;
   MMRCA_REQUIRE((((uintptr_t)qkv) & 15) == 0 && (((uintptr_t)out) & 15) == 0 && (((uintptr_t)dout) & 15) == 0 && (((uintptr_t)dqkv) & 7) == 0,
                 "mha_bwd: buffers must be 16-byte aligned");
   const int nkt = pick_nkt(S);
-  AT_SWITCH(mha_bwd_dq_mfma_k, BIAS_EXTRA, true, true, true, (const bf16_t*)qkv, key_mask, (const bf16_t*)out, (const bf16_t*)dout, lse, (bf16_t*)dqkv, H, S, scale, drop_p, drop_seed, dbias);
-  AT_SWITCH(mha_bwd_dkv_mfma_k, STAT_EXTRA, true, false, true, (const bf16_t*)qkv, key_mask, (const bf16_t*)out, (const bf16_t*)dout, lse, (bf16_t*)dqkv, H, S, scale, drop_p, drop_seed, dbias);
+  AT_SWITCH(mha_bwd_dq_mfma_k, BIAS_EXTRA, true, true, true, (const bf16_t*)qkv, key_mask, (const bf16_t*)out, (const bf16_t*)dout, lse, (bf16_t*)dqkv, H, S, scale, drop_p, drop_seed, dbias, cu);
+  AT_SWITCH(mha_bwd_dkv_mfma_k, STAT_EXTRA, true, false, true, (const bf16_t*)qkv, key_mask, (const bf16_t*)out, (const bf16_t*)dout, lse, (bf16_t*)dqkv, H, S, scale, drop_p, drop_seed, dbias, cu);
   MMRCA_CHECK_LAUNCH("mha_bwd(mfma)");
   return 0;
 }

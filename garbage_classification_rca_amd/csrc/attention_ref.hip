@@ -21,16 +21,17 @@ __device__ __forceinline__ float dot_row(const T* __restrict__ row, const float*
 template <typename T>
 __global__ void __launch_bounds__(256)
 mha_fwd_ref_k(const T* __restrict__ qkv, const int32_t* __restrict__ key_mask, T* __restrict__ out, float* __restrict__ lse,
-              int B, int H, int S, int dh, float scale, float drop_p, uint64_t drop_seed) {
+              int B, int H, int Smax, int dh, float scale, float drop_p, uint64_t drop_seed, const int32_t* __restrict__ cu) {
   const float drop_sc = drop_p > 0.f ? 1.f / (1.f - drop_p) : 1.f;
   extern __shared__ float sm[];     // per wave: q[dh] | p[S]
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const int b = blockIdx.y / H, h = blockIdx.y % H;
+  const int row0 = cu ? cu[b] : b * Smax, S = cu ? cu[b + 1] - cu[b] : Smax;     // packed / padded layout (see mmrca.h)
   const int i = blockIdx.x * 4 + wave;
-  float* qv = sm + wave * (ATT_MAX_DH + S);
+  float* qv = sm + wave * (ATT_MAX_DH + Smax);
   float* p = qv + ATT_MAX_DH;
   const int64_t ld = 3LL * H * dh;
-  const T* Q = qkv + (int64_t)b * S * ld + h * dh;
+  const T* Q = qkv + (int64_t)row0 * ld + h * dh;
   const T* Kp = Q + H * dh;
   const T* Vp = Kp + H * dh;
   if (i >= S) return;                      // whole wave exits together (i is wave-uniform); no block barrier below
@@ -39,7 +40,7 @@ mha_fwd_ref_k(const T* __restrict__ qkv, const int32_t* __restrict__ key_mask, T
   float m = -INFINITY;
   for (int j = lane; j < S; j += 64) {
     float s = -INFINITY;
-    if (!key_mask || key_mask[b * S + j] != 0) s = dot_row(Kp + (int64_t)j * ld, qv, dh) * scale;
+    if (!key_mask || key_mask[row0 + j] != 0) s = dot_row(Kp + (int64_t)j * ld, qv, dh) * scale;
     p[j] = s;
     m = fmaxf(m, s);
   }
@@ -54,14 +55,14 @@ mha_fwd_ref_k(const T* __restrict__ qkv, const int32_t* __restrict__ key_mask, T
   const float inv = l > 0.f ? 1.f / l : 0.f;
   if (drop_p > 0.f)
     for (int j = lane; j < S; j += 64)
-      p[j] *= mmrca_uniform(drop_seed, ((uint64_t)blockIdx.y * S + i) * S + j) >= drop_p ? drop_sc : 0.f;
+      p[j] *= mmrca_uniform(drop_seed, ((uint64_t)blockIdx.y * Smax + i) * Smax + j) >= drop_p ? drop_sc : 0.f;
   __builtin_amdgcn_wave_barrier();
   for (int d = lane; d < dh; d += 64) {
     float o = 0.f;
     for (int j = 0; j < S; ++j) o += p[j] * to_f(Vp[(int64_t)j * ld + d]);
-    out[((int64_t)b * S + i) * (H * dh) + h * dh + d] = from_f<T>(o * inv);
+    out[((int64_t)row0 + i) * (H * dh) + h * dh + d] = from_f<T>(o * inv);
   }
-  if (lane == 0) lse[((int64_t)b * H + h) * S + i] = l > 0.f ? m + __logf(l) : INFINITY;
+  if (lane == 0) lse[((int64_t)b * H + h) * Smax + i] = l > 0.f ? m + __logf(l) : INFINITY;
 }
 
 // dQ: one wave per query row
@@ -69,37 +70,38 @@ template <typename T>
 __global__ void __launch_bounds__(256)
 mha_bwd_dq_ref_k(const T* __restrict__ qkv, const int32_t* __restrict__ key_mask, const T* __restrict__ out,
                  const T* __restrict__ dout, const float* __restrict__ lse, T* __restrict__ dqkv,
-                 int B, int H, int S, int dh, float scale, float drop_p, uint64_t drop_seed) {
+                 int B, int H, int Smax, int dh, float scale, float drop_p, uint64_t drop_seed, const int32_t* __restrict__ cu) {
   const float drop_sc = drop_p > 0.f ? 1.f / (1.f - drop_p) : 1.f;
   extern __shared__ float sm[];     // per wave: q[dh] | do[dh] | ds[S]
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const int b = blockIdx.y / H, h = blockIdx.y % H;
+  const int row0 = cu ? cu[b] : b * Smax, S = cu ? cu[b + 1] - cu[b] : Smax;
   const int i = blockIdx.x * 4 + wave;
-  float* qv = sm + wave * (2 * ATT_MAX_DH + S);
+  float* qv = sm + wave * (2 * ATT_MAX_DH + Smax);
   float* dov = qv + ATT_MAX_DH;
   float* ds = dov + ATT_MAX_DH;
   const int64_t ld = 3LL * H * dh, ldo = (int64_t)H * dh;
-  const T* Q = qkv + (int64_t)b * S * ld + h * dh;
+  const T* Q = qkv + (int64_t)row0 * ld + h * dh;
   const T* Kp = Q + H * dh;
   const T* Vp = Kp + H * dh;
   if (i >= S) return;
   float dsum = 0.f;
   for (int d = lane; d < dh; d += 64) {
     qv[d] = to_f(Q[(int64_t)i * ld + d]);
-    const float g = to_f(dout[((int64_t)b * S + i) * ldo + h * dh + d]);
+    const float g = to_f(dout[((int64_t)row0 + i) * ldo + h * dh + d]);
     dov[d] = g;
-    dsum += g * to_f(out[((int64_t)b * S + i) * ldo + h * dh + d]);
+    dsum += g * to_f(out[((int64_t)row0 + i) * ldo + h * dh + d]);
   }
   dsum = wave_sum(dsum);
   __builtin_amdgcn_wave_barrier();
-  const float L = lse[((int64_t)b * H + h) * S + i];
+  const float L = lse[((int64_t)b * H + h) * Smax + i];
   for (int j = lane; j < S; j += 64) {
     float v = 0.f;
-    if (!key_mask || key_mask[b * S + j] != 0) {
+    if (!key_mask || key_mask[row0 + j] != 0) {
       const float s = dot_row(Kp + (int64_t)j * ld, qv, dh) * scale;
       const float pj = __expf(s - L);
       float dp = dot_row(Vp + (int64_t)j * ld, dov, dh);
-      if (drop_p > 0.f) dp *= mmrca_uniform(drop_seed, ((uint64_t)blockIdx.y * S + i) * S + j) >= drop_p ? drop_sc : 0.f;
+      if (drop_p > 0.f) dp *= mmrca_uniform(drop_seed, ((uint64_t)blockIdx.y * Smax + i) * Smax + j) >= drop_p ? drop_sc : 0.f;
       v = pj * (dp - dsum) * scale;
     }
     ds[j] = v;
@@ -108,7 +110,7 @@ mha_bwd_dq_ref_k(const T* __restrict__ qkv, const int32_t* __restrict__ key_mask
   for (int d = lane; d < dh; d += 64) {
     float a = 0.f;
     for (int j = 0; j < S; ++j) a += ds[j] * to_f(Kp[(int64_t)j * ld + d]);
-    dqkv[((int64_t)b * S + i) * ld + h * dh + d] = from_f<T>(a);
+    dqkv[((int64_t)row0 + i) * ld + h * dh + d] = from_f<T>(a);
   }
 }
 
@@ -117,35 +119,36 @@ template <typename T>
 __global__ void __launch_bounds__(256)
 mha_bwd_dkv_ref_k(const T* __restrict__ qkv, const int32_t* __restrict__ key_mask, const T* __restrict__ out,
                   const T* __restrict__ dout, const float* __restrict__ lse, T* __restrict__ dqkv,
-                  int B, int H, int S, int dh, float scale, float drop_p, uint64_t drop_seed) {
+                  int B, int H, int Smax, int dh, float scale, float drop_p, uint64_t drop_seed, const int32_t* __restrict__ cu) {
   const float drop_sc = drop_p > 0.f ? 1.f / (1.f - drop_p) : 1.f;
   extern __shared__ float sm[];     // per wave: k[dh] | v[dh] | p[S] | ds[S]
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const int b = blockIdx.y / H, h = blockIdx.y % H;
+  const int row0 = cu ? cu[b] : b * Smax, S = cu ? cu[b + 1] - cu[b] : Smax;
   const int j = blockIdx.x * 4 + wave;
-  float* kv = sm + wave * (2 * ATT_MAX_DH + 2 * S);
+  float* kv = sm + wave * (2 * ATT_MAX_DH + 2 * Smax);
   float* vv = kv + ATT_MAX_DH;
   float* p = vv + ATT_MAX_DH;
-  float* ds = p + S;
+  float* ds = p + Smax;
   const int64_t ld = 3LL * H * dh, ldo = (int64_t)H * dh;
-  const T* Q = qkv + (int64_t)b * S * ld + h * dh;
+  const T* Q = qkv + (int64_t)row0 * ld + h * dh;
   const T* Kp = Q + H * dh;
   const T* Vp = Kp + H * dh;
   if (j >= S) return;
-  const bool masked = key_mask && key_mask[b * S + j] == 0;
+  const bool masked = key_mask && key_mask[row0 + j] == 0;
   for (int d = lane; d < dh; d += 64) { kv[d] = to_f(Kp[(int64_t)j * ld + d]); vv[d] = to_f(Vp[(int64_t)j * ld + d]); }
   __builtin_amdgcn_wave_barrier();
   for (int i = lane; i < S; i += 64) {
     float pi = 0.f, dsi = 0.f;
     if (!masked) {
-      const T* dorow = dout + ((int64_t)b * S + i) * ldo + h * dh;
-      const T* orow = out + ((int64_t)b * S + i) * ldo + h * dh;
+      const T* dorow = dout + ((int64_t)row0 + i) * ldo + h * dh;
+      const T* orow = out + ((int64_t)row0 + i) * ldo + h * dh;
       const float s = dot_row(Q + (int64_t)i * ld, kv, dh) * scale;
-      pi = __expf(s - lse[((int64_t)b * H + h) * S + i]);
+      pi = __expf(s - lse[((int64_t)b * H + h) * Smax + i]);
       float dp = dot_row(dorow, vv, dh);
       float dsum = 0.f;
       for (int d = 0; d < dh; ++d) dsum += to_f(dorow[d]) * to_f(orow[d]);
-      const float keep = drop_p > 0.f ? (mmrca_uniform(drop_seed, ((uint64_t)blockIdx.y * S + i) * S + j) >= drop_p ? drop_sc : 0.f) : 1.f;
+      const float keep = drop_p > 0.f ? (mmrca_uniform(drop_seed, ((uint64_t)blockIdx.y * Smax + i) * Smax + j) >= drop_p ? drop_sc : 0.f) : 1.f;
       dsi = pi * (dp * keep - dsum) * scale;
       pi *= keep;
     }
@@ -156,32 +159,33 @@ mha_bwd_dkv_ref_k(const T* __restrict__ qkv, const int32_t* __restrict__ key_mas
     float ak = 0.f, av = 0.f;
     for (int i = 0; i < S; ++i) {
       ak += ds[i] * to_f(Q[(int64_t)i * ld + d]);
-      av += p[i] * to_f(dout[((int64_t)b * S + i) * ldo + h * dh + d]);
+      av += p[i] * to_f(dout[((int64_t)row0 + i) * ldo + h * dh + d]);
     }
-    dqkv[((int64_t)b * S + j) * ld + (int64_t)H * dh + h * dh + d] = from_f<T>(ak);
-    dqkv[((int64_t)b * S + j) * ld + 2LL * H * dh + h * dh + d] = from_f<T>(av);
+    dqkv[((int64_t)row0 + j) * ld + (int64_t)H * dh + h * dh + d] = from_f<T>(ak);
+    dqkv[((int64_t)row0 + j) * ld + 2LL * H * dh + h * dh + d] = from_f<T>(av);
   }
 }
 
 int mmrca_mha_fwd_ref(const void* qkv, const int32_t* key_mask, void* out, float* lse, int B, int H, int S, int dh,
-                      float scale, float drop_p, uint64_t drop_seed, int dtype, hipStream_t st) {
+                      float scale, float drop_p, uint64_t drop_seed, const int32_t* cu, int dtype, hipStream_t st) {
   MMRCA_REQUIRE(S <= ATT_MAX_S && dh <= ATT_MAX_DH && dh % 4 == 0, "mha_fwd(ref): S=%d dh=%d unsupported", S, dh);
   dim3 grid((S + 3) / 4, B * H);
   const size_t lds = 4 * (ATT_MAX_DH + S) * sizeof(float);
   MMRCA_DISPATCH_DTYPE(dtype, "mha_fwd",
-    hipLaunchKernelGGL(mha_fwd_ref_k<T>, grid, dim3(256), lds, st, (const T*)qkv, key_mask, (T*)out, lse, B, H, S, dh, scale, drop_p, drop_seed);)
+    hipLaunchKernelGGL(mha_fwd_ref_k<T>, grid, dim3(256), lds, st, (const T*)qkv, key_mask, (T*)out, lse, B, H, S, dh, scale, drop_p, drop_seed, cu);)
   MMRCA_CHECK_LAUNCH("mha_fwd(ref)");
   return 0;
 }
 
 int mmrca_mha_bwd_ref(const void* qkv, const int32_t* key_mask, const void* out, const void* dout, const float* lse,
-                      void* dqkv, int B, int H, int S, int dh, float scale, float drop_p, uint64_t drop_seed, int dtype, hipStream_t st) {
+                      void* dqkv, int B, int H, int S, int dh, float scale, float drop_p, uint64_t drop_seed, const int32_t* cu,
+                      int dtype, hipStream_t st) {
   MMRCA_REQUIRE(S <= ATT_MAX_S && dh <= ATT_MAX_DH && dh % 4 == 0, "mha_bwd(ref): S=%d dh=%d unsupported", S, dh);
   dim3 grid((S + 3) / 4, B * H);
   const size_t lds1 = 4 * (2 * ATT_MAX_DH + S) * sizeof(float), lds2 = 4 * (2 * ATT_MAX_DH + 2 * S) * sizeof(float);
   MMRCA_DISPATCH_DTYPE(dtype, "mha_bwd",
-    hipLaunchKernelGGL(mha_bwd_dq_ref_k<T>, grid, dim3(256), lds1, st, (const T*)qkv, key_mask, (const T*)out, (const T*)dout, lse, (T*)dqkv, B, H, S, dh, scale, drop_p, drop_seed);
-    hipLaunchKernelGGL(mha_bwd_dkv_ref_k<T>, grid, dim3(256), lds2, st, (const T*)qkv, key_mask, (const T*)out, (const T*)dout, lse, (T*)dqkv, B, H, S, dh, scale, drop_p, drop_seed);)
+    hipLaunchKernelGGL(mha_bwd_dq_ref_k<T>, grid, dim3(256), lds1, st, (const T*)qkv, key_mask, (const T*)out, (const T*)dout, lse, (T*)dqkv, B, H, S, dh, scale, drop_p, drop_seed, cu);
+    hipLaunchKernelGGL(mha_bwd_dkv_ref_k<T>, grid, dim3(256), lds2, st, (const T*)qkv, key_mask, (const T*)out, (const T*)dout, lse, (T*)dqkv, B, H, S, dh, scale, drop_p, drop_seed, cu);)
   MMRCA_CHECK_LAUNCH("mha_bwd(ref)");
   return 0;
 }

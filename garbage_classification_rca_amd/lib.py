@@ -53,11 +53,11 @@ _SIGS = {
     "mmrca_colsum_accum": [_vp, _vp, _i64, _i64, _i64, _i32, _vp],
     "mmrca_gelu_bwd": [_vp, _vp, _vp, _i64, _i32, _vp],
     "mmrca_gelu_bwd_colsum": [_vp, _vp, _vp, _vp, _i64, _i64, _i64, _i32, _vp],
-    "mmrca_mha_fwd": [_vp] * 4 + [_i32] * 4 + [_f32, _f32, _u64, _i32, _i32, _vp],
-    "mmrca_mha_bwd": [_vp] * 6 + [_i32] * 4 + [_f32, _f32, _u64, _i32, _i32, _vp],
-    "mmrca_mha_bwd_colsum": [_vp] * 7 + [_i32] * 4 + [_f32, _f32, _u64, _i32, _i32, _vp],
-    "mmrca_mha_cls_fwd": [_vp] * 4 + [_i32] * 4 + [_f32, _f32, _u64, _i32, _vp],
-    "mmrca_mha_cls_bwd": [_vp] * 6 + [_i32] * 4 + [_f32, _f32, _u64, _i32, _vp],
+    "mmrca_mha_fwd": [_vp] * 4 + [_i32] * 4 + [_f32, _f32, _u64, _vp, _i32, _i32, _vp],
+    "mmrca_mha_bwd": [_vp] * 6 + [_i32] * 4 + [_f32, _f32, _u64, _vp, _i32, _i32, _vp],
+    "mmrca_mha_bwd_colsum": [_vp] * 7 + [_i64] + [_i32] * 4 + [_f32, _f32, _u64, _vp, _i32, _i32, _vp],
+    "mmrca_mha_cls_fwd": [_vp] * 4 + [_i32] * 4 + [_f32, _f32, _u64, _vp, _i32, _vp],
+    "mmrca_mha_cls_bwd": [_vp] * 6 + [_i32] * 4 + [_f32, _f32, _u64, _vp, _i32, _vp],
     "mmrca_add_layernorm_fwd": [_vp] * 8 + [_i64, _i32, _i64, _i64, _f32, _f32, _u64, _f32, _u64, _i32, _vp],
     "mmrca_layernorm_bwd": [_vp] * 9 + [_i64, _i32, _i64, _i64, _i64, _f32, _u64, _f32, _u64, _vp, _vp, _vp, _i32, _vp],
     "mmrca_embed_fwd": [_vp] * 6 + [_i64, _i32, _i32, _vp],
@@ -165,32 +165,36 @@ def gelu_bwd_colsum(dG, H, dH, db, M, N, ld, dtype):
     _check(load().mmrca_gelu_bwd_colsum(ptr(dG), ptr(H), ptr(dH), ptr(db), M, N, ld, dtype, stream_ptr()), "mmrca_gelu_bwd_colsum")
 
 
-def mha_fwd(qkv, key_mask, out, lse, B, H, S, dh, scale, dtype, impl=IMPL_AUTO, drop_p=0.0, drop_seed=0):
+def mha_fwd(qkv, key_mask, out, lse, B, H, S, dh, scale, dtype, impl=IMPL_AUTO, drop_p=0.0, drop_seed=0, cu=None):
+    """cu (int32 [B+1], device): packed token layout, sequence b = rows [cu[b], cu[b+1]); None = padded [B*S] rows"""
     _dev(qkv, "mha qkv")
-    _check(load().mmrca_mha_fwd(ptr(qkv), ptr(key_mask), ptr(out), ptr(lse), B, H, S, dh, scale, drop_p, drop_seed, dtype,
+    _check(load().mmrca_mha_fwd(ptr(qkv), ptr(key_mask), ptr(out), ptr(lse), B, H, S, dh, scale, drop_p, drop_seed, ptr(cu), dtype,
                                 impl, stream_ptr()), "mmrca_mha_fwd")
 
 
-def mha_bwd(qkv, key_mask, out, dout, lse, dqkv, B, H, S, dh, scale, dtype, impl=IMPL_AUTO, drop_p=0.0, drop_seed=0, colsum=None):
-    """colsum (fp32 [3*H*dh], +=): column sums of dqkv = the in-projection bias gradient, reduced inside the kernels"""
+def mha_bwd(qkv, key_mask, out, dout, lse, dqkv, B, H, S, dh, scale, dtype, impl=IMPL_AUTO, drop_p=0.0, drop_seed=0, colsum=None,
+            cu=None, rows=None):
+    """colsum (fp32 [3*H*dh], +=): column sums of dqkv = the in-projection bias gradient, reduced inside the kernels;
+    rows = number of token rows (defaults to B*S; pass cu[B] for the packed layout)"""
     if colsum is not None:
-        _check(load().mmrca_mha_bwd_colsum(ptr(qkv), ptr(key_mask), ptr(out), ptr(dout), ptr(lse), ptr(dqkv), ptr(colsum), B, H, S,
-                                           dh, scale, drop_p, drop_seed, dtype, impl, stream_ptr()), "mmrca_mha_bwd_colsum")
+        _check(load().mmrca_mha_bwd_colsum(ptr(qkv), ptr(key_mask), ptr(out), ptr(dout), ptr(lse), ptr(dqkv), ptr(colsum),
+                                           B * S if rows is None else rows, B, H, S, dh, scale, drop_p, drop_seed, ptr(cu), dtype,
+                                           impl, stream_ptr()), "mmrca_mha_bwd_colsum")
         return
     _check(load().mmrca_mha_bwd(ptr(qkv), ptr(key_mask), ptr(out), ptr(dout), ptr(lse), ptr(dqkv), B, H, S, dh, scale,
-                                drop_p, drop_seed, dtype, impl, stream_ptr()), "mmrca_mha_bwd")
+                                drop_p, drop_seed, ptr(cu), dtype, impl, stream_ptr()), "mmrca_mha_bwd")
 
 
-def mha_cls_fwd(qkv, key_mask, out, lse, B, H, S, dh, scale, dtype, drop_p=0.0, drop_seed=0):
+def mha_cls_fwd(qkv, key_mask, out, lse, B, H, S, dh, scale, dtype, drop_p=0.0, drop_seed=0, cu=None):
     """attention of the class-token query (row 0) only: out [B, H*dh], lse [B, H]"""
     _dev(qkv, "mha_cls qkv")
-    _check(load().mmrca_mha_cls_fwd(ptr(qkv), ptr(key_mask), ptr(out), ptr(lse), B, H, S, dh, scale, drop_p, drop_seed, dtype,
-                                    stream_ptr()), "mmrca_mha_cls_fwd")
+    _check(load().mmrca_mha_cls_fwd(ptr(qkv), ptr(key_mask), ptr(out), ptr(lse), B, H, S, dh, scale, drop_p, drop_seed, ptr(cu),
+                                    dtype, stream_ptr()), "mmrca_mha_cls_fwd")
 
 
-def mha_cls_bwd(qkv, key_mask, out, dout, lse, dqkv, B, H, S, dh, scale, dtype, drop_p=0.0, drop_seed=0):
+def mha_cls_bwd(qkv, key_mask, out, dout, lse, dqkv, B, H, S, dh, scale, dtype, drop_p=0.0, drop_seed=0, cu=None):
     _check(load().mmrca_mha_cls_bwd(ptr(qkv), ptr(key_mask), ptr(out), ptr(dout), ptr(lse), ptr(dqkv), B, H, S, dh, scale,
-                                    drop_p, drop_seed, dtype, stream_ptr()), "mmrca_mha_cls_bwd")
+                                    drop_p, drop_seed, ptr(cu), dtype, stream_ptr()), "mmrca_mha_cls_bwd")
 
 
 def add_layernorm_fwd(x, res, gamma, beta, sum_out, y, mean, rstd, rows, D, ld_x, ld_y, eps, dtype,

@@ -74,32 +74,38 @@ int mmrca_gelu_bwd(const void* dG, const void* H, void* dH, int64_t n, int dtype
 int mmrca_gelu_bwd_colsum(const void* dG, const void* H, void* dH, float* db, int64_t M, int64_t N, int64_t ld,
                           int dtype, void* stream);
 
-/* K3. Multi-head attention over a fused QKV buffer [B*S, 3*H*dh] (q | k | v column blocks; head h at
- * columns h*dh).  out[B*S, H*dh].  key_mask (optional): int32 [B,S], 0 = masked key; a query row whose
+/* K3. Multi-head attention over a fused QKV buffer [rows, 3*H*dh] (q | k | v column blocks; head h at
+ * columns h*dh).  out[rows, H*dh].  key_mask (optional): int32 per token row, 0 = masked key; a query row whose
  * keys are all masked yields zeros (torch SDPA semantics used by transformers 5.x).  lse: fp32 [B,H,S].
  * Replaces modeling_distilbert.py:122-203 / torchvision MultiheadAttention (QK^T*scale, softmax, PV).
- * drop_p > 0: attention-probability dropout (modeling_distilbert.py:146), mask from (seed, ((b*H+h)*S+q)*S+key). */
+ * drop_p > 0: attention-probability dropout (modeling_distilbert.py:146), mask from (seed, ((b*H+h)*S+q)*S+key).
+ * Token layout: cu_seqlens == NULL -> padded, sequence b = rows [b*S, (b+1)*S).  cu_seqlens = int32 [B+1] (device)
+ * -> packed: sequence b = rows [cu[b], cu[b+1]) (captions stored back to back WITHOUT their padding, lengths <= S);
+ * S then only sizes the kernels and strides the lse / dropout-counter index spaces, which stay those of the padded
+ * layout, so a packed run reproduces the padded run on every kept row. */
 int mmrca_mha_fwd(const void* qkv, const int32_t* key_mask, void* out, float* lse,
                   int B, int H, int S, int dh, float scale, float drop_p, uint64_t drop_seed,
-                  int dtype, int impl, void* stream);
+                  const int32_t* cu_seqlens, int dtype, int impl, void* stream);
 int mmrca_mha_bwd(const void* qkv, const int32_t* key_mask, const void* out, const void* dout, const float* lse,
                   void* dqkv, int B, int H, int S, int dh, float scale, float drop_p, uint64_t drop_seed,
-                  int dtype, int impl, void* stream);
+                  const int32_t* cu_seqlens, int dtype, int impl, void* stream);
 /* mmrca_mha_bwd that also adds the column sums of the stored dqkv to dqkv_colsum[3*H*dh] (fp32, +=): the bias gradient of
- * the QKV in-projection, reduced inside the attention backward instead of by a pass of its own. */
+ * the QKV in-projection, reduced inside the attention backward instead of by a pass of its own.  total_rows = number of
+ * token rows (B*S padded, cu_seqlens[B] packed). */
 int mmrca_mha_bwd_colsum(const void* qkv, const int32_t* key_mask, const void* out, const void* dout, const float* lse,
-                         void* dqkv, float* dqkv_colsum, int B, int H, int S, int dh, float scale, float drop_p,
-                         uint64_t drop_seed, int dtype, int impl, void* stream);
+                         void* dqkv, float* dqkv_colsum, int64_t total_rows, int B, int H, int S, int dh, float scale,
+                         float drop_p, uint64_t drop_seed, const int32_t* cu_seqlens, int dtype, int impl, void* stream);
 /* K3c. The same attention for the class-token query only (row 0 of every sequence): what the LAST encoder layer needs,
  * because the reference reads hidden_state[:, 0] (multimodal_model.py:352,517) / torchvision reads x[:, 0] and nothing else
  * of that layer's output.  out / dout: [B, H*dh] (compact), lse: fp32 [B,H].  The backward fills the WHOLE fused dqkv
  * buffer: dQ row 0, dK / dV of every key row, zeros in dQ rows >= 1.  Equal to row 0 of mmrca_mha_fwd, and to
- * mmrca_mha_bwd with dout zero outside row 0 (same mask and dropout-counter semantics). */
+ * mmrca_mha_bwd with dout zero outside row 0 (same mask, dropout-counter and cu_seqlens semantics). */
 int mmrca_mha_cls_fwd(const void* qkv, const int32_t* key_mask, void* out, float* lse,
-                      int B, int H, int S, int dh, float scale, float drop_p, uint64_t drop_seed, int dtype, void* stream);
+                      int B, int H, int S, int dh, float scale, float drop_p, uint64_t drop_seed,
+                      const int32_t* cu_seqlens, int dtype, void* stream);
 int mmrca_mha_cls_bwd(const void* qkv, const int32_t* key_mask, const void* out, const void* dout, const float* lse,
                       void* dqkv, int B, int H, int S, int dh, float scale, float drop_p, uint64_t drop_seed,
-                      int dtype, void* stream);
+                      const int32_t* cu_seqlens, int dtype, void* stream);
 
 /* K4. s = x (+ res);  y = LayerNorm(s) * gamma + beta.  sum_out (optional) receives s.  mean/rstd fp32 [rows].
  * Row r of x/res/sum_out/y starts at r*ld_* elements (lets the ViT final norm run on class tokens only).

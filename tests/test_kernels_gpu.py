@@ -479,6 +479,53 @@ def test_class_token_attention_equals_row0_of_full_attention(dt, S, dh, masked, 
     assert float(dqkv_c.view(B, S, 3, H * dh)[:, 1:, 0].abs().max()) == 0.0
 
 
+@pytest.mark.parametrize("dt,impl", [(torch.float32, L.IMPL_REF), (torch.bfloat16, L.IMPL_REF), (torch.bfloat16, L.IMPL_AUTO)])
+@pytest.mark.parametrize("S,p", [(64, 0.0), (64, 0.1), (200, 0.0)])
+def test_attention_packed_layout_reproduces_the_padded_run(dt, impl, S, p):
+    """cu_seqlens: captions stored back to back without their padding give, on every kept row, what the padded layout
+    with a prefix key mask gives (same dropout counters); also for the class-token kernels and the fused bias column sums."""
+    B, H, dh, seed = 5, 3, 64, 21
+    lens = torch.tensor([S, 1, S // 2, 7, S - 3])
+    mask = (torch.arange(S)[None, :] < lens[:, None]).int().cuda()
+    keep = mask.bool().view(-1)
+    cu = torch.cat([torch.zeros(1, dtype=torch.int64), lens.cumsum(0)]).int().cuda()
+    Mv = int(lens.sum())
+    sc, code = 1 / math.sqrt(dh), L.dtype_code(dt)
+    qkv = dev(torch.randn(B * S, 3 * H * dh), dt)
+    qkv_p = torch.zeros(Mv + 128, 3 * H * dh, device="cuda", dtype=dt); qkv_p[:Mv] = qkv[keep]
+    out, lse = torch.zeros(B * S, H * dh, device="cuda", dtype=dt), torch.zeros(B, H, S, device="cuda")
+    L.mha_fwd(qkv, mask, out, lse, B, H, S, dh, sc, code, impl, drop_p=p, drop_seed=seed)
+    out_p, lse_p = torch.zeros(Mv + 128, H * dh, device="cuda", dtype=dt), torch.zeros(B, H, S, device="cuda")
+    L.mha_fwd(qkv_p, None, out_p, lse_p, B, H, S, dh, sc, code, impl, drop_p=p, drop_seed=seed, cu=cu)
+    tol = 1e-5 if dt == torch.float32 else 1e-2
+    assert rel_err(out_p[:Mv], out[keep]) < tol
+    valid_q = mask.bool()[:, None, :].expand(B, H, S)
+    assert rel_err(lse_p[valid_q], lse[valid_q]) < 1e-5
+    dout = dev(torch.randn(B * S, H * dh), dt) * keep[:, None]          # no gradient enters at padding rows
+    dout_p = torch.zeros(Mv + 128, H * dh, device="cuda", dtype=dt); dout_p[:Mv] = dout[keep]
+    dqkv, db = torch.zeros_like(qkv), torch.zeros(3 * H * dh, device="cuda")
+    L.mha_bwd(qkv, mask, out, dout, lse, dqkv, B, H, S, dh, sc, code, impl, drop_p=p, drop_seed=seed, colsum=db)
+    dqkv_p, db_p = torch.full_like(qkv_p, float("nan")), torch.zeros(3 * H * dh, device="cuda")
+    L.mha_bwd(qkv_p, None, out_p, dout_p, lse_p, dqkv_p, B, H, S, dh, sc, code, impl, drop_p=p, drop_seed=seed, colsum=db_p,
+              cu=cu, rows=Mv)
+    gtol = 1e-4 if dt == torch.float32 else 2e-2
+    assert torch.isfinite(dqkv_p[:Mv].float()).all()
+    assert rel_err(dqkv_p[:Mv], dqkv[keep]) < gtol
+    assert rel_err(db_p, dqkv[keep].float().sum(0)) < (1e-4 if dt == torch.float32 else 1e-2)
+    # class-token kernels in the packed layout
+    first = cu[:-1].long()
+    oc, lc = torch.zeros(B, H * dh, device="cuda", dtype=dt), torch.zeros(B, H, device="cuda")
+    L.mha_cls_fwd(qkv_p, None, oc, lc, B, H, S, dh, sc, code, drop_p=p, drop_seed=seed, cu=cu)
+    assert rel_err(oc, out_p[first]) < tol and rel_err(lc, lse_p[:, :, 0]) < 1e-5
+    dout_c = dev(torch.randn(B, H * dh), dt)
+    dfull = torch.zeros_like(dout_p); dfull[first] = dout_c
+    ref = torch.zeros_like(qkv_p)
+    L.mha_bwd(qkv_p, None, out_p, dfull, lse_p, ref, B, H, S, dh, sc, code, impl, drop_p=p, drop_seed=seed, cu=cu)
+    got = torch.full_like(qkv_p, float("nan"))
+    L.mha_cls_bwd(qkv_p, None, oc, dout_c, lc, got, B, H, S, dh, sc, code, drop_p=p, drop_seed=seed, cu=cu)
+    assert torch.isfinite(got[:Mv].float()).all() and rel_err(got[:Mv], ref[:Mv]) < gtol
+
+
 # ------------------------------------------------------------------------------------------------------
 # train-mode dropout of the text encoder (counter-based masks shared by forward and backward)
 # ------------------------------------------------------------------------------------------------------
