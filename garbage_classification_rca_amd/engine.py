@@ -78,6 +78,46 @@ class Arena:
         return a, off + n
 
 
+class TextPack:
+    """Packed (unpadded) token layout of one caption batch: the rows the text encoder works on are the live tokens of
+    every caption stored back to back -- padding rows are dead work under class-token pooling with masked keys (their
+    outputs are never read, their gradients are exact zeros).  ``perm`` [M] = index of each packed row in the padded
+    [B*T] layout, ``cu`` [B+1] = cumulative lengths, ``mask`` [M] = key mask per packed row, ``first`` [B] = row of
+    each caption's class token.  M is rounded up to a multiple of 64 with padding rows of captions that have room
+    (masked keys like in the padded layout), so the weight-gradient GEMMs see whole 64-row K steps."""
+
+    def __init__(self, perm, cu, mask, first, M, B, T):
+        self.perm, self.cu, self.mask, self.first, self.M, self.B, self.T = perm, cu, mask, first, M, B, T
+
+
+def make_text_pack(attention_mask, device) -> Optional["TextPack"]:
+    """Build the packed layout from a HOST attention mask [B,T] (numpy / CPU tensor: what a DataLoader hands over, so no
+    device sync is involved).  Returns None when packing does not apply: a mask that is not a non-empty prefix of ones
+    per caption (e.g. a caption zeroed by modality dropout), or B*T not a multiple of 64."""
+    import numpy as np
+    m = np.asarray(attention_mask.cpu() if isinstance(attention_mask, torch.Tensor) else attention_mask) != 0
+    B, T = m.shape
+    lens = m.sum(1)
+    if (B * T) % 64 != 0 or (lens < 1).any() or not (m == (np.arange(T)[None, :] < lens[:, None])).all():
+        return None
+    total = int(lens.sum())
+    extra = _round_up(total, 64) - total
+    ext = lens.astype(np.int64).copy()
+    for b in range(B - 1, -1, -1):
+        if extra == 0:
+            break
+        take = min(extra, T - int(ext[b]))
+        ext[b] += take
+        extra -= take
+    cu = np.zeros(B + 1, dtype=np.int64)
+    cu[1:] = np.cumsum(ext)
+    M = int(cu[-1])
+    within = np.arange(M) - np.repeat(cu[:-1], ext)
+    perm = np.repeat(np.arange(B) * T, ext) + within
+    to = lambda a, dt: torch.from_numpy(np.ascontiguousarray(a)).to(dt).to(device)
+    return TextPack(to(perm, torch.int64), to(cu, torch.int32), to(m.reshape(-1)[perm], torch.int32), to(cu[:-1], torch.int64), M, B, T)
+
+
 class MMRCAEngine:
     """Owns parameters, gradients and activations of one MM-RCA replica on one GPU."""
 
@@ -319,10 +359,10 @@ class MMRCAEngine:
         return (base * 1000003 + layer * 16 + site + 0x9E3779B97F4A7C15) & 0xFFFFFFFFFFFFFFFF
 
     # ------------------------------------------------------------------ text encoder
-    def _text_forward(self, ids, mask, save, drop_p: float = 0.0, drop_seed: int = 0):
+    def _text_forward(self, ids, mask, save, drop_p: float = 0.0, drop_seed: int = 0, pack: Optional[TextPack] = None):
         s, P = self.ts, "text_model."
         B, T = ids.shape
-        M, D, Fd, H = B * T, s.dim, s.ffn, s.heads
+        cap, D, Fd, H = B * T, s.dim, s.ffn, s.heads          # buffers are sized for the padded layout
         dh = D // H
         ids32 = ids.to(torch.int32).contiguous().view(-1)
         if s.pos_offset:
@@ -330,9 +370,17 @@ class MMRCAEngine:
             pos = (torch.cumsum(nonpad, dim=1) * nonpad + s.pad_id).to(torch.int32).contiguous().view(-1)
         else:
             pos = torch.arange(T, device=ids.device, dtype=torch.int32).repeat(B)
-        mask32 = mask.to(torch.int32).contiguous()
-        fb = lambda name, cols, l=0, dt=None: self.buf("t_" + name, M, cols, dt, l if save else 0)
-        stat = lambda name, l=0: self.buf("t_" + name, 1, _round_up(M, ROWPAD), torch.float32, l if save else 0)
+        if pack is not None:
+            if (pack.B, pack.T) != (B, T):
+                raise L.MmrcaError(f"text pack was built for a [{pack.B},{pack.T}] batch, got [{B},{T}]")
+            M, cu, first = pack.M, pack.cu, pack.first
+            ids32, pos, mask32 = ids32[pack.perm].contiguous(), pos[pack.perm].contiguous(), pack.mask
+        else:
+            M, cu = cap, None
+            first = torch.arange(B, device=ids.device, dtype=torch.int64) * T
+            mask32 = mask.to(torch.int32).contiguous()
+        fb = lambda name, cols, l=0, dt=None: self.buf("t_" + name, cap, cols, dt, l if save else 0)
+        stat = lambda name, l=0: self.buf("t_" + name, 1, _round_up(cap, ROWPAD), torch.float32, l if save else 0)
         emb = fb("emb", D)
         type_row = self.Wflat(P + "embeddings.token_type_embeddings.weight", D) if s.type_vocab else None
         L.embed_fwd(ids32, pos, self.W(P + "embeddings.word_embeddings.weight"), self.W(P + "embeddings.position_embeddings.weight"),
@@ -353,8 +401,8 @@ class MMRCAEngine:
                 cb = lambda name, cols, dt=None: self.buf("t_" + name + "_c", B, cols, dt, i if save else 0)
                 ctx_c, x_c = cb("ctx", D), cb("xin", D)
                 lse = self.buf("t_lse_c", 1, _round_up(B * H, ROWPAD), torch.float32, i if save else 0)
-                L.mha_cls_fwd(qkv, mask32, ctx_c, lse, B, H, T, dh, dh ** -0.5, self.dt, drop_p=dp, drop_seed=sd(i, 1))
-                x_c[:B].copy_(x[:M].view(B, T, D)[:, 0])
+                L.mha_cls_fwd(qkv, mask32, ctx_c, lse, B, H, T, dh, dh ** -0.5, self.dt, drop_p=dp, drop_seed=sd(i, 1), cu=cu)
+                x_c[:B].copy_(x.index_select(0, first))
                 att = cb("att", D)
                 self._lin_fwd(ctx_c, P + K["o"] + ".weight", P + K["o"] + ".bias", att, B, D, D)
                 s1, x1 = cb("s1", D), cb("x1", D)
@@ -370,9 +418,9 @@ class MMRCAEngine:
                 layers.append(dict(x=x, qkv=qkv, ctx=ctx, lse=lse, s1=s1, x1=x1, m1=m1, r1=r1, h=h, g=g, s2=s2, m2=m2, r2=r2,
                                    ctx_c=ctx_c, tail=True))
                 cls = xn[:B].clone()
-                return cls, dict(B=B, T=T, ids32=ids32, pos=pos, mask32=mask32, emb=emb, mean0=mean0, rstd0=rstd0, layers=layers,
+                return cls, dict(B=B, T=T, M=M, cu=cu, first=first, ids32=ids32, pos=pos, mask32=mask32, emb=emb, mean0=mean0, rstd0=rstd0, layers=layers,
                                  drop_p=dp, drop_seed=drop_seed)
-            L.mha_fwd(qkv, mask32, ctx, lse, B, H, T, dh, dh ** -0.5, self.dt, self.attn_impl, drop_p=dp, drop_seed=sd(i, 1))
+            L.mha_fwd(qkv, mask32, ctx, lse, B, H, T, dh, dh ** -0.5, self.dt, self.attn_impl, drop_p=dp, drop_seed=sd(i, 1), cu=cu)
             att = fb("tmpD", D)
             self._lin_fwd(ctx, P + K["o"] + ".weight", P + K["o"] + ".bias", att, M, D, D)
             s1, x1 = fb("s1", D, i), fb("x1", D, i)
@@ -387,21 +435,21 @@ class MMRCAEngine:
             self._ln_fwd(f, x1, P + K["ln2"], s2, xn, m2, r2, M, D, s.ln_eps, in_drop=(dp, sd(i, 3)))
             layers.append(dict(x=x, qkv=qkv, ctx=ctx, lse=lse, s1=s1, x1=x1, m1=m1, r1=r1, h=h, g=g, s2=s2, m2=m2, r2=r2))
             x = xn
-        cls = x[:M].view(B, T, D)[:, 0].contiguous()
-        return cls, dict(B=B, T=T, ids32=ids32, pos=pos, mask32=mask32, emb=emb, mean0=mean0, rstd0=rstd0, layers=layers,
+        cls = x.index_select(0, first)
+        return cls, dict(B=B, T=T, M=M, cu=cu, first=first, ids32=ids32, pos=pos, mask32=mask32, emb=emb, mean0=mean0, rstd0=rstd0, layers=layers,
                          drop_p=dp, drop_seed=drop_seed)
 
     def _text_backward(self, dcls, sv):
         s, P = self.ts, "text_model."
         B, T = sv["B"], sv["T"]
-        M, D, Fd, H = B * T, s.dim, s.ffn, s.heads
-        dh = D // H
-        gb = lambda name, cols: self.buf("tg_" + name, M, cols)
+        M, D, Fd, H = sv["M"], s.dim, s.ffn, s.heads
+        dh, cu, first = D // H, sv["cu"], sv["first"]
+        gb = lambda name, cols: self.buf("tg_" + name, B * T, cols)
         dx = gb("dxA", D)
         tail = bool(sv["layers"][-1].get("tail"))
         if not tail:
             dx[:M].zero_()
-            dx[:M].view(B, T, D)[:, 0] = dcls
+            dx.index_copy_(0, first, dcls.to(dx.dtype))
         for i in reversed(range(s.layers)):
             if tail and i == s.layers - 1:
                 self._text_backward_tail(dcls, sv, dx)
@@ -431,7 +479,7 @@ class MMRCAEngine:
             # the attention backward also reduces the q|k|v bias gradients (adjacent in the arena) while it has the tiles
             qkv_db = None if FUSE_BIAS_GRAD else self.Gflat(P + K["q"] + ".bias", 3 * D)
             L.mha_bwd(a["qkv"], sv["mask32"], a["ctx"], dctx, a["lse"], dqkv, B, H, T, dh, dh ** -0.5, self.dt, self.attn_impl,
-                      drop_p=dp, drop_seed=sd(i, 1), colsum=qkv_db)
+                      drop_p=dp, drop_seed=sd(i, 1), colsum=qkv_db, cu=cu, rows=M)
             self._wait_first_wgrad()       # (the FFN2 weight gradient does not read dx in the post-LN layout; harmless)
             self._lin_bwd(dqkv, a["x"], P + K["q"] + ".weight", P + K["q"] + ".bias", dx, M, 3 * D, D, addend=ds1, wnumel=3 * D * D,
                           bias_done=qkv_db is not None)
@@ -451,10 +499,10 @@ class MMRCAEngine:
         """Backward of the LAST text layer when its post-attention part ran on the class-token rows only (CLS_TAIL)."""
         s, P = self.ts, "text_model."
         B, T = sv["B"], sv["T"]
-        M, D, Fd, H = B * T, s.dim, s.ffn, s.heads
-        dh, i = D // H, s.layers - 1
+        M, D, Fd, H = sv["M"], s.dim, s.ffn, s.heads
+        dh, i, cu, first = D // H, s.layers - 1, sv["cu"], sv["first"]
         K, a = S.text_layer_keys(s, i), sv["layers"][i]
-        gb = lambda name, cols: self.buf("tg_" + name, M, cols)
+        gb = lambda name, cols: self.buf("tg_" + name, B * T, cols)
         gc = lambda name, cols: self.buf("tg_" + name + "_c", B, cols)
         dp, sd = sv["drop_p"], (lambda layer, site: self._site_seed(sv["drop_seed"], layer, site))
         post_attn_drop = dp if s.name != "distilbert" else 0.0
@@ -480,10 +528,10 @@ class MMRCAEngine:
         # back to all rows: the attention mixes the class-token gradient into every key / value row
         ds1_full = gb("ds1", D)
         ds1_full[:M].zero_()
-        ds1_full[:M].view(B, T, D)[:, 0] = ds1[:B]
+        ds1_full.index_copy_(0, first, ds1[:B])
         dqkv = gb("dqkv", 3 * D)
         L.mha_cls_bwd(a["qkv"], sv["mask32"], a["ctx_c"], dctx_c, a["lse"], dqkv, B, H, T, dh, dh ** -0.5, self.dt,
-                      drop_p=dp, drop_seed=sd(i, 1))
+                      drop_p=dp, drop_seed=sd(i, 1), cu=cu)
         self._lin_bwd(dqkv, a["x"], P + K["q"] + ".weight", P + K["q"] + ".bias", dx, M, 3 * D, D, addend=ds1_full, wnumel=3 * D * D)
         self._layer_boundary()
         self._ready(f"text_layer_{i}")
@@ -637,8 +685,10 @@ class MMRCAEngine:
         self._ready(f"image_layer_{i}")
 
     # ------------------------------------------------------------------ whole model
-    def forward(self, ids, mask, images, drop_p: float = 0.0, seed: int = 0, save: bool = True, enc_drop_p: float = 0.0):
-        """ids/mask int64 [B,S] and images fp32 [B,3,H,W] in HBM -> logits fp32 [B, n_classes]."""
+    def forward(self, ids, mask, images, drop_p: float = 0.0, seed: int = 0, save: bool = True, enc_drop_p: float = 0.0,
+                text_pack: Optional[TextPack] = None):
+        """ids/mask int64 [B,S] and images fp32 [B,3,H,W] in HBM -> logits fp32 [B, n_classes].
+        text_pack (``make_text_pack`` of the same batch's host-side mask): run the text encoder on the live tokens only."""
         for t, nm in ((ids, "input ids"), (mask, "attention mask"), (images, "images")):
             if not t.is_cuda:
                 raise L.MmrcaError(f"{nm} must be in HBM; the MM-RCA product path has no CPU fallback")
@@ -648,12 +698,12 @@ class MMRCAEngine:
         if self._text_stream is not None:
             self._text_stream.wait_stream(main)
             with torch.cuda.stream(self._text_stream):
-                cls, tsv = self._text_forward(ids, mask, save, enc_drop_p, int(seed))
+                cls, tsv = self._text_forward(ids, mask, save, enc_drop_p, int(seed), text_pack)
             feat, vsv = self._vision_forward(images, save)
             main.wait_stream(self._text_stream)
             cls.record_stream(main)
         else:
-            cls, tsv = self._text_forward(ids, mask, save, enc_drop_p, int(seed))
+            cls, tsv = self._text_forward(ids, mask, save, enc_drop_p, int(seed), text_pack)
             feat, vsv = self._vision_forward(images, save)
         logits = torch.empty(B, self.n_classes, dtype=torch.float32, device=self.device)
         L.head_fwd(feat, cls, self._head_w, logits, B, self.d_img, self.d_txt, self.n_classes, self.reverse, self.mode,

@@ -14,7 +14,13 @@ from typing import List, Optional, Sequence
 
 import torch
 
+import os
+
 from . import lib as L
+from .engine import make_text_pack
+
+# run the text encoder on the live tokens only (engine.TextPack); "0" keeps the padded [B*T] layout
+PACK_TEXT = os.environ.get("MMRCA_PACK_TEXT", "1") == "1"
 
 mode_config_dict = {      # main_both.py:43-47
     'image_only': {"remove_text": True, "remove_image": False},
@@ -45,17 +51,20 @@ class FusedCrossEntropy:
 
 
 def hip_train_step(model, ids, mask, images, labels, criterion: FusedCrossEntropy, optimizer=None, grad_sync=None,
-                   do_step: bool = True):
+                   do_step: bool = True, text_pack=None):
     """forward -> loss -> backward (-> gradient all-reduce) -> optimizer step -> zero grads, all on the current
-    stream without a host sync.  Returns the device loss tensor."""
+    stream without a host sync.  Returns the device loss tensor.
+    text_pack: ``engine.make_text_pack(host_mask, device)`` of this batch -- the text encoder then skips the padding rows."""
     eng = model.engine
     model._images, model._input_ids, model._attention_mask = images, ids, mask
     model.drop_modalities(False, False, False)
+    if model._input_ids is not ids:
+        text_pack = None                       # modality dropout zeroed the captions: the pack no longer describes them
     tt, ti = model._train_flags()
     model._fwd_count += 1
     logits = eng.forward(model._input_ids, model._attention_mask, model._images,
                          model.drop_ratio if model.training else 0.0, model._drop_seed + model._fwd_count, save=(tt or ti),
-                         enc_drop_p=(model.enc_dropout if model.training else 0.0))
+                         enc_drop_p=(model.enc_dropout if model.training else 0.0), text_pack=text_pack)
     loss, dlogits = criterion(logits, labels)
     if grad_sync is not None:
         grad_sync.enabled = bool(do_step)
@@ -88,6 +97,8 @@ def run_one_epoch(epoch_num, model, data_loader, len_train_data, hw_device, batc
     for batch_idx, (data, labels) in enumerate(data_loader):
         images = data['image']['raw_image'].to(hw_device, non_blocking=True)
         texts = data['text']
+        # the mask is still on the host here: build the packed token layout without a device sync
+        pack = make_text_pack(texts['attention_mask'], hw_device) if (fused and PACK_TEXT and not texts['attention_mask'].is_cuda) else None
         ids = texts['tokens'].to(hw_device, non_blocking=True)
         mask = texts['attention_mask'].to(hw_device, non_blocking=True)
         labels = labels.to(hw_device, non_blocking=True)
@@ -96,7 +107,7 @@ def run_one_epoch(epoch_num, model, data_loader, len_train_data, hw_device, batc
         else:
             do_step = True
         if fused:
-            loss = hip_train_step(model, ids, mask, images, labels, criterion, train_optimizer, grad_sync, do_step)[0]
+            loss = hip_train_step(model, ids, mask, images, labels, criterion, train_optimizer, grad_sync, do_step, text_pack=pack)[0]
         else:
             out = model(_input_ids=ids, _attention_mask=mask, _images=images)
             loss = criterion(out, labels)

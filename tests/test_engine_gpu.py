@@ -137,6 +137,78 @@ def test_class_token_tail_equals_full_top_layer(dtype, tol, cos_min, monkeypatch
             assert float((a - b).abs().max()) <= tol * float(b.abs().max()), name
 
 
+@pytest.mark.parametrize("dtype,tol,cos_min", [(torch.float32, 2e-4, 1 - 1e-6), (torch.bfloat16, 2e-2, 0.995)])
+@pytest.mark.parametrize("tail", [True, False])
+@pytest.mark.parametrize("text", ["distilbert", "roberta"])
+def test_packed_text_layout_equals_padded(dtype, tol, cos_min, tail, text, monkeypatch):
+    """engine.TextPack (text encoder on the live tokens only) must not change logits or any parameter gradient."""
+    from garbage_classification_rca_amd import engine as E
+    if text == "roberta" and (dtype == torch.bfloat16 or not tail):
+        pytest.skip("roberta: one configuration is enough (position ids from the pad pattern)")
+    monkeypatch.setattr(E, "CLS_TAIL", tail)
+    B, S_len = 8, 32                                  # B*T % 64 == 0
+    ids, mask = synth_captions(B, S_len, seed=77)
+    if text == "roberta":
+        ids = np.where(mask > 0, ids, 1)              # roberta pads with id 1
+    images = proc_input("e2e.images", (B, 3, 224, 224))
+    ids_t, mask_t, images_t = torch.from_numpy(ids), torch.from_numpy(mask), torch.from_numpy(images)
+    pack = E.make_text_pack(mask, "cuda")
+    assert pack is not None and pack.M % 64 == 0 and pack.M < B * S_len
+    gen = torch.Generator().manual_seed(1)
+    dfeat = (torch.randn(B, 768, generator=gen) * 0.1).cuda().to(dtype)
+    dcls = (torch.randn(B, 768, generator=gen) * 0.1).cuda().to(dtype)
+    out = {}
+    for packed in (True, False):
+        eng = MMRCAEngine(text, "transformer_B16", 4, True, 0, dtype)
+        eng.load_arrays(proc_state_for(eng))
+        logits = eng.forward(ids_t.cuda(), mask_t.cuda(), images_t.cuda(), enc_drop_p=0.0, text_pack=(pack if packed else None))
+        eng.arena.g.zero_()
+        eng._vision_backward(dfeat, eng._saved["vision"])
+        eng._text_backward(dcls, eng._saved["text"])
+        torch.cuda.synchronize()
+        out[packed] = (logits.float().clone(), eng.arena.g.clone(), dict(eng.groups))
+        eng.release_buffers()
+    assert rel(out[True][0], out[False][0]) < tol
+    for name, (lo, hi) in out[True][2].items():
+        a, b = out[True][1][lo:hi], out[False][1][lo:hi]
+        if float(b.norm()) == 0:
+            assert float(a.norm()) == 0, name
+            continue
+        cos = float(torch.nn.functional.cosine_similarity(a, b, dim=0))
+        assert cos > cos_min, (name, cos)
+        if dtype == torch.float32:
+            assert float((a - b).abs().max()) <= tol * float(b.abs().max()), name
+
+
+def test_packed_text_layout_in_the_fused_train_step_with_encoder_dropout():
+    """hip_train_step with a pack, train mode (hidden / attention dropout on): runs, repeats, loss is finite."""
+    from garbage_classification_rca_amd import engine as E
+    from garbage_classification_rca_amd.multimodal_model import MM_RCA
+    from garbage_classification_rca_amd.optim import FlatSGD
+    from garbage_classification_rca_amd.training import FusedCrossEntropy, hip_train_step
+    B, S_len = 8, 32
+    ids, mask = synth_captions(B, S_len, seed=78)
+    pack = E.make_text_pack(mask, "cuda")
+    images = torch.from_numpy(proc_input("e2e.images", (B, 3, 224, 224))).cuda()
+    ids_t, mask_t = torch.from_numpy(ids).cuda(), torch.from_numpy(mask).cuda()
+    labels = (torch.arange(B) % 4).int().cuda()
+    losses = []
+    for rep in range(2):
+        import contextlib, io
+        with contextlib.redirect_stdout(io.StringIO()):
+            m = MM_RCA(4, 0.6, 0.0, 0.7, 256, "distilbert", B, True, False, False, image_model_name="transformer_B16",
+                       dtype=torch.bfloat16, device=torch.device("cuda"), init_seed=0)
+        m.train()
+        for p in m.parameters():
+            p.requires_grad = True
+        opt, crit = FlatSGD(m, lr=1e-3, weight_decay=1e-2), FusedCrossEntropy(None, 0.0)
+        ls = [float(hip_train_step(m, ids_t, mask_t, images, labels, crit, opt, None, text_pack=pack)) for _ in range(3)]
+        assert all(np.isfinite(ls))
+        losses.append(ls)
+        m.engine.release_buffers()
+    assert np.allclose(losses[0], losses[1], rtol=1e-5)      # same masks; fp32 atomics order the weight-gradient sums
+
+
 @pytest.mark.parametrize("mode", [0, 2])
 def test_fp32_logits_and_gradients_match_oracle(mode):
     B, S_len = 3, 24

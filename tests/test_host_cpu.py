@@ -313,3 +313,30 @@ def test_test_split_evaluator_logic_on_cpu():
         csvp, pngp = E.generate_report_and_image(rd, acc, cm, "always_both", out_dir=td)
         assert os.path.basename(csvp) == "multimodal_model_report_test_set_acc_{:.2f}_always_both.csv".format(acc)
         assert os.path.exists(csvp)
+
+
+def test_make_text_pack_layout_and_fallbacks():
+    """engine.make_text_pack: live tokens back to back, total rounded up to 64 with padding rows of captions that have
+    room, class-token rows first in each caption; None when packing does not apply."""
+    from garbage_classification_rca_amd.engine import make_text_pack
+    B, T = 8, 32
+    lens = np.array([32, 5, 17, 1, 32, 9, 20, 3])
+    mask = (np.arange(T)[None, :] < lens[:, None]).astype(np.int64)
+    p = make_text_pack(mask, "cpu")
+    assert p is not None and p.M == 128 and p.M % 64 == 0 and p.M >= lens.sum()
+    cu, perm, km, first = p.cu.numpy(), p.perm.numpy(), p.mask.numpy(), p.first.numpy()
+    assert cu[0] == 0 and cu[-1] == p.M and (np.diff(cu) >= lens).all() and (np.diff(cu) <= T).all()
+    assert (first == cu[:-1]).all() and (perm[first] == np.arange(B) * T).all()
+    for b in range(B):
+        rows = perm[cu[b]:cu[b + 1]]
+        assert (rows == b * T + np.arange(len(rows))).all()              # a prefix of caption b, in order
+        assert km[cu[b]:cu[b + 1]].sum() == lens[b]                      # the padding rows taken in are masked keys
+    assert km.sum() == lens.sum()
+    assert make_text_pack(torch.from_numpy(mask), "cpu").M == p.M       # tensors work too
+    holes = mask.copy(); holes[2, 3] = 0
+    assert make_text_pack(holes, "cpu") is None                           # not a prefix mask
+    dropped = mask.copy(); dropped[4] = 0
+    assert make_text_pack(dropped, "cpu") is None                         # a caption zeroed by modality dropout
+    assert make_text_pack(mask[:3, :24], "cpu") is None                   # B*T not a multiple of 64
+    full = np.ones((2, 32), dtype=np.int64)
+    assert make_text_pack(full, "cpu").M == 64                            # nothing to skip: identity layout
