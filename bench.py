@@ -132,6 +132,7 @@ def main():
     # does per batch without a device sync): the text encoder skips the padding rows (engine.TextPack)
     from garbage_classification_rca_amd.engine import make_text_pack
     from garbage_classification_rca_amd.training import PACK_TEXT
+    from garbage_classification_rca_amd.engine import CLS_TAIL as E_CLS_TAIL
     packs = [make_text_pack(mask_host[k * B:(k + 1) * B], dev) if PACK_TEXT else None for k in range(nb)]
     live = sum(p.M for p in packs) / (nb * B * S) if all(p is not None for p in packs) else 1.0
 
@@ -219,7 +220,9 @@ def main():
             "config": {"workload": "MM_RCA --reverse ViT-B/16 + DistilBERT, " + ("frozen-backbone" if args.frozen else "fine-tune")
                        + " train step (fwd+loss+bwd+allreduce+SGD), 224x224 images, 64-token captions",
                        "per_gpu_batch": B, "global_batch": B * world, "seq_len": S, "image": 224, "parallelism": f"dp{world}",
-                       "optimizer": "sgd lr=1e-3 wd=1e-2", "random_init": True, "caption_rows_processed": round(live, 3), "final_loss": round(final_loss, 4),
+                       "optimizer": "sgd lr=1e-3 wd=1e-2", "random_init": True, "caption_rows_processed": round(live, 3),
+                       "dead_row_elimination": {"class_token_tail": bool(E_CLS_TAIL), "packed_captions": bool(PACK_TEXT),
+                                                "note": "identical logits and gradients; MMRCA_CLS_TAIL=0 MMRCA_PACK_TEXT=0 runs every row"}, "final_loss": round(final_loss, 4),
                        "host_enqueue_ms_per_step": round(host_enqueue / args.steps * 1e3, 2)},
             "roofline": {"bound": "mfma", "achieved": round(achieved, 2), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
                          "frac": round(achieved / PEAK_BF16_TFLOPS, 4), "traffic": None,

@@ -99,17 +99,6 @@ __device__ __forceinline__ void stage_key_bias(float* kb, const int32_t* __restr
   const int S = (cu_) ? (cu_)[(b_) + 1] - (cu_)[b_] : (Smax_);      \
   if (S <= 0) return;
 
-// column sums of a stored 16x16 output tile in the D^T layout (lane = (row group g, column l16); v = the 4 rows 4g..4g+3
-// of this lane's column): sum over the 16 columns (queries / keys) that are valid, accumulate into 4 LDS floats
-__device__ __forceinline__ void tile_colsum_to_lds(const bf16x4& v, bool valid, float* dst4, int l16) {
-#pragma unroll
-  for (int r = 0; r < 4; ++r) {
-    float x = valid ? (float)v[r] : 0.f;
-    x += __shfl_xor(x, 1, 64); x += __shfl_xor(x, 2, 64); x += __shfl_xor(x, 4, 64); x += __shfl_xor(x, 8, 64);
-    if (l16 == 0) atomicAdd(dst4 + r, x);
-  }
-}
-
 #define LOG2E 1.4426950408889634f
 #define LN2 0.6931471805599453f
 
@@ -215,16 +204,13 @@ template <int NKT, bool DROP, int NW>
 __global__ void __launch_bounds__(64 * NW, NW / 2)
 mha_bwd_dq_mfma_k(const bf16_t* __restrict__ qkv, const int32_t* __restrict__ key_mask, const bf16_t* __restrict__ out,
                   const bf16_t* __restrict__ dout, const float* __restrict__ lse, bf16_t* __restrict__ dqkv,
-                  int H, int Smax, float scale, float drop_p, uint64_t drop_seed, float* __restrict__ dbias,
-                  const int32_t* __restrict__ cu) {
+                  int H, int Smax, float scale, float drop_p, uint64_t drop_seed, const int32_t* __restrict__ cu) {
   const float drop_sc = DROP ? 1.f / (1.f - drop_p) : 1.f;
   extern __shared__ __attribute__((aligned(16))) char sm[];
   constexpr int Spad = NKT * 16;
   char* Kimg = sm; char* Vimg = sm + Spad * 128;
   float* kb = reinterpret_cast<float*>(sm + 2 * Spad * 128);
-  float* cs_lds = kb + Spad;                         // [64] column sums of dQ over this (b,h)'s queries (dbias != nullptr)
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, g = lane >> 4, l16 = lane & 15;
-  if (threadIdx.x < 64) cs_lds[threadIdx.x] = 0.f;
   const int b = blockIdx.x / H, h = blockIdx.x % H;
   AT_SEQ(b, Smax, cu)
   const int64_t ld = 3LL * H * AT_DH, ldo = (int64_t)H * AT_DH;
@@ -284,12 +270,7 @@ mha_bwd_dq_mfma_k(const bf16_t* __restrict__ qkv, const int32_t* __restrict__ ke
 #pragma unroll
       for (int r = 0; r < 4; ++r) v[r] = (bf16_t)(dq[dt][r] * scale);
       if (q < S) *reinterpret_cast<bf16x4*>(drow + dt * 16 + 4 * g) = v;
-      if (dbias) tile_colsum_to_lds(v, q < S, cs_lds + dt * 16 + 4 * g, l16);
     }
-  }
-  if (dbias) {       // in-projection bias gradient: column sums of the stored dQ, one atomic per column per block
-    __syncthreads();
-    if (threadIdx.x < 64) atomicAdd(dbias + h * AT_DH + threadIdx.x, cs_lds[threadIdx.x]);
   }
 }
 
@@ -300,17 +281,14 @@ template <int NKT, bool DROP, int NW>
 __global__ void __launch_bounds__(64 * NW, NW / 2)
 mha_bwd_dkv_mfma_k(const bf16_t* __restrict__ qkv, const int32_t* __restrict__ key_mask, const bf16_t* __restrict__ out,
                    const bf16_t* __restrict__ dout, const float* __restrict__ lse, bf16_t* __restrict__ dqkv,
-                   int H, int Smax, float scale, float drop_p, uint64_t drop_seed, float* __restrict__ dbias,
-                   const int32_t* __restrict__ cu) {
+                   int H, int Smax, float scale, float drop_p, uint64_t drop_seed, const int32_t* __restrict__ cu) {
   const float drop_sc = DROP ? 1.f / (1.f - drop_p) : 1.f;
   extern __shared__ __attribute__((aligned(16))) char sm[];
   constexpr int Spad = NKT * 16;
   char* Qimg = sm; char* Dimg = sm + Spad * 128;
   float* lse_s = reinterpret_cast<float*>(sm + 2 * Spad * 128);     // log-sum-exp in the exp2 domain
   float* dsum_s = lse_s + Spad;
-  float* cs_lds = dsum_s + Spad;                     // [2][64] column sums of dK | dV over this (b,h)'s keys
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, g = lane >> 4, l16 = lane & 15;
-  if (threadIdx.x < 128) cs_lds[threadIdx.x] = 0.f;
   const int b = blockIdx.x / H, h = blockIdx.x % H;
   AT_SEQ(b, Smax, cu)
   const int64_t ld = 3LL * H * AT_DH, ldo = (int64_t)H * AT_DH;
@@ -391,16 +369,7 @@ mha_bwd_dkv_mfma_k(const bf16_t* __restrict__ qkv, const int32_t* __restrict__ k
         *reinterpret_cast<bf16x4*>(krow + dt * 16 + 4 * g) = a;
         *reinterpret_cast<bf16x4*>(vrow + dt * 16 + 4 * g) = c;
       }
-      if (dbias) {
-        tile_colsum_to_lds(a, key < S, cs_lds + dt * 16 + 4 * g, l16);
-        tile_colsum_to_lds(c, key < S, cs_lds + 64 + dt * 16 + 4 * g, l16);
-      }
     }
-  }
-  if (dbias) {
-    __syncthreads();
-    if (threadIdx.x < 128)
-      atomicAdd(dbias + (int64_t)(1 + (threadIdx.x >> 6)) * H * AT_DH + h * AT_DH + (threadIdx.x & 63), cs_lds[threadIdx.x]);
   }
 }
 
@@ -447,8 +416,8 @@ static int pick_nkt(int S) {
     case 16: AT_LAUNCH8(KERNEL, 16, W8_PLAIN, W8_DROP, 2 * 16 * 16 * 128 + EXTRA(16), __VA_ARGS__); break;         \
     default: AT_LAUNCH8(KERNEL, 32, (W8_PLAIN && W8_32), (W8_DROP && W8_32), 2 * 32 * 16 * 128 + EXTRA(32), __VA_ARGS__); break; \
   }
-#define BIAS_EXTRA(n) ((n) * 16 * 4 + 64 * 4)
-#define STAT_EXTRA(n) (2 * (n) * 16 * 4 + 128 * 4)
+#define BIAS_EXTRA(n) ((n) * 16 * 4)
+#define STAT_EXTRA(n) (2 * (n) * 16 * 4)
 
 int mmrca_mha_fwd_mfma(const void* qkv, const int32_t* key_mask, void* out, float* lse, int B, int H, int S, int dh,
                        float scale, float drop_p, uint64_t drop_seed, const int32_t* cu, hipStream_t st) {
@@ -461,14 +430,14 @@ int mmrca_mha_fwd_mfma(const void* qkv, const int32_t* key_mask, void* out, floa
 }
 
 int mmrca_mha_bwd_mfma(const void* qkv, const int32_t* key_mask, const void* out, const void* dout, const float* lse,
-                       void* dqkv, int B, int H, int S, int dh, float scale, float drop_p, uint64_t drop_seed, float* dbias,
+                       void* dqkv, int B, int H, int S, int dh, float scale, float drop_p, uint64_t drop_seed,
                        const int32_t* cu, hipStream_t st) {
   (void)dh;
   MMRCA_REQUIRE((((uintptr_t)qkv) & 15) == 0 && (((uintptr_t)out) & 15) == 0 && (((uintptr_t)dout) & 15) == 0 && (((uintptr_t)dqkv) & 7) == 0,
                 "mha_bwd: buffers must be 16-byte aligned");
   const int nkt = pick_nkt(S);
-  AT_SWITCH(mha_bwd_dq_mfma_k, BIAS_EXTRA, true, true, true, (const bf16_t*)qkv, key_mask, (const bf16_t*)out, (const bf16_t*)dout, lse, (bf16_t*)dqkv, H, S, scale, drop_p, drop_seed, dbias, cu);
-  AT_SWITCH(mha_bwd_dkv_mfma_k, STAT_EXTRA, true, false, true, (const bf16_t*)qkv, key_mask, (const bf16_t*)out, (const bf16_t*)dout, lse, (bf16_t*)dqkv, H, S, scale, drop_p, drop_seed, dbias, cu);
+  AT_SWITCH(mha_bwd_dq_mfma_k, BIAS_EXTRA, true, true, true, (const bf16_t*)qkv, key_mask, (const bf16_t*)out, (const bf16_t*)dout, lse, (bf16_t*)dqkv, H, S, scale, drop_p, drop_seed, cu);
+  AT_SWITCH(mha_bwd_dkv_mfma_k, STAT_EXTRA, true, false, true, (const bf16_t*)qkv, key_mask, (const bf16_t*)out, (const bf16_t*)dout, lse, (bf16_t*)dqkv, H, S, scale, drop_p, drop_seed, cu);
   MMRCA_CHECK_LAUNCH("mha_bwd(mfma)");
   return 0;
 }

@@ -89,9 +89,9 @@ int mmrca_mha_fwd(const void* qkv, const int32_t* key_mask, void* out, float* ls
 int mmrca_mha_bwd(const void* qkv, const int32_t* key_mask, const void* out, const void* dout, const float* lse,
                   void* dqkv, int B, int H, int S, int dh, float scale, float drop_p, uint64_t drop_seed,
                   const int32_t* cu_seqlens, int dtype, int impl, void* stream);
-/* mmrca_mha_bwd that also adds the column sums of the stored dqkv to dqkv_colsum[3*H*dh] (fp32, +=): the bias gradient of
- * the QKV in-projection, reduced inside the attention backward instead of by a pass of its own.  total_rows = number of
- * token rows (B*S padded, cu_seqlens[B] packed). */
+/* mmrca_mha_bwd followed by dqkv_colsum[3*H*dh] (fp32) += column sums of the stored dqkv = the bias gradient of the QKV
+ * in-projection (one call; the reduction is a separate HBM pass -- fusing it into the MFMA kernels measured slower).
+ * total_rows = number of token rows (B*S padded, cu_seqlens[B] packed). */
 int mmrca_mha_bwd_colsum(const void* qkv, const int32_t* key_mask, const void* out, const void* dout, const float* lse,
                          void* dqkv, float* dqkv_colsum, int64_t total_rows, int B, int H, int S, int dh, float scale,
                          float drop_p, uint64_t drop_seed, const int32_t* cu_seqlens, int dtype, int impl, void* stream);

@@ -17,7 +17,9 @@ for name, B, H, S, masked in (("vit", 256, 12, 197, False), ("text", 256, 12, 64
     sc = 1 / math.sqrt(dh)
     def fwd(): L.mha_fwd(qkv, mask, out, lse, B, H, S, dh, sc, L.BF16)
     def bwd(): L.mha_bwd(qkv, mask, out, dout, lse, dqkv, B, H, S, dh, sc, L.BF16)
-    for fn, nm, mult in ((fwd, "fwd", 1.0), (bwd, "bwd", 2.5)):
+    db = torch.zeros(3 * H * dh, device="cuda")
+    def bwd_cs(): L.mha_bwd(qkv, mask, out, dout, lse, dqkv, B, H, S, dh, sc, L.BF16, colsum=db)
+    for fn, nm, mult in ((fwd, "fwd", 1.0), (bwd, "bwd", 2.5), (bwd_cs, "bwd+bias colsum", 2.5)):
         for _ in range(3): fn()
         torch.cuda.synchronize()
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
