@@ -202,6 +202,21 @@ def main():
             d = by_kind.setdefault(kind, [0.0, 0.0, 0])
             d[0] += f; d[1] += e0.elapsed_time(e1); d[2] += 1
         achieved = flops / (ms * 1e-3) / 1e12 if ms > 0 else 0.0
+        # HBM-side bytes per GEMM launch: PMC counters cannot be read in-process, so the committed summary of the two
+        # rocprofv3 --pmc passes over THIS command (tools/pmc_traffic.py) is quoted, next to the algorithmic bytes
+        # (operands once + outputs once, from the launch shapes of this run)
+        traffic, traffic_src = None, None
+        pmc_json = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r01_pmc_hbm_traffic.json")
+        if os.path.exists(pmc_json):
+            with open(pmc_json) as fh:
+                traffic = json.load(fh).get("gemm_hbm_bytes_per_launch_mean")
+            traffic_src = "profiles/r01_pmc_hbm_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes, x2 gfx950 fetch correction)"
+        alg = []
+        for f, kind, e0, e1, shp in prof:
+            Mg, Ng, Kg, actg = shp
+            out_b = 4 if kind[2] else 2
+            alg.append(2.0 * (Mg * Kg + Ng * Kg) + out_b * Mg * Ng * (2 if actg in (L.ACT_GELU, L.ACT_GELU_SAVE_GRAD, L.ACT_MUL) else 1))
+        alg_mean = sum(alg) / max(len(alg), 1)
         if os.environ.get("MMRCA_BENCH_SHAPES") == "1":       # in-situ per-shape table (stderr), for kernel tuning
             by_shape = {}
             for f, kind, e0, e1, shp in prof:
@@ -225,7 +240,9 @@ def main():
                                                 "note": "identical logits and gradients; MMRCA_CLS_TAIL=0 MMRCA_PACK_TEXT=0 runs every row"}, "final_loss": round(final_loss, 4),
                        "host_enqueue_ms_per_step": round(host_enqueue / args.steps * 1e3, 2)},
             "roofline": {"bound": "mfma", "achieved": round(achieved, 2), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
-                         "frac": round(achieved / PEAK_BF16_TFLOPS, 4), "traffic": None,
+                         "frac": round(achieved / PEAK_BF16_TFLOPS, 4), "traffic": traffic,
+                         "traffic_unit": "bytes per GEMM launch (mean over the launches of a step)", "traffic_source": traffic_src,
+                         "algorithmic_bytes_per_launch": round(alg_mean),
                          "kernel": "gemm_mfma_k1s / gemm_mfma_k32 (bf16 16x16x32 MFMA GEMM, 128x128 tiles; every nn.Linear fwd/dgrad/wgrad)",
                          "launches_per_step": len(prof) // replay, "gemm_ms_per_step": round(ms / replay, 3),
                          "measured_in": f"single-stream replay of {replay} steps after the timed region ({round(serial_ms, 2)} ms/step serialized)",
