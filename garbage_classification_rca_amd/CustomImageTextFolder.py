@@ -140,9 +140,15 @@ class DatasetFolder(torch.utils.data.Dataset):
         text_key = "long_text" if self.extended_desc is not None else "text"
         tokens_dict = {"original_text": path[text_key]}
         if self.tokenizer is not None:
-            enc = _tokenize(self.tokenizer, path[text_key], self.tokens_max_len)
-            tokens_dict["tokens"] = enc["input_ids"].flatten()
-            tokens_dict["attention_mask"] = enc["attention_mask"].flatten()
+            # pre-tokenised caption cache: a caption is tokenised once per worker, not once per
+            # epoch -- the result depends only on (caption, max_len), the reference re-runs encode_plus every time (:305-336)
+            cache = self.__dict__.setdefault("_token_cache", {})
+            hit = cache.get(path[text_key])
+            if hit is None:
+                enc = _tokenize(self.tokenizer, path[text_key], self.tokens_max_len)
+                hit = (enc["input_ids"].flatten(), enc["attention_mask"].flatten())
+                cache[path[text_key]] = hit
+            tokens_dict["tokens"], tokens_dict["attention_mask"] = hit[0].clone(), hit[1].clone()
         return {"image": {"raw_image": sample_image, "image_path": path["image"]}, "text": tokens_dict}, target
 
     def __len__(self) -> int:

@@ -50,6 +50,7 @@ _i64, _i32, _f32, _vp, _u64 = C.c_int64, C.c_int, C.c_float, C.c_void_p, C.c_uin
 _SIGS = {
     "mmrca_gemm": [_vp] * 6 + [_i64] * 6 + [_i32] * 6 + [_vp],
     "mmrca_gemm_colsum": [_vp] * 7 + [_i64] * 6 + [_i32] * 5 + [_vp],
+    "mmrca_image_preprocess": [_vp, _vp, _vp, _i32, _i32, _i32, _vp, _vp, _vp],
     "mmrca_colsum_accum": [_vp, _vp, _i64, _i64, _i64, _i32, _vp],
     "mmrca_gelu_bwd": [_vp, _vp, _vp, _i64, _i32, _vp],
     "mmrca_gelu_bwd_colsum": [_vp, _vp, _vp, _vp, _i64, _i64, _i64, _i32, _vp],

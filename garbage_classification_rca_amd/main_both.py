@@ -35,10 +35,12 @@ BASE_PATH = os.getcwd() + os.sep
 
 
 class Transforms:
-    """PIL image -> normalised CHW float tensor at the backbone's input size (validation pipeline of
-    main_both.py:431-440: pad to the target aspect ratio, bilinear resize, ImageNet mean/std).  The training
-    augmentations (albumentations, :407-429) are SURVEY.md section 8 f1 and not part of this build yet; horizontal /
-    vertical flips with probability ``prob_aug`` are applied so that the flag is honoured."""
+    """PIL image -> normalised CHW float tensor at the backbone's input size: the reference's VALIDATION pipeline
+    (main_both.py:433-440) = PadToMaintainAR (keep_aspect_ratio.py:18-53, axis quirk included, see preprocess.py) ->
+    Resize(INTER_LINEAR: half-pixel centres, no antialiasing, uint8 result) -> ImageNet mean/std.  This is the per-sample
+    DataLoader-worker form; ``preprocess.GpuImagePipeline`` is the same arithmetic as one GPU launch per batch.  Of the
+    training augmentations (albumentations, :407-429) only the vertical / horizontal flips with
+    probability ``prob_aug`` are applied."""
     MEAN = torch.tensor([0.485, 0.456, 0.406]).view(3, 1, 1)
     STD = torch.tensor([0.229, 0.224, 0.225]).view(3, 1, 1)
 
@@ -46,18 +48,16 @@ class Transforms:
         self.width, self.height, self.train, self.prob_aug = width, height, train, prob_aug
 
     def __call__(self, img):
-        from PIL import Image
+        from .preprocess import plan_padding
         arr = np.asarray(img.convert("RGB"))
         h, w = arr.shape[:2]
-        ar = self.width / self.height
-        if w / h < ar:                               # pad width (keep_aspect_ratio.py:18-53)
-            new_w = int(round(h * ar)); pad = new_w - w
-            arr = np.pad(arr, ((0, 0), (pad // 2, pad - pad // 2), (0, 0)))
-        elif w / h > ar:
-            new_h = int(round(w / ar)); pad = new_h - h
-            arr = np.pad(arr, ((pad // 2, pad - pad // 2), (0, 0), (0, 0)))
-        im = Image.fromarray(arr).resize((self.width, self.height), Image.BILINEAR)
-        t = torch.from_numpy(np.asarray(im).copy()).permute(2, 0, 1).float() / 255.0
+        pt, pl, ph, pw = plan_padding(h, w, self.width / self.height)
+        if (ph, pw) != (h, w):
+            arr = np.pad(arr, ((pt, ph - h - pt), (pl, pw - w - pl), (0, 0)))
+        t = torch.from_numpy(arr.copy()).permute(2, 0, 1).unsqueeze(0).float()
+        t = torch.nn.functional.interpolate(t, size=(self.height, self.width), mode="bilinear", align_corners=False,
+                                            antialias=False)[0]
+        t = torch.floor(t + 0.5).clamp_(0, 255) / 255.0          # cv2 returns uint8 for a uint8 image
         if self.train:
             if np.random.rand() < self.prob_aug:
                 t = t.flip(1)

@@ -186,6 +186,21 @@ int mmrca_adamw_step(float* p, const float* g, float* m, float* v, void* lp, int
                      float beta2, float eps, float wd, int step, float grad_scale, void* stream);
 int mmrca_cast_f32_to_bf16(const float* src, void* dst, int64_t n, void* stream);
 
+/* K7 (the step before the hot path).  The reference's validation image pipeline
+ * (main_both.py:433-440: PadToMaintainAR keep_aspect_ratio.py:18-53 -> A.Resize(INTER_LINEAR) -> A.Normalize ->
+ * ToTensorV2, plus the train pipeline's V/H flips :416-417) for a batch of decoded uint8 HWC images of different sizes
+ * that sit back to back in one device staging buffer.  out: fp32 [B, 3, out_h, out_w].  The padding itself is decided
+ * on the host (preprocess.py::plan_padding restates the reference's rule, axis quirk included) and passed per image. */
+typedef struct {
+  int64_t offset;            /* byte offset of the image in the staging buffer (uint8, HWC, tightly packed) */
+  int32_t h, w;              /* decoded size */
+  int32_t pad_top, pad_left; /* zeros added before the first row / column */
+  int32_t ph, pw;            /* padded size = what the resize sees */
+  int32_t flip_v, flip_h;    /* A.VerticalFlip / A.HorizontalFlip applied to the resized image */
+} MmrcaImageDesc;
+int mmrca_image_preprocess(const void* staging, const void* desc /* MmrcaImageDesc[B], device */, float* out, int B,
+                           int out_h, int out_w, const float* mean3 /* host */, const float* std3 /* host */, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -234,3 +234,32 @@ def test_weight_stream_checksum(head_g):
     shapes = [(4,), (4, 450), (4,), (4, 16)]
     c = checksum([proc_tensor(k, s) for k, s in zip(keys, shapes)])
     np.testing.assert_allclose(c, float(head_g["e2e_weight_checksum"]), rtol=1e-9)
+
+
+def test_pad_to_maintain_ar_matches_reference_goldens():
+    """oracle/transforms.py::pad_to_maintain_ar against PadToMaintainAR.apply of the reference run as it is
+    (tests/golden/pad_goldens.npz), axis quirk included; the product's plan_padding must describe the same padding."""
+    from oracle import transforms as T
+    from garbage_classification_rca_amd.preprocess import plan_padding
+    g = np.load(os.path.join(G, "pad_goldens.npz"))
+    for k, row in enumerate(g["pad_table"]):
+        img, ref, ar = g[f"pad_in_{k}"], g[f"pad_out_{k}"], float(row[2])
+        got = T.pad_to_maintain_ar(img, ar)
+        assert got.shape == ref.shape and np.array_equal(got, ref), k
+        pt, pl, ph, pw = plan_padding(img.shape[0], img.shape[1], ar)
+        assert (ph, pw) == ref.shape[:2], k
+        assert np.array_equal(ref[pt:pt + img.shape[0], pl:pl + img.shape[1]], img), k
+
+
+def test_host_transforms_equal_the_oracle_validation_pipeline():
+    """main_both.Transforms (DataLoader-worker form) == oracle validation pipeline on odd-sized images."""
+    from PIL import Image
+    from oracle import transforms as T
+    from garbage_classification_rca_amd.main_both import Transforms
+    rng = np.random.RandomState(3)
+    for h, w in ((300, 400), (400, 300), (224, 224), (97, 531), (1000, 64)):
+        img = rng.randint(0, 256, size=(h, w, 3)).astype(np.uint8)
+        got = Transforms(224, 224)(Image.fromarray(img)).numpy()
+        ref = T.validation_pipeline(img, 224, 224)
+        d = np.abs(got - ref)
+        assert d.max() <= 1.0 / 255 / 0.224 + 1e-5 and (d > 1e-5).mean() < 1e-3, (h, w, d.max(), (d > 1e-5).mean())
