@@ -89,6 +89,9 @@ def main():
     ap.add_argument("--seq_len", type=int, default=64)
     ap.add_argument("--no_cpu_baseline", action="store_true")
     ap.add_argument("--frozen", action="store_true", help="time the frozen-backbone phase instead (reported separately)")
+    ap.add_argument("--text_model", default="distilbert", help="distilbert (BASELINE configs[1]) | bert | roberta")
+    ap.add_argument("--image_model", default="transformer_B16", help="transformer_B16 (configs[1]) | transformer_L16")
+    ap.add_argument("--cross_attention_only", action="store_true", help="configs[3]: ViT-L/16 + BERT-base, --seq_len 128")
     args = ap.parse_args()
 
     from garbage_classification_rca_amd import lib as L
@@ -110,8 +113,8 @@ def main():
     import contextlib
     import io
     with contextlib.redirect_stdout(io.StringIO()):
-        model = MM_RCA(4, 0.6, 0.0, 0.7, 256, "distilbert", B, True, False, False, image_model_name="transformer_B16",
-                       dtype=torch.bfloat16, device=dev, init_seed=0)
+        model = MM_RCA(4, 0.6, 0.0, 0.7, 256, args.text_model, B, True, False, args.cross_attention_only,
+                       image_model_name=args.image_model, dtype=torch.bfloat16, device=dev, init_seed=0)
     model.train()
     if not args.frozen:
         for p in model.parameters():
@@ -226,14 +229,19 @@ def main():
                 print(f"[bench] gemm a{kind[0]}b{kind[1]}acc{kind[2]} M={shp[0]} N={shp[1]} K={shp[2]} act={shp[3]}: {v[2] // replay}/step, "
                       f"{v[1] / v[2] * 1e3:.0f} us, {v[0] / (v[1] * 1e-3) / 1e12:.0f} TF, {v[1] / replay:.2f} ms/step", file=sys.stderr, flush=True)
         value = B * world * args.steps / elapsed
-        train_flop_per_sample = (FWD_GFLOP_PER_SAMPLE * (1.0 if args.frozen else 3.0)) * 1e9
+        fwd_gflop = FWD_GFLOP_PER_SAMPLE if (args.text_model, args.image_model, S) == ("distilbert", "transformer_B16", 64) else (
+            145.5 if (args.text_model, args.image_model, S) == ("bert", "transformer_L16", 128) else float("nan"))
+        train_flop_per_sample = (fwd_gflop * (1.0 if args.frozen else 3.0)) * 1e9
         out = {
             "metric": "train samples/sec (image+text pairs), MM-RCA ViT-B16+DistilBERT", "value": round(value, 2),
             "unit": "samples/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(elapsed / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
-            "config": {"workload": "MM_RCA --reverse ViT-B/16 + DistilBERT, " + ("frozen-backbone" if args.frozen else "fine-tune")
-                       + " train step (fwd+loss+bwd+allreduce+SGD), 224x224 images, 64-token captions",
+            "config": {"workload": "MM_RCA --reverse" + (" --cross_attention_only " if args.cross_attention_only else " ")
+                       + {"transformer_B16": "ViT-B/16", "transformer_L16": "ViT-L/16"}[args.image_model] + " + "
+                       + {"distilbert": "DistilBERT", "bert": "BERT-base", "roberta": "RoBERTa-base"}[args.text_model] + ", "
+                       + ("frozen-backbone" if args.frozen else "fine-tune")
+                       + f" train step (fwd+loss+bwd+allreduce+SGD), 224x224 images, {S}-token captions",
                        "per_gpu_batch": B, "global_batch": B * world, "seq_len": S, "image": 224, "parallelism": f"dp{world}",
                        "optimizer": "sgd lr=1e-3 wd=1e-2", "random_init": True, "caption_rows_processed": round(live, 3),
                        "dead_row_elimination": {"class_token_tail": bool(E_CLS_TAIL), "packed_captions": bool(PACK_TEXT),
