@@ -48,6 +48,36 @@ def test_text_encoder_cls_matches_transformers_golden(text_g, name):
     eng.release_buffers()
 
 
+@pytest.mark.parametrize("dtype,tol", [(torch.float32, 1e-3), (torch.bfloat16, 5e-2)])
+def test_text_encoder_at_the_maximum_caption_length(dtype, tol):
+    """S = 512 = max_position_embeddings (multimodal_model.py:410-418: the longest caption the path can see), ragged
+    lengths incl. a length-1 caption, padded and packed layouts, against the oracle text encoder."""
+    from garbage_classification_rca_amd import engine as E
+    B, S_len = 4, 512
+    ids, mask = synth_captions(B, S_len, seed=5)
+    lens = [512, 1, 300, 77]
+    for b, n in enumerate(lens):
+        mask[b, :n], mask[b, n:] = 1, 0
+        ids[b, n:] = 0
+        ids[b, 0] = 101
+    eng = MMRCAEngine("distilbert", "transformer_B16", dtype=dtype)
+    sd = proc_state_for(eng)
+    eng.load_arrays(sd)
+    orc = O.OracleTextEncoder(S.TEXT_SPECS["distilbert"]).eval()
+    orc.load_flat(sd, "text_model.")
+    with torch.no_grad():
+        ref = orc(torch.from_numpy(ids), torch.from_numpy(mask))[:, 0]
+    ids_t, mask_t = torch.from_numpy(ids).cuda(), torch.from_numpy(mask).cuda()
+    eng.refresh_working_copy(force=True)          # (forward() does this; _text_forward is called directly here)
+    cls, _ = eng._text_forward(ids_t, mask_t, save=False)
+    assert torch.isfinite(cls.float()).all() and rel(cls, ref) < tol
+    pack = E.make_text_pack(mask, "cuda")
+    assert pack is not None and pack.M == 896
+    cls_p, _ = eng._text_forward(ids_t, mask_t, save=False, pack=pack)
+    assert rel(cls_p, ref) < tol
+    eng.release_buffers()
+
+
 def test_head_matches_reference_goldens_and_grads():
     """HIP fused head vs logits/gradients recorded from the reference's MM_RCA (d_img=1280, d_txt=768)."""
     g = np.load(os.path.join(G, "head_goldens.npz"))

@@ -413,8 +413,9 @@ def _attn_ref(qkv, mask, B, H, S, dh, dout=None):
 
 
 @pytest.mark.parametrize("dt,impl", [(torch.float32, L.IMPL_REF), (torch.bfloat16, L.IMPL_REF), (torch.bfloat16, L.IMPL_AUTO)])
-@pytest.mark.parametrize("S,masked", [(64, True), (197, False), (40, True)])
+@pytest.mark.parametrize("S,masked", [(64, True), (197, False), (40, True), (300, True), (512, False), (1, False), (17, True)])
 def test_mha_fwd_bwd(dt, impl, S, masked):
+    # S = 512 is the text encoders' max_position_embeddings (the largest sequence the path can see); S = 1 the smallest
     B, H, dh = 3, 4, 64
     qkv = dev(torch.randn(B * S, 3 * H * dh), dt)
     mask = None
