@@ -1,12 +1,13 @@
 #!/usr/bin/env python
 """Input-path throughput: the GPU image pipeline (pinned staging + H2D + one kernel per batch)
-against the CPU restatement of the reference's per-sample validation pipeline, on synthetic decoded images."""
+against the per-sample DataLoader-worker form of the same pipeline (main_both.Transforms), on synthetic decoded images."""
 import os, sys, time
 import numpy as np
 import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from garbage_classification_rca_amd.preprocess import GpuImagePipeline
-from oracle import transforms as T          # (bench tool: the CPU baseline leg only)
+from garbage_classification_rca_amd.main_both import Transforms     # the per-sample DataLoader-worker form of the same pipeline
+from PIL import Image
 
 B, H, W = 256, 384, 512
 rng = np.random.RandomState(0)
@@ -35,8 +36,11 @@ kus = e0.elapsed_time(e1) / 20 * 1e3
 src_mb = sum(i.size for i in imgs) / 1e6
 print(f"GPU pipeline (host pack + pinned H2D + kernel): {B / dt:9.0f} images/s  ({dt * 1e3:.2f} ms per batch of {B}, {src_mb:.0f} MB of pixels)")
 print(f"kernel alone: {kus:.1f} us per batch = {B / kus * 1e6:.0f} images/s, {(src_mb * 1e6 + B * 3 * 224 * 224 * 4) / kus / 1e6:.2f} TB/s (source read once + output)")
+torch.set_num_threads(1)
+tf = Transforms(224, 224)
+pil = [Image.fromarray(i) for i in imgs[:32]]
 t0 = time.perf_counter()
-for i in range(32):
-    T.validation_pipeline(imgs[i], 224, 224)
+for im in pil:
+    tf(im)
 dc = (time.perf_counter() - t0) / 32
-print(f"CPU restatement, one core: {1 / dc:9.0f} images/s")
+print(f"per-sample CPU form (main_both.Transforms), one core: {1 / dc:9.0f} images/s")
