@@ -16,7 +16,7 @@ SHAPES = [  # (name, M, N, K, a_layout, b_layout, accum)
     ("epi out addend", M, 768, 768, 0, 0, 0), ("epi ffn2 addend", M, 768, 3072, 0, 0, 0),
     ("text fwd qkv", 16384, 2304, 768, 0, 0, 0), ("text fwd out", 16384, 768, 768, 0, 0, 0),
 ]
-impls = {"1stage": L.IMPL_MFMA_1STAGE, "256w": L.IMPL_MFMA_256W}
+impls = {"auto": L.IMPL_AUTO}
 DBG = [int(x) for x in os.environ.get("MMRCA_DBG", "0").split(",")]
 only = sys.argv[1:] 
 L.load()
@@ -54,6 +54,17 @@ for name, m, n, k, al, bl, acc in SHAPES:
             L.load().mmrca_debug_set(dbg)
             L.gemm(A, B, C, bias=bias, M=m, N=n, K=k, lda=lda, ldb=ldb, ldc=n, a_layout=al, b_layout=bl, accum=bool(acc), dtype=L.BF16, impl=impl, **epi)
         runs[iname] = run
+    if os.environ.get("MMRCA_COLD") and not acc:   # the same launch over rotating A / C buffers (> 1 GB in total): operands not in L2 / MALL
+        nb = 6
+        As = [A.clone() for _ in range(nb)]
+        Cs = [torch.empty_like(C) for _ in range(nb)]
+        state = {"i": 0}
+        def run_cold():
+            i = state["i"] = (state["i"] + 1) % nb
+            L.load().mmrca_debug_set(0)
+            L.gemm(As[i], B, Cs[i], bias=bias, M=m, N=n, K=k, lda=lda, ldb=ldb, ldc=n, a_layout=al, b_layout=bl, accum=False, dtype=L.BF16,
+                   impl=L.IMPL_AUTO, **epi)
+        runs["auto_cold"] = run_cold
     if os.environ.get("MMRCA_YARDSTICK"):      # calibration only: the vendor library (hipBLASLt through torch.matmul) on the same operands
         At = A[:m] if al == 0 else A.t()
         Bt = B.t() if bl == 0 else B
