@@ -387,11 +387,11 @@ __device__ __forceinline__ bf16x8 load_frag32(const char* lds_tile, int rb, int 
   }
 }
 
-template <bool A_KROW, bool B_KROW, bool ATOMIC_F32>
+template <bool A_KROW, bool B_KROW, bool ATOMIC_F32, bool FUSE_DB>
 __global__ void __launch_bounds__(256, 4)
 gemm_mfma_k32(const bf16_t* __restrict__ A, const bf16_t* __restrict__ B, void* __restrict__ Cv, const bf16_t* __restrict__ bias,
               const bf16_t* __restrict__ addend, bf16_t* __restrict__ preact, int64_t M, int64_t N, int64_t K,
-              int64_t lda, int64_t ldb, int64_t ldc, int act, int tiles_m, int tiles_n, int64_t ksplit_len) {
+              int64_t lda, int64_t ldb, int64_t ldc, int act, int tiles_m, int tiles_n, int64_t ksplit_len, float* __restrict__ dbias) {
   extern __shared__ __attribute__((aligned(16))) char smem[];   // [2 buffers][A tile 8 KiB | B tile 8 KiB]
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
   const int wr = wave >> 1, wc = wave & 1;
@@ -415,6 +415,17 @@ gemm_mfma_k32(const bf16_t* __restrict__ A, const bf16_t* __restrict__ B, void* 
   for (int i = 0; i < 4; ++i)
 #pragma unroll
     for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  // bias gradient riding on the weight gradient (FUSE_DB): row sums of the A operand (= column sums of dY) from one extra
+  // MFMA per A fragment against an all-ones B fragment; the 32-deep steps are dealt round robin to the 2 * tiles_n
+  // (tile column, wave column) pairs that hold the same A fragments, so every block does 1 / (2 tiles_n) of it
+  constexpr bool do_bias = ATOMIC_F32 && FUSE_DB;
+  const int kstep0 = (int)(kbeg / 32);
+  f32x4 accb[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) accb[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  bf16x8 ones;
+#pragma unroll
+  for (int e = 0; e < 8; ++e) ones[e] = (bf16_t)1.0f;
   if (nt > 0) {
     stage_tile32<A_KROW>(A, lda, m_blk, M, kbeg, smem, wave, lane);
     stage_tile32<B_KROW>(B, ldb, n_blk, N, kbeg, smem + TILE32_BYTES, wave, lane);
@@ -440,6 +451,10 @@ gemm_mfma_k32(const bf16_t* __restrict__ A, const bf16_t* __restrict__ B, void* 
         if (ATOMIC_F32) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i], bfr[j], acc[i][j], 0, 0, 0);
         else            acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr[j], af[i], acc[i][j], 0, 0, 0);
       }
+    if (do_bias && ((kstep0 + t) % (2 * tiles_n)) == 2 * tn + wc) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) accb[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i], ones, accb[i], 0, 0, 0);
+    }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
   }
@@ -457,6 +472,15 @@ gemm_mfma_k32(const bf16_t* __restrict__ A, const bf16_t* __restrict__ B, void* 
           if (m < M && n < N) atomicAdd(C + m * ldc + n, acc[i][j][r]);
         }
       }
+    if (do_bias && l16 == 0) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int64_t m = m_blk + wr * 64 + i * 16 + 4 * g + r;
+          if (m < M) atomicAdd(dbias + m, accb[i][r]);
+        }
+    }
   } else {
     bf16_t* C = (bf16_t*)Cv;
     constexpr int EP_STRIDE = 128 * 4 + 16;
@@ -524,13 +548,13 @@ gemm_mfma_k32(const bf16_t* __restrict__ A, const bf16_t* __restrict__ B, void* 
   }
 }
 
-template <bool AK, bool BK2, bool AT>
+template <bool AK, bool BK2, bool AT, bool DB = false>
 static void launch_mfma32(const void* A, const void* B, void* C, const void* bias, const void* addend, void* preact,
                           int64_t M, int64_t N, int64_t K, int64_t lda, int64_t ldb, int64_t ldc, int act, int tiles_m,
-                          int tiles_n, int ksplits, int64_t ksplit_len, hipStream_t st) {
-  hipLaunchKernelGGL((gemm_mfma_k32<AK, BK2, AT>), dim3(tiles_m * tiles_n, ksplits), dim3(256), 4 * TILE32_BYTES, st,
+                          int tiles_n, int ksplits, int64_t ksplit_len, hipStream_t st, float* dbias = nullptr) {
+  hipLaunchKernelGGL((gemm_mfma_k32<AK, BK2, AT, DB>), dim3(tiles_m * tiles_n, ksplits), dim3(256), 4 * TILE32_BYTES, st,
                      (const bf16_t*)A, (const bf16_t*)B, C, (const bf16_t*)bias, (const bf16_t*)addend, (bf16_t*)preact,
-                     M, N, K, lda, ldb, ldc, act, tiles_m, tiles_n, ksplit_len);
+                     M, N, K, lda, ldb, ldc, act, tiles_m, tiles_n, ksplit_len, dbias);
 }
 
 // single-stage 128x128x64 variant (32 KiB LDS, four to five blocks per CU): full 128-byte lines for ROWK operands
@@ -1383,6 +1407,12 @@ static int gemm_dispatch(const void* A, const void* B, void* C, const void* bias
       else LP(true, true, true);
 #undef LP
       MMRCA_CHECK_LAUNCH("gemm(mfma,persistent)");
+      return 0;
+    }
+    if (at && bias && (impl == MMRCA_GEMM_MFMA_BK32 || auto32)) {   // the same on the 128x128x32 kernel (four blocks per CU)
+      if (bk) launch_mfma32<true, true, true, true>(A, B, C, nullptr, addend, preact, M, N, K, lda, ldb, ldc, act, tiles_m, tiles_n, ksplits, ksplit_len, st, (float*)bias);
+      else launch_mfma32<true, false, true, true>(A, B, C, nullptr, addend, preact, M, N, K, lda, ldb, ldc, act, tiles_m, tiles_n, ksplits, ksplit_len, st, (float*)bias);
+      MMRCA_CHECK_LAUNCH("gemm(mfma,bk32,wgrad+dbias)");
       return 0;
     }
     if (at && bias) {   // weight gradient with the bias gradient fused (A is KROW by contract)

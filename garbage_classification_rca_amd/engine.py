@@ -30,6 +30,10 @@ ALIGN = 64          # arena entries start on 256-byte boundaries
 # Bias gradient as an extra ones-operand MFMA inside the weight-gradient GEMM: parity-tested, measured net-neutral
 # (conditional MFMAs disturb the main loop), off by default.
 FUSE_BIAS_GRAD = os.environ.get("MMRCA_FUSE_BIAS", "0") == "1"
+# The same for the QKV in-projection only (the one linear whose bias gradient no neighbouring kernel produces) on the
+# 128x128x32 weight-gradient kernel, instead of a 232 MB column-sum pass per layer: measured 1.5 % SLOWER end to end
+# (5,720 vs 5,808 samples/s, same box, two rounds) -- the conditional MFMAs cost the main loop more than the pass. Off.
+QKV_BIAS_IN_WGRAD = os.environ.get("MMRCA_QKV_BIAS_IN_WGRAD", "0") == "1"
 # GELU backward fused into the GEMMs: FFN1's forward epilogue stores gelu'(h) instead of h, FFN2's input-gradient
 # epilogue multiplies by it and emits the FFN1 bias gradient (column sums): +3.8 % end to end (no separate pass).
 FUSE_GELU_GRAD = os.environ.get("MMRCA_FUSE_GELU", "1") == "1"
@@ -292,7 +296,8 @@ class MMRCAEngine:
         L.gemm(x, w, out, bias=b, addend=addend, preact=preact, M=M, N=N, K=K, lda=K, ldb=K, ldc=N,
                a_layout=L.ROWK, b_layout=L.ROWK, act=act, dtype=self.dt, impl=self.gemm_impl)
 
-    def _lin_bwd(self, dy, x, wkey, bkey, dx, M, N, K, addend=None, wnumel=None, gelu_h=None, bias_done=False, gelu_db=None):
+    def _lin_bwd(self, dy, x, wkey, bkey, dx, M, N, K, addend=None, wnumel=None, gelu_h=None, bias_done=False, gelu_db=None,
+                 fuse_db=False):
         """dy [M,N], x [M,K], weight [N,K]:  dW += dy^T x and db += colsum(dy) in ONE pass (the bias gradient rides
         on the weight-gradient GEMM); dx = dy W (+ addend), optionally times gelu'(gelu_h) in the epilogue."""
         Mk = _round_up(M, 64)
@@ -300,9 +305,10 @@ class MMRCAEngine:
         gb = self.G(bkey) if wnumel is None else self.Gflat(bkey, N)
 
         def wgrad():
-            L.gemm(dy, x, gw, bias=(gb if FUSE_BIAS_GRAD else None), M=N, N=K, K=Mk, lda=N, ldb=K, ldc=K, a_layout=L.KROW,
+            fused = (FUSE_BIAS_GRAD or fuse_db) and not bias_done
+            L.gemm(dy, x, gw, bias=(gb if fused else None), M=N, N=K, K=Mk, lda=N, ldb=K, ldc=K, a_layout=L.KROW,
                    b_layout=L.KROW, accum=True, dtype=self.dt, impl=self.gemm_impl)
-            if not FUSE_BIAS_GRAD and not bias_done:     # bias_done: the producer of dy already accumulated its column sums
+            if not fused and not bias_done:     # bias_done: the producer of dy already accumulated its column sums
                 L.colsum_accum(dy, gb, M, N, N, self.dt)
 
         if self._side is None:
@@ -477,12 +483,11 @@ class MMRCAEngine:
                           bias_done=True)
             dqkv = gb("dqkv", 3 * D)
             # the attention backward also reduces the q|k|v bias gradients (adjacent in the arena) while it has the tiles
-            qkv_db = None if FUSE_BIAS_GRAD else self.Gflat(P + K["q"] + ".bias", 3 * D)
             L.mha_bwd(a["qkv"], sv["mask32"], a["ctx"], dctx, a["lse"], dqkv, B, H, T, dh, dh ** -0.5, self.dt, self.attn_impl,
-                      drop_p=dp, drop_seed=sd(i, 1), colsum=qkv_db, cu=cu, rows=M)
+                      drop_p=dp, drop_seed=sd(i, 1), cu=cu)
             self._wait_first_wgrad()       # (the FFN2 weight gradient does not read dx in the post-LN layout; harmless)
             self._lin_bwd(dqkv, a["x"], P + K["q"] + ".weight", P + K["q"] + ".bias", dx, M, 3 * D, D, addend=ds1, wnumel=3 * D * D,
-                          bias_done=qkv_db is not None)
+                          fuse_db=QKV_BIAS_IN_WGRAD)
             self._layer_boundary()
             self._ready(f"text_layer_{i}")
         ds0 = gb("ds2", D)
@@ -532,7 +537,8 @@ class MMRCAEngine:
         dqkv = gb("dqkv", 3 * D)
         L.mha_cls_bwd(a["qkv"], sv["mask32"], a["ctx_c"], dctx_c, a["lse"], dqkv, B, H, T, dh, dh ** -0.5, self.dt,
                       drop_p=dp, drop_seed=sd(i, 1), cu=cu)
-        self._lin_bwd(dqkv, a["x"], P + K["q"] + ".weight", P + K["q"] + ".bias", dx, M, 3 * D, D, addend=ds1_full, wnumel=3 * D * D)
+        self._lin_bwd(dqkv, a["x"], P + K["q"] + ".weight", P + K["q"] + ".bias", dx, M, 3 * D, D, addend=ds1_full, wnumel=3 * D * D,
+                      fuse_db=QKV_BIAS_IN_WGRAD)
         self._layer_boundary()
         self._ready(f"text_layer_{i}")
 
@@ -634,11 +640,10 @@ class MMRCAEngine:
             self._lin_bwd(dx1, a["ctx"], Lk + "self_attention.out_proj.weight", Lk + "self_attention.out_proj.bias", dctx, M, D, D,
                           bias_done=True)
             dqkv = gb("dqkv", M, 3 * D)
-            qkv_db = None if FUSE_BIAS_GRAD else self.G(Lk + "self_attention.in_proj_bias")
-            L.mha_bwd(a["qkv"], None, a["ctx"], dctx, a["lse"], dqkv, B, H, Tn, dh, dh ** -0.5, self.dt, self.attn_impl, colsum=qkv_db)
+            L.mha_bwd(a["qkv"], None, a["ctx"], dctx, a["lse"], dqkv, B, H, Tn, dh, dh ** -0.5, self.dt, self.attn_impl)
             dy1 = gb("dy", M, D)
             self._lin_bwd(dqkv, a["y1"], Lk + "self_attention.in_proj_weight", Lk + "self_attention.in_proj_bias", dy1, M, 3 * D, D,
-                          bias_done=qkv_db is not None)
+                          fuse_db=QKV_BIAS_IN_WGRAD)
             self._wait_first_wgrad()       # mlp.3's weight gradient (side stream) reads dx; this op overwrites it
             below = P + f"encoder.layers.encoder_layer_{i - 1}.mlp.3.bias"
             self._ln_bwd(dy1, a["x"], Lk + "ln_1", a["m1"], a["r1"], dx1, dx, M, D, dcol=(self.G(below) if i > 0 else None))
@@ -678,7 +683,8 @@ class MMRCAEngine:
         dqkv = gb("dqkv", M, 3 * D)
         L.mha_cls_bwd(a["qkv"], None, a["ctx_c"], dctx_c, a["lse"], dqkv, B, H, Tn, dh, dh ** -0.5, self.dt)
         dy1 = gb("dy", M, D)
-        self._lin_bwd(dqkv, a["y1"], Lk + "self_attention.in_proj_weight", Lk + "self_attention.in_proj_bias", dy1, M, 3 * D, D)
+        self._lin_bwd(dqkv, a["y1"], Lk + "self_attention.in_proj_weight", Lk + "self_attention.in_proj_bias", dy1, M, 3 * D, D,
+                      fuse_db=QKV_BIAS_IN_WGRAD)
         below = P + f"encoder.layers.encoder_layer_{i - 1}.mlp.3.bias"
         self._ln_bwd(dy1, a["x"], Lk + "ln_1", a["m1"], a["r1"], dx1, dx, M, D, dcol=(self.G(below) if i > 0 else None))
         self._layer_boundary()

@@ -201,7 +201,8 @@ def test_gemm_mfma256_layouts_and_epilogues(layouts):
     _gemm_case(Mr, 256, 256, al, bl, torch.bfloat16, L.IMPL_MFMA256, act=L.ACT_GELU, bias=True, addend=True, preact=True)
 
 
-@pytest.mark.parametrize("dt,impl", [(torch.float32, L.IMPL_REF), (torch.bfloat16, L.IMPL_REF), (torch.bfloat16, L.IMPL_MFMA)])
+@pytest.mark.parametrize("dt,impl", [(torch.float32, L.IMPL_REF), (torch.bfloat16, L.IMPL_REF), (torch.bfloat16, L.IMPL_MFMA),
+                                     (torch.bfloat16, L.IMPL_MFMA_BK32), (torch.bfloat16, L.IMPL_AUTO)])
 def test_gemm_fused_bias_gradient_and_gelu_backward(dt, impl):
     """wgrad with the bias gradient riding on the same pass, and dgrad with gelu'(h) in the epilogue."""
     M, N, K = 788, 768, 256            # dY [M,N], X [M,K]
