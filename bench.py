@@ -139,10 +139,15 @@ def main():
     packs = [make_text_pack(mask_host[k * B:(k + 1) * B], dev) if PACK_TEXT else None for k in range(nb)]
     live = sum(p.M for p in packs) / (nb * B * S) if all(p is not None for p in packs) else 1.0
 
+    pack_in_loop = os.environ.get("MMRCA_BENCH_PACK_IN_LOOP", "1") == "1" and PACK_TEXT
+
     def step(i):
         j = (i % nb) * B
+        # the packed layout is rebuilt from the host mask INSIDE the timed step, as a DataLoader-fed loop does per batch
+        # (numpy + two small pinned async copies; MMRCA_BENCH_PACK_IN_LOOP=0 reuses the ones built above)
+        pack = make_text_pack(mask_host[j:j + B], dev) if pack_in_loop else packs[i % nb]
         return hip_train_step(model, ids[j:j + B], mask[j:j + B], images[j:j + B], labels[j:j + B], crit, opt, sync,
-                              text_pack=packs[i % nb])
+                              text_pack=pack)
 
     with contextlib.redirect_stdout(io.StringIO()):
         for i in range(args.warmup):

@@ -118,7 +118,14 @@ def make_text_pack(attention_mask, device) -> Optional["TextPack"]:
     M = int(cu[-1])
     within = np.arange(M) - np.repeat(cu[:-1], ext)
     perm = np.repeat(np.arange(B) * T, ext) + within
-    to = lambda a, dt: torch.from_numpy(np.ascontiguousarray(a)).to(dt).to(device)
+    dev = torch.device(device)
+
+    def to(a, dt):
+        t = torch.from_numpy(np.ascontiguousarray(a)).to(dt)
+        if dev.type == "cuda":                     # pinned staging + async copy: no stream synchronisation on the way
+            return t.pin_memory().to(dev, non_blocking=True)
+        return t.to(dev)
+
     return TextPack(to(perm, torch.int64), to(cu, torch.int32), to(m.reshape(-1)[perm], torch.int32), to(cu[:-1], torch.int64), M, B, T)
 
 
