@@ -242,20 +242,34 @@ mha_bwd_dq_mfma_k(const bf16_t* __restrict__ qkv, const int32_t* __restrict__ ke
 #pragma unroll 1
     for (int u = 0; u < NKT / 2; ++u) {      // rolled: keeps the live set small enough for 2 blocks per CU
       f32x4 ds2[2];
+      bf16x8 kfr[2][2], vfr[2][2];
+      f32x4 bias[2], sc[2], dpv[2];
 #pragma unroll
       for (int hh = 0; hh < 2; ++hh) {
         const int kt = 2 * u + hh;
-        f32x4 s = {0.f, 0.f, 0.f, 0.f}, dp = {0.f, 0.f, 0.f, 0.f};
-        s = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_rows(Kimg, IMG_TR, kt * 16, 0, lane), qf0, s, 0, 0, 0);
-        s = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_rows(Kimg, IMG_TR, kt * 16, 1, lane), qf1, s, 0, 0, 0);
-        dp = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_rows(Vimg, IMG_ROW, kt * 16, 0, lane), df0, dp, 0, 0, 0);
-        dp = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_rows(Vimg, IMG_ROW, kt * 16, 1, lane), df1, dp, 0, 0, 0);
-        const f32x4 bias = *reinterpret_cast<const f32x4*>(kb + kt * 16 + 4 * g);
+        kfr[hh][0] = frag_rows(Kimg, IMG_TR, kt * 16, 0, lane); kfr[hh][1] = frag_rows(Kimg, IMG_TR, kt * 16, 1, lane);
+        vfr[hh][0] = frag_rows(Vimg, IMG_ROW, kt * 16, 0, lane); vfr[hh][1] = frag_rows(Vimg, IMG_ROW, kt * 16, 1, lane);
+        bias[hh] = *reinterpret_cast<const f32x4*>(kb + kt * 16 + 4 * g);
+      }
+      const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int hh = 0; hh < 2; ++hh) {
+        sc[hh] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kfr[hh][0], qf0, zero4, 0, 0, 0);
+        dpv[hh] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vfr[hh][0], df0, zero4, 0, 0, 0);
+      }
+#pragma unroll
+      for (int hh = 0; hh < 2; ++hh) {
+        sc[hh] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kfr[hh][1], qf1, sc[hh], 0, 0, 0);
+        dpv[hh] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vfr[hh][1], df1, dpv[hh], 0, 0, 0);
+      }
+#pragma unroll
+      for (int hh = 0; hh < 2; ++hh) {
+        const int kt = 2 * u + hh;
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-          const float p = __builtin_amdgcn_exp2f(fmaf(s[r], c1, bias[r]) - L2);          // 0 for masked keys / queries
+          const float p = __builtin_amdgcn_exp2f(fmaf(sc[hh][r], c1, bias[hh][r]) - L2);          // 0 for masked keys / queries
           const float keep = DROP ? attn_keep(drop_p, drop_sc, drop_seed, blockIdx.x, Smax, q, kt * 16 + 4 * g + r) : 1.f;
-          ds2[hh][r] = p * (DROP ? dp[r] * keep - dsum : dp[r] - dsum);                   // (the score scale is applied to dQ below)
+          ds2[hh][r] = p * (DROP ? dpv[hh][r] * keep - dsum : dpv[hh][r] - dsum);                 // (the score scale is applied to dQ below)
         }
       }
       const bf16x8 dsf = pack_pair(ds2[0], ds2[1]);
@@ -328,26 +342,42 @@ mha_bwd_dkv_mfma_k(const bf16_t* __restrict__ qkv, const int32_t* __restrict__ k
 #pragma unroll 1
     for (int u = 0; u < NKT / 2; ++u) {
       f32x4 p2[2], ds2[2];
+      // all eight LDS fragments of the two query tiles first, then four independent MFMA chains (a dependent pair issued
+      // back to back stalls on the first result), then the elementwise part
+      bf16x8 qf[2][2], df[2][2];
+      f32x4 Lq[2], Dq[2], sc[2], dpv[2];
 #pragma unroll
       for (int hh = 0; hh < 2; ++hh) {
         const int qt = 2 * u + hh;
-        f32x4 s = {0.f, 0.f, 0.f, 0.f}, dp = {0.f, 0.f, 0.f, 0.f};
-        s = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_rows(Qimg, IMG_TR, qt * 16, 0, lane), kf0, s, 0, 0, 0);    // S[q][key]
-        s = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_rows(Qimg, IMG_TR, qt * 16, 1, lane), kf1, s, 0, 0, 0);
-        dp = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_rows(Dimg, IMG_TR, qt * 16, 0, lane), vf0, dp, 0, 0, 0);  // dP[q][key]
-        dp = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_rows(Dimg, IMG_TR, qt * 16, 1, lane), vf1, dp, 0, 0, 0);
-        const f32x4 Lq = *reinterpret_cast<const f32x4*>(lse_s + qt * 16 + 4 * g);       // queries 16qt + 4g + r
-        const f32x4 Dq = *reinterpret_cast<const f32x4*>(dsum_s + qt * 16 + 4 * g);
+        qf[hh][0] = frag_rows(Qimg, IMG_TR, qt * 16, 0, lane); qf[hh][1] = frag_rows(Qimg, IMG_TR, qt * 16, 1, lane);
+        df[hh][0] = frag_rows(Dimg, IMG_TR, qt * 16, 0, lane); df[hh][1] = frag_rows(Dimg, IMG_TR, qt * 16, 1, lane);
+        Lq[hh] = *reinterpret_cast<const f32x4*>(lse_s + qt * 16 + 4 * g);       // queries 16qt + 4g + r
+        Dq[hh] = *reinterpret_cast<const f32x4*>(dsum_s + qt * 16 + 4 * g);
+      }
+      const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int hh = 0; hh < 2; ++hh) {
+        sc[hh] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qf[hh][0], kf0, zero4, 0, 0, 0);      // S[q][key]
+        dpv[hh] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(df[hh][0], vf0, zero4, 0, 0, 0);     // dP[q][key]
+      }
+#pragma unroll
+      for (int hh = 0; hh < 2; ++hh) {
+        sc[hh] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qf[hh][1], kf1, sc[hh], 0, 0, 0);
+        dpv[hh] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(df[hh][1], vf1, dpv[hh], 0, 0, 0);
+      }
+#pragma unroll
+      for (int hh = 0; hh < 2; ++hh) {
+        const int qt = 2 * u + hh;
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-          const float p = __builtin_amdgcn_exp2f(fmaf(s[r], c1, kbias) - Lq[r]);
+          const float p = __builtin_amdgcn_exp2f(fmaf(sc[hh][r], c1, kbias) - Lq[hh][r]);
           if (DROP) {
             const float keep = attn_keep(drop_p, drop_sc, drop_seed, blockIdx.x, Smax, qt * 16 + 4 * g + r, key);
             p2[hh][r] = p * keep;
-            ds2[hh][r] = p * (dp[r] * keep - Dq[r]);
+            ds2[hh][r] = p * (dpv[hh][r] * keep - Dq[hh][r]);
           } else {
             p2[hh][r] = p;
-            ds2[hh][r] = p * (dp[r] - Dq[r]);                                            // (score scale applied to dK below)
+            ds2[hh][r] = p * (dpv[hh][r] - Dq[hh][r]);                                     // (score scale applied to dK below)
           }
         }
       }
