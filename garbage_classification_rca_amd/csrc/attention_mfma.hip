@@ -31,13 +31,20 @@ __device__ __forceinline__ int img_off(int mode, int row, int c /*16-B chunk 0..
   return row * 128 + ((((c >> 1) ^ ((row >> 1) & 3)) << 5) | ((c & 1) << 4));
 }
 
-// stage rows [0,S) of a [S, ld] slice (64 bf16 per row) into an LDS image, zero-filling rows [S, Spad)
+// stage rows [0,S) of a [S, ld] slice (64 bf16 per row) into an LDS image with global_load_lds (HBM -> LDS DMA, 16 B per
+// lane, no VGPR round trip; the caller waits on vmcnt(0) before its barrier).  The DMA writes lane-linear (one wave
+// instruction = 8 image rows of 128 B), so the image's XOR swizzle -- an involution within a row for both modes -- is
+// applied to the per-lane SOURCE chunk.  Rows [S, Spad) receive a copy of row S-1 instead of zeros: every consumer
+// multiplies them by an exact zero (keys >= S carry a -inf score bias, queries >= S a +inf log-sum-exp).
+typedef __attribute__((address_space(3))) void at_lds_void;
+typedef const __attribute__((address_space(1))) void at_gbl_void;
 __device__ __forceinline__ void stage_rows(char* img, int mode, const bf16_t* __restrict__ src, int64_t ld, int S, int Spad) {
-  for (int idx = threadIdx.x; idx < Spad * 8; idx += blockDim.x) {
-    const int row = idx >> 3, c = idx & 7;
-    uint4 v = make_uint4(0, 0, 0, 0);
-    if (row < S) v = *reinterpret_cast<const uint4*>(src + (int64_t)row * ld + c * 8);
-    *reinterpret_cast<uint4*>(img + img_off(mode, row, c)) = v;
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, nw = blockDim.x >> 6;
+  for (int j = wave; j < (Spad >> 3); j += nw) {
+    const int row = 8 * j + (lane >> 3), slot = lane & 7;
+    const int c = mode == IMG_ROW ? (slot ^ ((row >> 1) & 7)) : ((((slot >> 1) ^ ((row >> 1) & 3)) << 1) | (slot & 1));
+    const int r = row < S ? row : S - 1;
+    __builtin_amdgcn_global_load_lds((at_gbl_void*)(src + (int64_t)r * ld + c * 8), (at_lds_void*)(img + j * 1024), 16, 0, 0);
   }
 }
 
@@ -128,6 +135,7 @@ mha_fwd_mfma_k(const bf16_t* __restrict__ qkv, const int32_t* __restrict__ key_m
   stage_rows(Kimg, IMG_ROW, Kp, ld, S, Spad);
   stage_rows(Vimg, IMG_TR, Vp, ld, S, Spad);
   stage_key_bias(kb, key_mask ? key_mask + row0 : nullptr, S, Spad);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
   const float c1 = scale * LOG2E;                    // scores live in the exp2 domain
   const int nqt = (S + 15) / 16;
@@ -222,6 +230,7 @@ mha_bwd_dq_mfma_k(const bf16_t* __restrict__ qkv, const int32_t* __restrict__ ke
   stage_rows(Kimg, IMG_TR, Kp, ld, S, Spad);      // row reads for S^T (2-way), transposed reads for dQ^T
   stage_rows(Vimg, IMG_ROW, Vp, ld, S, Spad);     // row reads for dP^T
   stage_key_bias(kb, key_mask ? key_mask + row0 : nullptr, S, Spad);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
   const float c1 = scale * LOG2E;
   const int nqt = (S + 15) / 16;
@@ -327,6 +336,7 @@ mha_bwd_dkv_mfma_k(const bf16_t* __restrict__ qkv, const int32_t* __restrict__ k
     }
     lse_s[q] = L; dsum_s[q] = a;
   }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
   const float c1 = scale * LOG2E;
   const int nkt = (S + 15) / 16;
