@@ -807,7 +807,19 @@ vit_assemble_bwd_k(const T* __restrict__ dx, T* __restrict__ dproj, float* __res
   const int64_t e = i * 4;
   const int d = (int)(e % D), t = (int)(e / D);
   float acc[4] = {0.f, 0.f, 0.f, 0.f};
-  for (int b = 0; b < B; ++b) {
+  int b = 0;
+  for (; b + 8 <= B; b += 8) {                    // eight samples in flight per thread (only Tn*D/4 threads exist)
+    Vec4<T> v[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) v[u] = Vec4<T>::load(dx + ((int64_t)(b + u) * Tn + t) * D + d);
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      if (t > 0) v[u].store(dproj + ((int64_t)(b + u) * nP + (t - 1)) * D + d);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) acc[j] += v[u].v[j];
+    }
+  }
+  for (; b < B; ++b) {
     Vec4<T> v = Vec4<T>::load(dx + ((int64_t)b * Tn + t) * D + d);
     if (t > 0) v.store(dproj + ((int64_t)b * nP + (t - 1)) * D + d);
 #pragma unroll
