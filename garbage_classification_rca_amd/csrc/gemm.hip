@@ -1075,6 +1075,209 @@ static void launch_mfma256w(const void* A, const void* B, void* C, const void* b
                      M, N, K, lda, ldb, ldc, act, tiles_m, tiles_n, colsum);
 }
 
+// ======================================================================================================
+// 256x256x64 block tile, FOUR waves (2 x 2), each a 128x128 wave tile (8 x 8 accumulators of f32x4 = 256 registers, in
+// AGPRs), two 64-KiB LDS stages, one block per CU, ONE wave per SIMD: the classic large-tile design (the vendor library's
+// MT256x256x64).  LDS fragment traffic per MFMA is half that of the 64x64 wave tile and the staged bytes per flop half
+// those of the 128x128 block tile; with a single wave per SIMD all latency hiding is instruction-level, so the K loop is
+// software-pipelined over the two 32-deep halves of a stage (fragments of the next half are read while the MFMAs of the
+// current one run; sched_group_barrier interleaves 1 LDS read : 4 MFMAs).  A must be ROWK, N % 256 == 0, no accumulate.
+// Measured: 300-400 TFLOP/s at K = 768, 580-630 at K = 3072 (ROWK B), i.e. well below the 128x128 kernel at four waves per
+// SIMD (900): a single wave issues an MFMA at best every ~28 cycles (register-only probe: 1.41 PFLOP/s at one wave per SIMD
+// against 16 cycles of pipe occupancy), and every LDS read, s_nop and address update comes out of that one instruction
+// stream -- moving the stage DMA a full iteration ahead changed nothing.  Selectable (impl 9), never picked by AUTO.
+// ======================================================================================================
+template <bool B_KROW>
+__device__ __forceinline__ void stage256x4(const bf16_t* __restrict__ A, const bf16_t* __restrict__ B, int64_t lda, int64_t ldb,
+                                           int64_t m_blk, int64_t n_blk, int64_t M, int64_t N, int64_t k0, char* st, int wave, int lane) {
+  stage_tile_n<false, 8>(A, lda, m_blk, M, k0, st, wave, lane);                                   // 32 x 1 KiB over 4 waves
+  if (!B_KROW) stage_tile_n<false, 8>(B, ldb, n_blk, N, k0, st + 2 * TILE_BYTES, wave, lane);
+  else stage_tile_n<true, 8>(B, ldb, n_blk + (wave >> 1) * 128, N, k0, st + 2 * TILE_BYTES + (wave >> 1) * TILE_BYTES, wave & 1, lane);
+}
+
+template <bool B_KROW>
+__global__ void __launch_bounds__(256, 1)
+gemm_mfma_k256x4(const bf16_t* __restrict__ A, const bf16_t* __restrict__ B, bf16_t* __restrict__ C, const bf16_t* __restrict__ bias,
+                 const bf16_t* __restrict__ addend, bf16_t* __restrict__ preact, int64_t M, int64_t N, int64_t K,
+                 int64_t lda, int64_t ldb, int64_t ldc, int act, int tiles_m, int tiles_n, float* __restrict__ colsum) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];   // [2 stages][A 32 KiB | B 32 KiB]
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
+  const int wr = wave >> 1, wc = wave & 1;
+  const int nwg = tiles_m * tiles_n;
+  const int orig = blockIdx.x;
+  const int q8 = nwg >> 3, r8 = nwg & 7, xcd = orig & 7;
+  const int wgid = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (orig >> 3);
+  const int GROUP = 8;
+  const int group = wgid / (GROUP * tiles_n);
+  const int first_m = group * GROUP;
+  const int gsize = (tiles_m - first_m) < GROUP ? (tiles_m - first_m) : GROUP;
+  const int tm = first_m + (wgid % (GROUP * tiles_n)) % gsize;
+  const int tn = (wgid % (GROUP * tiles_n)) / gsize;
+  const int64_t m_blk = (int64_t)tm * 256, n_blk = (int64_t)tn * 256;
+  const int nt = (int)((K + GBK - 1) / GBK);
+  // B fragments of this wave's 128 columns: ROWK image = rows wc*128.. of the 256-row B tile; KROW image = sub-tile wc
+  const int boff = 2 * TILE_BYTES + (B_KROW ? wc * TILE_BYTES : 0);
+  const int bcol = B_KROW ? 0 : wc * 128;
+
+  f32x4 acc[8][8];
+#pragma unroll
+  for (int i = 0; i < 8; ++i)
+#pragma unroll
+    for (int j = 0; j < 8; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  stage256x4<B_KROW>(A, B, lda, ldb, m_blk, n_blk, M, N, 0, smem, wave, lane);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  if (nt > 1) stage256x4<B_KROW>(A, B, lda, ldb, m_blk, n_blk, M, N, GBK, smem + W256_STAGE_BYTES, wave, lane);
+  bf16x8 af[2][8], bfr[2][8];          // fragment double buffer over the 32-deep halves
+#pragma unroll
+  for (int i = 0; i < 8; ++i) af[0][i] = load_frag<false>(smem, wr * 128 + i * 16, 0, lane);
+#pragma unroll
+  for (int j = 0; j < 8; ++j) bfr[0][j] = load_frag<B_KROW>(smem + boff, bcol + j * 16, 0, lane);
+  for (int t = 0; t < nt; ++t) {
+    char* cur = smem + (t & 1) * W256_STAGE_BYTES;
+    char* nxt = smem + ((t + 1) & 1) * W256_STAGE_BYTES;
+    // half 0: MFMAs on fragment buffer 0 while buffer 1 is read for half 1 of the same stage
+#pragma unroll
+    for (int i = 0; i < 8; ++i) af[1][i] = load_frag<false>(cur, wr * 128 + i * 16, 1, lane);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) bfr[1][j] = load_frag<B_KROW>(cur + boff, bcol + j * 16, 1, lane);
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+#pragma unroll
+      for (int j = 0; j < 8; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr[0][j], af[0][i], acc[i][j], 0, 0, 0);
+#pragma unroll
+    for (int n = 0; n < 16; ++n) {
+      __builtin_amdgcn_sched_group_barrier(0x100, B_KROW ? 2 : 1, 0);     // DS read(s) of one fragment
+      __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);                  // 4 MFMAs
+    }
+    // stage t+1 (DMA issued a whole iteration ago) must have landed, and every wave must be done reading stage t
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    // stage t is free now: refill it with stage t+2, a full iteration (2,048 MFMA cycles) before it is needed
+    if (t + 2 < nt) stage256x4<B_KROW>(A, B, lda, ldb, m_blk, n_blk, M, N, (int64_t)(t + 2) * GBK, cur, wave, lane);
+    // half 1: MFMAs on buffer 1 while buffer 0 is read for half 0 of the NEXT stage
+    // (unconditional, so the reads stay in the MFMAs' scheduling region: after the last stage they fetch unused bytes)
+#pragma unroll
+    for (int i = 0; i < 8; ++i) af[0][i] = load_frag<false>(nxt, wr * 128 + i * 16, 0, lane);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) bfr[0][j] = load_frag<B_KROW>(nxt + boff, bcol + j * 16, 0, lane);
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+#pragma unroll
+      for (int j = 0; j < 8; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr[1][j], af[1][i], acc[i][j], 0, 0, 0);
+#pragma unroll
+    for (int n = 0; n < 16; ++n) {
+      __builtin_amdgcn_sched_group_barrier(0x100, B_KROW ? 2 : 1, 0);
+      __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);
+    }
+  }
+  // Hazards: half 1 of stage t is read (into buffer 1) BEFORE iteration t's barrier, half 0 of stage t+1 after it; the DMA
+  // that refills stage t's LDS buffer is issued after that barrier, i.e. after the last read of it has completed.
+  __syncthreads();
+  // ---------------- epilogue: 32 rows x 256 columns per pass through LDS (fp32), one whole row per wave instruction
+  const int g = lane >> 4, l16 = lane & 15;
+  constexpr int EP_STRIDE = 256 * 4 + 16;
+  const int64_t ncol = n_blk + lane * 4;
+  float bv[4] = {0.f, 0.f, 0.f, 0.f};
+  if (bias) {
+    bf16x4 b4 = *reinterpret_cast<const bf16x4*>(bias + ncol);
+#pragma unroll
+    for (int r = 0; r < 4; ++r) bv[r] = (float)b4[r];
+  }
+  const bf16_t* side = act == MMRCA_ACT_MUL ? preact : addend;
+  float cs[4] = {0.f, 0.f, 0.f, 0.f};
+  // (the pass index must be a compile-time constant: with a rolled loop the 256 accumulators would be indexed
+  //  dynamically and live in scratch memory, with a store after every MFMA of the main loop)
+#define EP256_PASS(i)                                                                                                   \
+  {                                                                                                                     \
+    bf16x4 add4[8];\
+    if (side) { \
+_Pragma("unroll") \
+      for (int rr = 0; rr < 8; ++rr) { \
+        const int lrow = rr * 4 + wave; \
+        int64_t m = m_blk + (lrow >> 4) * 128 + i * 16 + (lrow & 15); \
+        if (m > M - 1) m = M - 1; \
+        add4[rr] = *reinterpret_cast<const bf16x4*>(side + m * ldc + ncol); \
+      } \
+    } \
+_Pragma("unroll") \
+    for (int j = 0; j < 8; ++j) \
+      *reinterpret_cast<f32x4*>(smem + (wr * 16 + l16) * EP_STRIDE + (wc * 128 + j * 16 + 4 * g) * 4) = acc[i][j]; \
+    __syncthreads(); \
+_Pragma("unroll") \
+    for (int rr = 0; rr < 8; ++rr) { \
+      const int lrow = rr * 4 + wave; \
+      const int64_t m = m_blk + (lrow >> 4) * 128 + i * 16 + (lrow & 15); \
+      if (m < M) { \
+        const f32x4 c = *reinterpret_cast<const f32x4*>(smem + lrow * EP_STRIDE + lane * 16); \
+        float v[4] = {c[0] + bv[0], c[1] + bv[1], c[2] + bv[2], c[3] + bv[3]}; \
+        if (act == MMRCA_ACT_MUL) { \
+_Pragma("unroll") \
+          for (int r = 0; r < 4; ++r) v[r] *= (float)add4[rr][r]; \
+        } else if (act == MMRCA_ACT_GELU_SAVE_GRAD) { \
+          bf16x4 o; \
+_Pragma("unroll") \
+          for (int r = 0; r < 4; ++r) { \
+            float dg; \
+            v[r] = gelu_and_grad_fast_f(v[r], &dg); \
+            o[r] = (bf16_t)dg; \
+          } \
+          *reinterpret_cast<bf16x4*>(preact + m * ldc + ncol) = o; \
+        } else if (act == MMRCA_ACT_GELU_BWD) { \
+          bf16x4 h4 = *reinterpret_cast<const bf16x4*>(preact + m * ldc + ncol); \
+_Pragma("unroll") \
+          for (int r = 0; r < 4; ++r) v[r] *= gelu_grad_f((float)h4[r]); \
+        } else if (preact) { \
+          bf16x4 o; \
+_Pragma("unroll") \
+          for (int r = 0; r < 4; ++r) o[r] = (bf16_t)v[r]; \
+          *reinterpret_cast<bf16x4*>(preact + m * ldc + ncol) = o; \
+        } \
+        if (act == MMRCA_ACT_GELU) { \
+_Pragma("unroll") \
+          for (int r = 0; r < 4; ++r) v[r] = gelu_fast_f(v[r]); \
+        } \
+        if (addend) { \
+          if (act == MMRCA_ACT_MUL) { \
+            bf16x4 a4 = *reinterpret_cast<const bf16x4*>(addend + m * ldc + ncol); \
+_Pragma("unroll") \
+            for (int r = 0; r < 4; ++r) v[r] += (float)a4[r]; \
+          } else { \
+_Pragma("unroll") \
+            for (int r = 0; r < 4; ++r) v[r] += (float)add4[rr][r]; \
+          } \
+        } \
+        bf16x4 o; \
+_Pragma("unroll") \
+        for (int r = 0; r < 4; ++r) { o[r] = (bf16_t)v[r]; cs[r] += (float)o[r]; } \
+        *reinterpret_cast<bf16x4*>(C + m * ldc + ncol) = o; \
+      } \
+    } \
+\
+    __syncthreads();                                                                                                   \
+  }
+  EP256_PASS(0) EP256_PASS(1) EP256_PASS(2) EP256_PASS(3) EP256_PASS(4) EP256_PASS(5) EP256_PASS(6) EP256_PASS(7)
+#undef EP256_PASS
+  if (colsum) {
+    float* red = reinterpret_cast<float*>(smem);          // [4 waves][256 columns]
+#pragma unroll
+    for (int r = 0; r < 4; ++r) red[wave * 256 + lane * 4 + r] = cs[r];
+    __syncthreads();
+    atomicAdd(colsum + n_blk + threadIdx.x, red[threadIdx.x] + red[256 + threadIdx.x] + red[512 + threadIdx.x] + red[768 + threadIdx.x]);
+  }
+}
+
+template <bool BK2>
+static void launch_mfma256x4(const void* A, const void* B, void* C, const void* bias, const void* addend, void* preact,
+                             int64_t M, int64_t N, int64_t K, int64_t lda, int64_t ldb, int64_t ldc, int act, float* colsum,
+                             hipStream_t st) {
+  const int tiles_m = (int)((M + 255) / 256), tiles_n = (int)(N / 256);
+  (void)hipFuncSetAttribute((const void*)gemm_mfma_k256x4<BK2>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * W256_STAGE_BYTES);
+  hipLaunchKernelGGL((gemm_mfma_k256x4<BK2>), dim3(tiles_m * tiles_n), dim3(256), 2 * W256_STAGE_BYTES, st,
+                     (const bf16_t*)A, (const bf16_t*)B, (bf16_t*)C, (const bf16_t*)bias, (const bf16_t*)addend, (bf16_t*)preact,
+                     M, N, K, lda, ldb, ldc, act, tiles_m, tiles_n, colsum);
+}
+
 template <bool AK, bool BK2, bool AT, int WPE>
 static void launch_mfma1s(const void* A, const void* B, void* C, const void* bias, const void* addend, void* preact,
                           int64_t M, int64_t N, int64_t K, int64_t lda, int64_t ldb, int64_t ldc, int act, int tiles_m,
@@ -1319,7 +1522,7 @@ static int gemm_dispatch(const void* A, const void* B, void* C, const void* bias
   // per CU is faster than the 256x256 kernel on every encoder shape, so AUTO never picks the large tile
   if (ok256 && impl == MMRCA_GEMM_MFMA256)
     return mmrca_gemm256(A, B, C, bias, addend, preact, M, N, K, lda, ldb, ldc, a_layout, b_layout, act, st);
-  if ((impl == MMRCA_GEMM_MFMA || impl == MMRCA_GEMM_MFMA_PERSIST || impl == MMRCA_GEMM_MFMA_BK32 || impl == MMRCA_GEMM_MFMA_1STAGE || impl == MMRCA_GEMM_MFMA_TALL || impl == MMRCA_GEMM_MFMA_256W) && !ok_mfma)
+  if ((impl == MMRCA_GEMM_MFMA || impl == MMRCA_GEMM_MFMA_PERSIST || impl == MMRCA_GEMM_MFMA_BK32 || impl == MMRCA_GEMM_MFMA_1STAGE || impl == MMRCA_GEMM_MFMA_TALL || impl == MMRCA_GEMM_MFMA_256W || impl == MMRCA_GEMM_MFMA_256X4) && !ok_mfma)
     return mmrca_fail(-3, "gemm: shape M=%lld N=%lld K=%lld dtype=%d does not qualify for the MFMA kernel", (long long)M, (long long)N, (long long)K, dtype);
   const bool use_mfma = ok_mfma && impl != MMRCA_GEMM_REF;   // 128x128 kernel
 
@@ -1358,6 +1561,15 @@ static int gemm_dispatch(const void* A, const void* B, void* C, const void* bias
       else L32(true, true, true);
 #undef L32
       MMRCA_CHECK_LAUNCH("gemm(mfma,bk32)");
+      return 0;
+    }
+    if (impl == MMRCA_GEMM_MFMA_256X4 && (at || ak || N % 256 != 0))
+      return mmrca_fail(-3, "gemm: the 4-wave 256x256 kernel needs a ROWK A operand, N %% 256 == 0 and no accumulate mode");
+    if (impl == MMRCA_GEMM_MFMA_256X4) {
+      if (colsum_fused && fused_done) *fused_done = true;
+      if (bk) launch_mfma256x4<true>(A, B, C, bias, addend, preact, M, N, K, lda, ldb, ldc, act, colsum_fused, st);
+      else launch_mfma256x4<false>(A, B, C, bias, addend, preact, M, N, K, lda, ldb, ldc, act, colsum_fused, st);
+      MMRCA_CHECK_LAUNCH("gemm(mfma,256x256,4 waves)");
       return 0;
     }
     if (impl == MMRCA_GEMM_MFMA_256W && (at || ak || N % 256 != 0))

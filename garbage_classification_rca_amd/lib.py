@@ -18,7 +18,7 @@ LIB_PATH = os.path.join(_HERE, "libmmrca.so")
 F32, BF16 = 0, 1
 ACT_NONE, ACT_GELU, ACT_GELU_BWD, ACT_GELU_SAVE_GRAD, ACT_MUL = 0, 1, 2, 3, 4
 ROWK, KROW = 0, 1
-IMPL_AUTO, IMPL_REF, IMPL_MFMA, IMPL_MFMA256, IMPL_MFMA_PERSIST, IMPL_MFMA_BK32, IMPL_MFMA_1STAGE, IMPL_MFMA_TALL, IMPL_MFMA_256W = 0, 1, 2, 3, 4, 5, 6, 7, 8
+IMPL_AUTO, IMPL_REF, IMPL_MFMA, IMPL_MFMA256, IMPL_MFMA_PERSIST, IMPL_MFMA_BK32, IMPL_MFMA_1STAGE, IMPL_MFMA_TALL, IMPL_MFMA_256W, IMPL_MFMA_256X4 = 0, 1, 2, 3, 4, 5, 6, 7, 8, 9
 
 HEAD_FIELDS = [f"{blk}_{leaf}" for blk in ("sai", "sat", "c1", "c2")
                for leaf in ("wq", "bq", "wk", "bk", "wv", "bv", "g", "b")] + ["fin_w", "fin_b"]

@@ -149,6 +149,23 @@ def test_gemm_single_stage_kernel(layouts):
 
 
 @pytest.mark.parametrize("bl", [0, 1])
+def test_gemm_256x256_four_wave_pipelined_kernel(bl):
+    """256x256x64 four-wave kernel (128x128 wave tiles, fragment double buffer across the 32-deep halves): ragged M,
+    one / odd / many K steps, every epilogue, exact integers."""
+    M, N, K = 512, 256, 192
+    A = ((torch.arange(M)[:, None] * 7 + torch.arange(K)[None, :] * 3) % 5 - 2.0)
+    B = ((torch.arange(N)[:, None] * 3 + torch.arange(K)[None, :] * 5) % 7 - 3.0)
+    Ad, Bd = dev(A, torch.bfloat16), dev(B if bl == 0 else B.t(), torch.bfloat16)
+    Cd = torch.empty(M, N, device="cuda", dtype=torch.bfloat16)
+    L.gemm(Ad, Bd, Cd, M=M, N=N, K=K, lda=K, ldb=Bd.shape[1], ldc=N, a_layout=0, b_layout=bl, dtype=L.BF16, impl=L.IMPL_MFMA_256X4)
+    torch.cuda.synchronize()
+    assert torch.equal(Cd.float().cpu(), (A @ B.t()).bfloat16().float())
+    for M, N, K in ((300, 256, 64), (1000, 512, 192), (513, 256, 320), (2000, 768, 768)):
+        _gemm_case(M, N, K, 0, bl, torch.bfloat16, L.IMPL_MFMA_256X4, bias=True)
+    _gemm_case(700, 512, 256, 0, bl, torch.bfloat16, L.IMPL_MFMA_256X4, act=L.ACT_GELU, bias=True, addend=True, preact=True)
+
+
+@pytest.mark.parametrize("bl", [0, 1])
 def test_gemm_256x256_sixteen_wave_kernel(bl):
     """256x256x64 sixteen-wave kernel: ragged M, one / odd / many K steps, every epilogue."""
     for M, N, K in ((300, 256, 64), (1000, 512, 192), (513, 256, 320)):
@@ -240,10 +257,10 @@ def test_gemm_fused_bias_gradient_and_gelu_backward(dt, impl):
 
 
 @pytest.mark.parametrize("dt,impl", [(torch.float32, L.IMPL_REF), (torch.bfloat16, L.IMPL_AUTO), (torch.bfloat16, L.IMPL_MFMA),
-                                     (torch.bfloat16, L.IMPL_MFMA_1STAGE), (torch.bfloat16, L.IMPL_MFMA_TALL), (torch.bfloat16, L.IMPL_MFMA_256W)])
+                                     (torch.bfloat16, L.IMPL_MFMA_1STAGE), (torch.bfloat16, L.IMPL_MFMA_TALL), (torch.bfloat16, L.IMPL_MFMA_256W), (torch.bfloat16, L.IMPL_MFMA_256X4)])
 def test_gemm_colsum_rides_on_the_input_gradient(dt, impl):
     """mmrca_gemm_colsum: dH = (dY W) * gelu'(h) and db += column sums of the stored dH (ragged M, several row tiles)."""
-    M, N, K = 788, (512 if impl == L.IMPL_MFMA_256W else 384), 256            # dY [M,K], W [K,N] (KROW), C [M,N]
+    M, N, K = 788, (512 if impl in (L.IMPL_MFMA_256W, L.IMPL_MFMA_256X4) else 384), 256            # dY [M,K], W [K,N] (KROW), C [M,N]
     g = torch.Generator().manual_seed(5)
     dY, W = dev(torch.randn(M, K, generator=g), dt), dev(torch.randn(K, N, generator=g) * 0.1, dt)
     Gp, add = dev(torch.rand(M, N, generator=g), dt), dev(torch.randn(M, N, generator=g), dt)

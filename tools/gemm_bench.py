@@ -16,7 +16,7 @@ SHAPES = [  # (name, M, N, K, a_layout, b_layout, accum)
     ("epi out addend", M, 768, 768, 0, 0, 0), ("epi ffn2 addend", M, 768, 3072, 0, 0, 0),
     ("text fwd qkv", 16384, 2304, 768, 0, 0, 0), ("text fwd out", 16384, 768, 768, 0, 0, 0),
 ]
-impls = {"auto": L.IMPL_AUTO}
+impls = {"auto": L.IMPL_AUTO, "1stage": L.IMPL_MFMA_1STAGE, "bk32": L.IMPL_MFMA_BK32}
 DBG = [int(x) for x in os.environ.get("MMRCA_DBG", "0").split(",")]
 only = sys.argv[1:] 
 L.load()
@@ -48,7 +48,7 @@ for name, m, n, k, al, bl, acc in SHAPES:
     for iname, impl, dbg in variants:
         if impl == L.IMPL_MFMA256 and (acc or n % 256 or (al == 1 and m % 256)):
             continue
-        if impl in (L.IMPL_MFMA_TALL, L.IMPL_MFMA_256W) and (acc or al == 1 or (impl == L.IMPL_MFMA_256W and n % 256)):
+        if impl in (L.IMPL_MFMA_TALL, L.IMPL_MFMA_256W, L.IMPL_MFMA_256X4) and (acc or al == 1 or (impl != L.IMPL_MFMA_TALL and n % 256)):
             continue
         def run(impl=impl, dbg=dbg):
             L.load().mmrca_debug_set(dbg)
