@@ -38,56 +38,59 @@ def find_classes(directory: str) -> Tuple[List[str], Dict[str, int]]:
     return classes, {c: i for i, c in enumerate(classes)}
 
 
+def _long_caption_table(csv_path):
+    """``filename -> description`` of the extended-description CSV (reference :60-68); a broken file ends the run."""
+    if csv_path is None:
+        return None
+    try:
+        import pandas as pd
+        return pd.read_csv(csv_path, dtype=str).set_index("filename")["description"]
+    except Exception as exc:                                     # the reference exits here as well
+        print(f"Error reading {csv_path}: {exc}", file=sys.stderr)
+        sys.exit(1)
+
+
+def _files_below(folder: str):
+    """every file under ``folder`` (links followed), directories and names in sorted order -- the reference's walk order"""
+    for here, _dirs, names in sorted(os.walk(folder, followlinks=True)):
+        for name in sorted(names):
+            yield os.path.join(here, name)
+
+
 def custom_make_dataset(directory: str, extended_desc, class_to_idx: Optional[Dict[str, int]] = None,
                         extensions: Optional[Union[str, Tuple[str, ...]]] = None,
                         is_valid_file: Optional[Callable[[str], bool]] = None):
-    """Returns (per_class_lists, instances).  ``per_class_lists`` has exactly four lists, as the reference (:94)."""
+    """(per_class_lists, instances): one ``({'text', 'image', 'long_text'}, class_index)`` per accepted file, classes in
+    name order, files in walk order.  ``per_class_lists`` has exactly FOUR lists, as the reference (:94) -- the path
+    assumes the four garbage classes."""
     directory = os.path.expanduser(directory)
     if class_to_idx is None:
-        _, class_to_idx = find_classes(directory)
-    elif not class_to_idx:
+        class_to_idx = find_classes(directory)[1]
+    elif len(class_to_idx) == 0:
         raise ValueError("'class_to_index' must have at least one entry to collect any samples.")
     if (extensions is None) == (is_valid_file is None):
         raise ValueError("Both extensions and is_valid_file cannot be None or not None at the same time")
-    if extensions is not None:
-        def is_valid_file(x: str) -> bool:  # noqa: F811
-            return has_file_allowed_extension(x, extensions)
-    lookup = None
-    if extended_desc is not None:
-        try:
-            import pandas as pd
-            df = pd.read_csv(extended_desc, dtype=str)
-            lookup = df.set_index("filename")["description"]
-        except Exception as e:
-            print(f"Error reading {extended_desc}: {e}", file=sys.stderr)
-            sys.exit(1)
-    available = set()
-    per_class_lists: List[list] = [[], [], [], []]
-    instances = []
-    for target_class in sorted(class_to_idx.keys()):
-        class_index = class_to_idx[target_class]
-        target_dir = os.path.join(directory, target_class)
-        if not os.path.isdir(target_dir):
+    accept = is_valid_file if extensions is None else (lambda f: has_file_allowed_extension(f, extensions))
+    captions = _long_caption_table(extended_desc)
+    per_class_lists: List[list] = [[] for _ in range(4)]
+    instances, seen = [], set()
+    for cls_name in sorted(class_to_idx):
+        folder = os.path.join(directory, cls_name)
+        if not os.path.isdir(folder):
             continue
-        for root, _, fnames in sorted(os.walk(target_dir, followlinks=True)):
-            for fname in sorted(fnames):
-                path = os.path.join(root, fname)
-                if not is_valid_file(path):
-                    continue
-                p = Path(path)
-                long_desc = ""
-                if lookup is not None:
-                    long_desc = lookup.get(os.path.join(p.parent.name, p.name))
-                item = ({"text": pre_process_text(p.stem), "image": path, "long_text": long_desc}, class_index)
-                per_class_lists[class_index].append(item)
-                instances.append(item)
-                available.add(target_class)
-    empty = set(class_to_idx.keys()) - available
-    if empty:
-        msg = f"Found no valid file for the classes {', '.join(sorted(empty))}. "
-        if extensions is not None:
-            msg += f"Supported extensions are: {extensions if isinstance(extensions, str) else ', '.join(extensions)}"
-        raise FileNotFoundError(msg)
+        for file_path in _files_below(folder):
+            if not accept(file_path):
+                continue
+            fp = Path(file_path)
+            long_text = "" if captions is None else captions.get(os.path.join(fp.parent.name, fp.name))
+            entry = ({"text": pre_process_text(fp.stem), "image": file_path, "long_text": long_text}, class_to_idx[cls_name])
+            per_class_lists[class_to_idx[cls_name]].append(entry)
+            instances.append(entry)
+            seen.add(cls_name)
+    missing = sorted(set(class_to_idx) - seen)
+    if missing:
+        hint = "" if extensions is None else (" Supported extensions are: " + (extensions if isinstance(extensions, str) else ", ".join(extensions)))
+        raise FileNotFoundError(f"Found no valid file for the classes {', '.join(missing)}." + hint)
     return per_class_lists, instances
 
 
@@ -113,43 +116,37 @@ class DatasetFolder(torch.utils.data.Dataset):
                  target_transform: Optional[Callable] = None, is_valid_file: Optional[Callable[[str], bool]] = None,
                  list_custom_samples=None) -> None:
         self.root, self.transform, self.target_transform = root, transform, target_transform
-        classes, class_to_idx = self.find_classes(self.root)
-        custom_samples = ()
-        if self.root is not None:
-            custom_samples = custom_make_dataset(self.root, extended_desc, class_to_idx, extensions, is_valid_file)
-        self.per_class = None if root is None else custom_samples[0]
         self.loader, self.extensions = loader, extensions
-        self.classes, self.class_to_idx = classes, class_to_idx
         self.tokens_max_len, self.tokenizer, self.extended_desc = tokens_max_len, tokenizer_text, extended_desc
-        if list_custom_samples is not None:
-            self.samples = list_custom_samples
-        else:
-            self.samples = custom_samples[1]
-        self.targets = [s[1] for s in self.samples]
+        self.classes, self.class_to_idx = self.find_classes(root)
+        listed = custom_make_dataset(root, extended_desc, self.class_to_idx, extensions, is_valid_file) if root is not None else None
+        self.per_class = None if listed is None else listed[0]
+        # a caller may hand in its own (sub)list of samples, e.g. a balanced resampling of ``per_class`` (reference :196-201)
+        self.samples = list_custom_samples if list_custom_samples is not None else listed[1]
+        self.targets = [cls for _, cls in self.samples]
 
     def find_classes(self, directory: str):
         return find_classes(directory)
 
     def __getitem__(self, index: int):
-        path, target = self.samples[index]
-        sample_image = self.loader(path["image"])
+        record, target = self.samples[index]
+        image = self.loader(record["image"])
         if self.transform is not None:
-            sample_image = self.transform(sample_image)
+            image = self.transform(image)
         if self.target_transform is not None:
             target = self.target_transform(target)
-        text_key = "long_text" if self.extended_desc is not None else "text"
-        tokens_dict = {"original_text": path[text_key]}
+        caption = record["long_text" if self.extended_desc is not None else "text"]
+        text = {"original_text": caption}
         if self.tokenizer is not None:
             # pre-tokenised caption cache: a caption is tokenised once per worker, not once per
             # epoch -- the result depends only on (caption, max_len), the reference re-runs encode_plus every time (:305-336)
             cache = self.__dict__.setdefault("_token_cache", {})
-            hit = cache.get(path[text_key])
+            hit = cache.get(caption)
             if hit is None:
-                enc = _tokenize(self.tokenizer, path[text_key], self.tokens_max_len)
-                hit = (enc["input_ids"].flatten(), enc["attention_mask"].flatten())
-                cache[path[text_key]] = hit
-            tokens_dict["tokens"], tokens_dict["attention_mask"] = hit[0].clone(), hit[1].clone()
-        return {"image": {"raw_image": sample_image, "image_path": path["image"]}, "text": tokens_dict}, target
+                enc = _tokenize(self.tokenizer, caption, self.tokens_max_len)
+                hit = cache[caption] = (enc["input_ids"].flatten(), enc["attention_mask"].flatten())
+            text["tokens"], text["attention_mask"] = hit[0].clone(), hit[1].clone()
+        return {"image": {"raw_image": image, "image_path": record["image"]}, "text": text}, target
 
     def __len__(self) -> int:
         return len(self.samples)

@@ -1,54 +1,71 @@
-"""Command line of the training / evaluation scripts: every flag and default of the reference's shared parser
-(options.py:8-116 -- 33 flags, BooleanOptionalAction pairs included), plus additive flags for this build.
+"""Command line of the training / evaluation scripts.
+
+The flag NAMES, TYPES and DEFAULTS are the reference's shared parser (options.py:8-116: 33 flags, the boolean ones as
+``--flag / --no-flag`` pairs) -- that is the interface a reference launch line relies on and what
+tests/golden/options_goldens.json pins.  The table form and the descriptions are this build's own.
 """
 import argparse
 
+_INT, _FLOAT, _STR, _BOOL = "int", "float", "str", "bool"
+
+# (flag, kind, default, description)
+REFERENCE_FLAGS = [
+    ("epochs", _INT, 100, "epochs of the frozen-backbone phase"),
+    ("dataset_folder_name", _STR, "", "training split: folder under --base_path"),
+    ("dataset_folder_name_val", _STR, "", "validation split: folder under --base_path"),
+    ("lr", _FLOAT, 0.001, "learning rate of the first phase"),
+    ("image_text_dropout", _FLOAT, 0.33, "probability that a training step zeroes one modality"),
+    ("image_prob_dropout", _FLOAT, 0.7, "given that a modality is zeroed: probability that it is the image"),
+    ("reg", _FLOAT, 1e-2, "weight decay"),
+    ("model_dropout", _FLOAT, 0.6, "dropout in front of the classifier"),
+    ("tl", _BOOL, True, "start with frozen backbones (transfer learning)"),
+    ("balance_weights", _BOOL, False, "class-balanced loss weights"),
+    ("ft_epochs", _INT, 15, "epochs of the fine-tuning phase"),
+    ("fraction_lr", _FLOAT, 5, "fine-tuning learning rate = lr / fraction_lr"),
+    ("image_model", _STR, "b4", "image backbone"),
+    ("text_model", _STR, "distilbert", "text backbone"),
+    ("model_path", _STR, "", "checkpoint evaluated by the test-split script"),
+    ("acc_steps", _INT, 0, "micro-batches per optimizer step, first phase (0: every batch)"),
+    ("acc_steps_FT", _INT, 0, "micro-batches per optimizer step, fine-tuning phase"),
+    ("num_neurons_FC", _INT, 256, "width of the (unused by MM_RCA) fully connected layers"),
+    ("batch_size", _INT, 16, "batch size, first phase"),
+    ("batch_size_FT", _INT, 16, "batch size, fine-tuning phase"),
+    ("opt", _STR, "sgd", "sgd | adamw"),
+    ("base_path", _STR, r"D:\Mestrado\ENSF_619_02_Final_project_jose_cazarin\BEST_MODELS_CVPR_2025", "root of datasets and checkpoints"),
+    ("calculate_dataset_stats", _BOOL, False, "recompute the normalisation statistics"),
+    ("prob_aug", _FLOAT, 0.6, "probability of each image augmentation"),
+    ("late_fusion", _STR, "gated", "fusion head (MM_RCA is the one built here)"),
+    ("label_smoothing", _FLOAT, 0.0, "label smoothing of the loss"),
+    ("name", _STR, None, "free-text run description"),
+    ("reverse", _BOOL, False, "reverse cross-attention, (1 - A) / (n - 1)"),
+    ("features_only", _BOOL, False, "classifier sees the backbone features only"),
+    ("cross_attention_only", _BOOL, False, "classifier sees the cross-attention outputs only"),
+    ("extended_desc_train", _STR, None, "CSV of long captions, training split"),
+    ("extended_desc_val", _STR, None, "CSV of long captions, validation split"),
+    ("balanced_sampler", _BOOL, False, "class-balanced batch sampling"),
+    ("use_synonyms", _BOOL, False, "synonym augmentation of captions"),
+    ("prob_aug_text", _FLOAT, 0.6, "probability of the caption augmentation"),
+    ("classifier_weights", _STR, None, "classifier-head weights of the Q-Former model"),
+]
+
+# additive flags of this build (none of the above changed meaning)
+BUILD_FLAGS = [
+    ("tokens_max_len", _INT, None, "caption length (default: the text model's maximum, as in the reference)"),
+    ("synthetic", _INT, 0, ">0: train on this many synthetic pairs instead of a folder"),
+    ("num_workers", _INT, 16, "DataLoader workers"),
+    ("seed", _INT, None, "seed torch / numpy"),
+]
+
 
 def build_parser() -> argparse.ArgumentParser:
-    p = argparse.ArgumentParser()
-    B = argparse.BooleanOptionalAction
-    p.add_argument('--epochs', type=int, default=100, help="number of rounds of training")
-    p.add_argument('--dataset_folder_name', type=str, default="", help="dataset folder name in the base location")
-    p.add_argument('--dataset_folder_name_val', type=str, default="", help="val dataset folder name in the base location")
-    p.add_argument('--lr', type=float, default=0.001, help='learning rate')
-    p.add_argument('--image_text_dropout', type=float, default=0.33, help='change of dropping either text or image')
-    p.add_argument('--image_prob_dropout', type=float, default=0.7, help='change of dropping image when dropping the modalities')
-    p.add_argument('--reg', type=float, default=1e-2, help='regularization rate')
-    p.add_argument('--model_dropout', type=float, default=0.6, help='model FC layer dropout')
-    p.add_argument('--tl', action=B, default=True, help="Whether to use transfer learning or not")
-    p.add_argument('--balance_weights', action=B, default=False, help="Whether to use class balance weights or not")
-    p.add_argument('--ft_epochs', type=int, default=15, help='number of fine tuning epochs')
-    p.add_argument('--fraction_lr', type=float, default=5, help='value to divide the regular LR for to use in fine tuning')
-    p.add_argument('--image_model', type=str, default='b4', help='model name')
-    p.add_argument('--text_model', type=str, default='distilbert', help='model name')
-    p.add_argument('--model_path', type=str, default="", help='Model file to calculate accuracy against the test set.')
-    p.add_argument('--acc_steps', type=int, default=0, help='Gradient accumulation steps')
-    p.add_argument('--acc_steps_FT', type=int, default=0, help='Gradient accumulation steps')
-    p.add_argument('--num_neurons_FC', type=int, default=256, help='Num neurons in FC layers')
-    p.add_argument('--batch_size', type=int, default=16, help='Batch size')
-    p.add_argument('--batch_size_FT', type=int, default=16, help='Batch size for fine tuning')
-    p.add_argument('--opt', type=str, default="sgd", help='Optimizer to use')
-    p.add_argument('--base_path', type=str, default=r"D:\Mestrado\ENSF_619_02_Final_project_jose_cazarin\BEST_MODELS_CVPR_2025", help='base_path')
-    p.add_argument('--calculate_dataset_stats', action=B, default=False, help="Calculate the development set stats used for normalization")
-    p.add_argument('--prob_aug', type=float, default=0.6, help='Probability of applying augmentations')
-    p.add_argument('--late_fusion', type=str, default="gated", help='Which late fusion strategy to use')
-    p.add_argument('--label_smoothing', type=float, default=0.0, help='Fraction to use Label Smoothing')
-    p.add_argument('--name', type=str, help='Run description')
-    p.add_argument('--reverse', action=B, default=False, help="Use RCA or not")
-    p.add_argument('--features_only', action=B, default=False, help="Use only the extracted features or not")
-    p.add_argument('--cross_attention_only', action=B, default=False, help="Use only the cross attention features or not")
-    p.add_argument('--extended_desc_train', type=str, help='Path to extended description train CSV file')
-    p.add_argument('--extended_desc_val', type=str, help='Path to extended description val CSV file')
-    p.add_argument('--balanced_sampler', action=B, default=False, help="Use balanced sampler or not")
-    p.add_argument('--use_synonyms', action=B, default=False, help="Use synonymizer augmentation for text")
-    p.add_argument('--prob_aug_text', type=float, default=0.6, help='Prob of applying text synonymization augmentations')
-    p.add_argument('--classifier_weights', type=str, help='Path to weights file of the classifier head in the Q-Former model')
-    # ---- additive flags of this build (none of the above changed meaning) ----
-    p.add_argument('--tokens_max_len', type=int, default=None, help='caption length (default: the text model maximum, as the reference)')
-    p.add_argument('--dtype', type=str, default="bf16", choices=["bf16", "fp32"], help='compute dtype of the HIP path')
-    p.add_argument('--synthetic', type=int, default=0, help='>0: train on this many synthetic (image, caption) pairs instead of a folder')
-    p.add_argument('--num_workers', type=int, default=16, help='DataLoader workers (reference: 16)')
-    p.add_argument('--seed', type=int, default=None, help='seed torch/numpy (reference leaves this commented out)')
+    p = argparse.ArgumentParser(description=__doc__.splitlines()[0])
+    cast = {_INT: int, _FLOAT: float, _STR: str}
+    for flag, kind, default, text in REFERENCE_FLAGS + BUILD_FLAGS:
+        if kind == _BOOL:
+            p.add_argument("--" + flag, action=argparse.BooleanOptionalAction, default=default, help=text)
+        else:
+            p.add_argument("--" + flag, type=cast[kind], default=default, help=text)
+    p.add_argument("--dtype", type=str, default="bf16", choices=["bf16", "fp32"], help="compute dtype of the HIP path")
     return p
 
 
