@@ -279,6 +279,23 @@ def test_gemm_colsum_rides_on_the_input_gradient(dt, impl):
         assert rel_err(db - db0, C.float().sum(0)) < 1e-4          # sums of what was stored
 
 
+def test_gemm_auto_dispatch_random_shape_sweep():
+    """AUTO dispatch (single-stage forward / input-gradient kernel, 128x128x32 and two-stage weight-gradient kernels) over a
+    seeded sweep of ragged shapes: every layout, K from one step to many, M not a multiple of anything."""
+    rng = np.random.RandomState(2024)
+    for case in range(24):
+        al, bl = int(rng.randint(0, 2)), int(rng.randint(0, 2))
+        N = 128 * int(rng.randint(1, 7))
+        K = 64 * int(rng.randint(1, 14))
+        M = 128 * int(rng.randint(1, 9)) if al == L.KROW else int(rng.randint(1, 1100))
+        accum = bool(al == L.KROW and bl == L.KROW and rng.randint(0, 2))
+        if accum:
+            _gemm_case(M, N, K, al, bl, torch.bfloat16, L.IMPL_AUTO, accum=True)
+        else:
+            _gemm_case(M, N, K, al, bl, torch.bfloat16, L.IMPL_AUTO, bias=bool(rng.randint(0, 2)), addend=bool(rng.randint(0, 2)),
+                       act=(L.ACT_GELU if rng.randint(0, 2) else L.ACT_NONE), preact=bool(rng.randint(0, 2)))
+
+
 def test_gemm_rejects_bad_arguments():
     a = torch.zeros(4, 4, device="cuda")
     with pytest.raises(L.MmrcaError):
