@@ -83,8 +83,8 @@ def cpu_baseline(batch=8, steps=12, seq_len=64):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=8)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--batch", type=int, default=256, help="per-GPU batch (BASELINE config: 256)")
     ap.add_argument("--seq_len", type=int, default=64)
     ap.add_argument("--no_cpu_baseline", action="store_true")
