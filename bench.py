@@ -80,11 +80,42 @@ def cpu_baseline(batch=8, steps=12, seq_len=64):
                       f"batch {batch}, S={seq_len}, {steps} timed steps after 1 warm-up, {n} threads"}
 
 
+def parity_check(model, ids, mask, images, n=8):
+    """Logits of the benchmarked bf16 engine and of the fp32 parity mode against the oracle (CPU fp32) on the first `n`
+    synthetic pairs, with the benchmarked model's CURRENT weights (eval mode: no dropout).  Runs after the timed region;
+    the oracle is the checker here, never the thing measured."""
+    from oracle import model as O
+    from garbage_classification_rca_amd.engine import MMRCAEngine, make_text_pack
+    eng = model.engine
+    sd = {k: eng.arena.view(k).detach().cpu().clone() for k in eng.param_keys}
+    orc = O.build_oracle(eng.ts.name, eng.vs.name, eng.reverse, eng.mode == 1, eng.mode == 2, drop_ratio=0.0, enc_dropout=0.0).eval()
+    orc.text_model.load_flat(sd, "text_model.")
+    orc.image_model.load_flat(sd, "image_model.")
+    orc.load_state_dict({k: v for k, v in sd.items() if not k.startswith(("text_model.", "image_model."))}, strict=False)
+    i_h, m_h, x_h = ids[:n].cpu(), mask[:n].cpu(), images[:n].float().cpu()
+    torch.set_num_threads(effective_cores())
+    with torch.no_grad():
+        ref = orc(i_h, m_h, x_h, eval=True)
+    rel = lambda a: float(((a.float().cpu() - ref).abs().max() / ref.abs().max()).item())
+    pack = make_text_pack(m_h.numpy(), ids.device)
+    eng.refresh_working_copy(force=True)
+    l16 = eng.forward(ids[:n], mask[:n], images[:n], save=False, text_pack=pack)
+    out = {"bf16_logits_rel": round(rel(l16), 6), "samples": n,
+           "reference": "oracle (CPU fp32 restatement pinned by the reference's goldens), same weights, eval mode"}
+    eng32 = MMRCAEngine(eng.ts.name, eng.vs.name, eng.n_classes, eng.reverse, eng.mode, torch.float32, eng.device)
+    eng32.load_arrays(sd)
+    l32 = eng32.forward(ids[:n], mask[:n], images[:n], save=False)
+    out["fp32_logits_rel"] = round(rel(l32), 8)
+    eng32.release_buffers()
+    out["north_star_bound"] = 1e-3
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--steps", type=int, default=64)
+    ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--batch", type=int, default=256, help="per-GPU batch (BASELINE config: 256)")
     ap.add_argument("--seq_len", type=int, default=64)
     ap.add_argument("--no_cpu_baseline", action="store_true")
@@ -179,12 +210,14 @@ def main():
         step(0)
         torch.cuda.synchronize()
         L.GEMM_PROFILE = []
+        L.KERNEL_PROFILE = []
         ts0 = time.perf_counter()
         for i in range(replay):
             step(i)
         torch.cuda.synchronize()
         serial_ms = (time.perf_counter() - ts0) / replay * 1e3
     prof, L.GEMM_PROFILE = L.GEMM_PROFILE, None
+    kprof, L.KERNEL_PROFILE = L.KERNEL_PROFILE, None
     eng._side_v, eng._side_t, eng._side, eng._text_stream = saved_streams
     if world > 1 and os.environ.get("MMRCA_CHECK_REPLICAS") == "1":
         # data-parallel invariant: every rank applied the same averaged gradient, so the replicas are bit-identical
@@ -214,11 +247,13 @@ def main():
         # rocprofv3 --pmc passes over THIS command (tools/pmc_traffic.py) is quoted, next to the algorithmic bytes
         # (operands once + outputs once, from the launch shapes of this run)
         traffic, traffic_src = None, None
-        pmc_json = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r01_pmc_hbm_traffic.json")
-        if os.path.exists(pmc_json):
-            with open(pmc_json) as fh:
-                traffic = json.load(fh).get("gemm_hbm_bytes_per_launch_mean")
-            traffic_src = "profiles/r01_pmc_hbm_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes, x2 gfx950 fetch correction)"
+        for pmc_name in ("r02_pmc_hbm_traffic.json", "r01_pmc_hbm_traffic.json"):
+            pmc_json = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", pmc_name)
+            if os.path.exists(pmc_json):
+                with open(pmc_json) as fh:
+                    traffic = json.load(fh).get("gemm_hbm_bytes_per_launch_mean")
+                traffic_src = f"profiles/{pmc_name} (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes, x2 gfx950 fetch correction)"
+                break
         alg = []
         for f, kind, e0, e1, shp in prof:
             Mg, Ng, Kg, actg = shp
@@ -237,6 +272,46 @@ def main():
         fwd_gflop = FWD_GFLOP_PER_SAMPLE if (args.text_model, args.image_model, S) == ("distilbert", "transformer_B16", 64) else (
             145.5 if (args.text_model, args.image_model, S) == ("bert", "transformer_L16", 128) else float("nan"))
         train_flop_per_sample = (fwd_gflop * (1.0 if args.frozen else 3.0)) * 1e9
+
+        # attention kernels (K3): algorithmic QK^T + PV FLOPs (forward 4 S^2 d per (b,h); backward 2.5x that: five products,
+        # recomputation not counted) over the HIP-event time of the mha_* launches of the replay
+        lens = mask_host.reshape(nb, B, S).sum(-1).astype("float64")             # live caption lengths per batch
+        def attn_flops(kind, meta, batch_idx):
+            Bm, Hm, Sm, dm, packed = meta
+            s2 = float((lens[batch_idx] ** 2).sum()) if packed else float(Bm) * Sm * Sm
+            return 4.0 * Hm * dm * s2 * (1.0 if kind == "mha_fwd" else 2.5)
+        akind = {"mha_fwd": [0.0, 0.0, 0], "mha_bwd": [0.0, 0.0, 0]}
+        hk = {"head_fwd": [0.0, 0], "head_bwd": [0.0, 0]}
+        per_step = max(1, len(kprof) // replay)
+        for idx, (kind, meta, e0, e1) in enumerate(kprof):
+            dt_ms = e0.elapsed_time(e1)
+            if kind in akind:
+                akind[kind][0] += attn_flops(kind, meta, (idx // per_step) % nb); akind[kind][1] += dt_ms; akind[kind][2] += 1
+            elif kind in hk:
+                hk[kind][0] += dt_ms; hk[kind][1] += 1
+        a_fl, a_ms = akind["mha_fwd"][0] + akind["mha_bwd"][0], akind["mha_fwd"][1] + akind["mha_bwd"][1]
+        tf = lambda fl, ms_: round(fl / (ms_ * 1e-3) / 1e12, 1) if ms_ > 0 else None
+        attention = {"what": "fused attention kernels (QK^T, softmax, PV and their backward) of both encoders; algorithmic "
+                             "FLOPs = 4 S^2 d per (b,h) forward, 10 S^2 d backward (recomputation not counted)",
+                     "achieved": tf(a_fl, a_ms), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
+                     "frac": round(a_fl / (a_ms * 1e-3) / 1e12 / PEAK_BF16_TFLOPS, 4) if a_ms > 0 else None,
+                     "fwd_TFLOPs": tf(*akind["mha_fwd"][:2]), "bwd_TFLOPs": tf(*akind["mha_bwd"][:2]),
+                     "ms_per_step": round(a_ms / replay, 3), "launches_per_step": (akind["mha_fwd"][2] + akind["mha_bwd"][2]) // replay,
+                     "north_star_target_frac": 0.40}
+        # fused RCA head (K1): latency and HBM rate (4,112 B per sample + 190 KB of weights per launch)
+        d_i, d_t = eng.d_img, eng.d_txt
+        head_bytes = B * ((d_i + d_t) * 2 + 16) + 94820 * 2
+        hf = hk["head_fwd"][0] / max(hk["head_fwd"][1], 1) * 1e3
+        hb = hk["head_bwd"][0] / max(hk["head_bwd"][1], 1) * 1e3
+        head = {"what": "fused MM-RCA head (L2 norm, 2 self-attention + 2 reverse cross-attention blocks of 16x16, LN+ReLU, concat, "
+                        "dropout, classifier), one launch per direction", "fwd_us": round(hf, 1), "bwd_us": round(hb, 1),
+                "algorithmic_bytes_fwd": head_bytes, "fwd_GBps": round(head_bytes / (hf * 1e-6) / 1e9, 2) if hf > 0 else None,
+                "peak_GBps": 8000.0, "frac_of_hbm_peak": round(head_bytes / (hf * 1e-6) / 8e12, 6) if hf > 0 else None,
+                "bound": "launch latency (2.9 MFLOP and 4.1 KB per sample)"}
+        # whole step on EXECUTED FLOPs: GEMM launches (2MNK) + attention (algorithmic) per step; the nominal 3x-forward
+        # figure (which also counts rows the dead-row elimination never computes) is kept under its own key
+        exec_flop_per_step = flops / replay + a_fl / replay
+        step_s = elapsed / args.steps
         out = {
             "metric": "train samples/sec (image+text pairs), MM-RCA ViT-B16+DistilBERT", "value": round(value, 2),
             "unit": "samples/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -256,16 +331,21 @@ def main():
                          "frac": round(achieved / PEAK_BF16_TFLOPS, 4), "traffic": traffic,
                          "traffic_unit": "bytes per GEMM launch (mean over the launches of a step)", "traffic_source": traffic_src,
                          "algorithmic_bytes_per_launch": round(alg_mean),
-                         "kernel": "gemm_mfma_k1s / gemm_mfma_k32 (bf16 16x16x32 MFMA GEMM, 128x128 tiles; every nn.Linear fwd/dgrad/wgrad)",
+                         "kernel": "bf16 16x16x32 MFMA GEMMs: gemm_mfma_k1s (128x128 tiles, forward / input gradient), gemm_mfma256_k + "
+                                   "splitk_reduce256_k (256x256 tiles, weight gradient); every nn.Linear fwd/dgrad/wgrad",
                          "launches_per_step": len(prof) // replay, "gemm_ms_per_step": round(ms / replay, 3),
                          "measured_in": f"single-stream replay of {replay} steps after the timed region ({round(serial_ms, 2)} ms/step serialized)",
                          "by_layout_TFLOPs": {f"a{k[0]}b{k[1]}acc{k[2]}": round(v[0] / (v[1] * 1e-3) / 1e12, 1) for k, v in by_kind.items() if v[1] > 0},
-                         "flops_counted": "achieved = executed 2MNK of the GEMM launches; whole_step_* = nominal 3x forward model FLOPs "
-                                          "(the class-token tail executes ~5% fewer)",
-                         "whole_step_model_TFLOPs": round(value / world * train_flop_per_sample / 1e12, 2),
-                         "whole_step_frac": round(value / world * train_flop_per_sample / 1e12 / PEAK_BF16_TFLOPS, 4)},
+                         "flops_counted": "achieved = executed 2MNK of the GEMM launches / their HIP-event time; whole_step_* = executed "
+                                          "GEMM + attention FLOPs per step / wall time of the timed region",
+                         "whole_step_executed_TFLOPs": round(exec_flop_per_step / step_s / 1e12, 2),
+                         "whole_step_frac": round(exec_flop_per_step / step_s / 1e12 / PEAK_BF16_TFLOPS, 4),
+                         "whole_step_nominal_model_TFLOPs": round(value / world * train_flop_per_sample / 1e12, 2),
+                         "attention": attention, "head": head},
         }
         if not args.no_cpu_baseline and world == 1:
+            with contextlib.redirect_stdout(io.StringIO()):
+                out["parity"] = parity_check(model, ids, mask, images)
             out["cpu_baseline"] = cpu_baseline()
         print(json.dumps(out), flush=True)
     if world > 1:

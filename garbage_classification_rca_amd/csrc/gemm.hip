@@ -33,11 +33,16 @@ gemm_ref_k(const T* __restrict__ A, const T* __restrict__ B, void* __restrict__ 
   __shared__ float As[16][65], Bs[16][65];
   const int tx = threadIdx.x & 15, ty = threadIdx.x >> 4;
   const int64_t m0 = (int64_t)blockIdx.y * 64, n0 = (int64_t)blockIdx.x * 64;
-  float acc[4][4];
+  // Three-level summation (16 products -> 16 partials -> the rest): the rounding error of a length-K fp32 dot product
+  // then grows like sqrt(K/256) + 8 ulps instead of sqrt(K).  This kernel is the fp32 PARITY mode: with K up to 3,072
+  // (and 50 k for weight gradients) a single running sum put the encoder features ~1e-5 away from a float64 evaluation,
+  // which the head's softmax-gradient cancellation amplified to 2e-3 on its attention projections.
+  float acc[4][4], mid[4][4];
 #pragma unroll
   for (int i = 0; i < 4; ++i)
 #pragma unroll
-    for (int j = 0; j < 4; ++j) acc[i][j] = 0.f;
+    for (int j = 0; j < 4; ++j) acc[i][j] = mid[i][j] = 0.f;
+  int blk = 0;
   for (int64_t k0 = 0; k0 < K; k0 += 16) {
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
@@ -52,6 +57,11 @@ gemm_ref_k(const T* __restrict__ A, const T* __restrict__ B, void* __restrict__ 
       Bs[k2][nn] = (gn < N && gk2 < K) ? to_f(B[gn * sbn + gk2 * sbk]) : 0.f;
     }
     __syncthreads();
+    float part[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) part[i][j] = 0.f;
 #pragma unroll
     for (int kk = 0; kk < 16; ++kk) {
       float a[4], b[4];
@@ -60,10 +70,22 @@ gemm_ref_k(const T* __restrict__ A, const T* __restrict__ B, void* __restrict__ 
 #pragma unroll
       for (int i = 0; i < 4; ++i)
 #pragma unroll
-        for (int j = 0; j < 4; ++j) acc[i][j] = fmaf(a[i], b[j], acc[i][j]);
+        for (int j = 0; j < 4; ++j) part[i][j] = fmaf(a[i], b[j], part[i][j]);
     }
+    const bool fold = (++blk & 15) == 0;
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        mid[i][j] += part[i][j];
+        if (fold) { acc[i][j] += mid[i][j]; mid[i][j] = 0.f; }
+      }
     __syncthreads();
   }
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] += mid[i][j];
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
     const int64_t m = m0 + ty * 4 + i;
@@ -1478,10 +1500,10 @@ static void launch_mfma_p(const void* A, const void* B, void* C, const void* bia
 
 static bool aligned16(const void* p) { return (((uintptr_t)p) & 15) == 0; }
 
-bool mmrca_gemm256_ok(int64_t M, int64_t N, int64_t K, int a_layout);
+bool mmrca_gemm256_ok(int64_t M, int64_t N, int64_t K, int a_layout, int act);
 int mmrca_gemm256(const void* A, const void* B, void* C, const void* bias, const void* addend, void* preact, int64_t M,
                   int64_t N, int64_t K, int64_t lda, int64_t ldb, int64_t ldc, int a_layout, int b_layout, int act,
-                  hipStream_t st);
+                  float* colsum, hipStream_t st);
 
 extern int g_mmrca_dbg;
 #define MMRCA_TALL_MIN_M (1LL << 60)   // AUTO threshold for the 256x128 kernel (off until measured)
@@ -1515,13 +1537,18 @@ static int gemm_dispatch(const void* A, const void* B, void* C, const void* bias
                  (ldc % 4 == 0) && aligned16(A) && aligned16(B) && aligned16(C) && (!bias || aligned16(bias)) &&
                  (!addend || aligned16(addend)) && (!preact || aligned16(preact)) &&
                  (a_layout == MMRCA_ROWK || M % GBM == 0);
-  const bool ok256 = ok_mfma && !out_f32_accum && mmrca_gemm256_ok(M, N, K, a_layout);
+  const bool ok256 = ok_mfma && !out_f32_accum && mmrca_gemm256_ok(M, N, K, a_layout, act);
   if (impl == MMRCA_GEMM_MFMA256 && !ok256)
     return mmrca_fail(-3, "gemm: shape M=%lld N=%lld K=%lld does not qualify for the 256x256 MFMA kernel", (long long)M, (long long)N, (long long)K);
-  // measured (tools/gemm_bench.py, interleaved rounds): with the row-contiguous epilogue the 128x128 kernel at two blocks
-  // per CU is faster than the 256x256 kernel on every encoder shape, so AUTO never picks the large tile
-  if (ok256 && impl == MMRCA_GEMM_MFMA256)
-    return mmrca_gemm256(A, B, C, bias, addend, preact, M, N, K, lda, ldb, ldc, a_layout, b_layout, act, st);
+  // AUTO (tools/gemm_bench.py, interleaved rounds, round 2): the 256x256 kernel with its operand stream in flight across
+  // barriers runs its K loop at ~1.6 PFLOP/s-equivalent but pays ~10 us per tile outside the loop (one workgroup per CU:
+  // nothing overlaps the epilogue), so it wins where K is long and there is at least one full round of tiles:
+  // K >= 1536: 1,010-1,080 vs 900-950 TFLOP/s for the 128x128 single-stage kernel; K = 768: 750-915 vs 815-945.
+  const bool auto256 = impl == MMRCA_GEMM_AUTO && ok256 && K >= 1536 && ((M + 255) / 256) * (N / 256) >= 256;
+  if (ok256 && (impl == MMRCA_GEMM_MFMA256 || auto256)) {
+    if (colsum_fused && fused_done) *fused_done = true;
+    return mmrca_gemm256(A, B, C, bias, addend, preact, M, N, K, lda, ldb, ldc, a_layout, b_layout, act, colsum_fused, st);
+  }
   if ((impl == MMRCA_GEMM_MFMA || impl == MMRCA_GEMM_MFMA_PERSIST || impl == MMRCA_GEMM_MFMA_BK32 || impl == MMRCA_GEMM_MFMA_1STAGE || impl == MMRCA_GEMM_MFMA_TALL || impl == MMRCA_GEMM_MFMA_256W || impl == MMRCA_GEMM_MFMA_256X4) && !ok_mfma)
     return mmrca_fail(-3, "gemm: shape M=%lld N=%lld K=%lld dtype=%d does not qualify for the MFMA kernel", (long long)M, (long long)N, (long long)K, dtype);
   const bool use_mfma = ok_mfma && impl != MMRCA_GEMM_REF;   // 128x128 kernel

@@ -50,6 +50,7 @@ _i64, _i32, _f32, _vp, _u64 = C.c_int64, C.c_int, C.c_float, C.c_void_p, C.c_uin
 _SIGS = {
     "mmrca_gemm": [_vp] * 6 + [_i64] * 6 + [_i32] * 6 + [_vp],
     "mmrca_gemm_colsum": [_vp] * 7 + [_i64] * 6 + [_i32] * 5 + [_vp],
+    "mmrca_gemm_splitk": [_vp] * 4 + [_i64] * 7 + [_i32] * 2 + [_vp],
     "mmrca_image_preprocess": [_vp, _vp, _vp, _i32, _i32, _i32, _vp, _vp, _vp],
     "mmrca_colsum_accum": [_vp, _vp, _i64, _i64, _i64, _i32, _vp],
     "mmrca_gelu_bwd": [_vp, _vp, _vp, _i64, _i32, _vp],
@@ -73,7 +74,7 @@ _SIGS = {
     "mmrca_adamw_step": [_vp] * 5 + [_i64] + [_f32] * 5 + [_i32, _f32, _vp],
     "mmrca_cast_f32_to_bf16": [_vp, _vp, _i64, _vp],
 }
-EXPORTS = sorted(list(_SIGS) + ["mmrca_last_error", "mmrca_version", "mmrca_debug_set"])
+EXPORTS = sorted(list(_SIGS) + ["mmrca_last_error", "mmrca_version", "mmrca_debug_set", "mmrca_gemm_splitk_workspace_bytes"])
 
 
 def load(build_if_missing: bool = False):
@@ -91,6 +92,8 @@ def load(build_if_missing: bool = False):
         fn = getattr(lib, name)
         fn.argtypes = args
         fn.restype = C.c_int
+    lib.mmrca_gemm_splitk_workspace_bytes.argtypes = [_i64, _i64]
+    lib.mmrca_gemm_splitk_workspace_bytes.restype = _i64
     lib.mmrca_last_error.restype = C.c_char_p
     lib.mmrca_version.restype = C.c_int
     _lib = lib
@@ -127,6 +130,26 @@ def _dev(t: torch.Tensor, name: str):
 # thin typed wrappers (raw pointers in, nothing allocated)
 # ---------------------------------------------------------------------------------------------------------
 GEMM_PROFILE = None     # bench.py sets this to a list: every MFMA-qualified GEMM launch is bracketed by HIP events
+KERNEL_PROFILE = None   # bench.py sets this to a list: (kind, meta, start event, end event) of attention / head launches
+
+
+class _Bracket:
+    """HIP events around one launch on the current stream, recorded only while bench.py's replay asks for them."""
+
+    def __init__(self, kind, meta):
+        self.kind, self.meta, self.on = kind, meta, KERNEL_PROFILE is not None
+
+    def __enter__(self):
+        if self.on:
+            self.e0, self.e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            self.e0.record()
+        return self
+
+    def __exit__(self, *exc):
+        if self.on and exc[0] is None:
+            self.e1.record()
+            KERNEL_PROFILE.append((self.kind, self.meta, self.e0, self.e1))
+        return False
 
 
 def gemm_is_mfma(M, N, K, a_layout, dtype, impl):
@@ -154,6 +177,27 @@ def gemm(A, B, Cout, *, bias=None, addend=None, preact=None, M, N, K, lda, ldb, 
         GEMM_PROFILE.append((2.0 * M * N * K, (a_layout, b_layout, int(accum)), e0, e1, (M, N, K, act)))
 
 
+SPLITK_WS_BYTES = 64 << 20      # 256 partial tiles of 256x256 fp32: enough for every shape mmrca_gemm_splitk accepts
+
+
+def gemm_splitk_ok(M, N, K, dtype):
+    return dtype == BF16 and M % 256 == 0 and N % 256 == 0 and K % 64 == 0 and K >= 128 and (M // 256) * (N // 256) <= 256
+
+
+def gemm_splitk(A, B, Cout, workspace, *, M, N, K, lda, ldb, ldc, a_layout=KROW, b_layout=KROW):
+    """fp32 Cout += A (.) B over K on 256x256 tiles, partial tiles through `workspace` (uint8/any dtype tensor in HBM)"""
+    _dev(A, "gemm_splitk A")
+    prof = GEMM_PROFILE is not None
+    if prof:
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+    _check(load().mmrca_gemm_splitk(ptr(A), ptr(B), ptr(Cout), ptr(workspace), workspace.numel() * workspace.element_size(),
+                                    M, N, K, lda, ldb, ldc, a_layout, b_layout, stream_ptr()), "mmrca_gemm_splitk")
+    if prof:
+        e1.record()
+        GEMM_PROFILE.append((2.0 * M * N * K, (a_layout, b_layout, 1), e0, e1, (M, N, K, ACT_NONE)))
+
+
 def colsum_accum(dY, db, M, N, ld, dtype):
     _check(load().mmrca_colsum_accum(ptr(dY), ptr(db), M, N, ld, dtype, stream_ptr()), "mmrca_colsum_accum")
 
@@ -169,21 +213,23 @@ def gelu_bwd_colsum(dG, H, dH, db, M, N, ld, dtype):
 def mha_fwd(qkv, key_mask, out, lse, B, H, S, dh, scale, dtype, impl=IMPL_AUTO, drop_p=0.0, drop_seed=0, cu=None):
     """cu (int32 [B+1], device): packed token layout, sequence b = rows [cu[b], cu[b+1]); None = padded [B*S] rows"""
     _dev(qkv, "mha qkv")
-    _check(load().mmrca_mha_fwd(ptr(qkv), ptr(key_mask), ptr(out), ptr(lse), B, H, S, dh, scale, drop_p, drop_seed, ptr(cu), dtype,
-                                impl, stream_ptr()), "mmrca_mha_fwd")
+    with _Bracket("mha_fwd", (B, H, S, dh, cu is not None)):
+        _check(load().mmrca_mha_fwd(ptr(qkv), ptr(key_mask), ptr(out), ptr(lse), B, H, S, dh, scale, drop_p, drop_seed, ptr(cu), dtype,
+                                    impl, stream_ptr()), "mmrca_mha_fwd")
 
 
 def mha_bwd(qkv, key_mask, out, dout, lse, dqkv, B, H, S, dh, scale, dtype, impl=IMPL_AUTO, drop_p=0.0, drop_seed=0, colsum=None,
             cu=None, rows=None):
     """colsum (fp32 [3*H*dh], +=): column sums of dqkv = the in-projection bias gradient, reduced inside the kernels;
     rows = number of token rows (defaults to B*S; pass cu[B] for the packed layout)"""
-    if colsum is not None:
-        _check(load().mmrca_mha_bwd_colsum(ptr(qkv), ptr(key_mask), ptr(out), ptr(dout), ptr(lse), ptr(dqkv), ptr(colsum),
-                                           B * S if rows is None else rows, B, H, S, dh, scale, drop_p, drop_seed, ptr(cu), dtype,
-                                           impl, stream_ptr()), "mmrca_mha_bwd_colsum")
-        return
-    _check(load().mmrca_mha_bwd(ptr(qkv), ptr(key_mask), ptr(out), ptr(dout), ptr(lse), ptr(dqkv), B, H, S, dh, scale,
-                                drop_p, drop_seed, ptr(cu), dtype, impl, stream_ptr()), "mmrca_mha_bwd")
+    with _Bracket("mha_bwd", (B, H, S, dh, cu is not None)):
+        if colsum is not None:
+            _check(load().mmrca_mha_bwd_colsum(ptr(qkv), ptr(key_mask), ptr(out), ptr(dout), ptr(lse), ptr(dqkv), ptr(colsum),
+                                               B * S if rows is None else rows, B, H, S, dh, scale, drop_p, drop_seed, ptr(cu), dtype,
+                                               impl, stream_ptr()), "mmrca_mha_bwd_colsum")
+            return
+        _check(load().mmrca_mha_bwd(ptr(qkv), ptr(key_mask), ptr(out), ptr(dout), ptr(lse), ptr(dqkv), B, H, S, dh, scale,
+                                    drop_p, drop_seed, ptr(cu), dtype, impl, stream_ptr()), "mmrca_mha_bwd")
 
 
 def mha_cls_fwd(qkv, key_mask, out, lse, B, H, S, dh, scale, dtype, drop_p=0.0, drop_seed=0, cu=None):
@@ -238,13 +284,15 @@ def vit_assemble_bwd(dx, dproj, dcls, dpos, B, nP, D, dtype):
 
 def head_fwd(img, txt, w: HeadPtrs, logits, B, d_img, d_txt, n_classes, reverse, mode, drop_p, seed, dtype):
     _dev(img, "head img")
-    _check(load().mmrca_head_fwd(ptr(img), ptr(txt), C.byref(w), ptr(logits), B, d_img, d_txt, n_classes, int(reverse), mode,
-                                 drop_p, seed, dtype, stream_ptr()), "mmrca_head_fwd")
+    with _Bracket("head_fwd", (B, d_img, d_txt)):
+        _check(load().mmrca_head_fwd(ptr(img), ptr(txt), C.byref(w), ptr(logits), B, d_img, d_txt, n_classes, int(reverse), mode,
+                                     drop_p, seed, dtype, stream_ptr()), "mmrca_head_fwd")
 
 
 def head_bwd(dlogits, img, txt, w: HeadPtrs, g: HeadPtrs, dimg, dtxt, B, d_img, d_txt, n_classes, reverse, mode, drop_p, seed, dtype):
-    _check(load().mmrca_head_bwd(ptr(dlogits), ptr(img), ptr(txt), C.byref(w), C.byref(g), ptr(dimg), ptr(dtxt), B, d_img, d_txt,
-                                 n_classes, int(reverse), mode, drop_p, seed, dtype, stream_ptr()), "mmrca_head_bwd")
+    with _Bracket("head_bwd", (B, d_img, d_txt)):
+        _check(load().mmrca_head_bwd(ptr(dlogits), ptr(img), ptr(txt), C.byref(w), C.byref(g), ptr(dimg), ptr(dtxt), B, d_img, d_txt,
+                                     n_classes, int(reverse), mode, drop_p, seed, dtype, stream_ptr()), "mmrca_head_bwd")
 
 
 def xent_fwd_bwd(logits, labels, class_w, smoothing, loss, dlogits, B, Cc, grad_scale=1.0):

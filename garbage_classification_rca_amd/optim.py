@@ -22,6 +22,18 @@ class _FlatOptimizer(torch.optim.Optimizer):
         tt, ti = self.model._train_flags()
         return self.engine.trainable_spans(tt, ti)
 
+    def _named_spans(self):
+        """(name, lo, hi) of the trainable arena spans, never merged: text encoder | image encoder | head."""
+        tt, ti = self.model._train_flags()
+        i0, h0 = self.engine.groups["image_emb"][0], self.engine.groups["head"][0]
+        out = []
+        if tt:
+            out.append(("text", 0, i0))
+        if ti:
+            out.append(("image", i0, h0))
+        out.append(("head", h0, self.engine.arena.total))
+        return out
+
     @torch.no_grad()
     def zero_grad(self, set_to_none: bool = False):
         self.engine.arena.g.zero_()
@@ -52,15 +64,21 @@ class FlatAdamW(_FlatOptimizer):
         ar = self.engine.arena
         self.m = torch.zeros_like(ar.p)
         self.v = torch.zeros_like(ar.p)
+        # torch.optim.AdamW keeps a step count PER PARAMETER that starts when the parameter first receives a gradient
+        # (main_both.py:544-549 builds it over all parameters; frozen ones have grad None and are skipped).  The encoders
+        # are frozen for --epochs and unfrozen afterwards (main_both.py:690-697): their bias correction must start at
+        # t = 1 then, not at the head's count.  One counter per span that freezes / unfreezes as a unit.
+        self._span_steps = {"text": 0, "image": 0, "head": 0}
 
     @torch.no_grad()
     def step(self, closure=None, grad_scale: float = 1.0):
         gp = self.param_groups[0]
         ar = self.engine.arena
         self._step += 1
-        for a, b in self._spans():
+        for name, a, b in self._named_spans():
+            self._span_steps[name] += 1
             L.adamw_step(ar.p[a:b], ar.g[a:b], self.m[a:b], self.v[a:b], None if ar.lp is None else ar.lp[a:b], b - a,
                          float(gp["lr"]), float(gp["betas"][0]), float(gp["betas"][1]), float(gp["eps"]),
-                         float(gp["weight_decay"]), self._step, grad_scale)
+                         float(gp["weight_decay"]), self._span_steps[name], grad_scale)
         if ar.lp is not None:
             ar.lp_valid = True

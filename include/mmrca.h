@@ -66,6 +66,15 @@ int mmrca_gemm_colsum(const void* A, const void* B, void* C, const void* bias, c
                       float* colsum, int64_t M, int64_t N, int64_t K, int64_t lda, int64_t ldb, int64_t ldc,
                       int a_layout, int b_layout, int act, int dtype, int impl, void* stream);
 
+/* Weight gradient on 256x256 tiles with the contraction split over workgroups: C[M,N] (fp32) += A (.) B over K
+ * (torch autograd of nn.Linear: dW = dY^T X; same call sites as mmrca_gemm's accumulate mode).  bf16 operands, either
+ * layout; M % 256 == 0, N % 256 == 0, K % 64 == 0, at most 256 output tiles.  The per-workgroup fp32 partial tiles go
+ * through `workspace` (caller-owned, >= mmrca_gemm_splitk_workspace_bytes(M, N) bytes, one per concurrently used
+ * stream) with plain stores and a second launch adds them into C -- no atomics, bitwise reproducible. */
+int64_t mmrca_gemm_splitk_workspace_bytes(int64_t M, int64_t N);
+int mmrca_gemm_splitk(const void* A, const void* B, float* C, void* workspace, int64_t workspace_bytes, int64_t M,
+                      int64_t N, int64_t K, int64_t lda, int64_t ldb, int64_t ldc, int a_layout, int b_layout, void* stream);
+
 /* db[N] (fp32) += column sums of dY[M,N]  (bias gradients of every nn.Linear on the path). */
 int mmrca_colsum_accum(const void* dY, float* db, int64_t M, int64_t N, int64_t ld, int dtype, void* stream);
 

@@ -241,17 +241,24 @@ def test_packed_text_layout_in_the_fused_train_step_with_encoder_dropout():
 
 @pytest.mark.parametrize("mode", [0, 2])
 def test_fp32_logits_and_gradients_match_oracle(mode):
+    """fp32 engine vs the oracle evaluated in float64 (the oracle's own fp32 run is 2e-4 .. 5e-4 away from float64 on
+    the attention-projection gradients of the head: with the amplified test weights those gradients are differences of
+    nearly equal terms, so an fp32 reference carries its own rounding into the comparison; float64 does not)."""
     B, S_len = 3, 24
     eng, orc, sd = _build_pair(torch.float32, mode=mode)
     ids, mask, images = _inputs(B, S_len)
     logits = eng.forward(ids.cuda(), mask.cuda(), images.cuda())
+    with torch.no_grad():
+        ref32 = orc(ids, mask, images, eval=True)
+    assert rel(logits, ref32) < 1e-3                      # north-star bound, against the fp32 oracle as the reference runs it
+    orc = orc.double()
     for p in orc.parameters():
         p.requires_grad_(True)
-    ref = orc(ids, mask, images, eval=True)
-    assert rel(logits, ref.detach()) < 1e-3                      # north-star bound
+    ref = orc(ids, mask, images.double(), eval=True)
+    assert rel(logits, ref.detach()) < 1e-3
     labels = torch.tensor([0, 1, 2][:B])
     cw = torch.tensor([0.7, 1.3, 0.9, 1.1])
-    loss_ref = O.cross_entropy(ref, labels, cw, 0.1)
+    loss_ref = O.cross_entropy(ref, labels, cw.double(), 0.1)
     loss_ref.backward()
     loss, dl = torch.empty(1, device="cuda"), torch.empty(B, 4, device="cuda")
     L.xent_fwd_bwd(logits, labels.int().cuda(), cw.cuda(), 0.1, loss, dl, B, 4)
@@ -262,20 +269,76 @@ def test_fp32_logits_and_gradients_match_oracle(mode):
     named = {"text_model." + k.replace("/", "."): p for k, p in orc.text_model.params.items()}
     named.update({"image_model." + k.replace("/", "."): p for k, p in orc.image_model.params.items()})
     named.update({k: p for k, p in orc.named_parameters() if not k.startswith(("text_model.", "image_model."))})
-    worst = 0.0
+    worst, worst_k = 0.0, None
     gmax = max(float(p.grad.abs().max()) for p in named.values() if p.grad is not None)
     for k in eng.param_keys:
-        got = eng.arena.view(k, "g").cpu()
+        got = eng.arena.view(k, "g").cpu().double()
         gr = named[k].grad
         if gr is None:
             assert float(got.abs().max()) == 0.0, k
             continue
         err = (got - gr.view_as(got)).abs().max().item()
         scale = max(gr.abs().max().item(), 1e-3 * gmax)     # exactly-zero grads (key biases) compare on the global scale
-        worst = max(worst, err / scale)
-        assert err <= 5e-3 * scale, (k, err, scale)   # fp32 sums in a different order than torch-CPU; test weights are deliberately large
-    print("worst relative gradient error (fp32):", worst)
+        if err / scale > worst:
+            worst, worst_k = err / scale, k
+        assert err <= 2e-3 * scale, (k, err, scale)     # measured worst: 5e-4 (mode 0), 8e-4 (mode 2), on cross_attention_1.W_query.weight
+    print("worst relative gradient error (fp32 engine vs float64 oracle):", worst, worst_k)
     eng.release_buffers()
+
+
+def test_benchmarked_configuration_value_check_b256():
+    """BASELINE configs[1] at its exact shape: B=256, S=64, bf16, packed captions + class-token tail on (what bench.py
+    times).  Logits vs the oracle (CPU fp32) with the measured bf16 bound, and per-parameter-group gradient cosine vs
+    the fp32 engine (padded layout, full top layer: an independent path) for the same upstream gradient."""
+    from garbage_classification_rca_amd import engine as E
+    B, S_len = 256, 64
+    eng, orc, sd = _build_pair(torch.bfloat16)
+    ids_np, mask_np = synth_captions(B, S_len, seed=4321)
+    images = torch.from_numpy(proc_input("b256.images", (B, 3, 224, 224)))
+    ids, mask = torch.from_numpy(ids_np), torch.from_numpy(mask_np)
+    pack = E.make_text_pack(mask_np, "cuda")
+    assert pack is not None and E.CLS_TAIL
+    logits = eng.forward(ids.cuda(), mask.cuda(), images.cuda(), text_pack=pack)
+    torch.set_num_threads(max(1, min(16, len(os.sched_getaffinity(0)))))
+    with torch.no_grad():
+        ref = torch.cat([orc(ids[i:i + 32], mask[i:i + 32], images[i:i + 32], eval=True) for i in range(0, B, 32)])
+    e16 = rel(logits, ref)
+    print("B=256 bf16 logits relative error vs oracle:", e16)
+    assert torch.isfinite(logits).all() and e16 < 5e-2
+    gen = torch.Generator().manual_seed(1)
+    dfeat = (torch.randn(B, 768, generator=gen) * 0.1).cuda()
+    dcls = (torch.randn(B, 768, generator=gen) * 0.1).cuda()
+    eng.arena.g.zero_()
+    eng._vision_backward(dfeat.bfloat16(), eng._saved["vision"])
+    eng._text_backward(dcls.bfloat16(), eng._saved["text"])
+    g16 = eng.arena.g.clone()
+    eng.release_buffers()
+    del eng
+    torch.cuda.empty_cache()
+    import garbage_classification_rca_amd.engine as E2
+    old_tail = E2.CLS_TAIL
+    E2.CLS_TAIL = False
+    try:
+        eng32 = MMRCAEngine("distilbert", "transformer_B16", 4, True, 0, torch.float32)
+        eng32.load_arrays(sd)
+        l32 = eng32.forward(ids.cuda(), mask.cuda(), images.cuda())
+        e32 = rel(l32, ref)
+        print("B=256 fp32 logits relative error vs oracle:", e32)
+        assert e32 < 1e-3                                   # north-star bound at the benchmarked batch
+        eng32._vision_backward(dfeat, eng32._saved["vision"])
+        eng32._text_backward(dcls, eng32._saved["text"])
+    finally:
+        E2.CLS_TAIL = old_tail
+    worst = 1.0
+    for name, (lo, hi) in eng32.groups.items():
+        a, b = g16[lo:hi], eng32.arena.g[lo:hi]
+        if float(b.norm()) == 0:
+            continue
+        c = torch.nn.functional.cosine_similarity(a.double(), b.double(), dim=0).item()
+        worst = min(worst, c)
+        assert c > 0.99, (name, c)
+    print("B=256 worst per-group gradient cosine bf16 vs fp32:", worst)
+    eng32.release_buffers()
 
 
 def test_bf16_close_to_oracle_and_to_fp32():
@@ -359,6 +422,45 @@ def test_module_facade_state_dict_and_autograd():
         a = m(ids, mask, images, eval=True, remove_image=True)
         b = m(ids, mask, torch.zeros_like(images), eval=True)
     assert torch.equal(a, b)
+
+
+def test_adamw_bias_correction_restarts_when_the_encoders_unfreeze():
+    """--opt=adamw across the phase switch (main_both.py:544-549, 690-701): three frozen-phase steps (only the head has
+    gradients), then three fine-tuning steps at lr / fraction_lr.  torch.optim.AdamW keeps its step count per parameter,
+    so the encoders' first update is bias-corrected with t = 1; the flat optimizer must match torch on the same
+    gradient sequence for every parameter."""
+    import contextlib, io
+    from garbage_classification_rca_amd.multimodal_model import MM_RCA
+    from garbage_classification_rca_amd.optim import FlatAdamW
+    with contextlib.redirect_stdout(io.StringIO()):
+        m = MM_RCA(4, 0.0, 0.0, 0.7, 256, "distilbert", 4, True, False, False, image_model_name="transformer_B16",
+                   dtype=torch.float32, init_seed=3)
+    eng = m.engine
+    opt = FlatAdamW(m, lr=1e-3, weight_decay=1e-2)
+    h0 = eng.groups["head"][0]
+    # torch keeps ONE step per tensor, so the reference uses separate tensors for the encoder part and the head part
+    enc_p, head_p = eng.arena.p[:h0].clone().requires_grad_(True), eng.arena.p[h0:].clone().requires_grad_(True)
+    ref = torch.optim.AdamW([enc_p, head_p], lr=1e-3, weight_decay=1e-2)
+    gen = torch.Generator(device="cuda").manual_seed(0)
+    for step in range(6):
+        frozen = step < 3
+        if step == 3:
+            for p in m.parameters():
+                p.requires_grad = True
+            for grp in (opt.param_groups + ref.param_groups):
+                grp["lr"] = 1e-3 / 5
+        g = torch.randn(eng.arena.total, device="cuda", generator=gen) * 1e-2
+        if frozen:
+            g[:h0] = 0
+        eng.arena.g.copy_(g)
+        opt.step()
+        opt.zero_grad()
+        enc_p.grad = None if frozen else g[:h0].clone()
+        head_p.grad = g[h0:].clone()
+        ref.step()
+    torch.cuda.synchronize()
+    assert rel(eng.arena.p[:h0], enc_p.detach()) < 1e-6 and rel(eng.arena.p[h0:], head_p.detach()) < 1e-6
+    eng.release_buffers()
 
 
 def test_encoder_dropout_runs_and_is_seed_deterministic():

@@ -340,3 +340,44 @@ def test_make_text_pack_layout_and_fallbacks():
     assert make_text_pack(mask[:3, :24], "cpu") is None                   # B*T not a multiple of 64
     full = np.ones((2, 32), dtype=np.int64)
     assert make_text_pack(full, "cpu").M == 64                            # nothing to skip: identity layout
+
+
+# ------------------------------------------------------------------------------------------------ a4 / a5 goldens
+def test_state_dict_layout_equals_the_reference_constructor():
+    """a4: key -> shape of the reference's ``MM_RCA(...).state_dict()`` (multimodal_model.py:158-328), dumped by
+    tests/golden/make_goldens.py from the reference class for 2 text models x 4 flag combinations, against the product's
+    parameter inventories (what the module facade registers).  image_model.* is excluded there (torchvision absent)."""
+    import json
+    d = json.load(open(os.path.join(ROOT, "tests", "golden", "state_dict_layout.json")))
+    assert len(d) == 8
+    for cfg, ref in d.items():
+        text, fo, cao, bs, fc = cfg.split("|")
+        fo, cao = bool(int(fo.split("=")[1])), bool(int(cao.split("=")[1]))
+        bs, fc = int(bs.split("=")[1]), int(fc.split("=")[1])
+        mine = {"text_model." + k: list(s) for k, s in S.text_params(S.TEXT_SPECS[text])}
+        used = S.head_used_params(1280, 768, 4, fo, cao)
+        mine.update({k: list(s) for k, s in used})
+        mine.update({k: list(s) for k, s in S.head_unused_params(1280, 768, 4, fc, bs, fo, cao) if k not in dict(used)})
+        assert mine == ref, (cfg, sorted(set(mine) ^ set(ref))[:8], [k for k in mine if k in ref and mine[k] != ref[k]][:8])
+
+
+def test_product_drop_modalities_follows_the_reference_truth_table():
+    """a5: the PRODUCT's ``drop_modalities`` (not the oracle's copy) against the table recorded from the reference's
+    method (multimodal_model.py:420-455): which inputs are zeroed, int64 ids stay int64, and how many draws of the
+    global numpy RNG each call consumes."""
+    import types
+    from garbage_classification_rca_amd.multimodal_model import MM_RCA
+    g = np.load(os.path.join(ROOT, "tests", "golden", "head_goldens.npz"))
+    for row in g["dropmod_table"]:
+        ev, ri, rt, p_any, p_img, seed, z_img, z_ids, z_mask, draws, _ = row
+        m = types.SimpleNamespace(image_or_text_dropout_chance=p_any, img_dropout_prob=p_img,
+                                  _images=torch.ones(3, 3, 4, 4), _input_ids=torch.full((3, 8), 7, dtype=torch.int64),
+                                  _attention_mask=torch.ones(3, 8, dtype=torch.int64))
+        np.random.seed(int(seed))
+        MM_RCA.drop_modalities(m, bool(ev), bool(ri), bool(rt))
+        assert float(m._images.abs().sum() == 0) == z_img, row
+        assert float(m._input_ids.abs().sum() == 0) == z_ids and float(m._attention_mask.abs().sum() == 0) == z_mask, row
+        assert m._input_ids.dtype == torch.int64
+        nxt = np.random.rand()
+        fresh = np.random.RandomState(int(seed)).rand(6)
+        assert int(np.argmin(np.abs(fresh - nxt))) == int(draws), row

@@ -201,7 +201,7 @@ def test_gemm_persistent_kernel(layouts):
 @pytest.mark.parametrize("layouts", [(0, 0), (0, 1), (1, 1), (1, 0)])
 def test_gemm_mfma256_layouts_and_epilogues(layouts):
     """256x256 tile kernel with loads kept in flight across barriers: exact integers first, then random data with
-    every K-tile count from 1 (tail-only path) upward and a ragged M."""
+    K-tile counts from 2 (tail-only path) upward, odd and even (LDS stage parity of the tail), and a ragged M."""
     al, bl = layouts
     M, N, K = 512, 256, 192
     A = ((torch.arange(M)[:, None] * 7 + torch.arange(K)[None, :] * 3) % 5 - 2.0)
@@ -211,11 +211,39 @@ def test_gemm_mfma256_layouts_and_epilogues(layouts):
     L.gemm(Ad, Bd, Cd, M=M, N=N, K=K, lda=Ad.shape[1], ldb=Bd.shape[1], ldc=N, a_layout=al, b_layout=bl, dtype=L.BF16, impl=L.IMPL_MFMA256)
     torch.cuda.synchronize()
     assert torch.equal(Cd.float().cpu(), (A @ B.t()).bfloat16().float()), (al, bl)
-    for K in (64, 128, 320, 768):
+    for K in (128, 192, 320, 768, 832):
         Mr = 768 if al == L.KROW else 700
         _gemm_case(Mr, 512, K, al, bl, torch.bfloat16, L.IMPL_MFMA256, bias=True)
     Mr = 768 if al == L.KROW else 1000
-    _gemm_case(Mr, 256, 256, al, bl, torch.bfloat16, L.IMPL_MFMA256, act=L.ACT_GELU, bias=True, addend=True, preact=True)
+    _gemm_case(Mr, 256, 256, al, bl, torch.bfloat16, L.IMPL_MFMA256, bias=True, addend=True, preact=True)
+
+
+@pytest.mark.parametrize("bl", [0, 1])
+def test_gemm_mfma256_fused_gelu_epilogues_and_colsum(bl):
+    """The 256x256 kernel's compile-time epilogues: GELU with gelu' saved (forward FFN1), multiply by the saved gelu' with
+    the column sums of the stored result (input gradient of FFN2 + FFN1 bias gradient), residual addend; ragged M."""
+    dt = torch.bfloat16
+    M, N, K = 788, 512, 320
+    g = torch.Generator().manual_seed(11)
+    X = dev(torch.randn(M, K, generator=g) * 0.3, dt)
+    Wm = torch.randn(N, K, generator=g) * 0.2
+    Wd = dev(Wm if bl == 0 else Wm.t(), dt)
+    Wf = (Wd if bl == 0 else Wd.t()).double()
+    bias, add = dev(torch.randn(N, generator=g) * 0.1, dt), dev(torch.randn(M, N, generator=g), dt)
+    Y, Gp = torch.empty(M, N, device="cuda", dtype=dt), torch.empty(M, N, device="cuda", dtype=dt)
+    L.gemm(X, Wd, Y, bias=bias, preact=Gp, M=M, N=N, K=K, lda=K, ldb=Wd.shape[1], ldc=N, b_layout=bl, act=L.ACT_GELU_SAVE_GRAD,
+           dtype=L.BF16, impl=L.IMPL_MFMA256)
+    pre = (X.double() @ Wf.t() + bias.double()).float().requires_grad_(True)
+    yr = F.gelu(pre); yr.backward(torch.ones_like(yr))
+    assert rel_err(Y, yr.detach()) < TOL[dt] and rel_err(Gp, pre.grad) < TOL[dt]
+    for addend in (None, add):
+        C = torch.empty(M, N, device="cuda", dtype=dt)
+        db = dev(torch.randn(N, generator=g)); db0 = db.clone()
+        L.gemm(X, Wd, C, preact=Gp, addend=addend, M=M, N=N, K=K, lda=K, ldb=Wd.shape[1], ldc=N, b_layout=bl, act=L.ACT_MUL,
+               dtype=L.BF16, impl=L.IMPL_MFMA256, colsum=db)
+        ref = (X.double() @ Wf.t()) * Gp.double() + (0 if addend is None else addend.double())
+        assert rel_err(C, ref) < TOL[dt]
+        assert rel_err(db - db0, C.float().sum(0)) < 1e-4
 
 
 @pytest.mark.parametrize("dt,impl", [(torch.float32, L.IMPL_REF), (torch.bfloat16, L.IMPL_REF), (torch.bfloat16, L.IMPL_MFMA),
@@ -294,6 +322,74 @@ def test_gemm_auto_dispatch_random_shape_sweep():
         else:
             _gemm_case(M, N, K, al, bl, torch.bfloat16, L.IMPL_AUTO, bias=bool(rng.randint(0, 2)), addend=bool(rng.randint(0, 2)),
                        act=(L.ACT_GELU if rng.randint(0, 2) else L.ACT_NONE), preact=bool(rng.randint(0, 2)))
+
+
+def _splitk_case(M, N, K, al=1, bl=1, exact=False):
+    """mmrca_gemm_splitk (256x256 tiles, slab partials, reduce launch) vs fp64 on the rounded operands"""
+    g = torch.Generator().manual_seed(M + 3 * N + 7 * K)
+    if exact:
+        A = ((torch.arange(M)[:, None] * 7 + torch.arange(K)[None, :] * 3) % 5 - 2.0)
+        B = ((torch.arange(N)[:, None] * 3 + torch.arange(K)[None, :] * 5) % 7 - 3.0)
+    else:
+        A, B = torch.randn(M, K, generator=g) * 0.5, torch.randn(N, K, generator=g) * 0.5
+    Ad = dev(A if al == 0 else A.t(), torch.bfloat16)
+    Bd = dev(B if bl == 0 else B.t(), torch.bfloat16)
+    C0 = torch.randint(-8, 9, (M, N), generator=g).float() if exact else torch.randn(M, N, generator=g)
+    Cd = dev(C0)
+    ws = torch.empty(L.SPLITK_WS_BYTES, dtype=torch.uint8, device="cuda")
+    L.gemm_splitk(Ad, Bd, Cd, ws, M=M, N=N, K=K, lda=Ad.shape[1], ldb=Bd.shape[1], ldc=N, a_layout=al, b_layout=bl)
+    torch.cuda.synchronize()
+    Af = (Ad if al == 0 else Ad.t()).double()
+    Bf = (Bd if bl == 0 else Bd.t()).double()
+    ref = (Af @ Bf.t()).cpu() + C0.double()
+    if exact:
+        assert torch.equal(Cd.cpu().double(), ref), (M, N, K, al, bl)
+    else:
+        assert rel_err(Cd.cpu(), ref) < 2e-5, (M, N, K, al, bl, rel_err(Cd.cpu(), ref))
+    return Cd
+
+
+@pytest.mark.parametrize("layouts", [(1, 1), (0, 0), (0, 1), (1, 0)])
+def test_gemm_splitk_256_tiles(layouts):
+    al, bl = layouts
+    _splitk_case(256, 256, 256, al, bl, exact=True)          # one tile, one split of four K steps
+    _splitk_case(512, 256, 64 * 37, al, bl, exact=True)       # ragged last split
+    _splitk_case(768, 512, 64 * 101, al, bl)
+
+
+def test_gemm_splitk_is_bitwise_reproducible_and_matches_the_atomic_kernel():
+    a = _splitk_case(768, 768, 64 * 131)
+    b = _splitk_case(768, 768, 64 * 131)
+    assert torch.equal(a, b)
+
+
+def test_gemm_at_the_benchmarked_sizes():
+    """BASELINE configs[1]: 50,432 token rows (B=256 x 197).  Forward / input-gradient GEMM at M = 50,432 (XCD remap at
+    2,364 tiles, grouped rastering) and the weight gradient with a 50,432-row contraction (split-K over every resident
+    block slot), each against fp64 on the same bf16-rounded operands."""
+    M = 50432
+    g = torch.Generator().manual_seed(5)
+    X = dev(torch.randn(M, 768, generator=g) * 0.5, torch.bfloat16)
+    W = dev(torch.randn(3072, 768, generator=g) * 0.05, torch.bfloat16)
+    bias = dev(torch.randn(3072, generator=g) * 0.1, torch.bfloat16)
+    Y = torch.empty(M, 3072, device="cuda", dtype=torch.bfloat16)
+    L.gemm(X, W, Y, bias=bias, M=M, N=3072, K=768, lda=768, ldb=768, ldc=3072, dtype=L.BF16)           # forward FFN1
+    ref = X.double() @ W.double().t() + bias.double()
+    assert rel_err(Y, ref) < 1e-2
+    dX = torch.empty(M, 768, device="cuda", dtype=torch.bfloat16)
+    L.gemm(Y, W, dX, M=M, N=768, K=3072, lda=3072, ldb=768, ldc=768, a_layout=L.ROWK, b_layout=L.KROW, dtype=L.BF16)   # dgrad FFN1
+    ref = Y.double() @ W.double()
+    assert rel_err(dX, ref) < 1e-2
+    del ref
+    for impl in ("atomic", "splitk"):
+        dW = torch.zeros(3072, 768, device="cuda")
+        if impl == "atomic":
+            L.gemm(Y, X, dW, M=3072, N=768, K=M, lda=3072, ldb=768, ldc=768, a_layout=L.KROW, b_layout=L.KROW, accum=True, dtype=L.BF16)
+        else:
+            ws = torch.empty(L.SPLITK_WS_BYTES, dtype=torch.uint8, device="cuda")
+            L.gemm_splitk(Y, X, dW, ws, M=3072, N=768, K=M, lda=3072, ldb=768, ldc=768)
+        ref = Y.double().t() @ X.double()
+        assert rel_err(dW, ref) < 1e-5, (impl, rel_err(dW, ref))
 
 
 def test_gemm_rejects_bad_arguments():

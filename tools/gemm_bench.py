@@ -15,8 +15,12 @@ SHAPES = [  # (name, M, N, K, a_layout, b_layout, accum)
     ("epi ffn1 preact", M, 3072, 768, 0, 0, 0), ("epi ffn1 gelu", M, 3072, 768, 0, 0, 0), ("epi ffn1 gelu preact", M, 3072, 768, 0, 0, 0),
     ("epi out addend", M, 768, 768, 0, 0, 0), ("epi ffn2 addend", M, 768, 3072, 0, 0, 0),
     ("text fwd qkv", 16384, 2304, 768, 0, 0, 0), ("text fwd out", 16384, 768, 768, 0, 0, 0),
+    ("text wgrad qkv", 2304, 768, 9344, 1, 1, 1), ("text wgrad out", 768, 768, 9344, 1, 1, 1), ("text wgrad ffn1", 3072, 768, 9344, 1, 1, 1),
+    ("cube 4096", 4096, 4096, 4096, 0, 0, 0), ("cube 8192", 8192, 8192, 8192, 0, 0, 0),
 ]
 impls = {"auto": L.IMPL_AUTO, "1stage": L.IMPL_MFMA_1STAGE, "bk32": L.IMPL_MFMA_BK32}
+if os.environ.get("MMRCA_BENCH_256"):
+    impls["m256"] = L.IMPL_MFMA256
 DBG = [int(x) for x in os.environ.get("MMRCA_DBG", "0").split(",")]
 only = sys.argv[1:] 
 L.load()
@@ -46,7 +50,7 @@ for name, m, n, k, al, bl, acc in SHAPES:
     variants += [(f"bk32tgt{d >> 8}", L.IMPL_MFMA_BK32, d) for d in DBG if d >= 256]
     runs = {}
     for iname, impl, dbg in variants:
-        if impl == L.IMPL_MFMA256 and (acc or n % 256 or (al == 1 and m % 256)):
+        if impl == L.IMPL_MFMA256 and (acc or n % 256 or k < 128 or (al == 1 and m % 256)):
             continue
         if impl in (L.IMPL_MFMA_TALL, L.IMPL_MFMA_256W, L.IMPL_MFMA_256X4) and (acc or al == 1 or (impl != L.IMPL_MFMA_TALL and n % 256)):
             continue
@@ -54,6 +58,16 @@ for name, m, n, k, al, bl, acc in SHAPES:
             L.load().mmrca_debug_set(dbg)
             L.gemm(A, B, C, bias=bias, M=m, N=n, K=k, lda=lda, ldb=ldb, ldc=n, a_layout=al, b_layout=bl, accum=bool(acc), dtype=L.BF16, impl=impl, **epi)
         runs[iname] = run
+    if acc and L.gemm_splitk_ok(m, n, k, L.BF16):
+        ws = torch.empty(L.SPLITK_WS_BYTES, dtype=torch.uint8, device=dev)
+        runs["splitk256"] = lambda ws=ws: L.gemm_splitk(A, B, C, ws, M=m, N=n, K=k, lda=lda, ldb=ldb, ldc=n, a_layout=al, b_layout=bl)
+        for d in DBG:
+            if 0 < d < 8:
+                def run_d(ws=ws, d=d):
+                    L.load().mmrca_debug_set(d)
+                    L.gemm_splitk(A, B, C, ws, M=m, N=n, K=k, lda=lda, ldb=ldb, ldc=n, a_layout=al, b_layout=bl)
+                    L.load().mmrca_debug_set(0)
+                runs[f"splitk_dbg{d}"] = run_d
     if os.environ.get("MMRCA_COLD") and not acc:   # the same launch over rotating A / C buffers (> 1 GB in total): operands not in L2 / MALL
         nb = 6
         As = [A.clone() for _ in range(nb)]
