@@ -17,9 +17,9 @@
 //                    Weight gradients (fp32, +=) split the long contraction over blockIdx.y and combine with
 //                    fp32 atomics shaped as 64-B row segments.
 #include "common.h"
+#include "lds_asm.h"
+#include <stdlib.h>
 
-typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
-typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
 typedef __attribute__((ext_vector_type(4))) float f32x4;
 
 // ======================================================================================================
@@ -193,6 +193,22 @@ __device__ __forceinline__ bf16x8 load_frag(const char* lds_tile, int rb, int ks
   }
 }
 
+// the same fragment through an asm read (lds_asm.h): LDS byte addresses of the one or two reads
+template <bool KROW>
+__device__ __forceinline__ void frag_addr(const char* lds_tile, int rb, int ks, int lane, unsigned& a0, unsigned& a1) {
+  const unsigned base = (unsigned)(uintptr_t)(lds_void*)lds_tile;
+  if (!KROW) {
+    const int r = rb + (lane & 15);
+    const int ch = 4 * ks + (lane >> 4);
+    a0 = a1 = base + r * 128 + ((ch ^ ((r >> 1) & 7)) << 4);
+  } else {
+    const int g = lane >> 4, i = lane & 15, q = i >> 2, p = i & 3;
+    const int row = 32 * ks + 8 * g + q;
+    a0 = base + row * 256 + ((((rb >> 4) ^ krow_f(row))) << 5) + p * 8;
+    a1 = base + (row + 4) * 256 + ((((rb >> 4) ^ krow_f(row + 4))) << 5) + p * 8;
+  }
+}
+
 template <bool A_KROW, bool B_KROW, bool ATOMIC_F32, bool FUSE_DB>
 __global__ void __launch_bounds__(256)
 gemm_mfma_k(const bf16_t* __restrict__ A, const bf16_t* __restrict__ B, void* __restrict__ Cv, const bf16_t* __restrict__ bias,
@@ -250,13 +266,20 @@ gemm_mfma_k(const bf16_t* __restrict__ A, const bf16_t* __restrict__ B, void* __
       stage_tile<A_KROW>(A, lda, m_blk, M, kbeg + (int64_t)(t + 1) * GBK, nxt, wave, lane);
       stage_tile<B_KROW>(B, ldb, n_blk, N, kbeg + (int64_t)(t + 1) * GBK, nxt + TILE_BYTES, wave, lane);
     }
+    // fragment reads are asm (lds_asm.h): the prefetch of K-tile t+1 issued above stays in flight under these reads and
+    // the 32 MFMAs below; it is waited for (vmcnt(0)) only at the end of the step
 #pragma unroll
     for (int ks = 0; ks < 2; ++ks) {
+      Frag<A_KROW> afr[4];
+      Frag<B_KROW> bfrr[4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) { unsigned a0, a1; frag_addr<A_KROW>(cur, wr * 64 + i * 16, ks, lane, a0, a1); read_frag_rt<A_KROW>(afr[i], a0, a1); }
+#pragma unroll
+      for (int j = 0; j < 4; ++j) { unsigned a0, a1; frag_addr<B_KROW>(cur + TILE_BYTES, wc * 64 + j * 16, ks, lane, a0, a1); read_frag_rt<B_KROW>(bfrr[j], a0, a1); }
+      lgkm0(afr); lgkm0(bfrr);
       bf16x8 af[4], bfr[4];
 #pragma unroll
-      for (int i = 0; i < 4; ++i) af[i] = load_frag<A_KROW>(cur, wr * 64 + i * 16, ks, lane);
-#pragma unroll
-      for (int j = 0; j < 4; ++j) bfr[j] = load_frag<B_KROW>(cur + TILE_BYTES, wc * 64 + j * 16, ks, lane);
+      for (int i = 0; i < 4; ++i) { af[i] = frag_val(afr[i]); bfr[i] = frag_val(bfrr[i]); }
 #pragma unroll
       for (int i = 0; i < 4; ++i)
 #pragma unroll
@@ -269,8 +292,9 @@ gemm_mfma_k(const bf16_t* __restrict__ A, const bf16_t* __restrict__ B, void* __
         for (int i = 0; i < 4; ++i) accb[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i], ones, accb[i], 0, 0, 0);
       }
     }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
+    __builtin_amdgcn_sched_barrier(0);       // the MFMAs stay ABOVE the wait (they are register-only: asm ordering does not hold them)
+    asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
+    __builtin_amdgcn_sched_barrier(0);
   }
 
   const int g = lane >> 4, l16 = lane & 15;
@@ -409,6 +433,17 @@ __device__ __forceinline__ bf16x8 load_frag32(const char* lds_tile, int rb, int 
   }
 }
 
+template <bool KROW>
+__device__ __forceinline__ void frag_addr32(const char* lds_tile, int rb, int lane, unsigned& a0, unsigned& a1) {
+  if (!KROW) {
+    const int r = rb + (lane & 15);
+    const int ch = lane >> 4;
+    a0 = a1 = (unsigned)(uintptr_t)(lds_void*)lds_tile + r * 64 + ((ch ^ ((4 - (r >> 2)) & 3)) << 4);
+  } else {
+    frag_addr<true>(lds_tile, rb, 0, lane, a0, a1);
+  }
+}
+
 template <bool A_KROW, bool B_KROW, bool ATOMIC_F32, bool FUSE_DB>
 __global__ void __launch_bounds__(256, 4)
 gemm_mfma_k32(const bf16_t* __restrict__ A, const bf16_t* __restrict__ B, void* __restrict__ Cv, const bf16_t* __restrict__ bias,
@@ -461,11 +496,17 @@ gemm_mfma_k32(const bf16_t* __restrict__ A, const bf16_t* __restrict__ B, void* 
       stage_tile32<A_KROW>(A, lda, m_blk, M, kbeg + (int64_t)(t + 1) * 32, nxt, wave, lane);
       stage_tile32<B_KROW>(B, ldb, n_blk, N, kbeg + (int64_t)(t + 1) * 32, nxt + TILE32_BYTES, wave, lane);
     }
+    // asm fragment reads (lds_asm.h): the prefetch issued above stays in flight under them and under the 16 MFMAs
+    Frag<A_KROW> afr[4];
+    Frag<B_KROW> bfrr[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { unsigned a0, a1; frag_addr32<A_KROW>(cur, wr * 64 + i * 16, lane, a0, a1); read_frag_rt<A_KROW>(afr[i], a0, a1); }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) { unsigned a0, a1; frag_addr32<B_KROW>(cur + TILE32_BYTES, wc * 64 + j * 16, lane, a0, a1); read_frag_rt<B_KROW>(bfrr[j], a0, a1); }
+    lgkm0(afr); lgkm0(bfrr);
     bf16x8 af[4], bfr[4];
 #pragma unroll
-    for (int i = 0; i < 4; ++i) af[i] = load_frag32<A_KROW>(cur, wr * 64 + i * 16, lane);
-#pragma unroll
-    for (int j = 0; j < 4; ++j) bfr[j] = load_frag32<B_KROW>(cur + TILE32_BYTES, wc * 64 + j * 16, lane);
+    for (int i = 0; i < 4; ++i) { af[i] = frag_val(afr[i]); bfr[i] = frag_val(bfrr[i]); }
 #pragma unroll
     for (int i = 0; i < 4; ++i)
 #pragma unroll
@@ -477,8 +518,9 @@ gemm_mfma_k32(const bf16_t* __restrict__ A, const bf16_t* __restrict__ B, void* 
 #pragma unroll
       for (int i = 0; i < 4; ++i) accb[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i], ones, accb[i], 0, 0, 0);
     }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
+    __builtin_amdgcn_sched_barrier(0);       // the MFMAs stay ABOVE the wait
+    asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
+    __builtin_amdgcn_sched_barrier(0);
   }
   const int g = lane >> 4, l16 = lane & 15;
   if (ATOMIC_F32) {
@@ -1500,12 +1542,14 @@ static void launch_mfma_p(const void* A, const void* B, void* C, const void* bia
 
 static bool aligned16(const void* p) { return (((uintptr_t)p) & 15) == 0; }
 
-bool mmrca_gemm256_ok(int64_t M, int64_t N, int64_t K, int a_layout, int act);
+bool mmrca_gemm256_ok(int64_t M, int64_t N, int64_t K, int a_layout, int act, bool has_addend, bool has_preact, bool has_colsum, bool has_bias);
 int mmrca_gemm256(const void* A, const void* B, void* C, const void* bias, const void* addend, void* preact, int64_t M,
                   int64_t N, int64_t K, int64_t lda, int64_t ldb, int64_t ldc, int a_layout, int b_layout, int act,
                   float* colsum, hipStream_t st);
 
 extern int g_mmrca_dbg;
+static const int g_mmrca_auto256_side = getenv("MMRCA_AUTO256_SIDE") ? atoi(getenv("MMRCA_AUTO256_SIDE")) : 0;
+static const bool g_mmrca_auto256_gelu = getenv("MMRCA_AUTO256_GELU") ? atoi(getenv("MMRCA_AUTO256_GELU")) != 0 : true;
 #define MMRCA_TALL_MIN_M (1LL << 60)   // AUTO threshold for the 256x128 kernel (off until measured)
 
 template <bool AK, bool BK2, bool AT, bool DB>
@@ -1537,14 +1581,19 @@ static int gemm_dispatch(const void* A, const void* B, void* C, const void* bias
                  (ldc % 4 == 0) && aligned16(A) && aligned16(B) && aligned16(C) && (!bias || aligned16(bias)) &&
                  (!addend || aligned16(addend)) && (!preact || aligned16(preact)) &&
                  (a_layout == MMRCA_ROWK || M % GBM == 0);
-  const bool ok256 = ok_mfma && !out_f32_accum && mmrca_gemm256_ok(M, N, K, a_layout, act);
+  const bool ok256 = ok_mfma && !out_f32_accum && mmrca_gemm256_ok(M, N, K, a_layout, act, addend != nullptr, preact != nullptr, colsum_fused != nullptr, bias != nullptr) &&
+                     M * lda * 2 < (1ll << 32) && (b_layout == MMRCA_KROW ? K * ldb : N * ldb) * 2 < (1ll << 32) && M * ldc * 2 < (1ll << 32);
   if (impl == MMRCA_GEMM_MFMA256 && !ok256)
     return mmrca_fail(-3, "gemm: shape M=%lld N=%lld K=%lld does not qualify for the 256x256 MFMA kernel", (long long)M, (long long)N, (long long)K);
-  // AUTO (tools/gemm_bench.py, interleaved rounds, round 2): the 256x256 kernel with its operand stream in flight across
-  // barriers runs its K loop at ~1.6 PFLOP/s-equivalent but pays ~10 us per tile outside the loop (one workgroup per CU:
-  // nothing overlaps the epilogue), so it wins where K is long and there is at least one full round of tiles:
-  // K >= 1536: 1,010-1,080 vs 900-950 TFLOP/s for the 128x128 single-stage kernel; K = 768: 750-915 vs 815-945.
-  const bool auto256 = impl == MMRCA_GEMM_AUTO && ok256 && K >= 1536 && ((M + 255) / 256) * (N / 256) >= 256;
+  // AUTO (tools/gemm_bench.py, interleaved rounds, round 2): the persistent 256x256 kernel (operand stream in flight across
+  // barriers and tile boundaries, barrier-free epilogue) wins on every bias-only shape once there is a full round of tiles:
+  // K = 768: 870-1,120 vs 830-910 TFLOP/s for the 128x128 single-stage kernel, K >= 2304: 1,010-1,070 vs 910-920.
+  // Epilogues with a side operand (residual addend, gelu' factor) are not built there and stay on the 128x128 kernel.
+  const bool side256 = addend != nullptr || act == MMRCA_ACT_MUL;     // epilogues with a side operand: MMRCA_AUTO256_SIDE bit 0 = addend at K >= 1536, bit 1 = MUL, bit 2 = addend at any K
+  const bool side_ok = !side256 || (addend != nullptr && act == MMRCA_ACT_NONE && (((g_mmrca_auto256_side & 1) && K >= 1536) || (g_mmrca_auto256_side & 4))) ||
+                       (act == MMRCA_ACT_MUL && (g_mmrca_auto256_side & 2));
+  const bool auto256 = impl == MMRCA_GEMM_AUTO && ok256 && M % 256 == 0 && K >= 768 && (M / 256) * (N / 256) >= 256 && side_ok &&
+                       (act != MMRCA_ACT_GELU_SAVE_GRAD || g_mmrca_auto256_gelu);
   if (ok256 && (impl == MMRCA_GEMM_MFMA256 || auto256)) {
     if (colsum_fused && fused_done) *fused_done = true;
     return mmrca_gemm256(A, B, C, bias, addend, preact, M, N, K, lda, ldb, ldc, a_layout, b_layout, act, colsum_fused, st);

@@ -31,9 +31,10 @@
 //   both then precede the same barrier.  The last two K-tiles issue nothing new and their counts shrink to 8,8,8,4 /
 //   2,0,0,0.
 #include "common.h"
+#include "lds_asm.h"
+#include <stdlib.h>
+#include <type_traits>
 
-typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
-typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
 typedef __attribute__((ext_vector_type(4))) float f32x4;
 typedef __attribute__((address_space(3))) void lds_void;
 typedef const __attribute__((address_space(1))) void gbl_void;
@@ -48,47 +49,6 @@ typedef const __attribute__((address_space(1))) void gbl_void;
 
 __device__ __forceinline__ int krow_f2(int row) { return (row & 3) | (((row >> 3) & 1) << 2); }
 
-// ---- LDS fragment reads (inline asm, see header) ------------------------------------------------------------------
-#define DS_READ_B128(dst, addr, off) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "i"(off))
-#define DS_READ_TR(dst, addr, off) asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "i"(off))
-
-// One 16(rows) x 32(k) bf16 operand fragment in registers.  ROWK: one 16-byte read from base[ks]; KROW: two transposed
-// 8-byte reads from base[frag] (k rows +0..3 and +4..7) kept as two register pairs until the lgkmcnt wait has passed --
-// they are only joined into the MFMA operand afterwards, so no compiler-made copy can read them before the data lands.
-template <bool KROW> struct Frag;
-template <> struct Frag<false> { bf16x8 v; };
-template <> struct Frag<true> { bf16x4 lo, hi; };
-
-template <bool KROW, int OFF>
-__device__ __forceinline__ void read_frag(Frag<KROW>& f, unsigned base) {
-  if constexpr (!KROW) {
-    DS_READ_B128(f.v, base, OFF);
-  } else {
-    DS_READ_TR(f.lo, base, OFF);
-    DS_READ_TR(f.hi, base, OFF + 1024);
-  }
-}
-__device__ __forceinline__ bf16x8 frag_val(const Frag<false>& f) { return f.v; }
-__device__ __forceinline__ bf16x8 frag_val(const Frag<true>& f) { return __builtin_shufflevector(f.lo, f.hi, 0, 1, 2, 3, 4, 5, 6, 7); }
-
-// s_waitcnt lgkmcnt(0) with the fragment registers as read-write operands: nothing that uses them is scheduled above it
-__device__ __forceinline__ void lgkm0(Frag<false> (&f)[4][2]) {
-  asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(f[0][0].v), "+v"(f[0][1].v), "+v"(f[1][0].v), "+v"(f[1][1].v), "+v"(f[2][0].v),
-               "+v"(f[2][1].v), "+v"(f[3][0].v), "+v"(f[3][1].v) :: "memory");
-}
-__device__ __forceinline__ void lgkm0(Frag<true> (&f)[4][2]) {
-  asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(f[0][0].lo), "+v"(f[0][0].hi), "+v"(f[0][1].lo), "+v"(f[0][1].hi), "+v"(f[1][0].lo),
-               "+v"(f[1][0].hi), "+v"(f[1][1].lo), "+v"(f[1][1].hi), "+v"(f[2][0].lo), "+v"(f[2][0].hi), "+v"(f[2][1].lo),
-               "+v"(f[2][1].hi), "+v"(f[3][0].lo), "+v"(f[3][0].hi), "+v"(f[3][1].lo), "+v"(f[3][1].hi) :: "memory");
-}
-__device__ __forceinline__ void lgkm0(Frag<false> (&f)[2][2]) {
-  asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(f[0][0].v), "+v"(f[0][1].v), "+v"(f[1][0].v), "+v"(f[1][1].v) :: "memory");
-}
-__device__ __forceinline__ void lgkm0(Frag<true> (&f)[2][2]) {
-  asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(f[0][0].lo), "+v"(f[0][0].hi), "+v"(f[0][1].lo), "+v"(f[0][1].hi), "+v"(f[1][0].lo),
-               "+v"(f[1][0].hi), "+v"(f[1][1].lo), "+v"(f[1][1].hi) :: "memory");
-}
-
 // stage one 128x64 half-tile: 16 wave-instructions of 1 KiB, two per wave.  src0/src1: this lane's source pointers of the
 // wave's two pieces for the CURRENT K-tile of that half (advanced by the caller)
 __device__ __forceinline__ void stage_half(const bf16_t* src0, const bf16_t* src1, char* lds_piece0) {
@@ -96,21 +56,24 @@ __device__ __forceinline__ void stage_half(const bf16_t* src0, const bf16_t* src
   __builtin_amdgcn_global_load_lds((gbl_void*)src1, (lds_void*)(lds_piece0 + 1024), 16, 0, 0);
 }
 
-// per-lane source pointer of piece `i` (0..15) of a half-tile at K offset 0
-template <bool KROW>
+// per-lane source pointer of piece `i` (0..15) of a half-tile at K offset 0.
+// STRIPE (B operand of the persistent kernel): half-tile h holds the 32-row stripes {64w + 32h + [0,32) : w = 0..3} of the
+// 256-row tile instead of rows 128h + [0,128), so that a wave's two 32-column pieces are ADJACENT in the output (columns
+// 64wc + [0,64): whole 128-byte lines of bf16 per row in its epilogue).  row0 is then the tile origin, h the half.
+template <bool KROW, bool STRIPE = false>
 __device__ __forceinline__ const bf16_t* piece_src(const bf16_t* __restrict__ base, int64_t ld, int64_t row0, int64_t rows_total,
-                                                   int i, int lane) {
+                                                   int i, int lane, int h = 0) {
   if (!KROW) {
     const int r = 8 * i + (lane >> 3);
     const int c = (lane & 7) ^ ((r >> 1) & 7);
-    int64_t gr = row0 + r;
+    int64_t gr = row0 + (STRIPE ? 64 * (r >> 5) + 32 * h + (r & 31) : r);
     if (gr > rows_total - 1) gr = rows_total - 1;
     return base + gr * ld + c * 8;
   } else {
     const int kr = 4 * i + (lane >> 4);
     const int chp = lane & 15;
     const int c = ((((chp >> 1) ^ krow_f2(kr))) << 1) | (chp & 1);
-    return base + (int64_t)kr * ld + row0 + c * 8;
+    return base + (int64_t)kr * ld + row0 + (STRIPE ? 64 * (c >> 2) + 32 * h + 8 * (c & 3) : c * 8);
   }
 }
 
@@ -131,7 +94,6 @@ gemm_mfma256_k(const bf16_t* __restrict__ A, const bf16_t* __restrict__ B, bf16_
                int64_t lda, int64_t ldb, int64_t ldc, int tiles_m, int tiles_n, int ksteps_base, int ksteps_rem,
                float* __restrict__ slab, float* __restrict__ colsum) {
   constexpr bool SLAB = MODE == MODE_SLAB;
-  constexpr int act = SLAB ? 0 : MODE;
   extern __shared__ __attribute__((aligned(16))) char smem[];     // [2 stages][A0 A1 B0 B1]
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
   const int wr = wave >> 2, wc = wave & 3;
@@ -213,6 +175,7 @@ gemm_mfma256_k(const bf16_t* __restrict__ A, const bf16_t* __restrict__ B, bf16_
 
   Frag<A_KROW> af[4][2];
   Frag<B_KROW> b0f[2][2], b1f[2][2];
+  [[maybe_unused]] unsigned read_stage = 0;
 #define LOAD_A(SLOT)                                                                                          \
   do {                                                                                                        \
     A_FRAG(SLOT, 0, 0); A_FRAG(SLOT, 0, 1); A_FRAG(SLOT, 1, 0); A_FRAG(SLOT, 1, 1);                           \
@@ -237,32 +200,32 @@ gemm_mfma256_k(const bf16_t* __restrict__ A, const bf16_t* __restrict__ B, bf16_
 #define END_LOAD(N)    do { if (wr) VMCNT(N); BARRIER(); __builtin_amdgcn_sched_barrier(0); } while (0)
 #define END_COMPUTE(N) do { __builtin_amdgcn_sched_barrier(0); if (!wr) VMCNT(N); BARRIER(); } while (0)
   // one K-tile = four phases.  I0..I3: 1 = issue seq P+6 in phase p; W0..W3: vmcnt argument of the phase's counted wait
-#define K_TILE(I0, I1, I2, I3, W0, W1, W2, W3)                                                                \
+#define K_TILE_G(ISS, I0, I1, I2, I3, W0, W1, W2, W3)                                                         \
   do {                                                                                                        \
-    if (I0) ISSUE(2);                                                                                         \
+    if (I0) ISS(2);                                                                                           \
     LOAD_B(b0f, SLOT_B0); LOAD_A(SLOT_A0);                                                                    \
     END_LOAD(W0);                                                                                             \
     LGKM0_B(b0f); LGKM0_A();                                                                                  \
     MFMA_QUAD(0, 0, b0f);                                                                                     \
     END_COMPUTE(W0);                                                                                          \
-    if (I1) ISSUE(3);                                                                                         \
+    if (I1) ISS(3);                                                                                           \
     LOAD_B(b1f, SLOT_B1);                                                                                     \
     END_LOAD(W1);                                                                                             \
     LGKM0_B(b1f);                                                                                             \
     MFMA_QUAD(0, 1, b1f);                                                                                     \
     END_COMPUTE(W1);                                                                                          \
-    if (I2) ISSUE(0);                                                                                         \
+    if (I2) ISS(0);                                                                                           \
     LOAD_A(SLOT_A1);                                                                                          \
     END_LOAD(W2);                                                                                             \
     LGKM0_A();                                                                                                \
     MFMA_QUAD(1, 1, b1f);                                                                                     \
     END_COMPUTE(W2);                                                                                          \
-    if (I3) ISSUE(1);                                                                                         \
+    if (I3) ISS(1);                                                                                           \
     END_LOAD(W3);                                                                                             \
     MFMA_QUAD(1, 0, b0f);                                                                                     \
     END_COMPUTE(W3);                                                                                          \
     _Pragma("unroll") for (int x = 0; x < 4; ++x) abase[x] ^= STAGE_BYTES;                                    \
-    bbase[0] ^= STAGE_BYTES; bbase[1] ^= STAGE_BYTES;                                                         \
+    bbase[0] ^= STAGE_BYTES; bbase[1] ^= STAGE_BYTES; read_stage ^= STAGE_BYTES;                              \
   } while (0)
 
   // prologue: seq 0..5 (K-tile 0 and A0, B0 of K-tile 1); phase 0 needs seq 0, 1 -> four half-tiles may stay in flight
@@ -272,17 +235,10 @@ gemm_mfma256_k(const bf16_t* __restrict__ A, const bf16_t* __restrict__ B, bf16_
   if (wr) BARRIER();                    // group 1 runs one barrier behind
   __builtin_amdgcn_sched_barrier(0);
 
-  for (int t = 0; t < nt - 2; ++t) K_TILE(1, 1, 1, 1, 8, 8, 10, 8);
-  K_TILE(1, 1, 0, 0, 8, 8, 8, 4);       // K-tile nt-2: issues B1, A1 of the last K-tile
-  K_TILE(0, 0, 0, 0, 2, 0, 0, 0);       // K-tile nt-1
+  for (int t = 0; t < nt - 2; ++t) K_TILE_G(ISSUE, 1, 1, 1, 1, 8, 8, 10, 8);
+  K_TILE_G(ISSUE, 1, 1, 0, 0, 8, 8, 8, 4);       // K-tile nt-2: issues B1, A1 of the last K-tile
+  K_TILE_G(ISSUE, 0, 0, 0, 0, 2, 0, 0, 0);       // K-tile nt-1
   if (!wr) BARRIER();                   // group 0 waits for group 1's last segment
-#undef K_TILE
-#undef END_LOAD
-#undef END_COMPUTE
-#undef MFMA_QUAD
-#undef LOAD_A
-#undef LOAD_B
-#undef ISSUE
 
   if constexpr (SLAB) {
     float* dst = slab + ((int64_t)blockIdx.y * nwg + (int64_t)tm * tiles_n + tn) * 65536 + wave * 8192 + lane * 4;
@@ -298,133 +254,345 @@ gemm_mfma256_k(const bf16_t* __restrict__ A, const bf16_t* __restrict__ B, bf16_
     return;
   }
 
-  // Epilogue through LDS: the MFMA layout gives a lane 4 consecutive columns of ONE row, i.e. 32-byte pieces of 16
-  // different rows per store instruction (measured: 2.1 TB/s, fully exposed at one block per CU).  Instead each 128-row
-  // half of the tile goes to LDS as fp32 (rows padded by 16 B: conflict-free 16-byte writes), and is read back one
-  // whole 256-column row per wave instruction, so bias / GELU / addend are applied in fp32 and every global access
-  // (pre-activation store, addend load, output store) is a contiguous 512-byte row segment.
-  constexpr int EP_STRIDE = 256 * 4 + 16;
-  const int64_t ncol = n_blk + lane * 4;
-  float bv[4] = {0.f, 0.f, 0.f, 0.f};
-  if (bias) {
-    bf16x4 b4 = *reinterpret_cast<const bf16x4*>(bias + ncol);
-#pragma unroll
-    for (int r = 0; r < 4; ++r) bv[r] = (float)b4[r];
+}
+
+// =====================================================================================================================
+// Persistent form for the forward / input-gradient GEMMs (bf16 out): ONE workgroup per CU walks its share of the output
+// tiles, and the operand stream never stops at a tile boundary -- the issue slots of a tile's last K-tiles already load
+// the first K-tiles of the workgroup's NEXT tile (same seq numbering, same counted waits), so a tile starts computing the
+// moment the previous epilogue ends.  Measured before this form: ~10 us per tile outside the K loop at one workgroup
+// per CU (workgroup launch, a cold prologue, an LDS-staged epilogue that nothing overlaps) against 1.3 us per K-tile,
+// i.e. 40 % of the time of a K = 768 tile.
+//
+// Epilogue: the 32 KiB of LDS beyond the two stages (131,072 .. 163,839) are eight PRIVATE 4-KiB staging areas, one per
+// wave, so the epilogue has no barrier at all (a block-wide staging with two barriers per 32-row pass cost 4.6 us per
+// tile).  A wave owns output columns 64wc + [0,64) (the B half-tiles are 32-row stripes, see piece_src) and rows
+// 128a + 64wr + [0,64): per pass (a, i) it writes its four 16x16 fragments (16 rows x 64 columns fp32, 16-byte chunks
+// XOR-swizzled by the row) and reads four times four whole 256-byte rows back -- LDS operations of one wave execute in
+// order, so neither the read-after-write nor the next pass's write-after-read needs a wait -- then bias / activation /
+// addend in fp32 and 128-byte (whole cache line) bf16 row stores, which drain while the next pass or the next tile's K
+// loop runs.  All LDS accesses of the kernel are inline asm, so that no compiler-inserted vmcnt(0) drains the stream.
+// =====================================================================================================================
+#define EP_BASE (2 * STAGE_BYTES)
+#define DS_WRITE_B128(addr, val, off) asm volatile("ds_write_b128 %0, %1 offset:%2" :: "v"(addr), "v"(val), "i"(off) : "memory")
+
+// Epilogue variants are compile-time (run-time flags cost ~20 branches and twice the code per pass): ACT is
+// MMRCA_ACT_NONE (with or without a residual addend, ADD), MMRCA_ACT_GELU_SAVE_GRAD (stores gelu' to `preact`) or
+// MMRCA_ACT_MUL (multiplies by `preact`; column sums of the stored result to `colsum` when given).
+template <bool A_KROW, bool B_KROW, int ACT, bool ADD>
+__global__ void __launch_bounds__(512, 2)
+gemm_p256_k(const bf16_t* __restrict__ A, const bf16_t* __restrict__ B, bf16_t* __restrict__ C, const bf16_t* __restrict__ bias,
+            const bf16_t* __restrict__ addend, bf16_t* __restrict__ preact, int64_t M, int64_t N, int64_t K,
+            int64_t lda, int64_t ldb, int64_t ldc, int tiles_m, int tiles_n, float* __restrict__ colsum, int skew_ticks, int dbg) {
+  constexpr int act = ACT;
+  extern __shared__ __attribute__((aligned(16))) char smem[];     // [2 stages][A0 A1 B0 B1] + 32 KiB epilogue staging
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
+  const int wr = wave >> 2, wc = wave & 3;
+  const int ntiles = tiles_m * tiles_n, G = (int)gridDim.x;                  // G % 8 == 0 (host)
+  // workgroups that share an XCD (blockIdx % 8, observed round-robin placement: speed only) take consecutive tile ids
+  const int slot = ((int)blockIdx.x & 7) * (G >> 3) + ((int)blockIdx.x >> 3);
+  const int my_tiles = (ntiles - slot + G - 1) / G;                           // tile ids slot, slot + G, ...
+  if (my_tiles <= 0) return;
+  // Desynchronise the workgroups: all tiles take the same time, so without this every CU reaches its epilogue at the same
+  // moment and the chip alternates between "every CU stores 128 KiB" (32 MiB burst = the whole L2) and "nobody stores".
+  // Four groups per XCD start skew_ticks * {0,1,2,3} x 10 ns apart and keep that phase for the whole launch.
+  if (skew_ticks > 0) {
+    const uint64_t t0 = __builtin_amdgcn_s_memrealtime();
+    const uint64_t wait = (uint64_t)skew_ticks * (((unsigned)blockIdx.x >> 3) & 3);
+    while (__builtin_amdgcn_s_memrealtime() - t0 < wait) __builtin_amdgcn_s_sleep(32);
   }
-  float csum[4] = {0.f, 0.f, 0.f, 0.f};
-  __syncthreads();
+  const int nt = (int)(K / 64);                                               // >= 2 (host-checked)
+  const int GROUP = 4;
+  auto tile_origin = [&](int id, int64_t& m_blk, int64_t& n_blk) {
+    const int group = id / (GROUP * tiles_n);
+    const int first_m = group * GROUP;
+    const int gsize = (tiles_m - first_m) < GROUP ? (tiles_m - first_m) : GROUP;
+    const int tm = first_m + (id % (GROUP * tiles_n)) % gsize;
+    const int tn = (id % (GROUP * tiles_n)) / gsize;
+    m_blk = (int64_t)tm * 256; n_blk = (int64_t)tn * 256;
+  };
+
+  // ---- the stream
+  // per-lane BYTE offsets from A / B (32 bits: the host checks that both operands are < 4 GiB) of this wave's two pieces of
+  // half-tile 0, advanced per K-tile; half-tile 1 is a wave-uniform distance away (128 rows of A; 32 rows of the striped B).
+  // Rows of A past M (last row tile) are read as they are -- the caller provides round_up(M, 256) readable rows -- and the
+  // output rows they produce are never stored.
+  const unsigned a_step = (unsigned)(A_KROW ? 128 * lda : 128), b_step = (unsigned)(B_KROW ? 128 * ldb : 128);
+  const int64_t a_half = A_KROW ? 256 : 256 * lda, b_half = B_KROW ? 64 : 64 * ldb;       // bytes
+  unsigned oa[2], ob[2];
+  auto stream_to = [&](int id) {
+    int64_t mb, nb;
+    tile_origin(id, mb, nb);
 #pragma unroll
-  for (int a = 0; a < 2; ++a) {
+    for (int ii = 0; ii < 2; ++ii) {
+      oa[ii] = (unsigned)(2 * (piece_src<A_KROW>(A, lda, mb, (int64_t)1 << 40, wave * 2 + ii, lane) - A));
+      ob[ii] = (unsigned)(2 * (piece_src<B_KROW, true>(B, ldb, nb, (int64_t)1 << 40, wave * 2 + ii, lane, 0) - B));
+    }
+  };
+  stream_to(slot);
+  int stream_kt = 0, stream_tile = 0;          // K-tiles already issued of the stream's current tile; its index in my list
+  char* const my_piece = smem + wave * 2048;
+  int issue_stage = 0;
+  // the issue slot of half-tile A1 closes a K-tile of the stream: after the last K-tile of a tile, move on to the next tile
+#define SRC_A(h, ii) reinterpret_cast<const bf16_t*>(reinterpret_cast<const char*>(A) + (h) * a_half + oa[ii])
+#define SRC_B(h, ii) reinterpret_cast<const bf16_t*>(reinterpret_cast<const char*>(B) + (h) * b_half + ob[ii])
+#define ISSUE_P(which)                                                                                          \
+  do {                                                                                                          \
+    if ((which) == 0) { stage_half(SRC_A(0, 0), SRC_A(0, 1), my_piece + issue_stage + SLOT_A0 * HT_BYTES); }    \
+    else if ((which) == 1) { stage_half(SRC_B(0, 0), SRC_B(0, 1), my_piece + issue_stage + SLOT_B0 * HT_BYTES); } \
+    else if ((which) == 2) { stage_half(SRC_B(1, 0), SRC_B(1, 1), my_piece + issue_stage + SLOT_B1 * HT_BYTES); ob[0] += b_step; ob[1] += b_step; } \
+    else {                                                                                                      \
+      stage_half(SRC_A(1, 0), SRC_A(1, 1), my_piece + issue_stage + SLOT_A1 * HT_BYTES); oa[0] += a_step; oa[1] += a_step;  \
+      issue_stage ^= STAGE_BYTES;                                                                               \
+      if (++stream_kt == nt) { stream_kt = 0; ++stream_tile; if (stream_tile < my_tiles) stream_to(slot + stream_tile * G); } \
+    }                                                                                                           \
+  } while (0)
+
+  // ---- fragment read addresses: recomputed at every tile start from an opaque lane id and the scalar stage parity, so
+  // that they do not occupy registers during the epilogue (the side-operand registers need the room)
+  const unsigned lds0 = (unsigned)(uintptr_t)(lds_void*)smem;
+  unsigned abase[4], bbase[2];
+  unsigned read_stage = 0;                 // LDS stage (byte offset) of the K-tile the fragment reads are at
+  auto frag_bases = [&]() {
+    int lane_f = lane;
+    asm volatile("" : "+v"(lane_f));
+    const int g = lane_f >> 4, l16 = lane_f & 15;
+    if (!A_KROW) {
+      const int r0 = 64 * wr + l16;
 #pragma unroll
-    for (int b = 0; b < 2; ++b)
+      for (int ks = 0; ks < 2; ++ks) abase[ks] = (lds0 + r0 * 128 + (((4 * ks + g) ^ ((r0 >> 1) & 7)) << 4)) ^ read_stage;
+      abase[2] = abase[3] = 0;
+    } else {
+      const int q = l16 >> 2, p = l16 & 3, row = 8 * g + q;
 #pragma unroll
-      for (int i = 0; i < 4; ++i)
+      for (int i = 0; i < 4; ++i) abase[i] = (lds0 + row * 256 + ((((4 * wr + i) ^ krow_f2(row))) << 5) + p * 8) ^ read_stage;
+    }
+    if (!B_KROW) {
+      const int r0 = 32 * wc + l16;
 #pragma unroll
-        for (int j = 0; j < 2; ++j) {
-          const int row = 64 * wr + 16 * i + l16, col = 128 * b + 32 * wc + 16 * j + 4 * g;
-          *reinterpret_cast<f32x4*>(smem + row * EP_STRIDE + col * 4) = acc[a][b][i][j];
-        }
-    __syncthreads();
-    // the wave's 16 rows of this half: all LDS reads and all side-operand loads are issued before the first use, so the
-    // pass has 16 independent row streams in flight (as a rolled loop it was one latency chain per row: ~10 us per tile)
+      for (int ks = 0; ks < 2; ++ks) bbase[ks] = (lds0 + r0 * 128 + (((4 * ks + g) ^ ((r0 >> 1) & 7)) << 4)) ^ read_stage;
+    } else {
+      const int q = l16 >> 2, p = l16 & 3, row = 8 * g + q;
+#pragma unroll
+      for (int j = 0; j < 2; ++j) bbase[j] = (lds0 + row * 256 + ((((2 * wc + j) ^ krow_f2(row))) << 5) + p * 8) ^ read_stage;
+    }
+  };
+  Frag<A_KROW> af[4][2];
+  Frag<B_KROW> b0f[2][2], b1f[2][2];
+  f32x4 acc[2][2][4][2];
+
+  // prologue of the stream: seq 0..5 of the first tile
+  ISSUE_P(0); ISSUE_P(1); ISSUE_P(2); ISSUE_P(3); ISSUE_P(0); ISSUE_P(1);
+  VMCNT(8);
+  BARRIER();
+
+  for (int ti = 0; ti < my_tiles; ++ti) {
+    int64_t m_blk, n_blk;
+    tile_origin(slot + ti * G, m_blk, n_blk);
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+      for (int b = 0; b < 2; ++b)
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+          for (int j = 0; j < 2; ++j) acc[a][b][i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    frag_bases();
+    if (wr) BARRIER();                    // group 1 runs one barrier behind
+    __builtin_amdgcn_sched_barrier(0);
+    if (ti + 1 < my_tiles) {              // the stream runs on into the next tile: every K-tile is a steady-state one
+      for (int t = 0; t < nt; ++t) K_TILE_G(ISSUE_P, 1, 1, 1, 1, 8, 8, 10, 8);
+    } else {
+      for (int t = 0; t < nt - 2; ++t) K_TILE_G(ISSUE_P, 1, 1, 1, 1, 8, 8, 10, 8);
+      K_TILE_G(ISSUE_P, 1, 1, 0, 0, 8, 8, 8, 4);
+      K_TILE_G(ISSUE_P, 0, 0, 0, 0, 2, 0, 0, 0);
+    }
+    if (!wr) BARRIER();                   // group 0 waits for group 1's last segment: all eight waves aligned
+    __builtin_amdgcn_sched_barrier(0);
+
+    // ---- epilogue (see the header of this kernel).  Its per-lane addresses are derived from an opaque copy of the lane id,
+    // so that none of them is kept in a register (or spilled) across the K loop.
+    int lane_e = lane;
+    asm volatile("" : "+v"(lane_e));
+    const int e16 = lane_e & 15, eg = lane_e >> 4;
+    // write: row e16, chunk (8b + 4j + eg) ^ (e16 & 7)  (b -> address bit 7, j -> bit 6 of the swizzled chunk);
+    // read pass `it`: row 4it + eg, chunk e16 ^ (row & 7)
+    const unsigned wbase0 = lds0 + EP_BASE + wave * 4096 + e16 * 256 + ((eg ^ (e16 & 7)) << 4);
+    const unsigned rbase0 = lds0 + EP_BASE + wave * 4096 + eg * 256;
+    const int64_t ncol = n_blk + 64 * wc + 4 * e16;
+    const unsigned lane_off = (unsigned)(eg * (int)ldc + 4 * e16) * 2u;       // row eg, columns 4 e16 .. +3 (bytes)
+    float bv[4] = {0.f, 0.f, 0.f, 0.f};
+    if constexpr (act != MMRCA_ACT_MUL) {       // (the input-gradient form has no bias; the dispatcher checks)
+      if (bias) {
+        bf16x4 b4 = *reinterpret_cast<const bf16x4*>(bias + ncol);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) bv[r] = (float)b4[r];
+      }
+    }
+    float csum[4] = {0.f, 0.f, 0.f, 0.f};
     const bool full = m_blk + 256 <= M;
-    f32x4 cr[16];
+    asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");           // the last MFMAs' results are read by asm stores below
+    // (dbg & 2: timing-only ablation, no epilogue at all)
+    // Side operand (residual addend, or the saved gelu' of ACT_MUL): all 32 row pieces of the tile are requested here, before
+    // the tile's first store, by ORDINARY loads.  The compiler waits for an ordinary load that is in flight beside LDS-DMA
+    // with vmcnt(0), and vmcnt retires in order: issued later, between the stores, every pass would wait for all earlier
+    // stores and for the stream (51 such waits in the .s, 591 vs 870 TFLOP/s); issued up front there is ONE such wait per
+    // tile, at the first use in pass 0, when only loads are outstanding.  (Asm loads with hand-counted waits were tried: at
+    // this register pressure the compiler moved / re-used their destination registers before the data landed -- memory
+    // fault.)  Like A, the side operand must have round_up(M, 256) readable rows; rows past M are not stored.
+    constexpr bool SIDE = ADD || act == MMRCA_ACT_MUL;
+    bf16x4 side[SIDE ? 32 : 1];
+    if constexpr (SIDE) {
+      const char* sp = reinterpret_cast<const char*>(ADD ? (const bf16_t*)addend : (const bf16_t*)preact);
+      if (!(dbg & 2)) {
 #pragma unroll
-    for (int rr = 0; rr < 16; ++rr) cr[rr] = *reinterpret_cast<const f32x4*>(smem + (wave * 16 + rr) * EP_STRIDE + lane * 16);
-    const int64_t m0 = m_blk + 128 * a + wave * 16;
-    constexpr bool need_h = act == MMRCA_ACT_MUL;
-    bf16x4 hr[16], ar[16];
-    if constexpr (need_h) {
-#pragma unroll
-      for (int rr = 0; rr < 16; ++rr) {
-        const int64_t m = (full || m0 + rr < M) ? m0 + rr : M - 1;
-        hr[rr] = *reinterpret_cast<const bf16x4*>(preact + m * ldc + ncol);
-      }
-    }
-    if (addend) {
-#pragma unroll
-      for (int rr = 0; rr < 16; ++rr) {
-        const int64_t m = (full || m0 + rr < M) ? m0 + rr : M - 1;
-        ar[rr] = *reinterpret_cast<const bf16x4*>(addend + m * ldc + ncol);
-      }
-    }
-#pragma unroll
-    for (int rr = 0; rr < 16; ++rr) {
-      const int64_t m = m0 + rr;
-      float v[4] = {cr[rr][0] + bv[0], cr[rr][1] + bv[1], cr[rr][2] + bv[2], cr[rr][3] + bv[3]};
-      bf16x4 po;
-      bool store_pre = false;
-      if constexpr (act == MMRCA_ACT_MUL) {
-#pragma unroll
-        for (int r = 0; r < 4; ++r) v[r] *= (float)hr[rr][r];
-      } else if constexpr (act == MMRCA_ACT_GELU_SAVE_GRAD) {
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          float gr;
-          v[r] = gelu_and_grad_fast_f(v[r], &gr);
-          po[r] = (bf16_t)gr;
+        for (int q = 0; q < 32; ++q) {
+          const int64_t urow = m_blk + 128 * (q >> 4) + 64 * wr + 4 * (q & 15);    // wave-uniform; this lane's row: urow + eg
+          const int64_t ub = (urow * ldc + n_blk + 64 * wc) * 2;
+          side[q] = *reinterpret_cast<const bf16x4*>(sp + ub + lane_off);
         }
-        store_pre = true;
-      } else if (preact) {
-#pragma unroll
-        for (int r = 0; r < 4; ++r) po[r] = (bf16_t)v[r];
-        store_pre = true;
-      }
-      if (addend) {
-#pragma unroll
-        for (int r = 0; r < 4; ++r) v[r] += (float)ar[rr][r];
-      }
-      bf16x4 o;
-#pragma unroll
-      for (int r = 0; r < 4; ++r) o[r] = (bf16_t)v[r];
-      if (full || m < M) {
-#pragma unroll
-        for (int r = 0; r < 4; ++r) csum[r] += (float)o[r];       // column sums of what is STORED (the rounded values)
-        if (store_pre) *reinterpret_cast<bf16x4*>(preact + m * ldc + ncol) = po;
-        *reinterpret_cast<bf16x4*>(C + m * ldc + ncol) = o;
       }
     }
-    __syncthreads();
-  }
-  if (colsum) {      // lane owns columns ncol..ncol+3 over this wave's 32 rows: 8 partial sums per column per block
+    auto passes = [&](auto ragged_tag) {
+      constexpr bool RAGGED = decltype(ragged_tag)::value;
+  #pragma unroll
+      for (int pass = 0; pass < 8; ++pass) {
+        const int a = pass >> 2, i = pass & 3;
+        {
+          const unsigned wbase1 = wbase0 ^ 64u;         // fragment j = 1: chunk bit 2
+          DS_WRITE_B128(wbase0, acc[a][0][i][0], 0);
+          DS_WRITE_B128(wbase1, acc[a][0][i][1], 0);
+          DS_WRITE_B128(wbase0, acc[a][1][i][0], 128);   // b = 1: chunk bit 3 (not touched by the 3-bit swizzle)
+          DS_WRITE_B128(wbase1, acc[a][1][i][1], 128);
+        }
+        // global addresses = wave-uniform row base (scalar registers) + one per-lane byte offset for the whole tile
+        // (per-row 64-bit multiplies made this epilogue VALU-bound: 4 us per tile)
+        const int64_t urow0 = m_blk + 128 * a + 64 * wr + 16 * i;               // uniform; this lane's rows: urow0 + eg + 4it
+        // rows are read back two at a time when a side operand occupies registers (four at a time otherwise)
+        constexpr int RB = SIDE ? 2 : 4;
+  #pragma unroll
+        for (int it0 = 0; it0 < 4; it0 += RB) {
+          f32x4 cr[RB];
+  #pragma unroll
+          for (int u = 0; u < RB; ++u) {
+            const int it = it0 + u;
+            // row 4it + eg: (row & 7) = (4it + eg) & 7
+            const unsigned rb = rbase0 + it * 1024 + ((unsigned)(e16 ^ ((4 * it + eg) & 7)) << 4);
+            DS_READ_B128(cr[u], rb, 0);
+          }
+          if constexpr (RB == 4) asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(cr[0]), "+v"(cr[1]), "+v"(cr[2]), "+v"(cr[3]) :: "memory");
+          else asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(cr[0]), "+v"(cr[1]) :: "memory");
+  #pragma unroll
+          for (int u = 0; u < RB; ++u) {
+            const int it = it0 + u;
+            float v[4] = {cr[u][0], cr[u][1], cr[u][2], cr[u][3]};
+            if constexpr (act != MMRCA_ACT_MUL) {
+  #pragma unroll
+              for (int r = 0; r < 4; ++r) v[r] += bv[r];
+            }
+            bf16x4 po;
+            constexpr bool store_pre = act == MMRCA_ACT_GELU_SAVE_GRAD;
+            if constexpr (act == MMRCA_ACT_MUL) {
+  #pragma unroll
+              for (int r = 0; r < 4; ++r) v[r] *= (float)side[4 * pass + it][r];
+            } else if constexpr (act == MMRCA_ACT_GELU_SAVE_GRAD) {
+  #pragma unroll
+              for (int r = 0; r < 4; ++r) {
+                float gr;
+                v[r] = gelu_and_grad_fast_f(v[r], &gr);
+                po[r] = (bf16_t)gr;
+              }
+            }
+            if constexpr (ADD) {
+  #pragma unroll
+              for (int r = 0; r < 4; ++r) v[r] += (float)side[4 * pass + it][r];
+            }
+            bf16x4 o;
+  #pragma unroll
+            for (int r = 0; r < 4; ++r) o[r] = (bf16_t)v[r];
+            const bool ok = !RAGGED || urow0 + 4 * it + eg < M;
+            if (ok) {
+              if constexpr (act == MMRCA_ACT_MUL) {
+  #pragma unroll
+                for (int r = 0; r < 4; ++r) csum[r] += (float)o[r];
+              }
+              const int64_t ub = ((urow0 + 4 * it) * ldc + n_blk + 64 * wc) * 2;
+              if (store_pre) *reinterpret_cast<bf16x4*>(reinterpret_cast<char*>(preact) + ub + lane_off) = po;
+              *reinterpret_cast<bf16x4*>(reinterpret_cast<char*>(C) + ub + lane_off) = o;
+            }
+          }
+        }
+      }
+    };
+    if (!(dbg & 2)) {
+      if (full) passes(std::false_type{}); else passes(std::true_type{});   // whole tiles: no per-row predicates at all
+    }
+    if constexpr (act == MMRCA_ACT_MUL) {
+      if (colsum) {
 #pragma unroll
-    for (int r = 0; r < 4; ++r) atomicAdd(colsum + ncol + r, csum[r]);
+        for (int r = 0; r < 4; ++r) atomicAdd(colsum + ncol + r, csum[r]);
+      }
+    }
+    __builtin_amdgcn_sched_barrier(0);
   }
+}
+
+extern int g_mmrca_dbg;
+static int g_num_cus = 0;
+static int g_p256_skew = -1;      // x 10 ns between the four start groups (MMRCA_P256_SKEW; see gemm_p256_k)
+template <bool AK, bool BK2, int ACT, bool ADD>
+static void launch_p256(const void* A, const void* B, void* C, const void* bias, const void* addend, void* preact, int64_t M,
+                        int64_t N, int64_t K, int64_t lda, int64_t ldb, int64_t ldc, float* colsum, hipStream_t st) {
+  const int tiles_m = (int)((M + 255) / 256), tiles_n = (int)(N / 256);
+  if (g_num_cus == 0) {
+    int dev = 0, n = 0;
+    (void)hipGetDevice(&dev);
+    if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n < 8) n = 256;
+    g_num_cus = n & ~7;
+  }
+  if (g_p256_skew < 0) {
+    const char* e = getenv("MMRCA_P256_SKEW");
+    g_p256_skew = e ? atoi(e) : 0;
+  }
+  int grid = tiles_m * tiles_n < g_num_cus ? ((tiles_m * tiles_n) & ~7) : g_num_cus;
+  if (grid < 8) grid = 8;
+  constexpr int LDS_P = 2 * STAGE_BYTES + 32768;       // all 160 KiB of the CU
+  (void)hipFuncSetAttribute((const void*)gemm_p256_k<AK, BK2, ACT, ADD>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_P);
+  hipLaunchKernelGGL((gemm_p256_k<AK, BK2, ACT, ADD>), dim3(grid), dim3(512), LDS_P, st, (const bf16_t*)A, (const bf16_t*)B,
+                     (bf16_t*)C, (const bf16_t*)bias, (const bf16_t*)addend, (bf16_t*)preact, M, N, K, lda, ldb, ldc, tiles_m,
+                     tiles_n, colsum, tiles_m * tiles_n >= 2 * g_num_cus ? g_p256_skew : 0, g_mmrca_dbg);
 }
 
 int g_mmrca_dbg = 0;
 extern "C" int mmrca_debug_set(int v) { g_mmrca_dbg = v; return 0; }
 
-template <bool AK, bool BK2, int MODE>
-static void launch256(const void* A, const void* B, void* C, const void* bias, const void* addend, void* preact, int64_t M,
-                      int64_t N, int64_t K, int64_t lda, int64_t ldb, int64_t ldc, float* colsum, hipStream_t st) {
-  const int tiles_m = (int)((M + 255) / 256), tiles_n = (int)(N / 256);
-  (void)hipFuncSetAttribute((const void*)gemm_mfma256_k<AK, BK2, MODE>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS256_BYTES);
-  hipLaunchKernelGGL((gemm_mfma256_k<AK, BK2, MODE>), dim3(tiles_m * tiles_n), dim3(512), LDS256_BYTES, st, (const bf16_t*)A,
-                     (const bf16_t*)B, (bf16_t*)C, (const bf16_t*)bias, (const bf16_t*)addend, (bf16_t*)preact, M, N, K, lda,
-                     ldb, ldc, tiles_m, tiles_n, 0, 0, (float*)nullptr, colsum);
-}
-
-// called by mmrca_gemm (gemm.hip) for bf16-out GEMMs that qualify.  Epilogues built: no activation for every layout pair;
-// GELU_SAVE_GRAD and MUL for a ROWK A operand (forward / input gradient).
-bool mmrca_gemm256_ok(int64_t M, int64_t N, int64_t K, int a_layout, int act) {
-  return N % 256 == 0 && K % 64 == 0 && K >= 128 && (a_layout == MMRCA_ROWK || M % 256 == 0) &&
-         (act == MMRCA_ACT_NONE || (a_layout == MMRCA_ROWK && (act == MMRCA_ACT_GELU_SAVE_GRAD || act == MMRCA_ACT_MUL)));
+// called by mmrca_gemm (gemm.hip) for bf16-out GEMMs that qualify: A row-major (forward / input gradient), the epilogues
+// the engine uses (see gemm_p256_k), operands below 4 GiB (32-bit stream offsets)
+bool mmrca_gemm256_ok(int64_t M, int64_t N, int64_t K, int a_layout, int act, bool has_addend, bool has_preact, bool has_colsum, bool has_bias) {
+  if (!(N % 256 == 0 && K % 64 == 0 && K >= 128 && a_layout == MMRCA_ROWK)) return false;
+  if (act == MMRCA_ACT_NONE) return !has_preact && !has_colsum;
+  if (act == MMRCA_ACT_GELU_SAVE_GRAD) return has_preact && !has_addend && !has_colsum;
+  if (act == MMRCA_ACT_MUL) return has_preact && !has_addend && !has_bias;
+  return false;
 }
 
 int mmrca_gemm256(const void* A, const void* B, void* C, const void* bias, const void* addend, void* preact, int64_t M,
                   int64_t N, int64_t K, int64_t lda, int64_t ldb, int64_t ldc, int a_layout, int b_layout, int act,
                   float* colsum, hipStream_t st) {
-  const bool ak = a_layout == MMRCA_KROW, bk = b_layout == MMRCA_KROW;
-#define L256(AK_, BK_, MODE_) launch256<AK_, BK_, MODE_>(A, B, C, bias, addend, preact, M, N, K, lda, ldb, ldc, colsum, st)
-  if (ak) {
-    if (bk) L256(true, true, MMRCA_ACT_NONE); else L256(true, false, MMRCA_ACT_NONE);
-  } else if (act == MMRCA_ACT_GELU_SAVE_GRAD) {
-    if (bk) L256(false, true, MMRCA_ACT_GELU_SAVE_GRAD); else L256(false, false, MMRCA_ACT_GELU_SAVE_GRAD);
+  const bool bk = b_layout == MMRCA_KROW;
+  MMRCA_REQUIRE(mmrca_gemm256_ok(M, N, K, a_layout, act, addend != nullptr, preact != nullptr, colsum != nullptr, bias != nullptr),
+                "gemm(mfma256): shape / epilogue combination not built");
+  MMRCA_REQUIRE(M * lda * 2 < (1ll << 32) && (bk ? K * ldb : N * ldb) * 2 < (1ll << 32) && M * ldc * 2 < (1ll << 32),
+                "gemm(mfma256): operands must be smaller than 4 GiB");
+#define L256(BK_, MODE_, ADD_) launch_p256<false, BK_, MODE_, ADD_>(A, B, C, bias, addend, preact, M, N, K, lda, ldb, ldc, colsum, st)
+  if (act == MMRCA_ACT_GELU_SAVE_GRAD) {
+    if (bk) L256(true, MMRCA_ACT_GELU_SAVE_GRAD, false); else L256(false, MMRCA_ACT_GELU_SAVE_GRAD, false);
   } else if (act == MMRCA_ACT_MUL) {
-    if (bk) L256(false, true, MMRCA_ACT_MUL); else L256(false, false, MMRCA_ACT_MUL);
+    if (bk) L256(true, MMRCA_ACT_MUL, false); else L256(false, MMRCA_ACT_MUL, false);
+  } else if (addend) {
+    if (bk) L256(true, MMRCA_ACT_NONE, true); else L256(false, MMRCA_ACT_NONE, true);
   } else {
-    if (bk) L256(false, true, MMRCA_ACT_NONE); else L256(false, false, MMRCA_ACT_NONE);
+    if (bk) L256(true, MMRCA_ACT_NONE, false); else L256(false, MMRCA_ACT_NONE, false);
   }
 #undef L256
   MMRCA_CHECK_LAUNCH("gemm(mfma256)");

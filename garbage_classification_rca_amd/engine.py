@@ -50,7 +50,7 @@ CONCURRENT_ENCODERS = os.environ.get("MMRCA_CONCURRENT_ENCODERS", "1") == "1"
 CLS_TAIL = os.environ.get("MMRCA_CLS_TAIL", "1") == "1"
 # weight gradients on the 256x256 split-K kernel (mmrca_gemm_splitk) wherever the shape qualifies; "0" = 128x128 + fp32 atomics
 SPLITK_WGRAD = os.environ.get("MMRCA_SPLITK_WGRAD", "1") == "1"
-ROWPAD = 128
+ROWPAD = 256         # (the persistent 256x256 GEMM reads whole 256-row tiles of its A operand)
 
 
 def _round_up(x: int, m: int) -> int:

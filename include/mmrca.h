@@ -32,7 +32,9 @@ enum { MMRCA_ACT_NONE = 0, MMRCA_ACT_GELU = 1,
 /* operand layouts of mmrca_gemm: ROWK = [rows][contraction] (contraction contiguous),
  * KROW = [contraction][rows] (rows contiguous) */
 enum { MMRCA_ROWK = 0, MMRCA_KROW = 1 };
-enum { MMRCA_GEMM_AUTO = 0, MMRCA_GEMM_REF = 1, MMRCA_GEMM_MFMA = 2 /* 128x128 tiles */, MMRCA_GEMM_MFMA256 = 3 /* 256x256 tiles */,
+enum { MMRCA_GEMM_AUTO = 0, MMRCA_GEMM_REF = 1, MMRCA_GEMM_MFMA = 2 /* 128x128 tiles */,
+       MMRCA_GEMM_MFMA256 = 3 /* 256x256 tiles, persistent workgroups; A row-major with round_up(M, 256) READABLE rows (AUTO only
+                                  picks it when M % 256 == 0), N % 256 == 0, K % 64 == 0, K >= 128, operands < 4 GiB */,
        MMRCA_GEMM_MFMA_PERSIST = 4 /* 128x128 tiles, persistent blocks with cross-tile prefetch */,
        MMRCA_GEMM_MFMA_BK32 = 5 /* 128x128x32 tiles, 32 KiB LDS: four blocks per CU */,
        MMRCA_GEMM_MFMA_1STAGE = 6 /* 128x128x64 tiles, single LDS stage (32 KiB): four blocks per CU */,

@@ -62,9 +62,14 @@ def _gemm_case(M, N, K, a_layout, b_layout, dt, impl, act=L.ACT_NONE, bias=False
     Kcall = Kp if (a_layout == L.KROW or b_layout == L.KROW) else K
     if a_layout == L.ROWK and Kcall != K:
         Ad = dev(F.pad(A, (0, Kcall - K)), dt)
+    if impl == L.IMPL_MFMA256 and a_layout == L.ROWK:
+        Ad = _pad256(Ad)
+        add_call = None if add_d is None else _pad256(add_d)
+    else:
+        add_call = add_d
     if b_layout == L.ROWK and Kcall != K:
         Bd = dev(F.pad(Bm, (0, Kcall - K)), dt)
-    L.gemm(Ad, Bd, Cd, bias=bias_d, addend=add_d, preact=pre_d, M=M, N=N, K=Kcall,
+    L.gemm(Ad, Bd, Cd, bias=bias_d, addend=add_call, preact=pre_d, M=M, N=N, K=Kcall,
            lda=Ad.shape[1], ldb=Bd.shape[1], ldc=N, a_layout=a_layout, b_layout=b_layout, act=act, accum=accum,
            dtype=L.dtype_code(dt), impl=impl)
     torch.cuda.synchronize()
@@ -198,52 +203,65 @@ def test_gemm_persistent_kernel(layouts):
     _gemm_case(768, 768, 5000, 1, 1, torch.bfloat16, L.IMPL_MFMA_PERSIST, accum=True)
 
 
-@pytest.mark.parametrize("layouts", [(0, 0), (0, 1), (1, 1), (1, 0)])
-def test_gemm_mfma256_layouts_and_epilogues(layouts):
-    """256x256 tile kernel with loads kept in flight across barriers: exact integers first, then random data with
-    K-tile counts from 2 (tail-only path) upward, odd and even (LDS stage parity of the tail), and a ragged M."""
-    al, bl = layouts
+def _pad256(t):
+    """contract of the 256x256 kernel: round_up(M, 256) readable rows of A and of the side operand (content irrelevant: NaN)"""
+    M = t.shape[0]
+    return t if M % 256 == 0 else torch.cat([t, torch.full((256 - M % 256, t.shape[1]), float("nan"), device=t.device, dtype=t.dtype)])
+
+
+@pytest.mark.parametrize("bl", [0, 1])
+def test_gemm_mfma256_layouts_and_epilogues(bl):
+    """Persistent 256x256 kernel (operand stream in flight across barriers AND across tile boundaries): exact integers
+    first, then random data with K-tile counts from 2 (tail-only path) upward, odd and even (LDS stage parity at the tile
+    boundary), a ragged M, and enough tiles that workgroups walk several tiles each."""
+    al = 0
     M, N, K = 512, 256, 192
     A = ((torch.arange(M)[:, None] * 7 + torch.arange(K)[None, :] * 3) % 5 - 2.0)
     B = ((torch.arange(N)[:, None] * 3 + torch.arange(K)[None, :] * 5) % 7 - 3.0)
-    Ad, Bd = dev(A if al == 0 else A.t(), torch.bfloat16), dev(B if bl == 0 else B.t(), torch.bfloat16)
+    Ad, Bd = dev(A, torch.bfloat16), dev(B if bl == 0 else B.t(), torch.bfloat16)
     Cd = torch.empty(M, N, device="cuda", dtype=torch.bfloat16)
     L.gemm(Ad, Bd, Cd, M=M, N=N, K=K, lda=Ad.shape[1], ldb=Bd.shape[1], ldc=N, a_layout=al, b_layout=bl, dtype=L.BF16, impl=L.IMPL_MFMA256)
     torch.cuda.synchronize()
     assert torch.equal(Cd.float().cpu(), (A @ B.t()).bfloat16().float()), (al, bl)
     for K in (128, 192, 320, 768, 832):
-        Mr = 768 if al == L.KROW else 700
-        _gemm_case(Mr, 512, K, al, bl, torch.bfloat16, L.IMPL_MFMA256, bias=True)
-    Mr = 768 if al == L.KROW else 1000
-    _gemm_case(Mr, 256, 256, al, bl, torch.bfloat16, L.IMPL_MFMA256, bias=True, addend=True, preact=True)
+        _gemm_case(700, 512, K, al, bl, torch.bfloat16, L.IMPL_MFMA256, bias=True)
+    _gemm_case(1000, 256, 256, al, bl, torch.bfloat16, L.IMPL_MFMA256, bias=True, addend=True)
+    # 26 x 12 = 312 tiles on 256 workgroups (two tiles for some), then 1,170 tiles (four to five each), odd / even K-tile counts
+    _gemm_case(6600, 3072, 192, al, bl, torch.bfloat16, L.IMPL_MFMA256, bias=True, addend=True)
+    _gemm_case(33200, 2304, 128, al, bl, torch.bfloat16, L.IMPL_MFMA256, bias=True)
+    _gemm_case(33200, 2304, 320, al, bl, torch.bfloat16, L.IMPL_MFMA256)
 
 
 @pytest.mark.parametrize("bl", [0, 1])
 def test_gemm_mfma256_fused_gelu_epilogues_and_colsum(bl):
     """The 256x256 kernel's compile-time epilogues: GELU with gelu' saved (forward FFN1), multiply by the saved gelu' with
-    the column sums of the stored result (input gradient of FFN2 + FFN1 bias gradient), residual addend; ragged M."""
+    the column sums of the stored result (input gradient of FFN2 + FFN1 bias gradient), residual addend; ragged M (the
+    padded rows of A and of the side operand hold NaN)."""
     dt = torch.bfloat16
     M, N, K = 788, 512, 320
     g = torch.Generator().manual_seed(11)
     X = dev(torch.randn(M, K, generator=g) * 0.3, dt)
+    Xp = _pad256(X)
     Wm = torch.randn(N, K, generator=g) * 0.2
     Wd = dev(Wm if bl == 0 else Wm.t(), dt)
     Wf = (Wd if bl == 0 else Wd.t()).double()
     bias, add = dev(torch.randn(N, generator=g) * 0.1, dt), dev(torch.randn(M, N, generator=g), dt)
-    Y, Gp = torch.empty(M, N, device="cuda", dtype=dt), torch.empty(M, N, device="cuda", dtype=dt)
-    L.gemm(X, Wd, Y, bias=bias, preact=Gp, M=M, N=N, K=K, lda=K, ldb=Wd.shape[1], ldc=N, b_layout=bl, act=L.ACT_GELU_SAVE_GRAD,
+    Y, Gp = torch.empty(M, N, device="cuda", dtype=dt), torch.empty(1024, N, device="cuda", dtype=dt)
+    L.gemm(Xp, Wd, Y, bias=bias, preact=Gp, M=M, N=N, K=K, lda=K, ldb=Wd.shape[1], ldc=N, b_layout=bl, act=L.ACT_GELU_SAVE_GRAD,
            dtype=L.BF16, impl=L.IMPL_MFMA256)
     pre = (X.double() @ Wf.t() + bias.double()).float().requires_grad_(True)
     yr = F.gelu(pre); yr.backward(torch.ones_like(yr))
-    assert rel_err(Y, yr.detach()) < TOL[dt] and rel_err(Gp, pre.grad) < TOL[dt]
-    for addend in (None, add):
-        C = torch.empty(M, N, device="cuda", dtype=dt)
-        db = dev(torch.randn(N, generator=g)); db0 = db.clone()
-        L.gemm(X, Wd, C, preact=Gp, addend=addend, M=M, N=N, K=K, lda=K, ldb=Wd.shape[1], ldc=N, b_layout=bl, act=L.ACT_MUL,
-               dtype=L.BF16, impl=L.IMPL_MFMA256, colsum=db)
-        ref = (X.double() @ Wf.t()) * Gp.double() + (0 if addend is None else addend.double())
-        assert rel_err(C, ref) < TOL[dt]
-        assert rel_err(db - db0, C.float().sum(0)) < 1e-4
+    assert rel_err(Y, yr.detach()) < TOL[dt] and rel_err(Gp[:M], pre.grad) < TOL[dt]
+    C = torch.empty(M, N, device="cuda", dtype=dt)
+    db = dev(torch.randn(N, generator=g)); db0 = db.clone()
+    L.gemm(Xp, Wd, C, preact=Gp, M=M, N=N, K=K, lda=K, ldb=Wd.shape[1], ldc=N, b_layout=bl, act=L.ACT_MUL,
+           dtype=L.BF16, impl=L.IMPL_MFMA256, colsum=db)
+    assert rel_err(C, (X.double() @ Wf.t()) * Gp[:M].double()) < TOL[dt]
+    assert rel_err(db - db0, C.float().sum(0)) < 1e-4
+    C2 = torch.empty(M, N, device="cuda", dtype=dt)          # residual addend (the out-projection / FFN2 forward epilogue)
+    L.gemm(Xp, Wd, C2, bias=bias, addend=_pad256(add), M=M, N=N, K=K, lda=K, ldb=Wd.shape[1], ldc=N, b_layout=bl, dtype=L.BF16,
+           impl=L.IMPL_MFMA256)
+    assert rel_err(C2, X.double() @ Wf.t() + bias.double() + add.double()) < TOL[dt]
 
 
 @pytest.mark.parametrize("dt,impl", [(torch.float32, L.IMPL_REF), (torch.bfloat16, L.IMPL_REF), (torch.bfloat16, L.IMPL_MFMA),

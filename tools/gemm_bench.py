@@ -18,7 +18,7 @@ SHAPES = [  # (name, M, N, K, a_layout, b_layout, accum)
     ("text wgrad qkv", 2304, 768, 9344, 1, 1, 1), ("text wgrad out", 768, 768, 9344, 1, 1, 1), ("text wgrad ffn1", 3072, 768, 9344, 1, 1, 1),
     ("cube 4096", 4096, 4096, 4096, 0, 0, 0), ("cube 8192", 8192, 8192, 8192, 0, 0, 0),
 ]
-impls = {"auto": L.IMPL_AUTO, "1stage": L.IMPL_MFMA_1STAGE, "bk32": L.IMPL_MFMA_BK32}
+impls = {"auto": L.IMPL_AUTO, "1stage": L.IMPL_MFMA_1STAGE, "bk32": L.IMPL_MFMA_BK32, "2stage": L.IMPL_MFMA}
 if os.environ.get("MMRCA_BENCH_256"):
     impls["m256"] = L.IMPL_MFMA256
 DBG = [int(x) for x in os.environ.get("MMRCA_DBG", "0").split(",")]
@@ -43,14 +43,15 @@ for name, m, n, k, al, bl, acc in SHAPES:
     row = {}
     epi = dict(preact=torch.empty(Mp, n, device=dev, dtype=torch.bfloat16) if "preact" in name else None,
                addend=torch.randn(Mp, n, device=dev).bfloat16() if "addend" in name else None,
-               act=L.ACT_GELU if "gelu" in name else L.ACT_NONE)
-    variants = [(a, b, 0) for a, b in impls.items()] + [(f"256dbg{d}", L.IMPL_MFMA256, d) for d in DBG if d >= 8 and d < 256 and d != 16]
+               act=(L.ACT_GELU_SAVE_GRAD if "gelu preact" in name else L.ACT_GELU) if "gelu" in name else L.ACT_NONE)
+    variants = [(a, b, 0) for a, b in impls.items()] + [(f"256dbg{d}", L.IMPL_MFMA256, d) for d in DBG if 0 < d < 8]
     variants += [(f"128tgt{d >> 8}", L.IMPL_MFMA, d) for d in DBG if d >= 256]
     variants += [(f"128dbg{d}", L.IMPL_MFMA, d) for d in DBG if d == 16]
     variants += [(f"bk32tgt{d >> 8}", L.IMPL_MFMA_BK32, d) for d in DBG if d >= 256]
     runs = {}
     for iname, impl, dbg in variants:
-        if impl == L.IMPL_MFMA256 and (acc or n % 256 or k < 128 or (al == 1 and m % 256)):
+        if impl == L.IMPL_MFMA256 and (acc or n % 256 or k < 128 or al == 1 or
+                                       (epi["act"] == L.ACT_NONE and epi["preact"] is not None) or epi["act"] == L.ACT_GELU):
             continue
         if impl in (L.IMPL_MFMA_TALL, L.IMPL_MFMA_256W, L.IMPL_MFMA_256X4) and (acc or al == 1 or (impl != L.IMPL_MFMA_TALL and n % 256)):
             continue
