@@ -108,10 +108,13 @@ def main(argv=None):
     if args.late_fusion != "MM_RCA":
         print("Wrong late fusion strategy: ", args.late_fusion)
         sys.exit(1)
-    image_model = args.image_model if args.image_model not in ("b4",) else "transformer_B16"
+    from .conv_engine import CONV_MODELS
+    from . import spec as S
+    image_model = args.image_model if (args.image_model in S.VISION_SPECS or args.image_model in CONV_MODELS) else "EffNetv2-Medium"
     model = MM_RCA(_num_classes, args.model_dropout, args.image_text_dropout, args.image_prob_dropout, args.num_neurons_FC,
                    args.text_model, _batch_size, args.reverse, args.features_only, args.cross_attention_only,
-                   image_model_name=image_model, dtype=torch.bfloat16 if args.dtype == "bf16" else torch.float32, device=device)
+                   image_model_name=image_model, dtype=torch.bfloat16 if args.dtype == "bf16" else torch.float32, device=device,
+                   image_size=args.image_size)
     model.load_state_dict(torch.load(args.model_path, map_location=device))
     model.eval()
     WIDTH, HEIGHT = model.get_image_size()

@@ -1,0 +1,497 @@
+"""Conv image backbones over libmmrca (csrc/conv.hip + the K2 GEMM): EfficientNetV2-M / -L and ShuffleNetV2 x2.0.
+
+What this replaces in the reference: ``eff_net_v2()`` + ``EfficientNetV2MFullFeatureExtractor``
+(CVPR_code/multimodal_model.py:11-36, 113-126 -- the image model MM_RCA actually runs; ``main_both.py:259`` forces it) and, for
+the generalised ``--image_model`` values of BASELINE.json, torchvision's ``efficientnet_v2_l`` / ``shufflenet_v2_x2_0``
+(models.py:261-278).  Parameter / buffer names are those of the reference's ``image_model`` state_dict (the extractor wrapper's
+attribute names over torchvision's module tree); the architecture tables are restated from the published torchvision source
+(torchvision is not installed here: "torchvision-unpinned", pinned only by the parameter counts the reference quotes at
+main_image.py:295,302 and by the CPU restatement in oracle/conv_models.py).
+
+Data layout: NHWC, every activation a row-major [B*H*W, C] matrix (rows padded with zeros to a multiple of 256), so a 1x1
+convolution is ``mmrca_gemm`` on the rows and a full 3x3 convolution is ``mmrca_im2row3x3`` + ``mmrca_gemm``.  BatchNorm runs on
+batch statistics in training (and updates the running statistics), on running statistics in eval -- the reference calls
+``global_model.train()`` in BOTH phases (main_both.py:564, 706), so the frozen phase still normalises with batch statistics.
+No torch autograd: forward() saves what backward() needs, backward() accumulates (+=) into the gradient arena.
+"""
+from __future__ import annotations
+
+from typing import Dict, List, Optional, Tuple
+
+import torch
+
+from . import lib as L
+
+ROWPAD = 256
+
+# (fused, expand, kernel, stride, in, out, layers) -- torchvision/models/efficientnet.py, _efficientnet_conf("efficientnet_v2_m" / "_l")
+EFFNET_V2 = {
+    "eff_v2_medium": dict(sd=0.3, stem=24, cfg=[(1, 1, 3, 1, 24, 24, 3), (1, 4, 3, 2, 24, 48, 5), (1, 4, 3, 2, 48, 80, 5), (0, 4, 3, 2, 80, 160, 7),
+                                                (0, 6, 3, 1, 160, 176, 14), (0, 6, 3, 2, 176, 304, 18), (0, 6, 3, 1, 304, 512, 5)]),
+    "eff_v2_large": dict(sd=0.5, stem=32, cfg=[(1, 1, 3, 1, 32, 32, 4), (1, 4, 3, 2, 32, 64, 7), (1, 4, 3, 2, 64, 96, 7), (0, 4, 3, 2, 96, 192, 10),
+                                               (0, 6, 3, 1, 192, 224, 19), (0, 6, 3, 2, 224, 384, 25), (0, 6, 3, 1, 384, 640, 7)]),
+}
+SHUFFLE_X2 = dict(repeats=[4, 8, 4], channels=[24, 244, 488, 976, 2048])       # shufflenet_v2_x2_0
+CONV_MODELS = {"eff_v2_medium": 1280, "EffNetv2-Medium": 1280, "eff_v2_large": 1280, "shuffle_net": 2048}
+_ALIAS = {"EffNetv2-Medium": "eff_v2_medium"}
+
+
+def _ru(x, m):
+    return (x + m - 1) // m * m
+
+
+class _Unit:
+    """conv (1x1 | 3x3 | depthwise 3x3, no bias) -> BatchNorm -> activation.  ``key`` is the torchvision prefix of the
+    Conv2dNormActivation (conv = key.0, bn = key.1) or, for ShuffleNetV2's plain Sequentials, (conv key, bn key)."""
+
+    def __init__(self, conv_key, bn_key, cin, cout, k, stride, act, dw=False, eps=1e-3):
+        self.conv_key, self.bn_key = conv_key, bn_key
+        self.cin, self.cout, self.k, self.stride, self.act, self.dw, self.eps = cin, cout, k, stride, act, dw, eps
+
+    def params(self):
+        shp = (self.cout, 1, 3, 3) if self.dw else (self.cout, self.cin, self.k, self.k)
+        return [(self.conv_key + ".weight", shp), (self.bn_key + ".weight", (self.cout,)), (self.bn_key + ".bias", (self.cout,))]
+
+    def buffers(self):
+        return [(self.bn_key + ".running_mean", (self.cout,)), (self.bn_key + ".running_var", (self.cout,)),
+                (self.bn_key + ".num_batches_tracked", ())]
+
+
+class _SE:
+    def __init__(self, key, c, sq):
+        self.key, self.c, self.sq = key, c, sq
+
+    def params(self):
+        return [(self.key + ".fc1.weight", (self.sq, self.c, 1, 1)), (self.key + ".fc1.bias", (self.sq,)),
+                (self.key + ".fc2.weight", (self.c, self.sq, 1, 1)), (self.key + ".fc2.bias", (self.c,))]
+
+
+class ConvEncoder:
+    """Owns the structure of one conv backbone; parameters live in the owner's arenas (``owner.W(key)`` / ``owner.G(key)``
+    with the "image_model." prefix), BatchNorm buffers here."""
+
+    def __init__(self, name: str, owner, image_size: int = 224):
+        name = _ALIAS.get(name, name)
+        if name not in ("eff_v2_medium", "eff_v2_large", "shuffle_net"):
+            raise ValueError(f"Wrong image model: {name}")
+        self.name, self.o, self.image = name, owner, image_size
+        self.dim = CONV_MODELS[name]
+        self.blocks: List[dict] = []          # execution plan
+        self.sd_probs: List[float] = []
+        if name == "shuffle_net":
+            self._plan_shuffle()
+        else:
+            self._plan_effnet()
+        self.buffers: Dict[str, torch.Tensor] = {}
+        self._nbt_base: Dict[str, int] = {}
+        self._bufs: Dict[Tuple, torch.Tensor] = {}
+        self._maps: Dict[Tuple, torch.Tensor] = {}
+        self.saved = None
+        self.injected_keep = None             # tests: [n_sd_blocks, B] 0/1 keep masks instead of drawing them
+        self.n_train_forwards = 0             # = every BatchNorm's num_batches_tracked (written out by sync_buffers())
+
+    # ------------------------------------------------------------------ structure
+    def _plan_effnet(self):
+        spec = EFFNET_V2[self.name]
+        cfg = spec["cfg"]
+        names = ["stem.1", "stage1", "stage2", "stage3", "stage4", "stage5", "stage6"]       # extractor attributes (multimodal_model.py:14-21)
+        self.stem = _Unit("stem.0.0", "stem.0.1", 3, spec["stem"], 3, 2, L.CONV_SILU)
+        total = sum(c[6] for c in cfg)
+        bid = 0
+        for sname, (fused, expand, k, stride, cin, cout, n) in zip(names, cfg):
+            for i in range(n):
+                ci, st = (cin if i == 0 else cout), (stride if i == 0 else 1)
+                cexp = ci * expand
+                P = f"{sname}.{i}.block"
+                blk = dict(kind="fused" if fused else "mb", res=(st == 1 and ci == cout), sd=spec["sd"] * bid / total, units=[], se=None)
+                if fused:
+                    if cexp != ci:
+                        blk["units"] = [_Unit(P + ".0.0", P + ".0.1", ci, cexp, 3, st, L.CONV_SILU), _Unit(P + ".1.0", P + ".1.1", cexp, cout, 1, 1, L.CONV_NONE)]
+                    else:
+                        blk["units"] = [_Unit(P + ".0.0", P + ".0.1", ci, cout, 3, st, L.CONV_SILU)]
+                else:
+                    j = 0
+                    if cexp != ci:
+                        blk["units"].append(_Unit(f"{P}.{j}.0", f"{P}.{j}.1", ci, cexp, 1, 1, L.CONV_SILU)); j += 1
+                    blk["units"].append(_Unit(f"{P}.{j}.0", f"{P}.{j}.1", cexp, cexp, 3, st, L.CONV_SILU, dw=True)); j += 1
+                    blk["se"] = _SE(f"{P}.{j}", cexp, max(1, ci // 4)); j += 1
+                    blk["units"].append(_Unit(f"{P}.{j}.0", f"{P}.{j}.1", cexp, cout, 1, 1, L.CONV_NONE))
+                self.blocks.append(blk)
+                bid += 1
+        self.final = _Unit("final_conv.0", "final_conv.1", cfg[-1][5], 1280, 1, 1, L.CONV_SILU)
+
+    def _plan_shuffle(self):
+        ch = SHUFFLE_X2["channels"]
+        U = lambda ck, bk, ci, co, k, s, act, dw=False: _Unit(ck, bk, ci, co, k, s, act, dw, eps=1e-5)
+        self.stem = U("conv1.0", "conv1.1", 3, ch[0], 3, 2, L.CONV_RELU)
+        inp = ch[0]
+        for sname, rep, oup in zip(("stage2", "stage3", "stage4"), SHUFFLE_X2["repeats"], ch[1:4]):
+            bf = oup // 2
+            for i in range(rep):
+                P = f"{sname}.{i}"
+                if i == 0:
+                    b1 = [U(P + ".branch1.0", P + ".branch1.1", inp, inp, 3, 2, L.CONV_NONE, dw=True),
+                          U(P + ".branch1.2", P + ".branch1.3", inp, bf, 1, 1, L.CONV_RELU)]
+                    b2 = [U(P + ".branch2.0", P + ".branch2.1", inp, bf, 1, 1, L.CONV_RELU),
+                          U(P + ".branch2.3", P + ".branch2.4", bf, bf, 3, 2, L.CONV_NONE, dw=True),
+                          U(P + ".branch2.5", P + ".branch2.6", bf, bf, 1, 1, L.CONV_RELU)]
+                    self.blocks.append(dict(kind="shuffle_down", b1=b1, b2=b2, cin=inp, cout=oup))
+                else:
+                    b2 = [U(P + ".branch2.0", P + ".branch2.1", bf, bf, 1, 1, L.CONV_RELU),
+                          U(P + ".branch2.3", P + ".branch2.4", bf, bf, 3, 1, L.CONV_NONE, dw=True),
+                          U(P + ".branch2.5", P + ".branch2.6", bf, bf, 1, 1, L.CONV_RELU)]
+                    self.blocks.append(dict(kind="shuffle", b2=b2, cin=oup, cout=oup))
+            inp = oup
+        self.final = U("conv5.0", "conv5.1", inp, ch[4], 1, 1, L.CONV_RELU)
+
+    def _all_units(self):
+        yield self.stem
+        for b in self.blocks:
+            for u in b.get("units", []) + b.get("b1", []) + b.get("b2", []):
+                yield u
+        yield self.final
+
+    def param_entries(self) -> List[Tuple[str, Tuple[int, ...]]]:
+        """(key, shape) of every trainable parameter, in module order (= the oracle's / torchvision's state_dict order)."""
+        out = []
+        def unit(u):
+            out.extend(u.params())
+        unit(self.stem)
+        for b in self.blocks:
+            if b["kind"] in ("fused", "mb"):
+                us = list(b["units"])
+                if b["se"] is not None:
+                    for u in us[:-1]:
+                        unit(u)
+                    out.extend(b["se"].params())
+                    unit(us[-1])
+                else:
+                    for u in us:
+                        unit(u)
+            else:
+                for u in b.get("b1", []) + b["b2"]:
+                    unit(u)
+        unit(self.final)
+        return out
+
+    def buffer_entries(self):
+        return [e for u in self._all_units() for e in u.buffers()]
+
+    def init_buffers(self, device):
+        for k, shp in self.buffer_entries():
+            if k.endswith("num_batches_tracked"):
+                self.buffers[k] = torch.zeros((), dtype=torch.int64, device=device)
+            else:
+                self.buffers[k] = (torch.ones if k.endswith("running_var") else torch.zeros)(shp, dtype=torch.float32, device=device)
+
+    def sync_buffers(self):
+        for k, t in self.buffers.items():
+            if k.endswith("num_batches_tracked"):
+                t.fill_(self._nbt_base.get(k, 0) + self.n_train_forwards)
+
+    def load_buffers(self, sd: Dict[str, torch.Tensor], prefix: str = ""):
+        for k, t in self.buffers.items():
+            if prefix + k in sd:
+                if k.endswith("num_batches_tracked"):
+                    self._nbt_base[k] = int(sd[prefix + k]) - self.n_train_forwards
+                t.copy_(torch.as_tensor(sd[prefix + k]).to(t.device, t.dtype))
+
+    # ------------------------------------------------------------------ storage helpers
+    def buf(self, name, rows, cols, dtype=None):
+        dtype = dtype or self.o.dtype
+        key = (name, rows, cols, dtype)
+        t = self._bufs.get(key)
+        if t is None:
+            t = torch.zeros(_ru(max(rows, 1), ROWPAD), cols, dtype=dtype, device=self.o.device)
+            self._bufs[key] = t
+        return t
+
+    def release(self):
+        self._bufs.clear()
+        self.saved = None
+
+    def W(self, key):
+        return self.o.W("image_model." + key)
+
+    def G(self, key):
+        return self.o.G("image_model." + key)
+
+    def _cmap(self, name, idx: List[int]):
+        t = self._maps.get(name)
+        if t is None:
+            t = torch.tensor(idx, dtype=torch.int32, device=self.o.device)
+            self._maps[name] = t
+        return t
+
+    # ------------------------------------------------------------------ conv -> bn -> act
+    def _unit_fwd(self, u: _Unit, x, B, H, Wd, tag, train, save):
+        """x: rows [B*H*W, cin] -> y rows [B*Ho*Wo, cout]; returns (y, Ho, Wo, saved)."""
+        dt = self.o.dt
+        Ho, Wo = (H - 1) // u.stride + 1, (Wd - 1) // u.stride + 1
+        rows = B * Ho * Wo
+        z = self.buf(tag + ".z", rows, u.cout)
+        w = self.W(u.conv_key + ".weight")
+        if u.dw:
+            L.dwconv3x3_fwd(x, w, z, B, H, Wd, u.cin, u.stride, dt)
+        elif u.k == 1:
+            L.gemm(x, w, z, M=rows, N=u.cout, K=u.cin, lda=u.cin, ldb=u.cin, ldc=u.cout, dtype=dt, impl=self.o.gemm_impl)
+        else:
+            K = 9 * u.cin
+            col = self.buf("tmp.col", rows, K)
+            L.im2row3x3(x, col, B, H, Wd, u.cin, u.stride, K, dt)
+            L.gemm(col, w, z, M=rows, N=u.cout, K=K, lda=K, ldb=K, ldc=u.cout, dtype=dt, impl=self.o.gemm_impl)
+        mean = self.buf(tag + ".mean", 1, u.cout, torch.float32)
+        rstd = self.buf(tag + ".rstd", 1, u.cout, torch.float32)
+        rm, rv = self.buffers[u.bn_key + ".running_mean"], self.buffers[u.bn_key + ".running_var"]
+        L.bn_stats(z, mean, rstd, rm, rv, rows, u.cout, u.cout, u.eps, 0.1 if train else 0.0, train, dt)
+        y = self.buf(tag + ".y", rows, u.cout)
+        L.bn_act_fwd(z, mean, rstd, self.W(u.bn_key + ".weight"), self.W(u.bn_key + ".bias"), y, rows, u.cout, u.act, dt)
+        return y, Ho, Wo, dict(x=x, z=z, mean=mean, rstd=rstd, H=H, W=Wd, Ho=Ho, Wo=Wo, train=train)
+
+    def _unit_bwd(self, u: _Unit, dy, sv, B, need_dx=True, tag="g"):
+        """dy: gradient at the unit's output rows; returns dx rows (or None)."""
+        dt = self.o.dt
+        H, Wd, Ho, Wo = sv["H"], sv["W"], sv["Ho"], sv["Wo"]
+        rows = B * Ho * Wo
+        dz = self.buf(f"{tag}.dz.{u.cout}", rows, u.cout)
+        scratch = self.buf("g.bnscratch", 1, 2 * u.cout, torch.float32)
+        L.bn_act_bwd(dy, sv["z"], sv["mean"], sv["rstd"], self.W(u.bn_key + ".weight"), self.W(u.bn_key + ".bias"), dz,
+                     self.G(u.bn_key + ".weight"), self.G(u.bn_key + ".bias"), scratch, rows, u.cout, u.act, sv["train"], dt)
+        w, gw = self.W(u.conv_key + ".weight"), self.G(u.conv_key + ".weight")
+        rows_in = B * H * Wd
+        dx = self.buf(f"{tag}.dx.{u.cin}.{rows_in}", rows_in, u.cin) if need_dx else None
+        rows_k = _ru(rows, 64)                       # the contraction of the weight gradient runs over whole 64-row steps (zero pad rows)
+        if u.dw:
+            L.dwconv3x3_bwd(dz, sv["x"], w, dx, gw, B, H, Wd, u.cin, u.stride, dt)
+        elif u.k == 1:
+            L.gemm(dz, sv["x"], gw, M=u.cout, N=u.cin, K=rows_k, lda=u.cout, ldb=u.cin, ldc=u.cin, a_layout=L.KROW, b_layout=L.KROW,
+                   accum=True, dtype=dt, impl=self.o.gemm_impl)
+            if need_dx:
+                L.gemm(dz, w, dx, M=rows, N=u.cin, K=u.cout, lda=u.cout, ldb=u.cin, ldc=u.cin, a_layout=L.ROWK, b_layout=L.KROW, dtype=dt,
+                       impl=self.o.gemm_impl)
+        else:
+            K = 9 * u.cin
+            col = self.buf("tmp.col", rows, K)
+            L.im2row3x3(sv["x"], col, B, H, Wd, u.cin, u.stride, K, dt)
+            L.gemm(dz, col, gw, M=u.cout, N=K, K=rows_k, lda=u.cout, ldb=K, ldc=K, a_layout=L.KROW, b_layout=L.KROW, accum=True, dtype=dt,
+                   impl=self.o.gemm_impl)
+            if need_dx:
+                L.gemm(dz, w, col, M=rows, N=K, K=u.cout, lda=u.cout, ldb=K, ldc=K, a_layout=L.ROWK, b_layout=L.KROW, dtype=dt,
+                       impl=self.o.gemm_impl)
+                L.col2im3x3(col, dx, B, H, Wd, u.cin, u.stride, K, dt)
+        return dx
+
+    # ------------------------------------------------------------------ squeeze-excitation
+    def _se_fwd(self, se: _SE, x, B, HW, tag, save):
+        dt = self.o.dt
+        n = lambda s, r, c: self.buf(tag + s, r, c)
+        pooled, h_pre, h = n(".se.pool", B, se.c), n(".se.hpre", B, se.sq), n(".se.h", B, se.sq)
+        s_pre, s = n(".se.spre", B, se.c), n(".se.s", B, se.c)
+        L.rowpool_mean(x, pooled, B, HW, se.c, dt)
+        L.gemm(pooled, self.W(se.key + ".fc1.weight"), h_pre, M=B, N=se.sq, K=se.c, lda=se.c, ldb=se.c, ldc=se.sq, dtype=dt, impl=self.o.gemm_impl)
+        L.bias_act_fwd(h_pre, self.W(se.key + ".fc1.bias"), h, B, se.sq, L.CONV_SILU, dt)
+        L.gemm(h, self.W(se.key + ".fc2.weight"), s_pre, M=B, N=se.c, K=se.sq, lda=se.sq, ldb=se.sq, ldc=se.c, dtype=dt, impl=self.o.gemm_impl)
+        L.bias_act_fwd(s_pre, self.W(se.key + ".fc2.bias"), s, B, se.c, L.CONV_SIGMOID, dt)
+        y = self.buf(tag + ".se.y", B * HW, se.c)
+        L.se_scale_fwd(x, s, y, B, HW, se.c, dt)
+        return y, dict(x=x, pooled=pooled, h_pre=h_pre, h=h, s_pre=s_pre, s=s, HW=HW)
+
+    def _se_bwd(self, se: _SE, dy, sv, B, gp="g"):
+        dt = self.o.dt
+        HW = sv["HW"]
+        g = lambda s, r, c: self.buf(gp + ".se" + s + f".{c}", r, c)
+        dx, ds = self.buf(f"{gp}.se.dx.{se.c}.{B * HW}", B * HW, se.c), g(".ds", B, se.c)
+        L.se_scale_bwd(dy, sv["x"], sv["s"], dx, ds, B, HW, se.c, dt)
+        ds_pre = g(".dspre", B, se.c)
+        L.bias_act_bwd(ds, sv["s_pre"], self.W(se.key + ".fc2.bias"), ds_pre, self.G(se.key + ".fc2.bias"), B, se.c, L.CONV_SIGMOID, dt)
+        Bk = _ru(B, 64)
+        L.gemm(ds_pre, sv["h"], self.G(se.key + ".fc2.weight"), M=se.c, N=se.sq, K=Bk, lda=se.c, ldb=se.sq, ldc=se.sq, a_layout=L.KROW,
+               b_layout=L.KROW, accum=True, dtype=dt, impl=self.o.gemm_impl)
+        dh = g(".dh", B, se.sq)
+        L.gemm(ds_pre, self.W(se.key + ".fc2.weight"), dh, M=B, N=se.sq, K=se.c, lda=se.c, ldb=se.sq, ldc=se.sq, a_layout=L.ROWK, b_layout=L.KROW,
+               dtype=dt, impl=self.o.gemm_impl)
+        dh_pre = g(".dhpre", B, se.sq)
+        L.bias_act_bwd(dh, sv["h_pre"], self.W(se.key + ".fc1.bias"), dh_pre, self.G(se.key + ".fc1.bias"), B, se.sq, L.CONV_SILU, dt)
+        L.gemm(dh_pre, sv["pooled"], self.G(se.key + ".fc1.weight"), M=se.sq, N=se.c, K=Bk, lda=se.sq, ldb=se.c, ldc=se.c, a_layout=L.KROW,
+               b_layout=L.KROW, accum=True, dtype=dt, impl=self.o.gemm_impl)
+        dpool = g(".dpool", B, se.c)
+        L.gemm(dh_pre, self.W(se.key + ".fc1.weight"), dpool, M=B, N=se.c, K=se.sq, lda=se.sq, ldb=se.c, ldc=se.c, a_layout=L.ROWK, b_layout=L.KROW,
+               dtype=dt, impl=self.o.gemm_impl)
+        L.rowpool_mean_bwd(dpool, dx, B, HW, se.c, True, dt)
+        return dx
+
+    # ------------------------------------------------------------------ whole network
+    def forward(self, images, save: bool, train: bool, seed: int = 0):
+        """images [B,3,H,W] fp32 in HBM -> features [B, dim] (the pooled vector MM_RCA consumes, multimodal_model.py:659)."""
+        dt = self.o.dt
+        B, C, H, Wd = images.shape
+        if C != 3:
+            raise ValueError(f"images must be [B,3,H,W], got {tuple(images.shape)}")
+        x0 = self.buf("in.rows", B * H * Wd, 3)
+        L.nchw_to_rows(images.to(torch.float32).contiguous(), x0, B, 3, H, Wd, dt)
+        saved = dict(B=B, blocks=[], train=train)
+        x, h, w, saved["stem"] = self._unit_fwd(self.stem, x0, B, H, Wd, "stem", train, save)
+        if self.name == "shuffle_net":
+            Ho, Wo = (h - 1) // 2 + 1, (w - 1) // 2 + 1
+            c0 = self.stem.cout
+            y = self.buf("pool.y", B * Ho * Wo, c0)
+            arg = self.buf("pool.arg", B * Ho * Wo, c0, torch.uint8)
+            L.maxpool3x3s2_fwd(x, y, arg, B, h, w, c0, dt)
+            saved["pool"] = dict(arg=arg, H=h, W=w)
+            x, h, w = y, Ho, Wo
+        # stochastic depth ("row" mode, train only): one tiny device op draws every block's keep mask
+        rowscale = None
+        sd_idx = [i for i, b in enumerate(self.blocks) if b.get("res") and b.get("sd", 0.0) > 0.0]
+        if train and sd_idx:
+            p = torch.tensor([self.blocks[i]["sd"] for i in sd_idx], dtype=torch.float32, device=self.o.device).view(-1, 1)
+            if self.injected_keep is not None:
+                keep = self.injected_keep.to(self.o.device, torch.float32)
+            else:
+                gen = torch.Generator(device=self.o.device).manual_seed(int(seed) & 0x7FFFFFFFFFFFFFFF)
+                keep = (torch.rand(len(sd_idx), B, device=self.o.device, generator=gen) >= p).float()
+            rowscale = (keep / (1.0 - p)).contiguous()
+        sd_pos = {i: j for j, i in enumerate(sd_idx)}
+        if train:
+            self.n_train_forwards += 1
+        for bi, blk in enumerate(self.blocks):
+            # without `save` the activations of block bi are only needed by block bi + 1: two alternating buffer pools
+            tag = f"b{bi}" if save else f"t{bi % 2}"
+            if blk["kind"] in ("fused", "mb"):
+                bs = dict(units=[], H=h, W=w, cin=blk["units"][0].cin)
+                y, hh, ww = x, h, w
+                us = blk["units"]
+                for ui, u in enumerate(us):
+                    if blk["se"] is not None and ui == len(us) - 1:
+                        y, bs["se"] = self._se_fwd(blk["se"], y, B, hh * ww, tag, save)
+                    y, hh, ww, sv = self._unit_fwd(u, y, B, hh, ww, f"{tag}.u{ui}", train, save)
+                    bs["units"].append(sv)
+                if blk["res"]:
+                    rs = rowscale[sd_pos[bi]] if (rowscale is not None and bi in sd_pos) else None
+                    out = self.buf(f"{tag}.out", B * hh * ww, us[-1].cout)
+                    L.residual_add(x, y, rs, out, B, hh * ww * us[-1].cout, dt)
+                    bs["rowscale"] = rs
+                    y = out
+                x, h, w = y, hh, ww
+            elif blk["kind"] == "shuffle_down":
+                bs = dict(b1=[], b2=[], H=h, W=w)
+                y1, hh, ww = x, h, w
+                for ui, u in enumerate(blk["b1"]):
+                    y1, hh, ww, sv = self._unit_fwd(u, y1, B, hh, ww, f"{tag}.a{ui}", train, save)
+                    bs["b1"].append(sv)
+                y2, h2, w2 = x, h, w
+                for ui, u in enumerate(blk["b2"]):
+                    y2, h2, w2, sv = self._unit_fwd(u, y2, B, h2, w2, f"{tag}.c{ui}", train, save)
+                    bs["b2"].append(sv)
+                x = self._shuffle_cat(y1, y2, B * hh * ww, blk["cout"], f"{tag}.out")
+                h, w = hh, ww
+            else:   # stride-1 shuffle unit: x1 passes through, x2 goes through branch2
+                Cc = blk["cout"]
+                bf = Cc // 2
+                rows = B * h * w
+                x2 = self.buf(f"{tag}.x2", rows, bf)
+                L.channel_gather(x, self._cmap(("hi", Cc), list(range(bf, Cc))), x2, rows, Cc, bf, bf, 0, dt)
+                bs = dict(b2=[], H=h, W=w)
+                y2, h2, w2 = x2, h, w
+                for ui, u in enumerate(blk["b2"]):
+                    y2, h2, w2, sv = self._unit_fwd(u, y2, B, h2, w2, f"{tag}.c{ui}", train, save)
+                    bs["b2"].append(sv)
+                x = self._shuffle_cat(x, y2, rows, Cc, f"{tag}.out", first_is_full=True)
+            saved["blocks"].append(bs)
+        y, h, w, saved["final"] = self._unit_fwd(self.final, x, B, h, w, "final", train, save)
+        feat = self.buf("feat", B, self.dim)
+        L.rowpool_mean(y, feat, B, h * w, self.dim, dt)
+        saved["HW"] = h * w
+        self.saved = saved if save else None
+        return feat[:B]
+
+    def _shuffle_cat(self, a, b, rows, Cc, name, first_is_full=False):
+        """channel_shuffle(cat(a', b), groups=2): out[:, 2j] = a'[:, j], out[:, 2j+1] = b[:, j]  (a' = first half of a when
+        first_is_full).  Two gathers into the interleaved columns are written as one gather each over a [rows, Cc] view."""
+        dt = self.o.dt
+        bf = Cc // 2
+        out = self.buf(name + f".{Cc}.{rows}", rows, Cc)
+        # out[r, j] = src[r, map[j]] needs ONE source: assemble through a contiguous concat buffer first
+        cat = self.buf(f"tmp.cat.{Cc}.{rows}", rows, Cc)
+        ca = a.shape[1]
+        L.channel_gather(a, self._cmap(("lo", ca, bf), list(range(bf))), cat, rows, ca, bf, Cc, 0, dt)
+        L.channel_gather(b, self._cmap(("id", bf), list(range(bf))), cat, rows, bf, bf, Cc, bf, dt)
+        shuf = [(j % 2) * bf + j // 2 for j in range(Cc)]
+        L.channel_gather(cat, self._cmap(("shuf", Cc), shuf), out, rows, Cc, Cc, Cc, 0, dt)
+        return out
+
+    def _shuffle_cat_bwd(self, dout, rows, Cc, gp="g"):
+        """inverse of _shuffle_cat: returns (d first half [rows, bf], d second half [rows, bf])."""
+        dt = self.o.dt
+        bf = Cc // 2
+        d1, d2 = self.buf(f"{gp}.sh1.{bf}.{rows}", rows, bf), self.buf(f"{gp}.sh2.{bf}.{rows}", rows, bf)
+        L.channel_gather(dout, self._cmap(("unshuf_a", Cc), [2 * j for j in range(bf)]), d1, rows, Cc, bf, bf, 0, dt)
+        L.channel_gather(dout, self._cmap(("unshuf_b", Cc), [2 * j + 1 for j in range(bf)]), d2, rows, Cc, bf, bf, 0, dt)
+        return d1, d2
+
+    def backward(self, dfeat):
+        """dfeat [B, dim] -> accumulates every parameter gradient of the backbone (no gradient w.r.t. the images)."""
+        sv = self.saved
+        if sv is None:
+            raise L.MmrcaError("conv backbone: backward() needs forward(save=True)")
+        dt = self.o.dt
+        B = sv["B"]
+        HW = sv["HW"]
+        dpool = self.buf("g.dfeat", B, self.dim)
+        dpool[:B].copy_(dfeat.to(dpool.dtype))
+        dy = self.buf("g.dfinal", B * HW, self.dim)
+        L.rowpool_mean_bwd(dpool, dy, B, HW, self.dim, False, dt)
+        dx = self._unit_bwd(self.final, dy, sv["final"], B)
+        for bi in reversed(range(len(self.blocks))):
+            blk, bs = self.blocks[bi], sv["blocks"][bi]
+            gp = f"g{bi % 2}"          # gradient buffers alternate between two pools: the incoming gradient (written by block
+                                       # bi + 1) must survive until this block's residual sum
+            if blk["kind"] in ("fused", "mb"):
+                us = blk["units"]
+                dres = dx
+                rows_out = B * bs["units"][-1]["Ho"] * bs["units"][-1]["Wo"]
+                if blk["res"] and bs.get("rowscale") is not None:
+                    dbr = self.buf(f"{gp}.dbr.{us[-1].cout}.{rows_out}", rows_out, us[-1].cout)
+                    L.residual_add(None, dx, bs["rowscale"], dbr, B, (rows_out // B) * us[-1].cout, dt)
+                    d = dbr
+                else:
+                    d = dx
+                for ui in reversed(range(len(us))):
+                    first = ui == 0
+                    d = self._unit_bwd(us[ui], d, bs["units"][ui], B, need_dx=True, tag=f"{gp}.u{ui}")
+                    if blk["se"] is not None and ui == len(us) - 1:
+                        d = self._se_bwd(blk["se"], d, bs["se"], B, gp)
+                if blk["res"]:
+                    rows_in = B * bs["H"] * bs["W"]
+                    out = self.buf(f"{gp}.sum.{bs['cin']}.{rows_in}", rows_in, bs["cin"])
+                    L.residual_add(dres, d, None, out, B, (rows_in // B) * bs["cin"], dt)
+                    d = out
+                dx = d
+            elif blk["kind"] == "shuffle_down":
+                rows_out = B * bs["b2"][-1]["Ho"] * bs["b2"][-1]["Wo"]
+                d1, d2 = self._shuffle_cat_bwd(dx, rows_out, blk["cout"], gp)
+                for ui in reversed(range(len(blk["b1"]))):
+                    d1 = self._unit_bwd(blk["b1"][ui], d1, bs["b1"][ui], B, tag=f"{gp}.a{ui}")
+                for ui in reversed(range(len(blk["b2"]))):
+                    d2 = self._unit_bwd(blk["b2"][ui], d2, bs["b2"][ui], B, tag=f"{gp}.c{ui}")
+                rows_in = B * bs["H"] * bs["W"]
+                out = self.buf(f"{gp}.sum.{blk['cin']}.{rows_in}", rows_in, blk["cin"])
+                L.residual_add(d1, d2, None, out, B, (rows_in // B) * blk["cin"], dt)
+                dx = out
+            else:
+                Cc = blk["cout"]
+                bf = Cc // 2
+                rows = B * bs["H"] * bs["W"]
+                d1, d2 = self._shuffle_cat_bwd(dx, rows, Cc, gp)
+                for ui in reversed(range(len(blk["b2"]))):
+                    d2 = self._unit_bwd(blk["b2"][ui], d2, bs["b2"][ui], B, tag=f"{gp}.c{ui}")
+                out = self.buf(f"{gp}.cat.{Cc}.{rows}", rows, Cc)
+                L.channel_gather(d1, self._cmap(("id", bf), list(range(bf))), out, rows, bf, bf, Cc, 0, dt)
+                L.channel_gather(d2, self._cmap(("id", bf), list(range(bf))), out, rows, bf, bf, Cc, bf, dt)
+                dx = out
+        if self.name == "shuffle_net":
+            p = sv["pool"]
+            c0 = self.stem.cout
+            d = self.buf("g.pool", B * p["H"] * p["W"], c0)
+            L.maxpool3x3s2_bwd(dx, p["arg"], d, B, p["H"], p["W"], c0, dt)
+            dx = d
+        self._unit_bwd(self.stem, dx, sv["stem"], B, need_dx=False)

@@ -1,0 +1,675 @@
+// Conv-backbone kernels: EfficientNetV2-M/L (the image model the reference's MM_RCA runs,
+// CVPR_code/multimodal_model.py:11-36, 113-126) and ShuffleNetV2 x2.0 (models.py:261-278) on NHWC activations.
+//
+// Layout: an activation is a row-major matrix [B*H*W, C] (channels contiguous), so
+//   * every 1x1 convolution IS mmrca_gemm on the rows (weight [Cout, Cin] = torchvision's [Cout, Cin, 1, 1]);
+//   * a full 3x3 convolution is mmrca_im2row3x3 + mmrca_gemm: the patch row is channel-major, col[c*9 + ky*3 + kx], which is
+//     exactly the flattening of torchvision's [Cout, Cin, 3, 3] weight -- no re-laid weight copy exists; its input gradient is
+//     mmrca_gemm (dcol = dz W) + mmrca_col2im3x3 (a gather over the <= 9 output pixels that read an input pixel: no atomics);
+//   * depthwise 3x3, BatchNorm (batch statistics in training, running statistics in eval, running-stat update), SiLU / ReLU /
+//     sigmoid, squeeze-excitation pooling and scaling, stochastic depth, 3x3/2 max pooling are the kernels below.
+// Everything here is HBM-bound elementwise / reduction work: one thread per (pixel, channel) with the channel index
+// fastest (coalesced), fp32 arithmetic, fp32 statistics and parameter gradients.
+#include "common.h"
+
+#define CONV_ACT_NONE 0
+#define CONV_ACT_SILU 1
+#define CONV_ACT_RELU 2
+#define CONV_ACT_SIGMOID 3
+
+__device__ __forceinline__ float sigmoid_f(float x) { return 1.0f / (1.0f + __expf(-x)); }
+__device__ __forceinline__ float act_f(float u, int act) {
+  if (act == CONV_ACT_SILU) return u * sigmoid_f(u);
+  if (act == CONV_ACT_RELU) return u > 0.f ? u : 0.f;
+  if (act == CONV_ACT_SIGMOID) return sigmoid_f(u);
+  return u;
+}
+// d act(u) / du
+__device__ __forceinline__ float act_grad_f(float u, int act) {
+  if (act == CONV_ACT_SILU) { const float s = sigmoid_f(u); return s * (1.0f + u * (1.0f - s)); }
+  if (act == CONV_ACT_RELU) return u > 0.f ? 1.f : 0.f;
+  if (act == CONV_ACT_SIGMOID) { const float s = sigmoid_f(u); return s * (1.0f - s); }
+  return 1.f;
+}
+
+static inline unsigned blocks_for(int64_t n, int per) { return (unsigned)((n + per - 1) / per); }
+
+// ---------------------------------------------------------------------------------------------------------------------
+// NCHW fp32 images -> NHWC rows
+// ---------------------------------------------------------------------------------------------------------------------
+template <typename T>
+__global__ void nchw_to_rows_k(const float* __restrict__ img, T* __restrict__ x, int B, int C, int HW) {
+  const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;          // (b, pix, c), c fastest
+  if (idx >= (int64_t)B * HW * C) return;
+  const int c = (int)(idx % C);
+  const int64_t bp = idx / C;
+  const int p = (int)(bp % HW), b = (int)(bp / HW);
+  x[idx] = from_f<T>(img[((int64_t)b * C + c) * HW + p]);
+}
+
+extern "C" int mmrca_nchw_to_rows(const float* images, void* x, int B, int C, int H, int W, int dtype, void* stream) {
+  MMRCA_REQUIRE(images && x && B > 0 && C > 0 && H > 0 && W > 0, "nchw_to_rows: bad arguments");
+  const int64_t n = (int64_t)B * C * H * W;
+  MMRCA_DISPATCH_DTYPE(dtype, "nchw_to_rows",
+    hipLaunchKernelGGL(nchw_to_rows_k<T>, dim3(blocks_for(n, 256)), dim3(256), 0, (hipStream_t)stream, images, (T*)x, B, C, H * W);)
+  MMRCA_CHECK_LAUNCH("nchw_to_rows");
+  return 0;
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// im2row / col2im for 3x3, padding 1, stride 1 or 2
+// ---------------------------------------------------------------------------------------------------------------------
+template <typename T>
+__global__ void im2row3x3_k(const T* __restrict__ x, T* __restrict__ col, int B, int H, int W, int C, int Ho, int Wo, int stride,
+                            int64_t ldk) {
+  const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;          // (out pixel, c), c fastest
+  if (idx >= (int64_t)B * Ho * Wo * C) return;
+  const int c = (int)(idx % C);
+  const int64_t op = idx / C;
+  const int ox = (int)(op % Wo), oy = (int)((op / Wo) % Ho), b = (int)(op / ((int64_t)Wo * Ho));
+  T* dst = col + op * ldk + (int64_t)c * 9;
+#pragma unroll
+  for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+    for (int kx = 0; kx < 3; ++kx) {
+      const int iy = oy * stride + ky - 1, ix = ox * stride + kx - 1;
+      const bool in = iy >= 0 && iy < H && ix >= 0 && ix < W;
+      dst[ky * 3 + kx] = in ? x[(((int64_t)b * H + iy) * W + ix) * C + c] : from_f<T>(0.f);
+    }
+}
+
+extern "C" int mmrca_im2row3x3(const void* x, void* col, int B, int H, int W, int C, int stride, int64_t ldk, int dtype, void* stream) {
+  MMRCA_REQUIRE(x && col && B > 0 && H > 0 && W > 0 && C > 0 && (stride == 1 || stride == 2) && ldk >= 9LL * C, "im2row3x3: bad arguments");
+  const int Ho = (H - 1) / stride + 1, Wo = (W - 1) / stride + 1;
+  const int64_t n = (int64_t)B * Ho * Wo * C;
+  MMRCA_DISPATCH_DTYPE(dtype, "im2row3x3",
+    hipLaunchKernelGGL(im2row3x3_k<T>, dim3(blocks_for(n, 256)), dim3(256), 0, (hipStream_t)stream, (const T*)x, (T*)col, B, H, W, C,
+                       Ho, Wo, stride, ldk);)
+  MMRCA_CHECK_LAUNCH("im2row3x3");
+  return 0;
+}
+
+// dx[b, iy, ix, c] = sum over (ky, kx) with (iy + 1 - ky) % stride == 0 etc. of dcol[out pixel][c*9 + ky*3 + kx]
+template <typename T>
+__global__ void col2im3x3_k(const T* __restrict__ dcol, T* __restrict__ dx, int B, int H, int W, int C, int Ho, int Wo, int stride,
+                            int64_t ldk) {
+  const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;          // (in pixel, c), c fastest
+  if (idx >= (int64_t)B * H * W * C) return;
+  const int c = (int)(idx % C);
+  const int64_t ip = idx / C;
+  const int ix = (int)(ip % W), iy = (int)((ip / W) % H), b = (int)(ip / ((int64_t)W * H));
+  float s = 0.f;
+#pragma unroll
+  for (int ky = 0; ky < 3; ++ky) {
+    const int ty = iy + 1 - ky;
+    if (ty < 0 || ty % stride) continue;
+    const int oy = ty / stride;
+    if (oy >= Ho) continue;
+#pragma unroll
+    for (int kx = 0; kx < 3; ++kx) {
+      const int tx = ix + 1 - kx;
+      if (tx < 0 || tx % stride) continue;
+      const int ox = tx / stride;
+      if (ox >= Wo) continue;
+      s += to_f(dcol[(((int64_t)b * Ho + oy) * Wo + ox) * ldk + (int64_t)c * 9 + ky * 3 + kx]);
+    }
+  }
+  dx[idx] = from_f<T>(s);
+}
+
+extern "C" int mmrca_col2im3x3(const void* dcol, void* dx, int B, int H, int W, int C, int stride, int64_t ldk, int dtype, void* stream) {
+  MMRCA_REQUIRE(dcol && dx && B > 0 && H > 0 && W > 0 && C > 0 && (stride == 1 || stride == 2) && ldk >= 9LL * C, "col2im3x3: bad arguments");
+  const int Ho = (H - 1) / stride + 1, Wo = (W - 1) / stride + 1;
+  const int64_t n = (int64_t)B * H * W * C;
+  MMRCA_DISPATCH_DTYPE(dtype, "col2im3x3",
+    hipLaunchKernelGGL(col2im3x3_k<T>, dim3(blocks_for(n, 256)), dim3(256), 0, (hipStream_t)stream, (const T*)dcol, (T*)dx, B, H, W, C,
+                       Ho, Wo, stride, ldk);)
+  MMRCA_CHECK_LAUNCH("col2im3x3");
+  return 0;
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// depthwise 3x3, padding 1, stride 1 or 2.  w: [C, 9] in `dtype` (torchvision's [C, 1, 3, 3]); dw: fp32 [C, 9], +=
+// ---------------------------------------------------------------------------------------------------------------------
+template <typename T>
+__global__ void dwconv3x3_fwd_k(const T* __restrict__ x, const T* __restrict__ w, T* __restrict__ y, int B, int H, int W, int C,
+                                int Ho, int Wo, int stride) {
+  const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= (int64_t)B * Ho * Wo * C) return;
+  const int c = (int)(idx % C);
+  const int64_t op = idx / C;
+  const int ox = (int)(op % Wo), oy = (int)((op / Wo) % Ho), b = (int)(op / ((int64_t)Wo * Ho));
+  float s = 0.f;
+#pragma unroll
+  for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+    for (int kx = 0; kx < 3; ++kx) {
+      const int iy = oy * stride + ky - 1, ix = ox * stride + kx - 1;
+      if (iy >= 0 && iy < H && ix >= 0 && ix < W) s = fmaf(to_f(x[(((int64_t)b * H + iy) * W + ix) * C + c]), to_f(w[c * 9 + ky * 3 + kx]), s);
+    }
+  y[idx] = from_f<T>(s);
+}
+
+template <typename T>
+__global__ void dwconv3x3_bwd_data_k(const T* __restrict__ dy, const T* __restrict__ w, T* __restrict__ dx, int B, int H, int W, int C,
+                                     int Ho, int Wo, int stride) {
+  const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= (int64_t)B * H * W * C) return;
+  const int c = (int)(idx % C);
+  const int64_t ip = idx / C;
+  const int ix = (int)(ip % W), iy = (int)((ip / W) % H), b = (int)(ip / ((int64_t)W * H));
+  float s = 0.f;
+#pragma unroll
+  for (int ky = 0; ky < 3; ++ky) {
+    const int ty = iy + 1 - ky;
+    if (ty < 0 || ty % stride) continue;
+    const int oy = ty / stride;
+    if (oy >= Ho) continue;
+#pragma unroll
+    for (int kx = 0; kx < 3; ++kx) {
+      const int tx = ix + 1 - kx;
+      if (tx < 0 || tx % stride) continue;
+      const int ox = tx / stride;
+      if (ox >= Wo) continue;
+      s = fmaf(to_f(dy[(((int64_t)b * Ho + oy) * Wo + ox) * C + c]), to_f(w[c * 9 + ky * 3 + kx]), s);
+    }
+  }
+  dx[idx] = from_f<T>(s);
+}
+
+// dw[c][tap] += sum over output pixels of dy * x(tap).  Block = 256 threads = 64 channels x 4 pixel lanes; each block walks a
+// slice of the output pixels, reduces its 4 pixel lanes in LDS and adds 9 values per channel atomically.
+template <typename T>
+__global__ void dwconv3x3_bwd_weight_k(const T* __restrict__ dy, const T* __restrict__ x, float* __restrict__ dw, int B, int H, int W,
+                                       int C, int Ho, int Wo, int stride, int64_t pix_per_block) {
+  __shared__ float red[4][64][9];
+  const int cl = threadIdx.x & 63, pl = threadIdx.x >> 6;
+  const int c = blockIdx.y * 64 + cl;
+  float acc[9];
+#pragma unroll
+  for (int t = 0; t < 9; ++t) acc[t] = 0.f;
+  const int64_t npix = (int64_t)B * Ho * Wo;
+  const int64_t p0 = (int64_t)blockIdx.x * pix_per_block;
+  const int64_t p1 = p0 + pix_per_block < npix ? p0 + pix_per_block : npix;
+  if (c < C) {
+    for (int64_t op = p0 + pl; op < p1; op += 4) {
+      const int ox = (int)(op % Wo), oy = (int)((op / Wo) % Ho), b = (int)(op / ((int64_t)Wo * Ho));
+      const float g = to_f(dy[op * C + c]);
+#pragma unroll
+      for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+        for (int kx = 0; kx < 3; ++kx) {
+          const int iy = oy * stride + ky - 1, ix = ox * stride + kx - 1;
+          if (iy >= 0 && iy < H && ix >= 0 && ix < W) acc[ky * 3 + kx] = fmaf(g, to_f(x[(((int64_t)b * H + iy) * W + ix) * C + c]), acc[ky * 3 + kx]);
+        }
+    }
+  }
+#pragma unroll
+  for (int t = 0; t < 9; ++t) red[pl][cl][t] = acc[t];
+  __syncthreads();
+  if (pl == 0 && c < C) {
+#pragma unroll
+    for (int t = 0; t < 9; ++t) atomicAdd(dw + (int64_t)c * 9 + t, red[0][cl][t] + red[1][cl][t] + red[2][cl][t] + red[3][cl][t]);
+  }
+}
+
+extern "C" int mmrca_dwconv3x3_fwd(const void* x, const void* w, void* y, int B, int H, int W, int C, int stride, int dtype, void* stream) {
+  MMRCA_REQUIRE(x && w && y && B > 0 && H > 0 && W > 0 && C > 0 && (stride == 1 || stride == 2), "dwconv3x3_fwd: bad arguments");
+  const int Ho = (H - 1) / stride + 1, Wo = (W - 1) / stride + 1;
+  const int64_t n = (int64_t)B * Ho * Wo * C;
+  MMRCA_DISPATCH_DTYPE(dtype, "dwconv3x3_fwd",
+    hipLaunchKernelGGL(dwconv3x3_fwd_k<T>, dim3(blocks_for(n, 256)), dim3(256), 0, (hipStream_t)stream, (const T*)x, (const T*)w, (T*)y,
+                       B, H, W, C, Ho, Wo, stride);)
+  MMRCA_CHECK_LAUNCH("dwconv3x3_fwd");
+  return 0;
+}
+
+extern "C" int mmrca_dwconv3x3_bwd(const void* dy, const void* x, const void* w, void* dx, float* dw, int B, int H, int W, int C, int stride,
+                                   int dtype, void* stream) {
+  MMRCA_REQUIRE(dy && x && w && B > 0 && H > 0 && W > 0 && C > 0 && (stride == 1 || stride == 2), "dwconv3x3_bwd: bad arguments");
+  const int Ho = (H - 1) / stride + 1, Wo = (W - 1) / stride + 1;
+  hipStream_t st = (hipStream_t)stream;
+  if (dx) {
+    const int64_t n = (int64_t)B * H * W * C;
+    MMRCA_DISPATCH_DTYPE(dtype, "dwconv3x3_bwd",
+      hipLaunchKernelGGL(dwconv3x3_bwd_data_k<T>, dim3(blocks_for(n, 256)), dim3(256), 0, st, (const T*)dy, (const T*)w, (T*)dx, B, H, W, C,
+                         Ho, Wo, stride);)
+    MMRCA_CHECK_LAUNCH("dwconv3x3_bwd(data)");
+  }
+  if (dw) {
+    const int64_t npix = (int64_t)B * Ho * Wo;
+    int64_t nblk = npix / 512 > 0 ? npix / 512 : 1;
+    if (nblk > 1024) nblk = 1024;
+    const int64_t per = (npix + nblk - 1) / nblk;
+    MMRCA_DISPATCH_DTYPE(dtype, "dwconv3x3_bwd",
+      hipLaunchKernelGGL(dwconv3x3_bwd_weight_k<T>, dim3((unsigned)nblk, (unsigned)((C + 63) / 64)), dim3(256), 0, st, (const T*)dy,
+                         (const T*)x, dw, B, H, W, C, Ho, Wo, stride, per);)
+    MMRCA_CHECK_LAUNCH("dwconv3x3_bwd(weight)");
+  }
+  return 0;
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// BatchNorm2d over rows (torch.nn.BatchNorm2d as built by torchvision: eps 1e-3 EfficientNetV2 / 1e-5 ShuffleNetV2, momentum
+// 0.1).  Training: batch mean and BIASED variance normalise; running_var is updated with the UNBIASED variance.
+// Column reductions: block = 64 channels x 4 row lanes over a slice of rows -> LDS -> one atomic per channel per block.
+// ---------------------------------------------------------------------------------------------------------------------
+template <typename T, bool CENTERED>
+__global__ void col_moment_k(const T* __restrict__ x, const float* __restrict__ mean, float* __restrict__ out, int64_t rows, int C,
+                             int64_t ld, int64_t rows_per_block) {
+  __shared__ float red[4][64];
+  const int cl = threadIdx.x & 63, rl = threadIdx.x >> 6;
+  const int c = blockIdx.y * 64 + cl;
+  const int64_t r0 = (int64_t)blockIdx.x * rows_per_block;
+  const int64_t r1 = r0 + rows_per_block < rows ? r0 + rows_per_block : rows;
+  float s = 0.f;
+  if (c < C) {
+    const float m = CENTERED ? mean[c] : 0.f;
+    for (int64_t r = r0 + rl; r < r1; r += 4) {
+      const float v = to_f(x[r * ld + c]) - m;
+      s += CENTERED ? v * v : v;
+    }
+  }
+  red[rl][cl] = s;
+  __syncthreads();
+  if (rl == 0 && c < C) atomicAdd(out + c, red[0][cl] + red[1][cl] + red[2][cl] + red[3][cl]);
+}
+
+__global__ void bn_finish_mean_k(float* __restrict__ mean, int C, float inv_n) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c < C) mean[c] *= inv_n;
+}
+// var_sum -> rstd (in place), running stats
+__global__ void bn_finish_var_k(const float* __restrict__ mean, float* __restrict__ rstd, float* __restrict__ running_mean,
+                                float* __restrict__ running_var, int C, float n, float eps, float momentum) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  const float var = rstd[c] / n;
+  rstd[c] = rsqrtf(var + eps);
+  if (running_mean && momentum > 0.f) {
+    running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * mean[c];
+    running_var[c] = (1.f - momentum) * running_var[c] + momentum * (n > 1.f ? var * n / (n - 1.f) : var);
+  }
+}
+__global__ void bn_eval_stats_k(const float* __restrict__ running_mean, const float* __restrict__ running_var, float* __restrict__ mean,
+                                float* __restrict__ rstd, int C, float eps) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c < C) { mean[c] = running_mean[c]; rstd[c] = rsqrtf(running_var[c] + eps); }
+}
+
+static void col_grid(int64_t rows, int C, dim3* grid, int64_t* per) {
+  int64_t nblk = rows / 256 > 0 ? rows / 256 : 1;
+  if (nblk > 2048) nblk = 2048;
+  *per = (rows + nblk - 1) / nblk;
+  *grid = dim3((unsigned)((rows + *per - 1) / *per), (unsigned)((C + 63) / 64));
+}
+
+/* mean[C], rstd[C] (fp32) of x[rows, C] (two passes: mean, then centred second moment); momentum > 0 also updates the running
+ * statistics (torch semantics).  train == 0: mean / rstd are derived from the running statistics instead. */
+extern "C" int mmrca_bn_stats(const void* x, float* mean, float* rstd, float* running_mean, float* running_var, int64_t rows, int C,
+                              int64_t ld, float eps, float momentum, int train, int dtype, void* stream) {
+  MMRCA_REQUIRE(mean && rstd && rows > 0 && C > 0 && ld >= C, "bn_stats: bad arguments");
+  hipStream_t st = (hipStream_t)stream;
+  if (!train) {
+    MMRCA_REQUIRE(running_mean && running_var, "bn_stats: eval mode needs the running statistics");
+    hipLaunchKernelGGL(bn_eval_stats_k, dim3((C + 255) / 256), dim3(256), 0, st, running_mean, running_var, mean, rstd, C, eps);
+    MMRCA_CHECK_LAUNCH("bn_stats(eval)");
+    return 0;
+  }
+  MMRCA_REQUIRE(x, "bn_stats: null input");
+  dim3 grid; int64_t per;
+  col_grid(rows, C, &grid, &per);
+  (void)hipMemsetAsync(mean, 0, sizeof(float) * C, st);
+  (void)hipMemsetAsync(rstd, 0, sizeof(float) * C, st);
+  MMRCA_DISPATCH_DTYPE(dtype, "bn_stats",
+    hipLaunchKernelGGL((col_moment_k<T, false>), grid, dim3(256), 0, st, (const T*)x, (const float*)nullptr, mean, rows, C, ld, per);
+    hipLaunchKernelGGL(bn_finish_mean_k, dim3((C + 255) / 256), dim3(256), 0, st, mean, C, 1.0f / (float)rows);
+    hipLaunchKernelGGL((col_moment_k<T, true>), grid, dim3(256), 0, st, (const T*)x, (const float*)mean, rstd, rows, C, ld, per);)
+  hipLaunchKernelGGL(bn_finish_var_k, dim3((C + 255) / 256), dim3(256), 0, st, mean, rstd, running_mean, running_var, C, (float)rows, eps, momentum);
+  MMRCA_CHECK_LAUNCH("bn_stats");
+  return 0;
+}
+
+template <typename T>
+__global__ void bn_act_fwd_k(const T* __restrict__ x, const float* __restrict__ mean, const float* __restrict__ rstd,
+                             const T* __restrict__ gamma, const T* __restrict__ beta, T* __restrict__ y, int64_t n, int C, int act) {
+  const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= n) return;
+  const int c = (int)(idx % C);
+  const float u = (to_f(x[idx]) - mean[c]) * rstd[c] * to_f(gamma[c]) + to_f(beta[c]);
+  y[idx] = from_f<T>(act_f(u, act));
+}
+
+/* y = act(gamma * (x - mean) * rstd + beta) on contiguous [rows, C] */
+extern "C" int mmrca_bn_act_fwd(const void* x, const float* mean, const float* rstd, const void* gamma, const void* beta, void* y,
+                                int64_t rows, int C, int act, int dtype, void* stream) {
+  MMRCA_REQUIRE(x && mean && rstd && gamma && beta && y && rows > 0 && C > 0 && act >= 0 && act <= 3, "bn_act_fwd: bad arguments");
+  const int64_t n = rows * C;
+  MMRCA_DISPATCH_DTYPE(dtype, "bn_act_fwd",
+    hipLaunchKernelGGL(bn_act_fwd_k<T>, dim3(blocks_for(n, 256)), dim3(256), 0, (hipStream_t)stream, (const T*)x, mean, rstd, (const T*)gamma,
+                       (const T*)beta, (T*)y, n, C, act);)
+  MMRCA_CHECK_LAUNCH("bn_act_fwd");
+  return 0;
+}
+
+// backward, pass 1: du = dy * act'(u); sums[0][c] += du, sums[1][c] += du * xhat
+template <typename T>
+__global__ void bn_act_bwd_reduce_k(const T* __restrict__ dy, const T* __restrict__ x, const float* __restrict__ mean,
+                                    const float* __restrict__ rstd, const T* __restrict__ gamma, const T* __restrict__ beta,
+                                    float* __restrict__ sum_du, float* __restrict__ sum_duxh, int64_t rows, int C, int act,
+                                    int64_t rows_per_block) {
+  __shared__ float red[2][4][64];
+  const int cl = threadIdx.x & 63, rl = threadIdx.x >> 6;
+  const int c = blockIdx.y * 64 + cl;
+  const int64_t r0 = (int64_t)blockIdx.x * rows_per_block;
+  const int64_t r1 = r0 + rows_per_block < rows ? r0 + rows_per_block : rows;
+  float s0 = 0.f, s1 = 0.f;
+  if (c < C) {
+    const float m = mean[c], rs = rstd[c], g = to_f(gamma[c]), b = to_f(beta[c]);
+    for (int64_t r = r0 + rl; r < r1; r += 4) {
+      const float xh = (to_f(x[r * C + c]) - m) * rs;
+      const float du = to_f(dy[r * C + c]) * act_grad_f(xh * g + b, act);
+      s0 += du; s1 = fmaf(du, xh, s1);
+    }
+  }
+  red[0][rl][cl] = s0; red[1][rl][cl] = s1;
+  __syncthreads();
+  if (rl == 0 && c < C) {
+    atomicAdd(sum_du + c, red[0][0][cl] + red[0][1][cl] + red[0][2][cl] + red[0][3][cl]);
+    atomicAdd(sum_duxh + c, red[1][0][cl] + red[1][1][cl] + red[1][2][cl] + red[1][3][cl]);
+  }
+}
+// pass 2: dx = gamma * rstd * (du - [train] (sum_du + xhat * sum_duxh) / n)
+template <typename T>
+__global__ void bn_act_bwd_apply_k(const T* __restrict__ dy, const T* __restrict__ x, const float* __restrict__ mean,
+                                   const float* __restrict__ rstd, const T* __restrict__ gamma, const T* __restrict__ beta,
+                                   const float* __restrict__ sum_du, const float* __restrict__ sum_duxh, T* __restrict__ dx, int64_t n,
+                                   int C, int act, float inv_rows, int train) {
+  const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= n) return;
+  const int c = (int)(idx % C);
+  const float g = to_f(gamma[c]), rs = rstd[c];
+  const float xh = (to_f(x[idx]) - mean[c]) * rs;
+  float du = to_f(dy[idx]) * act_grad_f(xh * g + to_f(beta[c]), act);
+  if (train) du -= (sum_du[c] + xh * sum_duxh[c]) * inv_rows;
+  dx[idx] = from_f<T>(g * rs * du);
+}
+__global__ void bn_param_grads_k(const float* __restrict__ sum_du, const float* __restrict__ sum_duxh, float* __restrict__ dgamma,
+                                 float* __restrict__ dbeta, int C) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c < C) { dgamma[c] += sum_duxh[c]; dbeta[c] += sum_du[c]; }
+}
+
+/* Backward of y = act(BN(x)): dx (may be NULL), dgamma / dbeta (fp32, +=, may be NULL).  scratch: fp32 [2*C] workspace.
+ * train != 0: batch statistics took part in the forward (the usual three-term input gradient); 0: statistics were constants. */
+extern "C" int mmrca_bn_act_bwd(const void* dy, const void* x, const float* mean, const float* rstd, const void* gamma, const void* beta,
+                                void* dx, float* dgamma, float* dbeta, float* scratch, int64_t rows, int C, int act, int train, int dtype,
+                                void* stream) {
+  MMRCA_REQUIRE(dy && x && mean && rstd && gamma && beta && scratch && rows > 0 && C > 0 && act >= 0 && act <= 3, "bn_act_bwd: bad arguments");
+  hipStream_t st = (hipStream_t)stream;
+  dim3 grid; int64_t per;
+  col_grid(rows, C, &grid, &per);
+  (void)hipMemsetAsync(scratch, 0, sizeof(float) * 2 * C, st);
+  const int64_t n = rows * C;
+  MMRCA_DISPATCH_DTYPE(dtype, "bn_act_bwd",
+    hipLaunchKernelGGL(bn_act_bwd_reduce_k<T>, grid, dim3(256), 0, st, (const T*)dy, (const T*)x, mean, rstd, (const T*)gamma, (const T*)beta,
+                       scratch, scratch + C, rows, C, act, per);
+    if (dx) hipLaunchKernelGGL(bn_act_bwd_apply_k<T>, dim3(blocks_for(n, 256)), dim3(256), 0, st, (const T*)dy, (const T*)x, mean, rstd,
+                               (const T*)gamma, (const T*)beta, (const float*)scratch, (const float*)(scratch + C), (T*)dx, n, C, act,
+                               1.0f / (float)rows, train);)
+  if (dgamma && dbeta) hipLaunchKernelGGL(bn_param_grads_k, dim3((C + 255) / 256), dim3(256), 0, st, scratch, scratch + C, dgamma, dbeta, C);
+  MMRCA_CHECK_LAUNCH("bn_act_bwd");
+  return 0;
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// per-sample pooling over the H*W rows of a sample, squeeze-excitation scaling, residual with stochastic depth
+// ---------------------------------------------------------------------------------------------------------------------
+template <typename T>
+__global__ void rowpool_mean_k(const T* __restrict__ x, T* __restrict__ out, int HW, int C) {
+  __shared__ float red[4][64];
+  const int cl = threadIdx.x & 63, rl = threadIdx.x >> 6;
+  const int c = blockIdx.y * 64 + cl, b = blockIdx.x;
+  float s = 0.f;
+  if (c < C)
+    for (int p = rl; p < HW; p += 4) s += to_f(x[((int64_t)b * HW + p) * C + c]);
+  red[rl][cl] = s;
+  __syncthreads();
+  if (rl == 0 && c < C) out[(int64_t)b * C + c] = from_f<T>((red[0][cl] + red[1][cl] + red[2][cl] + red[3][cl]) / (float)HW);
+}
+/* out[b, c] = mean over the HW rows of sample b (AdaptiveAvgPool2d(1) / x.mean([2, 3])) */
+extern "C" int mmrca_rowpool_mean(const void* x, void* out, int B, int HW, int C, int dtype, void* stream) {
+  MMRCA_REQUIRE(x && out && B > 0 && HW > 0 && C > 0, "rowpool_mean: bad arguments");
+  MMRCA_DISPATCH_DTYPE(dtype, "rowpool_mean",
+    hipLaunchKernelGGL(rowpool_mean_k<T>, dim3(B, (C + 63) / 64), dim3(256), 0, (hipStream_t)stream, (const T*)x, (T*)out, HW, C);)
+  MMRCA_CHECK_LAUNCH("rowpool_mean");
+  return 0;
+}
+
+// dx[b, p, c] (+)= dpool[b, c] / HW
+template <typename T>
+__global__ void rowpool_mean_bwd_k(const T* __restrict__ dpool, T* __restrict__ dx, int64_t n, int HW, int C, int accumulate) {
+  const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= n) return;
+  const int c = (int)(idx % C);
+  const int64_t b = idx / ((int64_t)HW * C);
+  const float g = to_f(dpool[b * C + c]) / (float)HW;
+  dx[idx] = from_f<T>(accumulate ? to_f(dx[idx]) + g : g);
+}
+extern "C" int mmrca_rowpool_mean_bwd(const void* dpool, void* dx, int B, int HW, int C, int accumulate, int dtype, void* stream) {
+  MMRCA_REQUIRE(dpool && dx && B > 0 && HW > 0 && C > 0, "rowpool_mean_bwd: bad arguments");
+  const int64_t n = (int64_t)B * HW * C;
+  MMRCA_DISPATCH_DTYPE(dtype, "rowpool_mean_bwd",
+    hipLaunchKernelGGL(rowpool_mean_bwd_k<T>, dim3(blocks_for(n, 256)), dim3(256), 0, (hipStream_t)stream, (const T*)dpool, (T*)dx, n, HW, C, accumulate);)
+  MMRCA_CHECK_LAUNCH("rowpool_mean_bwd");
+  return 0;
+}
+
+// y = x * s[b, c]
+template <typename T>
+__global__ void se_scale_fwd_k(const T* __restrict__ x, const T* __restrict__ s, T* __restrict__ y, int64_t n, int HW, int C) {
+  const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= n) return;
+  const int c = (int)(idx % C);
+  const int64_t b = idx / ((int64_t)HW * C);
+  y[idx] = from_f<T>(to_f(x[idx]) * to_f(s[b * C + c]));
+}
+extern "C" int mmrca_se_scale_fwd(const void* x, const void* s, void* y, int B, int HW, int C, int dtype, void* stream) {
+  MMRCA_REQUIRE(x && s && y && B > 0 && HW > 0 && C > 0, "se_scale_fwd: bad arguments");
+  const int64_t n = (int64_t)B * HW * C;
+  MMRCA_DISPATCH_DTYPE(dtype, "se_scale_fwd",
+    hipLaunchKernelGGL(se_scale_fwd_k<T>, dim3(blocks_for(n, 256)), dim3(256), 0, (hipStream_t)stream, (const T*)x, (const T*)s, (T*)y, n, HW, C);)
+  MMRCA_CHECK_LAUNCH("se_scale_fwd");
+  return 0;
+}
+// dx = dy * s[b, c];  ds[b, c] = sum over the sample's rows of dy * x
+template <typename T>
+__global__ void se_scale_bwd_k(const T* __restrict__ dy, const T* __restrict__ x, const T* __restrict__ s, T* __restrict__ dx,
+                               T* __restrict__ ds, int HW, int C) {
+  __shared__ float red[4][64];
+  const int cl = threadIdx.x & 63, rl = threadIdx.x >> 6;
+  const int c = blockIdx.y * 64 + cl, b = blockIdx.x;
+  float acc = 0.f;
+  if (c < C) {
+    const float sv = to_f(s[(int64_t)b * C + c]);
+    for (int p = rl; p < HW; p += 4) {
+      const int64_t i = ((int64_t)b * HW + p) * C + c;
+      const float g = to_f(dy[i]);
+      acc = fmaf(g, to_f(x[i]), acc);
+      dx[i] = from_f<T>(g * sv);
+    }
+  }
+  red[rl][cl] = acc;
+  __syncthreads();
+  if (rl == 0 && c < C) ds[(int64_t)b * C + c] = from_f<T>(red[0][cl] + red[1][cl] + red[2][cl] + red[3][cl]);
+}
+extern "C" int mmrca_se_scale_bwd(const void* dy, const void* x, const void* s, void* dx, void* ds, int B, int HW, int C, int dtype, void* stream) {
+  MMRCA_REQUIRE(dy && x && s && dx && ds && B > 0 && HW > 0 && C > 0, "se_scale_bwd: bad arguments");
+  MMRCA_DISPATCH_DTYPE(dtype, "se_scale_bwd",
+    hipLaunchKernelGGL(se_scale_bwd_k<T>, dim3(B, (C + 63) / 64), dim3(256), 0, (hipStream_t)stream, (const T*)dy, (const T*)x, (const T*)s,
+                       (T*)dx, (T*)ds, HW, C);)
+  MMRCA_CHECK_LAUNCH("se_scale_bwd");
+  return 0;
+}
+
+// elementwise activation on [n] with an optional per-column bias (the 1x1 "convolutions" of squeeze-excitation carry a bias)
+template <typename T>
+__global__ void bias_act_fwd_k(const T* __restrict__ x, const T* __restrict__ bias, T* __restrict__ y, int64_t n, int C, int act) {
+  const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= n) return;
+  const float u = to_f(x[idx]) + (bias ? to_f(bias[idx % C]) : 0.f);
+  y[idx] = from_f<T>(act_f(u, act));
+}
+/* y = act(x + bias[c]) on [rows, C]; x is the pre-activation WITHOUT bias (kept for the backward) */
+extern "C" int mmrca_bias_act_fwd(const void* x, const void* bias, void* y, int64_t rows, int C, int act, int dtype, void* stream) {
+  MMRCA_REQUIRE(x && y && rows > 0 && C > 0 && act >= 0 && act <= 3, "bias_act_fwd: bad arguments");
+  const int64_t n = rows * C;
+  MMRCA_DISPATCH_DTYPE(dtype, "bias_act_fwd",
+    hipLaunchKernelGGL(bias_act_fwd_k<T>, dim3(blocks_for(n, 256)), dim3(256), 0, (hipStream_t)stream, (const T*)x, (const T*)bias, (T*)y, n, C, act);)
+  MMRCA_CHECK_LAUNCH("bias_act_fwd");
+  return 0;
+}
+// dx = dy * act'(x + bias);  dbias[c] += column sums of dx (tiny matrices: one thread per column)
+template <typename T>
+__global__ void bias_act_bwd_k(const T* __restrict__ dy, const T* __restrict__ x, const T* __restrict__ bias, T* __restrict__ dx,
+                               float* __restrict__ dbias, int64_t rows, int C, int act) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  const float b = bias ? to_f(bias[c]) : 0.f;
+  float s = 0.f;
+  for (int64_t r = 0; r < rows; ++r) {
+    const float g = to_f(dy[r * C + c]) * act_grad_f(to_f(x[r * C + c]) + b, act);
+    dx[r * C + c] = from_f<T>(g);
+    s += g;
+  }
+  if (dbias) dbias[c] += s;
+}
+extern "C" int mmrca_bias_act_bwd(const void* dy, const void* x, const void* bias, void* dx, float* dbias, int64_t rows, int C, int act,
+                                  int dtype, void* stream) {
+  MMRCA_REQUIRE(dy && x && dx && rows > 0 && C > 0 && act >= 0 && act <= 3, "bias_act_bwd: bad arguments");
+  MMRCA_DISPATCH_DTYPE(dtype, "bias_act_bwd",
+    hipLaunchKernelGGL(bias_act_bwd_k<T>, dim3((C + 63) / 64), dim3(64), 0, (hipStream_t)stream, (const T*)dy, (const T*)x, (const T*)bias,
+                       (T*)dx, dbias, rows, C, act);)
+  MMRCA_CHECK_LAUNCH("bias_act_bwd");
+  return 0;
+}
+
+// out = a + b * rowscale[sample]   (residual connection with torchvision's "row" stochastic depth; rowscale NULL = 1)
+template <typename T>
+__global__ void residual_add_k(const T* __restrict__ a, const T* __restrict__ b, const float* __restrict__ rowscale, T* __restrict__ out,
+                               int64_t n, int64_t per_sample) {
+  const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= n) return;
+  const float s = rowscale ? rowscale[idx / per_sample] : 1.f;
+  out[idx] = from_f<T>((a ? to_f(a[idx]) : 0.f) + to_f(b[idx]) * s);
+}
+/* out[b, ...] = a[b, ...] + branch[b, ...] * rowscale[b]; a == NULL gives the scaled branch alone (its backward) */
+extern "C" int mmrca_residual_add(const void* a, const void* branch, const float* rowscale, void* out, int B, int64_t per_sample, int dtype,
+                                  void* stream) {
+  MMRCA_REQUIRE(branch && out && B > 0 && per_sample > 0, "residual_add: bad arguments");
+  const int64_t n = (int64_t)B * per_sample;
+  MMRCA_DISPATCH_DTYPE(dtype, "residual_add",
+    hipLaunchKernelGGL(residual_add_k<T>, dim3(blocks_for(n, 256)), dim3(256), 0, (hipStream_t)stream, (const T*)a, (const T*)branch, rowscale,
+                       (T*)out, n, per_sample);)
+  MMRCA_CHECK_LAUNCH("residual_add");
+  return 0;
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// 3x3 / stride 2 / padding 1 max pooling (ShuffleNetV2's stem): the argmax tap is kept for the backward
+// ---------------------------------------------------------------------------------------------------------------------
+template <typename T>
+__global__ void maxpool3x3s2_fwd_k(const T* __restrict__ x, T* __restrict__ y, unsigned char* __restrict__ arg, int B, int H, int W, int C,
+                                   int Ho, int Wo) {
+  const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= (int64_t)B * Ho * Wo * C) return;
+  const int c = (int)(idx % C);
+  const int64_t op = idx / C;
+  const int ox = (int)(op % Wo), oy = (int)((op / Wo) % Ho), b = (int)(op / ((int64_t)Wo * Ho));
+  float best = -INFINITY;
+  int bt = 0;
+#pragma unroll
+  for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+    for (int kx = 0; kx < 3; ++kx) {
+      const int iy = oy * 2 + ky - 1, ix = ox * 2 + kx - 1;
+      if (iy >= 0 && iy < H && ix >= 0 && ix < W) {
+        const float v = to_f(x[(((int64_t)b * H + iy) * W + ix) * C + c]);
+        if (v > best) { best = v; bt = ky * 3 + kx; }       // first maximum wins, as torch's max_pool2d
+      }
+    }
+  y[idx] = from_f<T>(best);
+  arg[idx] = (unsigned char)bt;
+}
+template <typename T>
+__global__ void maxpool3x3s2_bwd_k(const T* __restrict__ dy, const unsigned char* __restrict__ arg, T* __restrict__ dx, int B, int H, int W,
+                                   int C, int Ho, int Wo) {
+  const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;          // input pixel: gather from the <= 4 windows that contain it
+  if (idx >= (int64_t)B * H * W * C) return;
+  const int c = (int)(idx % C);
+  const int64_t ip = idx / C;
+  const int ix = (int)(ip % W), iy = (int)((ip / W) % H), b = (int)(ip / ((int64_t)W * H));
+  float s = 0.f;
+#pragma unroll
+  for (int ky = 0; ky < 3; ++ky) {
+    const int ty = iy + 1 - ky;
+    if (ty < 0 || (ty & 1)) continue;
+    const int oy = ty >> 1;
+    if (oy >= Ho) continue;
+#pragma unroll
+    for (int kx = 0; kx < 3; ++kx) {
+      const int tx = ix + 1 - kx;
+      if (tx < 0 || (tx & 1)) continue;
+      const int ox = tx >> 1;
+      if (ox >= Wo) continue;
+      const int64_t o = (((int64_t)b * Ho + oy) * Wo + ox) * C + c;
+      if (arg[o] == ky * 3 + kx) s += to_f(dy[o]);
+    }
+  }
+  dx[idx] = from_f<T>(s);
+}
+extern "C" int mmrca_maxpool3x3s2_fwd(const void* x, void* y, void* argmax, int B, int H, int W, int C, int dtype, void* stream) {
+  MMRCA_REQUIRE(x && y && argmax && B > 0 && H > 0 && W > 0 && C > 0, "maxpool3x3s2_fwd: bad arguments");
+  const int Ho = (H - 1) / 2 + 1, Wo = (W - 1) / 2 + 1;
+  const int64_t n = (int64_t)B * Ho * Wo * C;
+  MMRCA_DISPATCH_DTYPE(dtype, "maxpool3x3s2_fwd",
+    hipLaunchKernelGGL(maxpool3x3s2_fwd_k<T>, dim3(blocks_for(n, 256)), dim3(256), 0, (hipStream_t)stream, (const T*)x, (T*)y,
+                       (unsigned char*)argmax, B, H, W, C, Ho, Wo);)
+  MMRCA_CHECK_LAUNCH("maxpool3x3s2_fwd");
+  return 0;
+}
+extern "C" int mmrca_maxpool3x3s2_bwd(const void* dy, const void* argmax, void* dx, int B, int H, int W, int C, int dtype, void* stream) {
+  MMRCA_REQUIRE(dy && dx && argmax && B > 0 && H > 0 && W > 0 && C > 0, "maxpool3x3s2_bwd: bad arguments");
+  const int Ho = (H - 1) / 2 + 1, Wo = (W - 1) / 2 + 1;
+  const int64_t n = (int64_t)B * H * W * C;
+  MMRCA_DISPATCH_DTYPE(dtype, "maxpool3x3s2_bwd",
+    hipLaunchKernelGGL(maxpool3x3s2_bwd_k<T>, dim3(blocks_for(n, 256)), dim3(256), 0, (hipStream_t)stream, (const T*)dy,
+                       (const unsigned char*)argmax, (T*)dx, B, H, W, C, Ho, Wo);)
+  MMRCA_CHECK_LAUNCH("maxpool3x3s2_bwd");
+  return 0;
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// channel gather: out[r, j] = in[r, map[j]] for j < Cout (split / concat / ShuffleNetV2's channel shuffle and their
+// backward are all instances; map is an int32 device array)
+// ---------------------------------------------------------------------------------------------------------------------
+template <typename T>
+__global__ void channel_gather_k(const T* __restrict__ in, const int* __restrict__ map, T* __restrict__ out, int64_t n, int Cin, int Cout,
+                                 int64_t ld_out, int col0) {
+  const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= n) return;
+  const int j = (int)(idx % Cout);
+  const int64_t r = idx / Cout;
+  out[r * ld_out + col0 + j] = in[r * Cin + map[j]];
+}
+/* out[r, col0 + j] = in[r, map[j]], j in [0, Cout): in is [rows, Cin] contiguous, out has leading dimension ld_out */
+extern "C" int mmrca_channel_gather(const void* in, const int* map, void* out, int64_t rows, int Cin, int Cout, int64_t ld_out, int col0,
+                                    int dtype, void* stream) {
+  MMRCA_REQUIRE(in && map && out && rows > 0 && Cin > 0 && Cout > 0 && ld_out >= col0 + Cout, "channel_gather: bad arguments");
+  const int64_t n = rows * Cout;
+  MMRCA_DISPATCH_DTYPE(dtype, "channel_gather",
+    hipLaunchKernelGGL(channel_gather_k<T>, dim3(blocks_for(n, 256)), dim3(256), 0, (hipStream_t)stream, (const T*)in, map, (T*)out, n, Cin,
+                       Cout, ld_out, col0);)
+  MMRCA_CHECK_LAUNCH("channel_gather");
+  return 0;
+}

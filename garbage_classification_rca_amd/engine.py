@@ -23,6 +23,7 @@ import torch
 
 from . import lib as L
 from . import spec as S
+from .conv_engine import ConvEncoder, CONV_MODELS
 
 import os
 
@@ -136,29 +137,32 @@ class MMRCAEngine:
 
     def __init__(self, text_model: str, image_model: str, n_classes: int = 4, reverse: bool = True, mode: int = 0,
                  dtype: torch.dtype = torch.bfloat16, device="cuda", gemm_impl: int = L.IMPL_AUTO,
-                 attn_impl: int = L.IMPL_AUTO):
+                 attn_impl: int = L.IMPL_AUTO, image_size: int = 224):
         L.load()
         if text_model not in S.TEXT_SPECS:
             raise ValueError(f"Wrong text model: {text_model}")
-        if image_model not in S.VISION_SPECS:
-            raise NotImplementedError(
-                f"image model {image_model!r}: only the ViT backbones {sorted(S.VISION_SPECS)} are HIP kernels so far; "
-                "EfficientNetV2 / ShuffleNetV2 are SURVEY.md section 8 f3 (next)")
-        self.ts, self.vs = S.TEXT_SPECS[text_model], S.VISION_SPECS[image_model]
+        if image_model not in S.VISION_SPECS and image_model not in CONV_MODELS:
+            raise ValueError(f"Wrong image model: {image_model}")
+        self.ts = S.TEXT_SPECS[text_model]
+        self.vs = S.VISION_SPECS.get(image_model)
         self.n_classes, self.reverse, self.mode = n_classes, bool(reverse), int(mode)
         self.dtype, self.device = dtype, torch.device(device)
         self.dt = L.dtype_code(dtype)
         self.gemm_impl, self.attn_impl = gemm_impl, attn_impl
-        self.d_txt, self.d_img = self.ts.dim, self.vs.dim
+        # conv image backbones (EfficientNetV2-M/L, ShuffleNetV2): conv_engine.ConvEncoder over csrc/conv.hip
+        self.conv = ConvEncoder(image_model, self, image_size) if self.vs is None else None
+        self.d_txt, self.d_img = self.ts.dim, (self.vs.dim if self.vs is not None else self.conv.dim)
         ents = [("text_model." + k, s) for k, s in S.text_params(self.ts)]
-        ents += [("image_model." + k, s) for k, s in S.vision_params(self.vs)]
+        vis_ents = S.vision_params(self.vs) if self.vs is not None else self.conv.param_entries()
+        ents += [("image_model." + k, s) for k, s in vis_ents]
         self.head_keys = S.head_used_params(self.d_img, self.d_txt, n_classes, mode == 1, mode == 2)
         ents += self.head_keys
         self.arena = Arena(ents, self.device, with_lp=(dtype == torch.bfloat16))
         self.param_keys = [k for k, _ in ents]
         self.text_span = self.arena.span(ents[0][0], "text_model." + S.text_params(self.ts)[-1][0])
-        self.image_span = self.arena.span("image_model." + S.vision_params(self.vs)[0][0],
-                                          "image_model." + S.vision_params(self.vs)[-1][0])
+        self.image_span = self.arena.span("image_model." + vis_ents[0][0], "image_model." + vis_ents[-1][0])
+        if self.conv is not None:
+            self.conv.init_buffers(self.device)
         self.head_span = self.arena.span(self.head_keys[0][0], self.head_keys[-1][0])
         self._bufs: Dict[Tuple, torch.Tensor] = {}
         self._saved = None
@@ -259,7 +263,16 @@ class MMRCAEngine:
                 is_head = not k.startswith(("text_model.", "image_model."))
                 lname = k.lower()
                 is_norm = ("norm" in lname) or (".ln_" in lname) or lname.endswith(("encoder.ln.weight", "encoder.ln.bias"))
-                if is_norm:
+                if self.conv is not None and k.startswith("image_model."):
+                    # torchvision's init: conv kaiming_normal_(fan_out), BatchNorm (1, 0), squeeze-excitation biases 0
+                    if v.dim() == 4:
+                        fan_out = v.shape[0] * v.shape[2] * v.shape[3]
+                        v.copy_(torch.randn(v.shape, generator=g) * math.sqrt(2.0 / fan_out))
+                    elif leaf == "weight":
+                        v.fill_(1.0)
+                    else:
+                        v.zero_()
+                elif is_norm:
                     v.fill_(1.0 if leaf == "weight" else 0.0)
                 elif is_head:
                     if v.dim() == 2:
@@ -307,6 +320,8 @@ class MMRCAEngine:
     def release_buffers(self):
         self._bufs.clear()
         self._saved = None
+        if self.conv is not None:
+            self.conv.release()
 
     # ------------------------------------------------------------------ op helpers
     def _lin_fwd(self, x, wkey, bkey, out, M, N, K, act=L.ACT_NONE, preact=None, addend=None, wnumel=None):
@@ -714,8 +729,13 @@ class MMRCAEngine:
         self._ready(f"image_layer_{i}")
 
     # ------------------------------------------------------------------ whole model
+    def _image_forward(self, images, save, bn_train, seed):
+        if self.conv is not None:
+            return self.conv.forward(images, save, bn_train, seed), None
+        return self._vision_forward(images, save)
+
     def forward(self, ids, mask, images, drop_p: float = 0.0, seed: int = 0, save: bool = True, enc_drop_p: float = 0.0,
-                text_pack: Optional[TextPack] = None):
+                text_pack: Optional[TextPack] = None, bn_train: bool = False):
         """ids/mask int64 [B,S] and images fp32 [B,3,H,W] in HBM -> logits fp32 [B, n_classes].
         text_pack (``make_text_pack`` of the same batch's host-side mask): run the text encoder on the live tokens only."""
         for t, nm in ((ids, "input ids"), (mask, "attention mask"), (images, "images")):
@@ -728,17 +748,24 @@ class MMRCAEngine:
             self._text_stream.wait_stream(main)
             with torch.cuda.stream(self._text_stream):
                 cls, tsv = self._text_forward(ids, mask, save, enc_drop_p, int(seed), text_pack)
-            feat, vsv = self._vision_forward(images, save)
+            feat, vsv = self._image_forward(images, save, bn_train, int(seed))
             main.wait_stream(self._text_stream)
             cls.record_stream(main)
         else:
             cls, tsv = self._text_forward(ids, mask, save, enc_drop_p, int(seed), text_pack)
-            feat, vsv = self._vision_forward(images, save)
+            feat, vsv = self._image_forward(images, save, bn_train, int(seed))
         logits = torch.empty(B, self.n_classes, dtype=torch.float32, device=self.device)
         L.head_fwd(feat, cls, self._head_w, logits, B, self.d_img, self.d_txt, self.n_classes, self.reverse, self.mode,
                    float(drop_p), int(seed), self.dt)
         self._saved = dict(B=B, cls=cls, feat=feat, text=tsv, vision=vsv, drop_p=float(drop_p), seed=int(seed), full=save)
         return logits
+
+    def _image_backward(self, dimg, vsv):
+        if self.conv is not None:
+            self.conv.backward(dimg)
+            self._ready("image_emb", flush=True)
+        else:
+            self._vision_backward(dimg, vsv)
 
     def backward(self, dlogits, train_text: bool = True, train_image: bool = True):
         sv = self._saved
@@ -761,7 +788,7 @@ class MMRCAEngine:
             dtxt.record_stream(self._text_stream)
             if train_image:
                 self._side = self._side_v
-                self._vision_backward(dimg, sv["vision"])
+                self._image_backward(dimg, sv["vision"])
             with torch.cuda.stream(self._text_stream):
                 self._side = self._side_t
                 self._text_backward(dtxt, sv["text"])
@@ -769,7 +796,7 @@ class MMRCAEngine:
         else:
             if train_image:
                 self._side = self._side_v
-                self._vision_backward(dimg, sv["vision"])
+                self._image_backward(dimg, sv["vision"])
             if train_text:
                 self._side = self._side_t
                 self._text_backward(dtxt, sv["text"])

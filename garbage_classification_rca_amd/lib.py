@@ -51,6 +51,24 @@ _SIGS = {
     "mmrca_gemm": [_vp] * 6 + [_i64] * 6 + [_i32] * 6 + [_vp],
     "mmrca_gemm_colsum": [_vp] * 7 + [_i64] * 6 + [_i32] * 5 + [_vp],
     "mmrca_gemm_splitk": [_vp] * 4 + [_i64] * 7 + [_i32] * 2 + [_vp],
+    "mmrca_nchw_to_rows": [_vp, _vp, _i32, _i32, _i32, _i32, _i32, _vp],
+    "mmrca_im2row3x3": [_vp, _vp, _i32, _i32, _i32, _i32, _i32, _i64, _i32, _vp],
+    "mmrca_col2im3x3": [_vp, _vp, _i32, _i32, _i32, _i32, _i32, _i64, _i32, _vp],
+    "mmrca_dwconv3x3_fwd": [_vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _vp],
+    "mmrca_dwconv3x3_bwd": [_vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _vp],
+    "mmrca_bn_stats": [_vp, _vp, _vp, _vp, _vp, _i64, _i32, _i64, _f32, _f32, _i32, _i32, _vp],
+    "mmrca_bn_act_fwd": [_vp] * 6 + [_i64, _i32, _i32, _i32, _vp],
+    "mmrca_bn_act_bwd": [_vp] * 10 + [_i64, _i32, _i32, _i32, _i32, _vp],
+    "mmrca_rowpool_mean": [_vp, _vp, _i32, _i32, _i32, _i32, _vp],
+    "mmrca_rowpool_mean_bwd": [_vp, _vp, _i32, _i32, _i32, _i32, _i32, _vp],
+    "mmrca_se_scale_fwd": [_vp, _vp, _vp, _i32, _i32, _i32, _i32, _vp],
+    "mmrca_se_scale_bwd": [_vp] * 5 + [_i32, _i32, _i32, _i32, _vp],
+    "mmrca_bias_act_fwd": [_vp, _vp, _vp, _i64, _i32, _i32, _i32, _vp],
+    "mmrca_bias_act_bwd": [_vp] * 5 + [_i64, _i32, _i32, _i32, _vp],
+    "mmrca_residual_add": [_vp, _vp, _vp, _vp, _i32, _i64, _i32, _vp],
+    "mmrca_maxpool3x3s2_fwd": [_vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _vp],
+    "mmrca_maxpool3x3s2_bwd": [_vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _vp],
+    "mmrca_channel_gather": [_vp, _vp, _vp, _i64, _i32, _i32, _i64, _i32, _i32, _vp],
     "mmrca_image_preprocess": [_vp, _vp, _vp, _i32, _i32, _i32, _vp, _vp, _vp],
     "mmrca_colsum_accum": [_vp, _vp, _i64, _i64, _i64, _i32, _vp],
     "mmrca_gelu_bwd": [_vp, _vp, _vp, _i64, _i32, _vp],
@@ -313,3 +331,91 @@ def adamw_step(p, g, m, v, lp, n, lr, b1, b2, eps, wd, step, grad_scale=1.0):
 def cast_f32_to_bf16(src, dst, n):
     _dev(src, "cast src")
     _check(load().mmrca_cast_f32_to_bf16(ptr(src), ptr(dst), n, stream_ptr()), "mmrca_cast_f32_to_bf16")
+
+
+# ---------------------------------------------------------------------------------------------------------
+# conv-backbone kernels (csrc/conv.hip); thin wrappers, raw pointers in
+# ---------------------------------------------------------------------------------------------------------
+CONV_NONE, CONV_SILU, CONV_RELU, CONV_SIGMOID = 0, 1, 2, 3
+
+
+def _c(name, *args):
+    _check(getattr(load(), name)(*args, stream_ptr()), name)
+
+
+def nchw_to_rows(images, x, B, C, H, W, dtype):
+    _dev(images, "nchw_to_rows images")
+    _c("mmrca_nchw_to_rows", ptr(images), ptr(x), B, C, H, W, dtype)
+
+
+def im2row3x3(x, col, B, H, W, C, stride, ldk, dtype):
+    _dev(x, "im2row x")
+    _c("mmrca_im2row3x3", ptr(x), ptr(col), B, H, W, C, stride, ldk, dtype)
+
+
+def col2im3x3(dcol, dx, B, H, W, C, stride, ldk, dtype):
+    _c("mmrca_col2im3x3", ptr(dcol), ptr(dx), B, H, W, C, stride, ldk, dtype)
+
+
+def dwconv3x3_fwd(x, w, y, B, H, W, C, stride, dtype):
+    _dev(x, "dwconv x")
+    _c("mmrca_dwconv3x3_fwd", ptr(x), ptr(w), ptr(y), B, H, W, C, stride, dtype)
+
+
+def dwconv3x3_bwd(dy, x, w, dx, dw, B, H, W, C, stride, dtype):
+    _c("mmrca_dwconv3x3_bwd", ptr(dy), ptr(x), ptr(w), ptr(dx), ptr(dw), B, H, W, C, stride, dtype)
+
+
+def bn_stats(x, mean, rstd, running_mean, running_var, rows, C, ld, eps, momentum, train, dtype):
+    _c("mmrca_bn_stats", ptr(x), ptr(mean), ptr(rstd), ptr(running_mean), ptr(running_var), rows, C, ld, eps, momentum, int(train), dtype)
+
+
+def bn_act_fwd(x, mean, rstd, gamma, beta, y, rows, C, act, dtype):
+    _dev(x, "bn x")
+    _c("mmrca_bn_act_fwd", ptr(x), ptr(mean), ptr(rstd), ptr(gamma), ptr(beta), ptr(y), rows, C, act, dtype)
+
+
+def bn_act_bwd(dy, x, mean, rstd, gamma, beta, dx, dgamma, dbeta, scratch, rows, C, act, train, dtype):
+    _c("mmrca_bn_act_bwd", ptr(dy), ptr(x), ptr(mean), ptr(rstd), ptr(gamma), ptr(beta), ptr(dx), ptr(dgamma), ptr(dbeta), ptr(scratch),
+       rows, C, act, int(train), dtype)
+
+
+def rowpool_mean(x, out, B, HW, C, dtype):
+    _dev(x, "rowpool x")
+    _c("mmrca_rowpool_mean", ptr(x), ptr(out), B, HW, C, dtype)
+
+
+def rowpool_mean_bwd(dpool, dx, B, HW, C, accumulate, dtype):
+    _c("mmrca_rowpool_mean_bwd", ptr(dpool), ptr(dx), B, HW, C, int(accumulate), dtype)
+
+
+def se_scale_fwd(x, s, y, B, HW, C, dtype):
+    _c("mmrca_se_scale_fwd", ptr(x), ptr(s), ptr(y), B, HW, C, dtype)
+
+
+def se_scale_bwd(dy, x, s, dx, ds, B, HW, C, dtype):
+    _c("mmrca_se_scale_bwd", ptr(dy), ptr(x), ptr(s), ptr(dx), ptr(ds), B, HW, C, dtype)
+
+
+def bias_act_fwd(x, bias, y, rows, C, act, dtype):
+    _c("mmrca_bias_act_fwd", ptr(x), ptr(bias), ptr(y), rows, C, act, dtype)
+
+
+def bias_act_bwd(dy, x, bias, dx, dbias, rows, C, act, dtype):
+    _c("mmrca_bias_act_bwd", ptr(dy), ptr(x), ptr(bias), ptr(dx), ptr(dbias), rows, C, act, dtype)
+
+
+def residual_add(a, branch, rowscale, out, B, per_sample, dtype):
+    _c("mmrca_residual_add", ptr(a), ptr(branch), ptr(rowscale), ptr(out), B, per_sample, dtype)
+
+
+def maxpool3x3s2_fwd(x, y, argmax, B, H, W, C, dtype):
+    _c("mmrca_maxpool3x3s2_fwd", ptr(x), ptr(y), ptr(argmax), B, H, W, C, dtype)
+
+
+def maxpool3x3s2_bwd(dy, argmax, dx, B, H, W, C, dtype):
+    _c("mmrca_maxpool3x3s2_bwd", ptr(dy), ptr(argmax), ptr(dx), B, H, W, C, dtype)
+
+
+def channel_gather(inp, cmap, out, rows, Cin, Cout, ld_out, col0, dtype):
+    _c("mmrca_channel_gather", ptr(inp), ptr(cmap), ptr(out), rows, Cin, Cout, ld_out, col0, dtype)

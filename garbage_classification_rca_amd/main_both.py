@@ -128,10 +128,12 @@ def main(argv=None):
         torch.manual_seed(args.seed); np.random.seed(args.seed)
     device = torch.device("cuda", local)
     torch.cuda.set_device(device)
-    if args.image_model in ("b4", "EffNetv2-Medium", "eff_v2_medium"):
-        print("Image model {!r}: the reference forces EfficientNetV2-M here (main_both.py:259); its conv backbone is not a "
-              "HIP kernel yet (SURVEY.md section 8 f3) -- use --image_model=transformer_B16|transformer_L16".format(args.image_model))
-        sys.exit(1)
+    from .conv_engine import CONV_MODELS
+    from . import spec as S
+    if args.image_model not in S.VISION_SPECS and args.image_model not in CONV_MODELS:
+        # the reference ignores --image_model and always builds EfficientNetV2-M (main_both.py:259, multimodal_model.py:188)
+        print("Image model {!r}: using EffNetv2-Medium, as the reference does for every value of this flag".format(args.image_model))
+        args.image_model = "EffNetv2-Medium"
     print("Text Model: {}".format(args.text_model))
     print("Image Model: {}".format(args.image_model))
     _batch_size, _batch_size_FT = args.batch_size, args.batch_size_FT
@@ -141,7 +143,7 @@ def main(argv=None):
     global_model = MM_RCA(_num_classes, args.model_dropout, args.image_text_dropout, args.image_prob_dropout,
                           args.num_neurons_FC, args.text_model, _batch_size, args.reverse, args.features_only,
                           args.cross_attention_only, image_model_name=args.image_model,
-                          dtype=torch.bfloat16 if args.dtype == "bf16" else torch.float32, device=device)
+                          dtype=torch.bfloat16 if args.dtype == "bf16" else torch.float32, device=device, image_size=args.image_size)
     print("Num total parameters of the model: {}".format(count_parameters(global_model)))
     wandb = _wandb() if is_main else _NoWandb()
     wandb.init(project="Garbage Classification Both - MI355X", config=dict(args.__dict__))

@@ -40,14 +40,21 @@ class ParamTree(torch.nn.Module):
     def __init__(self):
         super().__init__()
 
-    def add(self, dotted: str, p: torch.nn.Parameter):
+    def _node(self, parts):
         node = self
-        parts = dotted.split(".")
         for name in parts[:-1]:
             if name not in node._modules:
                 node.add_module(name, ParamTree())
             node = node._modules[name]
-        node.register_parameter(parts[-1], p)
+        return node
+
+    def add(self, dotted: str, p: torch.nn.Parameter):
+        parts = dotted.split(".")
+        self._node(parts).register_parameter(parts[-1], p)
+
+    def add_buffer(self, dotted: str, t: torch.Tensor):
+        parts = dotted.split(".")
+        self._node(parts).register_buffer(parts[-1], t)
 
 
 class HashingTokenizer:
@@ -80,7 +87,7 @@ class _EngineFunction(torch.autograd.Function):
     @staticmethod
     def forward(ctx, anchor, module, ids, mask, images, drop_p, seed, save, enc_p):
         ctx.module = module
-        return module.engine.forward(ids, mask, images, drop_p, seed, save=save, enc_drop_p=enc_p)
+        return module.engine.forward(ids, mask, images, drop_p, seed, save=save, enc_drop_p=enc_p, bn_train=module.training)
 
     @staticmethod
     def backward(ctx, dlogits):
@@ -94,7 +101,7 @@ class EffV2MediumAndDistilbertGated(torch.nn.Module):
     def __init__(self, n_classes, drop_ratio, image_or_text_dropout_chance, img_prob_dropout, num_neurons_fc,
                  text_model_name, batch_size, reverse, features_only, cross_attention_only,
                  image_model_name: str = "transformer_B16", dtype: torch.dtype = torch.bfloat16,
-                 device="cuda", init_seed: int = 0, build_unused_parameters: bool = True):
+                 device="cuda", init_seed: int = 0, build_unused_parameters: bool = True, image_size: Optional[int] = None):
         super().__init__()
         self.text_model_name = text_model_name
         self.image_model_name = image_model_name
@@ -105,7 +112,14 @@ class EffV2MediumAndDistilbertGated(torch.nn.Module):
             print("Wrong text model:", text_model_name)          # multimodal_model.py:184-186
             sys.exit(1)
         mode = 1 if self.features_only else (2 if self.cross_attention_only else 0)
-        self.engine = MMRCAEngine(text_model_name, image_model_name, n_classes, reverse, mode, dtype, device)
+        from .conv_engine import CONV_MODELS
+        if image_model_name not in S.VISION_SPECS and image_model_name not in CONV_MODELS:
+            print("Wrong image model:", image_model_name)
+            sys.exit(1)
+        # input size: ViT 224 (fixed by its position table); the conv backbones take any size -- the reference feeds its
+        # EfficientNetV2-M 480x480 (multimodal_model.py:407-408), BASELINE.json's synthetic workloads use 224x224
+        self.image_size = 224 if image_model_name in S.VISION_SPECS else int(image_size or (480 if image_model_name in ("eff_v2_medium", "EffNetv2-Medium") else 224))
+        self.engine = MMRCAEngine(text_model_name, image_model_name, n_classes, reverse, mode, dtype, device, image_size=self.image_size)
         self.engine.init_parameters(init_seed)
         self.drop_ratio = float(drop_ratio)
         # train-mode dropout inside the HF text encoders (DistilBertConfig.dropout = attention_dropout = 0.1; torchvision's
@@ -137,6 +151,9 @@ class EffV2MediumAndDistilbertGated(torch.nn.Module):
             else:
                 self._add_head_param(k, p)
         self._attach_grads()
+        if self.engine.conv is not None:       # BatchNorm running statistics: buffers with torchvision's names
+            for k, t in self.engine.conv.buffers.items():
+                self.image_model.add_buffer(k, t)
         if build_unused_parameters:
             # present-but-unused keys of the reference constructor (:199-328): kept for checkpoint interchange
             g = torch.Generator().manual_seed(init_seed + 1)
@@ -178,7 +195,7 @@ class EffV2MediumAndDistilbertGated(torch.nn.Module):
 
     def get_image_size(self):
         """(W, H) the image backbone expects (reference: (480, 480) for EfficientNetV2-M, :407-408)."""
-        return (self.engine.vs.image, self.engine.vs.image)
+        return (self.image_size, self.image_size)
 
     def get_max_token_size(self):
         """multimodal_model.py:410-418: the text backbone's max_position_embeddings."""
@@ -232,7 +249,17 @@ class EffV2MediumAndDistilbertGated(torch.nn.Module):
                 strict = False
         r = super().load_state_dict(state_dict, strict=strict, **kw)
         self.engine.arena.lp_valid = False
+        conv = self.engine.conv
+        if conv is not None:                   # num_batches_tracked continues from the loaded count
+            for k, t in conv.buffers.items():
+                if k.endswith("num_batches_tracked"):
+                    conv._nbt_base[k] = int(t) - conv.n_train_forwards
         return r
+
+    def state_dict(self, *a, **kw):
+        if self.engine.conv is not None:
+            self.engine.conv.sync_buffers()
+        return super().state_dict(*a, **kw)
 
     def _apply(self, fn, *a, **kw):
         # parameters live in the engine's arenas; .to()/.cuda()/.cpu() would detach them (save_model_weights'

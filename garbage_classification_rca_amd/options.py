@@ -54,6 +54,8 @@ BUILD_FLAGS = [
     ("synthetic", _INT, 0, ">0: train on this many synthetic pairs instead of a folder"),
     ("num_workers", _INT, 16, "DataLoader workers"),
     ("seed", _INT, None, "seed torch / numpy"),
+    ("image_size", _INT, None, "input side of the conv image backbones (default: 480 for EfficientNetV2-M as in the reference, else 224)"),
+    ("gpu_preprocess", _BOOL, True, "image pipeline (pad / resize / augment / normalise) as one GPU launch per batch instead of per-sample CPU transforms"),
 ]
 
 

@@ -57,8 +57,7 @@ VISION_SPECS: Dict[str, VisionSpec] = {
     "transformer_L16": VisionSpec("transformer_L16", 224, 16, 1024, 16, 4096, 24, 1e-6),
 }
 
-# feature widths of the conv backbones named by --image_model (SURVEY.md section 8 preamble);
-# they are not HIP kernels yet (section 8 f3) and are listed so that the head can be sized for them.
+# feature widths of the conv backbones named by --image_model (SURVEY.md section 8 preamble); built in conv_engine.py
 CONV_FEATURE_DIMS = {"eff_v2_medium": 1280, "EffNetv2-Medium": 1280, "eff_v2_large": 1280, "shuffle_net": 2048}
 
 

@@ -64,7 +64,7 @@ def hip_train_step(model, ids, mask, images, labels, criterion: FusedCrossEntrop
     model._fwd_count += 1
     logits = eng.forward(model._input_ids, model._attention_mask, model._images,
                          model.drop_ratio if model.training else 0.0, model._drop_seed + model._fwd_count, save=(tt or ti),
-                         enc_drop_p=(model.enc_dropout if model.training else 0.0), text_pack=text_pack)
+                         enc_drop_p=(model.enc_dropout if model.training else 0.0), text_pack=text_pack, bn_train=model.training)
     loss, dlogits = criterion(logits, labels)
     if grad_sync is not None:
         grad_sync.enabled = bool(do_step)

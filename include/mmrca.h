@@ -86,6 +86,50 @@ int mmrca_gelu_bwd(const void* dG, const void* H, void* dH, int64_t n, int dtype
 int mmrca_gelu_bwd_colsum(const void* dG, const void* H, void* dH, float* db, int64_t M, int64_t N, int64_t ld,
                           int dtype, void* stream);
 
+/* ---- conv image backbones: torchvision efficientnet_v2_m / _l as instantiated at
+ * CVPR_code/multimodal_model.py:11-36, 113-126 and shufflenet_v2_x2_0 (models.py:261-278), on NHWC activations stored as
+ * row-major [B*H*W, C] matrices.  1x1 convolutions are mmrca_gemm on those rows; a full 3x3 convolution is
+ * mmrca_im2row3x3 + mmrca_gemm (patch row = col[c*9 + ky*3 + kx], the flattening of torchvision's [Cout, Cin, 3, 3] weight).
+ * CONV activations: 0 none, 1 SiLU, 2 ReLU, 3 sigmoid. ------------------------------------------------------------- */
+/* images [B, C, H, W] fp32 (the tensor main_both.py:100-103 moves to the device) -> rows [B*H*W, C] in `dtype` */
+int mmrca_nchw_to_rows(const float* images, void* x, int B, int C, int H, int W, int dtype, void* stream);
+/* 3x3 patches, padding 1, stride 1 | 2: col[B*Ho*Wo, ldk] (ldk >= 9C), and the gather that sums a patch gradient back */
+int mmrca_im2row3x3(const void* x, void* col, int B, int H, int W, int C, int stride, int64_t ldk, int dtype, void* stream);
+int mmrca_col2im3x3(const void* dcol, void* dx, int B, int H, int W, int C, int stride, int64_t ldk, int dtype, void* stream);
+/* depthwise 3x3 (torch Conv2d(C, C, 3, stride, 1, groups=C, bias=False)); w [C, 9] in `dtype`; dw fp32 [C, 9] +=; dx / dw may be NULL */
+int mmrca_dwconv3x3_fwd(const void* x, const void* w, void* y, int B, int H, int W, int C, int stride, int dtype, void* stream);
+int mmrca_dwconv3x3_bwd(const void* dy, const void* x, const void* w, void* dx, float* dw, int B, int H, int W, int C, int stride,
+                        int dtype, void* stream);
+/* torch.nn.BatchNorm2d over the rows of x [rows, C] (ld): train != 0 -> batch mean / biased variance into mean, rstd and, with
+ * momentum > 0, the running statistics update (unbiased variance); train == 0 -> mean / rstd from the running statistics */
+int mmrca_bn_stats(const void* x, float* mean, float* rstd, float* running_mean, float* running_var, int64_t rows, int C,
+                   int64_t ld, float eps, float momentum, int train, int dtype, void* stream);
+int mmrca_bn_act_fwd(const void* x, const float* mean, const float* rstd, const void* gamma, const void* beta, void* y,
+                     int64_t rows, int C, int act, int dtype, void* stream);
+/* backward of y = act(BN(x)); scratch = fp32 [2C]; dx / dgamma+dbeta (fp32, +=) may be NULL; train as in the forward */
+int mmrca_bn_act_bwd(const void* dy, const void* x, const float* mean, const float* rstd, const void* gamma, const void* beta,
+                     void* dx, float* dgamma, float* dbeta, float* scratch, int64_t rows, int C, int act, int train, int dtype,
+                     void* stream);
+/* AdaptiveAvgPool2d(1) / x.mean([2,3]) over the HW rows of each sample, and its backward (dx (+)= dpool / HW) */
+int mmrca_rowpool_mean(const void* x, void* out, int B, int HW, int C, int dtype, void* stream);
+int mmrca_rowpool_mean_bwd(const void* dpool, void* dx, int B, int HW, int C, int accumulate, int dtype, void* stream);
+/* squeeze-excitation scaling y = x * s[b, c] and its backward (dx = dy * s, ds[b, c] = sum_rows dy * x) */
+int mmrca_se_scale_fwd(const void* x, const void* s, void* y, int B, int HW, int C, int dtype, void* stream);
+int mmrca_se_scale_bwd(const void* dy, const void* x, const void* s, void* dx, void* ds, int B, int HW, int C, int dtype, void* stream);
+/* y = act(x + bias[c]) on small [rows, C] matrices (the biased 1x1 convolutions of squeeze-excitation) and its backward */
+int mmrca_bias_act_fwd(const void* x, const void* bias, void* y, int64_t rows, int C, int act, int dtype, void* stream);
+int mmrca_bias_act_bwd(const void* dy, const void* x, const void* bias, void* dx, float* dbias, int64_t rows, int C, int act,
+                       int dtype, void* stream);
+/* out = a + branch * rowscale[sample] (residual + torchvision "row" stochastic depth); a NULL -> scaled branch alone */
+int mmrca_residual_add(const void* a, const void* branch, const float* rowscale, void* out, int B, int64_t per_sample, int dtype,
+                       void* stream);
+/* MaxPool2d(3, 2, 1) with the argmax tap (uint8) kept for the backward */
+int mmrca_maxpool3x3s2_fwd(const void* x, void* y, void* argmax, int B, int H, int W, int C, int dtype, void* stream);
+int mmrca_maxpool3x3s2_bwd(const void* dy, const void* argmax, void* dx, int B, int H, int W, int C, int dtype, void* stream);
+/* out[r, col0 + j] = in[r, map[j]] (channel split / concat / shuffle and their backward) */
+int mmrca_channel_gather(const void* in, const int* map, void* out, int64_t rows, int Cin, int Cout, int64_t ld_out, int col0,
+                         int dtype, void* stream);
+
 /* K3. Multi-head attention over a fused QKV buffer [rows, 3*H*dh] (q | k | v column blocks; head h at
  * columns h*dh).  out[rows, H*dh].  key_mask (optional): int32 per token row, 0 = masked key; a query row whose
  * keys are all masked yields zeros (torch SDPA semantics used by transformers 5.x).  lse: fp32 [B,H,S].

@@ -317,7 +317,17 @@ def cross_entropy(logits, labels, weight: Optional[torch.Tensor] = None, label_s
 
 def build_oracle(text_model: str, image_model: str, reverse=True, features_only=False, cross_attention_only=False,
                  n_classes=4, drop_ratio=0.6, image_text_dropout=0.0, image_prob_dropout=0.7, enc_dropout=0.1):
-    ts, vs = S.TEXT_SPECS[text_model], S.VISION_SPECS[image_model]
+    ts = S.TEXT_SPECS[text_model]
+    if image_model in S.VISION_SPECS:
+        vs = S.VISION_SPECS[image_model]
+        img, d_img = OracleViT(vs), vs.dim
+    else:       # conv backbones: oracle/conv_models.py (restated torchvision architectures)
+        from oracle import conv_models as CM
+        name = {"EffNetv2-Medium": "eff_v2_medium"}.get(image_model, image_model)
+        img = CM.build_conv_oracle(name)
+        if hasattr(img, "pooled_only"):
+            img.pooled_only = True
+        d_img = 2048 if name == "shuffle_net" else 1280
     return OracleMMRCA(n_classes, drop_ratio, image_text_dropout, image_prob_dropout,
-                       OracleTextEncoder(ts, enc_dropout), OracleViT(vs), vs.dim, ts.dim,
+                       OracleTextEncoder(ts, enc_dropout), img, d_img, ts.dim,
                        reverse, features_only, cross_attention_only)

@@ -1,0 +1,324 @@
+"""Conv image backbones (EfficientNetV2-M/L, ShuffleNetV2 x2.0) on the HIP path: every csrc/conv.hip kernel against the
+torch op it replaces, and the whole backbones (forward features, every parameter gradient, BatchNorm running statistics)
+against the oracle (oracle/conv_models.py: torchvision architectures restated, "torchvision-unpinned").  Needs an MI355X."""
+import os
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+from garbage_classification_rca_amd import lib as L                     # noqa: E402
+from garbage_classification_rca_amd.engine import MMRCAEngine           # noqa: E402
+from garbage_classification_rca_amd.conv_engine import ConvEncoder       # noqa: E402
+from oracle import conv_models as CM                                     # noqa: E402
+from oracle import model as O                                            # noqa: E402
+
+
+@pytest.fixture(scope="module", autouse=True)
+def _gpu():
+    assert torch.cuda.is_available()
+    L.load()
+    torch.manual_seed(0)
+
+
+def rel(a, b):
+    a, b = torch.as_tensor(a).double().cpu(), torch.as_tensor(b).double().cpu()
+    return ((a - b).abs().max() / (b.abs().max() + 1e-30)).item()
+
+
+def rows(t):      # NCHW -> [B*H*W, C]
+    return t.permute(0, 2, 3, 1).reshape(-1, t.shape[1]).contiguous()
+
+
+def nchw(r, B, H, W):
+    return r.view(B, H, W, -1).permute(0, 3, 1, 2).contiguous()
+
+
+TOL = {torch.float32: 1e-5, torch.bfloat16: 2e-2}
+
+
+@pytest.mark.parametrize("dt", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("stride", [1, 2])
+def test_im2row_gemm_is_conv3x3_and_col2im_is_its_input_gradient(dt, stride):
+    B, C, H, W, Co = 2, 10, 9, 7, 6
+    g = torch.Generator().manual_seed(1)
+    x = torch.randn(B, C, H, W, generator=g).to(dt).float()
+    w = (torch.randn(Co, C, 3, 3, generator=g) * 0.2).to(dt).float()
+    xr = rows(x).cuda().to(dt)
+    Ho, Wo = (H - 1) // stride + 1, (W - 1) // stride + 1
+    K = 9 * C
+    col = torch.empty(B * Ho * Wo, K, device="cuda", dtype=dt)
+    L.im2row3x3(xr, col, B, H, W, C, stride, K, L.dtype_code(dt))
+    y = col.float().cpu() @ w.view(Co, -1).t()
+    ref = F.conv2d(x, w, None, stride, 1)
+    assert rel(nchw(y, B, Ho, Wo), ref) < TOL[dt]
+    dcol = torch.randn(B * Ho * Wo, K, generator=g).to(dt)
+    dx = torch.empty(B * H * W, C, device="cuda", dtype=dt)
+    L.col2im3x3(dcol.cuda(), dx, B, H, W, C, stride, K, L.dtype_code(dt))
+    # reference: fold the patch gradient back with autograd of unfold
+    xr2 = x.clone().requires_grad_(True)
+    u = F.unfold(xr2, 3, padding=1, stride=stride)                      # [B, C*9, L] channel-major like the kernel
+    (u.transpose(1, 2).reshape(-1, K) * dcol.float()).sum().backward()
+    assert rel(nchw(dx.float().cpu(), B, H, W), xr2.grad) < TOL[dt]
+
+
+@pytest.mark.parametrize("dt", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("stride", [1, 2])
+def test_depthwise_conv_fwd_bwd(dt, stride):
+    B, C, H, W = 3, 70, 8, 11
+    g = torch.Generator().manual_seed(2)
+    x = torch.randn(B, C, H, W, generator=g).to(dt).float().requires_grad_(True)
+    w = (torch.randn(C, 1, 3, 3, generator=g) * 0.3).to(dt).float().requires_grad_(True)
+    ref = F.conv2d(x, w, None, stride, 1, groups=C)
+    Ho, Wo = ref.shape[2:]
+    xd, wd = rows(x.detach()).cuda().to(dt), w.detach().view(C, 9).cuda().to(dt)
+    y = torch.empty(B * Ho * Wo, C, device="cuda", dtype=dt)
+    L.dwconv3x3_fwd(xd, wd, y, B, H, W, C, stride, L.dtype_code(dt))
+    assert rel(nchw(y.float().cpu(), B, Ho, Wo), ref.detach()) < TOL[dt]
+    dy = torch.randn(ref.shape, generator=g).to(dt).float()
+    ref.backward(dy)
+    dx = torch.empty(B * H * W, C, device="cuda", dtype=dt)
+    dw = torch.zeros(C, 9, device="cuda")
+    L.dwconv3x3_bwd(rows(dy).cuda().to(dt), xd, wd, dx, dw, B, H, W, C, stride, L.dtype_code(dt))
+    assert rel(nchw(dx.float().cpu(), B, H, W), x.grad) < TOL[dt]
+    assert rel(dw.cpu().view(C, 1, 3, 3), w.grad) < (1e-4 if dt == torch.float32 else 2e-2)
+
+
+@pytest.mark.parametrize("dt", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("act", [L.CONV_NONE, L.CONV_SILU, L.CONV_RELU])
+@pytest.mark.parametrize("train", [True, False])
+def test_batchnorm_act_fwd_bwd_and_running_stats(dt, act, train):
+    R, C, eps = 1000, 70, 1e-3
+    g = torch.Generator().manual_seed(3)
+    x = (torch.randn(R, C, generator=g) * 2 + 0.5).to(dt).float().requires_grad_(True)
+    gam = (torch.rand(C, generator=g) + 0.5).to(dt).float().requires_grad_(True)
+    bet = (torch.randn(C, generator=g) * 0.3).to(dt).float().requires_grad_(True)
+    rm0, rv0 = torch.randn(C, generator=g) * 0.1, torch.rand(C, generator=g) + 0.5
+    bn = torch.nn.BatchNorm1d(C, eps=eps)
+    with torch.no_grad():
+        bn.running_mean.copy_(rm0); bn.running_var.copy_(rv0)
+    bn.train(train)
+    u = F.batch_norm(x, bn.running_mean, bn.running_var, gam, bet, train, 0.1, eps)
+    ref = {L.CONV_NONE: u, L.CONV_SILU: F.silu(u), L.CONV_RELU: F.relu(u)}[act]
+    xd = x.detach().cuda().to(dt)
+    mean, rstd = torch.empty(C, device="cuda"), torch.empty(C, device="cuda")
+    rm, rv = rm0.clone().cuda(), rv0.clone().cuda()
+    L.bn_stats(xd, mean, rstd, rm, rv, R, C, C, eps, 0.1 if train else 0.0, train, L.dtype_code(dt))
+    y = torch.empty(R, C, device="cuda", dtype=dt)
+    gd, bd = gam.detach().cuda().to(dt), bet.detach().cuda().to(dt)
+    L.bn_act_fwd(xd, mean, rstd, gd, bd, y, R, C, act, L.dtype_code(dt))
+    assert rel(y, ref.detach()) < TOL[dt]
+    if train:
+        assert rel(rm, bn.running_mean) < 1e-5 and rel(rv, bn.running_var) < 1e-5
+    dy = torch.randn(R, C, generator=g).to(dt).float()
+    ref.backward(dy)
+    dx = torch.empty(R, C, device="cuda", dtype=dt)
+    dg, db = torch.zeros(C, device="cuda"), torch.zeros(C, device="cuda")
+    scratch = torch.empty(2 * C, device="cuda")
+    L.bn_act_bwd(dy.cuda().to(dt), xd, mean, rstd, gd, bd, dx, dg, db, scratch, R, C, act, train, L.dtype_code(dt))
+    tol = 2e-4 if dt == torch.float32 else 3e-2
+    assert rel(dx, x.grad) < tol and rel(dg, gam.grad) < tol and rel(db, bet.grad) < tol
+
+
+@pytest.mark.parametrize("dt", [torch.float32, torch.bfloat16])
+def test_pool_se_residual_maxpool_gather(dt):
+    B, HW, C = 3, 35, 70
+    g = torch.Generator().manual_seed(4)
+    x = torch.randn(B, HW, C, generator=g).to(dt).float()
+    s = torch.rand(B, C, generator=g).to(dt).float()
+    xd, sd = x.view(-1, C).cuda().to(dt), s.cuda().to(dt)
+    code = L.dtype_code(dt)
+    out = torch.empty(B, C, device="cuda", dtype=dt)
+    L.rowpool_mean(xd, out, B, HW, C, code)
+    assert rel(out, x.mean(1)) < TOL[dt]
+    y = torch.empty(B * HW, C, device="cuda", dtype=dt)
+    L.se_scale_fwd(xd, sd, y, B, HW, C, code)
+    assert rel(y.view(B, HW, C), x * s[:, None]) < TOL[dt]
+    dy = torch.randn(B, HW, C, generator=g).to(dt).float()
+    dx, ds = torch.empty(B * HW, C, device="cuda", dtype=dt), torch.empty(B, C, device="cuda", dtype=dt)
+    L.se_scale_bwd(dy.view(-1, C).cuda().to(dt), xd, sd, dx, ds, B, HW, C, code)
+    assert rel(dx.view(B, HW, C), dy * s[:, None]) < TOL[dt] and rel(ds, (dy * x).sum(1)) < TOL[dt]
+    dp = torch.randn(B, C, generator=g).to(dt).float()
+    acc = dx.clone()
+    L.rowpool_mean_bwd(dp.cuda().to(dt), acc, B, HW, C, True, code)
+    assert rel(acc.view(B, HW, C), dx.float().cpu().view(B, HW, C) + dp[:, None] / HW) < TOL[dt]
+    rs = torch.tensor([0.0, 1.25, 1.25], device="cuda")
+    o = torch.empty(B * HW, C, device="cuda", dtype=dt)
+    L.residual_add(xd, y, rs, o, B, HW * C, code)
+    assert rel(o.view(B, HW, C), x + (x * s[:, None]).to(dt).float() * rs.cpu()[:, None, None]) < TOL[dt]
+    # biased activation of the squeeze-excitation 1x1 convolutions
+    bias = torch.randn(C, generator=g).to(dt).float()
+    pre = x[:, 0].clone().requires_grad_(True)
+    ref = torch.sigmoid(pre + bias)
+    yb = torch.empty(B, C, device="cuda", dtype=dt)
+    L.bias_act_fwd(pre.detach().cuda().to(dt), bias.cuda().to(dt), yb, B, C, L.CONV_SIGMOID, code)
+    assert rel(yb, ref.detach()) < TOL[dt]
+    go = torch.randn(B, C, generator=g).to(dt).float()
+    ref.backward(go)
+    dpre, dbias = torch.empty(B, C, device="cuda", dtype=dt), torch.zeros(C, device="cuda")
+    L.bias_act_bwd(go.cuda().to(dt), pre.detach().cuda().to(dt), bias.cuda().to(dt), dpre, dbias, B, C, L.CONV_SIGMOID, code)
+    assert rel(dpre, pre.grad) < TOL[dt] and rel(dbias, pre.grad.sum(0)) < 2e-2
+    # max pooling 3x3 / 2 / 1
+    H, W = 9, 6
+    xi = torch.randn(B, C, H, W, generator=g).to(dt).float().requires_grad_(True)
+    ref = F.max_pool2d(xi, 3, 2, 1)
+    Ho, Wo = ref.shape[2:]
+    yo = torch.empty(B * Ho * Wo, C, device="cuda", dtype=dt)
+    arg = torch.empty(B * Ho * Wo, C, device="cuda", dtype=torch.uint8)
+    L.maxpool3x3s2_fwd(rows(xi.detach()).cuda().to(dt), yo, arg, B, H, W, C, code)
+    assert rel(nchw(yo.float().cpu(), B, Ho, Wo), ref.detach()) < 1e-6
+    gy = torch.randn(ref.shape, generator=g).to(dt).float()
+    ref.backward(gy)
+    dxi = torch.empty(B * H * W, C, device="cuda", dtype=dt)
+    L.maxpool3x3s2_bwd(rows(gy).cuda().to(dt), arg, dxi, B, H, W, C, code)
+    assert rel(nchw(dxi.float().cpu(), B, H, W), xi.grad) < TOL[dt]
+    # channel gather
+    cmap = torch.randperm(C, generator=g)[:40].int().cuda()
+    og = torch.zeros(B * HW, 64, device="cuda", dtype=dt)
+    L.channel_gather(xd, cmap, og, B * HW, C, 40, 64, 8, code)
+    assert torch.equal(og[:, 8:48].float().cpu(), x.view(-1, C)[:, cmap.cpu().long()].to(dt).float())
+
+
+class _Owner:
+    """Minimal parameter owner for a bare ConvEncoder (what MMRCAEngine provides): fp32 tensors per key."""
+
+    def __init__(self, dtype):
+        self.dtype, self.device, self.dt, self.gemm_impl = dtype, torch.device("cuda"), L.dtype_code(dtype), L.IMPL_AUTO
+        self.p, self.g, self.lp = {}, {}, {}
+
+    def W(self, k):
+        return self.lp[k] if self.dtype == torch.bfloat16 else self.p[k]
+
+    def G(self, k):
+        return self.g[k]
+
+
+def _conv_pair(name, dtype, seed=0):
+    """Product ConvEncoder and oracle with the same (seeded, non-trivial) parameters and running statistics."""
+    torch.manual_seed(seed)
+    orc = CM.build_conv_oracle(name)
+    g = torch.Generator().manual_seed(seed + 1)
+    with torch.no_grad():
+        for k, t in orc.state_dict().items():
+            if k.endswith("running_mean"):
+                t.copy_(torch.randn(t.shape, generator=g) * 0.1)
+            elif k.endswith("running_var"):
+                t.copy_(torch.rand(t.shape, generator=g) * 0.5 + 0.75)
+            elif k.endswith(".1.weight") or (t.dim() == 1 and k.endswith("weight")):
+                t.copy_(torch.rand(t.shape, generator=g) * 0.5 + 0.75)
+            elif t.dim() == 1 and k.endswith("bias"):
+                t.copy_(torch.randn(t.shape, generator=g) * 0.1)
+    own = _Owner(dtype)
+    enc = ConvEncoder(name, own)
+    sd = orc.state_dict()
+    for k, shp in enc.param_entries():
+        assert tuple(sd[k].shape) == tuple(shp), k
+        own.p["image_model." + k] = sd[k].detach().clone().float().cuda().contiguous()
+        own.g["image_model." + k] = torch.zeros_like(own.p["image_model." + k])
+        own.lp["image_model." + k] = own.p["image_model." + k].bfloat16()
+    enc.init_buffers(own.device)
+    enc.load_buffers(sd)
+    return enc, own, orc
+
+
+def _sd_blocks(orc):
+    return [m for m in orc.modules() if isinstance(m, CM.MBConv) and m.use_res_connect and m.stochastic_depth.p > 0]
+
+
+@pytest.mark.parametrize("name,B,size", [("eff_v2_medium", 3, 64), ("shuffle_net", 4, 64), ("eff_v2_large", 3, 64)])
+@pytest.mark.parametrize("train", [True, False])
+def test_backbone_features_gradients_and_running_stats_match_oracle_fp32(name, B, size, train):
+    enc, own, orc = _conv_pair(name, torch.float32)
+    g = torch.Generator().manual_seed(9)
+    images = torch.randn(B, 3, size, size, generator=g)
+    orc.train(train)
+    blocks = _sd_blocks(orc)
+    if train and blocks:                      # drive both sides with the same stochastic-depth keep masks
+        keep = (torch.rand(len(blocks), B, generator=g) > 0.3).float()
+        for m, k in zip(blocks, keep):
+            m.stochastic_depth.keep = k
+        enc.injected_keep = keep
+    for p in orc.parameters():
+        p.requires_grad_(True)
+    feat_ref = CM.conv_features(orc, images)
+    feat = enc.forward(images.cuda(), save=True, train=train)
+    assert rel(feat, feat_ref.detach()) < 1e-3, rel(feat, feat_ref.detach())
+    dfeat = torch.randn(feat_ref.shape, generator=g)
+    feat_ref.backward(dfeat)
+    enc.backward(dfeat.cuda())
+    torch.cuda.synchronize()
+    named = dict(orc.named_parameters())
+    gmax = max(float(p.grad.abs().max()) for p in named.values() if p.grad is not None)
+    worst = 0.0
+    for k, _ in enc.param_entries():
+        got, ref = own.g["image_model." + k].cpu(), named[k].grad
+        if name == "shuffle_net":
+            # ShuffleNetV2 gates with ReLU behind BatchNorm over 64..1024 rows: the forwards agree to 2e-5, so about one
+            # pre-activation per layer (|u| < 1e-5 of ~1e5 values) takes the other side of the gate, and that single flip
+            # moves its channel's BatchNorm-backward sums -- entries of a few tensors differ by per cent, differently in every
+            # run (atomic summation order decides the flips).  The oracle in fp64 vs fp32 (no flips at 1e-7) agrees to 7e-5,
+            # every kernel is checked exactly against torch above, and EfficientNetV2 (smooth SiLU) matches to 1e-4; here the
+            # whole-network check is therefore in the flip-tolerant L2 / cosine sense.
+            num, den = (got - ref.view_as(got)).double().norm().item(), ref.double().norm().item()
+            cos = torch.nn.functional.cosine_similarity(got.double().flatten(), ref.double().flatten(), dim=0).item() if den > 0 else 1.0
+            worst = max(worst, num / max(den, 1e-30))
+            assert num <= 5e-2 * max(den, 1e-3 * gmax) and (cos > 0.998 or den < 1e-3 * gmax), (k, num / den, cos)   # (a BatchNorm bias in front of conv + BatchNorm has a ~0 gradient)
+            continue
+        err = (got - ref.view_as(got)).abs().max().item()
+        scale = max(ref.abs().max().item(), 1e-3 * gmax)
+        worst = max(worst, err / scale)
+        assert err <= 1e-3 * scale, (k, err, scale)        # measured 9e-5
+    print(f"{name} train={train}: features rel {rel(feat, feat_ref.detach()):.2e}, worst gradient rel {worst:.2e}")
+    if train:
+        enc.sync_buffers()
+        sd = orc.state_dict()
+        for k, t in enc.buffers.items():
+            assert rel(t, sd[k]) < 1e-4, k
+    enc.release()
+
+
+def test_backbone_bf16_close_to_oracle():
+    enc, own, orc = _conv_pair("eff_v2_medium", torch.bfloat16)
+    images = torch.randn(4, 3, 64, 64, generator=torch.Generator().manual_seed(2))
+    orc.eval()
+    with torch.no_grad():
+        ref = CM.conv_features(orc, images)
+    feat = enc.forward(images.cuda(), save=False, train=False)
+    e = rel(feat, ref)
+    print("EfficientNetV2-M bf16 features relative error:", e)
+    assert torch.isfinite(feat.float()).all() and e < 6e-2
+    enc.release()
+
+
+@pytest.mark.parametrize("image_model,size", [("eff_v2_medium", 64), ("shuffle_net", 64)])
+def test_mm_rca_with_conv_backbone_fp32_logits_and_train_step(image_model, size):
+    """MM_RCA over a conv image backbone end to end: fp32 logits within the north-star 1e-3 of the oracle (eval mode), and a
+    train-mode forward/backward that reaches every trainable parameter."""
+    eng = MMRCAEngine("distilbert", image_model, 4, True, 0, torch.float32, image_size=size)
+    eng.init_parameters(0)
+    orc = O.build_oracle("distilbert", image_model, True, False, False, drop_ratio=0.0, enc_dropout=0.0).eval()
+    sd = {k: eng.arena.view(k).detach().cpu().clone() for k in eng.param_keys}
+    orc.text_model.load_flat(sd, "text_model.")
+    isd = {k[len("image_model."):]: v for k, v in sd.items() if k.startswith("image_model.")}
+    missing = orc.image_model.load_state_dict(isd, strict=False)
+    assert not missing.unexpected_keys and all(("running" in k or "num_batches" in k) for k in missing.missing_keys)
+    orc.load_state_dict({k: v for k, v in sd.items() if not k.startswith(("text_model.", "image_model."))}, strict=False)
+    from garbage_classification_rca_amd.procedural import synth_captions
+    B = 3
+    ids, mask = (torch.from_numpy(a) for a in synth_captions(B, 24, seed=1))
+    images = torch.randn(B, 3, size, size, generator=torch.Generator().manual_seed(3))
+    logits = eng.forward(ids.cuda(), mask.cuda(), images.cuda(), save=False, bn_train=False)
+    with torch.no_grad():
+        ref = orc(ids, mask, images, eval=True)
+    assert rel(logits, ref) < 1e-3, rel(logits, ref)
+    logits = eng.forward(ids.cuda(), mask.cuda(), images.cuda(), drop_p=0.0, seed=5, save=True, bn_train=True)
+    eng.arena.g.zero_()
+    eng.backward(torch.randn(B, 4, device="cuda") * 0.1)
+    torch.cuda.synchronize()
+    assert torch.isfinite(logits).all() and torch.isfinite(eng.arena.g).all()
+    lo, hi = eng.groups["image_emb"]
+    assert float(eng.arena.g[lo:hi].abs().max()) > 0
+    eng.release_buffers()

@@ -75,7 +75,7 @@ def test_cli_defaults_match_reference_parser():
     for k, v in gold["example"].items():
         assert ex[k] == v
     extra = set(mine) - set(gold["defaults"])
-    assert extra == {"tokens_max_len", "dtype", "synthetic", "num_workers", "seed"}     # additive flags only
+    assert extra == {"tokens_max_len", "dtype", "synthetic", "num_workers", "seed", "image_size", "gpu_preprocess"}     # additive flags only
 
 
 # ------------------------------------------------------------------------------------------------ dataset
@@ -381,3 +381,25 @@ def test_product_drop_modalities_follows_the_reference_truth_table():
         nxt = np.random.rand()
         fresh = np.random.RandomState(int(seed)).rand(6)
         assert int(np.argmin(np.abs(fresh - nxt))) == int(draws), row
+
+
+def test_conv_backbone_inventories_match_the_reference_counts_and_the_oracle_layout():
+    """a7 / f3: the restated torchvision architectures carry exactly the parameter counts the reference quotes for its
+    4-class classifiers (main_image.py:295 eff_v2_medium 52 863 480, :302 eff_v2_large 117 239 396), and the product's
+    parameter / buffer inventory (names, shapes, order) is the oracle module tree's state_dict."""
+    from oracle import conv_models as CM
+    from garbage_classification_rca_amd.conv_engine import ConvEncoder
+    want = {"eff_v2_medium": 52863480, "eff_v2_large": 117239396}
+    for name in ("eff_v2_medium", "eff_v2_large", "shuffle_net"):
+        orc = CM.build_conv_oracle(name)
+        n = sum(p.numel() for p in orc.parameters())
+        if name in want:
+            assert n + 1280 * 4 + 4 == want[name]
+        enc = ConvEncoder(name, owner=None)
+        sd = orc.state_dict()
+        pk = [k for k, _ in enc.param_entries()]
+        assert pk == [k for k, _ in orc.named_parameters()], name
+        assert all(tuple(sd[k].shape) == tuple(s) for k, s in enc.param_entries())
+        bk = [k for k, _ in enc.buffer_entries()]
+        assert bk == [k for k, _ in orc.named_buffers()], name
+        assert sorted(pk + bk) == sorted(sd.keys())
