@@ -39,7 +39,7 @@ def effective_cores() -> int:
     return max(1, n)
 
 
-def cpu_baseline(batch=8, steps=12, seq_len=64):
+def cpu_baseline(batch=8, steps=12, seq_len=64, text_model="distilbert", image_model="transformer_B16", image_size=224):
     """The oracle (CPU restatement of the reference's model + run_one_epoch step) on this box's host cores, same
     synthetic tensors, fp32 eager, fine-tuning phase.  A reported baseline, not the optimisation target."""
     from oracle import model as O
@@ -47,10 +47,12 @@ def cpu_baseline(batch=8, steps=12, seq_len=64):
     n = effective_cores()
     torch.set_num_threads(n)
     print(f"[bench] cpu_baseline: oracle train step on {n} host threads, batch {batch} ...", file=sys.stderr, flush=True)
-    m = O.build_oracle("distilbert", "transformer_B16", True, drop_ratio=0.6, enc_dropout=0.1).train()
+    m = O.build_oracle(text_model, image_model, True, drop_ratio=0.6, enc_dropout=0.1).train()
     g = torch.Generator().manual_seed(0)
     with torch.no_grad():
         for name, p in m.named_parameters():
+            if name.startswith("image_model.") and image_model not in ("transformer_B16", "transformer_L16"):
+                continue              # conv backbone: torchvision's own init
             if p.dim() >= 2:
                 p.copy_(torch.randn(p.shape, generator=g) * 0.02)
             elif name.endswith("weight"):
@@ -59,7 +61,7 @@ def cpu_baseline(batch=8, steps=12, seq_len=64):
                 p.zero_()
     opt = torch.optim.SGD(m.parameters(), lr=1e-3, weight_decay=1e-2)
     ids, mask = (torch.from_numpy(a) for a in synth_captions(batch, seq_len, seed=4321))
-    images = torch.randn(batch, 3, 224, 224, generator=torch.Generator().manual_seed(1234))
+    images = torch.randn(batch, 3, image_size, image_size, generator=torch.Generator().manual_seed(1234))
     labels = torch.arange(batch) % 4
 
     def step():
@@ -76,7 +78,7 @@ def cpu_baseline(batch=8, steps=12, seq_len=64):
         print("[bench] cpu_baseline: step done", file=sys.stderr, flush=True)
     dt = time.time() - t0
     return {"value": round(batch * steps / dt, 3), "unit": "samples/s", "cores": n, "kind": "port",
-            "sample": f"oracle (PyTorch CPU fp32 eager restatement of MM_RCA + run_one_epoch step), ViT-B/16 + DistilBERT, "
+            "sample": f"oracle (PyTorch CPU fp32 eager restatement of MM_RCA + run_one_epoch step), {image_model} + {text_model}, "
                       f"batch {batch}, S={seq_len}, {steps} timed steps after 1 warm-up, {n} threads"}
 
 
@@ -88,9 +90,16 @@ def parity_check(model, ids, mask, images, n=8):
     from garbage_classification_rca_amd.engine import MMRCAEngine, make_text_pack
     eng = model.engine
     sd = {k: eng.arena.view(k).detach().cpu().clone() for k in eng.param_keys}
-    orc = O.build_oracle(eng.ts.name, eng.vs.name, eng.reverse, eng.mode == 1, eng.mode == 2, drop_ratio=0.0, enc_dropout=0.0).eval()
+    img_name = eng.vs.name if eng.vs is not None else eng.conv.name
+    orc = O.build_oracle(eng.ts.name, img_name, eng.reverse, eng.mode == 1, eng.mode == 2, drop_ratio=0.0, enc_dropout=0.0).eval()
     orc.text_model.load_flat(sd, "text_model.")
-    orc.image_model.load_flat(sd, "image_model.")
+    if eng.vs is not None:
+        orc.image_model.load_flat(sd, "image_model.")
+    else:       # conv backbone: parameters and BatchNorm running statistics by their torchvision names
+        eng.conv.sync_buffers()
+        isd = {k[len("image_model."):]: v for k, v in sd.items() if k.startswith("image_model.")}
+        isd.update({k: v.detach().cpu() for k, v in eng.conv.buffers.items()})
+        orc.image_model.load_state_dict(isd)
     orc.load_state_dict({k: v for k, v in sd.items() if not k.startswith(("text_model.", "image_model."))}, strict=False)
     i_h, m_h, x_h = ids[:n].cpu(), mask[:n].cpu(), images[:n].float().cpu()
     torch.set_num_threads(effective_cores())
@@ -102,8 +111,10 @@ def parity_check(model, ids, mask, images, n=8):
     l16 = eng.forward(ids[:n], mask[:n], images[:n], save=False, text_pack=pack)
     out = {"bf16_logits_rel": round(rel(l16), 6), "samples": n,
            "reference": "oracle (CPU fp32 restatement pinned by the reference's goldens), same weights, eval mode"}
-    eng32 = MMRCAEngine(eng.ts.name, eng.vs.name, eng.n_classes, eng.reverse, eng.mode, torch.float32, eng.device)
+    eng32 = MMRCAEngine(eng.ts.name, img_name, eng.n_classes, eng.reverse, eng.mode, torch.float32, eng.device)
     eng32.load_arrays(sd)
+    if eng.conv is not None:
+        eng32.conv.load_buffers({k: v for k, v in eng.conv.buffers.items()})
     l32 = eng32.forward(ids[:n], mask[:n], images[:n], save=False)
     out["fp32_logits_rel"] = round(rel(l32), 8)
     eng32.release_buffers()
@@ -121,7 +132,8 @@ def main():
     ap.add_argument("--no_cpu_baseline", action="store_true")
     ap.add_argument("--frozen", action="store_true", help="time the frozen-backbone phase instead (reported separately)")
     ap.add_argument("--text_model", default="distilbert", help="distilbert (BASELINE configs[1]) | bert | roberta")
-    ap.add_argument("--image_model", default="transformer_B16", help="transformer_B16 (configs[1]) | transformer_L16")
+    ap.add_argument("--image_model", default="transformer_B16", help="transformer_B16 (configs[1]) | transformer_L16 | eff_v2_medium | eff_v2_large (configs[2]) | shuffle_net")
+    ap.add_argument("--image_size", type=int, default=224)
     ap.add_argument("--cross_attention_only", action="store_true", help="configs[3]: ViT-L/16 + BERT-base, --seq_len 128")
     args = ap.parse_args()
 
@@ -145,7 +157,7 @@ def main():
     import io
     with contextlib.redirect_stdout(io.StringIO()):
         model = MM_RCA(4, 0.6, 0.0, 0.7, 256, args.text_model, B, True, False, args.cross_attention_only,
-                       image_model_name=args.image_model, dtype=torch.bfloat16, device=dev, init_seed=0)
+                       image_model_name=args.image_model, dtype=torch.bfloat16, device=dev, init_seed=0, image_size=args.image_size)
     model.train()
     if not args.frozen:
         for p in model.parameters():
@@ -157,9 +169,11 @@ def main():
     # synthetic pairs, resident in HBM before the timed region; a few distinct batches
     nb = 2
     ids, mask_host = synth_captions(B * nb, S, seed=4321 + rank)
+    if args.text_model == "roberta":
+        ids[mask_host == 0] = 1               # RoBERTa pads with id 1
     ids, mask = torch.from_numpy(ids).to(dev), torch.from_numpy(mask_host).to(dev)
     gen = torch.Generator(device=dev).manual_seed(1234 + rank)
-    images = torch.randn(B * nb, 3, 224, 224, device=dev, generator=gen)
+    images = torch.randn(B * nb, 3, args.image_size, args.image_size, device=dev, generator=gen)
     labels = (torch.arange(B * nb, device=dev) % 4).to(torch.int32)
 
     # packed token layouts of the batches, built from the HOST masks before the timed region (what a DataLoader-fed loop
@@ -318,11 +332,12 @@ def main():
             "ms_per_step": round(elapsed / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
             "config": {"workload": "MM_RCA --reverse" + (" --cross_attention_only " if args.cross_attention_only else " ")
-                       + {"transformer_B16": "ViT-B/16", "transformer_L16": "ViT-L/16"}[args.image_model] + " + "
+                       + {"transformer_B16": "ViT-B/16", "transformer_L16": "ViT-L/16", "eff_v2_medium": "EfficientNetV2-M", "eff_v2_large": "EfficientNetV2-L",
+                          "shuffle_net": "ShuffleNetV2-x2.0"}[args.image_model] + " + "
                        + {"distilbert": "DistilBERT", "bert": "BERT-base", "roberta": "RoBERTa-base"}[args.text_model] + ", "
                        + ("frozen-backbone" if args.frozen else "fine-tune")
-                       + f" train step (fwd+loss+bwd+allreduce+SGD), 224x224 images, {S}-token captions",
-                       "per_gpu_batch": B, "global_batch": B * world, "seq_len": S, "image": 224, "parallelism": f"dp{world}",
+                       + f" train step (fwd+loss+bwd+allreduce+SGD), {args.image_size}x{args.image_size} images, {S}-token captions",
+                       "per_gpu_batch": B, "global_batch": B * world, "seq_len": S, "image": args.image_size, "parallelism": f"dp{world}",
                        "optimizer": "sgd lr=1e-3 wd=1e-2", "random_init": True, "caption_rows_processed": round(live, 3),
                        "dead_row_elimination": {"class_token_tail": bool(E_CLS_TAIL), "packed_captions": bool(PACK_TEXT),
                                                 "note": "identical logits and gradients; MMRCA_CLS_TAIL=0 MMRCA_PACK_TEXT=0 runs every row"}, "final_loss": round(final_loss, 4),
@@ -346,7 +361,7 @@ def main():
         if not args.no_cpu_baseline and world == 1:
             with contextlib.redirect_stdout(io.StringIO()):
                 out["parity"] = parity_check(model, ids, mask, images)
-            out["cpu_baseline"] = cpu_baseline()
+            out["cpu_baseline"] = cpu_baseline(seq_len=S, text_model=args.text_model, image_model=args.image_model, image_size=args.image_size)
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.barrier()

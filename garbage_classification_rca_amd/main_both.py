@@ -165,8 +165,17 @@ def main(argv=None):
                                          tokenizer_text=_tokenizer, extended_desc=args.extended_desc_val)
     print("Class weights: {}".format(class_weights))
 
+    # one shuffle seed for all ranks (random when --seed is not given, like the reference's unseeded loader); dropout streams
+    # differ per rank so that replicas do not apply identical masks to their different samples
+    shuffle_seed = D.broadcast_seed(args.seed, device if world > 1 and torch.distributed.get_backend() == "nccl" else "cpu")
+    global_model._drop_seed += rank * 1000003
+    print("Per-process batch size: {} (global batch = {} x {} ranks; lr unchanged)".format(_batch_size, _batch_size, world))
+    for flag, default in (("balanced_sampler", False), ("use_synonyms", False)):
+        if getattr(args, flag, default) != default:
+            print("WARNING: --{} is accepted for CLI compatibility but not implemented on this path (SURVEY.md section 2: out of scope)".format(flag))
+
     def loader(ds, bs, shuffle):
-        sampler = D.ShardedSampler(len(ds), rank, world, shuffle=shuffle, seed=args.seed or 0)
+        sampler = D.ShardedSampler(len(ds), rank, world, shuffle=shuffle, seed=shuffle_seed)
         return torch.utils.data.DataLoader(ds, batch_size=bs, sampler=sampler, num_workers=args.num_workers, pin_memory=True), sampler
 
     (dl_train, s_train), (dl_val, _) = loader(train_data, _batch_size, True), loader(val_data, _batch_size, False)
@@ -195,15 +204,19 @@ def main(argv=None):
             global_model.eval()
             ar = D.all_reduce_counts if world > 1 else None
             # eval_mode False: the TRAINING-branch modality dropout still fires in these two passes (main_both.py:594-619)
-            train_acc, _ = calculate_set_accuracy(global_model, dl_tr, len(sampler), device, bs, mode_config_dict['both'], False, is_main, ar)
-            val_acc, val_report = calculate_set_accuracy(global_model, dl_v, len(dl_v.sampler), device, bs, mode_config_dict['both'], False, is_main, ar)
+            train_acc, _ = calculate_set_accuracy(global_model, dl_tr, len(sampler), device, bs, mode_config_dict['both'], False, is_main, ar,
+                                                  n_real=sampler.num_real)
+            val_acc, val_report = calculate_set_accuracy(global_model, dl_v, len(dl_v.sampler), device, bs, mode_config_dict['both'], False, is_main, ar,
+                                                         n_real=dl_v.sampler.num_real)
             if val_acc > state["max_val"]:
                 if is_main:
                     save_model_weights(global_model, args.text_model, args.image_model, epoch, val_acc, device, fine_tuning,
                                        args.balance_weights, args.opt, args.late_fusion, args)
                 state["max_val"], state["best_epoch"] = val_acc, epoch
-            img_only, _ = calculate_set_accuracy(global_model, dl_v, len(dl_v.sampler), device, bs, mode_config_dict['image_only'], True, is_main, ar)
-            txt_only, _ = calculate_set_accuracy(global_model, dl_v, len(dl_v.sampler), device, bs, mode_config_dict['text_only'], True, is_main, ar)
+            img_only, _ = calculate_set_accuracy(global_model, dl_v, len(dl_v.sampler), device, bs, mode_config_dict['image_only'], True, is_main, ar,
+                                                 n_real=dl_v.sampler.num_real)
+            txt_only, _ = calculate_set_accuracy(global_model, dl_v, len(dl_v.sampler), device, bs, mode_config_dict['text_only'], True, is_main, ar,
+                                                 n_real=dl_v.sampler.num_real)
             state["max_img"], state["max_txt"] = max(state["max_img"], img_only), max(state["max_txt"], txt_only)
             if fine_tuning:
                 scheduler.step(val_acc)                                 # main_both.py:769

@@ -66,6 +66,15 @@ def hip_train_step(model, ids, mask, images, labels, criterion: FusedCrossEntrop
                          model.drop_ratio if model.training else 0.0, model._drop_seed + model._fwd_count, save=(tt or ti),
                          enc_drop_p=(model.enc_dropout if model.training else 0.0), text_pack=text_pack, bn_train=model.training)
     loss, dlogits = criterion(logits, labels)
+    if grad_sync is not None and grad_sync.world > 1 and criterion.weight is not None:
+        # class-weighted loss under data parallelism: every rank normalised by ITS sum of w[y]; the all-reduce AVERAGES the
+        # ranks, so rescale to the weighted mean over the GLOBAL batch (what the reference's single-process DataParallel step
+        # computes): g_r * S_r * world / sum_r S_r.  Device-side scalar, no host sync.
+        import torch.distributed as dist
+        s_r = criterion.weight[labels.long()].sum()
+        s_tot = s_r.clone()
+        dist.all_reduce(s_tot)
+        dlogits = dlogits * (s_r * grad_sync.world / s_tot)
     if grad_sync is not None:
         grad_sync.enabled = bool(do_step)
     eng.grad_sync = grad_sync
@@ -126,11 +135,13 @@ def run_one_epoch(epoch_num, model, data_loader, len_train_data, hw_device, batc
 
 
 def calculate_set_accuracy(model, data_loader, len_data, device, batch_size, mode, eval_mode, verbose=True,
-                           all_reduce=None):
-    """main_both.py:141-198.  Returns (accuracy %, sklearn classification report dict)."""
+                           all_reduce=None, n_real=None):
+    """main_both.py:141-198.  Returns (accuracy %, sklearn classification report dict).
+    n_real: only the first n_real samples this rank draws are scored (ShardedSampler.num_real: the rest is the wrap-around
+    padding that equalises the ranks and would otherwise be counted twice)."""
     n_batches = math.ceil(len_data / batch_size)
     all_labels, all_predictions = [], []
-    correct = 0
+    correct, seen = 0, 0
     with torch.no_grad():
         for batch_idx, (data, labels) in enumerate(data_loader):
             images = data['image']['raw_image'].to(device)
@@ -140,6 +151,10 @@ def calculate_set_accuracy(model, data_loader, len_data, device, batch_size, mod
             outputs = model(_input_ids=ids, _attention_mask=mask, _images=images, eval=eval_mode,
                             remove_text=mode["remove_text"], remove_image=mode["remove_image"])
             pred = torch.max(outputs, 1)[1].view(-1)
+            if n_real is not None:
+                keep = max(0, min(len(labels), n_real - seen))
+                seen += len(labels)
+                pred, labels = pred[:keep], labels[:keep]
             correct += torch.sum(torch.eq(pred, labels)).item()
             if verbose:
                 print("Batches {}/{} ".format(batch_idx, n_batches))

@@ -403,3 +403,60 @@ def test_conv_backbone_inventories_match_the_reference_counts_and_the_oracle_lay
         bk = [k for k, _ in enc.buffer_entries()]
         assert bk == [k for k, _ in orc.named_buffers()], name
         assert sorted(pk + bk) == sorted(sd.keys())
+
+
+# ------------------------------------------------------------------------------------------------ (e) readiness
+def _ddp_worker2(rank, world, port, q):
+    """GradSync under the engine's real call pattern: spans of TWO producers (vision layers and text layers) arrive
+    interleaved, gradient accumulation syncs only on the stepping micro-batch, bf16 on the wire is optional."""
+    import torch.distributed as dist
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    out = {}
+    for wire in (None, torch.bfloat16):
+        flat = torch.zeros(96)
+        sync = D.GradSync(flat, world, bucket_bytes=16 * 4, wire_dtype=wire)
+        # micro-batch 1 of 2 (acc_steps = 2): accumulate only, nothing may be reduced
+        flat += (rank + 1.0)
+        sync.enabled = False
+        for lo, hi in ((80, 96), (64, 80), (16, 32), (48, 64), (0, 16), (32, 48)):
+            sync.span_ready(lo, hi)
+        sync.finish()
+        assert sync.bytes_reduced == 0 and torch.all(flat == rank + 1.0)
+        # micro-batch 2: the stepping one.  Arena order: text [0,48) | vision [48,80) | head [80,96); the head finishes first,
+        # then vision and text layers alternate (two streams), each descending within its own encoder
+        flat += 10.0 * (rank + 1.0)
+        sync.enabled = True
+        for lo, hi in ((80, 96), (64, 80), (32, 48), (48, 64), (16, 32), (0, 16)):
+            sync.span_ready(lo, hi, flush=(lo in (48, 0)))
+        sync.finish()
+        out["bf16" if wire else "fp32"] = (flat.clone(), sync.bytes_reduced)
+    # evaluation counts: 10 samples over 2 ranks of 5, then 7 samples over 2 ranks (rank 1 draws one wrapped duplicate)
+    s = D.ShardedSampler(7, rank, world, shuffle=False)
+    out["num_real"] = (len(s), s.num_real, D.all_reduce_counts(s.num_real, s.num_real, "cpu"))
+    out["seed"] = D.broadcast_seed(None)
+    q.put((rank, out))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_gradient_sync_two_producers_accumulation_and_bf16_wire_world2():
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 29900 + os.getpid() % 90
+    procs = [ctx.Process(target=_ddp_worker2, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = dict(q.get(timeout=120) for _ in range(2))
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    want = torch.full((96,), (11.0 + 22.0) / 2)            # mean over the two ranks of the ACCUMULATED gradient
+    for r in (0, 1):
+        flat, nbytes = res[r]["fp32"]
+        assert torch.equal(flat, want) and nbytes == 96 * 4
+        flat16, nbytes16 = res[r]["bf16"]
+        assert torch.allclose(flat16, want, rtol=1e-2) and nbytes16 == 96 * 2      # half the bytes on the wire
+    assert res[0]["num_real"][:2] == (4, 4) and res[1]["num_real"][:2] == (4, 3)
+    assert res[0]["num_real"][2] == (7, 7) and res[0]["seed"] == res[1]["seed"]
