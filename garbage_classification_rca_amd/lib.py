@@ -86,13 +86,14 @@ _SIGS = {
     "mmrca_vit_assemble_fwd": [_vp] * 4 + [_i32] * 4 + [_vp],
     "mmrca_vit_assemble_bwd": [_vp] * 4 + [_i32] * 4 + [_vp],
     "mmrca_head_fwd": [_vp, _vp, C.POINTER(HeadPtrs), _vp] + [_i32] * 6 + [_f32, _u64, _i32, _vp],
-    "mmrca_head_bwd": [_vp, _vp, _vp, C.POINTER(HeadPtrs), C.POINTER(HeadPtrs), _vp, _vp] + [_i32] * 6 + [_f32, _u64, _i32, _vp],
+    "mmrca_head_bwd": [_vp, _vp, _vp, C.POINTER(HeadPtrs), C.POINTER(HeadPtrs), _vp, _vp] + [_i32] * 6 + [_f32, _u64, _i32, _vp, _i64, _vp],
     "mmrca_xent_fwd_bwd": [_vp, _vp, _vp, _f32, _vp, _vp, _i32, _i32, _f32, _vp],
     "mmrca_sgd_step": [_vp, _vp, _vp, _i64, _f32, _f32, _f32, _vp],
     "mmrca_adamw_step": [_vp] * 5 + [_i64] + [_f32] * 5 + [_i32, _f32, _vp],
     "mmrca_cast_f32_to_bf16": [_vp, _vp, _i64, _vp],
 }
-EXPORTS = sorted(list(_SIGS) + ["mmrca_last_error", "mmrca_version", "mmrca_debug_set", "mmrca_gemm_splitk_workspace_bytes"])
+EXPORTS = sorted(list(_SIGS) + ["mmrca_last_error", "mmrca_version", "mmrca_debug_set", "mmrca_gemm_splitk_workspace_bytes",
+                                  "mmrca_head_bwd_workspace_bytes"])
 
 
 def load(build_if_missing: bool = False):
@@ -307,10 +308,29 @@ def head_fwd(img, txt, w: HeadPtrs, logits, B, d_img, d_txt, n_classes, reverse,
                                      drop_p, seed, dtype, stream_ptr()), "mmrca_head_fwd")
 
 
-def head_bwd(dlogits, img, txt, w: HeadPtrs, g: HeadPtrs, dimg, dtxt, B, d_img, d_txt, n_classes, reverse, mode, drop_p, seed, dtype):
+_HEAD_WS = {}      # (device index, stream) -> workspace tensor of the head backward (grows on demand)
+
+
+def head_bwd_workspace_bytes(B, d_img, d_txt) -> int:
+    fn = load().mmrca_head_bwd_workspace_bytes
+    fn.restype, fn.argtypes = C.c_int64, [_i32, _i32, _i32]
+    return int(fn(B, d_img, d_txt))
+
+
+def head_bwd(dlogits, img, txt, w: HeadPtrs, g: HeadPtrs, dimg, dtxt, B, d_img, d_txt, n_classes, reverse, mode, drop_p, seed, dtype,
+             workspace=None):
+    """Gradients are accumulated into ``g``.  ``workspace``: uint8/any tensor of ``head_bwd_workspace_bytes`` bytes; by default one
+    is kept per (device, stream) -- the two launches of the backward and its next use are ordered by that stream."""
+    need = head_bwd_workspace_bytes(B, d_img, d_txt)
+    if workspace is None:
+        key = (img.device.index, stream_ptr())
+        workspace = _HEAD_WS.get(key)
+        if workspace is None or workspace.numel() < need:
+            workspace = _HEAD_WS[key] = torch.empty(need, dtype=torch.uint8, device=img.device)
     with _Bracket("head_bwd", (B, d_img, d_txt)):
         _check(load().mmrca_head_bwd(ptr(dlogits), ptr(img), ptr(txt), C.byref(w), C.byref(g), ptr(dimg), ptr(dtxt), B, d_img, d_txt,
-                                     n_classes, int(reverse), mode, drop_p, seed, dtype, stream_ptr()), "mmrca_head_bwd")
+                                     n_classes, int(reverse), mode, drop_p, seed, dtype, ptr(workspace),
+                                     workspace.numel() * workspace.element_size(), stream_ptr()), "mmrca_head_bwd")
 
 
 def xent_fwd_bwd(logits, labels, class_w, smoothing, loss, dlogits, B, Cc, grad_scale=1.0):

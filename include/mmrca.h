@@ -203,10 +203,14 @@ int mmrca_vit_assemble_bwd(const void* dx, void* dproj, float* dcls, float* dpos
 
 /* K1. fused MM-RCA fusion head (CVPR_code/multimodal_model.py:662-726 with SelfAttention :39-68 and
  * ReverseCrossAttention :71-108): L2-normalise, reshape to 16 pseudo-patches, 2x self-attention, 2x (reverse)
- * cross-attention, LayerNorm+ReLU, concat by mode, dropout, final linear.  One workgroup per sample.
+ * cross-attention, LayerNorm+ReLU, concat by mode, dropout, final linear.  One 512-thread workgroup per sample, fp32
+ * matrix cores (v_mfma_f32_16x16x4_f32: 16 pseudo-patches = one tile).
  * weights: fp32 pointers in the order of MmrcaHeadWeights.  mode: 0 default, 1 features_only, 2 cross_attention_only.
  * drop_p>0 applies inverted dropout to the concatenated features with a counter-based mask (seed, sample, column).
- * The backward takes the same feature pointers and recomputes the (tiny) forward in LDS: nothing is saved in HBM.
+ * The backward takes the same feature pointers and recomputes the (tiny) forward in LDS; it is two launches: the
+ * per-sample kernel leaves dQ|dK|dV and the projection inputs in `workspace` (mmrca_head_bwd_workspace_bytes(), ~98 KB
+ * per sample, 16-byte aligned), and a second kernel forms all weight gradients from it as GEMMs over the B*16 rows.
+ * Gradients are ACCUMULATED into g (fp32 atomics).
  * dimg/dtxt (optional): gradients wrt the un-normalised backbone features, in `dtype`. */
 typedef struct {
   const float *sai_wq, *sai_bq, *sai_wk, *sai_bk, *sai_wv, *sai_bv, *sai_g, *sai_b;   /* self_attention_image */
@@ -225,9 +229,11 @@ typedef struct {
 int mmrca_head_fwd(const void* img, const void* txt, const MmrcaHeadWeights* w, float* logits,
                    int B, int d_img, int d_txt, int n_classes, int reverse, int mode,
                    float drop_p, uint64_t seed, int dtype, void* stream);
+int64_t mmrca_head_bwd_workspace_bytes(int B, int d_img, int d_txt);
 int mmrca_head_bwd(const float* dlogits, const void* img, const void* txt, const MmrcaHeadWeights* w,
                    const MmrcaHeadGrads* g, void* dimg, void* dtxt, int B, int d_img, int d_txt, int n_classes,
-                   int reverse, int mode, float drop_p, uint64_t seed, int dtype, void* stream);
+                   int reverse, int mode, float drop_p, uint64_t seed, int dtype, void* workspace,
+                   int64_t workspace_bytes, void* stream);
 
 /* K6. weighted, label-smoothed cross entropy (torch.nn.CrossEntropyLoss as built at main_both.py:87-93), mean
  * reduction with the weighted denominator.  loss: fp32[1]; dlogits (optional): fp32 [B,C] scaled by grad_scale. */
