@@ -19,7 +19,8 @@ import numpy as np
 import torch
 
 from .CustomImageTextFolder import CustomImageTextFolder
-from .main_both import Transforms
+from .main_both import DecodeOnly, Transforms, collate_decoded
+from .training import stage_images
 from .multimodal_model import MM_RCA
 from .options import args_parser
 from .training import mode_config_dict
@@ -36,7 +37,7 @@ def confusion_matrix(labels, preds, n=_num_classes) -> np.ndarray:
     return cm
 
 
-def calculate_test_accuracy(model, data_loader, len_test_data, hw_device, batch_size, mode, eval_mode, verbose=True):
+def calculate_test_accuracy(model, data_loader, len_test_data, hw_device, batch_size, mode, eval_mode, verbose=True, image_pipeline=None):
     """Reference :52-117.  Returns (accuracy %, text report, report dict, confusion matrix)."""
     correct = 0
     n_batches = math.ceil(len_test_data / batch_size)
@@ -44,7 +45,7 @@ def calculate_test_accuracy(model, data_loader, len_test_data, hw_device, batch_
     with torch.no_grad():
         for batch_idx, (data, labels) in enumerate(data_loader):
             texts = data['text']
-            images = data['image']['raw_image'].to(hw_device)
+            images = stage_images(data['image']['raw_image'], hw_device, image_pipeline)
             ids, mask = texts['tokens'].to(hw_device), texts['attention_mask'].to(hw_device)
             labels = labels.to(hw_device)
             outputs = model(_input_ids=ids, _attention_mask=mask, _images=images, eval=eval_mode,
@@ -119,12 +120,18 @@ def main(argv=None):
     model.eval()
     WIDTH, HEIGHT = model.get_image_size()
     test_data = CustomImageTextFolder(root=args.dataset_folder_name, tokens_max_len=args.tokens_max_len or model.get_max_token_size(),
-                                      tokenizer_text=model.get_tokenizer(), transform=Transforms(WIDTH, HEIGHT))
+                                      tokenizer_text=model.get_tokenizer(),
+                                      transform=DecodeOnly() if args.gpu_preprocess else Transforms(WIDTH, HEIGHT))
     print("Num of test samples: {}".format(len(test_data)))
+    image_pipeline = None
+    if args.gpu_preprocess:
+        from .preprocess import GpuImagePipeline
+        image_pipeline = GpuImagePipeline(HEIGHT, WIDTH, max_batch=_batch_size, max_pixels=640 * 480, device=device)
     loader = torch.utils.data.DataLoader(dataset=test_data, batch_size=_batch_size, shuffle=True, num_workers=min(8, args.num_workers),
-                                         pin_memory=True)
+                                         pin_memory=True, collate_fn=collate_decoded if args.gpu_preprocess else None,
+                                         multiprocessing_context="forkserver" if (args.gpu_preprocess and args.num_workers > 0) else None)
     acc, report, report_dict, cm = calculate_test_accuracy(model, loader, len(test_data), device, _batch_size,
-                                                           mode_config_dict['both'], True)
+                                                           mode_config_dict['both'], True, image_pipeline=image_pipeline)
     generate_report_and_image(report_dict, acc, cm, "always_both")
     print(test_data.class_to_idx)
     print("Test accuracy random both: {:.2f} %".format(acc))

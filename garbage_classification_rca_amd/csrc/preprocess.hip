@@ -11,8 +11,9 @@
 
 static_assert(sizeof(MmrcaImageDesc) == 40, "MmrcaImageDesc layout (preprocess.py::DESC_DTYPE mirrors it)");
 
+template <bool U8>          // U8: uint8 [B,H,W,3] output for the augmentation stages (augment.hip), no normalisation
 __global__ void __launch_bounds__(256)
-image_preprocess_k(const uint8_t* __restrict__ staging, const MmrcaImageDesc* __restrict__ desc, float* __restrict__ out,
+image_preprocess_k(const uint8_t* __restrict__ staging, const MmrcaImageDesc* __restrict__ desc, float* __restrict__ out, uint8_t* __restrict__ out_u8,
                    int out_h, int out_w, float m0, float m1, float m2, float is0, float is1, float is2) {
   const MmrcaImageDesc d = desc[blockIdx.y];
   const int idx = blockIdx.x * 256 + threadIdx.x;
@@ -42,6 +43,11 @@ image_preprocess_k(const uint8_t* __restrict__ staging, const MmrcaImageDesc* __
     const float val = top * (1.f - fy) + bot * fy;
     v[c] = fminf(fmaxf(floorf(val + 0.5f), 0.f), 255.f);          // uint8 rounding of the resized image
   }
+  if (U8) {
+    uint8_t* q = out_u8 + ((int64_t)blockIdx.y * out_h * out_w + (int64_t)oy * out_w + ox) * 3;
+    q[0] = (uint8_t)v[0]; q[1] = (uint8_t)v[1]; q[2] = (uint8_t)v[2];
+    return;
+  }
   const int64_t plane = (int64_t)out_h * out_w;
   float* o = out + (int64_t)blockIdx.y * 3 * plane + (int64_t)oy * out_w + ox;
   o[0] = (v[0] / 255.0f - m0) * is0;
@@ -55,9 +61,19 @@ extern "C" int mmrca_image_preprocess(const void* staging, const void* desc, flo
   MMRCA_REQUIRE(B > 0 && out_h > 0 && out_w > 0 && B <= 65535, "image_preprocess: bad shape B=%d %dx%d", B, out_h, out_w);
   MMRCA_REQUIRE(std3[0] != 0.f && std3[1] != 0.f && std3[2] != 0.f, "image_preprocess: zero std");
   dim3 grid((unsigned)((out_h * out_w + 255) / 256), (unsigned)B);
-  hipLaunchKernelGGL(image_preprocess_k, grid, dim3(256), 0, (hipStream_t)stream, (const uint8_t*)staging,
-                     (const MmrcaImageDesc*)desc, out, out_h, out_w, mean3[0], mean3[1], mean3[2], 1.f / std3[0], 1.f / std3[1],
+  hipLaunchKernelGGL(image_preprocess_k<false>, grid, dim3(256), 0, (hipStream_t)stream, (const uint8_t*)staging,
+                     (const MmrcaImageDesc*)desc, out, (uint8_t*)nullptr, out_h, out_w, mean3[0], mean3[1], mean3[2], 1.f / std3[0], 1.f / std3[1],
                      1.f / std3[2]);
   MMRCA_CHECK_LAUNCH("image_preprocess");
+  return 0;
+}
+
+extern "C" int mmrca_image_resize_u8(const void* staging, const void* desc, void* out_u8, int B, int out_h, int out_w, void* stream) {
+  MMRCA_REQUIRE(staging && desc && out_u8, "image_resize_u8: null pointer");
+  MMRCA_REQUIRE(B > 0 && out_h > 0 && out_w > 0 && B <= 65535, "image_resize_u8: bad shape B=%d %dx%d", B, out_h, out_w);
+  dim3 grid((unsigned)((out_h * out_w + 255) / 256), (unsigned)B);
+  hipLaunchKernelGGL(image_preprocess_k<true>, grid, dim3(256), 0, (hipStream_t)stream, (const uint8_t*)staging,
+                     (const MmrcaImageDesc*)desc, (float*)nullptr, (uint8_t*)out_u8, out_h, out_w, 0.f, 0.f, 0.f, 1.f, 1.f, 1.f);
+  MMRCA_CHECK_LAUNCH("image_resize_u8");
   return 0;
 }

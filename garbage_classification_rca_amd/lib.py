@@ -70,6 +70,9 @@ _SIGS = {
     "mmrca_maxpool3x3s2_bwd": [_vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _vp],
     "mmrca_channel_gather": [_vp, _vp, _vp, _i64, _i32, _i32, _i64, _i32, _i32, _vp],
     "mmrca_image_preprocess": [_vp, _vp, _vp, _i32, _i32, _i32, _vp, _vp, _vp],
+    "mmrca_image_rotate_crop": [_vp, _vp, _i32, _i32, _vp],
+    "mmrca_image_resize_u8": [_vp, _vp, _vp, _i32, _i32, _i32, _vp],
+    "mmrca_image_augment": [_vp, _vp, _vp, _vp, _i32, _i32, _i32, _vp, _vp, _vp],
     "mmrca_colsum_accum": [_vp, _vp, _i64, _i64, _i64, _i32, _vp],
     "mmrca_gelu_bwd": [_vp, _vp, _vp, _i64, _i32, _vp],
     "mmrca_gelu_bwd_colsum": [_vp, _vp, _vp, _vp, _i64, _i64, _i64, _i32, _vp],

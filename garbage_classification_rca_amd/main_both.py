@@ -66,6 +66,24 @@ class Transforms:
         return (t - self.MEAN) / self.STD
 
 
+class DecodeOnly:
+    """--gpu_preprocess: the DataLoader workers only decode (PIL -> uint8 HWC); padding, resize, the albumentations-style
+    augmentations and the normalisation run on the GPU, per batch (preprocess.GpuImagePipeline)."""
+
+    def __call__(self, img):
+        return torch.from_numpy(np.array(img.convert("RGB"), dtype=np.uint8))
+
+
+def collate_decoded(batch):
+    """default_collate, except that the decoded images (different sizes) are packed back to back into one uint8 tensor
+    (preprocess.pack_images: the GPU pipeline's staging layout, one shared-memory segment per batch)."""
+    from .preprocess import pack_images
+    raws = [sample[0]["image"].pop("raw_image") for sample in batch]
+    data, labels = torch.utils.data.default_collate(batch)
+    data["image"]["raw_image"] = pack_images(raws)
+    return data, labels
+
+
 def get_class_weights(train_dataset_path):
     """main_both.py:61-78."""
     ds = CustomImageTextFolder(train_dataset_path)
@@ -151,6 +169,7 @@ def main(argv=None):
     _tokenizer = global_model.get_tokenizer()
     _max_len = args.tokens_max_len or global_model.get_max_token_size()
 
+    gpu_pre = False
     if args.synthetic:
         train_data = SyntheticImageTextDataset(args.synthetic, WIDTH, _max_len)
         val_data = SyntheticImageTextDataset(max(args.synthetic // 4, _batch_size), WIDTH, _max_len, seed_images=99, seed_text=77)
@@ -159,9 +178,10 @@ def main(argv=None):
         train_path = os.path.join(BASE_PATH, args.dataset_folder_name)
         val_path = os.path.join(BASE_PATH, args.dataset_folder_name_val)
         class_weights = get_class_weights(train_path)
-        train_data = CustomImageTextFolder(root=train_path, transform=Transforms(WIDTH, HEIGHT, True, args.prob_aug),
+        gpu_pre = bool(args.gpu_preprocess)
+        train_data = CustomImageTextFolder(root=train_path, transform=DecodeOnly() if gpu_pre else Transforms(WIDTH, HEIGHT, True, args.prob_aug),
                                            tokens_max_len=_max_len, tokenizer_text=_tokenizer, extended_desc=args.extended_desc_train)
-        val_data = CustomImageTextFolder(root=val_path, transform=Transforms(WIDTH, HEIGHT), tokens_max_len=_max_len,
+        val_data = CustomImageTextFolder(root=val_path, transform=DecodeOnly() if gpu_pre else Transforms(WIDTH, HEIGHT), tokens_max_len=_max_len,
                                          tokenizer_text=_tokenizer, extended_desc=args.extended_desc_val)
     print("Class weights: {}".format(class_weights))
 
@@ -174,9 +194,26 @@ def main(argv=None):
         if getattr(args, flag, default) != default:
             print("WARNING: --{} is accepted for CLI compatibility but not implemented on this path (SURVEY.md section 2: out of scope)".format(flag))
 
+    # GPU input path: one pipeline object (two pinned + two device staging slots) for all loaders;
+    # the training passes draw albumentations' parameters per image on the host, the evaluation passes draw none
+    image_pipeline, aug_params = None, None
+    if gpu_pre:
+        from .preprocess import GpuImagePipeline, sample_train_params
+        image_pipeline = GpuImagePipeline(HEIGHT, WIDTH, max_batch=max(_batch_size, _batch_size_FT), max_pixels=640 * 480, device=device)
+        aug_rng = np.random.default_rng(None if args.seed is None else int(args.seed) + 7919 * (rank + 1))
+        aug_params = lambda n: sample_train_params(aug_rng, n, args.prob_aug)      # noqa: E731
+    else:
+        print("CPU image transforms (--gpu_preprocess=false): of the training augmentations only the flips are applied")
+
     def loader(ds, bs, shuffle):
         sampler = D.ShardedSampler(len(ds), rank, world, shuffle=shuffle, seed=shuffle_seed)
-        return torch.utils.data.DataLoader(ds, batch_size=bs, sampler=sampler, num_workers=args.num_workers, pin_memory=True), sampler
+        # GPU input path: workers come from a fork SERVER (a fresh interpreter without the GPU runtime), not from a fork of this
+        # process -- every fork of a process with registered host memory makes the kernel driver evict and restore its GPU
+        # queues; 16 workers cost 25-34 s of stalled GPU per loader start on the MI355X box (tools/input_bench.py)
+        ctx = "forkserver" if (gpu_pre and args.num_workers > 0) else None
+        return torch.utils.data.DataLoader(ds, batch_size=bs, sampler=sampler, num_workers=args.num_workers, pin_memory=True,
+                                           collate_fn=collate_decoded if gpu_pre else None, multiprocessing_context=ctx,
+                                           persistent_workers=bool(ctx)), sampler
 
     (dl_train, s_train), (dl_val, _) = loader(train_data, _batch_size, True), loader(val_data, _batch_size, False)
     (dl_train_ft, s_train_ft), (dl_val_ft, _) = loader(train_data, _batch_size_FT, True), loader(val_data, _batch_size_FT, False)
@@ -198,25 +235,26 @@ def main(argv=None):
             global_model.train()
             st = time.time()
             _, losses = run_one_epoch(epoch, global_model, dl_tr, len(sampler), device, bs, optimizer, class_weights,
-                                      args.balance_weights, acc_steps, args.label_smoothing, grad_sync=sync, verbose=is_main)
+                                      args.balance_weights, acc_steps, args.label_smoothing, grad_sync=sync, verbose=is_main,
+                                      image_pipeline=image_pipeline, aug_params=aug_params)
             elapsed = time.time() - st
             train_loss_avg = float(np.average([float(l) for l in losses])) if losses else float("nan")
             global_model.eval()
             ar = D.all_reduce_counts if world > 1 else None
             # eval_mode False: the TRAINING-branch modality dropout still fires in these two passes (main_both.py:594-619)
             train_acc, _ = calculate_set_accuracy(global_model, dl_tr, len(sampler), device, bs, mode_config_dict['both'], False, is_main, ar,
-                                                  n_real=sampler.num_real)
+                                                  n_real=sampler.num_real, image_pipeline=image_pipeline, aug_params=aug_params)   # the train set is scored through its own (augmenting) pipeline, as in the reference
             val_acc, val_report = calculate_set_accuracy(global_model, dl_v, len(dl_v.sampler), device, bs, mode_config_dict['both'], False, is_main, ar,
-                                                         n_real=dl_v.sampler.num_real)
+                                                         n_real=dl_v.sampler.num_real, image_pipeline=image_pipeline)
             if val_acc > state["max_val"]:
                 if is_main:
                     save_model_weights(global_model, args.text_model, args.image_model, epoch, val_acc, device, fine_tuning,
                                        args.balance_weights, args.opt, args.late_fusion, args)
                 state["max_val"], state["best_epoch"] = val_acc, epoch
             img_only, _ = calculate_set_accuracy(global_model, dl_v, len(dl_v.sampler), device, bs, mode_config_dict['image_only'], True, is_main, ar,
-                                                 n_real=dl_v.sampler.num_real)
+                                                 n_real=dl_v.sampler.num_real, image_pipeline=image_pipeline)
             txt_only, _ = calculate_set_accuracy(global_model, dl_v, len(dl_v.sampler), device, bs, mode_config_dict['text_only'], True, is_main, ar,
-                                                 n_real=dl_v.sampler.num_real)
+                                                 n_real=dl_v.sampler.num_real, image_pipeline=image_pipeline)
             state["max_img"], state["max_txt"] = max(state["max_img"], img_only), max(state["max_txt"], txt_only)
             if fine_tuning:
                 scheduler.step(val_acc)                                 # main_both.py:769

@@ -87,8 +87,20 @@ def hip_train_step(model, ids, mask, images, labels, criterion: FusedCrossEntrop
     return loss
 
 
+def stage_images(raw, hw_device, image_pipeline=None, aug_params=None):
+    """Batch images as the DataLoader delivers them -> fp32 [B,3,H,W] in HBM.  A tensor is the per-sample CPU transform's
+    output (copied over); decoded uint8 HWC images (a list, or ``collate_decoded``'s packed batch) go through the GPU
+    pipeline (preprocess.GpuImagePipeline): pad / resize / (augment) / normalise as a handful of launches per batch."""
+    if isinstance(raw, (list, tuple, dict)):
+        n = len(raw["shapes"]) if isinstance(raw, dict) else len(raw)
+        if image_pipeline is None:
+            raise ValueError("decoded image lists need an image_pipeline (main_both.py --gpu_preprocess)")
+        return image_pipeline(raw, aug=aug_params(n) if aug_params is not None else None)
+    return raw.to(hw_device, non_blocking=True)
+
+
 def run_one_epoch(epoch_num, model, data_loader, len_train_data, hw_device, batch_size, train_optimizer, weights,
-                  use_class_weights, acc_steps, smoothing, grad_sync=None, verbose=True):
+                  use_class_weights, acc_steps, smoothing, grad_sync=None, verbose=True, image_pipeline=None, aug_params=None):
     """main_both.py:81-134 (same argument order).  Works with any model exposing the MM_RCA forward; with the HIP
     module the criterion is the fused kernel and the backward is the engine's."""
     batch_loss = []
@@ -104,7 +116,7 @@ def run_one_epoch(epoch_num, model, data_loader, len_train_data, hw_device, batc
         criterion = torch.nn.CrossEntropyLoss(weight=opt_weights, label_smoothing=smoothing).to(hw_device)
     n_loader = len(data_loader)
     for batch_idx, (data, labels) in enumerate(data_loader):
-        images = data['image']['raw_image'].to(hw_device, non_blocking=True)
+        images = stage_images(data['image']['raw_image'], hw_device, image_pipeline, aug_params)
         texts = data['text']
         # the mask is still on the host here: build the packed token layout without a device sync
         pack = make_text_pack(texts['attention_mask'], hw_device) if (fused and PACK_TEXT and not texts['attention_mask'].is_cuda) else None
@@ -130,12 +142,15 @@ def run_one_epoch(epoch_num, model, data_loader, len_train_data, hw_device, batc
             if do_step and acc_steps != 0:
                 print("Optimizer step on batch idx: {}".format(batch_idx))
             print("Batch {}/{} on epoch {}".format(batch_idx, n_batches, epoch_num))
-        batch_loss.append(loss.detach().cpu())
-    return n_batches, batch_loss
+        # the reference copies every batch's loss to the host here (:131), which makes the host wait for the step it has just
+        # queued; the values are only read after the epoch, so they stay on the device until then and the host is free to
+        # stage the next batch (decode hand-over, descriptors, H2D) while the GPU works
+        batch_loss.append(loss.detach())
+    return n_batches, [l.cpu() for l in batch_loss]
 
 
 def calculate_set_accuracy(model, data_loader, len_data, device, batch_size, mode, eval_mode, verbose=True,
-                           all_reduce=None, n_real=None):
+                           all_reduce=None, n_real=None, image_pipeline=None, aug_params=None):
     """main_both.py:141-198.  Returns (accuracy %, sklearn classification report dict).
     n_real: only the first n_real samples this rank draws are scored (ShardedSampler.num_real: the rest is the wrap-around
     padding that equalises the ranks and would otherwise be counted twice)."""
@@ -144,7 +159,7 @@ def calculate_set_accuracy(model, data_loader, len_data, device, batch_size, mod
     correct, seen = 0, 0
     with torch.no_grad():
         for batch_idx, (data, labels) in enumerate(data_loader):
-            images = data['image']['raw_image'].to(device)
+            images = stage_images(data['image']['raw_image'], device, image_pipeline, aug_params)
             texts = data['text']
             ids, mask = texts['tokens'].to(device), texts['attention_mask'].to(device)
             labels = labels.to(device)

@@ -263,6 +263,44 @@ typedef struct {
 int mmrca_image_preprocess(const void* staging, const void* desc /* MmrcaImageDesc[B], device */, float* out, int B,
                            int out_h, int out_w, const float* mean3 /* host */, const float* std3 /* host */, void* stream);
 
+/* K7b (row f1, training side): the six remaining augmentations of the reference's TRAIN_PIPELINE (main_both.py:407-429)
+ * as per-image descriptors executed on the GPU.  The random draws (which transforms fire, with which parameters) are
+ * made on the host (preprocess.py::sample_train_params follows albumentations' distributions); the kernels are
+ * deterministic functions of the descriptors.  Stage order = the reference's:
+ *   A.Rotate(crop_border) -> PadToMaintainAR -> A.Resize -> A.GaussianBlur -> V/H flip -> A.RandomBrightnessContrast ->
+ *   A.Sharpen -> A.Perspective -> A.ShiftScaleRotate(scale only) -> A.Normalize -> ToTensorV2
+ * uint8 re-quantisation between stages is kept (cv2 returns uint8 images).  See garbage_classification_rca_amd/csrc/augment.hip
+ * for the arithmetic of each stage. */
+typedef struct {
+  int64_t src_offset;        /* decoded image in the staging buffer */
+  int64_t dst_offset;        /* where the rotated + cropped image goes (same buffer, past the sources) */
+  int32_t h, w;              /* source size */
+  int32_t dh, dw;            /* size after crop_border */
+  int32_t x_min, y_min;      /* crop origin in the rotated (h x w) frame */
+  int32_t enabled, pad_;
+  float inv[6];              /* rotated-frame pixel (x, y) -> source pixel: sx = inv0 x + inv1 y + inv2, sy = inv3 x + inv4 y + inv5 */
+} MmrcaRotateDesc;             /* 72 bytes */
+int mmrca_image_rotate_crop(void* staging, const void* desc /* MmrcaRotateDesc[B], device */, int B, int max_pixels, void* stream);
+/* PadToMaintainAR + Resize only (no flips, no normalisation): uint8 [B, out_h, out_w, 3] for the stages below */
+int mmrca_image_resize_u8(const void* staging, const void* desc /* MmrcaImageDesc[B] */, void* out_u8, int B, int out_h, int out_w,
+                          void* stream);
+typedef struct {
+  float blur[7];             /* 1-D Gaussian taps; the 2-D weight is blur[i] * blur[j] */
+  int32_t blur_k;            /* 0 = off, else 3 / 5 / 7 */
+  int32_t flip_v, flip_h;
+  int32_t has_bc;            /* brightness/contrast: v = trunc(clip(v * bc_alpha + bc_beta, 0, 255)) */
+  float bc_alpha, bc_beta;
+  int32_t has_sharp;         /* 3x3 correlation, reflect-101 border, round-to-nearest-even, saturate */
+  float sharp[9];
+  int32_t has_persp;         /* output pixel -> input pixel homography (keep_size resize folded in), constant border 0 */
+  float persp[9];
+  int32_t has_scale;         /* output pixel -> input pixel affine map of ShiftScaleRotate */
+  float scale[6];
+} MmrcaAugDesc;                /* 160 bytes */
+/* in_u8 / tmp_u8: uint8 [B, H, W, 3] (in_u8 is overwritten); out: fp32 [B, 3, H, W], normalised */
+int mmrca_image_augment(void* in_u8, void* tmp_u8, const void* desc /* MmrcaAugDesc[B], device */, float* out, int B, int H, int W,
+                        const float* mean3 /* host */, const float* std3 /* host */, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

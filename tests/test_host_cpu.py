@@ -460,3 +460,64 @@ def test_gradient_sync_two_producers_accumulation_and_bf16_wire_world2():
         assert torch.allclose(flat16, want, rtol=1e-2) and nbytes16 == 96 * 2      # half the bytes on the wire
     assert res[0]["num_real"][:2] == (4, 4) and res[1]["num_real"][:2] == (4, 3)
     assert res[0]["num_real"][2] == (7, 7) and res[0]["seed"] == res[1]["seed"]
+
+
+def test_train_augmentation_planning_matches_the_oracle_and_the_c_structs():
+    """Host side of row f1's training path: the per-image descriptors (preprocess.py::plan_*) against the oracle's
+    restatement of albumentations' geometry, the descriptor dtypes against the C structs, and the sampler's firing rates."""
+    from oracle import transforms as T
+    from garbage_classification_rca_amd import preprocess as P
+    assert P.ROT_DTYPE.itemsize == 72 and P.AUG_DTYPE.itemsize == 160
+    hdr = open(os.path.join(ROOT, "include", "mmrca.h")).read()
+    for f in P.AUG_DTYPE.names:
+        assert re.search(r"\b%s\b" % f, hdr), f
+    rng = np.random.default_rng(3)
+    for _ in range(50):
+        h, w, ang = int(rng.integers(20, 500)), int(rng.integers(20, 500)), float(rng.uniform(-90, 90))
+        inv, x_min, y_min, dh, dw = P.plan_rotation(h, w, ang)
+        x0, x1, y0, y1 = T.rotated_rect_with_max_area(h, w, ang)
+        assert (x_min, y_min, dh, dw) == (x0, y0, y1 - y0, x1 - x0)
+        assert 0 <= x_min and x_min + dw <= w and 0 <= y_min and y_min + dh <= h
+        j = np.mod(np.abs(rng.normal(0, 0.08, (4, 2))), 1.0)
+        assert np.allclose(P.plan_perspective(h, w, j), T.perspective_matrix(h, w, j).reshape(9), rtol=2e-5, atol=1e-6)    # closed form vs the oracle's 8x8 solve
+        a, l = float(rng.uniform(0.2, 0.5)), float(rng.uniform(0.5, 1.0))
+        assert np.allclose(P.sharpen_kernel(a, l), T.sharpen_matrix(a, l).reshape(9), rtol=0, atol=1e-7)
+        assert abs(P.sharpen_kernel(a, l).sum() - (1.0 - a + a * l)) < 1e-5     # (1 - alpha) * 1 + alpha * lightness
+    # rotating by 0 keeps the whole image; the crop of a 45-degree rotation of a square is about 1/sqrt 2 of its side... /2
+    assert P.plan_rotation(100, 100, 0.0)[1:] == (0, 0, 100, 100)
+    _, _, _, dh, dw = P.plan_rotation(100, 100, 45.0)
+    assert 68 <= dh <= 72 and dh == dw
+    ps = P.sample_train_params(np.random.default_rng(0), 4000, 0.3)
+    for key in ("angle", "blur_k", "bc", "sharpen", "persp", "scale"):
+        rate = np.mean([p.get(key) is not None for p in ps])
+        assert abs(rate - 0.3) < 0.03, (key, rate)
+    assert abs(np.mean([p["flip_v"] for p in ps]) - 0.3) < 0.03
+    angles = np.array([p["angle"] for p in ps if "angle" in p]); scales = np.array([p["scale"] for p in ps if "scale" in p])
+    assert -90 <= angles.min() and angles.max() <= 90 and abs(angles.mean()) < 6
+    assert 0.5 <= scales.min() and scales.max() <= 1.5 and abs(scales.mean() - 1.0) < 0.03
+    assert set(p["blur_k"] for p in ps if "blur_k" in p) == {3, 5, 7}
+    assert P.sample_train_params(np.random.default_rng(0), 10, 0.0) == [dict(flip_v=False, flip_h=False)] * 10
+
+
+def test_oracle_train_pipeline_stage_properties():
+    """Size-independent properties of the restated augmentations (no golden vectors exist for them: parity unpinned)."""
+    from oracle import transforms as T
+    rng = np.random.default_rng(4)
+    img = rng.integers(0, 256, (60, 44, 3), dtype=np.uint8)
+    const = np.full((40, 50, 3), 93, dtype=np.uint8)
+    assert np.array_equal(T.rotate_crop_u8(img, 0.0), img) and np.array_equal(T.scale_u8(img, 1.0), img)
+    sq = rng.integers(0, 256, (48, 48, 3), dtype=np.uint8)
+    x0, x1, y0, y1 = T.rotated_rect_with_max_area(48, 48, 90.0)
+    assert x1 - x0 >= 47 and y1 - y0 >= 47
+    assert np.array_equal(T.rotate_crop_u8(sq, 90.0), np.rot90(sq, 1)[y0:y1, x0:x1])      # +angle = counter-clockwise on the screen
+    for k in (3, 5, 7):
+        assert np.array_equal(T.gaussian_blur_u8(const, k), const) and abs(sum(T.BLUR_TAPS[k]) - 1.0) < 1e-12
+    assert np.array_equal(T.sharpen_u8(const, 0.4, 1.0), const)                     # lightness 1: the weights sum to 1
+    assert np.array_equal(T.brightness_contrast_u8(img, 1.0, 0.0), img)
+    assert T.brightness_contrast_u8(img, 1.2, 0.2).min() >= 51 and T.brightness_contrast_u8(img, 0.8, -0.2).max() <= 153
+    r = T.rotate_crop_u8(const, 37.0)
+    assert r.size > 0 and np.all(r[1:-1, 1:-1] == 93)           # crop_border: at most the outermost ring blends with the border
+    p = T.perspective_u8(const, np.full((4, 2), 0.08))
+    assert np.all(p == 93)                                                          # the jittered quadrilateral lies inside
+    z = T.scale_u8(const, 0.5)
+    assert z[0, 0, 0] == 0 and z[20, 25, 0] == 93 and abs(int((z[..., 0] == 93).sum()) - 20 * 25) <= 50
