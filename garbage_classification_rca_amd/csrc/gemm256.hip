@@ -92,25 +92,24 @@ __global__ void __launch_bounds__(512, 2)
 gemm_mfma256_k(const bf16_t* __restrict__ A, const bf16_t* __restrict__ B, bf16_t* __restrict__ C, const bf16_t* __restrict__ bias,
                const bf16_t* __restrict__ addend, bf16_t* __restrict__ preact, int64_t M, int64_t N, int64_t K,
                int64_t lda, int64_t ldb, int64_t ldc, int tiles_m, int tiles_n, int ksteps_base, int ksteps_rem,
-               float* __restrict__ slab, float* __restrict__ colsum) {
+               float* __restrict__ slab, float* __restrict__ colsum, int splits) {
   constexpr bool SLAB = MODE == MODE_SLAB;
   extern __shared__ __attribute__((aligned(16))) char smem[];     // [2 stages][A0 A1 B0 B1]
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
   const int wr = wave >> 2, wc = wave & 3;
 
   const int nwg = tiles_m * tiles_n;
-  const int orig = blockIdx.x;
-  const int q8 = nwg >> 3, r8 = nwg & 7, xcd = orig & 7;
-  const int wgid = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (orig >> 3);
-  const int GROUP = 4;
-  const int group = wgid / (GROUP * tiles_n);
-  const int first_m = group * GROUP;
-  const int gsize = (tiles_m - first_m) < GROUP ? (tiles_m - first_m) : GROUP;
-  const int tm = first_m + (wgid % (GROUP * tiles_n)) % gsize;
-  const int tn = (wgid % (GROUP * tiles_n)) / gsize;
+  // One-dimensional grid of tiles x K-ranges (rounded up to a multiple of 8).  All tiles of a K-range read the SAME rows of
+  // both operands, so they are placed on ONE XCD (workgroup id % 8, observed round-robin placement: speed only): that
+  // XCD's L2 fetches the rows once and the launch's HBM traffic falls from ~2x to ~1x the algorithmic bytes.
+  const int total = nwg * splits;
+  const int per_xcd = (total + 7) >> 3;
+  const int idx = ((int)blockIdx.x & 7) * per_xcd + ((int)blockIdx.x >> 3);
+  if (((int)blockIdx.x >> 3) >= per_xcd || idx >= total) return;
+  const int yb = idx / nwg, wgid = idx - yb * nwg;
+  const int tm = wgid / tiles_n, tn = wgid - tm * tiles_n;
   const int64_t m_blk = (int64_t)tm * 256, n_blk = (int64_t)tn * 256;
   // split-K: range y covers ksteps_base (+1 for the first ksteps_rem ranges) K-tiles
-  const int yb = (int)blockIdx.y;
   const int64_t kbeg = SLAB ? 64 * ((int64_t)yb * ksteps_base + (yb < ksteps_rem ? yb : ksteps_rem)) : 0;
   const int nt = SLAB ? ksteps_base + (yb < ksteps_rem ? 1 : 0) : (int)(K / 64);     // >= 2 (host-checked)
 
@@ -241,7 +240,7 @@ gemm_mfma256_k(const bf16_t* __restrict__ A, const bf16_t* __restrict__ B, bf16_
   if (!wr) BARRIER();                   // group 0 waits for group 1's last segment
 
   if constexpr (SLAB) {
-    float* dst = slab + ((int64_t)blockIdx.y * nwg + (int64_t)tm * tiles_n + tn) * 65536 + wave * 8192 + lane * 4;
+    float* dst = slab + ((int64_t)yb * nwg + (int64_t)tm * tiles_n + tn) * 65536 + wave * 8192 + lane * 4;
 #pragma unroll
     for (int a = 0; a < 2; ++a)
 #pragma unroll
@@ -655,9 +654,9 @@ extern "C" int mmrca_gemm_splitk(const void* A, const void* B, float* C, void* w
 #define LSLAB(AK_, BK_)                                                                                                          \
   do {                                                                                                                           \
     (void)hipFuncSetAttribute((const void*)gemm_mfma256_k<AK_, BK_, MODE_SLAB>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS256_BYTES); \
-    hipLaunchKernelGGL((gemm_mfma256_k<AK_, BK_, MODE_SLAB>), dim3(tiles, splits), dim3(512), LDS256_BYTES, st, (const bf16_t*)A,      \
+    hipLaunchKernelGGL((gemm_mfma256_k<AK_, BK_, MODE_SLAB>), dim3((tiles * splits + 7) / 8 * 8), dim3(512), LDS256_BYTES, st, (const bf16_t*)A,      \
                        (const bf16_t*)B, (bf16_t*)nullptr, (const bf16_t*)nullptr, (const bf16_t*)nullptr, (bf16_t*)nullptr, M, N, K, \
-                       lda, ldb, ldc, tiles_m, tiles_n, ksteps_base, ksteps_rem, (float*)workspace, (float*)nullptr);           \
+                       lda, ldb, ldc, tiles_m, tiles_n, ksteps_base, ksteps_rem, (float*)workspace, (float*)nullptr, splits);   \
   } while (0)
   if (!ak && !bk) LSLAB(false, false);
   else if (!ak && bk) LSLAB(false, true);

@@ -322,3 +322,46 @@ def test_mm_rca_with_conv_backbone_fp32_logits_and_train_step(image_model, size)
     lo, hi = eng.groups["image_emb"]
     assert float(eng.arena.g[lo:hi].abs().max()) > 0
     eng.release_buffers()
+
+
+def test_facade_state_dict_of_the_default_image_model_has_the_reference_layout_and_loads_it():
+    """SURVEY.md section 8 row a4 for the reference's default image model (EfficientNetV2-M, multimodal_model.py:113-126,
+    wrapped by EfficientNetV2MFullFeatureExtractor :11-36): ``MM_RCA(...).state_dict()`` carries exactly the image_model.* keys
+    (parameters AND BatchNorm buffers, incl. num_batches_tracked) and shapes that the reference module tree produces, and a
+    checkpoint shaped like the reference's loads and reproduces the oracle's logits."""
+    from garbage_classification_rca_amd.multimodal_model import MM_RCA
+    from garbage_classification_rca_amd.procedural import synth_captions
+    size, B = 64, 2
+    m = MM_RCA(4, 0.0, 0.0, 0.0, 256, "distilbert", B, True, False, False, image_model_name="eff_v2_medium", dtype=torch.float32,
+               device=torch.device("cuda:0"), image_size=size)
+    orc = O.build_oracle("distilbert", "eff_v2_medium", True, False, False, drop_ratio=0.0, enc_dropout=0.0).eval()
+    ref_img = {("image_model." + k): tuple(v.shape) for k, v in orc.image_model.state_dict().items()}
+    own = {k: tuple(v.shape) for k, v in m.state_dict().items() if k.startswith("image_model.")}
+    assert own == ref_img, (sorted(set(own) ^ set(ref_img))[:10])
+    assert sum(k.endswith("num_batches_tracked") for k in own) == sum(k.endswith("running_mean") for k in own) > 100
+    # a reference-shaped checkpoint: the oracle's image tree with non-trivial BatchNorm statistics
+    g = torch.Generator().manual_seed(4)
+    ck = dict(m.state_dict())
+    for k, v in orc.image_model.state_dict().items():
+        if k.endswith("running_var"):
+            v = 0.5 + torch.rand(v.shape, generator=g)
+        elif k.endswith("running_mean"):
+            v = 0.1 * torch.randn(v.shape, generator=g)
+        elif k.endswith("num_batches_tracked"):
+            v = torch.tensor(7)
+        ck["image_model." + k] = v.clone()
+    orc.image_model.load_state_dict({k[len("image_model."):]: v for k, v in ck.items() if k.startswith("image_model.")})
+    res = m.load_state_dict(ck)
+    assert not res.missing_keys and not res.unexpected_keys
+    sd = {k: v.detach().cpu() for k, v in m.state_dict().items()}
+    assert int(sd["image_model.stem.0.1.num_batches_tracked"]) == 7
+    orc.text_model.load_flat(sd, "text_model.")
+    orc.load_state_dict({k: v for k, v in sd.items() if not k.startswith(("text_model.", "image_model."))}, strict=False)
+    ids, mask = (torch.from_numpy(a) for a in synth_captions(B, 24, seed=2))
+    images = torch.randn(B, 3, size, size, generator=g)
+    m.eval()
+    with torch.no_grad():
+        out = m(_input_ids=ids.cuda(), _attention_mask=mask.cuda(), _images=images.cuda(), eval=True)
+        ref = orc(ids, mask, images, eval=True)
+    assert rel(out, ref) < 1e-3, rel(out, ref)
+    m.engine.release_buffers()

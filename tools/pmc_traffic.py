@@ -24,7 +24,7 @@ out, gem_b, gem_n = {}, 0.0, 0
 for k in sorted(fe, key=lambda k: -fe[k][0]):
     n = fe[k][1]
     f, w = fe[k][0] / n, (wr[k][0] / wr[k][1] if k in wr and wr[k][1] else 0.0)
-    is_gemm = k.startswith("gemm_mfma")
+    is_gemm = k.startswith(("gemm_mfma", "gemm_p256"))
     row = {"launches_seen": n, "fetch_bytes_per_launch_reported": round(f), "write_bytes_per_launch": round(w)}
     if is_gemm:
         row["fetch_bytes_per_launch_corrected_x2"] = round(2 * f)
