@@ -111,6 +111,133 @@ gemm_ref_k(const T* __restrict__ A, const T* __restrict__ B, void* __restrict__ 
 }
 
 // ======================================================================================================
+// gemm_gen_k: the general-shape kernel on the fp32 matrix cores (v_mfma_f32_32x32x2_f32), any dtype / layout / shape
+// ======================================================================================================
+// Same contract and epilogue as gemm_ref_k at about twice its speed (64-72 vs 31-35 TFLOP/s on the fp32 encoder shapes,
+// 157 peak): it is what AUTO runs for fp32 (the "<= 1e-3" mode, bench.py --dtype fp32) and for bf16 shapes the bf16 MFMA
+// kernels cannot take (the conv backbones' channel counts).  Operands are converted to fp32 while they are staged
+// (scalar, predicated loads), products accumulate in fp32, and -- like gemm_ref_k -- the running sum is folded into a
+// second accumulator every 64 k and a third every 1024 k so that the rounding error of a long dot product (K = 50 k in
+// the weight gradients) does not grow with sqrt(K).  128x64 tile, four waves of 32x64 (two MFMA tiles), K step 16,
+// double-buffered LDS with one barrier per step.  MFMA operand layout (32x32x2): lane l supplies A[l%32][l/32] and
+// B[l/32][l%32]; a lane that holds four consecutive k of its row feeds four MFMAs (k slot of MFMA m = 4 (l/32) + m: a
+// permutation of the 8 k of a chunk, the same for both operands).
+// (Measured and dropped: 16-byte group loads for the staging -- more registers, 47-55 TFLOP/s on the fp32 shapes, and the
+// small-K conv shapes stay latency-bound at 20-35 TFLOP/s either way; they need their own bf16 kernel.)
+typedef float f32x16g __attribute__((ext_vector_type(16)));
+typedef float f32x4g __attribute__((ext_vector_type(4)));
+#define GEN_LD 20     // LDS row pitch in floats (16 k + 4 pad)
+
+template <typename T>
+__global__ void __launch_bounds__(256)
+gemm_gen_k(const T* __restrict__ A, const T* __restrict__ B, void* __restrict__ Cv, const T* __restrict__ bias,
+           const T* __restrict__ addend, T* __restrict__ preact, int64_t M, int64_t N, int64_t K,
+           int64_t sam, int64_t sak, int64_t sbn, int64_t sbk, int64_t ldc, int act, int accum, int tiles_n) {
+  __shared__ __attribute__((aligned(16))) float As[2][128 * GEN_LD], Bs[2][64 * GEN_LD];
+  const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+  const int64_t m0 = (int64_t)(blockIdx.x / tiles_n) * 128, n0 = (int64_t)(blockIdx.x % tiles_n) * 64;
+  f32x16g acc[2], mid[2], tot[2];      // three-level summation: 64 k -> 1024 k -> the rest (see gemm_ref_k)
+#pragma unroll
+  for (int j = 0; j < 2; ++j)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { acc[j][r] = 0.f; mid[j][r] = 0.f; tot[j][r] = 0.f; }
+  // staging map: element e = t + 256 i of a (128 | 64) x 16 tile; consecutive lanes follow the operand's contiguous dimension
+  float ra[8], rb[4];
+  auto fetch = [&](int64_t k0) {
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const int e = t + 256 * i;
+      const int arow = sak == 1 ? e >> 4 : e & 127, ak = sak == 1 ? e & 15 : e >> 7;
+      const int64_t gm = m0 + arow;
+      ra[i] = (gm < M && k0 + ak < K) ? to_f(A[gm * sam + (k0 + ak) * sak]) : 0.f;
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int e = t + 256 * i;
+      const int brow = sbk == 1 ? e >> 4 : e & 63, bk = sbk == 1 ? e & 15 : e >> 6;
+      const int64_t gn = n0 + brow;
+      rb[i] = (gn < N && k0 + bk < K) ? to_f(B[gn * sbn + (k0 + bk) * sbk]) : 0.f;
+    }
+  };
+  auto stash = [&](int buf) {
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const int e = t + 256 * i;
+      const int arow = sak == 1 ? e >> 4 : e & 127, ak = sak == 1 ? e & 15 : e >> 7;
+      As[buf][arow * GEN_LD + ak] = ra[i];
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int e = t + 256 * i;
+      const int brow = sbk == 1 ? e >> 4 : e & 63, bk = sbk == 1 ? e & 15 : e >> 6;
+      Bs[buf][brow * GEN_LD + bk] = rb[i];
+    }
+  };
+  fetch(0);
+  stash(0);
+  __syncthreads();
+  const int l32 = lane & 31, g = lane >> 5;
+  int step = 0;
+  for (int64_t k0 = 0; k0 < K; k0 += 16, ++step) {
+    const int buf = step & 1;
+    const bool more = k0 + 16 < K;
+    if (more) fetch(k0 + 16);
+#pragma unroll
+    for (int c = 0; c < 2; ++c) {
+      const f32x4g a = *reinterpret_cast<const f32x4g*>(&As[buf][(32 * wave + l32) * GEN_LD + 8 * c + 4 * g]);
+      f32x4g b[2];
+#pragma unroll
+      for (int j = 0; j < 2; ++j) b[j] = *reinterpret_cast<const f32x4g*>(&Bs[buf][(32 * j + l32) * GEN_LD + 8 * c + 4 * g]);
+#pragma unroll
+      for (int m = 0; m < 4; ++m)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[m], b[j][m], acc[j], 0, 0, 0);
+    }
+    if ((step & 3) == 3) {
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        mid[j] += acc[j];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
+      }
+      if ((step & 63) == 63) {
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+          tot[j] += mid[j];
+#pragma unroll
+          for (int r = 0; r < 16; ++r) mid[j][r] = 0.f;
+        }
+      }
+    }
+    if (more) stash(buf ^ 1);
+    __syncthreads();
+  }
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+    const f32x16g sum = tot[j] + (mid[j] + acc[j]);
+    const int64_t n = n0 + 32 * j + l32;
+    if (n >= N) continue;
+    const float bn = bias ? to_f(bias[n]) : 0.f;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int64_t m = m0 + 32 * wave + 8 * (r >> 2) + 4 * g + (r & 3);
+      if (m >= M) continue;
+      float v = sum[r] + bn;
+      if (act == MMRCA_ACT_GELU_SAVE_GRAD) { preact[m * ldc + n] = from_f<T>(gelu_grad_f(v)); v = gelu_f(v); }
+      else if (act == MMRCA_ACT_MUL) v *= to_f(preact[m * ldc + n]);
+      else if (act == MMRCA_ACT_GELU_BWD) v *= gelu_grad_f(to_f(preact[m * ldc + n]));
+      else {
+        if (preact) preact[m * ldc + n] = from_f<T>(v);
+        if (act == MMRCA_ACT_GELU) v = gelu_f(v);
+      }
+      if (addend) v += to_f(addend[m * ldc + n]);
+      if (accum) ((float*)Cv)[m * ldc + n] += v;
+      else ((T*)Cv)[m * ldc + n] = from_f<T>(v);
+    }
+  }
+}
+
+// ======================================================================================================
 // MFMA kernel
 // ======================================================================================================
 #define GBM 128
@@ -1729,6 +1856,17 @@ static int gemm_dispatch(const void* A, const void* B, void* C, const void* bias
   }
   const int64_t sam = a_layout == MMRCA_ROWK ? lda : 1, sak = a_layout == MMRCA_ROWK ? 1 : lda;
   const int64_t sbn = b_layout == MMRCA_ROWK ? ldb : 1, sbk = b_layout == MMRCA_ROWK ? 1 : ldb;
+  // AUTO: the fp32-matrix-core kernel; impl == REF (or MMRCA_GEMM_GEN=0): the VALU reference kernel
+  static const bool gen_on = !(getenv("MMRCA_GEMM_GEN") && atoi(getenv("MMRCA_GEMM_GEN")) == 0);
+  if (impl != MMRCA_GEMM_REF && gen_on) {
+    const int64_t tm = (M + 127) / 128, tn = (N + 63) / 64;
+    MMRCA_REQUIRE(tm * tn < (1ll << 31), "gemm(gen): too many tiles");
+    MMRCA_DISPATCH_DTYPE(dtype, "gemm",
+      hipLaunchKernelGGL(gemm_gen_k<T>, dim3((unsigned)(tm * tn)), dim3(256), 0, st, (const T*)A, (const T*)B, C, (const T*)bias,
+                         (const T*)addend, (T*)preact, M, N, K, sam, sak, sbn, sbk, ldc, act, out_f32_accum, (int)tn);)
+    MMRCA_CHECK_LAUNCH("gemm(gen)");
+    return 0;
+  }
   dim3 grid((unsigned)((N + 63) / 64), (unsigned)((M + 63) / 64));
   MMRCA_REQUIRE(grid.y <= 65535, "gemm(ref): M too large for the reference kernel grid");
   MMRCA_DISPATCH_DTYPE(dtype, "gemm",

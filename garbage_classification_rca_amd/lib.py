@@ -182,7 +182,8 @@ def gemm(A, B, Cout, *, bias=None, addend=None, preact=None, M, N, K, lda, ldb, 
          act=ACT_NONE, accum=False, dtype, impl=IMPL_AUTO, colsum=None):
     """colsum (fp32 [N], +=): column sums of the stored C ride on the GEMM epilogue (mmrca_gemm_colsum)"""
     _dev(A, "gemm A")
-    prof = GEMM_PROFILE is not None and gemm_is_mfma(M, N, K, a_layout, dtype, impl)
+    # matrix-core launches: the bf16 MFMA kernels, and in fp32 mode the general kernel on the fp32 matrix cores
+    prof = GEMM_PROFILE is not None and (gemm_is_mfma(M, N, K, a_layout, dtype, impl) or (dtype == F32 and impl != IMPL_REF))
     if prof:
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
