@@ -51,6 +51,10 @@ CONCURRENT_ENCODERS = os.environ.get("MMRCA_CONCURRENT_ENCODERS", "1") == "1"
 CLS_TAIL = os.environ.get("MMRCA_CLS_TAIL", "1") == "1"
 # weight gradients on the 256x256 split-K kernel (mmrca_gemm_splitk) wherever the shape qualifies; "0" = 128x128 + fp32 atomics
 SPLITK_WGRAD = os.environ.get("MMRCA_SPLITK_WGRAD", "1") == "1"
+# ViT residual adds ride on the NEXT LayerNorm (add_layernorm: s = x + res, y = LN(s)) instead of the GEMM epilogue: the
+# out-projection and FFN2 forward GEMMs become bias-only and qualify for the persistent 256x256 kernel (1,050-1,150 TFLOP/s
+# against 780 for the 128x128 kernel with its addend read); the LayerNorm reads one more operand and writes the sum.
+LN_RESIDUAL = os.environ.get("MMRCA_LN_RESIDUAL", "1") == "1"
 ROWPAD = 256         # (the persistent 256x256 GEMM reads whole 256-row tiles of its A operand)
 
 
@@ -598,10 +602,17 @@ class MMRCAEngine:
         x = fb("x", M, D, 0)
         L.vit_assemble_fwd(proj, self.W(P + "class_token"), self.W(P + "encoder.pos_embedding"), x, B, nP, D, self.dt)
         layers = []
+        fuse_res = LN_RESIDUAL and self.dt == L.BF16
+        pend = None                      # (ffn2 output, x1) of the previous layer whose sum -- this layer's input -- is still to be formed
         for i in range(s.layers):
             Lk = P + f"encoder.layers.encoder_layer_{i}."
             y1, m1, r1 = fb("y1", M, D, i), stat("m1", i), stat("r1", i)
-            self._ln_fwd(x, None, Lk + "ln_1", None, y1, m1, r1, M, D, s.ln_eps)
+            if pend is None:
+                self._ln_fwd(x, None, Lk + "ln_1", None, y1, m1, r1, M, D, s.ln_eps)
+            else:
+                x = fb("x", M, D, i)
+                self._ln_fwd(pend[0], pend[1], Lk + "ln_1", x, y1, m1, r1, M, D, s.ln_eps)       # x = ffn2 + x1 (previous layer), y1 = LN(x)
+                pend = None
             qkv, ctx = fb("qkv", M, 3 * D, i), fb("ctx", M, D, i)
             lse = self.buf("v_lse", 1, _round_up(B * H * Tn, ROWPAD), torch.float32, i if save else 0)
             self._lin_fwd(y1, Lk + "self_attention.in_proj_weight", Lk + "self_attention.in_proj_bias", qkv, M, 3 * D, D)
@@ -628,18 +639,32 @@ class MMRCAEngine:
                 return feat[:B], dict(B=B, patches=patches, xL=xn, mf=mf, rf=rf, layers=layers)
             L.mha_fwd(qkv, None, ctx, lse, B, H, Tn, dh, dh ** -0.5, self.dt, self.attn_impl)
             x1 = fb("x1", M, D, i)
-            self._lin_fwd(ctx, Lk + "self_attention.out_proj.weight", Lk + "self_attention.out_proj.bias", x1, M, D, D, addend=x)
             y2, m2, r2 = fb("y2", M, D, i), stat("m2", i), stat("r2", i)
-            self._ln_fwd(x1, None, Lk + "ln_2", None, y2, m2, r2, M, D, s.ln_eps)
+            if fuse_res:
+                ao = fb("attn_o", M, D, 0)
+                self._lin_fwd(ctx, Lk + "self_attention.out_proj.weight", Lk + "self_attention.out_proj.bias", ao, M, D, D)
+                self._ln_fwd(ao, x, Lk + "ln_2", x1, y2, m2, r2, M, D, s.ln_eps)                 # x1 = attention output + x, y2 = LN(x1)
+            else:
+                self._lin_fwd(ctx, Lk + "self_attention.out_proj.weight", Lk + "self_attention.out_proj.bias", x1, M, D, D, addend=x)
+                self._ln_fwd(x1, None, Lk + "ln_2", None, y2, m2, r2, M, D, s.ln_eps)
             h, g = fb("h", M, Fd, i), fb("g", M, Fd, i)
             self._lin_fwd(y2, Lk + "mlp.0.weight", Lk + "mlp.0.bias", g, M, Fd, D, act=(L.ACT_GELU_SAVE_GRAD if FUSE_GELU_GRAD else L.ACT_GELU), preact=h)   # fused mode: h <- gelu'(pre-activation)
-            xn = fb("x", M, D, i + 1)
-            self._lin_fwd(g, Lk + "mlp.3.weight", Lk + "mlp.3.bias", xn, M, D, Fd, addend=x1)
             layers.append(dict(x=x, y1=y1, m1=m1, r1=r1, qkv=qkv, ctx=ctx, lse=lse, x1=x1, y2=y2, m2=m2, r2=r2, h=h, g=g))
-            x = xn
+            if fuse_res:
+                f2 = fb("ffn_o", M, D, 0)
+                self._lin_fwd(g, Lk + "mlp.3.weight", Lk + "mlp.3.bias", f2, M, D, Fd)
+                pend = (f2, x1)
+            else:
+                xn = fb("x", M, D, i + 1)
+                self._lin_fwd(g, Lk + "mlp.3.weight", Lk + "mlp.3.bias", xn, M, D, Fd, addend=x1)
+                x = xn
         feat = self.buf("v_feat", B, D)
         mf, rf = stat("mf"), stat("rf")
-        self._ln_fwd(x, None, P + "encoder.ln", None, feat, mf, rf, B, D, s.ln_eps, ld_x=Tn * D, ld_y=D)
+        if pend is None:
+            self._ln_fwd(x, None, P + "encoder.ln", None, feat, mf, rf, B, D, s.ln_eps, ld_x=Tn * D, ld_y=D)
+        else:               # class-token rows only: x = ffn2 + x1 of the top layer at rows b*Tn
+            x = fb("x", M, D, s.layers)
+            self._ln_fwd(pend[0], pend[1], P + "encoder.ln", x, feat, mf, rf, B, D, s.ln_eps, ld_x=Tn * D, ld_y=D)
         return feat[:B], dict(B=B, patches=patches, xL=x, mf=mf, rf=rf, layers=layers)
 
     def _vision_backward(self, dfeat, sv):
