@@ -132,8 +132,13 @@ template <typename T>
 __global__ void __launch_bounds__(256)
 gemm_gen_k(const T* __restrict__ A, const T* __restrict__ B, void* __restrict__ Cv, const T* __restrict__ bias,
            const T* __restrict__ addend, T* __restrict__ preact, int64_t M, int64_t N, int64_t K,
-           int64_t sam, int64_t sak, int64_t sbn, int64_t sbk, int64_t ldc, int act, int accum, int tiles_n) {
+           int64_t sam, int64_t sak, int64_t sbn, int64_t sbk, int64_t ldc, int act, int accum, int tiles_n, int64_t ksplit_len) {
   __shared__ __attribute__((aligned(16))) float As[2][128 * GEN_LD], Bs[2][64 * GEN_LD];
+  // accumulate mode with few tiles and a long contraction (conv weight gradients: K = B*H*W rows): blockIdx.y owns a K range and
+  // adds its partial product with fp32 atomics
+  const int64_t kbeg = (int64_t)blockIdx.y * ksplit_len;
+  const int64_t Kend = kbeg + ksplit_len < K ? kbeg + ksplit_len : K;
+  const bool split = gridDim.y > 1;
   const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
   const int64_t m0 = (int64_t)(blockIdx.x / tiles_n) * 128, n0 = (int64_t)(blockIdx.x % tiles_n) * 64;
   f32x16g acc[2], mid[2], tot[2];      // three-level summation: 64 k -> 1024 k -> the rest (see gemm_ref_k)
@@ -149,14 +154,14 @@ gemm_gen_k(const T* __restrict__ A, const T* __restrict__ B, void* __restrict__ 
       const int e = t + 256 * i;
       const int arow = sak == 1 ? e >> 4 : e & 127, ak = sak == 1 ? e & 15 : e >> 7;
       const int64_t gm = m0 + arow;
-      ra[i] = (gm < M && k0 + ak < K) ? to_f(A[gm * sam + (k0 + ak) * sak]) : 0.f;
+      ra[i] = (gm < M && k0 + ak < Kend) ? to_f(A[gm * sam + (k0 + ak) * sak]) : 0.f;
     }
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
       const int e = t + 256 * i;
       const int brow = sbk == 1 ? e >> 4 : e & 63, bk = sbk == 1 ? e & 15 : e >> 6;
       const int64_t gn = n0 + brow;
-      rb[i] = (gn < N && k0 + bk < K) ? to_f(B[gn * sbn + (k0 + bk) * sbk]) : 0.f;
+      rb[i] = (gn < N && k0 + bk < Kend) ? to_f(B[gn * sbn + (k0 + bk) * sbk]) : 0.f;
     }
   };
   auto stash = [&](int buf) {
@@ -173,14 +178,14 @@ gemm_gen_k(const T* __restrict__ A, const T* __restrict__ B, void* __restrict__ 
       Bs[buf][brow * GEN_LD + bk] = rb[i];
     }
   };
-  fetch(0);
+  fetch(kbeg);
   stash(0);
   __syncthreads();
   const int l32 = lane & 31, g = lane >> 5;
   int step = 0;
-  for (int64_t k0 = 0; k0 < K; k0 += 16, ++step) {
+  for (int64_t k0 = kbeg; k0 < Kend; k0 += 16, ++step) {
     const int buf = step & 1;
-    const bool more = k0 + 16 < K;
+    const bool more = k0 + 16 < Kend;
     if (more) fetch(k0 + 16);
 #pragma unroll
     for (int c = 0; c < 2; ++c) {
@@ -231,7 +236,7 @@ gemm_gen_k(const T* __restrict__ A, const T* __restrict__ B, void* __restrict__ 
         if (act == MMRCA_ACT_GELU) v = gelu_f(v);
       }
       if (addend) v += to_f(addend[m * ldc + n]);
-      if (accum) ((float*)Cv)[m * ldc + n] += v;
+      if (accum) { if (split) atomicAdd((float*)Cv + m * ldc + n, v); else ((float*)Cv)[m * ldc + n] += v; }
       else ((T*)Cv)[m * ldc + n] = from_f<T>(v);
     }
   }
@@ -1861,9 +1866,17 @@ static int gemm_dispatch(const void* A, const void* B, void* C, const void* bias
   if (impl != MMRCA_GEMM_REF && gen_on) {
     const int64_t tm = (M + 127) / 128, tn = (N + 63) / 64;
     MMRCA_REQUIRE(tm * tn < (1ll << 31), "gemm(gen): too many tiles");
+    int64_t splits = 1, ksplit_len = K;
+    if (out_f32_accum && tm * tn < 128 && K >= 4096) {       // fill ~512 workgroup slots, at least 1024 k per range
+      splits = (512 + tm * tn - 1) / (tm * tn);
+      if (splits > K / 1024) splits = K / 1024;
+      ksplit_len = ((K + splits - 1) / splits + 15) / 16 * 16;
+      splits = (K + ksplit_len - 1) / ksplit_len;
+    }
     MMRCA_DISPATCH_DTYPE(dtype, "gemm",
-      hipLaunchKernelGGL(gemm_gen_k<T>, dim3((unsigned)(tm * tn)), dim3(256), 0, st, (const T*)A, (const T*)B, C, (const T*)bias,
-                         (const T*)addend, (T*)preact, M, N, K, sam, sak, sbn, sbk, ldc, act, out_f32_accum, (int)tn);)
+      hipLaunchKernelGGL(gemm_gen_k<T>, dim3((unsigned)(tm * tn), (unsigned)splits), dim3(256), 0, st, (const T*)A, (const T*)B, C,
+                         (const T*)bias, (const T*)addend, (T*)preact, M, N, K, sam, sak, sbn, sbk, ldc, act, out_f32_accum, (int)tn,
+                         ksplit_len);)
     MMRCA_CHECK_LAUNCH("gemm(gen)");
     return 0;
   }

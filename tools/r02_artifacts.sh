@@ -19,3 +19,11 @@ cp $(find $O/ser -name "*kernel_stats.csv" | head -1) $O/kernel_stats_serialized
 # keep the merged output small: drop the raw traces
 find $O -name "*kernel_trace.csv" -delete; find $O -name "*counter_collection.csv" -delete; find $O -name "*.db" -delete
 ls -la $O; cat $O/bench_default.json
+# secondary lines (not the headline): frozen phase, configs[3], configs[2], configs[0]-shaped run, fp32 mode
+cd $R
+python3 bench.py --frozen --no_cpu_baseline > $O/bench_frozen.json 2>/dev/null
+python3 bench.py --text_model bert --image_model transformer_L16 --cross_attention_only --seq_len 128 --batch 128 --steps 16 --warmup 4 --no_cpu_baseline > $O/bench_cfg3.json 2>/dev/null
+python3 bench.py --image_model eff_v2_large --image_size 480 --batch 128 --steps 3 --warmup 1 --no_cpu_baseline > $O/bench_cfg2.json 2>/dev/null
+python3 bench.py --image_model shuffle_net --batch 4 --steps 16 --warmup 4 --no_cpu_baseline > $O/bench_cfg0.json 2>/dev/null
+python3 bench.py --dtype fp32 --steps 6 --warmup 2 --no_cpu_baseline > $O/bench_fp32.json 2>/dev/null
+for f in frozen cfg3 cfg2 cfg0 fp32; do python3 -c "import json,sys; d=json.load(open('$O/bench_$f.json')); print('$f', d['value'], d['ms_per_step'], d['roofline']['achieved'])"; done
