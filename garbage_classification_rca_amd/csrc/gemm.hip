@@ -141,11 +141,14 @@ gemm_gen_k(const T* __restrict__ A, const T* __restrict__ B, void* __restrict__ 
   const bool split = gridDim.y > 1;
   const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
   const int64_t m0 = (int64_t)(blockIdx.x / tiles_n) * 128, n0 = (int64_t)(blockIdx.x % tiles_n) * 64;
-  f32x16g acc[2], mid[2], tot[2];      // three-level summation: 64 k -> 1024 k -> the rest (see gemm_ref_k)
+  // fp32 operands: three-level summation, 64 k -> 1024 k -> the rest (see gemm_ref_k).  bf16 operands carry 8 bits of
+  // mantissa, a single fp32 running sum is exact enough for them and 64 fewer registers double the resident workgroups
+  constexpr bool LEVELS = sizeof(T) == 4;
+  f32x16g acc[2], mid[LEVELS ? 2 : 1], tot[LEVELS ? 2 : 1];
 #pragma unroll
   for (int j = 0; j < 2; ++j)
 #pragma unroll
-    for (int r = 0; r < 16; ++r) { acc[j][r] = 0.f; mid[j][r] = 0.f; tot[j][r] = 0.f; }
+    for (int r = 0; r < 16; ++r) { acc[j][r] = 0.f; if (LEVELS) { mid[j][r] = 0.f; tot[j][r] = 0.f; } }
   // staging map: element e = t + 256 i of a (128 | 64) x 16 tile; consecutive lanes follow the operand's contiguous dimension
   float ra[8], rb[4];
   auto fetch = [&](int64_t k0) {
@@ -198,7 +201,7 @@ gemm_gen_k(const T* __restrict__ A, const T* __restrict__ B, void* __restrict__ 
 #pragma unroll
         for (int j = 0; j < 2; ++j) acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[m], b[j][m], acc[j], 0, 0, 0);
     }
-    if ((step & 3) == 3) {
+    if (LEVELS && (step & 3) == 3) {
 #pragma unroll
       for (int j = 0; j < 2; ++j) {
         mid[j] += acc[j];
@@ -219,7 +222,7 @@ gemm_gen_k(const T* __restrict__ A, const T* __restrict__ B, void* __restrict__ 
   }
 #pragma unroll
   for (int j = 0; j < 2; ++j) {
-    const f32x16g sum = tot[j] + (mid[j] + acc[j]);
+    const f32x16g sum = LEVELS ? tot[LEVELS ? j : 0] + (mid[LEVELS ? j : 0] + acc[j]) : acc[j];
     const int64_t n = n0 + 32 * j + l32;
     if (n >= N) continue;
     const float bn = bias ? to_f(bias[n]) : 0.f;

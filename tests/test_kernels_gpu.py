@@ -92,6 +92,35 @@ def test_gemm_ref_epilogues(dt):
     _gemm_case(70, 68, 128, 1, 1, dt, L.IMPL_REF, accum=True)
 
 
+@pytest.mark.parametrize("dt", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("layouts", [(0, 0), (0, 1), (1, 1), (1, 0)])
+def test_gemm_general_kernel_on_the_fp32_matrix_cores(dt, layouts):
+    """gemm_gen_k = what AUTO runs for fp32 and for bf16 shapes outside the bf16 MFMA kernels: odd shapes (edge tiles in
+    M, N and K), all operand layouts, every epilogue, accumulate mode, and the split-K path of long-contraction weight
+    gradients (conv: K = B*H*W)."""
+    al, bl = layouts
+    _gemm_case(100, 72, 52, al, bl, dt, L.IMPL_AUTO, bias=True)                       # one partial tile in every dimension
+    _gemm_case(257, 96, 216, al, bl, dt, L.IMPL_AUTO, bias=True, addend=True)         # conv 3x3, 24 -> 96 channels
+    _gemm_case(64, 24, 96, al, bl, dt, L.IMPL_AUTO)                                   # conv 1x1, N below one tile
+    _gemm_case(300, 304, 1824, al, bl, dt, L.IMPL_AUTO, act=L.ACT_GELU, bias=True, preact=True)   # K > 1024: third summation level
+    _gemm_case(70, 68, 128, al, bl, dt, L.IMPL_AUTO, accum=True)
+
+
+@pytest.mark.parametrize("dt", [torch.float32, torch.bfloat16])
+def test_gemm_general_kernel_split_k_weight_gradient(dt):
+    """Few output tiles, long contraction, accumulate mode -> K ranges over blockIdx.y with fp32 atomics."""
+    M, N, K = 96, 216, 40_000
+    g = torch.Generator().manual_seed(3)
+    A = dev(torch.randn(K, M, generator=g) * 0.5, dt)       # KROW operands: dY [rows, cout], X [rows, 9 cin]
+    Bm = dev(torch.randn(K, N, generator=g) * 0.5, dt)
+    C0 = torch.randn(M, N, generator=g)
+    Cd = dev(C0)
+    L.gemm(A, Bm, Cd, M=M, N=N, K=K, lda=M, ldb=N, ldc=N, a_layout=L.KROW, b_layout=L.KROW, accum=True, dtype=L.dtype_code(dt),
+           impl=L.IMPL_AUTO)
+    ref = C0.double() + A.double().cpu().t() @ Bm.double().cpu()
+    assert rel_err(Cd.cpu(), ref) < 2e-5, rel_err(Cd.cpu(), ref)     # the bf16 INPUTS are taken as given; products and sums are fp32
+
+
 def test_gemm_mfma_exact_integers():
     """A = I-like / asymmetric small integers: catches swapped fragment maps exactly (no rounding)."""
     M, N, K = 256, 256, 128
