@@ -14,6 +14,7 @@
 //     dK/dV (a wave owns 16 keys, sweeps queries); no atomics, no fp32 scratch in HBM.
 // Masked keys get -inf; a query whose keys are all masked outputs zeros and lse=+inf (torch SDPA semantics).
 #include "common.h"
+#include <stdlib.h>
 
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
 typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
@@ -115,8 +116,11 @@ __device__ __forceinline__ void stage_key_bias(float* kb, const int32_t* __restr
 // NW waves per block share the two LDS images: LDS (2 x 28 KiB at S=197) allows two blocks per CU, so NW = 8 is what puts
 // four waves on every SIMD (the kernels are latency-bound on LDS reads between dependent MFMAs) and halves the number of
 // tiles a wave walks.
-template <int NKT, bool DROP, int NW>     // key tiles of 16 (Spad = 16*NKT, NKT even); DROP: attention-probability dropout compiled in
-__global__ void __launch_bounds__(64 * NW, NW / 2)
+// QT = query tiles (of 16) a wave processes together: with QT = 2 every K / V fragment read from LDS feeds two MFMAs (the
+// kernel is bound by LDS fragment traffic and VALU latency, not by MFMA issue), at the price of ~190 VGPRs = two waves per
+// SIMD instead of four.
+template <int NKT, bool DROP, int NW, int QT>     // key tiles of 16 (Spad = 16*NKT, NKT even); DROP: attention-probability dropout compiled in
+__global__ void __launch_bounds__(64 * NW, QT == 1 ? NW / 2 : NW / 4)
 mha_fwd_mfma_k(const bf16_t* __restrict__ qkv, const int32_t* __restrict__ key_mask, bf16_t* __restrict__ out,
                float* __restrict__ lse, int H, int Smax, float scale, float drop_p, uint64_t drop_seed,
                const int32_t* __restrict__ cu) {
@@ -139,68 +143,90 @@ mha_fwd_mfma_k(const bf16_t* __restrict__ qkv, const int32_t* __restrict__ key_m
   __syncthreads();
   const float c1 = scale * LOG2E;                    // scores live in the exp2 domain
   const int nqt = (S + 15) / 16;
-  for (int qt = wave; qt < nqt; qt += NW) {
-    const int q0 = qt * 16;
-    bf16x8 qf0 = frag_global(Q, ld, q0, S, 0, lane), qf1 = frag_global(Q, ld, q0, S, 1, lane);
-    f32x4 s[NKT];
+  for (int qg = wave; qg * QT < nqt; qg += NW) {
+    const int q0 = qg * QT * 16;
+    bf16x8 qf0[QT], qf1[QT];
+#pragma unroll
+    for (int t = 0; t < QT; ++t) { qf0[t] = frag_global(Q, ld, q0 + 16 * t, S, 0, lane); qf1[t] = frag_global(Q, ld, q0 + 16 * t, S, 1, lane); }
+    f32x4 s[QT][NKT];
 #pragma unroll
     for (int kt = 0; kt < NKT; ++kt) {
-      f32x4 a = {0.f, 0.f, 0.f, 0.f};
-      a = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_rows(Kimg, IMG_ROW, kt * 16, 0, lane), qf0, a, 0, 0, 0);
-      a = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_rows(Kimg, IMG_ROW, kt * 16, 1, lane), qf1, a, 0, 0, 0);
-      s[kt] = a;
+      const bf16x8 kf0 = frag_rows(Kimg, IMG_ROW, kt * 16, 0, lane), kf1 = frag_rows(Kimg, IMG_ROW, kt * 16, 1, lane);
+#pragma unroll
+      for (int t = 0; t < QT; ++t) {
+        f32x4 a = {0.f, 0.f, 0.f, 0.f};
+        a = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf0, qf0[t], a, 0, 0, 0);
+        a = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf1, qf1[t], a, 0, 0, 0);
+        s[t][kt] = a;
+      }
       // keep the scheduler from hoisting every K fragment of the row up front (it then needs > 128 VGPRs and spills);
       // with four waves per SIMD the other waves cover this tile's LDS latency
       if (NW > 4 && (kt & 1)) __builtin_amdgcn_sched_barrier(0);
     }
-    float m = -INFINITY;
+    float m[QT], l[QT];
 #pragma unroll
-    for (int kt = 0; kt < NKT; ++kt) {
-      const f32x4 bias = *reinterpret_cast<const f32x4*>(kb + kt * 16 + 4 * g);     // keys 16kt + 4g + r
+    for (int t = 0; t < QT; ++t) {
+      float mm = -INFINITY;
 #pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const float v = fmaf(s[kt][r], c1, bias[r]);
-        s[kt][r] = v;
-        m = fmaxf(m, v);
+      for (int kt = 0; kt < NKT; ++kt) {
+        const f32x4 bias = *reinterpret_cast<const f32x4*>(kb + kt * 16 + 4 * g);     // keys 16kt + 4g + r
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const float v = fmaf(s[t][kt][r], c1, bias[r]);
+          s[t][kt][r] = v;
+          mm = fmaxf(mm, v);
+        }
       }
-    }
-    m = colgroup_max(m);
-    float l = 0.f;
-    const float msafe = m > -INFINITY ? m : 0.f;
-#pragma unroll
-    for (int kt = 0; kt < NKT; ++kt)
-#pragma unroll
-      for (int r = 0; r < 4; ++r) { const float e = __builtin_amdgcn_exp2f(s[kt][r] - msafe); s[kt][r] = e; l += e; }
-    l = colgroup_sum(l);
-    if (DROP) {      // dropout acts on the normalised probabilities: mask the numerators, keep the denominator
+      mm = colgroup_max(mm);
+      float ll = 0.f;
+      const float msafe = mm > -INFINITY ? mm : 0.f;
 #pragma unroll
       for (int kt = 0; kt < NKT; ++kt)
 #pragma unroll
-        for (int r = 0; r < 4; ++r) s[kt][r] *= attn_keep(drop_p, drop_sc, drop_seed, blockIdx.x, Smax, q0 + l16, kt * 16 + 4 * g + r);
-    }
-    f32x4 o[4];
+        for (int r = 0; r < 4; ++r) { const float e = __builtin_amdgcn_exp2f(s[t][kt][r] - msafe); s[t][kt][r] = e; ll += e; }
+      ll = colgroup_sum(ll);
+      if (DROP) {      // dropout acts on the normalised probabilities: mask the numerators, keep the denominator
 #pragma unroll
-    for (int dt = 0; dt < 4; ++dt) o[dt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        for (int kt = 0; kt < NKT; ++kt)
+#pragma unroll
+          for (int r = 0; r < 4; ++r)
+            s[t][kt][r] *= attn_keep(drop_p, drop_sc, drop_seed, blockIdx.x, Smax, q0 + 16 * t + l16, kt * 16 + 4 * g + r);
+      }
+      m[t] = mm; l[t] = ll;
+    }
+    f32x4 o[QT][4];
+#pragma unroll
+    for (int t = 0; t < QT; ++t)
+#pragma unroll
+      for (int dt = 0; dt < 4; ++dt) o[t][dt] = (f32x4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int u = 0; u < NKT / 2; ++u) {
-      const bf16x8 pf = pack_pair(s[2 * u], s[2 * u + 1]);
+      bf16x8 pf[QT];
 #pragma unroll
-      for (int dt = 0; dt < 4; ++dt)
-        o[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_cols_tr(Vimg, u, dt, lane), pf, o[dt], 0, 0, 0);   // O^T[d][q]
-      if (NW > 4) __builtin_amdgcn_sched_barrier(0);
-    }
-    const int q = q0 + l16;
-    if (q < S) {
-      const float inv = l > 0.f ? 1.f / l : 0.f;
-      bf16_t* orow = out + ((int64_t)row0 + q) * (H * AT_DH) + h * AT_DH;
+      for (int t = 0; t < QT; ++t) pf[t] = pack_pair(s[t][2 * u], s[t][2 * u + 1]);
 #pragma unroll
       for (int dt = 0; dt < 4; ++dt) {
-        bf16x4 v;
+        const bf16x8 vf = frag_cols_tr(Vimg, u, dt, lane);
 #pragma unroll
-        for (int r = 0; r < 4; ++r) v[r] = (bf16_t)(o[dt][r] * inv);
-        *reinterpret_cast<bf16x4*>(orow + dt * 16 + 4 * g) = v;
+        for (int t = 0; t < QT; ++t) o[t][dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf, pf[t], o[t][dt], 0, 0, 0);   // O^T[d][q]
       }
-      if (g == 0) lse[((int64_t)b * H + h) * Smax + q] = l > 0.f ? m * LN2 + __logf(l) : INFINITY;
+      if (NW > 4) __builtin_amdgcn_sched_barrier(0);
+    }
+#pragma unroll
+    for (int t = 0; t < QT; ++t) {
+      const int q = q0 + 16 * t + l16;
+      if (q < S) {
+        const float inv = l[t] > 0.f ? 1.f / l[t] : 0.f;
+        bf16_t* orow = out + ((int64_t)row0 + q) * (H * AT_DH) + h * AT_DH;
+#pragma unroll
+        for (int dt = 0; dt < 4; ++dt) {
+          bf16x4 v;
+#pragma unroll
+          for (int r = 0; r < 4; ++r) v[r] = (bf16_t)(o[t][dt][r] * inv);
+          *reinterpret_cast<bf16x4*>(orow + dt * 16 + 4 * g) = v;
+        }
+        if (g == 0) lse[((int64_t)b * H + h) * Smax + q] = l[t] > 0.f ? m[t] * LN2 + __logf(l[t]) : INFINITY;
+      }
     }
   }
 }
@@ -425,10 +451,13 @@ static int pick_nkt(int S) {
   return 32;
 }
 
+#define K_FWD(N_, D_, W_) mha_fwd_mfma_k<N_, D_, W_, 1>
+#define K_DQ(N_, D_, W_) mha_bwd_dq_mfma_k<N_, D_, W_>
+#define K_DKV(N_, D_, W_) mha_bwd_dkv_mfma_k<N_, D_, W_>
 #define AT_LAUNCH1(KERNEL, NKT, DROP, NW, LDSBYTES, ...)                                                                        \
   do {                                                                                                                         \
-    (void)hipFuncSetAttribute((const void*)KERNEL<NKT, DROP, NW>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(LDSBYTES)); \
-    hipLaunchKernelGGL((KERNEL<NKT, DROP, NW>), dim3(B * H), dim3(64 * NW), LDSBYTES, st, __VA_ARGS__);                         \
+    (void)hipFuncSetAttribute((const void*)KERNEL(NKT, DROP, NW), hipFuncAttributeMaxDynamicSharedMemorySize, (int)(LDSBYTES)); \
+    hipLaunchKernelGGL((KERNEL(NKT, DROP, NW)), dim3(B * H), dim3(64 * NW), LDSBYTES, st, __VA_ARGS__);                         \
   } while (0)
 // small S: 4 waves.  S > 128: 8 waves when the kernel fits 128 VGPRs without spilling (W8_PLAIN / W8_DROP, per kernel)
 #define AT_LAUNCH4(KERNEL, NKT, LDSBYTES, ...)                                          \
@@ -464,7 +493,16 @@ int mmrca_mha_fwd_mfma(const void* qkv, const int32_t* key_mask, void* out, floa
   (void)dh;
   MMRCA_REQUIRE((((uintptr_t)qkv) & 15) == 0 && (((uintptr_t)out) & 7) == 0, "mha_fwd: qkv must be 16-byte aligned");
   const int nkt = pick_nkt(S);
-  AT_SWITCH(mha_fwd_mfma_k, BIAS_EXTRA, true, false, false, (const bf16_t*)qkv, key_mask, (bf16_t*)out, lse, H, S, scale, drop_p, drop_seed, cu);
+  static const int qt2 = getenv("MMRCA_ATTN_QT2") ? atoi(getenv("MMRCA_ATTN_QT2")) : 0;
+  if (qt2 && nkt == 14 && drop_p <= 0.f) {        // two query tiles per wave (S in 193..224: the ViT's 197 tokens)
+    const int ldsb = 2 * 14 * 16 * 128 + BIAS_EXTRA(14);
+    (void)hipFuncSetAttribute((const void*)mha_fwd_mfma_k<14, false, 8, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, ldsb);
+    hipLaunchKernelGGL((mha_fwd_mfma_k<14, false, 8, 2>), dim3(B * H), dim3(512), ldsb, st, (const bf16_t*)qkv, key_mask, (bf16_t*)out, lse, H, S,
+                       scale, drop_p, drop_seed, cu);
+    MMRCA_CHECK_LAUNCH("mha_fwd(mfma,qt2)");
+    return 0;
+  }
+  AT_SWITCH(K_FWD, BIAS_EXTRA, true, false, false, (const bf16_t*)qkv, key_mask, (bf16_t*)out, lse, H, S, scale, drop_p, drop_seed, cu);
   MMRCA_CHECK_LAUNCH("mha_fwd(mfma)");
   return 0;
 }
@@ -476,8 +514,8 @@ int mmrca_mha_bwd_mfma(const void* qkv, const int32_t* key_mask, const void* out
   MMRCA_REQUIRE((((uintptr_t)qkv) & 15) == 0 && (((uintptr_t)out) & 15) == 0 && (((uintptr_t)dout) & 15) == 0 && (((uintptr_t)dqkv) & 7) == 0,
                 "mha_bwd: buffers must be 16-byte aligned");
   const int nkt = pick_nkt(S);
-  AT_SWITCH(mha_bwd_dq_mfma_k, BIAS_EXTRA, true, true, true, (const bf16_t*)qkv, key_mask, (const bf16_t*)out, (const bf16_t*)dout, lse, (bf16_t*)dqkv, H, S, scale, drop_p, drop_seed, cu);
-  AT_SWITCH(mha_bwd_dkv_mfma_k, STAT_EXTRA, true, false, true, (const bf16_t*)qkv, key_mask, (const bf16_t*)out, (const bf16_t*)dout, lse, (bf16_t*)dqkv, H, S, scale, drop_p, drop_seed, cu);
+  AT_SWITCH(K_DQ, BIAS_EXTRA, true, true, true, (const bf16_t*)qkv, key_mask, (const bf16_t*)out, (const bf16_t*)dout, lse, (bf16_t*)dqkv, H, S, scale, drop_p, drop_seed, cu);
+  AT_SWITCH(K_DKV, STAT_EXTRA, true, false, true, (const bf16_t*)qkv, key_mask, (const bf16_t*)out, (const bf16_t*)dout, lse, (bf16_t*)dqkv, H, S, scale, drop_p, drop_seed, cu);
   MMRCA_CHECK_LAUNCH("mha_bwd(mfma)");
   return 0;
 }
