@@ -1685,6 +1685,8 @@ int mmrca_gemm256(const void* A, const void* B, void* C, const void* bias, const
 extern int g_mmrca_dbg;
 static const int g_mmrca_auto256_side = getenv("MMRCA_AUTO256_SIDE") ? atoi(getenv("MMRCA_AUTO256_SIDE")) : 0;
 static const bool g_mmrca_auto256_gelu = getenv("MMRCA_AUTO256_GELU") ? atoi(getenv("MMRCA_AUTO256_GELU")) != 0 : true;
+static const int g_mmrca_auto256_tail = getenv("MMRCA_AUTO256_TAIL") ? atoi(getenv("MMRCA_AUTO256_TAIL")) : 2;
+static const int g_mmrca_auto256_tail_pct = getenv("MMRCA_AUTO256_TAIL_PCT") ? atoi(getenv("MMRCA_AUTO256_TAIL_PCT")) : 60;
 #define MMRCA_TALL_MIN_M (1LL << 60)   // AUTO threshold for the 256x128 kernel (off until measured)
 
 template <bool AK, bool BK2, bool AT, bool DB>
@@ -1730,6 +1732,30 @@ static int gemm_dispatch(const void* A, const void* B, void* C, const void* bias
   const bool auto256 = impl == MMRCA_GEMM_AUTO && ok256 && M % 256 == 0 && K >= 768 && (M / 256) * (N / 256) >= 256 && side_ok &&
                        (act != MMRCA_ACT_GELU_SAVE_GRAD || g_mmrca_auto256_gelu);
   if (ok256 && (impl == MMRCA_GEMM_MFMA256 || auto256)) {
+    // Tile quantisation: the persistent kernel runs whole rounds of one 256x256 tile per CU.  N = 768 at M = 50,432 makes
+    // 591 tiles = 2.31 rounds on 256 CUs, i.e. the chip idles for 0.69 of a round.  AUTO gives the persistent kernel the
+    // leading row blocks that make whole rounds and hands the remaining rows to the 128x128 kernel (MMRCA_AUTO256_TAIL:
+    // 0 = off, 1 = single-stage kernel, 2 = two-stage kernel for the tail (default); only when the partial round is 25-60 % of a
+    // round).  Isolated: FFN2 forward 223 -> 209 us, QKV input gradient 179 -> 160, FFN1 input gradient 233 -> 218.
+    if (auto256 && g_mmrca_auto256_tail > 0 && !colsum_fused && a_layout == MMRCA_ROWK) {
+      int ncu = 256, devi = 0;
+      (void)hipGetDevice(&devi);
+      if (hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, devi) != hipSuccess || ncu < 8) ncu = 256;
+      ncu &= ~7;
+      const int64_t tm = M / 256, tn = N / 256, tiles = tm * tn;
+      const int64_t rounds = tiles / ncu, rem = tiles - rounds * ncu;
+      const int64_t m_split = rounds * ncu / tn;                  // row blocks of the whole rounds
+      if (rounds >= 1 && rem * 100 >= 25 * (int64_t)ncu && rem * 100 < (int64_t)g_mmrca_auto256_tail_pct * ncu && m_split >= 1 && m_split < tm) {
+        const int64_t M1 = m_split * 256;
+        if (int rc = mmrca_gemm256(A, B, C, bias, addend, preact, M1, N, K, lda, ldb, ldc, a_layout, b_layout, act, nullptr, st)) return rc;
+        const char* A2 = (const char*)A + M1 * lda * 2;
+        char* C2 = (char*)C + M1 * ldc * 2;
+        const char* add2 = addend ? (const char*)addend + M1 * ldc * 2 : nullptr;
+        char* pre2 = preact ? (char*)preact + M1 * ldc * 2 : nullptr;
+        return gemm_dispatch(A2, B, C2, bias, add2, pre2, M - M1, N, K, lda, ldb, ldc, a_layout, b_layout, act, 0, dtype,
+                             g_mmrca_auto256_tail == 2 ? MMRCA_GEMM_MFMA : MMRCA_GEMM_MFMA_1STAGE, stream, nullptr, nullptr);
+      }
+    }
     if (colsum_fused && fused_done) *fused_done = true;
     return mmrca_gemm256(A, B, C, bias, addend, preact, M, N, K, lda, ldb, ldc, a_layout, b_layout, act, colsum_fused, st);
   }
