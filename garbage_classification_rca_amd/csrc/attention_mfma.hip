@@ -15,6 +15,7 @@
 // Masked keys get -inf; a query whose keys are all masked outputs zeros and lse=+inf (torch SDPA semantics).
 #include "common.h"
 #include <stdlib.h>
+#include <type_traits>
 
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
 typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
@@ -228,6 +229,139 @@ mha_fwd_mfma_k(const bf16_t* __restrict__ qkv, const int32_t* __restrict__ key_m
         if (g == 0) lse[((int64_t)b * H + h) * Smax + q] = l[t] > 0.f ? m[t] * LN2 + __logf(l[t]) : INFINITY;
       }
     }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------------
+// forward, persistent over heads (unmasked, no dropout, padded layout: the ViT's attention)
+// ------------------------------------------------------------------------------------------------------
+// The per-head kernel above spends half of its waves' lifetime parked: all waves of a (b,h) wait for the 50 KB K/V staging and
+// for their Q fragments, then run stage -> QK^T -> softmax -> PV in lockstep on one or two tiles each.  Here a workgroup of NW
+// waves (one query tile per wave) walks heads bh = blockIdx.x, + gridDim.x, ... with TWO sets of LDS images: the DMA for the
+// next head and the next head's Q fragments are issued right after the barrier that opens the current head and land under
+// its MFMAs.  Fragment reads are inline asm (a C++ LDS read next to an in-flight global_load_lds makes hipcc insert
+// s_waitcnt vmcnt(0) in front of it, which would wait for the NEXT head's staging: see lds_asm.h); the key bias of the two
+// partly dead key tiles lives in registers, so the loop body has no compiler-visible LDS access at all.
+#define AT_DS_B128_OFF(dst, addr, off) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "i"(off))
+#define AT_DS_TR_OFF(dst, addr, off) asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "i"(off))
+template <int I, int N, typename F>
+__device__ __forceinline__ void static_for(F&& f) {
+  if constexpr (I < N) { f(std::integral_constant<int, I>{}); static_for<I + 1, N>(f); }
+}
+
+template <int NKT, int NW>
+__global__ void __launch_bounds__(64 * NW)
+mha_fwd_mfma_p_k(const bf16_t* __restrict__ qkv, bf16_t* __restrict__ out, float* __restrict__ lse, int H, int S, float scale, int nbh) {
+  extern __shared__ __attribute__((aligned(16))) char sm[];
+  constexpr int Spad = NKT * 16, IMG = Spad * 128;
+  const unsigned lds0 = (unsigned)(uintptr_t)(at_lds_void*)sm;
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, g = lane >> 4, l16 = lane & 15;
+  const int64_t ld = 3LL * H * AT_DH;
+  const float c1 = scale * LOG2E;
+  const int nqt = (S + 15) / 16;
+  const int qt = wave;
+  const bool has_tile = qt < nqt;
+  // per-lane byte offsets of the fragment reads inside an image; the XOR swizzles depend on (row >> 1) & 7 resp. & 3, which a
+  // step of 16 (key tile) or 32 (key pair) rows does not change, so a tile / pair index is a plain multiple of 2 / 4 KiB
+  const unsigned ksw = (l16 >> 1) & 7;
+  const unsigned koff0 = l16 * 128 + (((unsigned)g ^ ksw) << 4), koff1 = l16 * 128 + (((unsigned)(4 + g) ^ ksw) << 4);
+  const int qq = l16 >> 2, pp = l16 & 3, vsw = (2 * g + (qq >> 1)) & 3;
+  unsigned voff[4];
+#pragma unroll
+  for (int dt = 0; dt < 4; ++dt) voff[dt] = (4 * g + qq) * 128 + ((dt ^ vsw) << 5) + 8 * pp;
+
+  int bh = blockIdx.x;
+  if (bh >= nbh) return;
+  auto stage_head = [&](int slot, int bh_) {
+    const bf16_t* Kp = qkv + (int64_t)(bh_ / H) * S * ld + (int64_t)H * AT_DH + (bh_ % H) * AT_DH;
+    stage_rows(sm + slot * 2 * IMG, IMG_ROW, Kp, ld, S, Spad);
+    stage_rows(sm + slot * 2 * IMG + IMG, IMG_TR, Kp + (int64_t)H * AT_DH, ld, S, Spad);
+  };
+  auto q_frags = [&](int bh_, bf16x8& f0, bf16x8& f1) {
+    const bf16_t* Q = qkv + (int64_t)(bh_ / H) * S * ld + (bh_ % H) * AT_DH;
+    f0 = frag_global(Q, ld, qt * 16, S, 0, lane); f1 = frag_global(Q, ld, qt * 16, S, 1, lane);
+  };
+  stage_head(0, bh);
+  bf16x8 qf0, qf1;
+  if (has_tile) q_frags(bh, qf0, qf1);
+  int cur = 0;
+  for (;;) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();                    // images of head bh complete; the other slot's last readers have passed
+    const int nxt = bh + (int)gridDim.x;
+    if (nxt < nbh) stage_head(cur ^ 1, nxt);
+    if (has_tile) {
+      // instruction diet (the tile body is bound by VALU + LDS issue): LDS reads take their tile / pair index as an
+      // immediate offset (no address arithmetic), the row maximum is taken over the raw scores and scale + maximum fold
+      // into one fma inside the exponential's argument, the row sum comes from one all-ones MFMA per key pair
+      const unsigned kb0 = lds0 + cur * 2 * IMG + koff0, kb1 = lds0 + cur * 2 * IMG + koff1, vimg = lds0 + cur * 2 * IMG + IMG;
+      const unsigned vb[4] = {vimg + voff[0], vimg + voff[1], vimg + voff[2], vimg + voff[3]};
+      f32x4 s[NKT];
+      static_for<0, NKT>([&](auto ic) {
+        constexpr int kt = decltype(ic)::value;
+        bf16x8 kf0, kf1;
+        AT_DS_B128_OFF(kf0, kb0, kt * 2048);
+        AT_DS_B128_OFF(kf1, kb1, kt * 2048);
+        asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(kf0), "+v"(kf1));
+        f32x4 a = {0.f, 0.f, 0.f, 0.f};
+        a = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf0, qf0, a, 0, 0, 0);
+        a = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf1, qf1, a, 0, 0, 0);
+        s[kt] = a;
+      });
+      if (nxt < nbh) q_frags(nxt, qf0, qf1);     // the Q fragments are dead now: the next head's load straight into them
+      float m = -INFINITY;              // maximum of the RAW scores of the live keys (c1 > 0)
+#pragma unroll
+      for (int kt = 0; kt < NKT; ++kt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          // keys of the last two key tiles that lie beyond S are dead (kept out of registers: the loop body must not spill --
+          // a scratch reload counts in vmcnt and would wait for the next head's staging)
+          if (kt >= NKT - 2) s[kt][r] = kt * 16 + 4 * g + r < S ? s[kt][r] : -INFINITY;
+          m = fmaxf(m, s[kt][r]);
+        }
+      m = colgroup_max(m);
+      const float mc = -m * c1;
+#pragma unroll
+      for (int kt = 0; kt < NKT; ++kt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) s[kt][r] = __builtin_amdgcn_exp2f(fmaf(s[kt][r], c1, mc));
+      f32x4 o[4], osum = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int dt = 0; dt < 4; ++dt) o[dt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+      bf16x8 ones;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) ones[j] = (bf16_t)1.0f;
+      static_for<0, NKT / 2>([&](auto ic) {
+        constexpr int u = decltype(ic)::value;
+        const bf16x8 pf = pack_pair(s[2 * u], s[2 * u + 1]);
+        bf16x4 lo[4], hi[4];
+#pragma unroll
+        for (int dt = 0; dt < 4; ++dt) { AT_DS_TR_OFF(lo[dt], vb[dt], u * 4096); AT_DS_TR_OFF(hi[dt], vb[dt], u * 4096 + 2048); }
+        asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(lo[0]), "+v"(hi[0]), "+v"(lo[1]), "+v"(hi[1]), "+v"(lo[2]), "+v"(hi[2]), "+v"(lo[3]), "+v"(hi[3]));
+#pragma unroll
+        for (int dt = 0; dt < 4; ++dt)
+          o[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_shufflevector(lo[dt], hi[dt], 0, 1, 2, 3, 4, 5, 6, 7), pf, o[dt], 0, 0, 0);   // O^T[d][q]
+        osum = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ones, pf, osum, 0, 0, 0);      // every row: sum_k P[q][k] (of the bf16 values PV uses)
+      });
+      const float l = osum[0];          // >= 1: the row maximum contributes exp2(0)
+      m = m * c1;
+      const int q = qt * 16 + l16;
+      if (q < S) {
+        const float inv = 1.f / l;
+        const int b = bh / H, h = bh % H;
+        bf16_t* orow = out + ((int64_t)b * S + q) * (H * AT_DH) + h * AT_DH;
+#pragma unroll
+        for (int dt = 0; dt < 4; ++dt) {
+          bf16x4 v;
+#pragma unroll
+          for (int r = 0; r < 4; ++r) v[r] = (bf16_t)(o[dt][r] * inv);
+          *reinterpret_cast<bf16x4*>(orow + dt * 16 + 4 * g) = v;
+        }
+        if (g == 0) lse[(int64_t)bh * S + q] = m * LN2 + __logf(l);
+      }
+    }
+    if (nxt >= nbh) break;
+    bh = nxt; cur ^= 1;
   }
 }
 
@@ -493,6 +627,17 @@ int mmrca_mha_fwd_mfma(const void* qkv, const int32_t* key_mask, void* out, floa
   (void)dh;
   MMRCA_REQUIRE((((uintptr_t)qkv) & 15) == 0 && (((uintptr_t)out) & 7) == 0, "mha_fwd: qkv must be 16-byte aligned");
   const int nkt = pick_nkt(S);
+  static const int persist = getenv("MMRCA_ATTN_PERSIST") ? atoi(getenv("MMRCA_ATTN_PERSIST")) : 1;
+  if (persist && nkt == 14 && drop_p <= 0.f && !key_mask && !cu && S > 16 * 12) {     // the ViT's attention: 197 tokens, no mask
+    static int ncu = 0;
+    if (ncu == 0) { int d = 0; (void)hipGetDevice(&d); if (hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, d) != hipSuccess || ncu < 1) ncu = 256; }
+    const int ldsb = 4 * 14 * 16 * 128;
+    const int nbh = B * H, grid = nbh < ncu ? nbh : ncu;
+    (void)hipFuncSetAttribute((const void*)mha_fwd_mfma_p_k<14, 16>, hipFuncAttributeMaxDynamicSharedMemorySize, ldsb);
+    hipLaunchKernelGGL((mha_fwd_mfma_p_k<14, 16>), dim3(grid), dim3(1024), ldsb, st, (const bf16_t*)qkv, (bf16_t*)out, lse, H, S, scale, nbh);
+    MMRCA_CHECK_LAUNCH("mha_fwd(mfma,persistent)");
+    return 0;
+  }
   static const int qt2 = getenv("MMRCA_ATTN_QT2") ? atoi(getenv("MMRCA_ATTN_QT2")) : 0;
   if (qt2 && nkt == 14 && drop_p <= 0.f) {        // two query tiles per wave (S in 193..224: the ViT's 197 tokens)
     const int ldsb = 2 * 14 * 16 * 128 + BIAS_EXTRA(14);
