@@ -574,6 +574,235 @@ mha_bwd_dkv_mfma_k(const bf16_t* __restrict__ qkv, const int32_t* __restrict__ k
 }
 
 // ------------------------------------------------------------------------------------------------------
+// backward, dK/dV for the ViT (unmasked, no dropout, padded layout): hand-scheduled inner loop
+// ------------------------------------------------------------------------------------------------------
+// Same work split as mha_bwd_dkv_mfma_k (a wave owns 16 keys, sweeps the query tiles in pairs), but the inner loop is laid
+// out by hand: hipcc's schedule of the C++ version waits on every LDS read right in front of the MFMA that consumes it (19
+// s_waitcnt per query pair at 108 VGPRs).  Here a query pair issues its 8 row fragments and its row constants in one batch,
+// and the 16 transposed fragments of the dV / dK products right after the S / dP MFMAs, so that they land under the
+// exponentials; the tile / pair index is an immediate offset of the asm ds_read (no address arithmetic in the loop).
+// Row constants as the initial accumulator (the guide's attention-backward recipe): the prologue stores -lse/c1 and
+// -rowsum(dO*O) per query, the S and dP MFMA chains start from them, and p = exp2(c1 * S'), dS = p * dP' need no subtraction.
+template <int NKT, int NW>
+__global__ void __launch_bounds__(64 * NW, NW / 2)
+mha_bwd_dkv_mfma_v_k(const bf16_t* __restrict__ qkv, const bf16_t* __restrict__ out, const bf16_t* __restrict__ dout,
+                     const float* __restrict__ lse, bf16_t* __restrict__ dqkv, int H, int S, float scale) {
+  extern __shared__ __attribute__((aligned(16))) char sm[];
+  constexpr int Spad = NKT * 16, IMG = Spad * 128;
+  char* Qimg = sm; char* Dimg = sm + IMG;
+  float* lse_s = reinterpret_cast<float*>(sm + 2 * IMG);     // -lse / c1 in the exp2 domain (c1 * (S + this) = c1 S - L)
+  float* dsum_s = lse_s + Spad;                              // -rowsum(dO * O)
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, g = lane >> 4, l16 = lane & 15;
+  const int b = blockIdx.x / H, h = blockIdx.x % H;
+  const int row0 = b * S;
+  const int64_t ld = 3LL * H * AT_DH, ldo = (int64_t)H * AT_DH;
+  const bf16_t* Q = qkv + (int64_t)row0 * ld + h * AT_DH;
+  const bf16_t* Kp = Q + H * AT_DH;
+  const bf16_t* Vp = Kp + H * AT_DH;
+  const bf16_t* O = out + (int64_t)row0 * ldo + h * AT_DH;
+  const bf16_t* dO = dout + (int64_t)row0 * ldo + h * AT_DH;
+  const float c1 = scale * LOG2E, inv_c1 = 1.f / c1;
+  stage_rows(Qimg, IMG_TR, Q, ld, S, Spad);
+  stage_rows(Dimg, IMG_TR, dO, ldo, S, Spad);
+  for (int q = threadIdx.x; q < Spad; q += blockDim.x) {
+    float a = 0.f, L = INFINITY;                 // padded query rows: lse=+inf -> P = 0
+    if (q < S) {
+      L = lse[((int64_t)b * H + h) * S + q] * LOG2E;
+#pragma unroll
+      for (int c = 0; c < 8; ++c) {
+        const bf16x8 x = *reinterpret_cast<const bf16x8*>(dO + (int64_t)q * ldo + c * 8);
+        const bf16x8 y = *reinterpret_cast<const bf16x8*>(O + (int64_t)q * ldo + c * 8);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) a += (float)x[j] * (float)y[j];
+      }
+    }
+    lse_s[q] = -L * inv_c1; dsum_s[q] = -a;
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  const unsigned lds0 = (unsigned)(uintptr_t)(at_lds_void*)sm;
+  // per-lane byte offsets inside an image (see mha_fwd_mfma_p_k: the XOR swizzles do not depend on the tile / pair index)
+  const unsigned rsw = (l16 >> 1) & 3;
+  const unsigned roff0 = l16 * 128 + ((((unsigned)(g >> 1)) ^ rsw) << 5) + ((g & 1) << 4);           // k-step 0: chunk c = g
+  const unsigned roff1 = l16 * 128 + ((((unsigned)(2 + (g >> 1))) ^ rsw) << 5) + ((g & 1) << 4);     // k-step 1: chunk c = 4 + g
+  const int qq = l16 >> 2, pp = l16 & 3, vsw = (2 * g + (qq >> 1)) & 3;
+  unsigned tq[4], td[4];
+#pragma unroll
+  for (int dt = 0; dt < 4; ++dt) {
+    const unsigned o = (4 * g + qq) * 128 + ((dt ^ vsw) << 5) + 8 * pp;
+    tq[dt] = lds0 + o; td[dt] = lds0 + IMG + o;
+  }
+  const unsigned qb0 = lds0 + roff0, qb1 = lds0 + roff1, db0 = lds0 + IMG + roff0, db1 = lds0 + IMG + roff1;
+  const unsigned lb = lds0 + 2 * IMG + 16 * g, sb = lb + Spad * 4;      // row constants of queries 16 qt + 4 g + r
+  const int nkt = (S + 15) / 16;
+  for (int kt = wave; kt < nkt; kt += NW) {
+    const int k0 = kt * 16;
+    const int key = k0 + l16;
+    const float kbias = key < S ? 0.f : -INFINITY;                        // this lane's key
+    const bf16x8 kf0 = frag_global(Kp, ld, k0, S, 0, lane), kf1 = frag_global(Kp, ld, k0, S, 1, lane);
+    const bf16x8 vf0 = frag_global(Vp, ld, k0, S, 0, lane), vf1 = frag_global(Vp, ld, k0, S, 1, lane);
+    f32x4 dk[4], dv[4];
+#pragma unroll
+    for (int dt = 0; dt < 4; ++dt) { dk[dt] = (f32x4){0.f, 0.f, 0.f, 0.f}; dv[dt] = (f32x4){0.f, 0.f, 0.f, 0.f}; }
+    static_for<0, NKT / 2>([&](auto ic) {
+      constexpr int u = decltype(ic)::value;
+      bf16x8 qa0, qa1, qb0_, qb1_, da0, da1, db0_, db1_;      // row fragments of query tiles 2u (a) and 2u+1 (b), k-steps 0 / 1
+      f32x4 sa, sb_, pa, pb;                                  // S' and dP' accumulators, started from the row constants
+      AT_DS_B128_OFF(qa0, qb0, (2 * u) * 2048);     AT_DS_B128_OFF(da0, db0, (2 * u) * 2048);
+      AT_DS_B128_OFF(qb0_, qb0, (2 * u + 1) * 2048); AT_DS_B128_OFF(db0_, db0, (2 * u + 1) * 2048);
+      AT_DS_B128_OFF(sa, lb, (2 * u) * 64);          AT_DS_B128_OFF(pa, sb, (2 * u) * 64);
+      AT_DS_B128_OFF(sb_, lb, (2 * u + 1) * 64);     AT_DS_B128_OFF(pb, sb, (2 * u + 1) * 64);
+      AT_DS_B128_OFF(qa1, qb1, (2 * u) * 2048);     AT_DS_B128_OFF(da1, db1, (2 * u) * 2048);
+      AT_DS_B128_OFF(qb1_, qb1, (2 * u + 1) * 2048); AT_DS_B128_OFF(db1_, db1, (2 * u + 1) * 2048);
+      asm volatile("s_waitcnt lgkmcnt(4)" : "+v"(qa0), "+v"(da0), "+v"(qb0_), "+v"(db0_), "+v"(sa), "+v"(pa), "+v"(sb_), "+v"(pb));
+      sa = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qa0, kf0, sa, 0, 0, 0);       // S'[q][key]
+      pa = __builtin_amdgcn_mfma_f32_16x16x32_bf16(da0, vf0, pa, 0, 0, 0);       // dP'[q][key]
+      sb_ = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qb0_, kf0, sb_, 0, 0, 0);
+      pb = __builtin_amdgcn_mfma_f32_16x16x32_bf16(db0_, vf0, pb, 0, 0, 0);
+      asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(qa1), "+v"(da1), "+v"(qb1_), "+v"(db1_));
+      sa = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qa1, kf1, sa, 0, 0, 0);
+      pa = __builtin_amdgcn_mfma_f32_16x16x32_bf16(da1, vf1, pa, 0, 0, 0);
+      sb_ = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qb1_, kf1, sb_, 0, 0, 0);
+      pb = __builtin_amdgcn_mfma_f32_16x16x32_bf16(db1_, vf1, pb, 0, 0, 0);
+      // the transposed fragments of the second products do not depend on P: in flight under the exponentials
+      bf16x4 dlo[4], dhi[4], qlo[4], qhi[4];
+#pragma unroll
+      for (int dt = 0; dt < 4; ++dt) {
+        AT_DS_TR_OFF(dlo[dt], td[dt], u * 4096); AT_DS_TR_OFF(dhi[dt], td[dt], u * 4096 + 2048);
+        AT_DS_TR_OFF(qlo[dt], tq[dt], u * 4096); AT_DS_TR_OFF(qhi[dt], tq[dt], u * 4096 + 2048);
+      }
+      f32x4 p2a, p2b, dsa, dsb;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        p2a[r] = __builtin_amdgcn_exp2f(fmaf(sa[r], c1, kbias));            // 0 for dead keys and padded queries
+        p2b[r] = __builtin_amdgcn_exp2f(fmaf(sb_[r], c1, kbias));
+        dsa[r] = p2a[r] * pa[r];                                            // (the score scale is applied to dK below)
+        dsb[r] = p2b[r] * pb[r];
+      }
+      const bf16x8 pf = pack_pair(p2a, p2b), dsf = pack_pair(dsa, dsb);
+      asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(dlo[0]), "+v"(dhi[0]), "+v"(dlo[1]), "+v"(dhi[1]), "+v"(dlo[2]), "+v"(dhi[2]), "+v"(dlo[3]), "+v"(dhi[3]),
+                   "+v"(qlo[0]), "+v"(qhi[0]), "+v"(qlo[1]), "+v"(qhi[1]), "+v"(qlo[2]), "+v"(qhi[2]), "+v"(qlo[3]), "+v"(qhi[3]));
+#pragma unroll
+      for (int dt = 0; dt < 4; ++dt) {
+        dv[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_shufflevector(dlo[dt], dhi[dt], 0, 1, 2, 3, 4, 5, 6, 7), pf, dv[dt], 0, 0, 0);    // dV^T[d][key]
+        dk[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_shufflevector(qlo[dt], qhi[dt], 0, 1, 2, 3, 4, 5, 6, 7), dsf, dk[dt], 0, 0, 0);   // dK^T[d][key]
+      }
+    });
+    bf16_t* krow = dqkv + ((int64_t)row0 + (key < S ? key : S - 1)) * ld + (int64_t)H * AT_DH + h * AT_DH;
+    bf16_t* vrow = krow + (int64_t)H * AT_DH;
+#pragma unroll
+    for (int dt = 0; dt < 4; ++dt) {
+      bf16x4 a, c;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) { a[r] = (bf16_t)(dk[dt][r] * scale); c[r] = (bf16_t)dv[dt][r]; }
+      if (key < S) {
+        *reinterpret_cast<bf16x4*>(krow + dt * 16 + 4 * g) = a;
+        *reinterpret_cast<bf16x4*>(vrow + dt * 16 + 4 * g) = c;
+      }
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------------
+// backward, dQ for the ViT (unmasked, no dropout, padded layout): hand-scheduled inner loop (see mha_bwd_dkv_mfma_v_k)
+// ------------------------------------------------------------------------------------------------------
+template <int NKT, int NW>
+__global__ void __launch_bounds__(64 * NW, NW / 2)
+mha_bwd_dq_mfma_v_k(const bf16_t* __restrict__ qkv, const bf16_t* __restrict__ out, const bf16_t* __restrict__ dout,
+                    const float* __restrict__ lse, bf16_t* __restrict__ dqkv, int H, int S, float scale) {
+  extern __shared__ __attribute__((aligned(16))) char sm[];
+  constexpr int Spad = NKT * 16, IMG = Spad * 128;
+  char* Kimg = sm; char* Vimg = sm + IMG;
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, g = lane >> 4, l16 = lane & 15;
+  const int b = blockIdx.x / H, h = blockIdx.x % H;
+  const int row0 = b * S;
+  const int64_t ld = 3LL * H * AT_DH, ldo = (int64_t)H * AT_DH;
+  const bf16_t* Q = qkv + (int64_t)row0 * ld + h * AT_DH;
+  const bf16_t* Kp = Q + H * AT_DH;
+  const bf16_t* Vp = Kp + H * AT_DH;
+  const bf16_t* O = out + (int64_t)row0 * ldo + h * AT_DH;
+  const bf16_t* dO = dout + (int64_t)row0 * ldo + h * AT_DH;
+  stage_rows(Kimg, IMG_TR, Kp, ld, S, Spad);      // row reads for S^T (2-way), transposed reads for dQ^T
+  stage_rows(Vimg, IMG_ROW, Vp, ld, S, Spad);     // row reads for dP^T
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  const float c1 = scale * LOG2E, inv_c1 = 1.f / c1;
+  const unsigned lds0 = (unsigned)(uintptr_t)(at_lds_void*)sm;
+  const unsigned rsw = (l16 >> 1) & 3, ksw = (l16 >> 1) & 7;
+  const unsigned kb0 = lds0 + l16 * 128 + ((((unsigned)(g >> 1)) ^ rsw) << 5) + ((g & 1) << 4);          // K (TR image) rows, k-step 0
+  const unsigned kb1 = lds0 + l16 * 128 + ((((unsigned)(2 + (g >> 1))) ^ rsw) << 5) + ((g & 1) << 4);    // k-step 1
+  const unsigned vb0 = lds0 + IMG + l16 * 128 + (((unsigned)g ^ ksw) << 4);                                // V (ROW image) rows
+  const unsigned vb1 = lds0 + IMG + l16 * 128 + (((unsigned)(4 + g) ^ ksw) << 4);
+  const int qq = l16 >> 2, pp = l16 & 3, vsw = (2 * g + (qq >> 1)) & 3;
+  unsigned tk[4];
+#pragma unroll
+  for (int dt = 0; dt < 4; ++dt) tk[dt] = lds0 + (4 * g + qq) * 128 + ((dt ^ vsw) << 5) + 8 * pp;
+  const int nqt = (S + 15) / 16;
+  for (int qt = wave; qt < nqt; qt += NW) {
+    const int q0 = qt * 16;
+    const int q = q0 + l16;
+    const bf16x8 qf0 = frag_global(Q, ld, q0, S, 0, lane), qf1 = frag_global(Q, ld, q0, S, 1, lane);
+    const bf16x8 df0 = frag_global(dO, ldo, q0, S, 0, lane), df1 = frag_global(dO, ldo, q0, S, 1, lane);
+    const bf16x8 of0 = frag_global(O, ldo, q0, S, 0, lane), of1 = frag_global(O, ldo, q0, S, 1, lane);
+    float dsum = 0.f;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) dsum += (float)df0[j] * (float)of0[j] + (float)df1[j] * (float)of1[j];
+    dsum = colgroup_sum(dsum);                       // D_q = rowsum(dO * O)
+    // row constants as the initial accumulators: S' = S - L/c1 (so p = exp2(c1 S')), dP' = dP - D
+    const float nl = -(lse[((int64_t)b * H + h) * S + (q < S ? q : S - 1)] * LOG2E) * inv_c1, nd = -dsum;
+    f32x4 dq[4];
+#pragma unroll
+    for (int dt = 0; dt < 4; ++dt) dq[dt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    static_for<0, NKT / 2>([&](auto ic) {
+      constexpr int u = decltype(ic)::value;
+      bf16x8 ka0, ka1, kc0, kc1, va0, va1, vc0, vc1;         // key tiles 2u (a) and 2u+1 (c), k-steps 0 / 1
+      AT_DS_B128_OFF(ka0, kb0, (2 * u) * 2048);     AT_DS_B128_OFF(va0, vb0, (2 * u) * 2048);
+      AT_DS_B128_OFF(kc0, kb0, (2 * u + 1) * 2048); AT_DS_B128_OFF(vc0, vb0, (2 * u + 1) * 2048);
+      AT_DS_B128_OFF(ka1, kb1, (2 * u) * 2048);     AT_DS_B128_OFF(va1, vb1, (2 * u) * 2048);
+      AT_DS_B128_OFF(kc1, kb1, (2 * u + 1) * 2048); AT_DS_B128_OFF(vc1, vb1, (2 * u + 1) * 2048);
+      f32x4 sa = {nl, nl, nl, nl}, sc_ = {nl, nl, nl, nl}, pa = {nd, nd, nd, nd}, pc = {nd, nd, nd, nd};
+      asm volatile("s_waitcnt lgkmcnt(4)" : "+v"(ka0), "+v"(va0), "+v"(kc0), "+v"(vc0));
+      sa = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ka0, qf0, sa, 0, 0, 0);       // S'^T[key][q]
+      pa = __builtin_amdgcn_mfma_f32_16x16x32_bf16(va0, df0, pa, 0, 0, 0);       // dP'^T[key][q]
+      sc_ = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kc0, qf0, sc_, 0, 0, 0);
+      pc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vc0, df0, pc, 0, 0, 0);
+      asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(ka1), "+v"(va1), "+v"(kc1), "+v"(vc1));
+      sa = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ka1, qf1, sa, 0, 0, 0);
+      pa = __builtin_amdgcn_mfma_f32_16x16x32_bf16(va1, df1, pa, 0, 0, 0);
+      sc_ = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kc1, qf1, sc_, 0, 0, 0);
+      pc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vc1, df1, pc, 0, 0, 0);
+      bf16x4 klo[4], khi[4];                       // K^T fragments of the dQ product: in flight under the exponentials
+#pragma unroll
+      for (int dt = 0; dt < 4; ++dt) { AT_DS_TR_OFF(klo[dt], tk[dt], u * 4096); AT_DS_TR_OFF(khi[dt], tk[dt], u * 4096 + 2048); }
+      f32x4 dsa, dsc;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        float xa = sa[r] * c1, xc = sc_[r] * c1;
+        if (u == NKT / 2 - 1) {                    // only the last key pair holds keys beyond S (S > 16 (NKT - 2))
+          xa = (2 * u) * 16 + 4 * g + r < S ? xa : -INFINITY;
+          xc = (2 * u + 1) * 16 + 4 * g + r < S ? xc : -INFINITY;
+        }
+        dsa[r] = __builtin_amdgcn_exp2f(xa) * pa[r];        // p (dP - D); a padded query has lse = +inf -> p = 0
+        dsc[r] = __builtin_amdgcn_exp2f(xc) * pc[r];        // (the score scale is applied to dQ below)
+      }
+      const bf16x8 dsf = pack_pair(dsa, dsc);
+      asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(klo[0]), "+v"(khi[0]), "+v"(klo[1]), "+v"(khi[1]), "+v"(klo[2]), "+v"(khi[2]), "+v"(klo[3]), "+v"(khi[3]));
+#pragma unroll
+      for (int dt = 0; dt < 4; ++dt)
+        dq[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_shufflevector(klo[dt], khi[dt], 0, 1, 2, 3, 4, 5, 6, 7), dsf, dq[dt], 0, 0, 0);   // dQ^T[d][q]
+    });
+    bf16_t* drow = dqkv + ((int64_t)row0 + (q < S ? q : S - 1)) * ld + h * AT_DH;
+#pragma unroll
+    for (int dt = 0; dt < 4; ++dt) {
+      bf16x4 v;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) v[r] = (bf16_t)(dq[dt][r] * scale);
+      if (q < S) *reinterpret_cast<bf16x4*>(drow + dt * 16 + 4 * g) = v;
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------------
 // host side
 // ------------------------------------------------------------------------------------------------------
 bool mmrca_mha_mfma_ok(int S, int dh, int dtype) { return dtype == MMRCA_BF16 && dh == AT_DH && S >= 1 && S <= AT_MAX_S; }
@@ -659,6 +888,19 @@ int mmrca_mha_bwd_mfma(const void* qkv, const int32_t* key_mask, const void* out
   MMRCA_REQUIRE((((uintptr_t)qkv) & 15) == 0 && (((uintptr_t)out) & 15) == 0 && (((uintptr_t)dout) & 15) == 0 && (((uintptr_t)dqkv) & 7) == 0,
                 "mha_bwd: buffers must be 16-byte aligned");
   const int nkt = pick_nkt(S);
+  static const int bwd_v = getenv("MMRCA_ATTN_BWD_V") ? atoi(getenv("MMRCA_ATTN_BWD_V")) : 1;
+  const bool use_v = bwd_v && nkt == 14 && drop_p <= 0.f && !key_mask && !cu && S > 16 * 12;      // the ViT's attention
+  if (use_v) {
+    const int ldq = 2 * 14 * 16 * 128, ldkv = 2 * 14 * 16 * 128 + STAT_EXTRA(14);
+    (void)hipFuncSetAttribute((const void*)mha_bwd_dq_mfma_v_k<14, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, ldq);
+    hipLaunchKernelGGL((mha_bwd_dq_mfma_v_k<14, 8>), dim3(B * H), dim3(512), ldq, st, (const bf16_t*)qkv, (const bf16_t*)out, (const bf16_t*)dout, lse,
+                       (bf16_t*)dqkv, H, S, scale);
+    (void)hipFuncSetAttribute((const void*)mha_bwd_dkv_mfma_v_k<14, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, ldkv);
+    hipLaunchKernelGGL((mha_bwd_dkv_mfma_v_k<14, 8>), dim3(B * H), dim3(512), ldkv, st, (const bf16_t*)qkv, (const bf16_t*)out, (const bf16_t*)dout, lse,
+                       (bf16_t*)dqkv, H, S, scale);
+    MMRCA_CHECK_LAUNCH("mha_bwd(mfma,v)");
+    return 0;
+  }
   AT_SWITCH(K_DQ, BIAS_EXTRA, true, true, true, (const bf16_t*)qkv, key_mask, (const bf16_t*)out, (const bf16_t*)dout, lse, (bf16_t*)dqkv, H, S, scale, drop_p, drop_seed, cu);
   AT_SWITCH(K_DKV, STAT_EXTRA, true, false, true, (const bf16_t*)qkv, key_mask, (const bf16_t*)out, (const bf16_t*)dout, lse, (bf16_t*)dqkv, H, S, scale, drop_p, drop_seed, cu);
   MMRCA_CHECK_LAUNCH("mha_bwd(mfma)");

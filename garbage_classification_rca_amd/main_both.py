@@ -190,7 +190,7 @@ def main(argv=None):
     shuffle_seed = D.broadcast_seed(args.seed, device if world > 1 and torch.distributed.get_backend() == "nccl" else "cpu")
     global_model._drop_seed += rank * 1000003
     print("Per-process batch size: {} (global batch = {} x {} ranks; lr unchanged)".format(_batch_size, _batch_size, world))
-    for flag, default in (("balanced_sampler", False), ("use_synonyms", False)):
+    for flag, default in (("balanced_sampler", False), ("use_synonyms", False), ("prob_aug_text", 0.6)):
         if getattr(args, flag, default) != default:
             print("WARNING: --{} is accepted for CLI compatibility but not implemented on this path (SURVEY.md section 2: out of scope)".format(flag))
 

@@ -11,8 +11,8 @@ _INT, _FLOAT, _STR, _BOOL = "int", "float", "str", "bool"
 # (flag, kind, default, description)
 REFERENCE_FLAGS = [
     ("epochs", _INT, 100, "epochs of the frozen-backbone phase"),
-    ("dataset_folder_name", _STR, "", "training split: folder under --base_path"),
-    ("dataset_folder_name_val", _STR, "", "validation split: folder under --base_path"),
+    ("dataset_folder_name", _STR, "", "training split: folder under the working directory (the reference joins it to its script directory, main_both.py:39,458; --base_path is unused there too)"),
+    ("dataset_folder_name_val", _STR, "", "validation split: folder under the working directory"),
     ("lr", _FLOAT, 0.001, "learning rate of the first phase"),
     ("image_text_dropout", _FLOAT, 0.33, "probability that a training step zeroes one modality"),
     ("image_prob_dropout", _FLOAT, 0.7, "given that a modality is zeroed: probability that it is the image"),
@@ -31,7 +31,7 @@ REFERENCE_FLAGS = [
     ("batch_size", _INT, 16, "batch size, first phase"),
     ("batch_size_FT", _INT, 16, "batch size, fine-tuning phase"),
     ("opt", _STR, "sgd", "sgd | adamw"),
-    ("base_path", _STR, r"D:\Mestrado\ENSF_619_02_Final_project_jose_cazarin\BEST_MODELS_CVPR_2025", "root of datasets and checkpoints"),
+    ("base_path", _STR, r"D:\Mestrado\ENSF_619_02_Final_project_jose_cazarin\BEST_MODELS_CVPR_2025", "accepted for CLI compatibility; unused here as in the reference (paths are relative to the working directory)"),
     ("calculate_dataset_stats", _BOOL, False, "recompute the normalisation statistics"),
     ("prob_aug", _FLOAT, 0.6, "probability of each image augmentation"),
     ("late_fusion", _STR, "gated", "fusion head (MM_RCA is the one built here)"),
