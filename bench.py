@@ -349,7 +349,8 @@ def main():
                        "host_enqueue_ms_per_step": round(host_enqueue / args.steps * 1e3, 2)},
             "roofline": {"bound": "mfma", "achieved": round(achieved, 2), "peak": gemm_peak, "unit": "TFLOP/s",
                          "frac": round(achieved / gemm_peak, 4), "traffic": traffic if args.dtype == "bf16" else None,
-                         "traffic_unit": "bytes per GEMM launch (mean over the launches of a step)", "traffic_source": traffic_src,
+                         "traffic_unit": "bytes per GEMM KERNEL launch (mean; a call that AUTO splits into whole persistent rounds + a 128x128 tail is two "
+                                         "kernel launches there and one in launches_per_step / algorithmic_bytes_per_launch)", "traffic_source": traffic_src,
                          "algorithmic_bytes_per_launch": round(alg_mean),
                          "kernel": ("bf16 16x16x32 MFMA GEMMs: gemm_p256_k (persistent 256x256 tiles) and gemm_mfma_k1s (128x128 tiles) for the "
                                     "forward / input gradient, gemm_mfma256_k + splitk_reduce256_k (256x256 split-K) for the weight gradient; "
