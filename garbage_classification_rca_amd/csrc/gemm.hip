@@ -926,557 +926,6 @@ gemm_mfma_k1s(const bf16_t* __restrict__ A, const bf16_t* __restrict__ B, void* 
   }
 }
 
-// Tall single-stage variant: 256x128x64 block tile, EIGHT waves (4 x 2, each 64x64), 48 KiB of LDS, two blocks per CU.
-// Measured on the 128x128 kernel (halving its global->LDS staging gave +33%, halving its LDS fragment reads +1%): the
-// limiter is the per-CU vector-memory path that fills LDS -- 32 KiB per 128x128x64 step is 512 cycles at 64 B/clk, the same
-// as the step's MFMA time -- so the remedy is more flops per staged byte.  256x128 stages 48 KiB for twice the flops (0.75x
-// bytes per flop) and still keeps four waves on every SIMD.  A must be ROWK (forward and input-gradient GEMMs).
-template <bool B_KROW>
-__global__ void __launch_bounds__(512, 4)
-gemm_mfma_k1s_tall(const bf16_t* __restrict__ A, const bf16_t* __restrict__ B, void* __restrict__ Cv, const bf16_t* __restrict__ bias,
-              const bf16_t* __restrict__ addend, bf16_t* __restrict__ preact, int64_t M, int64_t N, int64_t K,
-              int64_t lda, int64_t ldb, int64_t ldc, int act, int tiles_m, int tiles_n, int64_t ksplit_len, float* __restrict__ colsum) {
-  extern __shared__ __attribute__((aligned(16))) char smem[];   // ONE buffer: [A tile 256 rows, 32 KiB | B tile 16 KiB]
-  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
-  const int wr = wave >> 1, wc = wave & 1;
-  const int nwg = tiles_m * tiles_n;
-  const int orig = blockIdx.x;
-  const int q8 = nwg >> 3, r8 = nwg & 7, xcd = orig & 7;
-  const int wgid = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (orig >> 3);
-  const int GROUP = 8;
-  const int group = wgid / (GROUP * tiles_n);
-  const int first_m = group * GROUP;
-  const int gsize = (tiles_m - first_m) < GROUP ? (tiles_m - first_m) : GROUP;
-  const int tm = first_m + (wgid % (GROUP * tiles_n)) % gsize;
-  const int tn = (wgid % (GROUP * tiles_n)) / gsize;
-  const int64_t m_blk = (int64_t)tm * 256, n_blk = (int64_t)tn * GBN;
-  const int64_t kbeg = (int64_t)blockIdx.y * ksplit_len;
-  int64_t kend = kbeg + ksplit_len; if (kend > K) kend = K;
-  const int nt = (int)((kend - kbeg + GBK - 1) / GBK);
-
-  f32x4 acc[4][4];
-#pragma unroll
-  for (int i = 0; i < 4; ++i)
-#pragma unroll
-    for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
-  for (int t = 0; t < nt; ++t) {
-    // single LDS stage: load -> wait -> barrier -> 32 MFMAs -> barrier; the load latency of this block is covered by the
-    // other three or four blocks resident on the CU (32 KiB of LDS each) instead of by software prefetch
-    stage_tile_n<false, 4>(A, lda, m_blk, M, kbeg + (int64_t)t * GBK, smem, wave, lane);                  // 32 x 1 KiB
-    stage_tile_n<B_KROW, 2>(B, ldb, n_blk, N, kbeg + (int64_t)t * GBK, smem + 2 * TILE_BYTES, wave, lane);  // 16 x 1 KiB
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-#pragma unroll
-    for (int ks = 0; ks < 2; ++ks) {
-      bf16x8 af[4], bfr[4];
-#pragma unroll
-      for (int i = 0; i < 4; ++i) af[i] = load_frag<false>(smem, wr * 64 + i * 16, ks, lane);
-#pragma unroll
-      for (int j = 0; j < 4; ++j) bfr[j] = load_frag<B_KROW>(smem + 2 * TILE_BYTES, wc * 64 + j * 16, ks, lane);
-#pragma unroll
-      for (int i = 0; i < 4; ++i)
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr[j], af[i], acc[i][j], 0, 0, 0);
-        }
-    }
-    __syncthreads();
-  }
-  const int g = lane >> 4, l16 = lane & 15;
-  {
-    bf16_t* C = (bf16_t*)Cv;
-    constexpr int EP_STRIDE = 128 * 4 + 16;
-    const int half = lane >> 5, l32 = lane & 31;
-    const int64_t ncol = n_blk + l32 * 4;
-    float bv[4] = {0.f, 0.f, 0.f, 0.f};
-    if (bias) {
-      bf16x4 b4 = *reinterpret_cast<const bf16x4*>(bias + ncol);
-#pragma unroll
-      for (int r = 0; r < 4; ++r) bv[r] = (float)b4[r];
-    }
-    // the side operand of the epilogue -- the residual addend, or the saved gelu'(h) that ACT_MUL multiplies by -- is
-    // fetched for the whole tile up front (16 x 8 B per lane, in the registers the operand fragments just vacated): in
-    // the model it was written many kernels ago and is long gone from L2/MALL, and loading it row by row inside the
-    // staged loop exposed one HBM round trip per pass
-    bf16x4 add4[4][4];
-    const bf16_t* side = act == MMRCA_ACT_MUL ? preact : addend;
-    if (side) {
-#pragma unroll
-      for (int i = 0; i < 4; ++i)
-#pragma unroll
-        for (int rr = 0; rr < 4; ++rr) {
-          const int lrow = wave * 8 + rr * 2 + half;
-          int64_t m = m_blk + (lrow >> 4) * 64 + i * 16 + (lrow & 15);
-          if (m > M - 1) m = M - 1;
-          add4[i][rr] = *reinterpret_cast<const bf16x4*>(side + m * ldc + ncol);
-        }
-    }
-    float cs[4] = {0.f, 0.f, 0.f, 0.f};      // column sums of what this lane stores (colsum != nullptr)
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-#pragma unroll
-      for (int j = 0; j < 4; ++j)
-        *reinterpret_cast<f32x4*>(smem + (wr * 16 + l16) * EP_STRIDE + (wc * 64 + j * 16 + 4 * g) * 4) = acc[i][j];
-      __syncthreads();
-#pragma unroll
-      for (int rr = 0; rr < 4; ++rr) {
-        const int lrow = wave * 8 + rr * 2 + half;
-        const int64_t m = m_blk + (lrow >> 4) * 64 + i * 16 + (lrow & 15);
-        if (m < M) {
-          const f32x4 c = *reinterpret_cast<const f32x4*>(smem + lrow * EP_STRIDE + l32 * 16);
-          float v[4] = {c[0] + bv[0], c[1] + bv[1], c[2] + bv[2], c[3] + bv[3]};
-          if (act == MMRCA_ACT_MUL) {
-#pragma unroll
-            for (int r = 0; r < 4; ++r) v[r] *= (float)add4[i][rr][r];
-          } else if (act == MMRCA_ACT_GELU_SAVE_GRAD) {
-            bf16x4 o;
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-              float dg;
-              v[r] = gelu_and_grad_fast_f(v[r], &dg);
-              o[r] = (bf16_t)dg;
-            }
-            *reinterpret_cast<bf16x4*>(preact + m * ldc + ncol) = o;
-          } else if (act == MMRCA_ACT_GELU_BWD) {
-            bf16x4 h4 = *reinterpret_cast<const bf16x4*>(preact + m * ldc + ncol);
-#pragma unroll
-            for (int r = 0; r < 4; ++r) v[r] *= gelu_grad_f((float)h4[r]);
-          } else if (preact) {
-            bf16x4 o;
-#pragma unroll
-            for (int r = 0; r < 4; ++r) o[r] = (bf16_t)v[r];
-            *reinterpret_cast<bf16x4*>(preact + m * ldc + ncol) = o;
-          }
-          if (act == MMRCA_ACT_GELU) {
-#pragma unroll
-            for (int r = 0; r < 4; ++r) v[r] = gelu_fast_f(v[r]);
-          }
-          if (addend) {
-            if (act == MMRCA_ACT_MUL) {       // (both side operands at once: the addend is read in place)
-              bf16x4 a4 = *reinterpret_cast<const bf16x4*>(addend + m * ldc + ncol);
-#pragma unroll
-              for (int r = 0; r < 4; ++r) v[r] += (float)a4[r];
-            } else {
-#pragma unroll
-              for (int r = 0; r < 4; ++r) v[r] += (float)add4[i][rr][r];
-            }
-          }
-          bf16x4 o;
-#pragma unroll
-          for (int r = 0; r < 4; ++r) { o[r] = (bf16_t)v[r]; cs[r] += (float)o[r]; }
-          *reinterpret_cast<bf16x4*>(C + m * ldc + ncol) = o;
-        }
-      }
-      __syncthreads();
-    }
-    if (colsum) {
-      // column sums of the stored tile (the bias gradient of the layer below, when this GEMM is its input gradient):
-      // 16 row groups (8 waves x 2 half-waves) -> LDS -> one atomic per column per block
-      float* red = reinterpret_cast<float*>(smem);
-#pragma unroll
-      for (int r = 0; r < 4; ++r) red[(wave * 2 + half) * 128 + l32 * 4 + r] = cs[r];
-      __syncthreads();
-      if (threadIdx.x < 128) {
-        float t = 0.f;
-#pragma unroll
-        for (int q = 0; q < 16; ++q) t += red[q * 128 + threadIdx.x];
-        atomicAdd(colsum + n_blk + threadIdx.x, t);
-      }
-    }
-  }
-}
-
-template <bool BK2>
-static void launch_mfma1s_tall(const void* A, const void* B, void* C, const void* bias, const void* addend, void* preact,
-                               int64_t M, int64_t N, int64_t K, int64_t lda, int64_t ldb, int64_t ldc, int act, int tiles_n,
-                               float* colsum, hipStream_t st) {
-  const int tiles_m = (int)((M + 255) / 256);
-  hipLaunchKernelGGL((gemm_mfma_k1s_tall<BK2>), dim3(tiles_m * tiles_n, 1), dim3(512), 3 * TILE_BYTES, st,
-                     (const bf16_t*)A, (const bf16_t*)B, C, (const bf16_t*)bias, (const bf16_t*)addend, (bf16_t*)preact,
-                     M, N, K, lda, ldb, ldc, act, tiles_m, tiles_n, K, colsum);
-}
-
-// ======================================================================================================
-// 256x256x64 block tile, SIXTEEN waves (4 x 4, each 64x64), two 64-KiB LDS stages, one block per CU.
-// The 128x128 kernels sit at ~73 % of the aggregate L2->CU bandwidth (32 flop per staged byte, ~28 TB/s at 900 TFLOP/s),
-// where queueing makes the staging latency ~2 us; this tile halves the staged bytes per flop (64 flop/B) and keeps a full
-// 64-KiB stage in flight behind 2,048 MFMA cycles per SIMD.  Four waves per SIMD (<= 128 VGPRs) hide the LDS read latency
-// the way the small kernels do; one barrier per K step.  A must be ROWK, no accumulate mode, N % 256 == 0.
-// Measured: 880-920 TFLOP/s on the wide-output shapes (= the 128x128 single-stage kernel), 5-12 % slower on the N = 768
-// shapes (591 tiles = 2.3 rounds of 256 CUs).  With its staging AND its LDS fragment reads halved (timing experiment) it
-// only reaches 1.0-1.23 PFLOP/s: no single limiter is left to remove, so AUTO keeps the small kernel; selectable (impl 8).
-// ======================================================================================================
-#define W256_STAGE_BYTES (4 * TILE_BYTES)      // A 256 rows x 128 B (32 KiB) | B 32 KiB
-
-template <bool B_KROW>
-__device__ __forceinline__ void stage256(const bf16_t* __restrict__ A, const bf16_t* __restrict__ B, int64_t lda, int64_t ldb,
-                                         int64_t m_blk, int64_t n_blk, int64_t M, int64_t N, int64_t k0, char* st, int wave, int lane) {
-  stage_tile_n<false, 2>(A, lda, m_blk, M, k0, st, wave, lane);                                   // 32 x 1 KiB over 16 waves
-  if (!B_KROW) stage_tile_n<false, 2>(B, ldb, n_blk, N, k0, st + 2 * TILE_BYTES, wave, lane);
-  else stage_tile_n<true, 2>(B, ldb, n_blk + (wave >> 3) * 128, N, k0, st + 2 * TILE_BYTES + (wave >> 3) * TILE_BYTES, wave & 7, lane);
-}
-
-template <bool B_KROW>
-__global__ void __launch_bounds__(1024, 4)
-gemm_mfma_k256w(const bf16_t* __restrict__ A, const bf16_t* __restrict__ B, bf16_t* __restrict__ C, const bf16_t* __restrict__ bias,
-                const bf16_t* __restrict__ addend, bf16_t* __restrict__ preact, int64_t M, int64_t N, int64_t K,
-                int64_t lda, int64_t ldb, int64_t ldc, int act, int tiles_m, int tiles_n, float* __restrict__ colsum) {
-  extern __shared__ __attribute__((aligned(16))) char smem[];   // [2 stages][A 32 KiB | B 32 KiB]
-  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
-  const int wr = wave >> 2, wc = wave & 3;
-  const int nwg = tiles_m * tiles_n;
-  const int orig = blockIdx.x;
-  const int q8 = nwg >> 3, r8 = nwg & 7, xcd = orig & 7;
-  const int wgid = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (orig >> 3);
-  const int GROUP = 8;
-  const int group = wgid / (GROUP * tiles_n);
-  const int first_m = group * GROUP;
-  const int gsize = (tiles_m - first_m) < GROUP ? (tiles_m - first_m) : GROUP;
-  const int tm = first_m + (wgid % (GROUP * tiles_n)) % gsize;
-  const int tn = (wgid % (GROUP * tiles_n)) / gsize;
-  const int64_t m_blk = (int64_t)tm * 256, n_blk = (int64_t)tn * 256;
-  const int nt = (int)((K + GBK - 1) / GBK);
-  // B fragments of this wave's 64 columns: ROWK image = rows of the 256-row B tile; KROW image = two 128-column sub-tiles
-  const int boff = 2 * TILE_BYTES + (B_KROW ? (wc >> 1) * TILE_BYTES : 0);
-  const int bcol = B_KROW ? (wc & 1) * 64 : wc * 64;
-
-  f32x4 acc[4][4];
-#pragma unroll
-  for (int i = 0; i < 4; ++i)
-#pragma unroll
-    for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
-  stage256<B_KROW>(A, B, lda, ldb, m_blk, n_blk, M, N, 0, smem, wave, lane);
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  __syncthreads();
-  for (int t = 0; t < nt; ++t) {
-    char* cur = smem + (t & 1) * W256_STAGE_BYTES;
-    char* nxt = smem + ((t + 1) & 1) * W256_STAGE_BYTES;
-    if (t + 1 < nt) stage256<B_KROW>(A, B, lda, ldb, m_blk, n_blk, M, N, (int64_t)(t + 1) * GBK, nxt, wave, lane);
-    const char* bt = cur + boff;
-#pragma unroll
-    for (int ks = 0; ks < 2; ++ks) {
-      bf16x8 af[4], bfr[4];
-#pragma unroll
-      for (int i = 0; i < 4; ++i) af[i] = load_frag<false>(cur, wr * 64 + i * 16, ks, lane);
-#pragma unroll
-      for (int j = 0; j < 4; ++j) bfr[j] = load_frag<B_KROW>(bt, bcol + j * 16, ks, lane);
-#pragma unroll
-      for (int i = 0; i < 4; ++i)
-#pragma unroll
-        for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr[j], af[i], acc[i][j], 0, 0, 0);
-    }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-  }
-  // ---------------- epilogue: 64 rows x 256 columns per pass through LDS (fp32), one whole row per wave instruction
-  const int g = lane >> 4, l16 = lane & 15;
-  constexpr int EP_STRIDE = 256 * 4 + 16;
-  const int64_t ncol = n_blk + lane * 4;
-  float bv[4] = {0.f, 0.f, 0.f, 0.f};
-  if (bias) {
-    bf16x4 b4 = *reinterpret_cast<const bf16x4*>(bias + ncol);
-#pragma unroll
-    for (int r = 0; r < 4; ++r) bv[r] = (float)b4[r];
-  }
-  bf16x4 add4[4][4];
-  const bf16_t* side = act == MMRCA_ACT_MUL ? preact : addend;
-  if (side) {
-#pragma unroll
-    for (int i = 0; i < 4; ++i)
-#pragma unroll
-      for (int rr = 0; rr < 4; ++rr) {
-        const int lrow = rr * 16 + wave;
-        int64_t m = m_blk + (lrow >> 4) * 64 + i * 16 + (lrow & 15);
-        if (m > M - 1) m = M - 1;
-        add4[i][rr] = *reinterpret_cast<const bf16x4*>(side + m * ldc + ncol);
-      }
-  }
-  float cs[4] = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-  for (int i = 0; i < 4; ++i) {
-#pragma unroll
-    for (int j = 0; j < 4; ++j)
-      *reinterpret_cast<f32x4*>(smem + (wr * 16 + l16) * EP_STRIDE + (wc * 64 + j * 16 + 4 * g) * 4) = acc[i][j];
-    __syncthreads();
-#pragma unroll
-    for (int rr = 0; rr < 4; ++rr) {
-      const int lrow = rr * 16 + wave;
-      const int64_t m = m_blk + (lrow >> 4) * 64 + i * 16 + (lrow & 15);
-      if (m < M) {
-        const f32x4 c = *reinterpret_cast<const f32x4*>(smem + lrow * EP_STRIDE + lane * 16);
-        float v[4] = {c[0] + bv[0], c[1] + bv[1], c[2] + bv[2], c[3] + bv[3]};
-        if (act == MMRCA_ACT_MUL) {
-#pragma unroll
-          for (int r = 0; r < 4; ++r) v[r] *= (float)add4[i][rr][r];
-        } else if (act == MMRCA_ACT_GELU_SAVE_GRAD) {
-          bf16x4 o;
-#pragma unroll
-          for (int r = 0; r < 4; ++r) {
-            float dg;
-            v[r] = gelu_and_grad_fast_f(v[r], &dg);
-            o[r] = (bf16_t)dg;
-          }
-          *reinterpret_cast<bf16x4*>(preact + m * ldc + ncol) = o;
-        } else if (act == MMRCA_ACT_GELU_BWD) {
-          bf16x4 h4 = *reinterpret_cast<const bf16x4*>(preact + m * ldc + ncol);
-#pragma unroll
-          for (int r = 0; r < 4; ++r) v[r] *= gelu_grad_f((float)h4[r]);
-        } else if (preact) {
-          bf16x4 o;
-#pragma unroll
-          for (int r = 0; r < 4; ++r) o[r] = (bf16_t)v[r];
-          *reinterpret_cast<bf16x4*>(preact + m * ldc + ncol) = o;
-        }
-        if (act == MMRCA_ACT_GELU) {
-#pragma unroll
-          for (int r = 0; r < 4; ++r) v[r] = gelu_fast_f(v[r]);
-        }
-        if (addend) {
-          if (act == MMRCA_ACT_MUL) {
-            bf16x4 a4 = *reinterpret_cast<const bf16x4*>(addend + m * ldc + ncol);
-#pragma unroll
-            for (int r = 0; r < 4; ++r) v[r] += (float)a4[r];
-          } else {
-#pragma unroll
-            for (int r = 0; r < 4; ++r) v[r] += (float)add4[i][rr][r];
-          }
-        }
-        bf16x4 o;
-#pragma unroll
-        for (int r = 0; r < 4; ++r) { o[r] = (bf16_t)v[r]; cs[r] += (float)o[r]; }
-        *reinterpret_cast<bf16x4*>(C + m * ldc + ncol) = o;
-      }
-    }
-    __syncthreads();
-  }
-  if (colsum) {
-    float* red = reinterpret_cast<float*>(smem);          // [16 waves][256 columns]
-#pragma unroll
-    for (int r = 0; r < 4; ++r) red[wave * 256 + lane * 4 + r] = cs[r];
-    __syncthreads();
-    if (threadIdx.x < 256) {
-      float t = 0.f;
-#pragma unroll
-      for (int q = 0; q < 16; ++q) t += red[q * 256 + threadIdx.x];
-      atomicAdd(colsum + n_blk + threadIdx.x, t);
-    }
-  }
-}
-
-template <bool BK2>
-static void launch_mfma256w(const void* A, const void* B, void* C, const void* bias, const void* addend, void* preact,
-                            int64_t M, int64_t N, int64_t K, int64_t lda, int64_t ldb, int64_t ldc, int act, float* colsum,
-                            hipStream_t st) {
-  const int tiles_m = (int)((M + 255) / 256), tiles_n = (int)(N / 256);
-  (void)hipFuncSetAttribute((const void*)gemm_mfma_k256w<BK2>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * W256_STAGE_BYTES);
-  hipLaunchKernelGGL((gemm_mfma_k256w<BK2>), dim3(tiles_m * tiles_n), dim3(1024), 2 * W256_STAGE_BYTES, st,
-                     (const bf16_t*)A, (const bf16_t*)B, (bf16_t*)C, (const bf16_t*)bias, (const bf16_t*)addend, (bf16_t*)preact,
-                     M, N, K, lda, ldb, ldc, act, tiles_m, tiles_n, colsum);
-}
-
-// ======================================================================================================
-// 256x256x64 block tile, FOUR waves (2 x 2), each a 128x128 wave tile (8 x 8 accumulators of f32x4 = 256 registers, in
-// AGPRs), two 64-KiB LDS stages, one block per CU, ONE wave per SIMD: the classic large-tile design (the vendor library's
-// MT256x256x64).  LDS fragment traffic per MFMA is half that of the 64x64 wave tile and the staged bytes per flop half
-// those of the 128x128 block tile; with a single wave per SIMD all latency hiding is instruction-level, so the K loop is
-// software-pipelined over the two 32-deep halves of a stage (fragments of the next half are read while the MFMAs of the
-// current one run; sched_group_barrier interleaves 1 LDS read : 4 MFMAs).  A must be ROWK, N % 256 == 0, no accumulate.
-// Measured: 300-400 TFLOP/s at K = 768, 580-630 at K = 3072 (ROWK B), i.e. well below the 128x128 kernel at four waves per
-// SIMD (900): a single wave issues an MFMA at best every ~28 cycles (register-only probe: 1.41 PFLOP/s at one wave per SIMD
-// against 16 cycles of pipe occupancy), and every LDS read, s_nop and address update comes out of that one instruction
-// stream -- moving the stage DMA a full iteration ahead changed nothing.  Selectable (impl 9), never picked by AUTO.
-// ======================================================================================================
-template <bool B_KROW>
-__device__ __forceinline__ void stage256x4(const bf16_t* __restrict__ A, const bf16_t* __restrict__ B, int64_t lda, int64_t ldb,
-                                           int64_t m_blk, int64_t n_blk, int64_t M, int64_t N, int64_t k0, char* st, int wave, int lane) {
-  stage_tile_n<false, 8>(A, lda, m_blk, M, k0, st, wave, lane);                                   // 32 x 1 KiB over 4 waves
-  if (!B_KROW) stage_tile_n<false, 8>(B, ldb, n_blk, N, k0, st + 2 * TILE_BYTES, wave, lane);
-  else stage_tile_n<true, 8>(B, ldb, n_blk + (wave >> 1) * 128, N, k0, st + 2 * TILE_BYTES + (wave >> 1) * TILE_BYTES, wave & 1, lane);
-}
-
-template <bool B_KROW>
-__global__ void __launch_bounds__(256, 1)
-gemm_mfma_k256x4(const bf16_t* __restrict__ A, const bf16_t* __restrict__ B, bf16_t* __restrict__ C, const bf16_t* __restrict__ bias,
-                 const bf16_t* __restrict__ addend, bf16_t* __restrict__ preact, int64_t M, int64_t N, int64_t K,
-                 int64_t lda, int64_t ldb, int64_t ldc, int act, int tiles_m, int tiles_n, float* __restrict__ colsum) {
-  extern __shared__ __attribute__((aligned(16))) char smem[];   // [2 stages][A 32 KiB | B 32 KiB]
-  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
-  const int wr = wave >> 1, wc = wave & 1;
-  const int nwg = tiles_m * tiles_n;
-  const int orig = blockIdx.x;
-  const int q8 = nwg >> 3, r8 = nwg & 7, xcd = orig & 7;
-  const int wgid = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (orig >> 3);
-  const int GROUP = 8;
-  const int group = wgid / (GROUP * tiles_n);
-  const int first_m = group * GROUP;
-  const int gsize = (tiles_m - first_m) < GROUP ? (tiles_m - first_m) : GROUP;
-  const int tm = first_m + (wgid % (GROUP * tiles_n)) % gsize;
-  const int tn = (wgid % (GROUP * tiles_n)) / gsize;
-  const int64_t m_blk = (int64_t)tm * 256, n_blk = (int64_t)tn * 256;
-  const int nt = (int)((K + GBK - 1) / GBK);
-  // B fragments of this wave's 128 columns: ROWK image = rows wc*128.. of the 256-row B tile; KROW image = sub-tile wc
-  const int boff = 2 * TILE_BYTES + (B_KROW ? wc * TILE_BYTES : 0);
-  const int bcol = B_KROW ? 0 : wc * 128;
-
-  f32x4 acc[8][8];
-#pragma unroll
-  for (int i = 0; i < 8; ++i)
-#pragma unroll
-    for (int j = 0; j < 8; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
-  stage256x4<B_KROW>(A, B, lda, ldb, m_blk, n_blk, M, N, 0, smem, wave, lane);
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  __syncthreads();
-  if (nt > 1) stage256x4<B_KROW>(A, B, lda, ldb, m_blk, n_blk, M, N, GBK, smem + W256_STAGE_BYTES, wave, lane);
-  bf16x8 af[2][8], bfr[2][8];          // fragment double buffer over the 32-deep halves
-#pragma unroll
-  for (int i = 0; i < 8; ++i) af[0][i] = load_frag<false>(smem, wr * 128 + i * 16, 0, lane);
-#pragma unroll
-  for (int j = 0; j < 8; ++j) bfr[0][j] = load_frag<B_KROW>(smem + boff, bcol + j * 16, 0, lane);
-  for (int t = 0; t < nt; ++t) {
-    char* cur = smem + (t & 1) * W256_STAGE_BYTES;
-    char* nxt = smem + ((t + 1) & 1) * W256_STAGE_BYTES;
-    // half 0: MFMAs on fragment buffer 0 while buffer 1 is read for half 1 of the same stage
-#pragma unroll
-    for (int i = 0; i < 8; ++i) af[1][i] = load_frag<false>(cur, wr * 128 + i * 16, 1, lane);
-#pragma unroll
-    for (int j = 0; j < 8; ++j) bfr[1][j] = load_frag<B_KROW>(cur + boff, bcol + j * 16, 1, lane);
-#pragma unroll
-    for (int i = 0; i < 8; ++i)
-#pragma unroll
-      for (int j = 0; j < 8; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr[0][j], af[0][i], acc[i][j], 0, 0, 0);
-#pragma unroll
-    for (int n = 0; n < 16; ++n) {
-      __builtin_amdgcn_sched_group_barrier(0x100, B_KROW ? 2 : 1, 0);     // DS read(s) of one fragment
-      __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);                  // 4 MFMAs
-    }
-    // stage t+1 (DMA issued a whole iteration ago) must have landed, and every wave must be done reading stage t
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-    // stage t is free now: refill it with stage t+2, a full iteration (2,048 MFMA cycles) before it is needed
-    if (t + 2 < nt) stage256x4<B_KROW>(A, B, lda, ldb, m_blk, n_blk, M, N, (int64_t)(t + 2) * GBK, cur, wave, lane);
-    // half 1: MFMAs on buffer 1 while buffer 0 is read for half 0 of the NEXT stage
-    // (unconditional, so the reads stay in the MFMAs' scheduling region: after the last stage they fetch unused bytes)
-#pragma unroll
-    for (int i = 0; i < 8; ++i) af[0][i] = load_frag<false>(nxt, wr * 128 + i * 16, 0, lane);
-#pragma unroll
-    for (int j = 0; j < 8; ++j) bfr[0][j] = load_frag<B_KROW>(nxt + boff, bcol + j * 16, 0, lane);
-#pragma unroll
-    for (int i = 0; i < 8; ++i)
-#pragma unroll
-      for (int j = 0; j < 8; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr[1][j], af[1][i], acc[i][j], 0, 0, 0);
-#pragma unroll
-    for (int n = 0; n < 16; ++n) {
-      __builtin_amdgcn_sched_group_barrier(0x100, B_KROW ? 2 : 1, 0);
-      __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);
-    }
-  }
-  // Hazards: half 1 of stage t is read (into buffer 1) BEFORE iteration t's barrier, half 0 of stage t+1 after it; the DMA
-  // that refills stage t's LDS buffer is issued after that barrier, i.e. after the last read of it has completed.
-  __syncthreads();
-  // ---------------- epilogue: 32 rows x 256 columns per pass through LDS (fp32), one whole row per wave instruction
-  const int g = lane >> 4, l16 = lane & 15;
-  constexpr int EP_STRIDE = 256 * 4 + 16;
-  const int64_t ncol = n_blk + lane * 4;
-  float bv[4] = {0.f, 0.f, 0.f, 0.f};
-  if (bias) {
-    bf16x4 b4 = *reinterpret_cast<const bf16x4*>(bias + ncol);
-#pragma unroll
-    for (int r = 0; r < 4; ++r) bv[r] = (float)b4[r];
-  }
-  const bf16_t* side = act == MMRCA_ACT_MUL ? preact : addend;
-  float cs[4] = {0.f, 0.f, 0.f, 0.f};
-  // (the pass index must be a compile-time constant: with a rolled loop the 256 accumulators would be indexed
-  //  dynamically and live in scratch memory, with a store after every MFMA of the main loop)
-#define EP256_PASS(i)                                                                                                   \
-  {                                                                                                                     \
-    bf16x4 add4[8];\
-    if (side) { \
-_Pragma("unroll") \
-      for (int rr = 0; rr < 8; ++rr) { \
-        const int lrow = rr * 4 + wave; \
-        int64_t m = m_blk + (lrow >> 4) * 128 + i * 16 + (lrow & 15); \
-        if (m > M - 1) m = M - 1; \
-        add4[rr] = *reinterpret_cast<const bf16x4*>(side + m * ldc + ncol); \
-      } \
-    } \
-_Pragma("unroll") \
-    for (int j = 0; j < 8; ++j) \
-      *reinterpret_cast<f32x4*>(smem + (wr * 16 + l16) * EP_STRIDE + (wc * 128 + j * 16 + 4 * g) * 4) = acc[i][j]; \
-    __syncthreads(); \
-_Pragma("unroll") \
-    for (int rr = 0; rr < 8; ++rr) { \
-      const int lrow = rr * 4 + wave; \
-      const int64_t m = m_blk + (lrow >> 4) * 128 + i * 16 + (lrow & 15); \
-      if (m < M) { \
-        const f32x4 c = *reinterpret_cast<const f32x4*>(smem + lrow * EP_STRIDE + lane * 16); \
-        float v[4] = {c[0] + bv[0], c[1] + bv[1], c[2] + bv[2], c[3] + bv[3]}; \
-        if (act == MMRCA_ACT_MUL) { \
-_Pragma("unroll") \
-          for (int r = 0; r < 4; ++r) v[r] *= (float)add4[rr][r]; \
-        } else if (act == MMRCA_ACT_GELU_SAVE_GRAD) { \
-          bf16x4 o; \
-_Pragma("unroll") \
-          for (int r = 0; r < 4; ++r) { \
-            float dg; \
-            v[r] = gelu_and_grad_fast_f(v[r], &dg); \
-            o[r] = (bf16_t)dg; \
-          } \
-          *reinterpret_cast<bf16x4*>(preact + m * ldc + ncol) = o; \
-        } else if (act == MMRCA_ACT_GELU_BWD) { \
-          bf16x4 h4 = *reinterpret_cast<const bf16x4*>(preact + m * ldc + ncol); \
-_Pragma("unroll") \
-          for (int r = 0; r < 4; ++r) v[r] *= gelu_grad_f((float)h4[r]); \
-        } else if (preact) { \
-          bf16x4 o; \
-_Pragma("unroll") \
-          for (int r = 0; r < 4; ++r) o[r] = (bf16_t)v[r]; \
-          *reinterpret_cast<bf16x4*>(preact + m * ldc + ncol) = o; \
-        } \
-        if (act == MMRCA_ACT_GELU) { \
-_Pragma("unroll") \
-          for (int r = 0; r < 4; ++r) v[r] = gelu_fast_f(v[r]); \
-        } \
-        if (addend) { \
-          if (act == MMRCA_ACT_MUL) { \
-            bf16x4 a4 = *reinterpret_cast<const bf16x4*>(addend + m * ldc + ncol); \
-_Pragma("unroll") \
-            for (int r = 0; r < 4; ++r) v[r] += (float)a4[r]; \
-          } else { \
-_Pragma("unroll") \
-            for (int r = 0; r < 4; ++r) v[r] += (float)add4[rr][r]; \
-          } \
-        } \
-        bf16x4 o; \
-_Pragma("unroll") \
-        for (int r = 0; r < 4; ++r) { o[r] = (bf16_t)v[r]; cs[r] += (float)o[r]; } \
-        *reinterpret_cast<bf16x4*>(C + m * ldc + ncol) = o; \
-      } \
-    } \
-\
-    __syncthreads();                                                                                                   \
-  }
-  EP256_PASS(0) EP256_PASS(1) EP256_PASS(2) EP256_PASS(3) EP256_PASS(4) EP256_PASS(5) EP256_PASS(6) EP256_PASS(7)
-#undef EP256_PASS
-  if (colsum) {
-    float* red = reinterpret_cast<float*>(smem);          // [4 waves][256 columns]
-#pragma unroll
-    for (int r = 0; r < 4; ++r) red[wave * 256 + lane * 4 + r] = cs[r];
-    __syncthreads();
-    atomicAdd(colsum + n_blk + threadIdx.x, red[threadIdx.x] + red[256 + threadIdx.x] + red[512 + threadIdx.x] + red[768 + threadIdx.x]);
-  }
-}
-
-template <bool BK2>
-static void launch_mfma256x4(const void* A, const void* B, void* C, const void* bias, const void* addend, void* preact,
-                             int64_t M, int64_t N, int64_t K, int64_t lda, int64_t ldb, int64_t ldc, int act, float* colsum,
-                             hipStream_t st) {
-  const int tiles_m = (int)((M + 255) / 256), tiles_n = (int)(N / 256);
-  (void)hipFuncSetAttribute((const void*)gemm_mfma_k256x4<BK2>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * W256_STAGE_BYTES);
-  hipLaunchKernelGGL((gemm_mfma_k256x4<BK2>), dim3(tiles_m * tiles_n), dim3(256), 2 * W256_STAGE_BYTES, st,
-                     (const bf16_t*)A, (const bf16_t*)B, (bf16_t*)C, (const bf16_t*)bias, (const bf16_t*)addend, (bf16_t*)preact,
-                     M, N, K, lda, ldb, ldc, act, tiles_m, tiles_n, colsum);
-}
-
 template <bool AK, bool BK2, bool AT, int WPE>
 static void launch_mfma1s(const void* A, const void* B, void* C, const void* bias, const void* addend, void* preact,
                           int64_t M, int64_t N, int64_t K, int64_t lda, int64_t ldb, int64_t ldc, int act, int tiles_m,
@@ -1484,195 +933,6 @@ static void launch_mfma1s(const void* A, const void* B, void* C, const void* bia
   hipLaunchKernelGGL((gemm_mfma_k1s<AK, BK2, AT, WPE>), dim3(tiles_m * tiles_n, ksplits), dim3(256), 2 * TILE_BYTES, st,
                      (const bf16_t*)A, (const bf16_t*)B, C, (const bf16_t*)bias, (const bf16_t*)addend, (bf16_t*)preact,
                      M, N, K, lda, ldb, ldc, act, tiles_m, tiles_n, ksplit_len, colsum);
-}
-
-// ======================================================================================================
-// persistent variant: grid = 2 blocks per CU; every block walks work items (tile, k-split) it, it+G, it+2G, ... and the
-// two-buffer K pipeline never stops at an item boundary: the first K-tile of the NEXT item is issued before the last
-// MFMAs of the current one, so its HBM latency hides behind those MFMAs and the epilogue (which stages through the
-// LDS buffer that is idle at that moment, 32 rows at a time).
-// ======================================================================================================
-template <bool A_KROW, bool B_KROW, bool ATOMIC_F32>
-__global__ void __launch_bounds__(256)
-gemm_mfma_p_k(const bf16_t* __restrict__ A, const bf16_t* __restrict__ B, void* __restrict__ Cv, const bf16_t* __restrict__ bias,
-              const bf16_t* __restrict__ addend, bf16_t* __restrict__ preact, int64_t M, int64_t N, int64_t K,
-              int64_t lda, int64_t ldb, int64_t ldc, int act, int tiles_m, int tiles_n, int ksplits, int64_t ksplit_len) {
-  extern __shared__ __attribute__((aligned(16))) char smem[];   // [2 buffers][A tile | B tile]
-  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
-  const int wr = wave >> 1, wc = wave & 1;
-  const int g = lane >> 4, l16 = lane & 15;
-  const int nwg = tiles_m * tiles_n;
-  const int total = nwg * ksplits;
-
-  auto decode = [&](int it, int64_t& m_blk, int64_t& n_blk, int64_t& kbeg, int& nt) {
-    const int orig = it % nwg, split = it / nwg;
-    const int q8 = nwg >> 3, r8 = nwg & 7, xcd = orig & 7;
-    const int wgid = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (orig >> 3);
-    const int GROUP = 8;
-    const int group = wgid / (GROUP * tiles_n);
-    const int first_m = group * GROUP;
-    const int gsize = (tiles_m - first_m) < GROUP ? (tiles_m - first_m) : GROUP;
-    m_blk = (int64_t)(first_m + (wgid % (GROUP * tiles_n)) % gsize) * GBM;
-    n_blk = (int64_t)((wgid % (GROUP * tiles_n)) / gsize) * GBN;
-    kbeg = (int64_t)split * ksplit_len;
-    int64_t kend = kbeg + ksplit_len; if (kend > K) kend = K;
-    nt = (int)((kend - kbeg + GBK - 1) / GBK);
-  };
-
-  int it = blockIdx.x;
-  if (it >= total) return;
-  int64_t m_blk, n_blk, kbeg; int nt;
-  decode(it, m_blk, n_blk, kbeg, nt);
-  int gstep = 0;                                   // global K-step counter: buffer = gstep & 1
-  stage_tile<A_KROW>(A, lda, m_blk, M, kbeg, smem, wave, lane);
-  stage_tile<B_KROW>(B, ldb, n_blk, N, kbeg, smem + TILE_BYTES, wave, lane);
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  __syncthreads();
-
-  while (true) {
-    const int it_next = it + gridDim.x;
-    const bool has_next = it_next < total;
-    int64_t m_n = 0, n_n = 0, k_n = 0; int nt_n = 0;
-    if (has_next) decode(it_next, m_n, n_n, k_n, nt_n);
-
-    f32x4 acc[4][4];
-#pragma unroll
-    for (int i = 0; i < 4; ++i)
-#pragma unroll
-      for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
-    // bias is fetched BEFORE the K loop: vmcnt retires in order, so a bias load issued in the epilogue would make its
-    // wait cover the run-ahead loads of the next item as well
-    float bv[4] = {0.f, 0.f, 0.f, 0.f};
-    if (!ATOMIC_F32 && bias) {
-      bf16x4 b4 = *reinterpret_cast<const bf16x4*>(bias + n_blk + (lane & 31) * 4);
-#pragma unroll
-      for (int r = 0; r < 4; ++r) bv[r] = (float)b4[r];
-    }
-
-    for (int t = 0; t < nt; ++t, ++gstep) {
-      char* cur = smem + (gstep & 1) * 2 * TILE_BYTES;
-      char* nxt = smem + ((gstep + 1) & 1) * 2 * TILE_BYTES;
-      const bool last = (t + 1 == nt);
-      if (!last) {
-        stage_tile<A_KROW>(A, lda, m_blk, M, kbeg + (int64_t)(t + 1) * GBK, nxt, wave, lane);
-        stage_tile<B_KROW>(B, ldb, n_blk, N, kbeg + (int64_t)(t + 1) * GBK, nxt + TILE_BYTES, wave, lane);
-      } else if (has_next) {                       // run ahead into the next work item
-        stage_tile<A_KROW>(A, lda, m_n, M, k_n, nxt, wave, lane);
-        stage_tile<B_KROW>(B, ldb, n_n, N, k_n, nxt + TILE_BYTES, wave, lane);
-      }
-#pragma unroll
-      for (int ks = 0; ks < 2; ++ks) {
-        bf16x8 af[4], bfr[4];
-#pragma unroll
-        for (int i = 0; i < 4; ++i) af[i] = load_frag<A_KROW>(cur, wr * 64 + i * 16, ks, lane);
-#pragma unroll
-        for (int j = 0; j < 4; ++j) bfr[j] = load_frag<B_KROW>(cur + TILE_BYTES, wc * 64 + j * 16, ks, lane);
-#pragma unroll
-        for (int i = 0; i < 4; ++i)
-#pragma unroll
-          for (int j = 0; j < 4; ++j) {
-            if (ATOMIC_F32) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i], bfr[j], acc[i][j], 0, 0, 0);
-            else            acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr[j], af[i], acc[i][j], 0, 0, 0);
-          }
-      }
-      if (!last) {
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();
-      } else {
-        asm volatile("s_barrier" ::: "memory");    // every wave is done reading `cur`; the run-ahead loads stay in flight
-      }
-    }
-    // ---------------- epilogue of the finished item; `ep` = the buffer just consumed (idle now)
-    char* ep = smem + ((gstep - 1) & 1) * 2 * TILE_BYTES;
-    if (ATOMIC_F32) {
-      float* C = (float*)Cv;
-#pragma unroll
-      for (int i = 0; i < 4; ++i)
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-          const int64_t n = n_blk + wc * 64 + j * 16 + l16;
-#pragma unroll
-          for (int r = 0; r < 4; ++r) {
-            const int64_t m = m_blk + wr * 64 + i * 16 + 4 * g + r;
-            if (m < M && n < N) atomicAdd(C + m * ldc + n, acc[i][j][r]);
-          }
-        }
-    } else {
-      bf16_t* C = (bf16_t*)Cv;
-      constexpr int EP_STRIDE = 128 * 4 + 16;      // 32 rows x 528 B = 16.5 KiB per pass
-      const int half = lane >> 5, l32 = lane & 31;
-      const int64_t ncol = n_blk + l32 * 4;
-#pragma unroll
-      for (int i = 0; i < 4; ++i) {                // pass i: tile rows wr*64 + i*16 + [0,16) of both wave rows
-#pragma unroll
-        for (int j = 0; j < 4; ++j)
-          *reinterpret_cast<f32x4*>(ep + (wr * 16 + l16) * EP_STRIDE + (wc * 64 + j * 16 + 4 * g) * 4) = acc[i][j];
-        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
-#pragma unroll
-        for (int rr = 0; rr < 4; ++rr) {
-          const int lrow = wave * 8 + rr * 2 + half;               // 0..31 within the pass
-          const int64_t m = m_blk + (lrow >> 4) * 64 + i * 16 + (lrow & 15);
-          if (m < M) {
-            const f32x4 c = *reinterpret_cast<const f32x4*>(ep + lrow * EP_STRIDE + l32 * 16);
-            float v[4] = {c[0] + bv[0], c[1] + bv[1], c[2] + bv[2], c[3] + bv[3]};
-            if (act == MMRCA_ACT_MUL) {
-              bf16x4 h4 = *reinterpret_cast<const bf16x4*>(preact + m * ldc + ncol);
-#pragma unroll
-              for (int r = 0; r < 4; ++r) v[r] *= (float)h4[r];
-            } else if (act == MMRCA_ACT_GELU_SAVE_GRAD) {
-              bf16x4 o;
-#pragma unroll
-              for (int r = 0; r < 4; ++r) {
-                const float e = erff(v[r] * 0.70710678118654752f);
-                o[r] = (bf16_t)(0.5f * (1.0f + e) + v[r] * 0.3989422804014327f * __expf(-0.5f * v[r] * v[r]));
-                v[r] = 0.5f * v[r] * (1.0f + e);
-              }
-              *reinterpret_cast<bf16x4*>(preact + m * ldc + ncol) = o;
-            } else if (act == MMRCA_ACT_GELU_BWD) {
-              bf16x4 h4 = *reinterpret_cast<const bf16x4*>(preact + m * ldc + ncol);
-#pragma unroll
-              for (int r = 0; r < 4; ++r) v[r] *= gelu_grad_f((float)h4[r]);
-            } else if (preact) {
-              bf16x4 o;
-#pragma unroll
-              for (int r = 0; r < 4; ++r) o[r] = (bf16_t)v[r];
-              *reinterpret_cast<bf16x4*>(preact + m * ldc + ncol) = o;
-            }
-            if (act == MMRCA_ACT_GELU) {
-#pragma unroll
-              for (int r = 0; r < 4; ++r) v[r] = gelu_fast_f(v[r]);
-            }
-            if (addend) {
-              bf16x4 a4 = *reinterpret_cast<const bf16x4*>(addend + m * ldc + ncol);
-#pragma unroll
-              for (int r = 0; r < 4; ++r) v[r] += (float)a4[r];
-            }
-            bf16x4 o;
-#pragma unroll
-            for (int r = 0; r < 4; ++r) o[r] = (bf16_t)v[r];
-            *reinterpret_cast<bf16x4*>(C + m * ldc + ncol) = o;
-          }
-        }
-        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");   // the pass buffer is re-written by the next pass
-      }
-    }
-    if (!has_next) break;
-    // the run-ahead K-tile of the next item must have landed before anyone reads it
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-    it = it_next; m_blk = m_n; n_blk = n_n; kbeg = k_n; nt = nt_n;
-  }
-}
-
-template <bool AK, bool BK2, bool AT>
-static void launch_mfma_p(const void* A, const void* B, void* C, const void* bias, const void* addend, void* preact,
-                          int64_t M, int64_t N, int64_t K, int64_t lda, int64_t ldb, int64_t ldc, int act, int tiles_m,
-                          int tiles_n, int ksplits, int64_t ksplit_len, hipStream_t st) {
-  const int total = tiles_m * tiles_n * ksplits;
-  const int grid = total < 512 ? total : 512;            // 256 CUs x 2 resident blocks (64 KiB LDS each)
-  hipLaunchKernelGGL((gemm_mfma_p_k<AK, BK2, AT>), dim3(grid), dim3(256), 4 * TILE_BYTES, st, (const bf16_t*)A, (const bf16_t*)B,
-                     C, (const bf16_t*)bias, (const bf16_t*)addend, (bf16_t*)preact, M, N, K, lda, ldb, ldc, act, tiles_m,
-                     tiles_n, ksplits, ksplit_len);
 }
 
 static bool aligned16(const void* p) { return (((uintptr_t)p) & 15) == 0; }
@@ -1687,7 +947,6 @@ static const int g_mmrca_auto256_side = getenv("MMRCA_AUTO256_SIDE") ? atoi(gete
 static const bool g_mmrca_auto256_gelu = getenv("MMRCA_AUTO256_GELU") ? atoi(getenv("MMRCA_AUTO256_GELU")) != 0 : true;
 static const int g_mmrca_auto256_tail = getenv("MMRCA_AUTO256_TAIL") ? atoi(getenv("MMRCA_AUTO256_TAIL")) : 2;
 static const int g_mmrca_auto256_tail_pct = getenv("MMRCA_AUTO256_TAIL_PCT") ? atoi(getenv("MMRCA_AUTO256_TAIL_PCT")) : 60;
-#define MMRCA_TALL_MIN_M (1LL << 60)   // AUTO threshold for the 256x128 kernel (off until measured)
 
 template <bool AK, bool BK2, bool AT, bool DB>
 static void launch_mfma(const void* A, const void* B, void* C, const void* bias, const void* addend, void* preact,
@@ -1759,7 +1018,9 @@ static int gemm_dispatch(const void* A, const void* B, void* C, const void* bias
     if (colsum_fused && fused_done) *fused_done = true;
     return mmrca_gemm256(A, B, C, bias, addend, preact, M, N, K, lda, ldb, ldc, a_layout, b_layout, act, colsum_fused, st);
   }
-  if ((impl == MMRCA_GEMM_MFMA || impl == MMRCA_GEMM_MFMA_PERSIST || impl == MMRCA_GEMM_MFMA_BK32 || impl == MMRCA_GEMM_MFMA_1STAGE || impl == MMRCA_GEMM_MFMA_TALL || impl == MMRCA_GEMM_MFMA_256W || impl == MMRCA_GEMM_MFMA_256X4) && !ok_mfma)
+  if (impl == MMRCA_GEMM_MFMA_PERSIST || impl == MMRCA_GEMM_MFMA_TALL || impl == MMRCA_GEMM_MFMA_256W || impl == MMRCA_GEMM_MFMA_256X4)
+    return mmrca_fail(-3, "gemm: impl %d was an experimental kernel of round 1 (measured slower, DESIGN.md K2) and has been removed", impl);
+  if ((impl == MMRCA_GEMM_MFMA || impl == MMRCA_GEMM_MFMA_BK32 || impl == MMRCA_GEMM_MFMA_1STAGE) && !ok_mfma)
     return mmrca_fail(-3, "gemm: shape M=%lld N=%lld K=%lld dtype=%d does not qualify for the MFMA kernel", (long long)M, (long long)N, (long long)K, dtype);
   const bool use_mfma = ok_mfma && impl != MMRCA_GEMM_REF;   // 128x128 kernel
 
@@ -1800,33 +1061,6 @@ static int gemm_dispatch(const void* A, const void* B, void* C, const void* bias
       MMRCA_CHECK_LAUNCH("gemm(mfma,bk32)");
       return 0;
     }
-    if (impl == MMRCA_GEMM_MFMA_256X4 && (at || ak || N % 256 != 0))
-      return mmrca_fail(-3, "gemm: the 4-wave 256x256 kernel needs a ROWK A operand, N %% 256 == 0 and no accumulate mode");
-    if (impl == MMRCA_GEMM_MFMA_256X4) {
-      if (colsum_fused && fused_done) *fused_done = true;
-      if (bk) launch_mfma256x4<true>(A, B, C, bias, addend, preact, M, N, K, lda, ldb, ldc, act, colsum_fused, st);
-      else launch_mfma256x4<false>(A, B, C, bias, addend, preact, M, N, K, lda, ldb, ldc, act, colsum_fused, st);
-      MMRCA_CHECK_LAUNCH("gemm(mfma,256x256,4 waves)");
-      return 0;
-    }
-    if (impl == MMRCA_GEMM_MFMA_256W && (at || ak || N % 256 != 0))
-      return mmrca_fail(-3, "gemm: the 16-wave 256x256 kernel needs a ROWK A operand, N %% 256 == 0 and no accumulate mode");
-    if (impl == MMRCA_GEMM_MFMA_256W) {
-      if (colsum_fused && fused_done) *fused_done = true;
-      if (bk) launch_mfma256w<true>(A, B, C, bias, addend, preact, M, N, K, lda, ldb, ldc, act, colsum_fused, st);
-      else launch_mfma256w<false>(A, B, C, bias, addend, preact, M, N, K, lda, ldb, ldc, act, colsum_fused, st);
-      MMRCA_CHECK_LAUNCH("gemm(mfma,256x256,16 waves)");
-      return 0;
-    }
-    if (impl == MMRCA_GEMM_MFMA_TALL && (at || ak))
-      return mmrca_fail(-3, "gemm: the 256x128 kernel needs a ROWK A operand and no accumulate mode");
-    if (impl == MMRCA_GEMM_MFMA_TALL || (auto1s && !ak && M >= MMRCA_TALL_MIN_M)) {
-      if (colsum_fused && fused_done) *fused_done = true;
-      if (bk) launch_mfma1s_tall<true>(A, B, C, bias, addend, preact, M, N, K, lda, ldb, ldc, act, tiles_n, colsum_fused, st);
-      else launch_mfma1s_tall<false>(A, B, C, bias, addend, preact, M, N, K, lda, ldb, ldc, act, tiles_n, colsum_fused, st);
-      MMRCA_CHECK_LAUNCH("gemm(mfma,256x128)");
-      return 0;
-    }
     // (compiled for five waves per SIMD, <= 96 VGPRs, this kernel spills and runs 2-5x slower: four is the sweet spot)
     if ((impl == MMRCA_GEMM_MFMA_1STAGE || auto1s) && !(at && bias)) {
       float* cs1 = at ? nullptr : colsum_fused;
@@ -1842,20 +1076,6 @@ static int gemm_dispatch(const void* A, const void* B, void* C, const void* bias
       else L1S(true, true, true);
 #undef L1S
       MMRCA_CHECK_LAUNCH("gemm(mfma,1stage)");
-      return 0;
-    }
-    if (impl == MMRCA_GEMM_MFMA_PERSIST && !(at && bias)) {
-#define LP(AK_, BK_, AT_) launch_mfma_p<AK_, BK_, AT_>(A, B, C, bias, addend, preact, M, N, K, lda, ldb, ldc, act, tiles_m, tiles_n, ksplits, ksplit_len, st)
-      if (!ak && !bk && !at) LP(false, false, false);
-      else if (!ak && bk && !at) LP(false, true, false);
-      else if (ak && !bk && !at) LP(true, false, false);
-      else if (ak && bk && !at) LP(true, true, false);
-      else if (!ak && !bk && at) LP(false, false, true);
-      else if (!ak && bk && at) LP(false, true, true);
-      else if (ak && !bk && at) LP(true, false, true);
-      else LP(true, true, true);
-#undef LP
-      MMRCA_CHECK_LAUNCH("gemm(mfma,persistent)");
       return 0;
     }
     if (at && bias && (impl == MMRCA_GEMM_MFMA_BK32 || auto32)) {   // the same on the 128x128x32 kernel (four blocks per CU)

@@ -35,12 +35,12 @@ enum { MMRCA_ROWK = 0, MMRCA_KROW = 1 };
 enum { MMRCA_GEMM_AUTO = 0, MMRCA_GEMM_REF = 1, MMRCA_GEMM_MFMA = 2 /* 128x128 tiles */,
        MMRCA_GEMM_MFMA256 = 3 /* 256x256 tiles, persistent workgroups; A row-major with round_up(M, 256) READABLE rows (AUTO only
                                   picks it when M % 256 == 0), N % 256 == 0, K % 64 == 0, K >= 128, operands < 4 GiB */,
-       MMRCA_GEMM_MFMA_PERSIST = 4 /* 128x128 tiles, persistent blocks with cross-tile prefetch */,
+       MMRCA_GEMM_MFMA_PERSIST = 4 /* reserved: experimental kernel of round 1, removed (rejected with an error) */,
        MMRCA_GEMM_MFMA_BK32 = 5 /* 128x128x32 tiles, 32 KiB LDS: four blocks per CU */,
        MMRCA_GEMM_MFMA_1STAGE = 6 /* 128x128x64 tiles, single LDS stage (32 KiB): four blocks per CU */,
-       MMRCA_GEMM_MFMA_TALL = 7 /* 256x128x64 tiles, eight waves, single LDS stage (48 KiB): two blocks per CU; A must be ROWK */,
-       MMRCA_GEMM_MFMA_256W = 8 /* 256x256x64 tiles, sixteen waves, two 64-KiB LDS stages: one block per CU; A ROWK, N % 256 == 0 */,
-       MMRCA_GEMM_MFMA_256X4 = 9 /* 256x256x64 tiles, FOUR waves of 128x128 (accumulators in AGPRs), software-pipelined: one wave per SIMD */ };
+       MMRCA_GEMM_MFMA_TALL = 7 /* reserved: removed */,
+       MMRCA_GEMM_MFMA_256W = 8 /* reserved: removed */,
+       MMRCA_GEMM_MFMA_256X4 = 9 /* reserved: removed */ };
 
 const char* mmrca_last_error(void);
 int mmrca_version(void);

@@ -53,8 +53,6 @@ for name, m, n, k, al, bl, acc in SHAPES:
         if impl == L.IMPL_MFMA256 and (acc or n % 256 or k < 128 or al == 1 or
                                        (epi["act"] == L.ACT_NONE and epi["preact"] is not None) or epi["act"] == L.ACT_GELU):
             continue
-        if impl in (L.IMPL_MFMA_TALL, L.IMPL_MFMA_256W, L.IMPL_MFMA_256X4) and (acc or al == 1 or (impl != L.IMPL_MFMA_TALL and n % 256)):
-            continue
         def run(impl=impl, dbg=dbg):
             L.load().mmrca_debug_set(dbg)
             L.gemm(A, B, C, bias=bias, M=m, N=n, K=k, lda=lda, ldb=ldb, ldc=n, a_layout=al, b_layout=bl, accum=bool(acc), dtype=L.BF16, impl=impl, **epi)
