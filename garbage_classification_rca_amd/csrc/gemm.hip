@@ -128,7 +128,11 @@ typedef float f32x16g __attribute__((ext_vector_type(16)));
 typedef float f32x4g __attribute__((ext_vector_type(4)));
 #define GEN_LD 20     // LDS row pitch in floats (16 k + 4 pad)
 
-template <typename T>
+// AK1 / BK1: the operand's k index is its contiguous dimension (ROWK).  With the layout a compile-time fact every staging
+// coordinate of a thread is fixed for the whole K loop: element i of a step sits at base + i * (uniform stride) in memory and
+// at base + i * (compile-time constant) in LDS, the row predicate is a per-thread bit mask, and only the last, partial K step
+// checks k -- the generic index arithmetic cost about as many VALU cycles per step as the MFMAs.
+template <typename T, bool AK1, bool BK1>
 __global__ void __launch_bounds__(256)
 gemm_gen_k(const T* __restrict__ A, const T* __restrict__ B, void* __restrict__ Cv, const T* __restrict__ bias,
            const T* __restrict__ addend, T* __restrict__ preact, int64_t M, int64_t N, int64_t K,
@@ -149,39 +153,38 @@ gemm_gen_k(const T* __restrict__ A, const T* __restrict__ B, void* __restrict__ 
   for (int j = 0; j < 2; ++j)
 #pragma unroll
     for (int r = 0; r < 16; ++r) { acc[j][r] = 0.f; if (LEVELS) { mid[j][r] = 0.f; tot[j][r] = 0.f; } }
-  // staging map: element e = t + 256 i of a (128 | 64) x 16 tile; consecutive lanes follow the operand's contiguous dimension
+  // staging: A tile = 128 rows x 16 k (8 elements per thread), B tile = 64 rows x 16 k (4 per thread); consecutive lanes follow
+  // the operand's contiguous dimension
+  const int a_row0 = AK1 ? (t >> 4) : (t & 127), a_k0 = AK1 ? (t & 15) : (t >> 7);
+  const int b_row0 = BK1 ? (t >> 4) : (t & 63), b_k0 = BK1 ? (t & 15) : (t >> 6);
+  constexpr int A_DROW = AK1 ? 16 : 0, A_DK = AK1 ? 0 : 2, B_DROW = BK1 ? 16 : 0, B_DK = BK1 ? 0 : 4;
+  const T* pa = A + (m0 + a_row0) * sam + (kbeg + a_k0) * sak;
+  const T* pb = B + (n0 + b_row0) * sbn + (kbeg + b_k0) * sbk;
+  const int64_t a_is = A_DROW * sam + A_DK * sak, b_is = B_DROW * sbn + B_DK * sbk;      // memory stride between a thread's elements
+  unsigned a_ok = 0, b_ok = 0;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) a_ok |= (unsigned)(m0 + a_row0 + i * A_DROW < M) << i;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) b_ok |= (unsigned)(n0 + b_row0 + i * B_DROW < N) << i;
+  const int a_lds = a_row0 * GEN_LD + a_k0, b_lds = b_row0 * GEN_LD + b_k0;
+  constexpr int A_LI = A_DROW * GEN_LD + A_DK, B_LI = B_DROW * GEN_LD + B_DK;
   float ra[8], rb[4];
-  auto fetch = [&](int64_t k0) {
+  auto fetch = [&](int64_t k0, bool full) {          // full: the whole 16-wide step lies inside [kbeg, Kend)
 #pragma unroll
-    for (int i = 0; i < 8; ++i) {
-      const int e = t + 256 * i;
-      const int arow = sak == 1 ? e >> 4 : e & 127, ak = sak == 1 ? e & 15 : e >> 7;
-      const int64_t gm = m0 + arow;
-      ra[i] = (gm < M && k0 + ak < Kend) ? to_f(A[gm * sam + (k0 + ak) * sak]) : 0.f;
-    }
+    for (int i = 0; i < 8; ++i)
+      ra[i] = ((a_ok >> i) & 1) && (full || k0 + a_k0 + i * A_DK < Kend) ? to_f(pa[i * a_is]) : 0.f;
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      const int e = t + 256 * i;
-      const int brow = sbk == 1 ? e >> 4 : e & 63, bk = sbk == 1 ? e & 15 : e >> 6;
-      const int64_t gn = n0 + brow;
-      rb[i] = (gn < N && k0 + bk < Kend) ? to_f(B[gn * sbn + (k0 + bk) * sbk]) : 0.f;
-    }
+    for (int i = 0; i < 4; ++i)
+      rb[i] = ((b_ok >> i) & 1) && (full || k0 + b_k0 + i * B_DK < Kend) ? to_f(pb[i * b_is]) : 0.f;
+    pa += 16 * sak; pb += 16 * sbk;
   };
   auto stash = [&](int buf) {
 #pragma unroll
-    for (int i = 0; i < 8; ++i) {
-      const int e = t + 256 * i;
-      const int arow = sak == 1 ? e >> 4 : e & 127, ak = sak == 1 ? e & 15 : e >> 7;
-      As[buf][arow * GEN_LD + ak] = ra[i];
-    }
+    for (int i = 0; i < 8; ++i) As[buf][a_lds + i * A_LI] = ra[i];
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      const int e = t + 256 * i;
-      const int brow = sbk == 1 ? e >> 4 : e & 63, bk = sbk == 1 ? e & 15 : e >> 6;
-      Bs[buf][brow * GEN_LD + bk] = rb[i];
-    }
+    for (int i = 0; i < 4; ++i) Bs[buf][b_lds + i * B_LI] = rb[i];
   };
-  fetch(kbeg);
+  fetch(kbeg, kbeg + 16 <= Kend);
   stash(0);
   __syncthreads();
   const int l32 = lane & 31, g = lane >> 5;
@@ -189,7 +192,7 @@ gemm_gen_k(const T* __restrict__ A, const T* __restrict__ B, void* __restrict__ 
   for (int64_t k0 = kbeg; k0 < Kend; k0 += 16, ++step) {
     const int buf = step & 1;
     const bool more = k0 + 16 < Kend;
-    if (more) fetch(k0 + 16);
+    if (more) fetch(k0 + 16, k0 + 32 <= Kend);
 #pragma unroll
     for (int c = 0; c < 2; ++c) {
       const f32x4g a = *reinterpret_cast<const f32x4g*>(&As[buf][(32 * wave + l32) * GEN_LD + 8 * c + 4 * g]);
@@ -204,16 +207,16 @@ gemm_gen_k(const T* __restrict__ A, const T* __restrict__ B, void* __restrict__ 
     if (LEVELS && (step & 3) == 3) {
 #pragma unroll
       for (int j = 0; j < 2; ++j) {
-        mid[j] += acc[j];
+        mid[LEVELS ? j : 0] += acc[j];
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
       }
       if ((step & 63) == 63) {
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
-          tot[j] += mid[j];
+          tot[LEVELS ? j : 0] += mid[LEVELS ? j : 0];
 #pragma unroll
-          for (int r = 0; r < 16; ++r) mid[j][r] = 0.f;
+          for (int r = 0; r < 16; ++r) mid[LEVELS ? j : 0][r] = 0.f;
         }
       }
     }
@@ -1122,10 +1125,16 @@ static int gemm_dispatch(const void* A, const void* B, void* C, const void* bias
       ksplit_len = ((K + splits - 1) / splits + 15) / 16 * 16;
       splits = (K + ksplit_len - 1) / ksplit_len;
     }
-    MMRCA_DISPATCH_DTYPE(dtype, "gemm",
-      hipLaunchKernelGGL(gemm_gen_k<T>, dim3((unsigned)(tm * tn), (unsigned)splits), dim3(256), 0, st, (const T*)A, (const T*)B, C,
-                         (const T*)bias, (const T*)addend, (T*)preact, M, N, K, sam, sak, sbn, sbk, ldc, act, out_f32_accum, (int)tn,
-                         ksplit_len);)
+#define LGEN(AK_, BK_)                                                                                                            \
+    MMRCA_DISPATCH_DTYPE(dtype, "gemm",                                                                                             \
+      hipLaunchKernelGGL((gemm_gen_k<T, AK_, BK_>), dim3((unsigned)(tm * tn), (unsigned)splits), dim3(256), 0, st, (const T*)A,     \
+                         (const T*)B, C, (const T*)bias, (const T*)addend, (T*)preact, M, N, K, sam, sak, sbn, sbk, ldc, act,     \
+                         out_f32_accum, (int)tn, ksplit_len);)
+    if (sak == 1 && sbk == 1) { LGEN(true, true) }
+    else if (sak == 1) { LGEN(true, false) }
+    else if (sbk == 1) { LGEN(false, true) }
+    else { LGEN(false, false) }
+#undef LGEN
     MMRCA_CHECK_LAUNCH("gemm(gen)");
     return 0;
   }
