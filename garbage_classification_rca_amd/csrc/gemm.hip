@@ -111,7 +111,7 @@ gemm_ref_k(const T* __restrict__ A, const T* __restrict__ B, void* __restrict__ 
 }
 
 // ======================================================================================================
-// gemm_gen_k: the general-shape kernel on the fp32 matrix cores (v_mfma_f32_32x32x2_f32), any dtype / layout / shape
+// gemm_gen_k: the general-shape kernel on the matrix cores (fp32: v_mfma_f32_32x32x2_f32, bf16: v_mfma_f32_32x32x16_bf16), any layout / shape
 // ======================================================================================================
 // Same contract and epilogue as gemm_ref_k at about twice its speed (64-72 vs 31-35 TFLOP/s on the fp32 encoder shapes,
 // 157 peak): it is what AUTO runs for fp32 (the "<= 1e-3" mode, bench.py --dtype fp32) and for bf16 shapes the bf16 MFMA
@@ -166,23 +166,29 @@ gemm_gen_k(const T* __restrict__ A, const T* __restrict__ B, void* __restrict__ 
   for (int i = 0; i < 8; ++i) a_ok |= (unsigned)(m0 + a_row0 + i * A_DROW < M) << i;
 #pragma unroll
   for (int i = 0; i < 4; ++i) b_ok |= (unsigned)(n0 + b_row0 + i * B_DROW < N) << i;
-  const int a_lds = a_row0 * GEN_LD + a_k0, b_lds = b_row0 * GEN_LD + b_k0;
-  constexpr int A_LI = A_DROW * GEN_LD + A_DK, B_LI = B_DROW * GEN_LD + B_DK;
-  float ra[8], rb[4];
+  // bf16 operands stay bf16 in LDS (row pitch 24 = 16 k + 8 pad: 16-byte aligned rows) and go through v_mfma_f32_32x32x16_bf16:
+  // one MFMA per 32x32 tile and K step instead of eight fp32 ones at a sixteenth of the cycles -- the products of two bf16
+  // values are exact in fp32 either way
+  constexpr bool BF = sizeof(T) == 2;
+  constexpr int LD = BF ? 24 : GEN_LD;
+  const int a_lds = a_row0 * LD + a_k0, b_lds = b_row0 * LD + b_k0;
+  constexpr int A_LI = A_DROW * LD + A_DK, B_LI = B_DROW * LD + B_DK;
+  typedef typename std::conditional<BF, T, float>::type S;      // staged element type
+  S ra[8], rb[4];
   auto fetch = [&](int64_t k0, bool full) {          // full: the whole 16-wide step lies inside [kbeg, Kend)
 #pragma unroll
     for (int i = 0; i < 8; ++i)
-      ra[i] = ((a_ok >> i) & 1) && (full || k0 + a_k0 + i * A_DK < Kend) ? to_f(pa[i * a_is]) : 0.f;
+      ra[i] = ((a_ok >> i) & 1) && (full || k0 + a_k0 + i * A_DK < Kend) ? (S)pa[i * a_is] : (S)0.f;
 #pragma unroll
     for (int i = 0; i < 4; ++i)
-      rb[i] = ((b_ok >> i) & 1) && (full || k0 + b_k0 + i * B_DK < Kend) ? to_f(pb[i * b_is]) : 0.f;
+      rb[i] = ((b_ok >> i) & 1) && (full || k0 + b_k0 + i * B_DK < Kend) ? (S)pb[i * b_is] : (S)0.f;
     pa += 16 * sak; pb += 16 * sbk;
   };
   auto stash = [&](int buf) {
 #pragma unroll
-    for (int i = 0; i < 8; ++i) As[buf][a_lds + i * A_LI] = ra[i];
+    for (int i = 0; i < 8; ++i) { if constexpr (BF) reinterpret_cast<T*>(As[buf])[a_lds + i * A_LI] = ra[i]; else As[buf][a_lds + i * A_LI] = ra[i]; }
 #pragma unroll
-    for (int i = 0; i < 4; ++i) Bs[buf][b_lds + i * B_LI] = rb[i];
+    for (int i = 0; i < 4; ++i) { if constexpr (BF) reinterpret_cast<T*>(Bs[buf])[b_lds + i * B_LI] = rb[i]; else Bs[buf][b_lds + i * B_LI] = rb[i]; }
   };
   fetch(kbeg, kbeg + 16 <= Kend);
   stash(0);
@@ -193,16 +199,26 @@ gemm_gen_k(const T* __restrict__ A, const T* __restrict__ B, void* __restrict__ 
     const int buf = step & 1;
     const bool more = k0 + 16 < Kend;
     if (more) fetch(k0 + 16, k0 + 32 <= Kend);
+    if constexpr (BF) {
+      typedef __attribute__((ext_vector_type(8))) __bf16 b16x8;
+      const b16x8 a = *reinterpret_cast<const b16x8*>(&reinterpret_cast<const T*>(As[buf])[(32 * wave + l32) * LD + 8 * g]);
 #pragma unroll
-    for (int c = 0; c < 2; ++c) {
-      const f32x4g a = *reinterpret_cast<const f32x4g*>(&As[buf][(32 * wave + l32) * GEN_LD + 8 * c + 4 * g]);
-      f32x4g b[2];
+      for (int j = 0; j < 2; ++j) {
+        const b16x8 bj = *reinterpret_cast<const b16x8*>(&reinterpret_cast<const T*>(Bs[buf])[(32 * j + l32) * LD + 8 * g]);
+        acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, bj, acc[j], 0, 0, 0);
+      }
+    } else {
 #pragma unroll
-      for (int j = 0; j < 2; ++j) b[j] = *reinterpret_cast<const f32x4g*>(&Bs[buf][(32 * j + l32) * GEN_LD + 8 * c + 4 * g]);
+      for (int c = 0; c < 2; ++c) {
+        const f32x4g a = *reinterpret_cast<const f32x4g*>(&As[buf][(32 * wave + l32) * GEN_LD + 8 * c + 4 * g]);
+        f32x4g b[2];
 #pragma unroll
-      for (int m = 0; m < 4; ++m)
+        for (int j = 0; j < 2; ++j) b[j] = *reinterpret_cast<const f32x4g*>(&Bs[buf][(32 * j + l32) * GEN_LD + 8 * c + 4 * g]);
 #pragma unroll
-        for (int j = 0; j < 2; ++j) acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[m], b[j][m], acc[j], 0, 0, 0);
+        for (int m = 0; m < 4; ++m)
+#pragma unroll
+          for (int j = 0; j < 2; ++j) acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[m], b[j][m], acc[j], 0, 0, 0);
+      }
     }
     if (LEVELS && (step & 3) == 3) {
 #pragma unroll
