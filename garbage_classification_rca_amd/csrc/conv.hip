@@ -495,10 +495,63 @@ __global__ void bn_act_fwd_k(const T* __restrict__ x, const float* __restrict__ 
 }
 
 /* y = act(gamma * (x - mean) * rstd + beta) on contiguous [rows, C] */
+// ---- 8 channels per thread (bf16, C % 8 == 0): the element-wise passes of BatchNorm with 16-byte accesses; same arithmetic
+typedef __attribute__((ext_vector_type(8))) __bf16 bn_b8;
+__device__ __forceinline__ void bn_load8(const float* __restrict__ p, float (&v)[8]) {
+  const float4 a = *reinterpret_cast<const float4*>(p), b = *reinterpret_cast<const float4*>(p + 4);
+  v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w; v[4] = b.x; v[5] = b.y; v[6] = b.z; v[7] = b.w;
+}
+__global__ void __launch_bounds__(256)
+bn_act_fwd_v8_k(const bf16_t* __restrict__ x, const float* __restrict__ mean, const float* __restrict__ rstd, const bf16_t* __restrict__ gamma,
+                const bf16_t* __restrict__ beta, bf16_t* __restrict__ y, int64_t n8, int C8, int act) {
+  const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= n8) return;
+  const int c0 = (int)(idx % C8) * 8;
+  float m[8], r[8];
+  bn_load8(mean + c0, m); bn_load8(rstd + c0, r);
+  const bn_b8 g = *reinterpret_cast<const bn_b8*>(gamma + c0), b = *reinterpret_cast<const bn_b8*>(beta + c0);
+  const bn_b8 xv = *reinterpret_cast<const bn_b8*>(x + idx * 8);
+  bn_b8 o;
+#pragma unroll
+  for (int j = 0; j < 8; ++j) o[j] = (bf16_t)act_f(((float)xv[j] - m[j]) * r[j] * (float)g[j] + (float)b[j], act);
+  *reinterpret_cast<bn_b8*>(y + idx * 8) = o;
+}
+__global__ void __launch_bounds__(256)
+bn_act_bwd_apply_v8_k(const bf16_t* __restrict__ dy, const bf16_t* __restrict__ x, const float* __restrict__ mean, const float* __restrict__ rstd,
+                      const bf16_t* __restrict__ gamma, const bf16_t* __restrict__ beta, const float* __restrict__ sum_du,
+                      const float* __restrict__ sum_duxh, bf16_t* __restrict__ dx, int64_t n8, int C8, int act, float inv_rows, int train) {
+  const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= n8) return;
+  const int c0 = (int)(idx % C8) * 8;
+  float m[8], r[8], sd[8], sx[8];
+  bn_load8(mean + c0, m); bn_load8(rstd + c0, r); bn_load8(sum_du + c0, sd); bn_load8(sum_duxh + c0, sx);
+  const bn_b8 g = *reinterpret_cast<const bn_b8*>(gamma + c0), b = *reinterpret_cast<const bn_b8*>(beta + c0);
+  const bn_b8 xv = *reinterpret_cast<const bn_b8*>(x + idx * 8), dv = *reinterpret_cast<const bn_b8*>(dy + idx * 8);
+  bn_b8 o;
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    const float gj = (float)g[j];
+    const float xh = ((float)xv[j] - m[j]) * r[j];
+    float du = (float)dv[j] * act_grad_f(xh * gj + (float)b[j], act);
+    if (train) du -= (sd[j] + xh * sx[j]) * inv_rows;
+    o[j] = (bf16_t)(gj * r[j] * du);
+  }
+  *reinterpret_cast<bn_b8*>(dx + idx * 8) = o;
+}
+static bool bn_v8_ok(int C, int dtype, const void* a, const void* b, const void* c, const void* d) {
+  return dtype == MMRCA_BF16 && C % 8 == 0 && ((((uintptr_t)a) | ((uintptr_t)b) | ((uintptr_t)c) | ((uintptr_t)d)) & 15) == 0;
+}
+
 extern "C" int mmrca_bn_act_fwd(const void* x, const float* mean, const float* rstd, const void* gamma, const void* beta, void* y,
                                 int64_t rows, int C, int act, int dtype, void* stream) {
   MMRCA_REQUIRE(x && mean && rstd && gamma && beta && y && rows > 0 && C > 0 && act >= 0 && act <= 3, "bn_act_fwd: bad arguments");
   const int64_t n = rows * C;
+  if (bn_v8_ok(C, dtype, x, y, gamma, beta) && ((((uintptr_t)mean) | ((uintptr_t)rstd)) & 15) == 0) {
+    hipLaunchKernelGGL(bn_act_fwd_v8_k, dim3(blocks_for(n / 8, 256)), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)x, mean, rstd,
+                       (const bf16_t*)gamma, (const bf16_t*)beta, (bf16_t*)y, n / 8, C / 8, act);
+    MMRCA_CHECK_LAUNCH("bn_act_fwd(v8)");
+    return 0;
+  }
   MMRCA_DISPATCH_DTYPE(dtype, "bn_act_fwd",
     hipLaunchKernelGGL(bn_act_fwd_k<T>, dim3(blocks_for(n, 256)), dim3(256), 0, (hipStream_t)stream, (const T*)x, mean, rstd, (const T*)gamma,
                        (const T*)beta, (T*)y, n, C, act);)
@@ -568,7 +621,11 @@ extern "C" int mmrca_bn_act_bwd(const void* dy, const void* x, const float* mean
   MMRCA_DISPATCH_DTYPE(dtype, "bn_act_bwd",
     hipLaunchKernelGGL(bn_act_bwd_reduce_k<T>, grid, dim3(256), 0, st, (const T*)dy, (const T*)x, mean, rstd, (const T*)gamma, (const T*)beta,
                        scratch, scratch + C, rows, C, act, per);
-    if (dx) hipLaunchKernelGGL(bn_act_bwd_apply_k<T>, dim3(blocks_for(n, 256)), dim3(256), 0, st, (const T*)dy, (const T*)x, mean, rstd,
+    const bool v8 = dx && bn_v8_ok(C, dtype, dy, x, dx, gamma) && ((((uintptr_t)mean) | ((uintptr_t)rstd) | ((uintptr_t)scratch) | ((uintptr_t)beta)) & 15) == 0;
+    if (v8) hipLaunchKernelGGL(bn_act_bwd_apply_v8_k, dim3(blocks_for(n / 8, 256)), dim3(256), 0, st, (const bf16_t*)dy, (const bf16_t*)x, mean, rstd,
+                               (const bf16_t*)gamma, (const bf16_t*)beta, (const float*)scratch, (const float*)(scratch + C), (bf16_t*)dx,
+                               n / 8, C / 8, act, 1.0f / (float)rows, train);
+    else if (dx) hipLaunchKernelGGL(bn_act_bwd_apply_k<T>, dim3(blocks_for(n, 256)), dim3(256), 0, st, (const T*)dy, (const T*)x, mean, rstd,
                                (const T*)gamma, (const T*)beta, (const float*)scratch, (const float*)(scratch + C), (T*)dx, n, C, act,
                                1.0f / (float)rows, train);)
   if (dgamma && dbeta) hipLaunchKernelGGL(bn_param_grads_k, dim3((C + 255) / 256), dim3(256), 0, st, scratch, scratch + C, dgamma, dbeta, C);
@@ -709,6 +766,25 @@ extern "C" int mmrca_bias_act_bwd(const void* dy, const void* x, const void* bia
 }
 
 // out = a + b * rowscale[sample]   (residual connection with torchvision's "row" stochastic depth; rowscale NULL = 1)
+__global__ void __launch_bounds__(256)
+residual_add_v8_k(const bf16_t* __restrict__ a, const bf16_t* __restrict__ b, const float* __restrict__ rowscale, bf16_t* __restrict__ out,
+                  int64_t n8, int64_t per_sample8) {
+  typedef __attribute__((ext_vector_type(8))) __bf16 b8;
+  const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= n8) return;
+  const float sc = rowscale ? rowscale[idx / per_sample8] : 1.f;
+  const b8 bv = *reinterpret_cast<const b8*>(b + idx * 8);
+  b8 o;
+  if (a) {
+    const b8 av = *reinterpret_cast<const b8*>(a + idx * 8);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) o[j] = (bf16_t)((float)av[j] + (float)bv[j] * sc);
+  } else {
+#pragma unroll
+    for (int j = 0; j < 8; ++j) o[j] = (bf16_t)(0.f + (float)bv[j] * sc);
+  }
+  *reinterpret_cast<b8*>(out + idx * 8) = o;
+}
 template <typename T>
 __global__ void residual_add_k(const T* __restrict__ a, const T* __restrict__ b, const float* __restrict__ rowscale, T* __restrict__ out,
                                int64_t n, int64_t per_sample) {
@@ -722,6 +798,12 @@ extern "C" int mmrca_residual_add(const void* a, const void* branch, const float
                                   void* stream) {
   MMRCA_REQUIRE(branch && out && B > 0 && per_sample > 0, "residual_add: bad arguments");
   const int64_t n = (int64_t)B * per_sample;
+  if (dtype == MMRCA_BF16 && per_sample % 8 == 0 && ((((uintptr_t)a) | ((uintptr_t)branch) | ((uintptr_t)out)) & 15) == 0) {
+    hipLaunchKernelGGL(residual_add_v8_k, dim3(blocks_for(n / 8, 256)), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)a, (const bf16_t*)branch,
+                       rowscale, (bf16_t*)out, n / 8, per_sample / 8);
+    MMRCA_CHECK_LAUNCH("residual_add(v8)");
+    return 0;
+  }
   MMRCA_DISPATCH_DTYPE(dtype, "residual_add",
     hipLaunchKernelGGL(residual_add_k<T>, dim3(blocks_for(n, 256)), dim3(256), 0, (hipStream_t)stream, (const T*)a, (const T*)branch, rowscale,
                        (T*)out, n, per_sample);)
