@@ -78,9 +78,91 @@ __global__ void im2row3x3_k(const T* __restrict__ x, T* __restrict__ col, int B,
     }
 }
 
+// ---- 8 channels per thread (bf16, C % 8 == 0): nine 16-byte reads of x, a register transpose to the channel-major patch order
+// (element 9 j + tap of the thread's 72-element chunk = channel j, tap), nine 16-byte stores
+typedef __attribute__((ext_vector_type(8))) __bf16 im_b8;
+__global__ void __launch_bounds__(256)
+im2row3x3_v8_k(const bf16_t* __restrict__ x, bf16_t* __restrict__ col, int B, int H, int W, int C, int Ho, int Wo, int stride, int64_t ldk) {
+  const int C8 = C >> 3;
+  const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= (int64_t)B * Ho * Wo * C8) return;
+  const int c0 = (int)(idx % C8) * 8;
+  const int64_t op = idx / C8;
+  const int ox = (int)(op % Wo), oy = (int)((op / Wo) % Ho), b = (int)(op / ((int64_t)Wo * Ho));
+  im_b8 v[9];
+#pragma unroll
+  for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+    for (int kx = 0; kx < 3; ++kx) {
+      const int iy = oy * stride + ky - 1, ix = ox * stride + kx - 1;
+      im_b8 t;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) t[j] = (bf16_t)0.f;
+      if (iy >= 0 && iy < H && ix >= 0 && ix < W) t = *reinterpret_cast<const im_b8*>(x + (((int64_t)b * H + iy) * W + ix) * C + c0);
+      v[ky * 3 + kx] = t;
+    }
+  im_b8* dst = reinterpret_cast<im_b8*>(col + op * ldk + (int64_t)c0 * 9);
+#pragma unroll
+  for (int i = 0; i < 9; ++i) {
+    im_b8 o;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) { const int e = 8 * i + k; o[k] = v[e % 9][e / 9]; }
+    dst[i] = o;
+  }
+}
+// the reverse: an input pixel gathers its (up to nine) contributions; every contribution is one element per channel of a
+// 72-element chunk, read as nine 16-byte loads (the same bytes the scalar kernel touches, a ninth of the instructions)
+__global__ void __launch_bounds__(256)
+col2im3x3_v8_k(const bf16_t* __restrict__ dcol, bf16_t* __restrict__ dx, int B, int H, int W, int C, int Ho, int Wo, int stride, int64_t ldk) {
+  const int C8 = C >> 3;
+  const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= (int64_t)B * H * W * C8) return;
+  const int c0 = (int)(idx % C8) * 8;
+  const int64_t ip = idx / C8;
+  const int ix = (int)(ip % W), iy = (int)((ip / W) % H), b = (int)(ip / ((int64_t)W * H));
+  float s[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) s[j] = 0.f;
+#pragma unroll
+  for (int ky = 0; ky < 3; ++ky) {
+    const int ty = iy + 1 - ky;
+    if (ty < 0 || ty % stride) continue;
+    const int oy = ty / stride;
+    if (oy >= Ho) continue;
+#pragma unroll
+    for (int kx = 0; kx < 3; ++kx) {
+      const int tx = ix + 1 - kx;
+      if (tx < 0 || tx % stride) continue;
+      const int ox = tx / stride;
+      if (ox >= Wo) continue;
+      const im_b8* src = reinterpret_cast<const im_b8*>(dcol + (((int64_t)b * Ho + oy) * Wo + ox) * ldk + (int64_t)c0 * 9);
+      const int tap = ky * 3 + kx;
+      im_b8 ch[9];
+#pragma unroll
+      for (int i = 0; i < 9; ++i) ch[i] = src[i];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) { const int e = 9 * j + tap; s[j] += (float)ch[e / 8][e % 8]; }
+    }
+  }
+  im_b8 o;
+#pragma unroll
+  for (int j = 0; j < 8; ++j) o[j] = (bf16_t)s[j];
+  *reinterpret_cast<im_b8*>(dx + ip * C + c0) = o;
+}
+static bool im_v8_ok(int C, int64_t ldk, int dtype, const void* a, const void* b) {
+  return dtype == MMRCA_BF16 && C % 8 == 0 && ldk % 8 == 0 && ((((uintptr_t)a) | ((uintptr_t)b)) & 15) == 0;
+}
+
 extern "C" int mmrca_im2row3x3(const void* x, void* col, int B, int H, int W, int C, int stride, int64_t ldk, int dtype, void* stream) {
   MMRCA_REQUIRE(x && col && B > 0 && H > 0 && W > 0 && C > 0 && (stride == 1 || stride == 2) && ldk >= 9LL * C, "im2row3x3: bad arguments");
   const int Ho = (H - 1) / stride + 1, Wo = (W - 1) / stride + 1;
+  if (im_v8_ok(C, ldk, dtype, x, col)) {
+    const int64_t n8 = (int64_t)B * Ho * Wo * (C / 8);
+    hipLaunchKernelGGL(im2row3x3_v8_k, dim3(blocks_for(n8, 256)), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)x, (bf16_t*)col, B, H, W, C,
+                       Ho, Wo, stride, ldk);
+    MMRCA_CHECK_LAUNCH("im2row3x3(v8)");
+    return 0;
+  }
   const int64_t n = (int64_t)B * Ho * Wo * C;
   MMRCA_DISPATCH_DTYPE(dtype, "im2row3x3",
     hipLaunchKernelGGL(im2row3x3_k<T>, dim3(blocks_for(n, 256)), dim3(256), 0, (hipStream_t)stream, (const T*)x, (T*)col, B, H, W, C,
@@ -120,6 +202,13 @@ __global__ void col2im3x3_k(const T* __restrict__ dcol, T* __restrict__ dx, int 
 extern "C" int mmrca_col2im3x3(const void* dcol, void* dx, int B, int H, int W, int C, int stride, int64_t ldk, int dtype, void* stream) {
   MMRCA_REQUIRE(dcol && dx && B > 0 && H > 0 && W > 0 && C > 0 && (stride == 1 || stride == 2) && ldk >= 9LL * C, "col2im3x3: bad arguments");
   const int Ho = (H - 1) / stride + 1, Wo = (W - 1) / stride + 1;
+  if (im_v8_ok(C, ldk, dtype, dcol, dx)) {
+    const int64_t n8 = (int64_t)B * H * W * (C / 8);
+    hipLaunchKernelGGL(col2im3x3_v8_k, dim3(blocks_for(n8, 256)), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)dcol, (bf16_t*)dx, B, H, W, C,
+                       Ho, Wo, stride, ldk);
+    MMRCA_CHECK_LAUNCH("col2im3x3(v8)");
+    return 0;
+  }
   const int64_t n = (int64_t)B * H * W * C;
   MMRCA_DISPATCH_DTYPE(dtype, "col2im3x3",
     hipLaunchKernelGGL(col2im3x3_k<T>, dim3(blocks_for(n, 256)), dim3(256), 0, (hipStream_t)stream, (const T*)dcol, (T*)dx, B, H, W, C,
