@@ -175,20 +175,52 @@ gemm_gen_k(const T* __restrict__ A, const T* __restrict__ B, void* __restrict__ 
   constexpr int A_LI = A_DROW * LD + A_DK, B_LI = B_DROW * LD + B_DK;
   typedef typename std::conditional<BF, T, float>::type S;      // staged element type
   S ra[8], rb[4];
-  auto fetch = [&](int64_t k0, bool full) {          // full: the whole 16-wide step lies inside [kbeg, Kend)
+  auto fetch_a = [&](int64_t k0, bool full) {        // full: the whole 16-wide step lies inside [kbeg, Kend)
 #pragma unroll
     for (int i = 0; i < 8; ++i)
       ra[i] = ((a_ok >> i) & 1) && (full || k0 + a_k0 + i * A_DK < Kend) ? (S)pa[i * a_is] : (S)0.f;
+    pa += 16 * sak;
+  };
+  auto fetch_b = [&](int64_t k0, bool full) {
 #pragma unroll
     for (int i = 0; i < 4; ++i)
       rb[i] = ((b_ok >> i) & 1) && (full || k0 + b_k0 + i * B_DK < Kend) ? (S)pb[i * b_is] : (S)0.f;
-    pa += 16 * sak; pb += 16 * sbk;
+    pb += 16 * sbk;
   };
-  auto stash = [&](int buf) {
+  auto stash_a = [&](int buf) {
 #pragma unroll
     for (int i = 0; i < 8; ++i) { if constexpr (BF) reinterpret_cast<T*>(As[buf])[a_lds + i * A_LI] = ra[i]; else As[buf][a_lds + i * A_LI] = ra[i]; }
+  };
+  auto stash_b = [&](int buf) {
 #pragma unroll
     for (int i = 0; i < 4; ++i) { if constexpr (BF) reinterpret_cast<T*>(Bs[buf])[b_lds + i * B_LI] = rb[i]; else Bs[buf][b_lds + i * B_LI] = rb[i]; }
+  };
+  // bf16 ROWK operands, aligned: a thread moves ONE group of 8 contiguous k of a row per step -- a 16-byte load and a 16-byte
+  // LDS store instead of eight two-byte ones.  (The same for KROW operands -- 8 rows of a k, eight 2-byte LDS stores 384 bytes
+  // apart -- was measured slower in situ: 8-way bank conflicts; they keep the element-wise staging.)
+  typedef __attribute__((ext_vector_type(8))) __bf16 g_b8;
+  bool vec_a = false, vec_b = false;
+  if constexpr (BF) {
+    const bool kok = (Kend - kbeg) % 8 == 0 && kbeg % 8 == 0;
+    vec_a = AK1 && kok && (((uintptr_t)A) & 15) == 0 && sam % 8 == 0;
+    vec_b = BK1 && kok && (((uintptr_t)B) & 15) == 0 && sbn % 8 == 0;
+  }
+  const int va_r = t >> 1, va_k = 8 * (t & 1), vb_r = (t & 127) >> 1, vb_k = 8 * (t & 1);      // group = (row, first k)
+  g_b8 ga, gb;
+  auto zero8 = [&]() { g_b8 z; for (int j = 0; j < 8; ++j) z[j] = (__bf16)0.f; return z; };
+  auto fetch = [&](int64_t k0, bool full) {
+    if constexpr (BF) {
+      if (vec_a) ga = (m0 + va_r < M && k0 + va_k < Kend) ? *reinterpret_cast<const g_b8*>(A + (m0 + va_r) * sam + (k0 + va_k)) : zero8();
+      else fetch_a(k0, full);
+      if (vec_b) { if (t < 128) gb = (n0 + vb_r < N && k0 + vb_k < Kend) ? *reinterpret_cast<const g_b8*>(B + (n0 + vb_r) * sbn + (k0 + vb_k)) : zero8(); }
+      else fetch_b(k0, full);
+    } else { fetch_a(k0, full); fetch_b(k0, full); }
+  };
+  auto stash = [&](int buf) {
+    if constexpr (BF) {
+      if (vec_a) *reinterpret_cast<g_b8*>(reinterpret_cast<T*>(As[buf]) + va_r * LD + va_k) = ga; else stash_a(buf);
+      if (vec_b) { if (t < 128) *reinterpret_cast<g_b8*>(reinterpret_cast<T*>(Bs[buf]) + vb_r * LD + vb_k) = gb; } else stash_b(buf);
+    } else { stash_a(buf); stash_b(buf); }
   };
   fetch(kbeg, kbeg + 16 <= Kend);
   stash(0);
