@@ -844,9 +844,51 @@ __global__ void rowpool_mean_bwd_k(const T* __restrict__ dpool, T* __restrict__ 
   const float g = to_f(dpool[b * C + c]) / (float)HW;
   dx[idx] = from_f<T>(accumulate ? to_f(dx[idx]) + g : g);
 }
+// ---- 8 channels per thread (bf16, C % 8 == 0) for the element-wise squeeze-excitation / pooling passes
+typedef __attribute__((ext_vector_type(8))) __bf16 se_b8;
+__global__ void __launch_bounds__(256)
+rowpool_mean_bwd_v8_k(const bf16_t* __restrict__ dpool, bf16_t* __restrict__ dx, int64_t n8, int HW, int C8, int accumulate) {
+  const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= n8) return;
+  const int c8 = (int)(idx % C8);
+  const int64_t b = idx / ((int64_t)HW * C8);
+  const se_b8 g = *reinterpret_cast<const se_b8*>(dpool + (b * C8 + c8) * 8);
+  se_b8 o;
+  if (accumulate) {
+    const se_b8 d = *reinterpret_cast<const se_b8*>(dx + idx * 8);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) o[j] = (bf16_t)((float)d[j] + (float)g[j] / (float)HW);
+  } else {
+#pragma unroll
+    for (int j = 0; j < 8; ++j) o[j] = (bf16_t)((float)g[j] / (float)HW);
+  }
+  *reinterpret_cast<se_b8*>(dx + idx * 8) = o;
+}
+__global__ void __launch_bounds__(256)
+se_scale_fwd_v8_k(const bf16_t* __restrict__ x, const bf16_t* __restrict__ sc, bf16_t* __restrict__ y, int64_t n8, int HW, int C8) {
+  const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= n8) return;
+  const int c8 = (int)(idx % C8);
+  const int64_t b = idx / ((int64_t)HW * C8);
+  const se_b8 xv = *reinterpret_cast<const se_b8*>(x + idx * 8), sv = *reinterpret_cast<const se_b8*>(sc + (b * C8 + c8) * 8);
+  se_b8 o;
+#pragma unroll
+  for (int j = 0; j < 8; ++j) o[j] = (bf16_t)((float)xv[j] * (float)sv[j]);
+  *reinterpret_cast<se_b8*>(y + idx * 8) = o;
+}
+static bool se_v8_ok(int C, int dtype, const void* a, const void* b, const void* c) {
+  return dtype == MMRCA_BF16 && C % 8 == 0 && ((((uintptr_t)a) | ((uintptr_t)b) | ((uintptr_t)c)) & 15) == 0;
+}
+
 extern "C" int mmrca_rowpool_mean_bwd(const void* dpool, void* dx, int B, int HW, int C, int accumulate, int dtype, void* stream) {
   MMRCA_REQUIRE(dpool && dx && B > 0 && HW > 0 && C > 0, "rowpool_mean_bwd: bad arguments");
   const int64_t n = (int64_t)B * HW * C;
+  if (se_v8_ok(C, dtype, dpool, dx, dx)) {
+    hipLaunchKernelGGL(rowpool_mean_bwd_v8_k, dim3(blocks_for(n / 8, 256)), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)dpool, (bf16_t*)dx,
+                       n / 8, HW, C / 8, accumulate);
+    MMRCA_CHECK_LAUNCH("rowpool_mean_bwd(v8)");
+    return 0;
+  }
   MMRCA_DISPATCH_DTYPE(dtype, "rowpool_mean_bwd",
     hipLaunchKernelGGL(rowpool_mean_bwd_k<T>, dim3(blocks_for(n, 256)), dim3(256), 0, (hipStream_t)stream, (const T*)dpool, (T*)dx, n, HW, C, accumulate);)
   MMRCA_CHECK_LAUNCH("rowpool_mean_bwd");
@@ -865,6 +907,12 @@ __global__ void se_scale_fwd_k(const T* __restrict__ x, const T* __restrict__ s,
 extern "C" int mmrca_se_scale_fwd(const void* x, const void* s, void* y, int B, int HW, int C, int dtype, void* stream) {
   MMRCA_REQUIRE(x && s && y && B > 0 && HW > 0 && C > 0, "se_scale_fwd: bad arguments");
   const int64_t n = (int64_t)B * HW * C;
+  if (se_v8_ok(C, dtype, x, s, y)) {
+    hipLaunchKernelGGL(se_scale_fwd_v8_k, dim3(blocks_for(n / 8, 256)), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)x, (const bf16_t*)s,
+                       (bf16_t*)y, n / 8, HW, C / 8);
+    MMRCA_CHECK_LAUNCH("se_scale_fwd(v8)");
+    return 0;
+  }
   MMRCA_DISPATCH_DTYPE(dtype, "se_scale_fwd",
     hipLaunchKernelGGL(se_scale_fwd_k<T>, dim3(blocks_for(n, 256)), dim3(256), 0, (hipStream_t)stream, (const T*)x, (const T*)s, (T*)y, n, HW, C);)
   MMRCA_CHECK_LAUNCH("se_scale_fwd");
