@@ -1,21 +1,27 @@
 // K2: C[M,N] = act(A (.) B + bias) + addend  -- every nn.Linear forward, input-gradient and weight-gradient
 // on the MM-RCA path (see include/mmrca.h).
 //
-// Two implementations behind one entry point:
-//   * gemm_ref_k   : fp32-accumulating VALU tile kernel, any dtype / layout / shape.  It is the fp32 "parity mode"
-//                    and the fallback for shapes the MFMA kernel does not take (e.g. the 4-class logits).
-//   * gemm_mfma_k  : bf16 v_mfma_f32_16x16x32_bf16 kernel, 128x128x64 tiles, 4 waves (2x2, 64x64 per wave),
-//                    operands staged HBM->LDS with global_load_lds (16 B/lane, no VGPR round trip), double-buffered.
-//                    Both operand layouts are handled in LDS, so no transposed copies of weights or activations
-//                    ever exist in HBM:
-//                      ROWK [rows][k]  : 128-B LDS rows, 16-B chunks XOR-swizzled by (row>>1)&7 -> conflict-free
-//                                        ds_read_b128 fragment reads (swizzle applied on the global source address,
-//                                        because global_load_lds writes lane-linear).
-//                      KROW [k][rows]  : 256-B LDS rows, 32-B granules XOR-swizzled by (k&3)|((k>>3)&1)<<2, read
-//                                        with ds_read_b64_tr_b16 (hardware transpose) -> conflict-free.
-//                    XCD-aware block->tile map (8 XCDs, private L2s) with grouped-M rastering.
-//                    Weight gradients (fp32, +=) split the long contraction over blockIdx.y and combine with
-//                    fp32 atomics shaped as 64-B row segments.
+// Implementations behind the one entry point (gemm_dispatch picks; MMRCA_GEMM_* variables and the impl argument override):
+//   * gemm_ref_k    : fp32-accumulating VALU tile kernel, any dtype / layout / shape: the checker the other kernels are
+//                     tested against (impl = REF) and the last-resort fallback.
+//   * gemm_gen_k    : the general-shape kernel on the matrix cores (fp32 32x32x2 / bf16 32x32x16), any layout / shape:
+//                     the fp32 "<= 1e-3" mode and the bf16 shapes the tiled kernels cannot take (conv channel counts,
+//                     the 4-class logits).
+//   * gemm_mfma_k   : bf16 v_mfma_f32_16x16x32_bf16 kernel, 128x128x64 tiles, 4 waves (2x2, 64x64 per wave),
+//                     operands staged HBM->LDS with global_load_lds (16 B/lane, no VGPR round trip), double-buffered.
+//                     Both operand layouts are handled in LDS, so no transposed copies of weights or activations
+//                     ever exist in HBM:
+//                       ROWK [rows][k]  : 128-B LDS rows, 16-B chunks XOR-swizzled by (row>>1)&7 -> conflict-free
+//                                         ds_read_b128 fragment reads (swizzle applied on the global source address,
+//                                         because global_load_lds writes lane-linear).
+//                       KROW [k][rows]  : 256-B LDS rows, 32-B granules XOR-swizzled by (k&3)|((k>>3)&1)<<2, read
+//                                         with ds_read_b64_tr_b16 (hardware transpose) -> conflict-free.
+//                     XCD-aware block->tile map (8 XCDs, private L2s) with grouped-M rastering.
+//                     Weight gradients (fp32, +=) split the long contraction over blockIdx.y and combine with
+//                     fp32 atomics shaped as 64-B row segments.
+//   * gemm_mfma_k32 / gemm_mfma_k1s : the same tile with a 32-deep K step / a single LDS stage (more blocks per CU);
+//                     used for the shapes the dispatch table names.
+//   * gemm256.hip   : the persistent 256x256 kernel that runs the encoder-sized GEMMs (the headline K2 number).
 #include "common.h"
 #include "lds_asm.h"
 #include <stdlib.h>

@@ -767,9 +767,32 @@ patchify_k(const float* __restrict__ img, T* __restrict__ out, int B, int C, int
   }
 }
 
+// any patch size (BLIP-2's ViT-g/14: P = 14): one element per thread
+template <typename T>
+__global__ void __launch_bounds__(256)
+patchify_any_k(const float* __restrict__ img, T* __restrict__ out, int B, int C, int Himg, int Wimg, int P, int64_t total) {
+  const int nPw = Wimg / P, nPh = Himg / P, Kp = C * P * P;
+  for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (int64_t)gridDim.x * blockDim.x) {
+    const int k = (int)(e % Kp);
+    const int64_t row = e / Kp;
+    const int pw = (int)(row % nPw), ph = (int)((row / nPw) % nPh), b = (int)(row / ((int64_t)nPw * nPh));
+    const int px = k % P, py = (k / P) % P, c = k / (P * P);
+    out[e] = from_f<T>(img[(((int64_t)b * C + c) * Himg + (ph * P + py)) * Wimg + pw * P + px]);
+  }
+}
+
 extern "C" int mmrca_patchify_fwd(const float* images, void* patches, int B, int C, int Himg, int Wimg, int P, int dtype, void* stream) {
   MMRCA_REQUIRE(images && patches, "patchify_fwd: null pointer");
-  MMRCA_REQUIRE(P % 4 == 0 && Himg % P == 0 && Wimg % P == 0 && Wimg % 4 == 0, "patchify_fwd: unsupported geometry");
+  MMRCA_REQUIRE(P > 0 && Himg % P == 0 && Wimg % P == 0, "patchify_fwd: image %dx%d is not a whole number of %dx%d patches", Himg, Wimg, P, P);
+  if (P % 4 != 0 || Wimg % 4 != 0) {
+    const int64_t total = (int64_t)B * C * Himg * Wimg;
+    if (total <= 0) return 0;
+    const int grid = (int)((total + 255) / 256 < 16384 ? (total + 255) / 256 : 16384);
+    MMRCA_DISPATCH_DTYPE(dtype, "patchify_fwd",
+      hipLaunchKernelGGL(patchify_any_k<T>, dim3(grid), dim3(256), 0, (hipStream_t)stream, images, (T*)patches, B, C, Himg, Wimg, P, total);)
+    MMRCA_CHECK_LAUNCH("patchify_fwd");
+    return 0;
+  }
   const int64_t total4 = (int64_t)B * C * Himg * Wimg / 4;
   if (total4 <= 0) return 0;
   const int grid = (int)((total4 + 255) / 256 < 8192 ? (total4 + 255) / 256 : 8192);

@@ -79,6 +79,7 @@ _SIGS = {
     "mmrca_mha_fwd": [_vp] * 4 + [_i32] * 4 + [_f32, _f32, _u64, _vp, _i32, _i32, _vp],
     "mmrca_mha_bwd": [_vp] * 6 + [_i32] * 4 + [_f32, _f32, _u64, _vp, _i32, _i32, _vp],
     "mmrca_mha_bwd_colsum": [_vp] * 7 + [_i64] + [_i32] * 4 + [_f32, _f32, _u64, _vp, _i32, _i32, _vp],
+    "mmrca_mha_cross_fwd": [_vp, _i64, _vp, _i64, _vp, _i64, _vp, _i64] + [_i32] * 5 + [_f32, _f32, _u64, _i32, _i32, _vp],
     "mmrca_mha_cls_fwd": [_vp] * 4 + [_i32] * 4 + [_f32, _f32, _u64, _vp, _i32, _vp],
     "mmrca_mha_cls_bwd": [_vp] * 6 + [_i32] * 4 + [_f32, _f32, _u64, _vp, _i32, _vp],
     "mmrca_add_layernorm_fwd": [_vp] * 8 + [_i64, _i32, _i64, _i64, _f32, _f32, _u64, _f32, _u64, _i32, _vp],
@@ -253,6 +254,13 @@ def mha_bwd(qkv, key_mask, out, dout, lse, dqkv, B, H, S, dh, scale, dtype, impl
             return
         _check(load().mmrca_mha_bwd(ptr(qkv), ptr(key_mask), ptr(out), ptr(dout), ptr(lse), ptr(dqkv), B, H, S, dh, scale,
                                     drop_p, drop_seed, ptr(cu), dtype, impl, stream_ptr()), "mmrca_mha_bwd")
+
+
+def mha_cross_fwd(q, ldq, k, ldk, v, ldv, out, ldo, B, H, Sq, Skv, dh, scale, dtype, impl=IMPL_AUTO, drop_p=0.0, drop_seed=0):
+    """attention forward with separate q / k / v operands (tensors or views; the pointers are taken at their first element)"""
+    _dev(q, "q"); _dev(k, "k"); _dev(v, "v"); _dev(out, "out")
+    _check(load().mmrca_mha_cross_fwd(ptr(q), ldq, ptr(k), ldk, ptr(v), ldv, ptr(out), ldo, B, H, Sq, Skv, dh, scale, drop_p,
+                                      drop_seed, dtype, impl, stream_ptr()), "mha_cross_fwd")
 
 
 def mha_cls_fwd(qkv, key_mask, out, lse, B, H, S, dh, scale, dtype, drop_p=0.0, drop_seed=0, cu=None):

@@ -151,6 +151,17 @@ int mmrca_mha_bwd(const void* qkv, const int32_t* key_mask, const void* out, con
 int mmrca_mha_bwd_colsum(const void* qkv, const int32_t* key_mask, const void* out, const void* dout, const float* lse,
                          void* dqkv, float* dqkv_colsum, int64_t total_rows, int B, int H, int S, int dh, float scale,
                          float drop_p, uint64_t drop_seed, const int32_t* cu_seqlens, int dtype, int impl, void* stream);
+/* K3x. Attention FORWARD with separate operands: out[b*Sq + i, h*dh + d] = softmax_j(q_i . k_j * scale) v_j over the S_kv
+ * rows of sequence b.  q: [B*Sq, ldq], k / v: [B*Skv, ldk / ldv], out: [B*Sq, ldo]; head h at columns h*dh of each.
+ * Covers what the BLIP-2 path (q_former_training.py:289 -> transformers 5.15.0 modeling_blip_2.py) needs beyond K3:
+ * the ViT-g tower's head dim 88 at S = 257 (modeling_blip_2.py:282-354: pass the three column blocks of its fused qkv
+ * buffer) and the Q-Former cross-attention, 32 queries over 257 image tokens (modeling_blip_2.py:536-606).
+ * drop_p > 0: attention-probability dropout, mask from (seed, ((b*H+h)*Sq + i)*Skv + j).  No key mask: the reference
+ * passes an all-ones image_attention_mask.  bf16 with dh % 8 == 0, S_kv <= 288 and 16-byte aligned rows runs on MFMA
+ * (impl = MMRCA_GEMM_MFMA demands it); anything else, and impl = MMRCA_GEMM_REF, runs the fp32-math kernel. */
+int mmrca_mha_cross_fwd(const void* q, int64_t ldq, const void* k, int64_t ldk, const void* v, int64_t ldv, void* out,
+                        int64_t ldo, int B, int H, int Sq, int Skv, int dh, float scale, float drop_p, uint64_t drop_seed,
+                        int dtype, int impl, void* stream);
 /* K3c. The same attention for the class-token query only (row 0 of every sequence): what the LAST encoder layer needs,
  * because the reference reads hidden_state[:, 0] (multimodal_model.py:352,517) / torchvision reads x[:, 0] and nothing else
  * of that layer's output.  out / dout: [B, H*dh] (compact), lse: fp32 [B,H].  The backward fills the WHOLE fused dqkv

@@ -1,0 +1,184 @@
+"""GPU parity tests of the BLIP-2 Q-Former path: the K3x attention kernels against torch, the HIP
+engine against oracle/qformer.py (pinned to transformers 5.15.0's Blip2VisionModel / Blip2QFormerModel), and the training
+loop of q_former_training.py:274-309 against stock torch AdamW / CrossEntropyLoss."""
+import numpy as np
+import pytest
+import torch
+
+from garbage_classification_rca_amd import lib as L
+from garbage_classification_rca_amd import q_former as QF
+from garbage_classification_rca_amd.procedural import proc_tensor, proc_input, counter_uniform
+from oracle import qformer as OQ
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+
+
+def _attn_ref(q, k, v, H, mask=None):
+    B, Sq, D = q.shape
+    return OQ.attention(q.float().cpu(), k.float().cpu(), v.float().cpu(), H, mask)
+
+
+def _run_cross(q, k, v, B, H, Sq, Skv, dh, dtype, impl, drop_p=0.0, seed=0):
+    out = torch.zeros(B * Sq, H * dh, dtype=dtype, device=DEV)
+    L.mha_cross_fwd(q, q.stride(0), k, k.stride(0), v, v.stride(0), out, H * dh, B, H, Sq, Skv, dh, dh ** -0.5, L.dtype_code(dtype), impl,
+                    drop_p=drop_p, drop_seed=seed)
+    torch.cuda.synchronize()
+    return out.float().cpu().view(B, Sq, H * dh)
+
+
+@pytest.mark.parametrize("B,H,S,dh", [(2, 16, 257, 88), (1, 4, 17, 24), (3, 2, 32, 64), (2, 3, 100, 96), (1, 2, 288, 128)])
+@pytest.mark.parametrize("dtype,impl", [(torch.bfloat16, L.IMPL_MFMA), (torch.bfloat16, L.IMPL_REF), (torch.float32, L.IMPL_AUTO)])
+def test_cross_attention_self_fused_qkv(B, H, S, dh, dtype, impl):
+    """the vision tower's use: q / k / v are the three column blocks of one fused [rows, 3*H*dh] buffer (head dim 88 at S=257)"""
+    g = torch.Generator().manual_seed(S * 7 + dh)
+    D = H * dh
+    qkv = (torch.randn(B * S, 3 * D, generator=g) * 0.8).to(dtype).to(DEV)
+    got = _run_cross(qkv, qkv[:, D:], qkv[:, 2 * D:], B, H, S, S, dh, dtype, impl)
+    x = qkv.float().cpu().view(B, S, 3 * D)
+    exp = _attn_ref(x[..., :D], x[..., D:2 * D], x[..., 2 * D:], H)
+    tol = 2e-5 if dtype == torch.float32 else 1.2e-2
+    assert (got - exp).abs().max().item() < tol * max(1.0, exp.abs().max().item())
+
+
+@pytest.mark.parametrize("B,H,Sq,Skv,dh", [(3, 12, 32, 257, 64), (2, 2, 8, 17, 32), (1, 3, 33, 50, 40), (2, 4, 70, 224, 64)])
+@pytest.mark.parametrize("dtype,impl", [(torch.bfloat16, L.IMPL_MFMA), (torch.float32, L.IMPL_AUTO)])
+def test_cross_attention_separate_operands_and_dropout(B, H, Sq, Skv, dh, dtype, impl):
+    """the Q-Former's use: 32 queries over 257 image tokens, K | V fused in one buffer; the dropout mask is the documented
+    counter hash over ((b*H+h)*Sq + i)*Skv + j"""
+    g = torch.Generator().manual_seed(Sq * 13 + Skv)
+    D = H * dh
+    q = (torch.randn(B * Sq, D, generator=g) * 0.7).to(dtype).to(DEV)
+    kv = (torch.randn(B * Skv, 2 * D, generator=g) * 0.7).to(dtype).to(DEV)
+    qf, kvf = q.float().cpu().view(B, Sq, D), kv.float().cpu().view(B, Skv, 2 * D)
+    tol = 2e-5 if dtype == torch.float32 else 1.2e-2
+    for p, seed in ((0.0, 0), (0.1, 12345), (0.5, 7)):
+        got = _run_cross(q, kv, kv[:, D:], B, H, Sq, Skv, dh, dtype, impl, drop_p=p, seed=seed)
+        mask = OQ.keep_mask(seed, (B * H, Sq, Skv), p) if p > 0 else None
+        exp = _attn_ref(qf, kvf[..., :D], kvf[..., D:], H, mask)
+        assert (got - exp).abs().max().item() < tol * max(1.0, exp.abs().max().item()), (p, seed)
+
+
+def test_cross_attention_rejects_bad_arguments():
+    q = torch.zeros(64, 64, dtype=torch.float32, device=DEV)
+    with pytest.raises(L.MmrcaError):       # fp32 cannot be forced onto the bf16 MFMA kernel
+        L.mha_cross_fwd(q, 64, q, 64, q, 64, q, 64, 2, 1, 32, 32, 64, 0.125, L.F32, L.IMPL_MFMA)
+    with pytest.raises(L.MmrcaError):       # row stride smaller than H*dh
+        L.mha_cross_fwd(q, 32, q, 64, q, 64, q, 64, 2, 1, 32, 32, 64, 0.125, L.F32, L.IMPL_AUTO)
+    with pytest.raises(L.MmrcaError):
+        L.mha_cross_fwd(q, 64, q, 64, q, 64, q, 64, 2, 1, 32, 32, 64, 0.125, L.F32, L.IMPL_AUTO, drop_p=1.0)
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# engine vs oracle
+# ------------------------------------------------------------------------------------------------------------------
+TINY = QF.Blip2Spec(v_dim=96, v_layers=2, v_heads=4, v_mlp=192, image_size=56, patch=14, q_dim=64, q_layers=3, q_heads=2,
+                    q_mlp=128, cross_freq=2, n_query=8, n_classes=4)
+# real widths (K = 1408, head dim 88, 257 tokens, 32 queries x 257 keys) at two layers each: the shapes the full model runs
+WIDE = QF.Blip2Spec(v_layers=2, q_layers=2)
+
+
+def _state(spec):
+    sd = {k: proc_tensor(k, shp) for k, shp in QF.blip2_params(spec)}
+    sd["query_tokens"] = sd["query_tokens"] * np.float32(20.0)
+    cls = {"classifier.weight": proc_tensor("classifier.weight", (spec.n_classes, spec.q_dim)) * np.float32(4.0),
+           "classifier.bias": proc_tensor("classifier.bias", (spec.n_classes,))}
+    return sd, cls
+
+
+def _cfg(spec):
+    return dict(v_layers=spec.v_layers, v_heads=spec.v_heads, patch=spec.patch, q_layers=spec.q_layers, q_heads=spec.q_heads,
+                cross_freq=spec.cross_freq, hidden_drop=spec.hidden_drop, attn_drop=spec.attn_drop)
+
+
+def _engine(spec, dtype, sd, cls):
+    eng = QF.Blip2QFormerEngine(spec, dtype=dtype, device=DEV)
+    eng.load_state_dict(sd, cls)
+    return eng
+
+
+@pytest.mark.parametrize("spec,B", [(TINY, 3), (WIDE, 2)], ids=["tiny", "wide"])
+def test_engine_eval_logits_match_oracle(spec, B):
+    sd, cls = _state(spec)
+    px = proc_input("qf_px_%d" % spec.v_dim, (B, 3, spec.image_size, spec.image_size))
+    exp, hs = OQ.forward_logits(sd, cls, torch.from_numpy(px), _cfg(spec), train=False)
+    scale = exp.abs().max().item()
+    eng = _engine(spec, torch.float32, sd, cls).eval()
+    got = eng.forward(torch.from_numpy(px).to(DEV)).cpu()
+    rel = (got - exp).abs().max().item() / scale
+    assert rel < 1e-3, rel                      # north_star: logits within 1e-3 relative of the reference
+    eng16 = _engine(spec, torch.bfloat16, sd, cls).eval()
+    got16 = eng16.forward(torch.from_numpy(px).to(DEV)).cpu()
+    rel16 = (got16 - exp).abs().max().item() / scale
+    assert rel16 < 5e-2, rel16                  # bf16 storage of 1408-wide activations through 2 + 2 layers
+    assert (got16.argmax(1) == exp.argmax(1)).all() or rel16 < 1e-2
+
+
+def test_engine_train_mode_dropout_matches_oracle_masks():
+    """train mode (q_former_training.py:276): the Q-Former's five dropout sites per layer + the embedding dropout, with the
+    masks rebuilt on the host from the counter hash"""
+    spec = TINY
+    sd, cls = _state(spec)
+    px = proc_input("qf_px_train", (4, 3, spec.image_size, spec.image_size))
+    eng = _engine(spec, torch.float32, sd, cls).train()
+    got = eng.forward(torch.from_numpy(px).to(DEV), drop_seed=77).cpu()
+    exp, _ = OQ.forward_logits(sd, cls, torch.from_numpy(px), _cfg(spec), train=True, drop_seed=77)
+    assert (got - exp).abs().max().item() < 1e-3 * exp.abs().max().item()
+    ev, _ = OQ.forward_logits(sd, cls, torch.from_numpy(px), _cfg(spec), train=False)
+    assert (exp - ev).abs().max().item() > 1e-2 * ev.abs().max().item()          # the masks do act
+    # a new forward pass draws new masks
+    a = eng.forward(torch.from_numpy(px).to(DEV)).cpu()
+    b = eng.forward(torch.from_numpy(px).to(DEV)).cpu()
+    assert not torch.equal(a, b)
+
+
+def test_training_loop_matches_reference_loop():
+    """nine iterations of q_former_training.py:279-309 (accumulation 8: one step at iteration 8, one for the remainder):
+    classifier weights, per-iteration losses and the epoch's avg_loss against torch.optim.AdamW / CrossEntropyLoss"""
+    spec = TINY
+    sd, cls = _state(spec)
+    n_it, B = 9, 5
+    rng = np.random.default_rng(3)
+    batches = [{"pixel_values": torch.from_numpy(proc_input("qf_loop_%d" % i, (B, 3, spec.image_size, spec.image_size))),
+                "labels": torch.from_numpy(rng.integers(0, 4, size=(B, 1)).astype(np.int64))} for i in range(n_it)]
+    eng = _engine(spec, torch.float32, sd, cls)
+    opt = QF.ClassifierAdamW(eng)
+    avg = QF.run_one_epoch(eng, opt, batches, DEV)
+    lin = torch.nn.Linear(spec.q_dim, spec.n_classes)
+    with torch.no_grad():
+        lin.weight.copy_(torch.from_numpy(cls["classifier.weight"])); lin.bias.copy_(torch.from_numpy(cls["classifier.bias"]))
+    count = [0]
+
+    def feats(px):        # the product numbers its forward passes 1, 2, ... and seeds the dropout sites with that count
+        count[0] += 1
+        _, hs = OQ.forward_logits(sd, cls, px, _cfg(spec), train=True, drop_seed=count[0])
+        return hs[:, 0, :]
+
+    exp_avg, exp_losses = OQ.reference_loop(feats, lin, [(b["pixel_values"], b["labels"]) for b in batches])
+    got = eng.classifier_state_dict()
+    assert (got["classifier.weight"] - lin.weight.detach()).abs().max().item() < 2e-5
+    assert (got["classifier.bias"] - lin.bias.detach()).abs().max().item() < 2e-5
+    assert (got["classifier.weight"] - torch.from_numpy(cls["classifier.weight"])).abs().max().item() > 5e-4     # two steps were taken
+    assert abs(avg - exp_avg) < 1e-4 * max(1.0, abs(exp_avg))
+    acc = QF.calculate_acc(eng, batches, DEV)
+    assert 0.0 <= acc <= 1.0 and not eng.training
+
+
+def test_load_state_dict_accepts_peft_prefix_and_split_qkv_bias():
+    spec = TINY
+    sd, cls = _state(spec)
+    old = {}
+    for k, v in sd.items():
+        if k.endswith("self_attn.qkv.bias"):
+            D = spec.v_dim
+            v = v.copy(); v[D:2 * D] = 0
+            sd[k] = v
+            old["base_model.model." + k[:-len("qkv.bias")] + "q_bias"] = v[:D]
+            old["base_model.model." + k[:-len("qkv.bias")] + "v_bias"] = v[2 * D:]
+        else:
+            old["base_model.model." + k] = v
+    old["base_model.model.language_model.model.decoder.layers.0.self_attn.q_proj.lora_A.default.weight"] = np.zeros((32, 8), np.float32)
+    a, b = _engine(spec, torch.float32, sd, cls), _engine(spec, torch.float32, old, cls)
+    assert torch.equal(a.store.w, b.store.w)
+    with pytest.raises(KeyError):
+        QF.Blip2QFormerEngine(spec, dtype=torch.float32, device=DEV).load_state_dict({"query_tokens": sd["query_tokens"]})
