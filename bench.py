@@ -123,6 +123,128 @@ def parity_check(model, ids, mask, images, n=8):
     return out
 
 
+def bench_qformer(args):
+    """BASELINE.json configs[4]: one iteration of q_former_training.py:279-302 per step -- frozen ViT-g/14 + Q-Former forward
+    (train mode: Q-Former dropouts active), Linear(768,4) classifier, CE / 8, classifier backward, AdamW every 8th step.
+    The OPT-2.7B forward the reference also runs feeds neither the loss nor the metrics and is not computed (q_former.py)."""
+    from garbage_classification_rca_amd import lib as L
+    from garbage_classification_rca_amd import distributed as D
+    from garbage_classification_rca_amd import q_former as QF
+    import torch.distributed as dist
+    rank, local, world = D.init_from_env("nccl")
+    assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
+    assert torch.cuda.is_available(), "bench.py needs a GPU: the product path has no CPU fallback"
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    L.load()
+    B = args.batch
+    dtype = torch.bfloat16 if args.dtype == "bf16" else torch.float32
+    spec = QF.BLIP2_OPT_2_7B
+    eng = QF.Blip2QFormerEngine(spec, dtype=dtype, device=dev)
+    eng.init_parameters(seed=0)
+    opt = QF.ClassifierAdamW(eng)
+    nb = 2
+    gen = torch.Generator(device=dev).manual_seed(1234 + rank)
+    images = torch.randn(B * nb, 3, spec.image_size, spec.image_size, device=dev, generator=gen)
+    labels = (torch.arange(B * nb, device=dev) % 4).view(-1, 1)
+
+    def step(i):
+        j = (i % nb) * B
+        return QF.train_step(eng, opt, images[j:j + B], labels[j:j + B], i, world=world)
+
+    for i in range(args.warmup):
+        step(i)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        loss = step(i)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    # roofline of the dominant kernel family (the bf16 MFMA GEMMs): HIP events around every GEMM launch of a replay
+    replay = max(1, min(2, args.steps))
+    L.GEMM_PROFILE = []
+    for i in range(replay):
+        step(i)
+    torch.cuda.synchronize()
+    prof, L.GEMM_PROFILE = L.GEMM_PROFILE, None
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    if rank != 0:
+        return
+    flops = sum(p[0] for p in prof)
+    ms = sum(p[2].elapsed_time(p[3]) for p in prof)
+    achieved = flops / (ms * 1e-3) / 1e12 if ms > 0 else 0.0
+    alg = [(2.0 if args.dtype == "bf16" else 4.0) * (Mg * Kg + Ng * Kg + Mg * Ng) for _f, _k, _e0, _e1, (Mg, Ng, Kg, _a) in prof]
+    peak = PEAK_BF16_TFLOPS if args.dtype == "bf16" else PEAK_F32_TFLOPS
+    T, D_, NQ = spec.v_tokens, spec.v_dim, spec.n_query
+    attn_flop = B * (spec.v_layers * 4.0 * T * T * D_ + spec.q_layers * 4.0 * NQ * NQ * spec.q_dim
+                     + (spec.q_layers // spec.cross_freq) * 4.0 * NQ * T * spec.q_dim)
+    out = {"metric": "train samples/sec (images), BLIP-2 Q-Former classifier (q_former_training.py)", "value": round(B * world * args.steps / elapsed, 2),
+           "unit": "samples/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 3),
+           "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16" if args.dtype == "bf16" else "f32",
+           "data": "synthetic",
+           "config": {"workload": "BASELINE configs[4]: q_former_training.py iteration -- frozen BLIP-2 ViT-g/14 (39 layers, 257x1408) + Q-Former "
+                                  "(12 layers, 32 queries, cross-attention to the image tokens) forward in train mode, Linear(768,4) classifier fwd/bwd, "
+                                  "CE/8, AdamW(5e-4, eps 1e-5) every 8th iteration; 224x224 images",
+                      "per_gpu_batch": B, "global_batch": B * world, "parallelism": f"dp{world}", "random_init": True,
+                      "not_computed": "OPT-2.7B language-model forward (feeds neither the loss nor the metrics; its LoRA factors never get a gradient)",
+                      "fwd_gemm_gflop_per_sample": round(flops / replay / B / 1e9, 1), "attention_gflop_per_sample": round(attn_flop / B / 1e9, 1),
+                      "final_loss_over_8": round(float(loss.item()), 5)},
+           "roofline": {"bound": "mfma", "achieved": round(achieved, 2), "peak": peak, "unit": "TFLOP/s", "frac": round(achieved / peak, 4),
+                        "traffic": None, "algorithmic_bytes_per_launch": round(sum(alg) / max(len(alg), 1)),
+                        "kernel": "bf16 16x16x32 MFMA GEMMs (every nn.Linear of the vision tower and the Q-Former, forward only)",
+                        "launches_per_step": len(prof) // replay, "gemm_ms_per_step": round(ms / replay, 3),
+                        "measured_in": f"replay of {replay} steps after the timed region, HIP events around each GEMM launch"}}
+    if not args.no_cpu_baseline:
+        out["cpu_baseline"] = cpu_baseline_qformer(spec)
+    print(json.dumps(out), flush=True)
+
+
+def cpu_baseline_qformer(spec, batch=2, steps=2):
+    """oracle/qformer.py (CPU fp32 restatement pinned to transformers' Blip2 classes) at the full blip2-opt-2.7b widths on this
+    box's host cores: forward in train mode + classifier step, `steps` iterations of `batch` images."""
+    from oracle import qformer as OQ
+    from garbage_classification_rca_amd import q_former as QF
+    n = effective_cores()
+    torch.set_num_threads(n)
+    print(f"[bench] cpu_baseline: Q-Former oracle on {n} host threads, batch {batch} ...", file=sys.stderr, flush=True)
+    g = torch.Generator().manual_seed(0)
+    sd = {}
+    for k, shp in QF.blip2_params(spec):
+        if "LayerNorm" in k or "layer_norm" in k or "layernorm" in k:
+            sd[k] = torch.ones(shp) if k.endswith("weight") else torch.zeros(shp)
+        elif k.endswith("bias"):
+            sd[k] = torch.zeros(shp)
+        else:
+            sd[k] = torch.randn(shp, generator=g) * 0.02
+    lin = torch.nn.Linear(spec.q_dim, spec.n_classes)
+    cfg = dict(v_layers=spec.v_layers, v_heads=spec.v_heads, patch=spec.patch, q_layers=spec.q_layers, q_heads=spec.q_heads,
+               cross_freq=spec.cross_freq, hidden_drop=spec.hidden_drop, attn_drop=spec.attn_drop)
+    cls = {"classifier.weight": lin.weight.detach(), "classifier.bias": lin.bias.detach()}
+    batches = [(torch.randn(batch, 3, spec.image_size, spec.image_size, generator=g), torch.arange(batch).view(-1, 1) % 4) for _ in range(steps + 1)]
+    count = [0]
+
+    def feats(px):
+        count[0] += 1
+        return OQ.forward_logits(sd, cls, px, cfg, train=True, drop_seed=count[0])[1][:, 0, :]
+    OQ.reference_loop(feats, lin, batches[:1])
+    print("[bench] cpu_baseline: warm-up iteration done", file=sys.stderr, flush=True)
+    t0 = time.time()
+    OQ.reference_loop(feats, lin, batches[1:])
+    dt = time.time() - t0
+    return {"value": round(batch * steps / dt, 3), "unit": "samples/s", "cores": n, "kind": "port",
+            "sample": f"oracle/qformer.py (PyTorch CPU fp32 restatement of the Blip2 vision tower + Q-Former + the q_former_training.py loop), "
+                      f"full widths, batch {batch}, {steps} timed iterations after 1 warm-up, {n} threads"}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -138,7 +260,11 @@ def main():
     ap.add_argument("--image_model", default="transformer_B16", help="transformer_B16 (configs[1]) | transformer_L16 | eff_v2_medium | eff_v2_large (configs[2]) | shuffle_net")
     ap.add_argument("--image_size", type=int, default=224)
     ap.add_argument("--cross_attention_only", action="store_true", help="configs[3]: ViT-L/16 + BERT-base, --seq_len 128")
+    ap.add_argument("--workload", default="mmrca", choices=("mmrca", "qformer"),
+                    help="mmrca: the headline MM-RCA train step | qformer: BASELINE configs[4], the BLIP-2 Q-Former classifier iteration")
     args = ap.parse_args()
+    if args.workload == "qformer":
+        return bench_qformer(args)
 
     from garbage_classification_rca_amd import lib as L
     from garbage_classification_rca_amd import distributed as D

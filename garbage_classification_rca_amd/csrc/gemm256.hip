@@ -276,7 +276,7 @@ gemm_mfma256_k(const bf16_t* __restrict__ A, const bf16_t* __restrict__ B, bf16_
 #define DS_WRITE_B128(addr, val, off) asm volatile("ds_write_b128 %0, %1 offset:%2" :: "v"(addr), "v"(val), "i"(off) : "memory")
 
 // Epilogue variants are compile-time (run-time flags cost ~20 branches and twice the code per pass): ACT is
-// MMRCA_ACT_NONE (with or without a residual addend, ADD), MMRCA_ACT_GELU_SAVE_GRAD (stores gelu' to `preact`) or
+// MMRCA_ACT_NONE (with or without a residual addend, ADD), MMRCA_ACT_GELU, MMRCA_ACT_GELU_SAVE_GRAD (stores gelu' to `preact`) or
 // MMRCA_ACT_MUL (multiplies by `preact`; column sums of the stored result to `colsum` when given).
 template <bool A_KROW, bool B_KROW, int ACT, bool ADD>
 __global__ void __launch_bounds__(512, 2)
@@ -501,6 +501,9 @@ gemm_p256_k(const bf16_t* __restrict__ A, const bf16_t* __restrict__ B, bf16_t* 
                 v[r] = gelu_and_grad_fast_f(v[r], &gr);
                 po[r] = (bf16_t)gr;
               }
+            } else if constexpr (act == MMRCA_ACT_GELU) {      // forward-only callers (the frozen BLIP-2 towers)
+  #pragma unroll
+              for (int r = 0; r < 4; ++r) v[r] = gelu_fast_f(v[r]);
             }
             if constexpr (ADD) {
   #pragma unroll
@@ -571,6 +574,7 @@ bool mmrca_gemm256_ok(int64_t M, int64_t N, int64_t K, int a_layout, int act, bo
   if (!(N % 256 == 0 && K % 64 == 0 && K >= 128 && a_layout == MMRCA_ROWK)) return false;
   if (act == MMRCA_ACT_NONE) return !has_preact && !has_colsum;
   if (act == MMRCA_ACT_GELU_SAVE_GRAD) return has_preact && !has_addend && !has_colsum;
+  if (act == MMRCA_ACT_GELU) return !has_preact && !has_addend && !has_colsum;
   if (act == MMRCA_ACT_MUL) return has_preact && !has_addend && !has_bias;
   return false;
 }
@@ -586,6 +590,8 @@ int mmrca_gemm256(const void* A, const void* B, void* C, const void* bias, const
 #define L256(BK_, MODE_, ADD_) launch_p256<false, BK_, MODE_, ADD_>(A, B, C, bias, addend, preact, M, N, K, lda, ldb, ldc, colsum, st)
   if (act == MMRCA_ACT_GELU_SAVE_GRAD) {
     if (bk) L256(true, MMRCA_ACT_GELU_SAVE_GRAD, false); else L256(false, MMRCA_ACT_GELU_SAVE_GRAD, false);
+  } else if (act == MMRCA_ACT_GELU) {
+    if (bk) L256(true, MMRCA_ACT_GELU, false); else L256(false, MMRCA_ACT_GELU, false);
   } else if (act == MMRCA_ACT_MUL) {
     if (bk) L256(true, MMRCA_ACT_MUL, false); else L256(false, MMRCA_ACT_MUL, false);
   } else if (addend) {

@@ -123,7 +123,7 @@ def blip2_params(s: Blip2Spec) -> List[Tuple[str, Tuple[int, ...]]]:
 
 class _FrozenStore:
     """The frozen weights as ONE flat tensor in the compute dtype (no master copy, no gradient, no optimizer state:
-    2.2 GB in bf16 for blip2-opt-2.7b's vision tower + Q-Former).  Entries start on 128-element boundaries and the
+    2.2 GB in bf16 for blip2-opt-2.7b's vision tower + Q-Former).  Entries start on 8-element (16-byte) boundaries and the
     store is padded by one 256 x 6144 tile so that whole-tile operand reads stay inside it."""
 
     def __init__(self, entries, dtype, device):
@@ -259,9 +259,9 @@ class Blip2QFormerEngine:
         L.gemm(x, w, out, bias=b, addend=addend, M=M, N=N, K=K, lda=K, ldb=K, ldc=N, a_layout=L.ROWK, b_layout=L.ROWK, act=act,
                dtype=self.dt, impl=self.gemm_impl)
 
-    def _ln(self, x, res, pfx, y, rows, D, eps, in_drop=(0.0, 0), out_drop=(0.0, 0)):
+    def _ln(self, x, res, pfx, y, rows, D, eps, in_drop=(0.0, 0), out_drop=(0.0, 0), sum_out=None):
         mean, rstd = self.buf("ln_mean", rows, 1, torch.float32), self.buf("ln_rstd", rows, 1, torch.float32)
-        L.add_layernorm_fwd(x, res, self.store.view(pfx + ".weight"), self.store.view(pfx + ".bias"), None, y, mean, rstd, rows, D,
+        L.add_layernorm_fwd(x, res, self.store.view(pfx + ".weight"), self.store.view(pfx + ".bias"), sum_out, y, mean, rstd, rows, D,
                             D, D, eps, self.dt, in_drop=in_drop, out_drop=out_drop)
 
     @staticmethod
@@ -290,18 +290,26 @@ class Blip2QFormerEngine:
         y, qkv, ao, x1 = self.buf("vy", M, D), self.buf("vqkv", M, 3 * D), self.buf("vao", M, D), self.buf("vx1", M, D)
         h = self.buf("vh", M, s.v_mlp)
         dh = D // s.v_heads
+        # GEMMs run over whole 256-row tiles of the (zero-padded) buffers: that is what lets the dispatcher give the
+        # persistent 256x256 kernel the shapes it takes (N % 256 == 0: FFN1 and the Q-Former's K|V projection); rows >= M
+        # are never read by the attention or the LayerNorms.  The residual adds ride on the GEMM epilogues (addend): moving
+        # them onto the next LayerNorm, as engine.LN_RESIDUAL does for ViT-B, measured slower here (N = 1408 cannot use the
+        # 256-wide kernel that move pays for; the LayerNorm got 20 us slower per call, the GEMMs 3 us faster).
+        Mg = _round_up(M, ROWPAD) if self.dtype == torch.bfloat16 else M
+        if Mg > M:
+            x[M:Mg].zero_()          # the padding rows of the residual stream would otherwise carry over from the last pass
         for i in range(s.v_layers):
             p = f"vision_model.encoder.layers.{i}."
             self._ln(x, None, p + "layer_norm1", y, M, D, s.v_eps)
-            self._lin(y, p + "self_attn.qkv.weight", p + "self_attn.qkv.bias", qkv, M, 3 * D, D)
+            self._lin(y, p + "self_attn.qkv.weight", p + "self_attn.qkv.bias", qkv, Mg, 3 * D, D)
             L.mha_cross_fwd(qkv, 3 * D, qkv[:, D:], 3 * D, qkv[:, 2 * D:], 3 * D, ao, D, B, s.v_heads, T, T, dh, dh ** -0.5,
                             self.dt, self.attn_impl)
-            self._lin(ao, p + "self_attn.projection.weight", p + "self_attn.projection.bias", x1, M, D, D, addend=x)
+            self._lin(ao, p + "self_attn.projection.weight", p + "self_attn.projection.bias", x1, Mg, D, D, addend=x)      # :395
             self._ln(x1, None, p + "layer_norm2", y, M, D, s.v_eps)
-            self._lin(y, p + "mlp.fc1.weight", p + "mlp.fc1.bias", h, M, s.v_mlp, D, act=L.ACT_GELU)
-            self._lin(h, p + "mlp.fc2.weight", p + "mlp.fc2.bias", x, M, D, s.v_mlp, addend=x1)
+            self._lin(y, p + "mlp.fc1.weight", p + "mlp.fc1.bias", h, Mg, s.v_mlp, D, act=L.ACT_GELU)
+            self._lin(h, p + "mlp.fc2.weight", p + "mlp.fc2.bias", x, Mg, D, s.v_mlp, addend=x1)                           # :401
         emb = self.buf("image_embeds", M, D)
-        self._ln(x, None, "vision_model.post_layernorm", emb, M, D, s.v_eps)
+        self._ln(x, None, "vision_model.post_layernorm", emb, M, D, s.v_eps)                                               # :521
         return emb
 
     def qformer_forward(self, image_embeds: torch.Tensor, B: int, drop_seed: int = 0) -> torch.Tensor:
@@ -333,8 +341,8 @@ class Blip2QFormerEngine:
             if i % s.cross_freq == 0:
                 # cross-attention of the queries to the image tokens (:717-727)
                 self._lin(hcur, p + "crossattention.attention.query.weight", p + "crossattention.attention.query.bias", cq, M, Q, Q)
-                self._lin(image_embeds, p + "crossattention.attention.key.weight", p + "crossattention.attention.key.bias", ckv, Mi,
-                          2 * Q, D, wnumel=2 * Q * D)
+                self._lin(image_embeds, p + "crossattention.attention.key.weight", p + "crossattention.attention.key.bias", ckv,
+                          _round_up(Mi, ROWPAD) if self.dtype == torch.bfloat16 else Mi, 2 * Q, D, wnumel=2 * Q * D)
                 L.mha_cross_fwd(cq, Q, ckv, 2 * Q, ckv[:, Q:], 2 * Q, ao, Q, B, H, NQ, T, dh, dh ** -0.5, self.dt, self.attn_impl,
                                 drop_p=ap, drop_seed=self._site_seed(drop_seed, i + 1, 3))
                 self._lin(ao, p + "crossattention.output.dense.weight", p + "crossattention.output.dense.bias", o, M, Q, Q)
@@ -410,10 +418,12 @@ ACCUMULATION_STEPS = 8       # q_former_training.py:241
 
 
 def train_step(engine: Blip2QFormerEngine, optimizer: ClassifierAdamW, pixel_values, labels, step: int,
-               accumulation_steps: int = ACCUMULATION_STEPS):
+               accumulation_steps: int = ACCUMULATION_STEPS, world: int = 1):
     """One iteration of the reference loop (:279-302): zero_grad, forward, CE / accumulation_steps, backward, and an
     optimizer step on every ``accumulation_steps``-th iteration.  Returns the device scalar ``loss / accumulation_steps``
-    (what the reference adds to ``total_loss``, :296)."""
+    (what the reference adds to ``total_loss``, :296).
+    world > 1 (one process per GPU, torch.distributed initialised): every rank runs its shard of the batch through the
+    frozen encoders; the only exchange is the all-reduce (RCCL) of the classifier's 3,076 gradient values before a step."""
     optimizer.zero_grad()                                                        # :283
     logits = engine.forward(pixel_values)                                        # :289-291
     B, C = logits.shape
@@ -422,6 +432,10 @@ def train_step(engine: Blip2QFormerEngine, optimizer: ClassifierAdamW, pixel_val
     L.xent_fwd_bwd(logits, labels.view(-1).to(torch.int32), None, 0.0, loss, dlogits, B, C, 1.0 / accumulation_steps)   # :293-294
     engine.backward(dlogits)                                                     # :295
     if (step + 1) % accumulation_steps == 0:                                     # :299-300
+        if world > 1:
+            import torch.distributed as dist
+            dist.all_reduce(engine.cls_g)
+            engine.cls_g.mul_(1.0 / world)
         optimizer.step()
     return loss / accumulation_steps
 

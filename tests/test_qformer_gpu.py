@@ -69,6 +69,25 @@ def test_cross_attention_rejects_bad_arguments():
         L.mha_cross_fwd(q, 64, q, 64, q, 64, q, 64, 2, 1, 32, 32, 64, 0.125, L.F32, L.IMPL_AUTO, drop_p=1.0)
 
 
+def test_persistent_gemm_plain_gelu_epilogue():
+    """FFN1 of the frozen towers: bias + GELU without the saved derivative, on the persistent 256x256 kernel (AUTO picks it
+    at this shape) against the fp32 reference kernel"""
+    M, N, K = 3072, 6144, 1408
+    g = torch.Generator().manual_seed(11)
+    a = (torch.randn(M, K, generator=g) * 0.5).to(torch.bfloat16).to(DEV)
+    w = (torch.randn(N, K, generator=g) * 0.05).to(torch.bfloat16).to(DEV)
+    b = (torch.randn(N, generator=g) * 0.1).to(torch.bfloat16).to(DEV)
+    outs = []
+    for impl in (L.IMPL_AUTO, L.IMPL_MFMA256, L.IMPL_REF):
+        c = torch.zeros(M, N, dtype=torch.bfloat16, device=DEV)
+        L.gemm(a, w, c, bias=b, M=M, N=N, K=K, lda=K, ldb=K, ldc=N, act=L.ACT_GELU, dtype=L.BF16, impl=impl)
+        outs.append(c.float())
+    exp = torch.nn.functional.gelu(a.float() @ w.float().t() + b.float())
+    for c in outs:
+        assert (c - exp).abs().max().item() < 2e-2 * exp.abs().max().item()
+    assert torch.equal(outs[0], outs[1])          # AUTO is the 256x256 kernel here
+
+
 # ------------------------------------------------------------------------------------------------------------------
 # engine vs oracle
 # ------------------------------------------------------------------------------------------------------------------
