@@ -115,3 +115,39 @@ def test_engine_needs_the_hip_library_and_a_gpu():
     eng = QF.Blip2QFormerEngine(tiny_spec(), dtype=torch.float32, device="cpu")
     with pytest.raises(L.MmrcaError):
         eng.forward(torch.zeros(1, 3, 56, 56))
+
+
+def _make_folder(root, n_per_class=3, size=(50, 40)):
+    from PIL import Image
+    rng = np.random.default_rng(0)
+    paths = []
+    for cname in ("Blue", "Green", "Black", "TTR"):
+        os.makedirs(os.path.join(root, cname), exist_ok=True)
+        for i in range(n_per_class):
+            fn = os.path.join(root, cname, f"plastic_bottle_{i}12.png")
+            Image.fromarray(rng.integers(0, 256, size=(size[1], size[0], 3), dtype=np.uint8)).save(fn)
+            paths.append(fn)
+    return paths
+
+
+def test_dataset_labels_collate_and_image_transform(tmp_path):
+    """ImageCaptioningDataset / collate_fn of q_former_training.py:62-122 for the keys on the path, and the image half of the
+    processor against transformers' BlipImageProcessor at blip2-opt-2.7b's settings"""
+    from garbage_classification_rca_amd import q_former_training as QT
+    paths = _make_folder(str(tmp_path))
+    ds = QT.ImageCaptioningDataset(sorted(paths), image_size=56)
+    assert len(ds) == 12 and ds.item_text(0) == "plastic bottle"                    # digits, extension, underscores removed (:72)
+    batch = QT.collate_fn([ds[i] for i in range(len(ds))])
+    assert batch["pixel_values"].shape == (12, 3, 56, 56) and batch["labels"].shape == (12, 1)
+    by_dir = {p.split("/")[-2]: int(batch["labels"][i, 0]) for i, p in enumerate(sorted(paths))}
+    assert by_dir == {"Blue": 0, "Green": 1, "Black": 2, "TTR": 3}                  # TTR -> Yellow -> 3 (:86-89, 259-263)
+    pytest.importorskip("transformers")
+    # (the default BlipImageProcessor backend needs torchvision, absent here; the PIL backend is the same pipeline)
+    from transformers.models.blip.image_processing_pil_blip import BlipImageProcessorPil
+    from PIL import Image
+    proc = BlipImageProcessorPil(size={"height": 224, "width": 224})
+    img = Image.open(sorted(paths)[0])
+    ref = proc(images=img, return_tensors="pt")["pixel_values"][0]
+    got = QT.Blip2ImageTransform(224)(img)
+    assert got.shape == ref.shape and (got - ref).abs().max().item() < 0.05       # same PIL bicubic; 1/255 steps are 0.015 wide
+    assert (got - ref).abs().mean().item() < 2e-3

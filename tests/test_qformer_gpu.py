@@ -201,3 +201,32 @@ def test_load_state_dict_accepts_peft_prefix_and_split_qkv_bias():
     assert torch.equal(a.store.w, b.store.w)
     with pytest.raises(KeyError):
         QF.Blip2QFormerEngine(spec, dtype=torch.float32, device=DEV).load_state_dict({"query_tokens": sd["query_tokens"]})
+
+
+def test_q_former_training_script_end_to_end(tmp_path):
+    """folder -> q_former_training.main (two epochs, tiny widths) -> Classifier_epoch_*.pth -> reload and score"""
+    import glob
+    import os
+    from PIL import Image
+    from garbage_classification_rca_amd import q_former_training as QT
+    rng = np.random.default_rng(1)
+    for split in ("Train", "Val"):
+        for c, cname in enumerate(("Blue", "Green", "Black", "TTR")):
+            os.makedirs(tmp_path / split / cname, exist_ok=True)
+            for i in range(5 if split == "Train" else 2):
+                a = rng.integers(0, 80, size=(44, 60, 3)).astype(np.uint8)
+                a[..., c % 3] += np.uint8(120 + 20 * c)                      # a learnable colour cue per class
+                Image.fromarray(a).save(tmp_path / split / cname / f"item_{i}7.png")
+    hist = QT.main(["--dataset_folder_name", str(tmp_path / "Train"), "--dataset_folder_name_val", str(tmp_path / "Val"),
+                    "--batch_size", "4", "--epochs", "2", "--num_workers", "0", "--dtype", "fp32"], spec=TINY, out_dir=str(tmp_path))
+    assert len(hist) == 2 and all(np.isfinite(h["train_loss_avg"]) for h in hist)
+    files = glob.glob(str(tmp_path / "Classifier_epoch_*_acc_*.pth"))
+    assert files, "the first epoch always beats max_val_accuracy = 0 unless accuracy is exactly 0"
+    sd = torch.load(files[0])
+    assert set(sd) == {"classifier.weight", "classifier.bias"} and sd["classifier.weight"].shape == (4, TINY.q_dim)
+    eng = QF.Blip2QFormerEngine(TINY, dtype=torch.float32, device=DEV)
+    eng.init_parameters(seed=0)
+    eng.load_state_dict({}, sd, strict=False)
+    ds = QT.ImageCaptioningDataset(sorted(glob.glob(str(tmp_path / "Val") + "/*/*")), image_size=TINY.image_size)
+    batches = [QT.collate_fn([ds[i] for i in range(len(ds))])]
+    assert 0.0 <= QF.calculate_acc(eng, batches, DEV) <= 1.0
