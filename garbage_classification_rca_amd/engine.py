@@ -143,6 +143,11 @@ class MMRCAEngine:
                  dtype: torch.dtype = torch.bfloat16, device="cuda", gemm_impl: int = L.IMPL_AUTO,
                  attn_impl: int = L.IMPL_AUTO, image_size: int = 224):
         L.load()
+        if text_model == "bart":
+            # the reference accepts the name (multimodal_model.py:137-144, 182-183) but its head is built for 768-wide text
+            # features (input_size_txt = 768, :257) while facebook/bart-large emits 1024: its forward fails on the first batch
+            raise ValueError("Wrong text model: bart (facebook/bart-large is 1024 wide; the reference's MM_RCA head is hard-wired to "
+                             "768-wide text features, multimodal_model.py:257, and cannot run it either)")
         if text_model not in S.TEXT_SPECS:
             raise ValueError(f"Wrong text model: {text_model}")
         if image_model not in S.VISION_SPECS and image_model not in CONV_MODELS:
