@@ -177,6 +177,14 @@ def bench_qformer(args):
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
+        if os.environ.get("MMRCA_CHECK_REPLICAS") == "1":
+            # data-parallel invariant: every rank applied the same averaged classifier gradient
+            chk = eng.cls_p.double().sum().view(1)
+            lo, hi = chk.clone(), chk.clone()
+            dist.all_reduce(lo, op=dist.ReduceOp.MIN); dist.all_reduce(hi, op=dist.ReduceOp.MAX)
+            assert float(hi - lo) == 0.0, f"replicas diverged: {float(lo)} vs {float(hi)}"
+            if rank == 0:
+                print(f"[bench] classifier replicas identical after {opt.t} optimizer steps (checksum {float(chk):.8f})", file=sys.stderr, flush=True)
     if rank != 0:
         return
     flops = sum(p[0] for p in prof)

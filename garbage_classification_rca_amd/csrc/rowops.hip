@@ -189,15 +189,15 @@ extern "C" int mmrca_add_layernorm_fwd(const void* x, const void* res, const voi
   MMRCA_REQUIRE(D > 0 && D % 4 == 0 && D <= 256 * LN_MAXV, "add_layernorm_fwd: D=%d unsupported (multiple of 4, <= %d)", D, 256 * LN_MAXV);
   MMRCA_REQUIRE(ld_x >= D && ld_y >= D && ld_x % 4 == 0 && ld_y % 4 == 0, "add_layernorm_fwd: bad leading dims");
   if (rows <= 0) return 0;
-  if (dtype == MMRCA_BF16 && D % 8 == 0 && D <= 1024 && ld_x % 8 == 0 && ld_y % 8 == 0 && aligned16p(x) && aligned16p(y) &&
+  if (dtype == MMRCA_BF16 && D % 8 == 0 && D <= 1536 && ld_x % 8 == 0 && ld_y % 8 == 0 && aligned16p(x) && aligned16p(y) &&
       aligned16p(gamma) && aligned16p(beta) && (!res || aligned16p(res)) && (!sum_out || aligned16p(sum_out))) {
     const int g2 = (int)((rows + 7) / 8 < 1024 ? (rows + 7) / 8 : 1024);
-#define LN_FWD16(NV2_)                                                                                                       \
-    hipLaunchKernelGGL((add_ln_fwd_bf16_k<NV2_, 2>), dim3(g2), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)x,              \
+#define LN_FWD16(NV2_, RP_)                                                                                                  \
+    hipLaunchKernelGGL((add_ln_fwd_bf16_k<NV2_, RP_>), dim3(g2), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)x,              \
                        (const bf16_t*)res, (const bf16_t*)gamma, (const bf16_t*)beta, (bf16_t*)sum_out, (bf16_t*)y, mean, rstd, \
                        rows, D, ld_x, ld_y, eps, in_drop_p, in_drop_seed, out_drop_p, out_drop_seed)
     const int nv2 = (D + 511) / 512;
-    if (nv2 <= 1) LN_FWD16(1); else LN_FWD16(2);
+    if (nv2 <= 1) LN_FWD16(1, 2); else if (nv2 == 2) LN_FWD16(2, 2); else LN_FWD16(3, 1);      // 3: BLIP-2's ViT-g rows (D = 1408); one row per wave in flight keeps four waves per SIMD
 #undef LN_FWD16
     MMRCA_CHECK_LAUNCH("add_layernorm_fwd(bf16)");
     return 0;

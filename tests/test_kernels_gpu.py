@@ -411,7 +411,7 @@ def test_gemm_rejects_bad_arguments():
 # LayerNorm, GELU', column sums
 # ------------------------------------------------------------------------------------------------------
 @pytest.mark.parametrize("dt", [torch.float32, torch.bfloat16])
-@pytest.mark.parametrize("D", [768, 1024, 96])
+@pytest.mark.parametrize("D", [768, 1024, 96, 1408])
 def test_layernorm_fwd_bwd(dt, D):
     rows, eps = 37, 1e-6
     x, r = dev(torch.randn(rows, D), dt), dev(torch.randn(rows, D), dt)

@@ -230,3 +230,22 @@ def test_q_former_training_script_end_to_end(tmp_path):
     ds = QT.ImageCaptioningDataset(sorted(glob.glob(str(tmp_path / "Val") + "/*/*")), image_size=TINY.image_size)
     batches = [QT.collate_fn([ds[i] for i in range(len(ds))])]
     assert 0.0 <= QF.calculate_acc(eng, batches, DEV) <= 1.0
+
+
+def test_two_rank_rehearsal_of_the_qformer_bench_keeps_classifiers_identical():
+    """N>1 path of `bench.py --workload qformer`: two ranks share this one GPU (gloo standing in for RCCL), each runs its own
+    images through the frozen towers, the 3,076 classifier gradients are all-reduced before the optimizer step"""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, MMRCA_DIST_BACKEND="gloo", MMRCA_CHECK_REPLICAS="1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", "29541", os.path.join(root, "bench.py"), "--workload", "qformer", "--gpus", "2", "--batch", "4", "--steps", "8",
+           "--warmup", "0", "--no_cpu_baseline"]
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900, cwd=root)
+    assert r.returncode == 0, r.stderr[-2000:]
+    assert "classifier replicas identical after" in r.stderr and " 0 optimizer steps" not in r.stderr
+    d = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+    assert d["n_gpus"] == 2 and d["config"]["global_batch"] == 8 and d["scaling"] == "weak"
