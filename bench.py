@@ -203,6 +203,9 @@ def bench_qformer(args):
                                   "(12 layers, 32 queries, cross-attention to the image tokens) forward in train mode, Linear(768,4) classifier fwd/bwd, "
                                   "CE/8, AdamW(5e-4, eps 1e-5) every 8th iteration; 224x224 images",
                       "per_gpu_batch": B, "global_batch": B * world, "parallelism": f"dp{world}", "random_init": True,
+                      "dtype_note": "BASELINE configs[4] says fp16; the reference script itself runs fp32 (from_pretrained default, no autocast). "
+                                    "This build stores the frozen towers in bf16 with fp32 accumulation -- the same byte width and MFMA rate as fp16 "
+                                    "(the C ABI has no fp16 type) -- and keeps the classifier, loss and AdamW in fp32; --dtype fp32 runs everything in fp32",
                       "not_computed": "OPT-2.7B language-model forward (feeds neither the loss nor the metrics; its LoRA factors never get a gradient)",
                       "fwd_gemm_gflop_per_sample": round(flops / replay / B / 1e9, 1), "attention_gflop_per_sample": round(attn_flop / B / 1e9, 1),
                       "final_loss_over_8": round(float(loss.item()), 5)},
