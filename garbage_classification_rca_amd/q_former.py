@@ -403,12 +403,17 @@ class ClassifierAdamW:
     def __init__(self, engine: Blip2QFormerEngine, lr=5e-4, betas=(0.9, 0.999), eps=1e-5, weight_decay=1e-2):
         self.engine, self.lr, self.betas, self.eps, self.weight_decay = engine, lr, betas, eps, weight_decay
         self.t = 0
+        self.world = 1          # > 1: data parallel, the classifier gradient is averaged over the ranks before every step
 
     def zero_grad(self):
         self.engine.zero_grad()
 
     def step(self):
         e = self.engine
+        if self.world > 1:      # the path's only exchange: 3,076 fp32 values (RCCL through torch.distributed)
+            import torch.distributed as dist
+            dist.all_reduce(e.cls_g)
+            e.cls_g.mul_(1.0 / self.world)
         self.t += 1
         L.adamw_step(e.cls_p, e.cls_g, e.cls_m, e.cls_v, None, e.n_cls, float(self.lr), float(self.betas[0]), float(self.betas[1]),
                      float(self.eps), float(self.weight_decay), self.t, 1.0)
@@ -418,12 +423,13 @@ ACCUMULATION_STEPS = 8       # q_former_training.py:241
 
 
 def train_step(engine: Blip2QFormerEngine, optimizer: ClassifierAdamW, pixel_values, labels, step: int,
-               accumulation_steps: int = ACCUMULATION_STEPS, world: int = 1):
+               accumulation_steps: int = ACCUMULATION_STEPS, world: Optional[int] = None):
     """One iteration of the reference loop (:279-302): zero_grad, forward, CE / accumulation_steps, backward, and an
     optimizer step on every ``accumulation_steps``-th iteration.  Returns the device scalar ``loss / accumulation_steps``
     (what the reference adds to ``total_loss``, :296).
-    world > 1 (one process per GPU, torch.distributed initialised): every rank runs its shard of the batch through the
-    frozen encoders; the only exchange is the all-reduce (RCCL) of the classifier's 3,076 gradient values before a step."""
+    world (None = leave ``optimizer.world`` alone) > 1 (one process per GPU, torch.distributed initialised): every rank runs its shard of the batch through the
+    frozen encoders; the only exchange is the all-reduce (RCCL) of the classifier's 3,076 gradient values inside
+    ``optimizer.step()`` (also the remainder step run_one_epoch takes after the loop)."""
     optimizer.zero_grad()                                                        # :283
     logits = engine.forward(pixel_values)                                        # :289-291
     B, C = logits.shape
@@ -431,11 +437,9 @@ def train_step(engine: Blip2QFormerEngine, optimizer: ClassifierAdamW, pixel_val
     dlogits = torch.empty_like(logits)
     L.xent_fwd_bwd(logits, labels.view(-1).to(torch.int32), None, 0.0, loss, dlogits, B, C, 1.0 / accumulation_steps)   # :293-294
     engine.backward(dlogits)                                                     # :295
+    if world is not None:
+        optimizer.world = world
     if (step + 1) % accumulation_steps == 0:                                     # :299-300
-        if world > 1:
-            import torch.distributed as dist
-            dist.all_reduce(engine.cls_g)
-            engine.cls_g.mul_(1.0 / world)
         optimizer.step()
     return loss / accumulation_steps
 
