@@ -564,8 +564,7 @@ gemm_mfma_k(const bf16_t* __restrict__ A, const bf16_t* __restrict__ B, void* __
           *reinterpret_cast<bf16x4*>(preact + m * ldc + ncol) = o;
         }
         if (act == MMRCA_ACT_GELU) {
-#pragma unroll
-          for (int r = 0; r < 4; ++r) v[r] = gelu_fast_f(v[r]);
+          gelu_fast4(v);
         }
         if (addend) {
           bf16x4 a4 = *reinterpret_cast<const bf16x4*>(addend + m * ldc + ncol);
@@ -785,8 +784,7 @@ gemm_mfma_k32(const bf16_t* __restrict__ A, const bf16_t* __restrict__ B, void* 
             *reinterpret_cast<bf16x4*>(preact + m * ldc + ncol) = o;
           }
           if (act == MMRCA_ACT_GELU) {
-#pragma unroll
-            for (int r = 0; r < 4; ++r) v[r] = gelu_fast_f(v[r]);
+            gelu_fast4(v);
           }
           if (addend) {
             bf16x4 a4 = *reinterpret_cast<const bf16x4*>(addend + m * ldc + ncol);
@@ -927,12 +925,10 @@ gemm_mfma_k1s(const bf16_t* __restrict__ A, const bf16_t* __restrict__ B, void* 
             for (int r = 0; r < 4; ++r) v[r] *= (float)add4[i][rr][r];
           } else if (act == MMRCA_ACT_GELU_SAVE_GRAD) {
             bf16x4 o;
+            float dg[4];
+            gelu_and_grad_fast4(v, dg);
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-              float dg;
-              v[r] = gelu_and_grad_fast_f(v[r], &dg);
-              o[r] = (bf16_t)dg;
-            }
+            for (int r = 0; r < 4; ++r) o[r] = (bf16_t)dg[r];
             *reinterpret_cast<bf16x4*>(preact + m * ldc + ncol) = o;
           } else if (act == MMRCA_ACT_GELU_BWD) {
             bf16x4 h4 = *reinterpret_cast<const bf16x4*>(preact + m * ldc + ncol);
@@ -945,8 +941,7 @@ gemm_mfma_k1s(const bf16_t* __restrict__ A, const bf16_t* __restrict__ B, void* 
             *reinterpret_cast<bf16x4*>(preact + m * ldc + ncol) = o;
           }
           if (act == MMRCA_ACT_GELU) {
-#pragma unroll
-            for (int r = 0; r < 4; ++r) v[r] = gelu_fast_f(v[r]);
+            gelu_fast4(v);
           }
           if (addend) {
             if (act == MMRCA_ACT_MUL) {       // (both side operands at once: the addend is read in place)

@@ -495,15 +495,12 @@ gemm_p256_k(const bf16_t* __restrict__ A, const bf16_t* __restrict__ B, bf16_t* 
   #pragma unroll
               for (int r = 0; r < 4; ++r) v[r] *= (float)side[4 * pass + it][r];
             } else if constexpr (act == MMRCA_ACT_GELU_SAVE_GRAD) {
+              float gr[4];
+              gelu_and_grad_fast4(v, gr);
   #pragma unroll
-              for (int r = 0; r < 4; ++r) {
-                float gr;
-                v[r] = gelu_and_grad_fast_f(v[r], &gr);
-                po[r] = (bf16_t)gr;
-              }
+              for (int r = 0; r < 4; ++r) po[r] = (bf16_t)gr[r];
             } else if constexpr (act == MMRCA_ACT_GELU) {      // forward-only callers (the frozen BLIP-2 towers)
-  #pragma unroll
-              for (int r = 0; r < 4; ++r) v[r] = gelu_fast_f(v[r]);
+              gelu_fast4(v);
             }
             if constexpr (ADD) {
   #pragma unroll
