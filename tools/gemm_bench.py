@@ -51,7 +51,7 @@ for name, m, n, k, al, bl, acc in SHAPES:
     runs = {}
     for iname, impl, dbg in variants:
         if impl == L.IMPL_MFMA256 and (acc or n % 256 or k < 128 or al == 1 or
-                                       (epi["act"] == L.ACT_NONE and epi["preact"] is not None) or epi["act"] == L.ACT_GELU):
+                                       (epi["act"] == L.ACT_NONE and epi["preact"] is not None)):
             continue
         def run(impl=impl, dbg=dbg):
             L.load().mmrca_debug_set(dbg)
