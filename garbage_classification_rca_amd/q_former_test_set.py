@@ -1,0 +1,117 @@
+"""Drop-in for the reference's ``q_former_test_set.py``: the Q-Former classifier on a test folder.
+
+    python -m garbage_classification_rca_amd.q_former_test_set --dataset_folder_name Test \\
+        --blip2_checkpoint blip2-opt-2.7b.safetensors --classifier_weights Classifier_epoch_9_acc_0.8855.pth
+
+Same CLI flags (options.args_parser), folder convention and outputs (``QFORMER_report_test_set_acc_<a>.csv``; the
+confusion-matrix PNG only when matplotlib is installed).  ``--model_path`` (the reference's peft checkpoint, :260-267) is
+accepted as an alternative source of the frozen BLIP-2 weights: no LoRA factor is on the path to the logits (q_former.py).
+The classifier file is ``--classifier_weights`` (the reference hard-codes ``../classifier_epoch_9_acc_0.8855.pth``, :269).
+
+Reporting quirks of the reference kept, because they change the numbers it prints:
+  * the running and final "test accuracy" divide by ``len_test_set = 2000`` whatever the folder holds (:170, 197, 220);
+  * the arrays are named the other way round (:203-204: ``ytrue_`` holds the model's predictions, ``outs_`` the ground
+    truth), so ``classification_report`` gets (y_true = predictions, y_pred = truth) -- precision and recall trade places --
+    while the confusion matrix, swapped twice, comes out with rows = truth;
+  * ``target_names = ["Black", "Blue", "Green", "Yellow"]`` (:36) although the label ids are Blue 0, Green 1, Black 2,
+    Yellow 3 (:29-34).
+The true accuracy (correct / number of samples) is returned next to the reference's figure.
+"""
+from __future__ import annotations
+
+import glob
+import os
+import sys
+
+import numpy as np
+import torch
+from torch.utils.data import DataLoader
+
+from . import q_former as QF
+from .options import args_parser
+from .q_former_training import ImageCaptioningDataset, collate_fn, load_blip2_state
+
+classes = ["Black", "Blue", "Green", "Yellow"]            # q_former_test_set.py:36
+LEN_TEST_SET = 2000                                       # :170
+
+
+def calculate_acc(engine: QF.Blip2QFormerEngine, loader, device, len_test_set: int = LEN_TEST_SET, verbose: bool = True):
+    """:168-235.  Returns (test_acc as the reference computes it, report text, report dict, confusion matrix, true accuracy)."""
+    from sklearn.metrics import classification_report, confusion_matrix
+    engine.eval()
+    model_out, truth, correct = [], [], 0
+    with torch.no_grad():
+        for idx, b in enumerate(loader):
+            px = b["pixel_values"].to(device)
+            y = b["labels"].view(-1)
+            model_out.append(engine.forward(px).argmax(1).cpu())
+            truth.append(y.cpu())
+            correct = int((torch.cat(model_out) == torch.cat(truth)).sum().item())
+            if verbose:
+                print("Running test accuracy: {:.3f} %".format(100 * (correct / len_test_set)))
+    all_labels = torch.cat(model_out).numpy()             # the reference's `ytrue_` / `all_labels`: the model's predictions
+    all_preds = torch.cat(truth).numpy()                  # the reference's `outs_` / `all_preds`: the ground truth
+    test_acc = 100 * (correct / len_test_set)
+    # torchmetrics ConfusionMatrix(preds = all_labels, target = all_preds): rows = target = ground truth
+    conf = confusion_matrix(all_preds, all_labels, labels=[0, 1, 2, 3])
+    kw = dict(labels=[0, 1, 2, 3], target_names=classes, zero_division=0)
+    report = classification_report(all_labels, all_preds, **kw)
+    report_dict = classification_report(all_labels, all_preds, output_dict=True, **kw)
+    true_acc = correct / max(len(all_preds), 1)
+    return test_acc, report, report_dict, conf, true_acc
+
+
+def generate_report_and_image(test_report_dict, test_accuracy, conf_matrix, out_dir: str = "."):
+    """:47-66"""
+    import pandas as pd
+    fn = os.path.join(out_dir, "QFORMER_report_test_set_acc_{:.2f}.csv".format(test_accuracy))
+    pd.DataFrame.from_dict(test_report_dict).to_csv(fn, index=True)
+    try:
+        import matplotlib
+        matplotlib.use("Agg")
+        import matplotlib.pyplot as plt
+        plt.rcParams.update({'font.size': 16})
+        fig, ax = plt.subplots(figsize=(10, 5))
+        ax.imshow(np.asarray(conf_matrix), cmap='viridis')
+        ax.set_xticks(range(4)); ax.set_xticklabels(classes); ax.set_yticks(range(4)); ax.set_yticklabels(classes)
+        for i in range(4):
+            for j in range(4):
+                ax.text(j, i, str(int(conf_matrix[i][j])), ha="center", va="center", color="w")
+        fig.savefig(os.path.join(out_dir, 'conf_matrix_QFORMER_model_test_set_acc_{:.2f}.png'.format(test_accuracy)))
+    except ImportError:
+        print("matplotlib is not installed: confusion-matrix image skipped", file=sys.stderr)
+    print("Test accuracy: {:.2f} %".format(test_accuracy))
+    return fn
+
+
+def main(argv=None, spec: QF.Blip2Spec = QF.BLIP2_OPT_2_7B, out_dir: str = "."):
+    args = args_parser(argv)
+    device = torch.device("cuda:0")
+    engine = QF.Blip2QFormerEngine(spec, dtype=torch.bfloat16 if args.dtype == "bf16" else torch.float32, device=device)
+    engine.init_parameters(seed=0)
+    src = args.blip2_checkpoint or args.model_path
+    if src:
+        sd = load_blip2_state(src)
+        engine.load_state_dict(sd.get("model_state_dict", sd) if isinstance(sd, dict) else sd)       # :262-267
+    else:
+        print("WARNING: neither --blip2_checkpoint nor --model_path given: the frozen BLIP-2 weights are RANDOM", file=sys.stderr)
+    if args.classifier_weights:
+        engine.load_state_dict({}, torch.load(args.classifier_weights, map_location="cpu"), strict=False)
+    else:
+        print("WARNING: no --classifier_weights given: the classifier is at its random initialisation", file=sys.stderr)
+    ims = sorted(glob.glob(args.dataset_folder_name + "/*/*"))
+    if not ims:
+        raise FileNotFoundError(f"no images under {args.dataset_folder_name}/*/*")
+    workers = min(32, args.num_workers)
+    loader = DataLoader(ImageCaptioningDataset(ims, image_size=spec.image_size), batch_size=16, num_workers=workers,      # :244-248
+                        collate_fn=collate_fn, shuffle=True, multiprocessing_context="forkserver" if workers > 0 else None)
+    test_acc, report, report_dict, conf, true_acc = calculate_acc(engine, loader, device)
+    print(conf)
+    print("Test Report:")
+    print(report)
+    fn = generate_report_and_image(report_dict, test_acc, conf, out_dir)
+    return {"test_accuracy_reference_formula": test_acc, "accuracy": true_acc, "report_csv": fn, "confusion_matrix": conf}
+
+
+if __name__ == "__main__":
+    main()

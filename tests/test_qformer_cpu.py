@@ -151,3 +151,26 @@ def test_dataset_labels_collate_and_image_transform(tmp_path):
     got = QT.Blip2ImageTransform(224)(img)
     assert got.shape == ref.shape and (got - ref).abs().max().item() < 0.05       # same PIL bicubic; 1/255 steps are 0.015 wide
     assert (got - ref).abs().mean().item() < 2e-3
+
+
+def test_test_set_report_keeps_the_reference_quirks():
+    """q_former_test_set.py:168-235: accuracy over a hard-coded 2000, classification_report fed (predictions, truth)"""
+    from garbage_classification_rca_amd import q_former_test_set as QS
+
+    class Fake:
+        def eval(self):
+            return self
+
+        def forward(self, px):
+            return torch.nn.functional.one_hot(px.view(-1).long(), 4).float()      # "pixel_values" carry the wanted prediction
+
+    pred = torch.tensor([0, 0, 1, 2, 3, 3, 3, 1])
+    true = torch.tensor([0, 1, 1, 2, 3, 0, 3, 2])
+    loader = [{"pixel_values": pred[:5], "labels": true[:5].view(-1, 1)}, {"pixel_values": pred[5:], "labels": true[5:].view(-1, 1)}]
+    acc2000, report, rd, conf, acc = QS.calculate_acc(Fake(), loader, "cpu", verbose=False)
+    assert acc == 5 / 8 and acc2000 == 100 * 5 / 2000
+    assert conf.sum() == 8 and conf[0, 3] == 1 and conf[1, 0] == 1              # rows = ground truth, columns = prediction
+    # class id 3 (printed under the reference's fourth name, "Yellow"): 3 predicted, 2 true, 2 right.  With the arguments
+    # swapped the report's "precision" is the true recall (2/2) and its "recall" the true precision (2/3)
+    assert abs(rd["Yellow"]["precision"] - 1.0) < 1e-12 and abs(rd["Yellow"]["recall"] - 2 / 3) < 1e-12
+    assert list(rd)[:4] == ["Black", "Blue", "Green", "Yellow"]
