@@ -176,9 +176,11 @@ gemm_gen_k(const T* __restrict__ A, const T* __restrict__ B, void* __restrict__ 
   // one MFMA per 32x32 tile and K step instead of eight fp32 ones at a sixteenth of the cycles -- the products of two bf16
   // values are exact in fp32 either way
   constexpr bool BF = sizeof(T) == 2;
-  constexpr int LD = BF ? 24 : GEN_LD;
-  const int a_lds = a_row0 * LD + a_k0, b_lds = b_row0 * LD + b_k0;
-  constexpr int A_LI = A_DROW * LD + A_DK, B_LI = B_DROW * LD + B_DK;
+  // (a KROW bf16 operand uses pitch 20: its tile is written TRANSPOSED, eight 2-byte stores per 16-byte global load, and with
+  //  40-byte rows the four row groups of a wave land in four different bank quarters; its fragments are read as 2 x 8 bytes)
+  constexpr int LDA = BF ? (AK1 ? 24 : 20) : GEN_LD, LDB = BF ? ((BK1 || AK1) ? 24 : 20) : GEN_LD;     // (B: only beside a KROW A, see vec_b)
+  const int a_lds = a_row0 * LDA + a_k0, b_lds = b_row0 * LDB + b_k0;
+  constexpr int A_LI = A_DROW * LDA + A_DK, B_LI = B_DROW * LDB + B_DK;
   typedef typename std::conditional<BF, T, float>::type S;      // staged element type
   S ra[8], rb[4];
   auto fetch_a = [&](int64_t k0, bool full) {        // full: the whole 16-wide step lies inside [kbeg, Kend)
@@ -202,30 +204,58 @@ gemm_gen_k(const T* __restrict__ A, const T* __restrict__ B, void* __restrict__ 
     for (int i = 0; i < 4; ++i) { if constexpr (BF) reinterpret_cast<T*>(Bs[buf])[b_lds + i * B_LI] = rb[i]; else Bs[buf][b_lds + i * B_LI] = rb[i]; }
   };
   // bf16 ROWK operands, aligned: a thread moves ONE group of 8 contiguous k of a row per step -- a 16-byte load and a 16-byte
-  // LDS store instead of eight two-byte ones.  (The same for KROW operands -- 8 rows of a k, eight 2-byte LDS stores 384 bytes
-  // apart -- was measured slower in situ: 8-way bank conflicts; they keep the element-wise staging.)
+  // LDS store instead of eight two-byte ones.  KROW operands (weight gradients): ONE 16-byte load of 8 rows of a k, written
+  // transposed with eight 2-byte stores into a pitch-20 image (with pitch 24 the stores were 8-way bank conflicted and the
+  // variant lost): conv weight gradients 542 -> 426 us on average (configs[2]).
   typedef __attribute__((ext_vector_type(8))) __bf16 g_b8;
   bool vec_a = false, vec_b = false;
   if constexpr (BF) {
     const bool kok = (Kend - kbeg) % 8 == 0 && kbeg % 8 == 0;
-    vec_a = AK1 && kok && (((uintptr_t)A) & 15) == 0 && sam % 8 == 0;
-    vec_b = BK1 && kok && (((uintptr_t)B) & 15) == 0 && sbn % 8 == 0;
+    vec_a = AK1 ? (kok && (((uintptr_t)A) & 15) == 0 && sam % 8 == 0) : (sam == 1 && (((uintptr_t)A) & 15) == 0 && sak % 8 == 0 && M % 8 == 0);
+    // (a KROW B beside a ROWK A -- the input-gradient form -- keeps the element-wise staging: measured 5 % faster there, the
+    //  transposing stores of only half the threads outweigh the saved loads; beside a KROW A -- weight gradients -- 21 % slower)
+    vec_b = BK1 ? (kok && (((uintptr_t)B) & 15) == 0 && sbn % 8 == 0) : (!AK1 && sbn == 1 && (((uintptr_t)B) & 15) == 0 && sbk % 8 == 0 && N % 8 == 0);
   }
-  const int va_r = t >> 1, va_k = 8 * (t & 1), vb_r = (t & 127) >> 1, vb_k = 8 * (t & 1);      // group = (row, first k)
+  // ROWK group = (row, first of 8 k); KROW group = (one k, first of 8 rows): 16 k x 16 (A) / 8 (B) row groups per step, lanes of a
+  // wave = 16 k x 4 row groups
+  const int va_r = AK1 ? t >> 1 : 8 * (t >> 4), va_k = AK1 ? 8 * (t & 1) : (t & 15);
+  const int vb_r = BK1 ? (t & 127) >> 1 : 8 * ((t & 127) >> 4), vb_k = BK1 ? 8 * (t & 1) : (t & 15);
   g_b8 ga, gb;
   auto zero8 = [&]() { g_b8 z; for (int j = 0; j < 8; ++j) z[j] = (__bf16)0.f; return z; };
   auto fetch = [&](int64_t k0, bool full) {
     if constexpr (BF) {
-      if (vec_a) ga = (m0 + va_r < M && k0 + va_k < Kend) ? *reinterpret_cast<const g_b8*>(A + (m0 + va_r) * sam + (k0 + va_k)) : zero8();
-      else fetch_a(k0, full);
-      if (vec_b) { if (t < 128) gb = (n0 + vb_r < N && k0 + vb_k < Kend) ? *reinterpret_cast<const g_b8*>(B + (n0 + vb_r) * sbn + (k0 + vb_k)) : zero8(); }
-      else fetch_b(k0, full);
+      if (vec_a) {
+        const bool ok = m0 + va_r < M && k0 + va_k < Kend;
+        ga = ok ? *reinterpret_cast<const g_b8*>(AK1 ? A + (m0 + va_r) * sam + (k0 + va_k) : A + (k0 + va_k) * sak + (m0 + va_r)) : zero8();
+      } else fetch_a(k0, full);
+      if (vec_b) {
+        if (t < 128) {
+          const bool ok = n0 + vb_r < N && k0 + vb_k < Kend;
+          gb = ok ? *reinterpret_cast<const g_b8*>(BK1 ? B + (n0 + vb_r) * sbn + (k0 + vb_k) : B + (k0 + vb_k) * sbk + (n0 + vb_r)) : zero8();
+        }
+      } else fetch_b(k0, full);
     } else { fetch_a(k0, full); fetch_b(k0, full); }
   };
   auto stash = [&](int buf) {
     if constexpr (BF) {
-      if (vec_a) *reinterpret_cast<g_b8*>(reinterpret_cast<T*>(As[buf]) + va_r * LD + va_k) = ga; else stash_a(buf);
-      if (vec_b) { if (t < 128) *reinterpret_cast<g_b8*>(reinterpret_cast<T*>(Bs[buf]) + vb_r * LD + vb_k) = gb; } else stash_b(buf);
+      if (vec_a) {
+        T* d = reinterpret_cast<T*>(As[buf]) + va_r * LDA + va_k;
+        if constexpr (AK1) *reinterpret_cast<g_b8*>(d) = ga;
+        else {
+#pragma unroll
+          for (int j = 0; j < 8; ++j) d[j * LDA] = ga[j];
+        }
+      } else stash_a(buf);
+      if (vec_b) {
+        if (t < 128) {
+          T* d = reinterpret_cast<T*>(Bs[buf]) + vb_r * LDB + vb_k;
+          if constexpr (BK1) *reinterpret_cast<g_b8*>(d) = gb;
+          else {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) d[j * LDB] = gb[j];
+          }
+        }
+      } else stash_b(buf);
     } else { stash_a(buf); stash_b(buf); }
   };
   fetch(kbeg, kbeg + 16 <= Kend);
@@ -239,10 +269,18 @@ gemm_gen_k(const T* __restrict__ A, const T* __restrict__ B, void* __restrict__ 
     if (more) fetch(k0 + 16, k0 + 32 <= Kend);
     if constexpr (BF) {
       typedef __attribute__((ext_vector_type(8))) __bf16 b16x8;
-      const b16x8 a = *reinterpret_cast<const b16x8*>(&reinterpret_cast<const T*>(As[buf])[(32 * wave + l32) * LD + 8 * g]);
+      typedef __attribute__((ext_vector_type(4))) __bf16 b16x4;
+      auto frag = [&](const T* p, auto aligned16) -> b16x8 {
+        if constexpr (decltype(aligned16)::value) return *reinterpret_cast<const b16x8*>(p);
+        else {
+          const b16x4 lo = *reinterpret_cast<const b16x4*>(p), hi = *reinterpret_cast<const b16x4*>(p + 4);
+          return __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+        }
+      };
+      const b16x8 a = frag(&reinterpret_cast<const T*>(As[buf])[(32 * wave + l32) * LDA + 8 * g], std::integral_constant<bool, LDA % 8 == 0>{});
 #pragma unroll
       for (int j = 0; j < 2; ++j) {
-        const b16x8 bj = *reinterpret_cast<const b16x8*>(&reinterpret_cast<const T*>(Bs[buf])[(32 * j + l32) * LD + 8 * g]);
+        const b16x8 bj = frag(&reinterpret_cast<const T*>(Bs[buf])[(32 * j + l32) * LDB + 8 * g], std::integral_constant<bool, LDB % 8 == 0>{});
         acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, bj, acc[j], 0, 0, 0);
       }
     } else {
