@@ -20,7 +20,12 @@ from typing import Dict, List, Optional, Tuple
 
 import torch
 
+import os
+
 from . import lib as L
+
+# dense 3x3 convolutions on tap-major patches (see ConvEncoder._tap_major); "0" = torchvision's channel-major order everywhere
+TAP_MAJOR = os.environ.get("MMRCA_CONV_TAP_MAJOR", "1") == "1"
 
 ROWPAD = 256
 
@@ -224,6 +229,16 @@ class ConvEncoder:
         return t
 
     # ------------------------------------------------------------------ conv -> bn -> act
+    def _tap_major(self, u: "_Unit") -> bool:
+        """dense 3x3 convolutions in bf16 with cin % 8 == 0 run on tap-major patches (k = tap*cin + c: every im2row / col2im
+        access is a contiguous 16-byte vector); the 3-channel stem and the fp32 mode keep torchvision's channel-major order"""
+        return TAP_MAJOR and self.o.dtype == torch.bfloat16 and u.cin % 8 == 0
+
+    def _tap_weight(self, u: "_Unit", w):
+        """[cout, cin, 3, 3] -> [cout, 9, cin] copy in the compute dtype (a few KB..1 MB; rebuilt at each use: the weights change
+        every optimizer step)"""
+        return w.view(u.cout, u.cin, 9).transpose(1, 2).contiguous()
+
     def _unit_fwd(self, u: _Unit, x, B, H, Wd, tag, train, save):
         """x: rows [B*H*W, cin] -> y rows [B*Ho*Wo, cout]; returns (y, Ho, Wo, saved)."""
         dt = self.o.dt
@@ -238,7 +253,11 @@ class ConvEncoder:
         else:
             K = 9 * u.cin
             col = self.buf("tmp.col", rows, K)
-            L.im2row3x3(x, col, B, H, Wd, u.cin, u.stride, K, dt)
+            if self._tap_major(u):
+                L.im2row3x3_tap(x, col, B, H, Wd, u.cin, u.stride, K, dt)
+                w = self._tap_weight(u, w)
+            else:
+                L.im2row3x3(x, col, B, H, Wd, u.cin, u.stride, K, dt)
             L.gemm(col, w, z, M=rows, N=u.cout, K=K, lda=K, ldb=K, ldc=u.cout, dtype=dt, impl=self.o.gemm_impl)
         mean = self.buf(tag + ".mean", 1, u.cout, torch.float32)
         rstd = self.buf(tag + ".rstd", 1, u.cout, torch.float32)
@@ -272,13 +291,25 @@ class ConvEncoder:
         else:
             K = 9 * u.cin
             col = self.buf("tmp.col", rows, K)
-            L.im2row3x3(sv["x"], col, B, H, Wd, u.cin, u.stride, K, dt)
-            L.gemm(dz, col, gw, M=u.cout, N=K, K=rows_k, lda=u.cout, ldb=K, ldc=K, a_layout=L.KROW, b_layout=L.KROW, accum=True, dtype=dt,
-                   impl=self.o.gemm_impl)
+            tap = self._tap_major(u)
+            if tap:
+                # tap-major patches: the weight gradient comes out as [cout, 9, cin]; it is summed into a zeroed scratch and
+                # added to the arena's [cout, cin, 3, 3] gradient through a permuted view
+                L.im2row3x3_tap(sv["x"], col, B, H, Wd, u.cin, u.stride, K, dt)
+                gwt = self.buf(f"g.wtap.{u.cout}.{K}", u.cout, K, torch.float32)[: u.cout]
+                gwt.zero_()
+                L.gemm(dz, col, gwt, M=u.cout, N=K, K=rows_k, lda=u.cout, ldb=K, ldc=K, a_layout=L.KROW, b_layout=L.KROW, accum=True,
+                       dtype=dt, impl=self.o.gemm_impl)
+                gw.view(u.cout, u.cin, 9).add_(gwt.view(u.cout, 9, u.cin).transpose(1, 2))
+                w = self._tap_weight(u, w)
+            else:
+                L.im2row3x3(sv["x"], col, B, H, Wd, u.cin, u.stride, K, dt)
+                L.gemm(dz, col, gw, M=u.cout, N=K, K=rows_k, lda=u.cout, ldb=K, ldc=K, a_layout=L.KROW, b_layout=L.KROW, accum=True,
+                       dtype=dt, impl=self.o.gemm_impl)
             if need_dx:
                 L.gemm(dz, w, col, M=rows, N=K, K=u.cout, lda=u.cout, ldb=K, ldc=K, a_layout=L.ROWK, b_layout=L.KROW, dtype=dt,
                        impl=self.o.gemm_impl)
-                L.col2im3x3(col, dx, B, H, Wd, u.cin, u.stride, K, dt)
+                (L.col2im3x3_tap if tap else L.col2im3x3)(col, dx, B, H, Wd, u.cin, u.stride, K, dt)
         return dx
 
     # ------------------------------------------------------------------ squeeze-excitation

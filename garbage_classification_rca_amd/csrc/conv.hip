@@ -171,6 +171,80 @@ extern "C" int mmrca_im2row3x3(const void* x, void* col, int B, int H, int W, in
   return 0;
 }
 
+// ---- tap-major patch order, k = tap * C + c (bf16, C % 8 == 0): one 16-byte load and one 16-byte store per thread, lanes
+// contiguous on both sides (the channel-major order above writes 16 bytes at a 144-byte lane stride and reads its 72-element
+// chunk nine times in col2im: 1.05 TB/s).  The GEMM that follows takes the weight permuted to [C_out, 9, C_in].
+__global__ void __launch_bounds__(256)
+im2row3x3_tap_v8_k(const bf16_t* __restrict__ x, bf16_t* __restrict__ col, int B, int H, int W, int C, int Ho, int Wo, int stride, int64_t ldk) {
+  const int C8 = C >> 3;
+  const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= (int64_t)B * Ho * Wo * 9 * C8) return;
+  const int c0 = (int)(idx % C8) * 8;
+  const int tap = (int)((idx / C8) % 9);
+  const int64_t op = idx / (9 * C8);
+  const int ox = (int)(op % Wo), oy = (int)((op / Wo) % Ho), b = (int)(op / ((int64_t)Wo * Ho));
+  const int iy = oy * stride + tap / 3 - 1, ix = ox * stride + tap % 3 - 1;
+  im_b8 t;
+#pragma unroll
+  for (int j = 0; j < 8; ++j) t[j] = (bf16_t)0.f;
+  if (iy >= 0 && iy < H && ix >= 0 && ix < W) t = *reinterpret_cast<const im_b8*>(x + (((int64_t)b * H + iy) * W + ix) * C + c0);
+  *reinterpret_cast<im_b8*>(col + op * ldk + (int64_t)tap * C + c0) = t;
+}
+__global__ void __launch_bounds__(256)
+col2im3x3_tap_v8_k(const bf16_t* __restrict__ dcol, bf16_t* __restrict__ dx, int B, int H, int W, int C, int Ho, int Wo, int stride, int64_t ldk) {
+  const int C8 = C >> 3;
+  const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= (int64_t)B * H * W * C8) return;
+  const int c0 = (int)(idx % C8) * 8;
+  const int64_t ip = idx / C8;
+  const int ix = (int)(ip % W), iy = (int)((ip / W) % H), b = (int)(ip / ((int64_t)W * H));
+  float s[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) s[j] = 0.f;
+#pragma unroll
+  for (int ky = 0; ky < 3; ++ky) {
+    const int ty = iy + 1 - ky;
+    if (ty < 0 || ty % stride) continue;
+    const int oy = ty / stride;
+    if (oy >= Ho) continue;
+#pragma unroll
+    for (int kx = 0; kx < 3; ++kx) {
+      const int tx = ix + 1 - kx;
+      if (tx < 0 || tx % stride) continue;
+      const int ox = tx / stride;
+      if (ox >= Wo) continue;
+      const im_b8 v = *reinterpret_cast<const im_b8*>(dcol + (((int64_t)b * Ho + oy) * Wo + ox) * ldk + (int64_t)(ky * 3 + kx) * C + c0);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) s[j] += (float)v[j];
+    }
+  }
+  im_b8 o;
+#pragma unroll
+  for (int j = 0; j < 8; ++j) o[j] = (bf16_t)s[j];
+  *reinterpret_cast<im_b8*>(dx + ip * C + c0) = o;
+}
+
+extern "C" int mmrca_im2row3x3_tap(const void* x, void* col, int B, int H, int W, int C, int stride, int64_t ldk, int dtype, void* stream) {
+  MMRCA_REQUIRE(x && col && B > 0 && H > 0 && W > 0 && C > 0 && (stride == 1 || stride == 2) && ldk >= 9LL * C, "im2row3x3_tap: bad arguments");
+  MMRCA_REQUIRE(im_v8_ok(C, ldk, dtype, x, col), "im2row3x3_tap: bf16, C %% 8 == 0, ldk %% 8 == 0 and 16-byte aligned operands only (C=%d)", C);
+  const int Ho = (H - 1) / stride + 1, Wo = (W - 1) / stride + 1;
+  const int64_t n = (int64_t)B * Ho * Wo * 9 * (C / 8);
+  hipLaunchKernelGGL(im2row3x3_tap_v8_k, dim3(blocks_for(n, 256)), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)x, (bf16_t*)col, B, H, W, C,
+                     Ho, Wo, stride, ldk);
+  MMRCA_CHECK_LAUNCH("im2row3x3_tap");
+  return 0;
+}
+extern "C" int mmrca_col2im3x3_tap(const void* dcol, void* dx, int B, int H, int W, int C, int stride, int64_t ldk, int dtype, void* stream) {
+  MMRCA_REQUIRE(dcol && dx && B > 0 && H > 0 && W > 0 && C > 0 && (stride == 1 || stride == 2) && ldk >= 9LL * C, "col2im3x3_tap: bad arguments");
+  MMRCA_REQUIRE(im_v8_ok(C, ldk, dtype, dcol, dx), "col2im3x3_tap: bf16, C %% 8 == 0, ldk %% 8 == 0 and 16-byte aligned operands only (C=%d)", C);
+  const int Ho = (H - 1) / stride + 1, Wo = (W - 1) / stride + 1;
+  const int64_t n8 = (int64_t)B * H * W * (C / 8);
+  hipLaunchKernelGGL(col2im3x3_tap_v8_k, dim3(blocks_for(n8, 256)), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)dcol, (bf16_t*)dx, B, H, W, C,
+                     Ho, Wo, stride, ldk);
+  MMRCA_CHECK_LAUNCH("col2im3x3_tap");
+  return 0;
+}
+
 // dx[b, iy, ix, c] = sum over (ky, kx) with (iy + 1 - ky) % stride == 0 etc. of dcol[out pixel][c*9 + ky*3 + kx]
 template <typename T>
 __global__ void col2im3x3_k(const T* __restrict__ dcol, T* __restrict__ dx, int B, int H, int W, int C, int Ho, int Wo, int stride,

@@ -54,6 +54,8 @@ _SIGS = {
     "mmrca_nchw_to_rows": [_vp, _vp, _i32, _i32, _i32, _i32, _i32, _vp],
     "mmrca_im2row3x3": [_vp, _vp, _i32, _i32, _i32, _i32, _i32, _i64, _i32, _vp],
     "mmrca_col2im3x3": [_vp, _vp, _i32, _i32, _i32, _i32, _i32, _i64, _i32, _vp],
+    "mmrca_im2row3x3_tap": [_vp, _vp, _i32, _i32, _i32, _i32, _i32, _i64, _i32, _vp],
+    "mmrca_col2im3x3_tap": [_vp, _vp, _i32, _i32, _i32, _i32, _i32, _i64, _i32, _vp],
     "mmrca_dwconv3x3_fwd": [_vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _vp],
     "mmrca_dwconv3x3_bwd": [_vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _vp],
     "mmrca_bn_stats": [_vp, _vp, _vp, _vp, _vp, _i64, _i32, _i64, _f32, _f32, _i32, _i32, _vp],
@@ -387,6 +389,16 @@ def im2row3x3(x, col, B, H, W, C, stride, ldk, dtype):
 
 def col2im3x3(dcol, dx, B, H, W, C, stride, ldk, dtype):
     _c("mmrca_col2im3x3", ptr(dcol), ptr(dx), B, H, W, C, stride, ldk, dtype)
+
+
+def im2row3x3_tap(x, col, B, H, W, C, stride, ldk, dtype):
+    """tap-major patches (k = tap*C + c); bf16, C % 8 == 0"""
+    _dev(x, "im2row x")
+    _c("mmrca_im2row3x3_tap", ptr(x), ptr(col), B, H, W, C, stride, ldk, dtype)
+
+
+def col2im3x3_tap(dcol, dx, B, H, W, C, stride, ldk, dtype):
+    _c("mmrca_col2im3x3_tap", ptr(dcol), ptr(dx), B, H, W, C, stride, ldk, dtype)
 
 
 def dwconv3x3_fwd(x, w, y, B, H, W, C, stride, dtype):

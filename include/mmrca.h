@@ -96,6 +96,11 @@ int mmrca_nchw_to_rows(const float* images, void* x, int B, int C, int H, int W,
 /* 3x3 patches, padding 1, stride 1 | 2: col[B*Ho*Wo, ldk] (ldk >= 9C), and the gather that sums a patch gradient back */
 int mmrca_im2row3x3(const void* x, void* col, int B, int H, int W, int C, int stride, int64_t ldk, int dtype, void* stream);
 int mmrca_col2im3x3(const void* dcol, void* dx, int B, int H, int W, int C, int stride, int64_t ldk, int dtype, void* stream);
+/* The same pair with TAP-MAJOR patches, k = tap*C + c (bf16, C % 8 == 0, 16-byte aligned): every access a contiguous 16-byte
+ * vector.  The GEMM on these patches takes the convolution weight permuted from torchvision's [C_out, C_in, 3, 3] to
+ * [C_out, 9, C_in] (conv_engine.py keeps that copy); same convolution (multimodal_model.py:11-36 -> torchvision Conv2d 3x3). */
+int mmrca_im2row3x3_tap(const void* x, void* col, int B, int H, int W, int C, int stride, int64_t ldk, int dtype, void* stream);
+int mmrca_col2im3x3_tap(const void* dcol, void* dx, int B, int H, int W, int C, int stride, int64_t ldk, int dtype, void* stream);
 /* depthwise 3x3 (torch Conv2d(C, C, 3, stride, 1, groups=C, bias=False)); w [C, 9] in `dtype`; dw fp32 [C, 9] +=; dx / dw may be NULL */
 int mmrca_dwconv3x3_fwd(const void* x, const void* w, void* y, int B, int H, int W, int C, int stride, int dtype, void* stream);
 int mmrca_dwconv3x3_bwd(const void* dy, const void* x, const void* w, void* dx, float* dw, int B, int H, int W, int C, int stride,

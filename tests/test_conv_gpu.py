@@ -365,3 +365,61 @@ def test_facade_state_dict_of_the_default_image_model_has_the_reference_layout_a
         ref = orc(ids, mask, images, eval=True)
     assert rel(out, ref) < 1e-3, rel(out, ref)
     m.engine.release_buffers()
+
+
+@pytest.mark.parametrize("stride", [1, 2])
+def test_tap_major_patch_kernels_are_the_channel_major_ones_permuted(stride):
+    """mmrca_im2row3x3_tap / col2im3x3_tap (k = tap*C + c) against the channel-major pair (k = c*9 + tap): same patches, same
+    folded gradient"""
+    B, C, H, W = 2, 24, 9, 7
+    g = torch.Generator().manual_seed(3)
+    xr = torch.randn(B * H * W, C, generator=g).bfloat16().cuda()
+    Ho, Wo = (H - 1) // stride + 1, (W - 1) // stride + 1
+    K, n = 9 * C, B * Ho * Wo
+    col_c, col_t = torch.empty(n, K, device="cuda", dtype=torch.bfloat16), torch.empty(n, K, device="cuda", dtype=torch.bfloat16)
+    L.im2row3x3(xr, col_c, B, H, W, C, stride, K, L.BF16)
+    L.im2row3x3_tap(xr, col_t, B, H, W, C, stride, K, L.BF16)
+    assert torch.equal(col_t.view(n, 9, C), col_c.view(n, C, 9).transpose(1, 2))
+    dcol_t = torch.randn(n, K, generator=g).bfloat16().cuda()
+    dcol_c = dcol_t.view(n, 9, C).transpose(1, 2).contiguous().view(n, K)
+    dx_c, dx_t = torch.empty(B * H * W, C, device="cuda", dtype=torch.bfloat16), torch.empty(B * H * W, C, device="cuda", dtype=torch.bfloat16)
+    L.col2im3x3(dcol_c, dx_c, B, H, W, C, stride, K, L.BF16)
+    L.col2im3x3_tap(dcol_t, dx_t, B, H, W, C, stride, K, L.BF16)
+    assert torch.equal(dx_c, dx_t)
+    with pytest.raises(L.MmrcaError):          # the 3-channel stem cannot use it
+        L.im2row3x3_tap(xr, col_t, B, H, W, 3, stride, 27, L.BF16)
+
+
+def test_backbone_bf16_tap_major_equals_channel_major_forward_and_backward():
+    """EfficientNetV2-M in bf16: features and every parameter gradient with the dense 3x3 convolutions on tap-major patches
+    (default) against the channel-major path (MMRCA_CONV_TAP_MAJOR=0).  BatchNorm on running statistics: with batch statistics
+    over the 12..48 rows this small input leaves in the late stages, bf16 rounding differences between two summation orders are
+    amplified to tens of per cent by the normalisation itself (either order is equally far from the fp32 oracle)."""
+    from garbage_classification_rca_amd import conv_engine as CE
+    images = torch.randn(3, 3, 64, 64, generator=torch.Generator().manual_seed(5)).cuda()
+    out = {}
+    for tap in (True, False):
+        CE.TAP_MAJOR = tap
+        try:
+            enc, own, _ = _conv_pair("eff_v2_medium", torch.bfloat16, seed=4)
+            feat = enc.forward(images, save=True, train=False, seed=9)
+            dfeat = (torch.randn(feat.shape, generator=torch.Generator().manual_seed(6)) * 0.1).to(feat.dtype).cuda()
+            enc.backward(dfeat)
+            torch.cuda.synchronize()
+            out[tap] = (feat.float().cpu(), {k: v.float().cpu().clone() for k, v in own.g.items()})
+            enc.release()
+        finally:
+            CE.TAP_MAJOR = True
+    print("tap-major vs channel-major features:", rel(out[True][0], out[False][0]))
+    assert rel(out[True][0], out[False][0]) < 2e-2
+    errs = {k: rel(out[True][1][k], out[False][1][k]) for k in out[True][1] if out[False][1][k].abs().max() > 0}
+    worst = max(errs, key=errs.get)
+    # the 3x3 weight gradients themselves (the tensors the permuted accumulation writes)
+    k3 = [k for k, v in out[True][1].items() if v.dim() == 4 and v.shape[-1] == 3 and v.shape[1] % 8 == 0 and v.shape[1] > 1]
+    print("worst gradient:", worst, errs[worst], "; worst 3x3 weight gradient:", max(errs[k] for k in k3))
+    # two bf16 runs of a 57-layer backward that differ in the summation order of 19 GEMMs: per-cent level on the worst tensor
+    assert errs[worst] < 1e-1, (worst, errs[worst])
+    assert k3 and all(errs[k] < 6e-2 for k in k3)
+    cos = min(torch.nn.functional.cosine_similarity(out[True][1][k].double().flatten(), out[False][1][k].double().flatten(), dim=0).item() for k in k3)
+    print("smallest cosine between the two 3x3 weight gradients:", cos)
+    assert cos > 0.999
