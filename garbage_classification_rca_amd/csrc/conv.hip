@@ -663,6 +663,51 @@ col_moment_v8_k(const bf16_t* __restrict__ x, const float* __restrict__ mean, fl
   col_reduce8<1>(acc, red, outs, blockIdx.y, C);
 }
 
+// Both moments in ONE pass over x (bf16 fast path of mmrca_bn_stats): sums of d and d*d with d = x - x[0, c], the channel's
+// first-row value as the shift (any value within a few standard deviations of the mean keeps var = E[d^2] - E[d]^2 free of
+// cancellation; fp32 sums).  Saves the second 2-byte-per-element pass of the two-pass form per BatchNorm layer.
+__global__ void __launch_bounds__(256)
+col_moment2_v8_k(const bf16_t* __restrict__ x, float* __restrict__ s1, float* __restrict__ s2, int64_t rows, int C, int64_t ld,
+                 int64_t rows_per_block) {
+  __shared__ float red[4][8][17];
+  const int cg = threadIdx.x & 7, rl = threadIdx.x >> 3;
+  const int c0 = blockIdx.y * 64 + cg * 8;
+  const int64_t r0 = (int64_t)blockIdx.x * rows_per_block;
+  const int64_t r1 = r0 + rows_per_block < rows ? r0 + rows_per_block : rows;
+  float acc[2][8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) { acc[0][j] = 0.f; acc[1][j] = 0.f; }
+  if (c0 < C) {
+    const cm_b8 sv = *reinterpret_cast<const cm_b8*>(x + c0);
+    float m[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) m[j] = (float)sv[j];
+    for (int64_t r = r0 + rl; r < r1; r += 32) {
+      const cm_b8 v = *reinterpret_cast<const cm_b8*>(x + r * ld + c0);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) { const float d = (float)v[j] - m[j]; acc[0][j] += d; acc[1][j] = fmaf(d, d, acc[1][j]); }
+    }
+  }
+  float* const outs[2] = {s1, s2};
+  col_reduce8<2>(acc, red, outs, blockIdx.y, C);
+}
+// (sum d, sum d^2) -> mean, rstd (in place), running stats
+__global__ void bn_finish_shifted_k(const bf16_t* __restrict__ x, float* __restrict__ mean, float* __restrict__ rstd,
+                                    float* __restrict__ running_mean, float* __restrict__ running_var, int C, float n, float eps,
+                                    float momentum) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  const float d1 = mean[c] / n;
+  const float mu = (float)x[c] + d1;
+  const float var = fmaxf(rstd[c] / n - d1 * d1, 0.f);
+  mean[c] = mu;
+  rstd[c] = rsqrtf(var + eps);
+  if (running_mean && momentum > 0.f) {
+    running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * mu;
+    running_var[c] = (1.f - momentum) * running_var[c] + momentum * (n > 1.f ? var * n / (n - 1.f) : var);
+  }
+}
+
 __global__ void __launch_bounds__(256)
 bn_act_bwd_reduce_v8_k(const bf16_t* __restrict__ dy, const bf16_t* __restrict__ x, const float* __restrict__ mean,
                        const float* __restrict__ rstd, const bf16_t* __restrict__ gamma, const bf16_t* __restrict__ beta,
@@ -700,7 +745,8 @@ static void col_grid(int64_t rows, int C, dim3* grid, int64_t* per) {
   *grid = dim3((unsigned)((rows + *per - 1) / *per), (unsigned)((C + 63) / 64));
 }
 
-/* mean[C], rstd[C] (fp32) of x[rows, C] (two passes: mean, then centred second moment); momentum > 0 also updates the running
+static const bool g_bn_one_pass = !(getenv("MMRCA_BN_ONE_PASS") && atoi(getenv("MMRCA_BN_ONE_PASS")) == 0);
+/* mean[C], rstd[C] (fp32) of x[rows, C] (two passes: mean, then centred second moment; the bf16 fast path: one pass of shifted sums); momentum > 0 also updates the running
  * statistics (torch semantics).  train == 0: mean / rstd are derived from the running statistics instead. */
 extern "C" int mmrca_bn_stats(const void* x, float* mean, float* rstd, float* running_mean, float* running_var, int64_t rows, int C,
                               int64_t ld, float eps, float momentum, int train, int dtype, void* stream) {
@@ -718,6 +764,13 @@ extern "C" int mmrca_bn_stats(const void* x, float* mean, float* rstd, float* ru
   (void)hipMemsetAsync(mean, 0, sizeof(float) * C, st);
   (void)hipMemsetAsync(rstd, 0, sizeof(float) * C, st);
   if (dtype == MMRCA_BF16 && C % 8 == 0 && ld % 8 == 0 && (((uintptr_t)x) & 15) == 0) {
+    if (g_bn_one_pass) {
+      hipLaunchKernelGGL(col_moment2_v8_k, grid, dim3(256), 0, st, (const bf16_t*)x, mean, rstd, rows, C, ld, per);
+      hipLaunchKernelGGL(bn_finish_shifted_k, dim3((C + 255) / 256), dim3(256), 0, st, (const bf16_t*)x, mean, rstd, running_mean, running_var, C,
+                         (float)rows, eps, momentum);
+      MMRCA_CHECK_LAUNCH("bn_stats(one pass)");
+      return 0;
+    }
     hipLaunchKernelGGL((col_moment_v8_k<false>), grid, dim3(256), 0, st, (const bf16_t*)x, (const float*)nullptr, mean, rows, C, ld, per);
     hipLaunchKernelGGL(bn_finish_mean_k, dim3((C + 255) / 256), dim3(256), 0, st, mean, C, 1.0f / (float)rows);
     hipLaunchKernelGGL((col_moment_v8_k<true>), grid, dim3(256), 0, st, (const bf16_t*)x, (const float*)mean, rstd, rows, C, ld, per);
