@@ -423,6 +423,56 @@ dwconv3x3_fwd_v8_k(const bf16_t* __restrict__ x, const bf16_t* __restrict__ w, b
   *reinterpret_cast<cv_b8*>(y + op * C + c0) = o;
 }
 
+// Stride-1 layers (all but three of EfficientNetV2's depthwise convolutions): a thread owns FOUR consecutive output pixels of a
+// row for its 8 channels -- the 72 weights are fetched once per four outputs and the 3 x 6 input window serves all of them
+// (6.75 sixteen-byte loads per output instead of 18).  FLIP = the input gradient (the same correlation with the kernel turned
+// by 180 degrees).  Per output the products are added in the same (ky, kx) order as in the one-pixel kernels: identical bits.
+template <bool FLIP>
+__global__ void __launch_bounds__(256)
+dw3x3_s1_strip_v8_k(const bf16_t* __restrict__ in, const bf16_t* __restrict__ w, bf16_t* __restrict__ out, int B, int H, int W, int C) {
+  const int C8 = C >> 3, XG = (W + 3) >> 2;
+  const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= (int64_t)B * H * XG * C8) return;
+  const int c0 = (int)(idx % C8) * 8;
+  const int64_t g = idx / C8;
+  const int x0 = (int)(g % XG) * 4, y = (int)((g / XG) % H), b = (int)(g / ((int64_t)XG * H));
+  float wf[8][9];
+  dw_load_w8(w, c0, wf);
+  float s[4][8];
+#pragma unroll
+  for (int o = 0; o < 4; ++o)
+#pragma unroll
+    for (int j = 0; j < 8; ++j) s[o][j] = 0.f;
+#pragma unroll
+  for (int ky = 0; ky < 3; ++ky) {
+    const int iy = y + ky - 1;
+    if (iy < 0 || iy >= H) continue;
+    const bf16_t* row = in + ((int64_t)b * H + iy) * W * C + c0;
+#pragma unroll
+    for (int col = 0; col < 6; ++col) {
+      const int ix = x0 + col - 1;
+      if (ix < 0 || ix >= W) continue;
+      const cv_b8 v = *reinterpret_cast<const cv_b8*>(row + (int64_t)ix * C);
+#pragma unroll
+      for (int o = 0; o < 4; ++o) {
+        const int kx = col - o;
+        if (kx < 0 || kx > 2) continue;
+        const int tap = FLIP ? (2 - ky) * 3 + (2 - kx) : ky * 3 + kx;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) s[o][j] = fmaf((float)v[j], wf[j][tap], s[o][j]);
+      }
+    }
+  }
+#pragma unroll
+  for (int o = 0; o < 4; ++o) {
+    if (x0 + o >= W) continue;
+    cv_b8 r;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) r[j] = (bf16_t)s[o][j];
+    *reinterpret_cast<cv_b8*>(out + (((int64_t)b * H + y) * W + x0 + o) * C + c0) = r;
+  }
+}
+
 __global__ void __launch_bounds__(256)
 dwconv3x3_bwd_data_v8_k(const bf16_t* __restrict__ dy, const bf16_t* __restrict__ w, bf16_t* __restrict__ dx, int B, int H, int W, int C,
                         int Ho, int Wo, int stride) {
@@ -512,9 +562,17 @@ static bool dw_v8_ok(int C, int dtype, const void* a, const void* b, const void*
   return dtype == MMRCA_BF16 && C % 8 == 0 && ((((uintptr_t)a) | ((uintptr_t)b) | ((uintptr_t)c)) & 15) == 0;
 }
 
+static const bool g_dw_strip = !(getenv("MMRCA_DW_STRIP") && atoi(getenv("MMRCA_DW_STRIP")) == 0);
 extern "C" int mmrca_dwconv3x3_fwd(const void* x, const void* w, void* y, int B, int H, int W, int C, int stride, int dtype, void* stream) {
   MMRCA_REQUIRE(x && w && y && B > 0 && H > 0 && W > 0 && C > 0 && (stride == 1 || stride == 2), "dwconv3x3_fwd: bad arguments");
   const int Ho = (H - 1) / stride + 1, Wo = (W - 1) / stride + 1;
+  if (dw_v8_ok(C, dtype, x, w, y) && stride == 1 && g_dw_strip) {
+    const int64_t n = (int64_t)B * H * ((W + 3) / 4) * (C / 8);
+    hipLaunchKernelGGL(dw3x3_s1_strip_v8_k<false>, dim3(blocks_for(n, 256)), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)x,
+                       (const bf16_t*)w, (bf16_t*)y, B, H, W, C);
+    MMRCA_CHECK_LAUNCH("dwconv3x3_fwd(strip)");
+    return 0;
+  }
   if (dw_v8_ok(C, dtype, x, w, y)) {
     const int64_t n8 = (int64_t)B * Ho * Wo * (C / 8);
     hipLaunchKernelGGL(dwconv3x3_fwd_v8_k, dim3(blocks_for(n8, 256)), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)x, (const bf16_t*)w,
@@ -535,7 +593,12 @@ extern "C" int mmrca_dwconv3x3_bwd(const void* dy, const void* x, const void* w,
   MMRCA_REQUIRE(dy && x && w && B > 0 && H > 0 && W > 0 && C > 0 && (stride == 1 || stride == 2), "dwconv3x3_bwd: bad arguments");
   const int Ho = (H - 1) / stride + 1, Wo = (W - 1) / stride + 1;
   hipStream_t st = (hipStream_t)stream;
-  if (dx && dw_v8_ok(C, dtype, dy, w, dx)) {
+  if (dx && dw_v8_ok(C, dtype, dy, w, dx) && stride == 1 && g_dw_strip) {
+    const int64_t n = (int64_t)B * H * ((W + 3) / 4) * (C / 8);
+    hipLaunchKernelGGL(dw3x3_s1_strip_v8_k<true>, dim3(blocks_for(n, 256)), dim3(256), 0, st, (const bf16_t*)dy, (const bf16_t*)w,
+                       (bf16_t*)dx, B, H, W, C);
+    MMRCA_CHECK_LAUNCH("dwconv3x3_bwd(data,strip)");
+  } else if (dx && dw_v8_ok(C, dtype, dy, w, dx)) {
     const int64_t n8 = (int64_t)B * H * W * (C / 8);
     hipLaunchKernelGGL(dwconv3x3_bwd_data_v8_k, dim3(blocks_for(n8, 256)), dim3(256), 0, st, (const bf16_t*)dy, (const bf16_t*)w, (bf16_t*)dx,
                        B, H, W, C, Ho, Wo, stride);

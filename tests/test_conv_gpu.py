@@ -67,8 +67,9 @@ def test_im2row_gemm_is_conv3x3_and_col2im_is_its_input_gradient(dt, stride):
 
 @pytest.mark.parametrize("dt", [torch.float32, torch.bfloat16])
 @pytest.mark.parametrize("stride", [1, 2])
-def test_depthwise_conv_fwd_bwd(dt, stride):
-    B, C, H, W = 3, 70, 8, 11
+@pytest.mark.parametrize("C", [70, 72])      # 72: the 8-channel kernels (stride 1: four output pixels per thread)
+def test_depthwise_conv_fwd_bwd(dt, stride, C):
+    B, H, W = 3, 8, 11
     g = torch.Generator().manual_seed(2)
     x = torch.randn(B, C, H, W, generator=g).to(dt).float().requires_grad_(True)
     w = (torch.randn(C, 1, 3, 3, generator=g) * 0.3).to(dt).float().requires_grad_(True)
