@@ -1015,9 +1015,74 @@ __global__ void rowpool_mean_k(const T* __restrict__ x, T* __restrict__ out, int
   __syncthreads();
   if (rl == 0 && c < C) out[(int64_t)b * C + c] = from_f<T>((red[0][cl] + red[1][cl] + red[2][cl] + red[3][cl]) / (float)HW);
 }
+// ---- 8 channels per thread (bf16, C % 8 == 0): block = (sample, 64 channels) = 8 channel groups x 32 row lanes, 16-byte accesses;
+// the row lanes of a wave meet through shuffles, the four waves through LDS.  Shared by the pooling and by the backward of the
+// squeeze-excitation scale (which also writes dx = dy * s on the way).
+typedef __attribute__((ext_vector_type(8))) __bf16 pl_b8;
+__device__ __forceinline__ void pool_reduce8(float (&acc)[8], float (*red)[8][9], bf16_t* __restrict__ out_row, int cblk, int C, float scale) {
+  const int cg = threadIdx.x & 7, wv = threadIdx.x >> 6;
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    float v = acc[j];
+    v += __shfl_xor(v, 8, 64); v += __shfl_xor(v, 16, 64); v += __shfl_xor(v, 32, 64);
+    if ((threadIdx.x & 63) < 8) red[wv][cg][j] = v;
+  }
+  __syncthreads();
+  if (threadIdx.x < 64) {
+    const int g = threadIdx.x >> 3, j = threadIdx.x & 7, c = cblk * 64 + threadIdx.x;
+    if (c < C) out_row[c] = (bf16_t)(((red[0][g][j] + red[1][g][j]) + (red[2][g][j] + red[3][g][j])) * scale);
+  }
+}
+__global__ void __launch_bounds__(256)
+rowpool_mean_v8_k(const bf16_t* __restrict__ x, bf16_t* __restrict__ out, int HW, int C) {
+  __shared__ float red[4][8][9];
+  const int cg = threadIdx.x & 7, rl = threadIdx.x >> 3;
+  const int c0 = blockIdx.y * 64 + cg * 8, b = blockIdx.x;
+  float acc[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) acc[j] = 0.f;
+  if (c0 < C)
+    for (int p = rl; p < HW; p += 32) {
+      const pl_b8 v = *reinterpret_cast<const pl_b8*>(x + ((int64_t)b * HW + p) * C + c0);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) acc[j] += (float)v[j];
+    }
+  pool_reduce8(acc, red, out + (int64_t)b * C, blockIdx.y, C, 1.0f / (float)HW);
+}
+__global__ void __launch_bounds__(256)
+se_scale_bwd_v8_k(const bf16_t* __restrict__ dy, const bf16_t* __restrict__ x, const bf16_t* __restrict__ s, bf16_t* __restrict__ dx,
+                  bf16_t* __restrict__ ds, int HW, int C) {
+  __shared__ float red[4][8][9];
+  const int cg = threadIdx.x & 7, rl = threadIdx.x >> 3;
+  const int c0 = blockIdx.y * 64 + cg * 8, b = blockIdx.x;
+  float acc[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) acc[j] = 0.f;
+  if (c0 < C) {
+    const pl_b8 s8 = *reinterpret_cast<const pl_b8*>(s + (int64_t)b * C + c0);
+    for (int p = rl; p < HW; p += 32) {
+      const int64_t i = ((int64_t)b * HW + p) * C + c0;
+      const pl_b8 g = *reinterpret_cast<const pl_b8*>(dy + i), xv = *reinterpret_cast<const pl_b8*>(x + i);
+      pl_b8 o;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) { acc[j] = fmaf((float)g[j], (float)xv[j], acc[j]); o[j] = (bf16_t)((float)g[j] * (float)s8[j]); }
+      *reinterpret_cast<pl_b8*>(dx + i) = o;
+    }
+  }
+  pool_reduce8(acc, red, ds + (int64_t)b * C, blockIdx.y, C, 1.0f);
+}
+static bool pool_v8_ok(int C, int dtype, const void* a, const void* b, const void* c, const void* d) {
+  return dtype == MMRCA_BF16 && C % 8 == 0 && ((((uintptr_t)a) | ((uintptr_t)b) | ((uintptr_t)c) | ((uintptr_t)d)) & 15) == 0;
+}
+
 /* out[b, c] = mean over the HW rows of sample b (AdaptiveAvgPool2d(1) / x.mean([2, 3])) */
 extern "C" int mmrca_rowpool_mean(const void* x, void* out, int B, int HW, int C, int dtype, void* stream) {
   MMRCA_REQUIRE(x && out && B > 0 && HW > 0 && C > 0, "rowpool_mean: bad arguments");
+  if (pool_v8_ok(C, dtype, x, x, x, x)) {
+    hipLaunchKernelGGL(rowpool_mean_v8_k, dim3(B, (C + 63) / 64), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)x, (bf16_t*)out, HW, C);
+    MMRCA_CHECK_LAUNCH("rowpool_mean(v8)");
+    return 0;
+  }
   MMRCA_DISPATCH_DTYPE(dtype, "rowpool_mean",
     hipLaunchKernelGGL(rowpool_mean_k<T>, dim3(B, (C + 63) / 64), dim3(256), 0, (hipStream_t)stream, (const T*)x, (T*)out, HW, C);)
   MMRCA_CHECK_LAUNCH("rowpool_mean");
@@ -1131,6 +1196,12 @@ __global__ void se_scale_bwd_k(const T* __restrict__ dy, const T* __restrict__ x
 }
 extern "C" int mmrca_se_scale_bwd(const void* dy, const void* x, const void* s, void* dx, void* ds, int B, int HW, int C, int dtype, void* stream) {
   MMRCA_REQUIRE(dy && x && s && dx && ds && B > 0 && HW > 0 && C > 0, "se_scale_bwd: bad arguments");
+  if (pool_v8_ok(C, dtype, dy, x, s, dx)) {
+    hipLaunchKernelGGL(se_scale_bwd_v8_k, dim3(B, (C + 63) / 64), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)dy, (const bf16_t*)x,
+                       (const bf16_t*)s, (bf16_t*)dx, (bf16_t*)ds, HW, C);
+    MMRCA_CHECK_LAUNCH("se_scale_bwd(v8)");
+    return 0;
+  }
   MMRCA_DISPATCH_DTYPE(dtype, "se_scale_bwd",
     hipLaunchKernelGGL(se_scale_bwd_k<T>, dim3(B, (C + 63) / 64), dim3(256), 0, (hipStream_t)stream, (const T*)dy, (const T*)x, (const T*)s,
                        (T*)dx, (T*)ds, HW, C);)

@@ -125,8 +125,9 @@ def test_batchnorm_act_fwd_bwd_and_running_stats(dt, act, train):
 
 
 @pytest.mark.parametrize("dt", [torch.float32, torch.bfloat16])
-def test_pool_se_residual_maxpool_gather(dt):
-    B, HW, C = 3, 35, 70
+@pytest.mark.parametrize("C", [70, 72])      # 72: the 8-channel kernels
+def test_pool_se_residual_maxpool_gather(dt, C):
+    B, HW = 3, 35
     g = torch.Generator().manual_seed(4)
     x = torch.randn(B, HW, C, generator=g).to(dt).float()
     s = torch.rand(B, C, generator=g).to(dt).float()
