@@ -558,6 +558,72 @@ dwconv3x3_bwd_weight_v8_k(const bf16_t* __restrict__ dy, const bf16_t* __restric
   }
 }
 
+// stride 1: four consecutive output pixels of a row per thread and iteration -- 4 loads of dy and the 3 x 6 window of x serve 36
+// (pixel, tap) pairs (5.5 sixteen-byte loads per pixel instead of 10); same reduction afterwards
+__global__ void __launch_bounds__(256)
+dwconv3x3_bwd_weight_s1_strip_v8_k(const bf16_t* __restrict__ dy, const bf16_t* __restrict__ x, float* __restrict__ dw, int B, int H, int W,
+                                   int C, int64_t grp_per_block) {
+  __shared__ float red[4][8][73];
+  const int cg = threadIdx.x & 7, pl = threadIdx.x >> 3;
+  const int c0 = blockIdx.y * 64 + cg * 8, XG = (W + 3) >> 2;
+  float acc[8][9];
+#pragma unroll
+  for (int j = 0; j < 8; ++j)
+#pragma unroll
+    for (int t = 0; t < 9; ++t) acc[j][t] = 0.f;
+  const int64_t ngrp = (int64_t)B * H * XG;
+  const int64_t g0 = (int64_t)blockIdx.x * grp_per_block;
+  const int64_t g1 = g0 + grp_per_block < ngrp ? g0 + grp_per_block : ngrp;
+  if (c0 < C) {
+    for (int64_t g = g0 + pl; g < g1; g += 32) {
+      const int x0 = (int)(g % XG) * 4, y = (int)((g / XG) % H), b = (int)(g / ((int64_t)XG * H));
+      float gv[4][8];
+#pragma unroll
+      for (int o = 0; o < 4; ++o) {
+        cv_b8 v;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v[j] = (bf16_t)0.f;
+        if (x0 + o < W) v = *reinterpret_cast<const cv_b8*>(dy + (((int64_t)b * H + y) * W + x0 + o) * C + c0);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) gv[o][j] = (float)v[j];
+      }
+#pragma unroll
+      for (int ky = 0; ky < 3; ++ky) {
+        const int iy = y + ky - 1;
+        if (iy < 0 || iy >= H) continue;
+        const bf16_t* row = x + ((int64_t)b * H + iy) * W * C + c0;
+#pragma unroll
+        for (int col = 0; col < 6; ++col) {
+          const int ix = x0 + col - 1;
+          if (ix < 0 || ix >= W) continue;
+          const cv_b8 xv = *reinterpret_cast<const cv_b8*>(row + (int64_t)ix * C);
+#pragma unroll
+          for (int o = 0; o < 4; ++o) {
+            const int kx = col - o;
+            if (kx < 0 || kx > 2) continue;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) acc[j][ky * 3 + kx] = fmaf(gv[o][j], (float)xv[j], acc[j][ky * 3 + kx]);
+          }
+        }
+      }
+    }
+  }
+#pragma unroll
+  for (int j = 0; j < 8; ++j)
+#pragma unroll
+    for (int t = 0; t < 9; ++t) {
+      float v = acc[j][t];
+      v += __shfl_xor(v, 8, 64); v += __shfl_xor(v, 16, 64); v += __shfl_xor(v, 32, 64);
+      if ((threadIdx.x & 63) < 8) red[threadIdx.x >> 6][cg][j * 9 + t] = v;
+    }
+  __syncthreads();
+  for (int e = threadIdx.x; e < 8 * 72; e += 256) {
+    const int g = e / 72, r = e % 72;
+    const int c = blockIdx.y * 64 + g * 8 + r / 9;
+    if (c < C) atomicAdd(dw + (int64_t)c * 9 + r % 9, (red[0][g][r] + red[1][g][r]) + (red[2][g][r] + red[3][g][r]));
+  }
+}
+
 static bool dw_v8_ok(int C, int dtype, const void* a, const void* b, const void* c) {
   return dtype == MMRCA_BF16 && C % 8 == 0 && ((((uintptr_t)a) | ((uintptr_t)b) | ((uintptr_t)c)) & 15) == 0;
 }
@@ -615,6 +681,16 @@ extern "C" int mmrca_dwconv3x3_bwd(const void* dy, const void* x, const void* w,
     int64_t nblk = npix / 512 > 0 ? npix / 512 : 1;
     if (nblk > 1024) nblk = 1024;
     const int64_t per = (npix + nblk - 1) / nblk;
+    if (dw_v8_ok(C, dtype, dy, x, dw) && stride == 1 && g_dw_strip) {
+      const int64_t ngrp = (int64_t)B * H * ((W + 3) / 4);
+      int64_t nb = ngrp / 128 > 0 ? ngrp / 128 : 1;
+      if (nb > 1024) nb = 1024;
+      const int64_t gper = (ngrp + nb - 1) / nb;
+      hipLaunchKernelGGL(dwconv3x3_bwd_weight_s1_strip_v8_k, dim3((unsigned)((ngrp + gper - 1) / gper), (unsigned)((C + 63) / 64)), dim3(256), 0, st,
+                         (const bf16_t*)dy, (const bf16_t*)x, dw, B, H, W, C, gper);
+      MMRCA_CHECK_LAUNCH("dwconv3x3_bwd(weight,strip)");
+      return 0;
+    }
     if (dw_v8_ok(C, dtype, dy, x, dw)) {
       hipLaunchKernelGGL(dwconv3x3_bwd_weight_v8_k, dim3((unsigned)nblk, (unsigned)((C + 63) / 64)), dim3(256), 0, st, (const bf16_t*)dy,
                          (const bf16_t*)x, dw, B, H, W, C, Ho, Wo, stride, per);
