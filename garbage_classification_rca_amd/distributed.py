@@ -76,6 +76,45 @@ class ShardedSampler(torch.utils.data.Sampler):
         return len(range(self.rank, self.n, self.world))
 
 
+class BalancedShardedSampler(torch.utils.data.Sampler):
+    """``--balanced_sampler`` (reference main_both.py:478-526 -> imbalanced_sampler/imbalanced.py:9-74): every draw picks sample i
+    with probability proportional to 1 / count[label_i], WITH replacement, ``len(dataset)`` draws per epoch (so each class
+    contributes the same expected number of draws).  Under data parallelism one multinomial draw of the whole epoch is made
+    from the shared seed (+ epoch) and strided by rank, so the ranks together see exactly what one process would.  The
+    reference uses it for the validation loaders too (every pass re-draws); ``num_real`` equals ``len`` -- there is no padding
+    to exclude because the draws are random anyway."""
+
+    def __init__(self, targets, rank: int, world: int, seed: int = 0):
+        t = torch.as_tensor(list(targets), dtype=torch.int64)
+        self.n, self.rank, self.world, self.seed, self.epoch = int(t.numel()), rank, world, seed, 0
+        counts = torch.bincount(t) if self.n else torch.zeros(1, dtype=torch.int64)
+        self.weights = (1.0 / counts[t].double()) if self.n else torch.zeros(0, dtype=torch.float64)     # imbalanced.py:42-46
+        self.per_rank = math.ceil(self.n / world) if self.n else 0
+        self._pass = 0
+
+    def set_epoch(self, epoch: int):
+        self.epoch = epoch
+
+    def indices(self) -> List[int]:
+        if not self.n:
+            return []
+        g = torch.Generator().manual_seed(self.seed + self.epoch + 7919 * self._pass)
+        total = self.per_rank * self.world
+        order = torch.multinomial(self.weights, total, replacement=True, generator=g).tolist()          # imbalanced.py:70-71
+        return order[self.rank: total: self.world]
+
+    def __iter__(self) -> Iterator[int]:
+        self._pass += 1            # every pass over the loader re-draws, as the reference's global-RNG multinomial does
+        return iter(self.indices())
+
+    def __len__(self) -> int:
+        return self.per_rank
+
+    @property
+    def num_real(self) -> int:
+        return self.per_rank
+
+
 class GradSync:
     """Overlapped gradient averaging over contiguous slices of a flat gradient buffer."""
 

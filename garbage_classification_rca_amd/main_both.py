@@ -190,7 +190,9 @@ def main(argv=None):
     shuffle_seed = D.broadcast_seed(args.seed, device if world > 1 and torch.distributed.get_backend() == "nccl" else "cpu")
     global_model._drop_seed += rank * 1000003
     print("Per-process batch size: {} (global batch = {} x {} ranks; lr unchanged)".format(_batch_size, _batch_size, world))
-    for flag, default in (("balanced_sampler", False), ("use_synonyms", False), ("prob_aug_text", 0.6)):
+    if args.balanced_sampler:
+        print("Using balanced sampler for training and validation sets")                  # main_both.py:478-479
+    for flag, default in (("use_synonyms", False), ("prob_aug_text", 0.6)):
         if getattr(args, flag, default) != default:
             print("WARNING: --{} is accepted for CLI compatibility but not implemented on this path (SURVEY.md section 2: out of scope)".format(flag))
 
@@ -206,7 +208,10 @@ def main(argv=None):
         print("CPU image transforms (--gpu_preprocess=false): of the training augmentations only the flips are applied")
 
     def loader(ds, bs, shuffle):
-        sampler = D.ShardedSampler(len(ds), rank, world, shuffle=shuffle, seed=shuffle_seed)
+        if args.balanced_sampler:     # class-balanced draws with replacement, training AND validation loaders (main_both.py:481-526)
+            sampler = D.BalancedShardedSampler(ds.targets, rank, world, seed=shuffle_seed + (0 if shuffle else 104729))
+        else:
+            sampler = D.ShardedSampler(len(ds), rank, world, shuffle=shuffle, seed=shuffle_seed)
         # GPU input path: workers come from a fork SERVER (a fresh interpreter without the GPU runtime), not from a fork of this
         # process -- every fork of a process with registered host memory makes the kernel driver evict and restore its GPU
         # queues; 16 workers cost 25-34 s of stalled GPU per loader start on the MI355X box (tools/input_bench.py)

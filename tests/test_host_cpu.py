@@ -521,3 +521,28 @@ def test_oracle_train_pipeline_stage_properties():
     assert np.all(p == 93)                                                          # the jittered quadrilateral lies inside
     z = T.scale_u8(const, 0.5)
     assert z[0, 0, 0] == 0 and z[20, 25, 0] == 93 and abs(int((z[..., 0] == 93).sum()) - 20 * 25) <= 50
+
+
+# ------------------------------------------------------------------------------------------------ --balanced_sampler
+def test_balanced_sampler_weights_draws_and_rank_striding():
+    """main_both.py:478-526 -> imbalanced_sampler/imbalanced.py: weight_i = 1 / count[label_i], len(dataset) draws with
+    replacement; under data parallelism the ranks' draws interleave to the single-process draw"""
+    from garbage_classification_rca_amd.distributed import BalancedShardedSampler
+    targets = [0] * 600 + [1] * 300 + [2] * 90 + [3] * 10
+    s = BalancedShardedSampler(targets, 0, 1, seed=5)
+    w = s.weights.numpy()
+    assert np.allclose(w[0], 1 / 600) and np.allclose(w[650], 1 / 300) and np.allclose(w[995], 1 / 10) and len(s) == 1000
+    idx = list(iter(s))
+    assert len(idx) == 1000 and all(0 <= i < 1000 for i in idx)
+    cls = np.bincount(np.asarray(targets)[idx], minlength=4)
+    assert (np.abs(cls - 250) < 60).all(), cls                       # each class ~ a quarter of the draws (sigma ~ 14)
+    assert len(set(i for i in idx if targets[i] == 3)) <= 10 and cls[3] > 150          # the rare class is drawn WITH replacement
+    assert list(iter(s)) != idx                                        # the next pass re-draws
+    # two ranks: same seed, same pass -> interleaved halves of one draw of ceil(n / 2) * 2
+    a, b = BalancedShardedSampler(targets, 0, 2, seed=5), BalancedShardedSampler(targets, 1, 2, seed=5)
+    one = BalancedShardedSampler(targets, 0, 1, seed=5)
+    ia, ib, io = list(iter(a)), list(iter(b)), list(iter(one))
+    assert len(ia) == len(ib) == 500 and [x for p in zip(ia, ib) for x in p] == io
+    a.set_epoch(3); one.set_epoch(3)
+    assert list(iter(a)) == list(iter(one))[0::2]
+    assert len(BalancedShardedSampler([], 0, 1)) == 0 and list(iter(BalancedShardedSampler([], 0, 1))) == []
