@@ -850,11 +850,17 @@ static void launch_mfma32(const void* A, const void* B, void* C, const void* bia
 }
 
 // single-stage 128x128x64 variant (32 KiB LDS, four to five blocks per CU): full 128-byte lines for ROWK operands
-template <bool A_KROW, bool B_KROW, bool ATOMIC_F32, int WPE>
+// X3 ("bf16x3", the <= 1e-3 fast mode, see gemm_x3.hip): both operands are fp32 values stored as two bf16 planes, x = hi + lo
+// (hi = bf16(x), lo = bf16(x - hi): 16 mantissa bits).  The K loop runs three times over the same output tile -- (A_hi, B_hi),
+// (A_lo, B_hi), (A_hi, B_lo); lo x lo is below fp32 resolution -- into the same fp32 accumulators, and the epilogue's
+// bias / side operands / outputs are fp32 (biasv / addendv / preactv / Cv point at floats), or, with C_lo given, the output is
+// written as two bf16 planes (Cv = hi plane) for a consumer that is another X3 GEMM.
+template <bool A_KROW, bool B_KROW, bool ATOMIC_F32, int WPE, bool X3 = false>
 __global__ void __launch_bounds__(256, WPE)
 gemm_mfma_k1s(const bf16_t* __restrict__ A, const bf16_t* __restrict__ B, void* __restrict__ Cv, const bf16_t* __restrict__ bias,
               const bf16_t* __restrict__ addend, bf16_t* __restrict__ preact, int64_t M, int64_t N, int64_t K,
-              int64_t lda, int64_t ldb, int64_t ldc, int act, int tiles_m, int tiles_n, int64_t ksplit_len, float* __restrict__ colsum) {
+              int64_t lda, int64_t ldb, int64_t ldc, int act, int tiles_m, int tiles_n, int64_t ksplit_len, float* __restrict__ colsum,
+              const bf16_t* __restrict__ A_lo = nullptr, const bf16_t* __restrict__ B_lo = nullptr, bf16_t* __restrict__ C_lo = nullptr) {
   extern __shared__ __attribute__((aligned(16))) char smem[];   // ONE buffer: [A tile 16 KiB | B tile 16 KiB]
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
   const int wr = wave >> 1, wc = wave & 1;
@@ -878,11 +884,20 @@ gemm_mfma_k1s(const bf16_t* __restrict__ A, const bf16_t* __restrict__ B, void* 
   for (int i = 0; i < 4; ++i)
 #pragma unroll
     for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
-  for (int t = 0; t < nt; ++t) {
+  for (int tt = 0; tt < (X3 ? 3 : 1) * nt; ++tt) {
     // single LDS stage: load -> wait -> barrier -> 32 MFMAs -> barrier; the load latency of this block is covered by the
     // other three or four blocks resident on the CU (32 KiB of LDS each) instead of by software prefetch
-    stage_tile<A_KROW>(A, lda, m_blk, M, kbeg + (int64_t)t * GBK, smem, wave, lane);
-    stage_tile<B_KROW>(B, ldb, n_blk, N, kbeg + (int64_t)t * GBK, smem + TILE_BYTES, wave, lane);
+    int t = tt;
+    const bf16_t* Ap = A;
+    const bf16_t* Bp = B;
+    if constexpr (X3) {
+      const int seg = tt >= 2 * nt ? 2 : (tt >= nt ? 1 : 0);
+      t = tt - seg * nt;
+      if (seg == 1) Ap = A_lo;
+      if (seg == 2) Bp = B_lo;
+    }
+    stage_tile<A_KROW>(Ap, lda, m_blk, M, kbeg + (int64_t)t * GBK, smem, wave, lane);
+    stage_tile<B_KROW>(Bp, ldb, n_blk, N, kbeg + (int64_t)t * GBK, smem + TILE_BYTES, wave, lane);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
 #pragma unroll
@@ -916,6 +931,95 @@ gemm_mfma_k1s(const bf16_t* __restrict__ A, const bf16_t* __restrict__ B, void* 
           if (m < M && n < N) atomicAdd(C + m * ldc + n, acc[i][j][r]);
         }
       }
+  } else if constexpr (X3) {
+    // fp32 epilogue of the bf16x3 mode: same LDS staging, 16-byte fp32 accesses.  The side operand (fp32) of a pass is
+    // requested before the pass's staging barrier, so its latency overlaps the LDS round trip (the other resident blocks
+    // cover the rest).
+    const float* biasf = reinterpret_cast<const float*>(bias);
+    const float* addf = reinterpret_cast<const float*>(addend);
+    float* pref = reinterpret_cast<float*>(preact);
+    constexpr int EP_STRIDE = 128 * 4 + 16;
+    const int half = lane >> 5, l32 = lane & 31;
+    const int64_t ncol = n_blk + l32 * 4;
+    f32x4 bv = (f32x4){0.f, 0.f, 0.f, 0.f};
+    if (biasf) bv = *reinterpret_cast<const f32x4*>(biasf + ncol);
+    const float* side = act == MMRCA_ACT_MUL ? pref : addf;
+    float cs[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      f32x4 sd[4];
+      if (side) {
+#pragma unroll
+        for (int rr = 0; rr < 4; ++rr) {
+          const int lrow = wave * 8 + rr * 2 + half;
+          int64_t m = m_blk + (lrow >> 4) * 64 + i * 16 + (lrow & 15);
+          if (m > M - 1) m = M - 1;
+          sd[rr] = *reinterpret_cast<const f32x4*>(side + m * ldc + ncol);
+        }
+      }
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+        *reinterpret_cast<f32x4*>(smem + (wr * 16 + l16) * EP_STRIDE + (wc * 64 + j * 16 + 4 * g) * 4) = acc[i][j];
+      __syncthreads();
+#pragma unroll
+      for (int rr = 0; rr < 4; ++rr) {
+        const int lrow = wave * 8 + rr * 2 + half;
+        const int64_t m = m_blk + (lrow >> 4) * 64 + i * 16 + (lrow & 15);
+        if (m < M) {
+          const f32x4 c = *reinterpret_cast<const f32x4*>(smem + lrow * EP_STRIDE + l32 * 16);
+          float v[4] = {c[0] + bv[0], c[1] + bv[1], c[2] + bv[2], c[3] + bv[3]};
+          if (act == MMRCA_ACT_MUL) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) v[r] *= sd[rr][r];
+          } else if (act == MMRCA_ACT_GELU_SAVE_GRAD) {
+            float dg[4];
+            gelu_and_grad_fast4(v, dg);
+            *reinterpret_cast<f32x4*>(pref + m * ldc + ncol) = (f32x4){dg[0], dg[1], dg[2], dg[3]};
+          } else if (act == MMRCA_ACT_GELU_BWD) {
+            const f32x4 h4 = *reinterpret_cast<const f32x4*>(pref + m * ldc + ncol);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) v[r] *= gelu_grad_f(h4[r]);
+          } else if (pref) {
+            *reinterpret_cast<f32x4*>(pref + m * ldc + ncol) = (f32x4){v[0], v[1], v[2], v[3]};
+          }
+          if (act == MMRCA_ACT_GELU) gelu_fast4(v);
+          if (addf) {
+            if (act == MMRCA_ACT_MUL) {
+              const f32x4 a4 = *reinterpret_cast<const f32x4*>(addf + m * ldc + ncol);
+#pragma unroll
+              for (int r = 0; r < 4; ++r) v[r] += a4[r];
+            } else {
+#pragma unroll
+              for (int r = 0; r < 4; ++r) v[r] += sd[rr][r];
+            }
+          }
+          if (C_lo) {
+            bf16x4 hi, lo;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) { hi[r] = (bf16_t)v[r]; lo[r] = (bf16_t)(v[r] - (float)hi[r]); cs[r] += (float)hi[r] + (float)lo[r]; }
+            *reinterpret_cast<bf16x4*>(reinterpret_cast<bf16_t*>(Cv) + m * ldc + ncol) = hi;
+            *reinterpret_cast<bf16x4*>(C_lo + m * ldc + ncol) = lo;
+          } else {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) cs[r] += v[r];
+            *reinterpret_cast<f32x4*>(reinterpret_cast<float*>(Cv) + m * ldc + ncol) = (f32x4){v[0], v[1], v[2], v[3]};
+          }
+        }
+      }
+      __syncthreads();
+    }
+    if (colsum) {
+      float* red = reinterpret_cast<float*>(smem);
+#pragma unroll
+      for (int r = 0; r < 4; ++r) red[(wave * 2 + half) * 128 + l32 * 4 + r] = cs[r];
+      __syncthreads();
+      if (threadIdx.x < 128) {
+        float t = 0.f;
+#pragma unroll
+        for (int q = 0; q < 8; ++q) t += red[q * 128 + threadIdx.x];
+        atomicAdd(colsum + n_blk + threadIdx.x, t);
+      }
+    }
   } else {
     bf16_t* C = (bf16_t*)Cv;
     constexpr int EP_STRIDE = 128 * 4 + 16;
@@ -1016,13 +1120,46 @@ gemm_mfma_k1s(const bf16_t* __restrict__ A, const bf16_t* __restrict__ B, void* 
   }
 }
 
-template <bool AK, bool BK2, bool AT, int WPE>
+template <bool AK, bool BK2, bool AT, int WPE, bool X3 = false>
 static void launch_mfma1s(const void* A, const void* B, void* C, const void* bias, const void* addend, void* preact,
                           int64_t M, int64_t N, int64_t K, int64_t lda, int64_t ldb, int64_t ldc, int act, int tiles_m,
-                          int tiles_n, int ksplits, int64_t ksplit_len, float* colsum, hipStream_t st) {
-  hipLaunchKernelGGL((gemm_mfma_k1s<AK, BK2, AT, WPE>), dim3(tiles_m * tiles_n, ksplits), dim3(256), 2 * TILE_BYTES, st,
+                          int tiles_n, int ksplits, int64_t ksplit_len, float* colsum, hipStream_t st,
+                          const void* A_lo = nullptr, const void* B_lo = nullptr, void* C_lo = nullptr) {
+  hipLaunchKernelGGL((gemm_mfma_k1s<AK, BK2, AT, WPE, X3>), dim3(tiles_m * tiles_n, ksplits), dim3(256), 2 * TILE_BYTES, st,
                      (const bf16_t*)A, (const bf16_t*)B, C, (const bf16_t*)bias, (const bf16_t*)addend, (bf16_t*)preact,
-                     M, N, K, lda, ldb, ldc, act, tiles_m, tiles_n, ksplit_len, colsum);
+                     M, N, K, lda, ldb, ldc, act, tiles_m, tiles_n, ksplit_len, colsum, (const bf16_t*)A_lo, (const bf16_t*)B_lo,
+                     (bf16_t*)C_lo);
+}
+
+// entry used by gemm_x3.hip: the single-stage 128x128 kernel in its bf16x3 form (any epilogue; accumulate mode = fp32 atomics)
+int mmrca_gemm_k1s_x3(const void* A_hi, const void* A_lo, const void* B_hi, const void* B_lo, void* C, void* C_lo, const void* bias,
+                      const void* addend, void* preact, float* colsum, int64_t M, int64_t N, int64_t K, int64_t lda, int64_t ldb,
+                      int64_t ldc, int a_layout, int b_layout, int act, int accum, hipStream_t st) {
+  const int tiles_m = (int)((M + GBM - 1) / GBM), tiles_n = (int)(N / GBN);
+  int ksplits = 1;
+  int64_t ksplit_len = K;
+  if (accum) {
+    const int64_t ksteps = K / GBK;
+    int64_t want = 1024 / ((int64_t)tiles_m * tiles_n);
+    if (want < 1) want = 1;
+    if (want > ksteps / 4) want = ksteps / 4 > 0 ? ksteps / 4 : 1;
+    const int64_t steps_per = (ksteps + want - 1) / want;
+    ksplit_len = steps_per * GBK;
+    ksplits = (int)((ksteps + steps_per - 1) / steps_per);
+  }
+  const bool ak = a_layout == MMRCA_KROW, bk = b_layout == MMRCA_KROW, at = accum != 0;
+#define L1SX(AK_, BK_, AT_) launch_mfma1s<AK_, BK_, AT_, 4, true>(A_hi, B_hi, C, bias, addend, preact, M, N, K, lda, ldb, ldc, act, tiles_m, tiles_n, ksplits, ksplit_len, colsum, st, A_lo, B_lo, C_lo)
+  if (!ak && !bk && !at) L1SX(false, false, false);
+  else if (!ak && bk && !at) L1SX(false, true, false);
+  else if (ak && !bk && !at) L1SX(true, false, false);
+  else if (ak && bk && !at) L1SX(true, true, false);
+  else if (!ak && !bk && at) L1SX(false, false, true);
+  else if (!ak && bk && at) L1SX(false, true, true);
+  else if (ak && !bk && at) L1SX(true, false, true);
+  else L1SX(true, true, true);
+#undef L1SX
+  MMRCA_CHECK_LAUNCH("gemm_x3(k1s)");
+  return 0;
 }
 
 static bool aligned16(const void* p) { return (((uintptr_t)p) & 15) == 0; }

@@ -87,12 +87,16 @@ __device__ __forceinline__ const bf16_t* piece_src(const bf16_t* __restrict__ ba
 // MODE: the epilogue, fixed at compile time (a run-time `act` switch inside the unrolled epilogue made 18 k lines of code):
 //   MODE_SLAB, or the activation MMRCA_ACT_NONE / MMRCA_ACT_GELU_SAVE_GRAD / MMRCA_ACT_MUL (the ones the engine uses)
 #define MODE_SLAB (-1)
-template <bool A_KROW, bool B_KROW, int MODE>
+// X3 (bf16x3 mode, gemm_x3.hip): operands are (hi, lo) bf16 plane pairs and the contraction is the VIRTUAL one of length 3K --
+// K-tiles [0, K/64) pair (A_hi, B_hi), [K/64, 2K/64) pair (A_lo, B_hi), [2K/64, 3K/64) pair (A_hi, B_lo) -- which the split-K
+// ranges cut like any other contraction; the stream re-points its source pointers when it crosses a segment boundary.
+template <bool A_KROW, bool B_KROW, int MODE, bool X3 = false>
 __global__ void __launch_bounds__(512, 2)
 gemm_mfma256_k(const bf16_t* __restrict__ A, const bf16_t* __restrict__ B, bf16_t* __restrict__ C, const bf16_t* __restrict__ bias,
                const bf16_t* __restrict__ addend, bf16_t* __restrict__ preact, int64_t M, int64_t N, int64_t K,
                int64_t lda, int64_t ldb, int64_t ldc, int tiles_m, int tiles_n, int ksteps_base, int ksteps_rem,
-               float* __restrict__ slab, float* __restrict__ colsum, int splits) {
+               float* __restrict__ slab, float* __restrict__ colsum, int splits,
+               const bf16_t* __restrict__ A_lo = nullptr, const bf16_t* __restrict__ B_lo = nullptr) {
   constexpr bool SLAB = MODE == MODE_SLAB;
   extern __shared__ __attribute__((aligned(16))) char smem[];     // [2 stages][A0 A1 B0 B1]
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
@@ -110,8 +114,13 @@ gemm_mfma256_k(const bf16_t* __restrict__ A, const bf16_t* __restrict__ B, bf16_
   const int tm = wgid / tiles_n, tn = wgid - tm * tiles_n;
   const int64_t m_blk = (int64_t)tm * 256, n_blk = (int64_t)tn * 256;
   // split-K: range y covers ksteps_base (+1 for the first ksteps_rem ranges) K-tiles
-  const int64_t kbeg = SLAB ? 64 * ((int64_t)yb * ksteps_base + (yb < ksteps_rem ? yb : ksteps_rem)) : 0;
+  // X3: kbeg counts virtual K (segment = kbeg / K)
+  const int64_t kbeg_v = SLAB ? 64 * ((int64_t)yb * ksteps_base + (yb < ksteps_rem ? yb : ksteps_rem)) : 0;
   const int nt = SLAB ? ksteps_base + (yb < ksteps_rem ? 1 : 0) : (int)(K / 64);     // >= 2 (host-checked)
+  const int ksteps_seg = (int)(K / 64);
+  int issue_seg = X3 ? (int)(kbeg_v / K) : 0;
+  const int64_t kbeg = X3 ? kbeg_v - (int64_t)issue_seg * K : kbeg_v;
+  int issue_kt = (int)(kbeg / 64);               // K-tile (within its segment) the next closing issue slot completes
 
   f32x4 acc[2][2][4][2];
 #pragma unroll
@@ -127,13 +136,18 @@ gemm_mfma256_k(const bf16_t* __restrict__ A, const bf16_t* __restrict__ B, bf16_
   const int64_t a_step = A_KROW ? 64 * lda : 64, b_step = B_KROW ? 64 * ldb : 64;       // elements per K-tile
   const bf16_t* pa[2][2];     // [half][piece]
   const bf16_t* pb[2][2];
+  auto repoint = [&](int seg, int64_t k0) {
+    const bf16_t* Ab = (X3 && seg == 1) ? A_lo : A;
+    const bf16_t* Bb = (X3 && seg == 2) ? B_lo : B;
 #pragma unroll
-  for (int h = 0; h < 2; ++h)
+    for (int h = 0; h < 2; ++h)
 #pragma unroll
-    for (int ii = 0; ii < 2; ++ii) {
-      pa[h][ii] = piece_src<A_KROW>(A, lda, m_blk + 128 * h, M, wave * 2 + ii, lane) + (A_KROW ? kbeg * lda : kbeg);
-      pb[h][ii] = piece_src<B_KROW>(B, ldb, n_blk + 128 * h, N, wave * 2 + ii, lane) + (B_KROW ? kbeg * ldb : kbeg);
-    }
+      for (int ii = 0; ii < 2; ++ii) {
+        pa[h][ii] = piece_src<A_KROW>(Ab, lda, m_blk + 128 * h, M, wave * 2 + ii, lane) + (A_KROW ? k0 * lda : k0);
+        pb[h][ii] = piece_src<B_KROW>(Bb, ldb, n_blk + 128 * h, N, wave * 2 + ii, lane) + (B_KROW ? k0 * ldb : k0);
+      }
+  };
+  repoint(issue_seg, kbeg);
   char* const my_piece = smem + wave * 2048;              // this wave's first piece inside a half-tile
   int issue_stage = 0;                                     // LDS stage (byte offset) of the next issue group's K-tile
   // issue order within a K-tile: A0, B0, B1, A1 (order of first use); `which` is a compile-time constant at every call
@@ -142,7 +156,8 @@ gemm_mfma256_k(const bf16_t* __restrict__ A, const bf16_t* __restrict__ B, bf16_
     if ((which) == 0) { stage_half(pa[0][0], pa[0][1], my_piece + issue_stage + SLOT_A0 * HT_BYTES); pa[0][0] += a_step; pa[0][1] += a_step; } \
     else if ((which) == 1) { stage_half(pb[0][0], pb[0][1], my_piece + issue_stage + SLOT_B0 * HT_BYTES); pb[0][0] += b_step; pb[0][1] += b_step; } \
     else if ((which) == 2) { stage_half(pb[1][0], pb[1][1], my_piece + issue_stage + SLOT_B1 * HT_BYTES); pb[1][0] += b_step; pb[1][1] += b_step; } \
-    else { stage_half(pa[1][0], pa[1][1], my_piece + issue_stage + SLOT_A1 * HT_BYTES); pa[1][0] += a_step; pa[1][1] += a_step; issue_stage ^= STAGE_BYTES; } \
+    else { stage_half(pa[1][0], pa[1][1], my_piece + issue_stage + SLOT_A1 * HT_BYTES); pa[1][0] += a_step; pa[1][1] += a_step; issue_stage ^= STAGE_BYTES; \
+           if constexpr (X3) { if (++issue_kt == ksteps_seg) { issue_kt = 0; if (++issue_seg < 3) repoint(issue_seg, 0); } } } \
   } while (0)
 
   // ---- fragment read addresses (LDS byte addresses of stage 0; the stage is toggled by XOR per K-tile)
@@ -278,11 +293,16 @@ gemm_mfma256_k(const bf16_t* __restrict__ A, const bf16_t* __restrict__ B, bf16_
 // Epilogue variants are compile-time (run-time flags cost ~20 branches and twice the code per pass): ACT is
 // MMRCA_ACT_NONE (with or without a residual addend, ADD), MMRCA_ACT_GELU, MMRCA_ACT_GELU_SAVE_GRAD (stores gelu' to `preact`) or
 // MMRCA_ACT_MUL (multiplies by `preact`; column sums of the stored result to `colsum` when given).
-template <bool A_KROW, bool B_KROW, int ACT, bool ADD>
+// X3 (bf16x3 mode, gemm_x3.hip): A / B are the hi planes, A_lo / B_lo the lo planes of fp32 operands; every output tile runs
+// the K loop three times -- (A_hi, B_hi), (A_lo, B_hi), (A_hi, B_lo) -- the stream switching planes where it used to switch
+// tiles; bias / preact / C are fp32, or, with PLANES, C is written as two bf16 planes (C = hi, C_lo = lo).  No side operands.
+template <bool A_KROW, bool B_KROW, int ACT, bool ADD, bool X3 = false, bool PLANES = false>
 __global__ void __launch_bounds__(512, 2)
 gemm_p256_k(const bf16_t* __restrict__ A, const bf16_t* __restrict__ B, bf16_t* __restrict__ C, const bf16_t* __restrict__ bias,
             const bf16_t* __restrict__ addend, bf16_t* __restrict__ preact, int64_t M, int64_t N, int64_t K,
-            int64_t lda, int64_t ldb, int64_t ldc, int tiles_m, int tiles_n, float* __restrict__ colsum, int skew_ticks, int dbg) {
+            int64_t lda, int64_t ldb, int64_t ldc, int tiles_m, int tiles_n, float* __restrict__ colsum, int skew_ticks, int dbg,
+            const bf16_t* __restrict__ A_lo = nullptr, const bf16_t* __restrict__ B_lo = nullptr, bf16_t* __restrict__ C_lo = nullptr) {
+  static_assert(!X3 || (!ADD && ACT != MMRCA_ACT_MUL), "the bf16x3 form has no side-operand epilogue");
   constexpr int act = ACT;
   extern __shared__ __attribute__((aligned(16))) char smem[];     // [2 stages][A0 A1 B0 B1] + 32 KiB epilogue staging
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
@@ -330,11 +350,14 @@ gemm_p256_k(const bf16_t* __restrict__ A, const bf16_t* __restrict__ B, bf16_t* 
   };
   stream_to(slot);
   int stream_kt = 0, stream_tile = 0;          // K-tiles already issued of the stream's current tile; its index in my list
+  [[maybe_unused]] int stream_seg = 0;         // X3: which plane pair the stream is in
+  const bf16_t* Acur = A;
+  const bf16_t* Bcur = B;
   char* const my_piece = smem + wave * 2048;
   int issue_stage = 0;
   // the issue slot of half-tile A1 closes a K-tile of the stream: after the last K-tile of a tile, move on to the next tile
-#define SRC_A(h, ii) reinterpret_cast<const bf16_t*>(reinterpret_cast<const char*>(A) + (h) * a_half + oa[ii])
-#define SRC_B(h, ii) reinterpret_cast<const bf16_t*>(reinterpret_cast<const char*>(B) + (h) * b_half + ob[ii])
+#define SRC_A(h, ii) reinterpret_cast<const bf16_t*>(reinterpret_cast<const char*>(Acur) + (h) * a_half + oa[ii])
+#define SRC_B(h, ii) reinterpret_cast<const bf16_t*>(reinterpret_cast<const char*>(Bcur) + (h) * b_half + ob[ii])
 #define ISSUE_P(which)                                                                                          \
   do {                                                                                                          \
     if ((which) == 0) { stage_half(SRC_A(0, 0), SRC_A(0, 1), my_piece + issue_stage + SLOT_A0 * HT_BYTES); }    \
@@ -343,7 +366,14 @@ gemm_p256_k(const bf16_t* __restrict__ A, const bf16_t* __restrict__ B, bf16_t* 
     else {                                                                                                      \
       stage_half(SRC_A(1, 0), SRC_A(1, 1), my_piece + issue_stage + SLOT_A1 * HT_BYTES); oa[0] += a_step; oa[1] += a_step;  \
       issue_stage ^= STAGE_BYTES;                                                                               \
-      if (++stream_kt == nt) { stream_kt = 0; ++stream_tile; if (stream_tile < my_tiles) stream_to(slot + stream_tile * G); } \
+      if (++stream_kt == nt) {                                                                                  \
+        stream_kt = 0;                                                                                          \
+        if constexpr (X3) {                                                                                     \
+          if (++stream_seg == 3) { stream_seg = 0; ++stream_tile; }                                             \
+          Acur = stream_seg == 1 ? A_lo : A; Bcur = stream_seg == 2 ? B_lo : B;                                 \
+        } else ++stream_tile;                                                                                   \
+        if (stream_tile < my_tiles) stream_to(slot + stream_tile * G);                                          \
+      }                                                                                                         \
     }                                                                                                           \
   } while (0)
 
@@ -399,10 +429,11 @@ gemm_p256_k(const bf16_t* __restrict__ A, const bf16_t* __restrict__ B, bf16_t* 
     frag_bases();
     if (wr) BARRIER();                    // group 1 runs one barrier behind
     __builtin_amdgcn_sched_barrier(0);
+    const int ntv = X3 ? 3 * nt : nt;     // K-tiles per output tile
     if (ti + 1 < my_tiles) {              // the stream runs on into the next tile: every K-tile is a steady-state one
-      for (int t = 0; t < nt; ++t) K_TILE_G(ISSUE_P, 1, 1, 1, 1, 8, 8, 10, 8);
+      for (int t = 0; t < ntv; ++t) K_TILE_G(ISSUE_P, 1, 1, 1, 1, 8, 8, 10, 8);
     } else {
-      for (int t = 0; t < nt - 2; ++t) K_TILE_G(ISSUE_P, 1, 1, 1, 1, 8, 8, 10, 8);
+      for (int t = 0; t < ntv - 2; ++t) K_TILE_G(ISSUE_P, 1, 1, 1, 1, 8, 8, 10, 8);
       K_TILE_G(ISSUE_P, 1, 1, 0, 0, 8, 8, 8, 4);
       K_TILE_G(ISSUE_P, 0, 0, 0, 0, 2, 0, 0, 0);
     }
@@ -423,9 +454,15 @@ gemm_p256_k(const bf16_t* __restrict__ A, const bf16_t* __restrict__ B, bf16_t* 
     float bv[4] = {0.f, 0.f, 0.f, 0.f};
     if constexpr (act != MMRCA_ACT_MUL) {       // (the input-gradient form has no bias; the dispatcher checks)
       if (bias) {
-        bf16x4 b4 = *reinterpret_cast<const bf16x4*>(bias + ncol);
+        if constexpr (X3) {
+          const f32x4 b4 = *reinterpret_cast<const f32x4*>(reinterpret_cast<const float*>(bias) + ncol);
 #pragma unroll
-        for (int r = 0; r < 4; ++r) bv[r] = (float)b4[r];
+          for (int r = 0; r < 4; ++r) bv[r] = b4[r];
+        } else {
+          bf16x4 b4 = *reinterpret_cast<const bf16x4*>(bias + ncol);
+#pragma unroll
+          for (int r = 0; r < 4; ++r) bv[r] = (float)b4[r];
+        }
       }
     }
     float csum[4] = {0.f, 0.f, 0.f, 0.f};
@@ -490,6 +527,7 @@ gemm_p256_k(const bf16_t* __restrict__ A, const bf16_t* __restrict__ B, bf16_t* 
               for (int r = 0; r < 4; ++r) v[r] += bv[r];
             }
             bf16x4 po;
+            [[maybe_unused]] float pf[4] = {0.f, 0.f, 0.f, 0.f};
             constexpr bool store_pre = act == MMRCA_ACT_GELU_SAVE_GRAD;
             if constexpr (act == MMRCA_ACT_MUL) {
   #pragma unroll
@@ -498,7 +536,7 @@ gemm_p256_k(const bf16_t* __restrict__ A, const bf16_t* __restrict__ B, bf16_t* 
               float gr[4];
               gelu_and_grad_fast4(v, gr);
   #pragma unroll
-              for (int r = 0; r < 4; ++r) po[r] = (bf16_t)gr[r];
+              for (int r = 0; r < 4; ++r) { po[r] = (bf16_t)gr[r]; pf[r] = gr[r]; }
             } else if constexpr (act == MMRCA_ACT_GELU) {      // forward-only callers (the frozen BLIP-2 towers)
               gelu_fast4(v);
             }
@@ -516,8 +554,23 @@ gemm_p256_k(const bf16_t* __restrict__ A, const bf16_t* __restrict__ B, bf16_t* 
                 for (int r = 0; r < 4; ++r) csum[r] += (float)o[r];
               }
               const int64_t ub = ((urow0 + 4 * it) * ldc + n_blk + 64 * wc) * 2;
+              if constexpr (X3) {
+                // fp32 outputs: 16 bytes per lane (a wave instruction writes four whole 256-byte row segments); the byte
+                // offsets above are those of 2-byte elements
+                if (store_pre) *reinterpret_cast<f32x4*>(reinterpret_cast<char*>(preact) + 2 * (ub + lane_off)) = (f32x4){pf[0], pf[1], pf[2], pf[3]};
+                if constexpr (PLANES) {
+                  bf16x4 lo;
+#pragma unroll
+                  for (int r = 0; r < 4; ++r) lo[r] = (bf16_t)(v[r] - (float)o[r]);
+                  *reinterpret_cast<bf16x4*>(reinterpret_cast<char*>(C) + ub + lane_off) = o;
+                  *reinterpret_cast<bf16x4*>(reinterpret_cast<char*>(C_lo) + ub + lane_off) = lo;
+                } else {
+                  *reinterpret_cast<f32x4*>(reinterpret_cast<char*>(C) + 2 * (ub + lane_off)) = (f32x4){v[0], v[1], v[2], v[3]};
+                }
+              } else {
               if (store_pre) *reinterpret_cast<bf16x4*>(reinterpret_cast<char*>(preact) + ub + lane_off) = po;
               *reinterpret_cast<bf16x4*>(reinterpret_cast<char*>(C) + ub + lane_off) = o;
+              }
             }
           }
         }
@@ -539,9 +592,10 @@ gemm_p256_k(const bf16_t* __restrict__ A, const bf16_t* __restrict__ B, bf16_t* 
 extern int g_mmrca_dbg;
 static int g_num_cus = 0;
 static int g_p256_skew = -1;      // x 10 ns between the four start groups (MMRCA_P256_SKEW; see gemm_p256_k)
-template <bool AK, bool BK2, int ACT, bool ADD>
+template <bool AK, bool BK2, int ACT, bool ADD, bool X3 = false, bool PLANES = false>
 static void launch_p256(const void* A, const void* B, void* C, const void* bias, const void* addend, void* preact, int64_t M,
-                        int64_t N, int64_t K, int64_t lda, int64_t ldb, int64_t ldc, float* colsum, hipStream_t st) {
+                        int64_t N, int64_t K, int64_t lda, int64_t ldb, int64_t ldc, float* colsum, hipStream_t st,
+                        const void* A_lo = nullptr, const void* B_lo = nullptr, void* C_lo = nullptr) {
   const int tiles_m = (int)((M + 255) / 256), tiles_n = (int)(N / 256);
   if (g_num_cus == 0) {
     int dev = 0, n = 0;
@@ -556,10 +610,11 @@ static void launch_p256(const void* A, const void* B, void* C, const void* bias,
   int grid = tiles_m * tiles_n < g_num_cus ? ((tiles_m * tiles_n) & ~7) : g_num_cus;
   if (grid < 8) grid = 8;
   constexpr int LDS_P = 2 * STAGE_BYTES + 32768;       // all 160 KiB of the CU
-  (void)hipFuncSetAttribute((const void*)gemm_p256_k<AK, BK2, ACT, ADD>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_P);
-  hipLaunchKernelGGL((gemm_p256_k<AK, BK2, ACT, ADD>), dim3(grid), dim3(512), LDS_P, st, (const bf16_t*)A, (const bf16_t*)B,
+  (void)hipFuncSetAttribute((const void*)gemm_p256_k<AK, BK2, ACT, ADD, X3, PLANES>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_P);
+  hipLaunchKernelGGL((gemm_p256_k<AK, BK2, ACT, ADD, X3, PLANES>), dim3(grid), dim3(512), LDS_P, st, (const bf16_t*)A, (const bf16_t*)B,
                      (bf16_t*)C, (const bf16_t*)bias, (const bf16_t*)addend, (bf16_t*)preact, M, N, K, lda, ldb, ldc, tiles_m,
-                     tiles_n, colsum, tiles_m * tiles_n >= 2 * g_num_cus ? g_p256_skew : 0, g_mmrca_dbg);
+                     tiles_n, colsum, tiles_m * tiles_n >= 2 * g_num_cus ? g_p256_skew : 0, g_mmrca_dbg, (const bf16_t*)A_lo,
+                     (const bf16_t*)B_lo, (bf16_t*)C_lo);
 }
 
 int g_mmrca_dbg = 0;
@@ -602,6 +657,31 @@ int mmrca_gemm256(const void* A, const void* B, void* C, const void* bias, const
 }
 
 
+// bf16x3 forms (called by gemm_x3.hip): persistent forward / input-gradient kernel with fp32 or two-plane output
+bool mmrca_gemm256_x3_ok(int64_t M, int64_t N, int64_t K, int a_layout, int act, bool has_addend, bool has_colsum) {
+  if (!(N % 256 == 0 && K % 64 == 0 && K >= 128 && a_layout == MMRCA_ROWK) || has_addend || has_colsum) return false;
+  return act == MMRCA_ACT_NONE || act == MMRCA_ACT_GELU_SAVE_GRAD;
+}
+
+int mmrca_gemm256_x3(const void* A_hi, const void* A_lo, const void* B_hi, const void* B_lo, void* C, void* C_lo, const void* bias,
+                     void* preact, int64_t M, int64_t N, int64_t K, int64_t lda, int64_t ldb, int64_t ldc, int b_layout, int act,
+                     hipStream_t st) {
+  const bool bk = b_layout == MMRCA_KROW;
+  MMRCA_REQUIRE(M * lda * 2 < (1ll << 32) && (bk ? K * ldb : N * ldb) * 2 < (1ll << 32) && M * ldc * 4 < (1ll << 32),
+                "gemm_x3(mfma256): operands must be smaller than 4 GiB");
+#define L256X(BK_, ACT_, PL_) launch_p256<false, BK_, ACT_, false, true, PL_>(A_hi, B_hi, C, bias, nullptr, preact, M, N, K, lda, ldb, ldc, nullptr, st, A_lo, B_lo, C_lo)
+  if (act == MMRCA_ACT_GELU_SAVE_GRAD) {
+    if (C_lo) { if (bk) L256X(true, MMRCA_ACT_GELU_SAVE_GRAD, true); else L256X(false, MMRCA_ACT_GELU_SAVE_GRAD, true); }
+    else { if (bk) L256X(true, MMRCA_ACT_GELU_SAVE_GRAD, false); else L256X(false, MMRCA_ACT_GELU_SAVE_GRAD, false); }
+  } else {
+    if (C_lo) { if (bk) L256X(true, MMRCA_ACT_NONE, true); else L256X(false, MMRCA_ACT_NONE, true); }
+    else { if (bk) L256X(true, MMRCA_ACT_NONE, false); else L256X(false, MMRCA_ACT_NONE, false); }
+  }
+#undef L256X
+  MMRCA_CHECK_LAUNCH("gemm_x3(mfma256)");
+  return 0;
+}
+
 // ---------------------------------------------------------------------------------------------------------------------
 // Split-K weight gradient on the 256x256 tile: C[M,N] (fp32) += A^T-contracted product over K, partial tiles through a
 // caller-owned workspace.  One block per CU: (M/256)*(N/256) tiles x `splits` K ranges <= 256 blocks.
@@ -634,10 +714,11 @@ extern "C" int64_t mmrca_gemm_splitk_workspace_bytes(int64_t M, int64_t N) {
   return (256 / tiles) * tiles * 65536 * 4;
 }
 
-extern "C" int mmrca_gemm_splitk(const void* A, const void* B, float* C, void* workspace, int64_t workspace_bytes, int64_t M,
-                                 int64_t N, int64_t K, int64_t lda, int64_t ldb, int64_t ldc, int a_layout, int b_layout,
-                                 void* stream) {
-  MMRCA_REQUIRE(A && B && C && workspace, "gemm_splitk: null operand");
+static int gemm_splitk_impl(const void* A, const void* A_lo, const void* B, const void* B_lo, float* C, void* workspace,
+                           int64_t workspace_bytes, int64_t M, int64_t N, int64_t K, int64_t lda, int64_t ldb, int64_t ldc,
+                           int a_layout, int b_layout, void* stream) {
+  const bool x3 = A_lo != nullptr;
+  MMRCA_REQUIRE(A && B && C && workspace && (!x3 || B_lo), "gemm_splitk: null operand");
   MMRCA_REQUIRE(M > 0 && N > 0 && M % 256 == 0 && N % 256 == 0 && K >= 128 && K % 64 == 0,
                 "gemm_splitk: needs M %% 256 == 0, N %% 256 == 0, K %% 64 == 0, K >= 128 (got M=%lld N=%lld K=%lld)", (long long)M, (long long)N, (long long)K);
   MMRCA_REQUIRE(lda % 8 == 0 && ldb % 8 == 0 && ldc % 4 == 0 && (((uintptr_t)A | (uintptr_t)B | (uintptr_t)C | (uintptr_t)workspace) & 15) == 0,
@@ -645,7 +726,7 @@ extern "C" int mmrca_gemm_splitk(const void* A, const void* B, float* C, void* w
   MMRCA_REQUIRE(lda >= (a_layout == MMRCA_ROWK ? K : M) && ldb >= (b_layout == MMRCA_ROWK ? K : N) && ldc >= N, "gemm_splitk: leading dimension too small");
   const int tiles_m = (int)(M / 256), tiles_n = (int)(N / 256), tiles = tiles_m * tiles_n;
   MMRCA_REQUIRE(tiles <= 256, "gemm_splitk: more than 256 output tiles (use mmrca_gemm)");
-  const int64_t ksteps = K / 64;
+  const int64_t ksteps = (x3 ? 3 : 1) * (K / 64);   // bf16x3: the virtual contraction [A_hi|A_lo|A_hi] . [B_hi|B_hi|B_lo]
   int64_t splits64 = 256 / tiles;                   // one workgroup per CU
   if (splits64 > ksteps / 2) splits64 = ksteps / 2; // the kernel's pipeline needs two K-tiles per range
   const int splits = (int)splits64;
@@ -654,20 +735,41 @@ extern "C" int mmrca_gemm_splitk(const void* A, const void* B, float* C, void* w
                 (long long)workspace_bytes, (long long)splits * tiles * 65536 * 4);
   hipStream_t st = (hipStream_t)stream;
   const bool ak = a_layout == MMRCA_KROW, bk = b_layout == MMRCA_KROW;
-#define LSLAB(AK_, BK_)                                                                                                          \
+#define LSLAB(AK_, BK_, X3_)                                                                                                     \
   do {                                                                                                                           \
-    (void)hipFuncSetAttribute((const void*)gemm_mfma256_k<AK_, BK_, MODE_SLAB>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS256_BYTES); \
-    hipLaunchKernelGGL((gemm_mfma256_k<AK_, BK_, MODE_SLAB>), dim3((tiles * splits + 7) / 8 * 8), dim3(512), LDS256_BYTES, st, (const bf16_t*)A,      \
+    (void)hipFuncSetAttribute((const void*)gemm_mfma256_k<AK_, BK_, MODE_SLAB, X3_>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS256_BYTES); \
+    hipLaunchKernelGGL((gemm_mfma256_k<AK_, BK_, MODE_SLAB, X3_>), dim3((tiles * splits + 7) / 8 * 8), dim3(512), LDS256_BYTES, st, (const bf16_t*)A,      \
                        (const bf16_t*)B, (bf16_t*)nullptr, (const bf16_t*)nullptr, (const bf16_t*)nullptr, (bf16_t*)nullptr, M, N, K, \
-                       lda, ldb, ldc, tiles_m, tiles_n, ksteps_base, ksteps_rem, (float*)workspace, (float*)nullptr, splits);   \
+                       lda, ldb, ldc, tiles_m, tiles_n, ksteps_base, ksteps_rem, (float*)workspace, (float*)nullptr, splits,    \
+                       (const bf16_t*)A_lo, (const bf16_t*)B_lo);                                                               \
   } while (0)
-  if (!ak && !bk) LSLAB(false, false);
-  else if (!ak && bk) LSLAB(false, true);
-  else if (ak && !bk) LSLAB(true, false);
-  else LSLAB(true, true);
+  if (x3) {
+    if (!ak && !bk) LSLAB(false, false, true);
+    else if (!ak && bk) LSLAB(false, true, true);
+    else if (ak && !bk) LSLAB(true, false, true);
+    else LSLAB(true, true, true);
+  } else {
+    if (!ak && !bk) LSLAB(false, false, false);
+    else if (!ak && bk) LSLAB(false, true, false);
+    else if (ak && !bk) LSLAB(true, false, false);
+    else LSLAB(true, true, false);
+  }
 #undef LSLAB
   MMRCA_CHECK_LAUNCH("gemm_splitk(mfma256)");
   hipLaunchKernelGGL(splitk_reduce256_k, dim3(tiles * 64), dim3(256), 0, st, (const float*)workspace, C, ldc, tiles, tiles_n, splits);
   MMRCA_CHECK_LAUNCH("gemm_splitk(reduce)");
   return 0;
+}
+
+extern "C" int mmrca_gemm_splitk(const void* A, const void* B, float* C, void* workspace, int64_t workspace_bytes, int64_t M,
+                                 int64_t N, int64_t K, int64_t lda, int64_t ldb, int64_t ldc, int a_layout, int b_layout,
+                                 void* stream) {
+  return gemm_splitk_impl(A, nullptr, B, nullptr, C, workspace, workspace_bytes, M, N, K, lda, ldb, ldc, a_layout, b_layout, stream);
+}
+
+extern "C" int mmrca_gemm_splitk_x3(const void* A_hi, const void* A_lo, const void* B_hi, const void* B_lo, float* C, void* workspace,
+                                    int64_t workspace_bytes, int64_t M, int64_t N, int64_t K, int64_t lda, int64_t ldb, int64_t ldc,
+                                    int a_layout, int b_layout, void* stream) {
+  MMRCA_REQUIRE(A_lo && B_lo, "gemm_x3(splitk): null lo plane");
+  return gemm_splitk_impl(A_hi, A_lo, B_hi, B_lo, C, workspace, workspace_bytes, M, N, K, lda, ldb, ldc, a_layout, b_layout, stream);
 }

@@ -946,19 +946,21 @@ extern "C" int mmrca_xent_fwd_bwd(const float* logits, const int32_t* labels, co
 // optimizers on the flat arenas (+ refresh of the bf16 working copy)
 // --------------------------------------------------------------------------------------------------------
 __global__ void __launch_bounds__(256)
-sgd_k(float* __restrict__ p, const float* __restrict__ g, bf16_t* __restrict__ lp, int64_t n4, float lr, float wd, float gs) {
+sgd_k(float* __restrict__ p, const float* __restrict__ g, bf16_t* __restrict__ lp, int64_t n4, float lr, float wd, float gs,
+      bf16_t* __restrict__ lp_lo) {
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (int64_t)gridDim.x * blockDim.x) {
     Vec4<float> pv = Vec4<float>::load(p + i * 4), gv = Vec4<float>::load(g + i * 4);
 #pragma unroll
     for (int j = 0; j < 4; ++j) pv.v[j] -= lr * (gv.v[j] * gs + wd * pv.v[j]);
     pv.store(p + i * 4);
     if (lp) { Vec4<bf16_t> o; for (int j = 0; j < 4; ++j) o.v[j] = pv.v[j]; o.store(lp + i * 4); }
+    if (lp_lo) { Vec4<bf16_t> o; for (int j = 0; j < 4; ++j) o.v[j] = pv.v[j] - (float)(bf16_t)pv.v[j]; o.store(lp_lo + i * 4); }   // bf16x3 mode: p = hi + lo
   }
 }
 
 __global__ void __launch_bounds__(256)
 adamw_k(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m, float* __restrict__ v, bf16_t* __restrict__ lp,
-        int64_t n4, float lr, float b1, float b2, float eps, float wd, float bc1, float bc2, float gs) {
+        int64_t n4, float lr, float b1, float b2, float eps, float wd, float bc1, float bc2, float gs, bf16_t* __restrict__ lp_lo) {
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (int64_t)gridDim.x * blockDim.x) {
     Vec4<float> pv = Vec4<float>::load(p + i * 4), gv = Vec4<float>::load(g + i * 4), mv = Vec4<float>::load(m + i * 4), vv = Vec4<float>::load(v + i * 4);
 #pragma unroll
@@ -972,47 +974,74 @@ adamw_k(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ 
     }
     pv.store(p + i * 4); mv.store(m + i * 4); vv.store(v + i * 4);
     if (lp) { Vec4<bf16_t> o; for (int j = 0; j < 4; ++j) o.v[j] = pv.v[j]; o.store(lp + i * 4); }
+    if (lp_lo) { Vec4<bf16_t> o; for (int j = 0; j < 4; ++j) o.v[j] = pv.v[j] - (float)(bf16_t)pv.v[j]; o.store(lp_lo + i * 4); }
   }
 }
 
-__global__ void __launch_bounds__(256) cast_k(const float* __restrict__ s, bf16_t* __restrict__ d, int64_t n4) {
+__global__ void __launch_bounds__(256) cast_k(const float* __restrict__ s, bf16_t* __restrict__ d, int64_t n4, bf16_t* __restrict__ d_lo) {
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (int64_t)gridDim.x * blockDim.x) {
     Vec4<float> a = Vec4<float>::load(s + i * 4);
     Vec4<bf16_t> o;
 #pragma unroll
     for (int j = 0; j < 4; ++j) o.v[j] = a.v[j];
     o.store(d + i * 4);
+    if (d_lo) {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) o.v[j] = a.v[j] - (float)(bf16_t)a.v[j];
+      o.store(d_lo + i * 4);
+    }
   }
 }
 
 static inline int ew_grid(int64_t n4) { int64_t g = (n4 + 255) / 256; return (int)(g < 8192 ? g : 8192); }
 
-extern "C" int mmrca_sgd_step(float* p, const float* g, void* lp, int64_t n, float lr, float wd, float grad_scale, void* stream) {
+extern "C" int mmrca_sgd_step_x3(float* p, const float* g, void* lp_hi, void* lp_lo, int64_t n, float lr, float wd, float grad_scale,
+                                 void* stream) {
   MMRCA_REQUIRE(p && g, "sgd_step: null pointer");
   MMRCA_REQUIRE(n % 4 == 0, "sgd_step: arena length must be a multiple of 4");
+  MMRCA_REQUIRE(!lp_lo || lp_hi, "sgd_step: a lo plane needs its hi plane");
   if (n <= 0) return 0;
-  hipLaunchKernelGGL(sgd_k, dim3(ew_grid(n / 4)), dim3(256), 0, (hipStream_t)stream, p, g, (bf16_t*)lp, n / 4, lr, wd, grad_scale);
+  hipLaunchKernelGGL(sgd_k, dim3(ew_grid(n / 4)), dim3(256), 0, (hipStream_t)stream, p, g, (bf16_t*)lp_hi, n / 4, lr, wd, grad_scale,
+                     (bf16_t*)lp_lo);
   MMRCA_CHECK_LAUNCH("sgd_step");
   return 0;
 }
+extern "C" int mmrca_sgd_step(float* p, const float* g, void* lp, int64_t n, float lr, float wd, float grad_scale, void* stream) {
+  return mmrca_sgd_step_x3(p, g, lp, nullptr, n, lr, wd, grad_scale, stream);
+}
 
-extern "C" int mmrca_adamw_step(float* p, const float* g, float* m, float* v, void* lp, int64_t n, float lr, float beta1,
-                                float beta2, float eps, float wd, int step, float grad_scale, void* stream) {
+extern "C" int mmrca_adamw_step_x3(float* p, const float* g, float* m, float* v, void* lp_hi, void* lp_lo, int64_t n, float lr,
+                                   float beta1, float beta2, float eps, float wd, int step, float grad_scale, void* stream) {
   MMRCA_REQUIRE(p && g && m && v, "adamw_step: null pointer");
   MMRCA_REQUIRE(n % 4 == 0 && step >= 1, "adamw_step: bad arguments");
+  MMRCA_REQUIRE(!lp_lo || lp_hi, "adamw_step: a lo plane needs its hi plane");
   if (n <= 0) return 0;
   const float bc1 = 1.f - powf(beta1, (float)step), bc2 = 1.f - powf(beta2, (float)step);
-  hipLaunchKernelGGL(adamw_k, dim3(ew_grid(n / 4)), dim3(256), 0, (hipStream_t)stream, p, g, m, v, (bf16_t*)lp, n / 4, lr, beta1,
-                     beta2, eps, wd, bc1, bc2, grad_scale);
+  hipLaunchKernelGGL(adamw_k, dim3(ew_grid(n / 4)), dim3(256), 0, (hipStream_t)stream, p, g, m, v, (bf16_t*)lp_hi, n / 4, lr, beta1,
+                     beta2, eps, wd, bc1, bc2, grad_scale, (bf16_t*)lp_lo);
   MMRCA_CHECK_LAUNCH("adamw_step");
   return 0;
+}
+extern "C" int mmrca_adamw_step(float* p, const float* g, float* m, float* v, void* lp, int64_t n, float lr, float beta1,
+                                float beta2, float eps, float wd, int step, float grad_scale, void* stream) {
+  return mmrca_adamw_step_x3(p, g, m, v, lp, nullptr, n, lr, beta1, beta2, eps, wd, step, grad_scale, stream);
 }
 
 extern "C" int mmrca_cast_f32_to_bf16(const float* src, void* dst, int64_t n, void* stream) {
   MMRCA_REQUIRE(src && dst, "cast: null pointer");
   MMRCA_REQUIRE(n % 4 == 0, "cast: n must be a multiple of 4");
   if (n <= 0) return 0;
-  hipLaunchKernelGGL(cast_k, dim3(ew_grid(n / 4)), dim3(256), 0, (hipStream_t)stream, src, (bf16_t*)dst, n / 4);
+  hipLaunchKernelGGL(cast_k, dim3(ew_grid(n / 4)), dim3(256), 0, (hipStream_t)stream, src, (bf16_t*)dst, n / 4, (bf16_t*)nullptr);
   MMRCA_CHECK_LAUNCH("cast");
+  return 0;
+}
+
+// bf16x3 mode: x = hi + lo with hi = bf16(x) (round to nearest even), lo = bf16(x - hi): 16 significant bits in two bf16 planes
+extern "C" int mmrca_split_f32(const float* src, void* hi, void* lo, int64_t n, void* stream) {
+  MMRCA_REQUIRE(src && hi && lo, "split_f32: null pointer");
+  MMRCA_REQUIRE(n % 4 == 0, "split_f32: n must be a multiple of 4");
+  if (n <= 0) return 0;
+  hipLaunchKernelGGL(cast_k, dim3(ew_grid(n / 4)), dim3(256), 0, (hipStream_t)stream, src, (bf16_t*)hi, n / 4, (bf16_t*)lo);
+  MMRCA_CHECK_LAUNCH("split_f32");
   return 0;
 }

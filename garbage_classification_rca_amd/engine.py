@@ -63,7 +63,7 @@ def _round_up(x: int, m: int) -> int:
 
 
 class Arena:
-    def __init__(self, entries: List[Tuple[str, Tuple[int, ...]]], device, with_lp: bool):
+    def __init__(self, entries: List[Tuple[str, Tuple[int, ...]]], device, with_lp: bool, with_lo: bool = False):
         self.offsets: Dict[str, Tuple[int, Tuple[int, ...], int]] = {}
         off = 0
         for k, shp in entries:
@@ -77,6 +77,8 @@ class Arena:
         self.p = torch.zeros(self.total, dtype=torch.float32, device=device)
         self.g = torch.zeros(self.total, dtype=torch.float32, device=device)
         self.lp = torch.zeros(self.total, dtype=torch.bfloat16, device=device) if with_lp else None
+        # bf16x3 mode: p = lp + lp_lo (hi / lo bf16 planes of the fp32 masters, see csrc/gemm_x3.hip)
+        self.lp_lo = torch.zeros(self.total, dtype=torch.bfloat16, device=device) if with_lo else None
         self.lp_valid = False
 
     def view(self, key, which="p"):
@@ -140,9 +142,18 @@ class MMRCAEngine:
     """Owns parameters, gradients and activations of one MM-RCA replica on one GPU."""
 
     def __init__(self, text_model: str, image_model: str, n_classes: int = 4, reverse: bool = True, mode: int = 0,
-                 dtype: torch.dtype = torch.bfloat16, device="cuda", gemm_impl: int = L.IMPL_AUTO,
+                 dtype=torch.bfloat16, device="cuda", gemm_impl: int = L.IMPL_AUTO,
                  attn_impl: int = L.IMPL_AUTO, image_size: int = 224):
+        """dtype: torch.bfloat16 (the benchmarked mode) | torch.float32 (every GEMM on the fp32 matrix cores) | "bf16x3": fp32
+        storage, residual stream, LayerNorm, attention and head, with every encoder nn.Linear (forward, input gradient, weight
+        gradient) as a three-pass split-bf16 product on the bf16 matrix cores (csrc/gemm_x3.hip): the reference's fp32
+        arithmetic (multimodal_model.py:651-726) to ~1e-6 on the logits at several times the fp32 mode's speed."""
         L.load()
+        self.x3 = isinstance(dtype, str) and dtype.lower() in ("bf16x3", "x3")
+        if self.x3:
+            dtype = torch.float32
+        elif isinstance(dtype, str):
+            dtype = {"bf16": torch.bfloat16, "fp32": torch.float32, "f32": torch.float32}[dtype.lower()]
         if text_model == "bart":
             # the reference accepts the name (multimodal_model.py:137-144, 182-183) but its head is built for 768-wide text
             # features (input_size_txt = 768, :257) while facebook/bart-large emits 1024: its forward fails on the first batch
@@ -166,7 +177,7 @@ class MMRCAEngine:
         ents += [("image_model." + k, s) for k, s in vis_ents]
         self.head_keys = S.head_used_params(self.d_img, self.d_txt, n_classes, mode == 1, mode == 2)
         ents += self.head_keys
-        self.arena = Arena(ents, self.device, with_lp=(dtype == torch.bfloat16))
+        self.arena = Arena(ents, self.device, with_lp=(dtype == torch.bfloat16 or self.x3), with_lo=self.x3)
         self.param_keys = [k for k, _ in ents]
         self.text_span = self.arena.span(ents[0][0], "text_model." + S.text_params(self.ts)[-1][0])
         self.image_span = self.arena.span("image_model." + vis_ents[0][0], "image_model." + vis_ents[-1][0])
@@ -174,6 +185,7 @@ class MMRCAEngine:
             self.conv.init_buffers(self.device)
         self.head_span = self.arena.span(self.head_keys[0][0], self.head_keys[-1][0])
         self._bufs: Dict[Tuple, torch.Tensor] = {}
+        self._plane_valid = set()
         self._saved = None
         # parameter groups that become final together during backward; they tile the arena exactly (padding included)
         self.groups: Dict[str, Tuple[int, int]] = {}
@@ -249,6 +261,30 @@ class MMRCAEngine:
         src = self.arena.lp if self.dtype == torch.bfloat16 else self.arena.p
         return src[off:off + numel]
 
+    def Wx3(self, key, numel=None):
+        """(hi, lo) bf16 planes of a weight (bf16x3 mode)"""
+        off, _, n = self.arena.offsets[key]
+        n = n if numel is None else numel
+        return self.arena.lp[off:off + n], self.arena.lp_lo[off:off + n]
+
+    # ---- bf16x3: (hi, lo) bf16 planes of fp32 activations.  One pair of plane buffers per fp32 buffer (keyed by its address:
+    # saved activations have per-layer buffers, so the planes a forward GEMM made of its input are still there for that
+    # layer's weight-gradient GEMM); `_plane_valid` lists the ones made since the current forward began.
+    def _planes_of(self, x):
+        key = ("planes", x.data_ptr(), tuple(x.shape))
+        pl = self._bufs.get(key)
+        if pl is None:
+            pl = (torch.zeros(x.shape, dtype=torch.bfloat16, device=self.device), torch.zeros(x.shape, dtype=torch.bfloat16, device=self.device))
+            self._bufs[key] = pl
+        return key, pl
+
+    def _split(self, x, rows, cols, reuse=False):
+        key, pl = self._planes_of(x)
+        if not (reuse and key in self._plane_valid):
+            L.split_f32(x, pl[0], pl[1], rows * cols)
+            self._plane_valid.add(key)
+        return pl
+
     def G(self, key):
         return self.arena.view(key, "g")
 
@@ -258,7 +294,10 @@ class MMRCAEngine:
 
     def refresh_working_copy(self, force=False):
         if self.arena.lp is not None and (force or not self.arena.lp_valid):
-            L.cast_f32_to_bf16(self.arena.p, self.arena.lp, self.arena.total)
+            if self.x3:
+                L.split_f32(self.arena.p, self.arena.lp, self.arena.lp_lo, self.arena.total)
+            else:
+                L.cast_f32_to_bf16(self.arena.p, self.arena.lp, self.arena.total)
             self.arena.lp_valid = True
 
     def init_parameters(self, seed: int = 0):
@@ -328,12 +367,18 @@ class MMRCAEngine:
 
     def release_buffers(self):
         self._bufs.clear()
+        self._plane_valid.clear()
         self._saved = None
         if self.conv is not None:
             self.conv.release()
 
     # ------------------------------------------------------------------ op helpers
     def _lin_fwd(self, x, wkey, bkey, out, M, N, K, act=L.ACT_NONE, preact=None, addend=None, wnumel=None):
+        if self.x3:
+            b = self.arena.view(bkey) if wnumel is None else self.arena.p[self.arena.offsets[bkey][0]:self.arena.offsets[bkey][0] + N]
+            L.gemm_x3(self._split(x, M, K), self.Wx3(wkey, wnumel), out, bias=b, addend=addend, preact=preact, M=M, N=N, K=K, lda=K,
+                      ldb=K, ldc=N, a_layout=L.ROWK, b_layout=L.ROWK, act=act, impl=self.gemm_impl)
+            return
         w = self.W(wkey) if wnumel is None else self.Wflat(wkey, wnumel)
         b = self.W(bkey) if wnumel is None else self.Wflat(bkey, N)
         L.gemm(x, w, out, bias=b, addend=addend, preact=preact, M=M, N=N, K=K, lda=K, ldb=K, ldc=N,
@@ -346,6 +391,8 @@ class MMRCAEngine:
         Mk = _round_up(M, 64)
         gw = self.G(wkey) if wnumel is None else self.Gflat(wkey, wnumel)
         gb = self.G(bkey) if wnumel is None else self.Gflat(bkey, N)
+        if self.x3:
+            return self._lin_bwd_x3(dy, x, wkey, dx, M, N, K, Mk, gw, gb, addend, wnumel, gelu_h, bias_done, gelu_db)
 
         def wgrad():
             fused = (FUSE_BIAS_GRAD or fuse_db) and not bias_done
@@ -380,6 +427,40 @@ class MMRCAEngine:
                    impl=self.gemm_impl, colsum=(gelu_db if fuse else None))
             if gelu_h is not None and not fuse:
                 if gelu_db is not None:     # dh = dg * gelu'(h) and the FFN1 bias gradient (column sums of dh) in one pass
+                    L.gelu_bwd_colsum(dx, gelu_h, dx, gelu_db, M, K, K, self.dt)
+                else:
+                    L.gelu_bwd(dx, gelu_h, dx, M * K, self.dt)
+
+    def _lin_bwd_x3(self, dy, x, wkey, dx, M, N, K, Mk, gw, gb, addend, wnumel, gelu_h, bias_done, gelu_db):
+        """bf16x3 form of _lin_bwd: dy is split once for both products, x's planes are the ones its forward GEMM made"""
+        dyp = self._split(dy, M, N)
+        xp = self._split(x, M, K, reuse=True)
+
+        def wgrad():
+            if SPLITK_WGRAD and self.gemm_impl == L.IMPL_AUTO and L.gemm_splitk_ok(N, K, Mk, L.BF16):
+                L.gemm_splitk_x3(dyp, xp, gw, self._splitk_ws(), M=N, N=K, K=Mk, lda=N, ldb=K, ldc=K)
+            else:
+                L.gemm_x3(dyp, xp, gw, M=N, N=K, K=Mk, lda=N, ldb=K, ldc=K, a_layout=L.KROW, b_layout=L.KROW, accum=True)
+            if not bias_done:
+                L.colsum_accum(dy, gb, M, N, N, self.dt)
+
+        if self._side is None:
+            wgrad()
+        else:
+            main = torch.cuda.current_stream()
+            self._side.wait_stream(main)
+            with torch.cuda.stream(self._side):
+                wgrad()
+                if self._first_wgrad_ev is None:
+                    self._first_wgrad_ev = torch.cuda.Event()
+                    self._first_wgrad_ev.record(self._side)
+        if dx is not None:
+            fuse = gelu_h is not None and FUSE_GELU_GRAD
+            L.gemm_x3(dyp, self.Wx3(wkey, wnumel), dx, addend=addend, preact=(gelu_h if fuse else None), colsum=(gelu_db if fuse else None),
+                      M=M, N=K, K=N, lda=N, ldb=K, ldc=K, a_layout=L.ROWK, b_layout=L.KROW, act=(L.ACT_MUL if fuse else L.ACT_NONE),
+                      impl=self.gemm_impl)
+            if gelu_h is not None and not fuse:
+                if gelu_db is not None:
                     L.gelu_bwd_colsum(dx, gelu_h, dx, gelu_db, M, K, K, self.dt)
                 else:
                     L.gelu_bwd(dx, gelu_h, dx, M * K, self.dt)
@@ -607,7 +688,7 @@ class MMRCAEngine:
         x = fb("x", M, D, 0)
         L.vit_assemble_fwd(proj, self.W(P + "class_token"), self.W(P + "encoder.pos_embedding"), x, B, nP, D, self.dt)
         layers = []
-        fuse_res = LN_RESIDUAL and self.dt == L.BF16
+        fuse_res = LN_RESIDUAL and (self.dt == L.BF16 or self.x3)
         pend = None                      # (ffn2 output, x1) of the previous layer whose sum -- this layer's input -- is still to be formed
         for i in range(s.layers):
             Lk = P + f"encoder.layers.encoder_layer_{i}."
@@ -772,6 +853,7 @@ class MMRCAEngine:
             if not t.is_cuda:
                 raise L.MmrcaError(f"{nm} must be in HBM; the MM-RCA product path has no CPU fallback")
         self.refresh_working_copy()
+        self._plane_valid.clear()
         B = ids.shape[0]
         main = torch.cuda.current_stream()
         if self._text_stream is not None:

@@ -51,6 +51,11 @@ _SIGS = {
     "mmrca_gemm": [_vp] * 6 + [_i64] * 6 + [_i32] * 6 + [_vp],
     "mmrca_gemm_colsum": [_vp] * 7 + [_i64] * 6 + [_i32] * 5 + [_vp],
     "mmrca_gemm_splitk": [_vp] * 4 + [_i64] * 7 + [_i32] * 2 + [_vp],
+    "mmrca_gemm_x3": [_vp] * 10 + [_i64] * 6 + [_i32] * 5 + [_vp],
+    "mmrca_gemm_splitk_x3": [_vp] * 6 + [_i64] * 7 + [_i32] * 2 + [_vp],
+    "mmrca_split_f32": [_vp, _vp, _vp, _i64, _vp],
+    "mmrca_sgd_step_x3": [_vp, _vp, _vp, _vp, _i64, _f32, _f32, _f32, _vp],
+    "mmrca_adamw_step_x3": [_vp] * 6 + [_i64] + [_f32] * 5 + [_i32, _f32, _vp],
     "mmrca_nchw_to_rows": [_vp, _vp, _i32, _i32, _i32, _i32, _i32, _vp],
     "mmrca_im2row3x3": [_vp, _vp, _i32, _i32, _i32, _i32, _i32, _i64, _i32, _vp],
     "mmrca_col2im3x3": [_vp, _vp, _i32, _i32, _i32, _i32, _i32, _i64, _i32, _vp],
@@ -224,6 +229,46 @@ def gemm_splitk(A, B, Cout, workspace, *, M, N, K, lda, ldb, ldc, a_layout=KROW,
         GEMM_PROFILE.append((2.0 * M * N * K, (a_layout, b_layout, 1), e0, e1, (M, N, K, ACT_NONE)))
 
 
+def gemm_x3(A, B, Cout, *, C_lo=None, bias=None, addend=None, preact=None, colsum=None, M, N, K, lda, ldb, ldc, a_layout=ROWK,
+            b_layout=ROWK, act=ACT_NONE, accum=False, impl=IMPL_AUTO):
+    """bf16x3 product (csrc/gemm_x3.hip): A and B are (hi, lo) pairs of bf16 planes of fp32 operands; Cout / bias / addend /
+    preact are fp32 -- or, with C_lo, the output is written as two bf16 planes (Cout = hi plane)."""
+    _dev(A[0], "gemm_x3 A")
+    prof = GEMM_PROFILE is not None
+    if prof:
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+    _check(load().mmrca_gemm_x3(ptr(A[0]), ptr(A[1]), ptr(B[0]), ptr(B[1]), ptr(Cout), ptr(C_lo), ptr(bias), ptr(addend), ptr(preact),
+                                ptr(colsum), M, N, K, lda, ldb, ldc, a_layout, b_layout, act, int(accum), impl, stream_ptr()),
+           "mmrca_gemm_x3")
+    if prof:
+        e1.record()
+        # three bf16 MFMA passes per product: the executed matrix-core work is 3 x 2MNK
+        GEMM_PROFILE.append((6.0 * M * N * K, (a_layout, b_layout, int(accum)), e0, e1, (M, N, K, act)))
+
+
+def gemm_splitk_x3(A, B, Cout, workspace, *, M, N, K, lda, ldb, ldc, a_layout=KROW, b_layout=KROW):
+    """fp32 Cout += A (.) B over K, bf16x3 operands ((hi, lo) plane pairs), 256x256 tiles with the virtual 3K contraction split
+    over the CUs (partial tiles through `workspace`, no atomics)"""
+    _dev(A[0], "gemm_splitk_x3 A")
+    prof = GEMM_PROFILE is not None
+    if prof:
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+    _check(load().mmrca_gemm_splitk_x3(ptr(A[0]), ptr(A[1]), ptr(B[0]), ptr(B[1]), ptr(Cout), ptr(workspace),
+                                       workspace.numel() * workspace.element_size(), M, N, K, lda, ldb, ldc, a_layout, b_layout,
+                                       stream_ptr()), "mmrca_gemm_splitk_x3")
+    if prof:
+        e1.record()
+        GEMM_PROFILE.append((6.0 * M * N * K, (a_layout, b_layout, 1), e0, e1, (M, N, K, ACT_NONE)))
+
+
+def split_f32(src, hi, lo, n):
+    """hi = bf16(src), lo = bf16(src - hi): the two-plane form of fp32 values the bf16x3 GEMMs read"""
+    _dev(src, "split src")
+    _check(load().mmrca_split_f32(ptr(src), ptr(hi), ptr(lo), n, stream_ptr()), "mmrca_split_f32")
+
+
 def colsum_accum(dY, db, M, N, ld, dtype):
     _check(load().mmrca_colsum_accum(ptr(dY), ptr(db), M, N, ld, dtype, stream_ptr()), "mmrca_colsum_accum")
 
@@ -352,13 +397,21 @@ def xent_fwd_bwd(logits, labels, class_w, smoothing, loss, dlogits, B, Cc, grad_
     _check(load().mmrca_xent_fwd_bwd(ptr(logits), ptr(labels), ptr(class_w), smoothing, ptr(loss), ptr(dlogits), B, Cc, grad_scale, stream_ptr()), "mmrca_xent_fwd_bwd")
 
 
-def sgd_step(p, g, lp, n, lr, wd, grad_scale=1.0):
+def sgd_step(p, g, lp, n, lr, wd, grad_scale=1.0, lp_lo=None):
+    """lp / lp_lo: bf16 working copy (hi plane) and, in bf16x3 mode, the lo plane, rewritten in the same pass"""
     _dev(p, "sgd params")
+    if lp_lo is not None:
+        _check(load().mmrca_sgd_step_x3(ptr(p), ptr(g), ptr(lp), ptr(lp_lo), n, lr, wd, grad_scale, stream_ptr()), "mmrca_sgd_step_x3")
+        return
     _check(load().mmrca_sgd_step(ptr(p), ptr(g), ptr(lp), n, lr, wd, grad_scale, stream_ptr()), "mmrca_sgd_step")
 
 
-def adamw_step(p, g, m, v, lp, n, lr, b1, b2, eps, wd, step, grad_scale=1.0):
+def adamw_step(p, g, m, v, lp, n, lr, b1, b2, eps, wd, step, grad_scale=1.0, lp_lo=None):
     _dev(p, "adamw params")
+    if lp_lo is not None:
+        _check(load().mmrca_adamw_step_x3(ptr(p), ptr(g), ptr(m), ptr(v), ptr(lp), ptr(lp_lo), n, lr, b1, b2, eps, wd, step, grad_scale,
+                                          stream_ptr()), "mmrca_adamw_step_x3")
+        return
     _check(load().mmrca_adamw_step(ptr(p), ptr(g), ptr(m), ptr(v), ptr(lp), n, lr, b1, b2, eps, wd, step, grad_scale, stream_ptr()), "mmrca_adamw_step")
 
 

@@ -100,7 +100,7 @@ class EffV2MediumAndDistilbertGated(torch.nn.Module):
 
     def __init__(self, n_classes, drop_ratio, image_or_text_dropout_chance, img_prob_dropout, num_neurons_fc,
                  text_model_name, batch_size, reverse, features_only, cross_attention_only,
-                 image_model_name: str = "transformer_B16", dtype: torch.dtype = torch.bfloat16,
+                 image_model_name: str = "transformer_B16", dtype=torch.bfloat16,
                  device="cuda", init_seed: int = 0, build_unused_parameters: bool = True, image_size: Optional[int] = None):
         super().__init__()
         self.text_model_name = text_model_name

@@ -51,7 +51,7 @@ class FlatSGD(_FlatOptimizer):
         ar = self.engine.arena
         for a, b in self._spans():
             L.sgd_step(ar.p[a:b], ar.g[a:b], None if ar.lp is None else ar.lp[a:b], b - a, float(gp["lr"]),
-                       float(gp["weight_decay"]), grad_scale)
+                       float(gp["weight_decay"]), grad_scale, lp_lo=(None if ar.lp_lo is None else ar.lp_lo[a:b]))
         if ar.lp is not None:
             # the kernel rewrote the bf16 copy of every stepped span; un-stepped spans did not change since the
             # forward that validated the copy
@@ -79,6 +79,7 @@ class FlatAdamW(_FlatOptimizer):
             self._span_steps[name] += 1
             L.adamw_step(ar.p[a:b], ar.g[a:b], self.m[a:b], self.v[a:b], None if ar.lp is None else ar.lp[a:b], b - a,
                          float(gp["lr"]), float(gp["betas"][0]), float(gp["betas"][1]), float(gp["eps"]),
-                         float(gp["weight_decay"]), self._span_steps[name], grad_scale)
+                         float(gp["weight_decay"]), self._span_steps[name], grad_scale,
+                         lp_lo=(None if ar.lp_lo is None else ar.lp_lo[a:b]))
         if ar.lp is not None:
             ar.lp_valid = True

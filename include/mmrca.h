@@ -77,6 +77,31 @@ int64_t mmrca_gemm_splitk_workspace_bytes(int64_t M, int64_t N);
 int mmrca_gemm_splitk(const void* A, const void* B, float* C, void* workspace, int64_t workspace_bytes, int64_t M,
                       int64_t N, int64_t K, int64_t lda, int64_t ldb, int64_t ldc, int a_layout, int b_layout, void* stream);
 
+/* K2x. The same products with fp32 ACCURACY on the bf16 matrix cores ("bf16x3", the fast mode that meets the reference's
+ * precision: the reference computes every nn.Linear in fp32, CVPR_code/multimodal_model.py:651-726 with no autocast anywhere).
+ * An fp32 operand x is carried as two bf16 planes, hi = bf16(x), lo = bf16(x - hi) (mmrca_split_f32; x = hi + lo to 2^-17),
+ * and A.B = A_hi.B_hi + A_lo.B_hi + A_hi.B_lo with fp32 accumulation (A_lo.B_lo is below fp32 resolution) -- one pass of the
+ * bf16 MFMA kernels over the virtual contraction [A_hi|A_lo|A_hi].[B_hi|B_hi|B_lo] of length 3K, no operand copies.
+ *   A_hi/A_lo, B_hi/B_lo: bf16 planes with the layouts / leading dimensions of mmrca_gemm.
+ *   C: fp32 [M, ldc]; or, with C_lo != NULL, the result is stored as two bf16 planes (C = hi plane, C_lo = lo plane) for a
+ *   consumer that is another bf16x3 product.  bias [N], addend [M, ldc], preact [M, ldc]: fp32, same roles as in mmrca_gemm
+ *   (MMRCA_ACT_GELU_SAVE_GRAD writes gelu' to preact, MMRCA_ACT_MUL multiplies by it).  colsum (optional, fp32 [N], +=):
+ *   column sums of the stored C.  out_f32_accum != 0: C (fp32) += result, no epilogue (prefer mmrca_gemm_splitk_x3).
+ *   Shapes: N % 128 == 0, K % 64 == 0, M % 128 == 0 for a KROW A; 16-byte aligned operands.
+ *   impl: MMRCA_GEMM_AUTO | MMRCA_GEMM_MFMA_1STAGE (128x128 tiles, any epilogue) | MMRCA_GEMM_MFMA256 (persistent 256x256
+ *   tiles: row-major A with M % 256 == 0 -- REJECTED otherwise, the kernel streams whole 256-row tiles --, N % 256 == 0,
+ *   K >= 128, bias-only or GELU_SAVE_GRAD epilogue, operands < 4 GiB). */
+int mmrca_gemm_x3(const void* A_hi, const void* A_lo, const void* B_hi, const void* B_lo, void* C, void* C_lo,
+                  const void* bias, const void* addend, void* preact, float* colsum, int64_t M, int64_t N, int64_t K,
+                  int64_t lda, int64_t ldb, int64_t ldc, int a_layout, int b_layout, int act, int out_f32_accum,
+                  int impl, void* stream);
+/* weight gradient in that form: C[M,N] (fp32) += A (.) B over K; the contracts of mmrca_gemm_splitk (workspace included) */
+int mmrca_gemm_splitk_x3(const void* A_hi, const void* A_lo, const void* B_hi, const void* B_lo, float* C, void* workspace,
+                         int64_t workspace_bytes, int64_t M, int64_t N, int64_t K, int64_t lda, int64_t ldb, int64_t ldc,
+                         int a_layout, int b_layout, void* stream);
+/* hi[i] = bf16(src[i]) (round to nearest even), lo[i] = bf16(src[i] - hi[i]); n % 4 == 0 */
+int mmrca_split_f32(const float* src, void* hi, void* lo, int64_t n, void* stream);
+
 /* db[N] (fp32) += column sums of dY[M,N]  (bias gradients of every nn.Linear on the path). */
 int mmrca_colsum_accum(const void* dY, float* db, int64_t M, int64_t N, int64_t ld, int dtype, void* stream);
 
@@ -263,6 +288,10 @@ int mmrca_sgd_step(float* p, const float* g, void* lp, int64_t n, float lr, floa
 int mmrca_adamw_step(float* p, const float* g, float* m, float* v, void* lp, int64_t n, float lr, float beta1,
                      float beta2, float eps, float wd, int step, float grad_scale, void* stream);
 int mmrca_cast_f32_to_bf16(const float* src, void* dst, int64_t n, void* stream);
+/* the same steps in bf16x3 mode: lp_hi / lp_lo receive the two bf16 planes of the updated parameters (lp_lo may be NULL) */
+int mmrca_sgd_step_x3(float* p, const float* g, void* lp_hi, void* lp_lo, int64_t n, float lr, float wd, float grad_scale, void* stream);
+int mmrca_adamw_step_x3(float* p, const float* g, float* m, float* v, void* lp_hi, void* lp_lo, int64_t n, float lr, float beta1,
+                        float beta2, float eps, float wd, int step, float grad_scale, void* stream);
 
 /* K7 (the step before the hot path).  The reference's validation image pipeline
  * (main_both.py:433-440: PadToMaintainAR keep_aspect_ratio.py:18-53 -> A.Resize(INTER_LINEAR) -> A.Normalize ->
