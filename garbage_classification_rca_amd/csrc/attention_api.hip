@@ -5,6 +5,10 @@
 int mmrca_mha_fwd_ref(const void*, const int32_t*, void*, float*, int, int, int, int, float, float, uint64_t, const int32_t*, int, hipStream_t);
 int mmrca_mha_bwd_ref(const void*, const int32_t*, const void*, const void*, const float*, void*, int, int, int, int, float, float, uint64_t, const int32_t*, int, hipStream_t);
 bool mmrca_mha_mfma_ok(int S, int dh, int dtype);
+// fp32 on the fp32 matrix cores (attention_f32.hip): what the fp32 / bf16x3 modes run for head dim 64, S <= 208
+bool mmrca_mha_f32m_ok(int S, int dh, int dtype);
+int mmrca_mha_fwd_f32m(const void*, const int32_t*, void*, float*, int, int, int, int, float, float, uint64_t, const int32_t*, hipStream_t);
+int mmrca_mha_bwd_f32m(const void*, const int32_t*, const void*, const void*, const float*, void*, int, int, int, int, float, float, uint64_t, const int32_t*, hipStream_t);
 int mmrca_mha_fwd_mfma(const void*, const int32_t*, void*, float*, int, int, int, int, float, float, uint64_t, const int32_t*, hipStream_t);
 int mmrca_mha_bwd_mfma(const void*, const int32_t*, const void*, const void*, const float*, void*, int, int, int, int, float, float, uint64_t, const int32_t*, hipStream_t);
 
@@ -15,8 +19,10 @@ extern "C" int mmrca_mha_fwd(const void* qkv, const int32_t* key_mask, void* out
   MMRCA_REQUIRE(drop_p >= 0.f && drop_p < 1.f, "mha_fwd: dropout p must be in [0,1)");
   MMRCA_REQUIRE(B > 0 && H > 0 && S > 0 && dh > 0, "mha_fwd: bad shape");
   const bool ok = mmrca_mha_mfma_ok(S, dh, dtype);
-  if (impl == MMRCA_GEMM_MFMA && !ok) return mmrca_fail(-3, "mha_fwd: S=%d dh=%d dtype=%d does not qualify for the MFMA kernel", S, dh, dtype);
+  if (impl == MMRCA_GEMM_MFMA && !ok && !mmrca_mha_f32m_ok(S, dh, dtype)) return mmrca_fail(-3, "mha_fwd: S=%d dh=%d dtype=%d does not qualify for the MFMA kernel", S, dh, dtype);
   if (ok && impl != MMRCA_GEMM_REF) return mmrca_mha_fwd_mfma(qkv, key_mask, out, lse, B, H, S, dh, scale, drop_p, drop_seed, cu_seqlens, (hipStream_t)stream);
+  if (impl != MMRCA_GEMM_REF && mmrca_mha_f32m_ok(S, dh, dtype))
+    return mmrca_mha_fwd_f32m(qkv, key_mask, out, lse, B, H, S, dh, scale, drop_p, drop_seed, cu_seqlens, (hipStream_t)stream);
   return mmrca_mha_fwd_ref(qkv, key_mask, out, lse, B, H, S, dh, scale, drop_p, drop_seed, cu_seqlens, dtype, (hipStream_t)stream);
 }
 
@@ -27,12 +33,14 @@ static int mha_bwd_impl(const void* qkv, const int32_t* key_mask, const void* ou
   MMRCA_REQUIRE(drop_p >= 0.f && drop_p < 1.f, "mha_bwd: dropout p must be in [0,1)");
   MMRCA_REQUIRE(B > 0 && H > 0 && S > 0 && dh > 0, "mha_bwd: bad shape");
   const bool ok = mmrca_mha_mfma_ok(S, dh, dtype);
-  if (impl == MMRCA_GEMM_MFMA && !ok) return mmrca_fail(-3, "mha_bwd: S=%d dh=%d dtype=%d does not qualify for the MFMA kernel", S, dh, dtype);
+  if (impl == MMRCA_GEMM_MFMA && !ok && !mmrca_mha_f32m_ok(S, dh, dtype)) return mmrca_fail(-3, "mha_bwd: S=%d dh=%d dtype=%d does not qualify for the MFMA kernel", S, dh, dtype);
   // (reducing the bias column sums inside the MFMA kernels was measured: +41 us per ViT layer against 32 us for this pass --
   //  256 blocks contend on every one of the 2,304 fp32 atomics addresses)
   int rc;
   if (ok && impl != MMRCA_GEMM_REF)
     rc = mmrca_mha_bwd_mfma(qkv, key_mask, out, dout, lse, dqkv, B, H, S, dh, scale, drop_p, drop_seed, cu_seqlens, (hipStream_t)stream);
+  else if (impl != MMRCA_GEMM_REF && mmrca_mha_f32m_ok(S, dh, dtype))
+    rc = mmrca_mha_bwd_f32m(qkv, key_mask, out, dout, lse, dqkv, B, H, S, dh, scale, drop_p, drop_seed, cu_seqlens, (hipStream_t)stream);
   else
     rc = mmrca_mha_bwd_ref(qkv, key_mask, out, dout, lse, dqkv, B, H, S, dh, scale, drop_p, drop_seed, cu_seqlens, dtype, (hipStream_t)stream);
   if (rc) return rc;

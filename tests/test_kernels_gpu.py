@@ -548,7 +548,7 @@ def _attn_ref(qkv, mask, B, H, S, dh, dout=None):
     return out, qkv.grad
 
 
-@pytest.mark.parametrize("dt,impl", [(torch.float32, L.IMPL_REF), (torch.bfloat16, L.IMPL_REF), (torch.bfloat16, L.IMPL_AUTO)])
+@pytest.mark.parametrize("dt,impl", [(torch.float32, L.IMPL_REF), (torch.float32, L.IMPL_AUTO), (torch.bfloat16, L.IMPL_REF), (torch.bfloat16, L.IMPL_AUTO)])
 @pytest.mark.parametrize("S,masked", [(64, True), (197, False), (40, True), (300, True), (512, False), (1, False), (17, True)])
 def test_mha_fwd_bwd(dt, impl, S, masked):
     # S = 512 is the text encoders' max_position_embeddings (the largest sequence the path can see); S = 1 the smallest
@@ -616,7 +616,7 @@ def test_class_token_attention_equals_row0_of_full_attention(dt, S, dh, masked, 
     assert float(dqkv_c.view(B, S, 3, H * dh)[:, 1:, 0].abs().max()) == 0.0
 
 
-@pytest.mark.parametrize("dt,impl", [(torch.float32, L.IMPL_REF), (torch.bfloat16, L.IMPL_REF), (torch.bfloat16, L.IMPL_AUTO)])
+@pytest.mark.parametrize("dt,impl", [(torch.float32, L.IMPL_REF), (torch.float32, L.IMPL_AUTO), (torch.bfloat16, L.IMPL_REF), (torch.bfloat16, L.IMPL_AUTO)])
 @pytest.mark.parametrize("S,p", [(64, 0.0), (64, 0.1), (200, 0.0)])
 def test_attention_packed_layout_reproduces_the_padded_run(dt, impl, S, p):
     """cu_seqlens: captions stored back to back without their padding give, on every kept row, what the padded layout
@@ -693,6 +693,32 @@ def test_layernorm_dropout_fwd_bwd_match_masked_reference():
     L.layernorm_bwd(dy, s_out, g, mean, rstd, None, ds, dg, db, rows, D, D, D, D, L.F32, dy_drop=(p, 22), branch_drop=(p, 11), dbranch=dbr)
     assert rel_err(dbr, xr.grad) < 1e-4
     assert rel_err(ds * k_in, xr.grad) < 1e-4
+
+
+@pytest.mark.parametrize("S,masked", [(64, True), (128, True), (197, False), (33, True)])
+def test_fp32_matrix_core_attention_with_dropout_matches_the_reference_kernel(S, masked):
+    """attention_f32.hip (what the fp32 / bf16x3 modes run: fp32 MFMA, AUTO) against the row-per-wave fp32 kernel (REF):
+    same masks from the same counter hash, so forward, lse and all three gradients agree to fp32 rounding"""
+    B, H, dh, p, seed = 3, 5, 64, 0.1, 91
+    qkv = dev(torch.randn(B * S, 3 * H * dh))
+    mask = None
+    if masked:
+        mask = torch.ones(B, S, dtype=torch.int32); mask[1, S // 3:] = 0; mask[2, :] = 0; mask = mask.cuda()
+    sc = 1 / math.sqrt(dh)
+    dout = dev(torch.randn(B * S, H * dh, generator=torch.Generator().manual_seed(1)))
+    res = {}
+    for impl in (L.IMPL_REF, L.IMPL_AUTO):
+        out, lse = torch.empty(B * S, H * dh, device="cuda"), torch.empty(B, H, S, device="cuda")
+        L.mha_fwd(qkv, mask, out, lse, B, H, S, dh, sc, L.F32, impl, drop_p=p, drop_seed=seed)
+        dqkv = torch.full_like(qkv, float("nan"))
+        L.mha_bwd(qkv, mask, out, dout, lse, dqkv, B, H, S, dh, sc, L.F32, impl, drop_p=p, drop_seed=seed)
+        res[impl] = (out, lse, dqkv)
+    (o0, l0, g0), (o1, l1, g1) = res[L.IMPL_REF], res[L.IMPL_AUTO]
+    assert torch.isfinite(o1).all() and torch.isfinite(g1).all()
+    assert rel_err(o1, o0) < 1e-5
+    fin = torch.isfinite(l0)
+    assert torch.equal(fin, torch.isfinite(l1)) and rel_err(l1[fin], l0[fin]) < 1e-5
+    assert rel_err(g1, g0) < 5e-5
 
 
 @pytest.mark.parametrize("S,masked", [(64, True), (197, False)])
