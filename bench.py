@@ -27,6 +27,16 @@ PEAK_F32_TFLOPS = 157.3        # fp32-in MFMA (v_mfma_f32_32x32x2_f32), same gui
 FWD_GFLOP_PER_SAMPLE = 40.6
 
 
+def gemm_sources_sha256() -> str:
+    """hash of the GEMM kernel sources: roofline.traffic quotes a committed PMC summary only if it was measured on these"""
+    import hashlib
+    h = hashlib.sha256()
+    for f in ("gemm.hip", "gemm256.hip", "gemm_x3.hip", "lds_asm.h", "common.h"):
+        with open(os.path.join(ROOT, "garbage_classification_rca_amd", "csrc", f), "rb") as fh:
+            h.update(fh.read())
+    return h.hexdigest()
+
+
 def effective_cores() -> int:
     """Cores this process may actually use: min(affinity, cgroup CPU quota).  (On the GPU boxes os.cpu_count() is 256
     while the container's quota is 16 CPUs; 256 threads under that quota run ~10x slower than 16.)"""
@@ -40,14 +50,15 @@ def effective_cores() -> int:
     return max(1, n)
 
 
-def cpu_baseline(batch=8, steps=12, seq_len=64, text_model="distilbert", image_model="transformer_B16", image_size=224):
-    """The oracle (CPU restatement of the reference's model + run_one_epoch step) on this box's host cores, same
-    synthetic tensors, fp32 eager, fine-tuning phase.  A reported baseline, not the optimisation target."""
+def cpu_baseline(batches=(4, 32), steps=3, seq_len=64, text_model="distilbert", image_model="transformer_B16", image_size=224):
+    """The oracle (CPU restatement of the reference's model + run_one_epoch step) on this box's host cores, same synthetic
+    tensors, fp32 eager, fine-tuning phase, as SURVEY.md section 8(d) states it: batch 4 (configs[0]'s batch) and batch 32,
+    `steps` timed steps after one warm-up each, torch threads = the cores this process may use (stated).  `value` is the
+    batch-32 figure.  A reported baseline, not the optimisation target."""
     from oracle import model as O
     from garbage_classification_rca_amd.procedural import synth_captions
     n = effective_cores()
     torch.set_num_threads(n)
-    print(f"[bench] cpu_baseline: oracle train step on {n} host threads, batch {batch} ...", file=sys.stderr, flush=True)
     m = O.build_oracle(text_model, image_model, True, drop_ratio=0.6, enc_dropout=0.1).train()
     g = torch.Generator().manual_seed(0)
     with torch.no_grad():
@@ -61,32 +72,36 @@ def cpu_baseline(batch=8, steps=12, seq_len=64, text_model="distilbert", image_m
             else:
                 p.zero_()
     opt = torch.optim.SGD(m.parameters(), lr=1e-3, weight_decay=1e-2)
-    ids, mask = (torch.from_numpy(a) for a in synth_captions(batch, seq_len, seed=4321))
-    images = torch.randn(batch, 3, image_size, image_size, generator=torch.Generator().manual_seed(1234))
-    labels = torch.arange(batch) % 4
+    by_batch = {}
+    for batch in batches:
+        print(f"[bench] cpu_baseline: oracle train step on {n} host threads, batch {batch} ...", file=sys.stderr, flush=True)
+        ids, mask = (torch.from_numpy(a) for a in synth_captions(batch, seq_len, seed=4321))
+        images = torch.randn(batch, 3, image_size, image_size, generator=torch.Generator().manual_seed(1234))
+        labels = torch.arange(batch) % 4
 
-    def step():
-        out = m(ids, mask, images)
-        loss = O.cross_entropy(out, labels)
-        loss.backward()
-        opt.step()
-        opt.zero_grad()
-    step()
-    print("[bench] cpu_baseline: warm-up step done", file=sys.stderr, flush=True)
-    t0 = time.time()
-    for _ in range(steps):
+        def step():
+            out = m(ids, mask, images)
+            loss = O.cross_entropy(out, labels)
+            loss.backward()
+            opt.step()
+            opt.zero_grad()
         step()
-        print("[bench] cpu_baseline: step done", file=sys.stderr, flush=True)
-    dt = time.time() - t0
-    return {"value": round(batch * steps / dt, 3), "unit": "samples/s", "cores": n, "kind": "port",
+        t0 = time.time()
+        for _ in range(steps):
+            step()
+            print("[bench] cpu_baseline: step done", file=sys.stderr, flush=True)
+        by_batch[batch] = round(batch * steps / (time.time() - t0), 3)
+    return {"value": by_batch[batches[-1]], "unit": "samples/s", "cores": n, "threads": n, "kind": "port",
+            "by_batch": {str(k): v for k, v in by_batch.items()},
             "sample": f"oracle (PyTorch CPU fp32 eager restatement of MM_RCA + run_one_epoch step), {image_model} + {text_model}, "
-                      f"batch {batch}, S={seq_len}, {steps} timed steps after 1 warm-up, {n} threads"}
+                      f"S={seq_len}, batch {' and '.join(str(b_) for b_ in batches)} (value = batch {batches[-1]}), {steps} timed steps after 1 warm-up each, "
+                      f"torch.set_num_threads({n}) = min(affinity, cgroup quota) of this box"}
 
 
 def parity_check(model, ids, mask, images, n=8):
-    """Logits of the benchmarked bf16 engine and of the fp32 parity mode against the oracle (CPU fp32) on the first `n`
-    synthetic pairs, with the benchmarked model's CURRENT weights (eval mode: no dropout).  Runs after the timed region;
-    the oracle is the checker here, never the thing measured."""
+    """Logits of all three precision modes of the engine against the oracle (CPU fp32) on the first `n` synthetic pairs, with
+    the benchmarked model's CURRENT weights (eval mode: no dropout).  Runs after the timed region; the oracle is the checker
+    here, never the thing measured."""
     from oracle import model as O
     from garbage_classification_rca_amd.engine import MMRCAEngine, make_text_pack
     eng = model.engine
@@ -108,18 +123,23 @@ def parity_check(model, ids, mask, images, n=8):
         ref = orc(i_h, m_h, x_h, eval=True)
     rel = lambda a: float(((a.float().cpu() - ref).abs().max() / ref.abs().max()).item())
     pack = make_text_pack(m_h.numpy(), ids.device)
+    own = "bf16x3" if eng.x3 else ("bf16" if eng.dtype == torch.bfloat16 else "fp32")
     eng.refresh_working_copy(force=True)
-    l16 = eng.forward(ids[:n], mask[:n], images[:n], save=False, text_pack=pack)
-    out = {"bf16_logits_rel": round(rel(l16), 6), "samples": n,
+    out = {own + "_logits_rel": round(rel(eng.forward(ids[:n], mask[:n], images[:n], save=False, text_pack=pack)), 8), "samples": n,
+           "benchmarked_mode": own,
            "reference": "oracle (CPU fp32 restatement pinned by the reference's goldens), same weights, eval mode"}
-    eng32 = MMRCAEngine(eng.ts.name, img_name, eng.n_classes, eng.reverse, eng.mode, torch.float32, eng.device)
-    eng32.load_arrays(sd)
-    if eng.conv is not None:
-        eng32.conv.load_buffers({k: v for k, v in eng.conv.buffers.items()})
-    l32 = eng32.forward(ids[:n], mask[:n], images[:n], save=False)
-    out["fp32_logits_rel"] = round(rel(l32), 8)
-    eng32.release_buffers()
+    for name, dt in (("bf16", torch.bfloat16), ("bf16x3", "bf16x3"), ("fp32", torch.float32)):
+        if name == own:
+            continue
+        e2 = MMRCAEngine(eng.ts.name, img_name, eng.n_classes, eng.reverse, eng.mode, dt, eng.device)
+        e2.load_arrays(sd)
+        if eng.conv is not None:
+            e2.conv.load_buffers({k: v for k, v in eng.conv.buffers.items()})
+        out[name + "_logits_rel"] = round(rel(e2.forward(ids[:n], mask[:n], images[:n], save=False)), 8)
+        e2.release_buffers()
+        del e2
     out["north_star_bound"] = 1e-3
+    out["modes_meeting_the_bound"] = [k[:-len("_logits_rel")] for k, v in out.items() if k.endswith("_logits_rel") and v <= 1e-3]
     return out
 
 
@@ -307,6 +327,15 @@ def main():
     opt = FlatSGD(model, lr=1e-3, weight_decay=1e-2)
     crit = FusedCrossEntropy(None, 0.0)
     sync = D.GradSync(model.engine.arena.g, world) if world > 1 else None
+    comm = None
+    if world > 1:
+        # self-diagnosis of the data-parallel exchange (the one collective of the path: gradient average before the optimizer)
+        ones = torch.ones(1, device=dev)
+        dist.all_reduce(ones)
+        ranks_seen = int(ones.item())
+        assert ranks_seen == world, f"collective saw {ranks_seen} ranks, WORLD_SIZE={world}"
+        comm = {"backend": dist.get_backend() + (" (RCCL)" if dist.get_backend() == "nccl" else ""), "ranks_seen": ranks_seen,
+                "wire_dtype": "bf16" if sync.wire_dtype == torch.bfloat16 else "fp32", "bucket_bytes": sync.bucket_elems * 4}
 
     # synthetic pairs, resident in HBM before the timed region; a few distinct batches
     nb = 2
@@ -342,6 +371,7 @@ def main():
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
+        sync.bytes_reduced, sync.launches, sync.wait_events, sync.timing = 0, 0, [], True
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     with contextlib.redirect_stdout(io.StringIO()):
@@ -353,6 +383,13 @@ def main():
         dist.barrier()
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
+    if world > 1:
+        sync.timing = False
+        wait_ms = sum(e0.elapsed_time(e1) for e0, e1 in sync.wait_events)
+        comm.update({"bytes_per_step": int(sync.bytes_reduced // args.steps), "allreduce_launches_per_step": sync.launches // args.steps,
+                     "allreduce_wait_ms_per_step": round(wait_ms / args.steps, 3),
+                     "wait_definition": "time the compute stream spends blocked in GradSync.finish() (HIP events around its waits): the part of the "
+                                        "exchange NOT hidden behind the backward"})
 
     # Roofline of the dominant kernel (the MFMA GEMM).  The timed region above overlaps kernels on several HIP streams
     # (weight-gradient GEMMs beside the input-gradient chain, text beside vision encoder), so per-launch durations there
@@ -403,12 +440,19 @@ def main():
         # rocprofv3 --pmc passes over THIS command (tools/pmc_traffic.py) is quoted, next to the algorithmic bytes
         # (operands once + outputs once, from the launch shapes of this run)
         traffic, traffic_src = None, None
-        for pmc_name in ("r02_pmc_hbm_traffic.json", "r01_pmc_hbm_traffic.json"):
+        for pmc_name in ("r03_pmc_hbm_traffic.json", "r02_pmc_hbm_traffic.json", "r01_pmc_hbm_traffic.json"):
             pmc_json = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", pmc_name)
             if os.path.exists(pmc_json):
                 with open(pmc_json) as fh:
-                    traffic = json.load(fh).get("gemm_hbm_bytes_per_launch_mean")
-                traffic_src = f"profiles/{pmc_name} (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes, x2 gfx950 fetch correction)"
+                    pj = json.load(fh)
+                # the summary names the GEMM sources it was measured on (tools/pmc_traffic.py); a kernel edit since then makes it stale
+                if pj.get("gemm_sources_sha256") != gemm_sources_sha256():
+                    traffic_src = (f"profiles/{pmc_name} is STALE (measured on other GEMM sources: {str(pj.get('gemm_sources_sha256'))[:12]} vs "
+                                   f"{gemm_sources_sha256()[:12]} now); not quoted -- re-run tools/r03_artifacts.sh")
+                    break
+                traffic = pj.get("gemm_hbm_bytes_per_launch_mean")
+                traffic_src = (f"profiles/{pmc_name} (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes, x2 gfx950 fetch correction; "
+                               f"GEMM sources sha256 {pj['gemm_sources_sha256'][:12]} = this build)")
                 break
         alg = []
         for f, kind, e0, e1, shp in prof:
@@ -506,6 +550,8 @@ def main():
                          "whole_step_nominal_model_TFLOPs": round(value / world * train_flop_per_sample / 1e12, 2),
                          "attention": attention, "head": head},
         }
+        if comm is not None:
+            out["comm"] = comm
         if not args.no_cpu_baseline and world == 1:
             with contextlib.redirect_stdout(io.StringIO()):
                 out["parity"] = parity_check(model, ids, mask, images)

@@ -802,9 +802,13 @@ col_moment_v8_k(const bf16_t* __restrict__ x, const float* __restrict__ mean, fl
   col_reduce8<1>(acc, red, outs, blockIdx.y, C);
 }
 
-// Both moments in ONE pass over x (bf16 fast path of mmrca_bn_stats): sums of d and d*d with d = x - x[0, c], the channel's
-// first-row value as the shift (any value within a few standard deviations of the mean keeps var = E[d^2] - E[d]^2 free of
-// cancellation; fp32 sums).  Saves the second 2-byte-per-element pass of the two-pass form per BatchNorm layer.
+// Both moments in ONE pass over x (bf16 fast path of mmrca_bn_stats): sums of d and d*d with d = x - shift[c] (fp32 sums).
+// Any shift within a few standard deviations of the channel mean keeps var = E[d^2] - E[d]^2 free of cancellation.  The shift is
+// the mean of BN_SHIFT_ROWS rows spread evenly over the tensor -- a single row (round 2 used row 0: the top-left pixel of image 0,
+// a zero-padded conv border / letterbox region) can sit many standard deviations from the channel mean, and the subtraction then
+// cancels in fp32 over millions of rows.  Both kernels below form it with the same adds in the same order.
+#define BN_SHIFT_ROWS 16
+__device__ __forceinline__ int64_t bn_shift_row(int k, int64_t rows) { return (int64_t)k * rows / BN_SHIFT_ROWS; }
 __global__ void __launch_bounds__(256)
 col_moment2_v8_k(const bf16_t* __restrict__ x, float* __restrict__ s1, float* __restrict__ s2, int64_t rows, int C, int64_t ld,
                  int64_t rows_per_block) {
@@ -817,10 +821,16 @@ col_moment2_v8_k(const bf16_t* __restrict__ x, float* __restrict__ s1, float* __
 #pragma unroll
   for (int j = 0; j < 8; ++j) { acc[0][j] = 0.f; acc[1][j] = 0.f; }
   if (c0 < C) {
-    const cm_b8 sv = *reinterpret_cast<const cm_b8*>(x + c0);
     float m[8];
 #pragma unroll
-    for (int j = 0; j < 8; ++j) m[j] = (float)sv[j];
+    for (int j = 0; j < 8; ++j) m[j] = 0.f;
+    for (int k = 0; k < BN_SHIFT_ROWS; ++k) {
+      const cm_b8 sv = *reinterpret_cast<const cm_b8*>(x + bn_shift_row(k, rows) * ld + c0);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) m[j] += (float)sv[j];
+    }
+#pragma unroll
+    for (int j = 0; j < 8; ++j) m[j] *= 1.0f / BN_SHIFT_ROWS;
     for (int64_t r = r0 + rl; r < r1; r += 32) {
       const cm_b8 v = *reinterpret_cast<const cm_b8*>(x + r * ld + c0);
 #pragma unroll
@@ -833,11 +843,14 @@ col_moment2_v8_k(const bf16_t* __restrict__ x, float* __restrict__ s1, float* __
 // (sum d, sum d^2) -> mean, rstd (in place), running stats
 __global__ void bn_finish_shifted_k(const bf16_t* __restrict__ x, float* __restrict__ mean, float* __restrict__ rstd,
                                     float* __restrict__ running_mean, float* __restrict__ running_var, int C, float n, float eps,
-                                    float momentum) {
+                                    float momentum, int64_t rows, int64_t ld) {
   const int c = blockIdx.x * blockDim.x + threadIdx.x;
   if (c >= C) return;
+  float shift = 0.f;
+  for (int k = 0; k < BN_SHIFT_ROWS; ++k) shift += (float)x[bn_shift_row(k, rows) * ld + c];
+  shift *= 1.0f / BN_SHIFT_ROWS;
   const float d1 = mean[c] / n;
-  const float mu = (float)x[c] + d1;
+  const float mu = shift + d1;
   const float var = fmaxf(rstd[c] / n - d1 * d1, 0.f);
   mean[c] = mu;
   rstd[c] = rsqrtf(var + eps);
@@ -906,7 +919,7 @@ extern "C" int mmrca_bn_stats(const void* x, float* mean, float* rstd, float* ru
     if (g_bn_one_pass) {
       hipLaunchKernelGGL(col_moment2_v8_k, grid, dim3(256), 0, st, (const bf16_t*)x, mean, rstd, rows, C, ld, per);
       hipLaunchKernelGGL(bn_finish_shifted_k, dim3((C + 255) / 256), dim3(256), 0, st, (const bf16_t*)x, mean, rstd, running_mean, running_var, C,
-                         (float)rows, eps, momentum);
+                         (float)rows, eps, momentum, rows, ld);
       MMRCA_CHECK_LAUNCH("bn_stats(one pass)");
       return 0;
     }

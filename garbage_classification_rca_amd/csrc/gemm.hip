@@ -1186,10 +1186,11 @@ static void launch_mfma(const void* A, const void* B, void* C, const void* bias,
 }
 
 // colsum_fused: honoured by the single-stage kernel only; *fused_done tells the caller whether it was
+// rows_readable: the caller vouches (mmrca_gemm_rows) that A and the side operand have round_up(M, 256) readable rows
 static int gemm_dispatch(const void* A, const void* B, void* C, const void* bias, const void* addend, void* preact,
                          int64_t M, int64_t N, int64_t K, int64_t lda, int64_t ldb, int64_t ldc,
                          int a_layout, int b_layout, int act, int out_f32_accum, int dtype, int impl, void* stream,
-                         float* colsum_fused, bool* fused_done) {
+                         float* colsum_fused, bool* fused_done, bool rows_readable = false) {
   MMRCA_REQUIRE(A && B && C, "gemm: null operand");
   MMRCA_REQUIRE(M > 0 && N > 0 && K > 0, "gemm: bad shape M=%lld N=%lld K=%lld", (long long)M, (long long)N, (long long)K);
   MMRCA_REQUIRE((a_layout == MMRCA_ROWK || a_layout == MMRCA_KROW) && (b_layout == MMRCA_ROWK || b_layout == MMRCA_KROW), "gemm: bad layout");
@@ -1208,6 +1209,12 @@ static int gemm_dispatch(const void* A, const void* B, void* C, const void* bias
                      M * lda * 2 < (1ll << 32) && (b_layout == MMRCA_KROW ? K * ldb : N * ldb) * 2 < (1ll << 32) && M * ldc * 2 < (1ll << 32);
   if (impl == MMRCA_GEMM_MFMA256 && !ok256)
     return mmrca_fail(-3, "gemm: shape M=%lld N=%lld K=%lld does not qualify for the 256x256 MFMA kernel", (long long)M, (long long)N, (long long)K);
+  // The persistent kernel streams whole 256-row tiles of A (and fetches whole tiles of a side operand): with a ragged M it reads
+  // rows M .. round_up(M, 256) - 1.  An explicit request must therefore either come with whole tiles or through mmrca_gemm_rows,
+  // where the caller states how many rows are readable (AUTO only picks the kernel when M % 256 == 0).
+  if (impl == MMRCA_GEMM_MFMA256 && M % 256 != 0 && !rows_readable)
+    return mmrca_fail(-4, "gemm: impl=MFMA256 with M=%lld (not a multiple of 256) reads rows up to %lld of A and of the side operand: "
+                      "call mmrca_gemm_rows and state the readable row counts", (long long)M, (long long)((M + 255) / 256 * 256));
   // AUTO (tools/gemm_bench.py, interleaved rounds, round 2): the persistent 256x256 kernel (operand stream in flight across
   // barriers and tile boundaries, barrier-free epilogue) wins on every bias-only shape once there is a full round of tiles:
   // K = 768: 870-1,120 vs 830-910 TFLOP/s for the 128x128 single-stage kernel, K >= 2304: 1,010-1,070 vs 910-920.
@@ -1387,5 +1394,30 @@ extern "C" int mmrca_gemm_colsum(const void* A, const void* B, void* C, const vo
                              stream, colsum, &done))
     return rc;
   if (!done) return mmrca_colsum_accum(C, colsum, M, N, ldc, dtype, stream);    // kernels without the fused sums: one more pass
+  return 0;
+}
+
+// mmrca_gemm / mmrca_gemm_colsum with the row contract of the 256x256 kernel made explicit: a_rows_readable / side_rows_readable
+// = rows of A / of the side operand (addend, or preact under MMRCA_ACT_MUL) that exist in memory.  impl = MMRCA_GEMM_MFMA256 with
+// a ragged M is accepted only when both cover round_up(M, 256).
+extern "C" int mmrca_gemm_rows(const void* A, const void* B, void* C, const void* bias, const void* addend, void* preact,
+                               float* colsum, int64_t M, int64_t N, int64_t K, int64_t lda, int64_t ldb, int64_t ldc,
+                               int64_t a_rows_readable, int64_t side_rows_readable, int a_layout, int b_layout, int act, int dtype,
+                               int impl, void* stream) {
+  const int64_t need = (M + 255) / 256 * 256;
+  const bool has_side = addend != nullptr || act == MMRCA_ACT_MUL;
+  MMRCA_REQUIRE(a_rows_readable >= M && (!has_side || side_rows_readable >= M), "gemm_rows: readable rows below M");
+  bool vouched = true;
+  if (impl == MMRCA_GEMM_MFMA256 && a_layout == MMRCA_ROWK) {
+    if (a_rows_readable < need)
+      return mmrca_fail(-4, "gemm_rows: the 256x256 kernel reads %lld rows of A, only %lld are readable", (long long)need, (long long)a_rows_readable);
+    if (has_side && side_rows_readable < need)
+      return mmrca_fail(-4, "gemm_rows: the 256x256 kernel reads %lld rows of the side operand, only %lld are readable", (long long)need, (long long)side_rows_readable);
+  }
+  bool done = false;
+  if (int rc = gemm_dispatch(A, B, C, bias, addend, preact, M, N, K, lda, ldb, ldc, a_layout, b_layout, act, 0, dtype, impl, stream,
+                             colsum, colsum ? &done : nullptr, vouched))
+    return rc;
+  if (colsum && !done) return mmrca_colsum_accum(C, colsum, M, N, ldc, dtype, stream);
   return 0;
 }

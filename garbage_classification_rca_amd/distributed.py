@@ -133,6 +133,9 @@ class GradSync:
         self.enabled = True
         self._acc_lo, self._acc_hi = None, None
         self.bytes_reduced = 0
+        self.launches = 0
+        # bench.py's self-diagnosis: with `timing` on, finish() brackets its waits with events on the compute stream
+        self.timing, self.wait_events = False, []
 
     def span_ready(self, lo: int, hi: int, flush: bool = False):
         """Called by the engine when grads in [lo, hi) are final.  Adjacent ready spans are merged until a bucket is
@@ -158,16 +161,24 @@ class GradSync:
         work = dist.all_reduce(wire, op=op, async_op=True)
         self.pending.append((work, view, op, wire))
         self.bytes_reduced += wire.numel() * wire.element_size()
+        self.launches += 1
         self._acc_lo = self._acc_hi = None
 
     def finish(self):
         self._flush()
+        timed = self.timing and self.pending and torch.cuda.is_available() and self.g.is_cuda
+        if timed:
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
         for work, view, op, wire in self.pending:
             work.wait()
             if wire is not view:
                 view.copy_(wire)
             if op == dist.ReduceOp.SUM:
                 view.div_(self.world)
+        if timed:
+            e1.record()
+            self.wait_events.append((e0, e1))
         self.pending.clear()
 
 

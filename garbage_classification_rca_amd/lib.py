@@ -50,6 +50,7 @@ _i64, _i32, _f32, _vp, _u64 = C.c_int64, C.c_int, C.c_float, C.c_void_p, C.c_uin
 _SIGS = {
     "mmrca_gemm": [_vp] * 6 + [_i64] * 6 + [_i32] * 6 + [_vp],
     "mmrca_gemm_colsum": [_vp] * 7 + [_i64] * 6 + [_i32] * 5 + [_vp],
+    "mmrca_gemm_rows": [_vp] * 7 + [_i64] * 8 + [_i32] * 5 + [_vp],
     "mmrca_gemm_splitk": [_vp] * 4 + [_i64] * 7 + [_i32] * 2 + [_vp],
     "mmrca_gemm_x3": [_vp] * 10 + [_i64] * 6 + [_i32] * 5 + [_vp],
     "mmrca_gemm_splitk_x3": [_vp] * 6 + [_i64] * 7 + [_i32] * 2 + [_vp],
@@ -187,9 +188,18 @@ def gemm_is_mfma(M, N, K, a_layout, dtype, impl):
 
 
 def gemm(A, B, Cout, *, bias=None, addend=None, preact=None, M, N, K, lda, ldb, ldc, a_layout=ROWK, b_layout=ROWK,
-         act=ACT_NONE, accum=False, dtype, impl=IMPL_AUTO, colsum=None):
-    """colsum (fp32 [N], +=): column sums of the stored C ride on the GEMM epilogue (mmrca_gemm_colsum)"""
+         act=ACT_NONE, accum=False, dtype, impl=IMPL_AUTO, colsum=None, rows_readable=None):
+    """colsum (fp32 [N], +=): column sums of the stored C ride on the GEMM epilogue (mmrca_gemm_colsum).
+    rows_readable = (rows of A, rows of the side operand) that exist in memory: required for impl=IMPL_MFMA256 with a ragged M
+    (mmrca_gemm_rows; the 256x256 kernel reads whole 256-row tiles)"""
     _dev(A, "gemm A")
+    if rows_readable is not None:
+        if accum:
+            raise MmrcaError("gemm: rows_readable is not available in accumulate mode")
+        _check(load().mmrca_gemm_rows(ptr(A), ptr(B), ptr(Cout), ptr(bias), ptr(addend), ptr(preact), ptr(colsum), M, N, K, lda, ldb, ldc,
+                                      int(rows_readable[0]), int(rows_readable[1]), a_layout, b_layout, act, dtype, impl, stream_ptr()),
+               "mmrca_gemm_rows")
+        return
     # matrix-core launches: the bf16 MFMA kernels, and in fp32 mode the general kernel on the fp32 matrix cores
     prof = GEMM_PROFILE is not None and (gemm_is_mfma(M, N, K, a_layout, dtype, impl) or (dtype == F32 and impl != IMPL_REF))
     if prof:

@@ -161,7 +161,7 @@ def main(argv=None):
     global_model = MM_RCA(_num_classes, args.model_dropout, args.image_text_dropout, args.image_prob_dropout,
                           args.num_neurons_FC, args.text_model, _batch_size, args.reverse, args.features_only,
                           args.cross_attention_only, image_model_name=args.image_model,
-                          dtype=torch.bfloat16 if args.dtype == "bf16" else torch.float32, device=device, image_size=args.image_size)
+                          dtype={"bf16": torch.bfloat16, "fp32": torch.float32, "bf16x3": "bf16x3"}[args.dtype], device=device, image_size=args.image_size)
     print("Num total parameters of the model: {}".format(count_parameters(global_model)))
     wandb = _wandb() if is_main else _NoWandb()
     wandb.init(project="Garbage Classification Both - MI355X", config=dict(args.__dict__))
@@ -220,8 +220,10 @@ def main(argv=None):
                                            collate_fn=collate_decoded if gpu_pre else None, multiprocessing_context=ctx,
                                            persistent_workers=bool(ctx)), sampler
 
+    # The fine-tuning loaders are built when that phase starts, after the first phase's loaders are shut down: with persistent
+    # (fork-server) workers all four at once would keep up to 4 x num_workers processes alive, the idle ones competing with the
+    # decode workers that feed the GPU input path.
     (dl_train, s_train), (dl_val, _) = loader(train_data, _batch_size, True), loader(val_data, _batch_size, False)
-    (dl_train_ft, s_train_ft), (dl_val_ft, _) = loader(train_data, _batch_size_FT, True), loader(val_data, _batch_size_FT, False)
 
     if args.opt == "adamw":
         optimizer = FlatAdamW(global_model, lr=args.lr, weight_decay=args.reg)
@@ -279,6 +281,13 @@ def main(argv=None):
             p.requires_grad = True
         for group in optimizer.param_groups:                            # :700-701
             group['lr'] = args.lr / args.fraction_lr
+        for dl in (dl_train, dl_val):           # stop the first phase's persistent workers
+            it = getattr(dl, "_iterator", None)
+            if it is not None and hasattr(it, "_shutdown_workers"):
+                it._shutdown_workers()
+            dl._iterator = None
+        del dl_train, dl_val
+        (dl_train_ft, s_train_ft), (dl_val_ft, _) = loader(train_data, _batch_size_FT, True), loader(val_data, _batch_size_FT, False)
         one_phase(args.ft_epochs, dl_train_ft, s_train_ft, dl_val_ft, _batch_size_FT, args.acc_steps_FT, True)
     if world > 1:
         torch.distributed.barrier()

@@ -68,7 +68,9 @@ def build_parser() -> argparse.ArgumentParser:
             p.add_argument("--" + flag, action=argparse.BooleanOptionalAction, default=default, help=text)
         else:
             p.add_argument("--" + flag, type=cast[kind], default=default, help=text)
-    p.add_argument("--dtype", type=str, default="bf16", choices=["bf16", "fp32"], help="compute dtype of the HIP path")
+    p.add_argument("--dtype", type=str, default="bf16", choices=["bf16", "fp32", "bf16x3"],
+                   help="compute mode of the HIP path: bf16 (fastest) | bf16x3 (the reference's fp32 arithmetic to ~1e-5 on the logits: fp32 "
+                        "storage, every nn.Linear as a three-pass split-bf16 product) | fp32 (every GEMM on the fp32 matrix cores)")
     return p
 
 

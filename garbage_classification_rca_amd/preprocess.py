@@ -209,7 +209,8 @@ class GpuImagePipeline:
         # caller forks its DataLoader workers (the first launch from a process with 16 live forked children took 20 s on the
         # MI355X box; after this warm-up every call is ~10 ms).
         tiny = np.zeros((8, 8, 3), dtype=np.uint8)
-        self(tiny[None].repeat(2, 0), aug=[dict(angle=10.0, blur_k=3, bc=(1.0, 0.0), sharpen=(0.3, 1.0), persp=np.full((4, 2), 0.05), scale=0.9), {}])
+        warm = [dict(angle=10.0, blur_k=3, bc=(1.0, 0.0), sharpen=(0.3, 1.0), persp=np.full((4, 2), 0.05), scale=0.9), {}][:min(2, self.max_batch)]
+        self(tiny[None].repeat(len(warm), 0), aug=warm)          # (a --batch_size 1 pipeline has room for one image only)
         self([tiny])
         torch.cuda.synchronize(self.device)
 

@@ -166,6 +166,11 @@ class Blip2QFormerEngine:
             assert o[1][0] == o[0][0] + o[0][2] and o[2][0] == o[1][0] + o[1][2], "q/k/v weights not adjacent"
             o = [self.store.offsets[p + n + ".bias"] for n in ("query", "key", "value")]
             assert o[1][0] == o[0][0] + o[0][2] and o[2][0] == o[1][0] + o[1][2], "q/k/v biases not adjacent"
+            if i % spec.cross_freq == 0:    # the cross-attention K|V pair is read as one fused [2Q, D] operand with a [2Q] bias as well
+                pc = f"qformer.encoder.layer.{i}.crossattention.attention."
+                for leaf in (".weight", ".bias"):
+                    o = [self.store.offsets[pc + n + leaf] for n in ("key", "value")]
+                    assert o[1][0] == o[0][0] + o[0][2], f"cross-attention key/value {leaf[1:]}s not adjacent (q_dim and q_dim * v_dim must be multiples of 8)"
         # the trainable classifier (q_former_training.py:24-31): fp32 parameters, gradients and AdamW moments, one flat
         # tensor each, weight [n_classes, 768] then bias [n_classes]
         C, Q = spec.n_classes, spec.q_dim

@@ -33,8 +33,9 @@ enum { MMRCA_ACT_NONE = 0, MMRCA_ACT_GELU = 1,
  * KROW = [contraction][rows] (rows contiguous) */
 enum { MMRCA_ROWK = 0, MMRCA_KROW = 1 };
 enum { MMRCA_GEMM_AUTO = 0, MMRCA_GEMM_REF = 1, MMRCA_GEMM_MFMA = 2 /* 128x128 tiles */,
-       MMRCA_GEMM_MFMA256 = 3 /* 256x256 tiles, persistent workgroups; A row-major with round_up(M, 256) READABLE rows (AUTO only
-                                  picks it when M % 256 == 0), N % 256 == 0, K % 64 == 0, K >= 128, operands < 4 GiB */,
+       MMRCA_GEMM_MFMA256 = 3 /* 256x256 tiles, persistent workgroups; A row-major, M % 256 == 0 (a ragged M only through
+                                  mmrca_gemm_rows, which checks that round_up(M, 256) rows are readable; AUTO only picks the
+                                  kernel when M % 256 == 0), N % 256 == 0, K % 64 == 0, K >= 128, operands < 4 GiB */,
        MMRCA_GEMM_MFMA_PERSIST = 4 /* reserved: experimental kernel of round 1, removed (rejected with an error) */,
        MMRCA_GEMM_MFMA_BK32 = 5 /* 128x128x32 tiles, 32 KiB LDS: four blocks per CU */,
        MMRCA_GEMM_MFMA_1STAGE = 6 /* 128x128x64 tiles, single LDS stage (32 KiB): four blocks per CU */,
@@ -67,6 +68,18 @@ int mmrca_gemm(const void* A, const void* B, void* C, const void* bias, const vo
 int mmrca_gemm_colsum(const void* A, const void* B, void* C, const void* bias, const void* addend, void* preact,
                       float* colsum, int64_t M, int64_t N, int64_t K, int64_t lda, int64_t ldb, int64_t ldc,
                       int a_layout, int b_layout, int act, int dtype, int impl, void* stream);
+
+/* mmrca_gemm (colsum == NULL) / mmrca_gemm_colsum with the row contract of MMRCA_GEMM_MFMA256 made explicit.  That kernel
+ * streams whole 256-row tiles: with M % 256 != 0 it READS (never stores) rows M .. round_up(M, 256) - 1 of A and of the side
+ * operand (addend, or preact under MMRCA_ACT_MUL).  mmrca_gemm / mmrca_gemm_colsum therefore reject impl = MMRCA_GEMM_MFMA256
+ * with a ragged M (-4); here the caller states how many rows of each exist, and a request they do not cover is rejected
+ * before any launch.  (AUTO needs none of this: it only picks the kernel for whole tiles.)  The other precondition of the
+ * tiled kernels cannot be checked from pointers: a KROW operand contracts over its ROW index in 64-row steps, so K must be a
+ * multiple of 64 and a caller that rounds its row count up owns zero-filled rows up to that K (wrong sums otherwise, no fault). */
+int mmrca_gemm_rows(const void* A, const void* B, void* C, const void* bias, const void* addend, void* preact,
+                    float* colsum, int64_t M, int64_t N, int64_t K, int64_t lda, int64_t ldb, int64_t ldc,
+                    int64_t a_rows_readable, int64_t side_rows_readable, int a_layout, int b_layout, int act, int dtype,
+                    int impl, void* stream);
 
 /* Weight gradient on 256x256 tiles with the contraction split over workgroups: C[M,N] (fp32) += A (.) B over K
  * (torch autograd of nn.Linear: dW = dY^T X; same call sites as mmrca_gemm's accumulate mode).  bf16 operands, either

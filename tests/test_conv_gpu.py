@@ -295,13 +295,35 @@ def test_backbone_bf16_close_to_oracle():
     enc.release()
 
 
-@pytest.mark.parametrize("image_model,size", [("eff_v2_medium", 64), ("shuffle_net", 64)])
-def test_mm_rca_with_conv_backbone_fp32_logits_and_train_step(image_model, size):
+def test_one_pass_batchnorm_statistics_survive_an_outlier_first_row():
+    """The bf16 one-pass BatchNorm moments subtract a shift before squaring.  With a single row as the shift (round 2: row 0 --
+    the top-left pixel of image 0, a zero-padded border) a channel whose first row sits 500 sigma from its mean cancels in fp32
+    over many rows; the shift is now the mean of 16 rows spread over the tensor.  Channel mean 50, sigma 0.1, first row 0."""
+    R, C, eps = 400000, 64, 1e-5
+    g = torch.Generator().manual_seed(5)
+    x = (torch.randn(R, C, generator=g) * 0.1 + 50.0)
+    x[0] = 0.0
+    xd = x.cuda().to(torch.bfloat16)
+    mean, rstd = torch.empty(C, device="cuda"), torch.empty(C, device="cuda")
+    rm, rv = torch.zeros(C, device="cuda"), torch.ones(C, device="cuda")
+    L.bn_stats(xd, mean, rstd, rm, rv, R, C, C, eps, 0.1, True, L.BF16)
+    x64 = xd.double()
+    mu, var = x64.mean(0), x64.var(0, unbiased=False)
+    assert rel(mean, mu) < 1e-6
+    got_var = 1.0 / rstd.double() ** 2 - eps
+    assert float(((got_var - var).abs() / var).max()) < 1e-3, float(((got_var - var).abs() / var).max())
+
+
+@pytest.mark.parametrize("text_model,image_model,size", [("distilbert", "eff_v2_medium", 64), ("distilbert", "shuffle_net", 64),
+                                                         ("roberta", "eff_v2_large", 64)])
+def test_mm_rca_with_conv_backbone_fp32_logits_and_train_step(text_model, image_model, size):
     """MM_RCA over a conv image backbone end to end: fp32 logits within the north-star 1e-3 of the oracle (eval mode), and a
-    train-mode forward/backward that reaches every trainable parameter."""
-    eng = MMRCAEngine("distilbert", image_model, 4, True, 0, torch.float32, image_size=size)
+    train-mode forward/backward that reaches every trainable parameter.  ("roberta", "eff_v2_large") is BASELINE.json
+    configs[2]'s pairing (multimodal_model.py:113-126 with the RoBERTa CLS-pooling convention of text_models.py:43-72) as ONE
+    model; for it a bf16 train step (the benchmarked precision of configs[2]) runs as well."""
+    eng = MMRCAEngine(text_model, image_model, 4, True, 0, torch.float32, image_size=size)
     eng.init_parameters(0)
-    orc = O.build_oracle("distilbert", image_model, True, False, False, drop_ratio=0.0, enc_dropout=0.0).eval()
+    orc = O.build_oracle(text_model, image_model, True, False, False, drop_ratio=0.0, enc_dropout=0.0).eval()
     sd = {k: eng.arena.view(k).detach().cpu().clone() for k in eng.param_keys}
     orc.text_model.load_flat(sd, "text_model.")
     isd = {k[len("image_model."):]: v for k, v in sd.items() if k.startswith("image_model.")}
@@ -311,6 +333,8 @@ def test_mm_rca_with_conv_backbone_fp32_logits_and_train_step(image_model, size)
     from garbage_classification_rca_amd.procedural import synth_captions
     B = 3
     ids, mask = (torch.from_numpy(a) for a in synth_captions(B, 24, seed=1))
+    if text_model == "roberta":
+        ids = ids.clone(); ids[mask == 0] = 1          # RoBERTa pads with id 1
     images = torch.randn(B, 3, size, size, generator=torch.Generator().manual_seed(3))
     logits = eng.forward(ids.cuda(), mask.cuda(), images.cuda(), save=False, bn_train=False)
     with torch.no_grad():
@@ -324,6 +348,20 @@ def test_mm_rca_with_conv_backbone_fp32_logits_and_train_step(image_model, size)
     lo, hi = eng.groups["image_emb"]
     assert float(eng.arena.g[lo:hi].abs().max()) > 0
     eng.release_buffers()
+    if text_model == "roberta":
+        e16 = MMRCAEngine(text_model, image_model, 4, True, 0, torch.bfloat16, image_size=size)
+        e16.load_arrays(sd)
+        l16 = e16.forward(ids.cuda(), mask.cuda(), images.cuda(), save=False, bn_train=False)
+        assert rel(l16, ref) < 5e-2, rel(l16, ref)         # bf16 bound of this suite
+        l16 = e16.forward(ids.cuda(), mask.cuda(), images.cuda(), drop_p=0.6, seed=5, save=True, enc_drop_p=0.1, bn_train=True)
+        e16.arena.g.zero_()
+        e16.backward(torch.randn(B, 4, device="cuda") * 0.1)
+        torch.cuda.synchronize()
+        assert torch.isfinite(l16).all() and torch.isfinite(e16.arena.g).all()
+        for grp in ("image_emb", "text_emb", "head"):
+            lo, hi = e16.groups[grp]
+            assert float(e16.arena.g[lo:hi].abs().max()) > 0, grp
+        e16.release_buffers()
 
 
 def test_facade_state_dict_of_the_default_image_model_has_the_reference_layout_and_loads_it():

@@ -496,20 +496,6 @@ def test_cfg4_vit_l16_bert_cross_attention_only_fp32_logits():
     eng.release_buffers()
 
 
-def test_cfg3_text_side_roberta_bf16_step_runs():
-    """configs[2] pairs RoBERTa-base with EfficientNetV2-L; the conv backbone is not built, the
-    RoBERTa text path is: one bf16 train step with ViT-B/16 standing in for the image encoder."""
-    eng = MMRCAEngine("roberta", "transformer_B16", 4, True, 0, torch.bfloat16)
-    eng.init_parameters(0)
-    ids, mask, images = _inputs(2, 32)
-    ids = ids.clone(); ids[ids == 0] = 1          # RoBERTa pads with id 1
-    logits = eng.forward(ids.cuda(), mask.cuda(), images.cuda(), enc_drop_p=0.1, seed=3)
-    eng.backward(torch.randn(2, 4, device="cuda") * 0.1)
-    torch.cuda.synchronize()
-    assert torch.isfinite(logits).all() and torch.isfinite(eng.arena.g).all()
-    eng.release_buffers()
-
-
 def test_two_rank_data_parallel_rehearsal_keeps_replicas_identical():
     """N>1 path of bench.py (sharded synthetic data, overlapped gradient all-reduce over the flat arena, fused SGD) with
     two ranks sharing this one GPU and gloo standing in for RCCL: after several steps both replicas hold bit-identical
@@ -530,10 +516,12 @@ def test_two_rank_data_parallel_rehearsal_keeps_replicas_identical():
     assert d["n_gpus"] == 2 and d["config"]["global_batch"] == 16 and d["scaling"] == "weak"
 
 
-def test_end_to_end_training_driver_and_evaluator_on_a_tiny_folder(tmp_path):
-    """Drop-in plumbing on real files (the shape of BASELINE configs[0], with ViT-B/16 for the image side):
-    folder dataset -> main_both.py two-phase loop (frozen epoch, fine-tune epoch, four accuracy passes, best-val
-    checkpoint with the reference's file-name pattern) -> calculate_test_accuracy_both.py on that checkpoint."""
+@pytest.mark.parametrize("image_model", ["transformer_B16", "shuffle_net"])
+def test_end_to_end_training_driver_and_evaluator_on_a_tiny_folder(tmp_path, image_model):
+    """Drop-in plumbing on real files: folder dataset -> main_both.py two-phase loop (frozen epoch, fine-tune epoch, four
+    accuracy passes, best-val checkpoint with the reference's file-name pattern) -> calculate_test_accuracy_both.py on that
+    checkpoint.  Once with ViT-B/16 (BASELINE configs[1]'s image model) and once with BASELINE configs[0]'s actual pairing,
+    shuffle_net + distilbert at batch 4 (main_image.py:295-302 naming)."""
     import glob
     import subprocess
     import sys
@@ -549,7 +537,7 @@ def test_end_to_end_training_driver_and_evaluator_on_a_tiny_folder(tmp_path):
                 arr[:, :, ci % 3] = 255 - 40 * ci
                 Image.fromarray(arr).save(d / f"{['chip_bag','pizza_box','banana_peel','aa_batteries'][ci]}_{k}.png")
     env = dict(os.environ, PYTHONPATH=root)
-    common = ["--late_fusion=MM_RCA", "--reverse", "--image_model=transformer_B16", "--text_model=distilbert",
+    common = ["--late_fusion=MM_RCA", "--reverse", f"--image_model={image_model}", "--text_model=distilbert", "--image_size", "64" if image_model == "shuffle_net" else "224",
               "--tokens_max_len", "16", "--num_workers", "0", "--dtype", "bf16"]
     r = subprocess.run([sys.executable, os.path.join(root, "main_both.py"), *common, "--dataset_folder_name=Train",
                         "--dataset_folder_name_val=Val", "--epochs", "1", "--ft_epochs", "1", "--batch_size", "4",
@@ -560,7 +548,7 @@ def test_end_to_end_training_driver_and_evaluator_on_a_tiny_folder(tmp_path):
     assert "Starting Fine tuning!!" in r.stdout and "Optimizer step on batch idx" in r.stdout
     assert "Using balanced sampler for training and validation sets" in r.stdout
     assert "CPU image transforms" not in r.stdout          # default: decoded uint8 images -> GpuImagePipeline (all augmentations)
-    ckpts = glob.glob(str(tmp_path / "model_weights" / "distilbert_transformer_B16" / "BEST_model_*_MM_RCA_*.pth"))
+    ckpts = glob.glob(str(tmp_path / "model_weights" / f"distilbert_{image_model}" / "BEST_model_*_MM_RCA_*.pth"))
     assert ckpts, r.stdout[-2000:]
     sd = torch.load(ckpts[0], map_location="cpu")
     assert "cross_attention_1.W_query.weight" in sd and "text_model.embeddings.word_embeddings.weight" in sd

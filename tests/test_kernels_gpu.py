@@ -69,9 +69,12 @@ def _gemm_case(M, N, K, a_layout, b_layout, dt, impl, act=L.ACT_NONE, bias=False
         add_call = add_d
     if b_layout == L.ROWK and Kcall != K:
         Bd = dev(F.pad(Bm, (0, Kcall - K)), dt)
+    rr = None
+    if impl == L.IMPL_MFMA256 and a_layout == L.ROWK and M % 256:     # ragged M on the 256x256 kernel: state the readable rows
+        rr = (Ad.shape[0], add_call.shape[0] if add_call is not None else 0)
     L.gemm(Ad, Bd, Cd, bias=bias_d, addend=add_call, preact=pre_d, M=M, N=N, K=Kcall,
            lda=Ad.shape[1], ldb=Bd.shape[1], ldc=N, a_layout=a_layout, b_layout=b_layout, act=act, accum=accum,
-           dtype=L.dtype_code(dt), impl=impl)
+           dtype=L.dtype_code(dt), impl=impl, rows_readable=rr)
     torch.cuda.synchronize()
     tol = TOL[dt] * (1 if dt == torch.float32 else 1.0)
     assert rel_err(Cd, ref) < tol, (M, N, K, a_layout, b_layout, dt, impl)
@@ -235,19 +238,28 @@ def test_gemm_mfma256_fused_gelu_epilogues_and_colsum(bl):
     bias, add = dev(torch.randn(N, generator=g) * 0.1, dt), dev(torch.randn(M, N, generator=g), dt)
     Y, Gp = torch.empty(M, N, device="cuda", dtype=dt), torch.empty(1024, N, device="cuda", dtype=dt)
     L.gemm(Xp, Wd, Y, bias=bias, preact=Gp, M=M, N=N, K=K, lda=K, ldb=Wd.shape[1], ldc=N, b_layout=bl, act=L.ACT_GELU_SAVE_GRAD,
-           dtype=L.BF16, impl=L.IMPL_MFMA256)
+           dtype=L.BF16, impl=L.IMPL_MFMA256, rows_readable=(Xp.shape[0], 0))
     pre = (X.double() @ Wf.t() + bias.double()).float().requires_grad_(True)
     yr = F.gelu(pre); yr.backward(torch.ones_like(yr))
     assert rel_err(Y, yr.detach()) < TOL[dt] and rel_err(Gp[:M], pre.grad) < TOL[dt]
     C = torch.empty(M, N, device="cuda", dtype=dt)
     db = dev(torch.randn(N, generator=g)); db0 = db.clone()
     L.gemm(Xp, Wd, C, preact=Gp, M=M, N=N, K=K, lda=K, ldb=Wd.shape[1], ldc=N, b_layout=bl, act=L.ACT_MUL,
-           dtype=L.BF16, impl=L.IMPL_MFMA256, colsum=db)
+           dtype=L.BF16, impl=L.IMPL_MFMA256, colsum=db, rows_readable=(Xp.shape[0], Gp.shape[0]))
     assert rel_err(C, (X.double() @ Wf.t()) * Gp[:M].double()) < TOL[dt]
     assert rel_err(db - db0, C.float().sum(0)) < 1e-4
     C2 = torch.empty(M, N, device="cuda", dtype=dt)          # residual addend (the out-projection / FFN2 forward epilogue)
     L.gemm(Xp, Wd, C2, bias=bias, addend=_pad256(add), M=M, N=N, K=K, lda=K, ldb=Wd.shape[1], ldc=N, b_layout=bl, dtype=L.BF16,
-           impl=L.IMPL_MFMA256)
+           impl=L.IMPL_MFMA256, rows_readable=(Xp.shape[0], 1024))
+    # the row contract of the 256x256 kernel is checked before any launch (one call per precondition):
+    with pytest.raises(L.MmrcaError, match="mmrca_gemm_rows"):           # ragged M without a statement of the readable rows
+        L.gemm(Xp, Wd, C2, bias=bias, M=M, N=N, K=K, lda=K, ldb=Wd.shape[1], ldc=N, b_layout=bl, dtype=L.BF16, impl=L.IMPL_MFMA256)
+    with pytest.raises(L.MmrcaError, match="rows of A"):                 # A shorter than the tiles the kernel streams
+        L.gemm(X, Wd, C2, bias=bias, M=M, N=N, K=K, lda=K, ldb=Wd.shape[1], ldc=N, b_layout=bl, dtype=L.BF16, impl=L.IMPL_MFMA256,
+               rows_readable=(M, 0))
+    with pytest.raises(L.MmrcaError, match="side operand"):              # side operand shorter than the tiles
+        L.gemm(Xp, Wd, C2, bias=bias, addend=add, M=M, N=N, K=K, lda=K, ldb=Wd.shape[1], ldc=N, b_layout=bl, dtype=L.BF16,
+               impl=L.IMPL_MFMA256, rows_readable=(Xp.shape[0], M))
     assert rel_err(C2, X.double() @ Wf.t() + bias.double() + add.double()) < TOL[dt]
 
 
@@ -886,6 +898,8 @@ def test_gpu_image_pipeline_matches_oracle_validation_pipeline():
             # same float32 formula; a tap sum that lands within rounding of x.5 may round to the neighbouring uint8 step
             assert d.max() <= 1.0 / 255 / 0.224 + 1e-5 and (d > 1e-5).mean() < 1e-3, (sizes[b], d.max(), (d > 1e-5).mean())
     out2 = GpuImagePipeline(480, 384, max_batch=2, max_pixels=400 * 400)(imgs[:2]).cpu().numpy()     # non-square target
+    one = GpuImagePipeline(224, 224, max_batch=1, max_pixels=512 * 512)       # --batch_size 1: the constructor's warm-up must fit
+    assert np.array_equal(one(imgs[:1]).cpu().numpy(), pipe(imgs[:1]).cpu().numpy())
     for b in range(2):
         ref = T.validation_pipeline(imgs[b], 480, 384)
         assert np.abs(out2[b] - ref).max() <= 1.0 / 255 / 0.224 + 1e-5

@@ -34,7 +34,11 @@ for k in sorted(fe, key=lambda k: -fe[k][0]):
     else:
         row["hbm_bytes_per_launch"] = round(f + w)
     out[k] = row
-res = {"source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) -- python3 bench.py --steps 2 --warmup 1, "
+import hashlib, os
+_h = hashlib.sha256()
+for _f in ("gemm.hip", "gemm256.hip", "gemm_x3.hip", "lds_asm.h", "common.h"):       # = bench.py::gemm_sources_sha256
+    _h.update(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "garbage_classification_rca_amd", "csrc", _f), "rb").read())
+res = {"gemm_sources_sha256": _h.hexdigest(), "source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) -- python3 bench.py --steps 2 --warmup 1, "
                  "MMRCA_CONCURRENT_ENCODERS=0 (one stream)",
        "gemm_hbm_bytes_per_launch_mean": round(gem_b / max(gem_n, 1)), "gemm_launches_seen": gem_n, "kernels": out}
 json.dump(res, open(sys.argv[3], "w"), indent=1)
