@@ -7,7 +7,7 @@ int mmrca_mha_bwd_ref(const void*, const int32_t*, const void*, const void*, con
 bool mmrca_mha_mfma_ok(int S, int dh, int dtype);
 // fp32 on the fp32 matrix cores (attention_f32.hip): what the fp32 / bf16x3 modes run for head dim 64, S <= 208
 bool mmrca_mha_f32m_ok(int S, int dh, int dtype);
-int mmrca_mha_fwd_f32m(const void*, const int32_t*, void*, float*, int, int, int, int, float, float, uint64_t, const int32_t*, hipStream_t);
+int mmrca_mha_fwd_f32m(const void*, const int32_t*, void*, float*, int, int, int, int, float, float, uint64_t, const int32_t*, hipStream_t, void*, void*);
 int mmrca_mha_bwd_f32m(const void*, const int32_t*, const void*, const void*, const float*, void*, int, int, int, int, float, float, uint64_t, const int32_t*, hipStream_t);
 int mmrca_mha_fwd_mfma(const void*, const int32_t*, void*, float*, int, int, int, int, float, float, uint64_t, const int32_t*, hipStream_t);
 int mmrca_mha_bwd_mfma(const void*, const int32_t*, const void*, const void*, const float*, void*, int, int, int, int, float, float, uint64_t, const int32_t*, hipStream_t);
@@ -22,8 +22,20 @@ extern "C" int mmrca_mha_fwd(const void* qkv, const int32_t* key_mask, void* out
   if (impl == MMRCA_GEMM_MFMA && !ok && !mmrca_mha_f32m_ok(S, dh, dtype)) return mmrca_fail(-3, "mha_fwd: S=%d dh=%d dtype=%d does not qualify for the MFMA kernel", S, dh, dtype);
   if (ok && impl != MMRCA_GEMM_REF) return mmrca_mha_fwd_mfma(qkv, key_mask, out, lse, B, H, S, dh, scale, drop_p, drop_seed, cu_seqlens, (hipStream_t)stream);
   if (impl != MMRCA_GEMM_REF && mmrca_mha_f32m_ok(S, dh, dtype))
-    return mmrca_mha_fwd_f32m(qkv, key_mask, out, lse, B, H, S, dh, scale, drop_p, drop_seed, cu_seqlens, (hipStream_t)stream);
+    return mmrca_mha_fwd_f32m(qkv, key_mask, out, lse, B, H, S, dh, scale, drop_p, drop_seed, cu_seqlens, (hipStream_t)stream, nullptr, nullptr);
   return mmrca_mha_fwd_ref(qkv, key_mask, out, lse, B, H, S, dh, scale, drop_p, drop_seed, cu_seqlens, dtype, (hipStream_t)stream);
+}
+
+// fp32 attention forward that also writes the context as two bf16 planes (out_hi + out_lo = out to 2^-17): the operand form of the
+// bf16x3 out-projection GEMM (mmrca_gemm_x3).  fp32 operands, head dim 64, S <= 208 (the fp32-matrix-core kernels); other shapes:
+// call mmrca_mha_fwd and mmrca_split_f32.
+extern "C" int mmrca_mha_fwd_planes(const void* qkv, const int32_t* key_mask, void* out, void* out_hi, void* out_lo, float* lse,
+                                    int B, int H, int S, int dh, float scale, float drop_p, uint64_t drop_seed,
+                                    const int32_t* cu_seqlens, void* stream) {
+  MMRCA_REQUIRE(qkv && out && out_hi && out_lo && lse, "mha_fwd_planes: null pointer");
+  MMRCA_REQUIRE(drop_p >= 0.f && drop_p < 1.f, "mha_fwd_planes: dropout p must be in [0,1)");
+  MMRCA_REQUIRE(B > 0 && H > 0 && mmrca_mha_f32m_ok(S, dh, MMRCA_F32), "mha_fwd_planes: needs head dim 64 and 1 <= S <= 208 (got S=%d dh=%d)", S, dh);
+  return mmrca_mha_fwd_f32m(qkv, key_mask, out, lse, B, H, S, dh, scale, drop_p, drop_seed, cu_seqlens, (hipStream_t)stream, out_hi, out_lo);
 }
 
 static int mha_bwd_impl(const void* qkv, const int32_t* key_mask, const void* out, const void* dout, const float* lse,

@@ -56,7 +56,8 @@ __device__ __forceinline__ float keep_factor(uint64_t seed, uint64_t bh, int Sma
 template <int NKT, bool DROP>
 __global__ void __launch_bounds__(64 * (NKT < F32A_MAX_WAVES ? NKT : F32A_MAX_WAVES))
 mha_fwd_f32m_k(const float* __restrict__ qkv, const int32_t* __restrict__ key_mask, float* __restrict__ out, float* __restrict__ lse,
-               int H, int Smax, float scale, float drop_p, uint64_t drop_seed, const int32_t* __restrict__ cu) {
+               int H, int Smax, float scale, float drop_p, uint64_t drop_seed, const int32_t* __restrict__ cu,
+               bf16_t* __restrict__ out_hi, bf16_t* __restrict__ out_lo) {
   extern __shared__ __attribute__((aligned(16))) float sm[];      // K image (swizzled) | V image (linear) | key bias
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
   const int g = lane >> 4, c = lane & 15;
@@ -137,6 +138,18 @@ mha_fwd_f32m_k(const float* __restrict__ qkv, const int32_t* __restrict__ key_ma
       float* orow = out + ((int64_t)row0 + qi) * ldo + h * F32A_DH + 16 * g;
 #pragma unroll
       for (int r = 0; r < 4; ++r) *reinterpret_cast<f4*>(orow + 4 * r) = (f4){o[0][r] * inv, o[1][r] * inv, o[2][r] * inv, o[3][r] * inv};
+      if (out_hi) {        // bf16x3 mode: the context also as two bf16 planes, the operand form of the out-projection GEMM
+        typedef __attribute__((ext_vector_type(4))) __bf16 b4;
+        const int64_t off = ((int64_t)row0 + qi) * ldo + h * F32A_DH + 16 * g;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          b4 hi, lo;
+#pragma unroll
+          for (int t = 0; t < 4; ++t) { const float v = o[t][r] * inv; hi[t] = (bf16_t)v; lo[t] = (bf16_t)(v - (float)hi[t]); }
+          *reinterpret_cast<b4*>(out_hi + off + 4 * r) = hi;
+          *reinterpret_cast<b4*>(out_lo + off + 4 * r) = lo;
+        }
+      }
       if (g == 0) lse[((int64_t)b * H + h) * Smax + qi] = l > 0.f ? m * scale + __logf(l) : INFINITY;
     }
   }
@@ -321,7 +334,7 @@ bool mmrca_mha_f32m_ok(int S, int dh, int dtype) {
 static int nkt_for(int S) { return S <= 64 ? 4 : (S <= 128 ? 8 : 13); }
 
 int mmrca_mha_fwd_f32m(const void* qkv, const int32_t* key_mask, void* out, float* lse, int B, int H, int S, int dh, float scale,
-                       float drop_p, uint64_t drop_seed, const int32_t* cu, hipStream_t st) {
+                       float drop_p, uint64_t drop_seed, const int32_t* cu, hipStream_t st, void* out_hi, void* out_lo) {
   MMRCA_REQUIRE(mmrca_mha_f32m_ok(S, dh, MMRCA_F32), "mha_fwd(f32 mfma): S=%d dh=%d unsupported", S, dh);
   MMRCA_REQUIRE((((uintptr_t)qkv | (uintptr_t)out) & 15) == 0, "mha_fwd(f32 mfma): operands must be 16-byte aligned");
   const int nkt = nkt_for(S);
@@ -330,7 +343,8 @@ int mmrca_mha_fwd_f32m(const void* qkv, const int32_t* key_mask, void* out, floa
   do {                                                                                                                             \
     (void)hipFuncSetAttribute((const void*)mha_fwd_f32m_k<NKT_, DROP_>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);     \
     hipLaunchKernelGGL((mha_fwd_f32m_k<NKT_, DROP_>), dim3(B * H), dim3(64 * (NKT_ < F32A_MAX_WAVES ? NKT_ : F32A_MAX_WAVES)), lds, st, \
-                       (const float*)qkv, key_mask, (float*)out, lse, H, S, scale, drop_p, drop_seed, cu);                         \
+                       (const float*)qkv, key_mask, (float*)out, lse, H, S, scale, drop_p, drop_seed, cu, (bf16_t*)out_hi,         \
+                       (bf16_t*)out_lo);                                                                                           \
   } while (0)
   const bool drop = drop_p > 0.f;
   if (nkt == 4) { if (drop) LF(4, true); else LF(4, false); }

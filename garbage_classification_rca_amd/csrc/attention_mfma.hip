@@ -803,6 +803,258 @@ mha_bwd_dq_mfma_v_k(const bf16_t* __restrict__ qkv, const bf16_t* __restrict__ o
 }
 
 // ------------------------------------------------------------------------------------------------------
+// backward for the ViT as ONE launch (unmasked, no dropout, padded layout)
+// ------------------------------------------------------------------------------------------------------
+// The two-kernel form reads q|k|v, O and dO twice (~1.0 GB per ViT-B layer at B = 256) where the algorithm needs them once
+// (0.62 GB incl. the dqkv store), and in-kernel stamps (tools/attn_stamps.py) show where a workgroup's time goes: not in the
+// MFMA loops (6-8 k cycles per part with every operand in LDS) but in waiting -- for the staging DMA and for the per-tile
+// operand fragments that come straight from HBM.  One workgroup per (b, h) runs BOTH parts -- the hand-scheduled loops of the two
+// kernels above -- so every operand crosses HBM once.  S and dP are still formed in both orientations (28 MFMA passes
+// instead of the 20 of a single-orientation kernel): the matrix pipe idles ~75 % of these kernels' time, the bytes and the
+// exposed latencies are what count.  No atomics, no cross-wave reduction, same summation order per output element.
+//   SHARE = true (default): two 8-wave workgroups per CU, so one's staging runs under the other's MFMAs.  The image pairs
+//     TIME-SHARE one 56-KiB region: Q | dO (+ the per-query constants, from whole dO / O rows) are staged first for the dK / dV
+//     part, whose key / value fragments come from HBM; after a barrier K | V are staged over them for the dQ part, whose query-side
+//     fragments now hit this XCD's L2 (just staged) and whose row constants sit in LDS.
+//   SHARE = false: one 16-wave workgroup per CU with all four images resident (4 x 28 KiB), no global fragment loads at all;
+//     nothing overlaps its staging, so it is the slower of the two (MMRCA_ATTN_BWD_FUSED=2 selects it).
+template <int NKT, int NW, bool SHARE>
+__global__ void __launch_bounds__(64 * NW, SHARE ? NW / 2 : NW / 4)
+mha_bwd_fused_mfma_v_k(const bf16_t* __restrict__ qkv, const bf16_t* __restrict__ out, const bf16_t* __restrict__ dout,
+                       const float* __restrict__ lse, bf16_t* __restrict__ dqkv, int H, int S, float scale,
+                       unsigned long long* __restrict__ stamps) {
+  // stamps (tools/attn_stamps.py only, nullptr otherwise): s_memtime of wave 0 at kernel entry, after the first staging barrier,
+  // between the two parts and at exit, [block][4]; written to a buffer nothing else reads
+  unsigned long long t_in = 0, t_staged = 0, t_mid = 0;
+  if (stamps) t_in = __builtin_amdgcn_s_memtime();
+  extern __shared__ __attribute__((aligned(16))) char sm[];
+  constexpr int Spad = NKT * 16, IMG = Spad * 128;
+  constexpr int KB = 0, VB = IMG, QB = SHARE ? 0 : 2 * IMG, DB = SHARE ? IMG : 3 * IMG, ST = SHARE ? 2 * IMG : 4 * IMG;
+  float* lse_s = reinterpret_cast<float*>(sm + ST);          // -lse / c1 in the exp2 domain (c1 * (S + this) = c1 S - L)
+  float* dsum_s = lse_s + Spad;                              // -rowsum(dO * O)
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, g = lane >> 4, l16 = lane & 15;
+  const int b = blockIdx.x / H, h = blockIdx.x % H;
+  const int row0 = b * S;
+  const int64_t ld = 3LL * H * AT_DH, ldo = (int64_t)H * AT_DH;
+  const bf16_t* Q = qkv + (int64_t)row0 * ld + h * AT_DH;
+  const bf16_t* Kp = Q + H * AT_DH;
+  const bf16_t* Vp = Kp + H * AT_DH;
+  const bf16_t* O = out + (int64_t)row0 * ldo + h * AT_DH;
+  const bf16_t* dO = dout + (int64_t)row0 * ldo + h * AT_DH;
+  const float c1 = scale * LOG2E, inv_c1 = 1.f / c1;
+  const unsigned lds0 = (unsigned)(uintptr_t)(at_lds_void*)sm;
+  const unsigned rsw = (l16 >> 1) & 3, ksw = (l16 >> 1) & 7;
+  const unsigned roff0 = l16 * 128 + ((((unsigned)(g >> 1)) ^ rsw) << 5) + ((g & 1) << 4);           // TR image rows, k-step 0: chunk c = g
+  const unsigned roff1 = l16 * 128 + ((((unsigned)(2 + (g >> 1))) ^ rsw) << 5) + ((g & 1) << 4);     // k-step 1: chunk c = 4 + g
+  const int qq = l16 >> 2, pp = l16 & 3, vsw = (2 * g + (qq >> 1)) & 3;
+  const int nt = (S + 15) / 16;
+
+  auto stage_key_side = [&]() {
+    stage_rows(sm + KB, IMG_TR, Kp, ld, S, Spad);      // row reads for S^T (2-way), transposed reads for dQ^T
+    stage_rows(sm + VB, IMG_ROW, Vp, ld, S, Spad);     // row reads for dP^T
+  };
+  auto stage_query_side = [&]() {
+    stage_rows(sm + QB, IMG_TR, Q, ld, S, Spad);
+    stage_rows(sm + DB, IMG_TR, dO, ldo, S, Spad);
+    for (int q = threadIdx.x; q < Spad; q += blockDim.x) {
+      float a = 0.f, L = INFINITY;                 // padded query rows: lse=+inf -> P = 0
+      if (q < S) {
+        L = lse[((int64_t)b * H + h) * S + q] * LOG2E;
+#pragma unroll
+        for (int c = 0; c < 8; ++c) {
+          const bf16x8 x = *reinterpret_cast<const bf16x8*>(dO + (int64_t)q * ldo + c * 8);
+          const bf16x8 y = *reinterpret_cast<const bf16x8*>(O + (int64_t)q * ldo + c * 8);
+#pragma unroll
+          for (int j = 0; j < 8; ++j) a += (float)x[j] * (float)y[j];
+        }
+      }
+      lse_s[q] = -L * inv_c1; dsum_s[q] = -a;
+    }
+  };
+
+  // ---- dQ: a wave's query tile(s) against every key pair (K | V images, row constants in LDS)
+  auto dq_part = [&]() {
+    const unsigned kb0 = lds0 + KB + roff0, kb1 = lds0 + KB + roff1;
+    const unsigned vb0 = lds0 + VB + l16 * 128 + (((unsigned)g ^ ksw) << 4), vb1 = lds0 + VB + l16 * 128 + (((unsigned)(4 + g) ^ ksw) << 4);
+    unsigned tk[4];
+#pragma unroll
+    for (int dt = 0; dt < 4; ++dt) tk[dt] = lds0 + KB + (4 * g + qq) * 128 + ((dt ^ vsw) << 5) + 8 * pp;
+    for (int qt = wave; qt < nt; qt += NW) {
+      const int q0 = qt * 16;
+      const int q = q0 + l16;
+      bf16x8 qf0, qf1, df0, df1;
+      if constexpr (SHARE) {                          // the Q | dO images are gone: fragments from global memory (L2: staged moments ago)
+        qf0 = frag_global(Q, ld, q0, S, 0, lane); qf1 = frag_global(Q, ld, q0, S, 1, lane);
+        df0 = frag_global(dO, ldo, q0, S, 0, lane); df1 = frag_global(dO, ldo, q0, S, 1, lane);
+      } else {
+        qf0 = frag_rows(sm + QB, IMG_TR, q0, 0, lane); qf1 = frag_rows(sm + QB, IMG_TR, q0, 1, lane);
+        df0 = frag_rows(sm + DB, IMG_TR, q0, 0, lane); df1 = frag_rows(sm + DB, IMG_TR, q0, 1, lane);
+      }
+      const float nl = lse_s[q], nd = dsum_s[q];      // row constants as the initial accumulators: S' = S - L/c1, dP' = dP - D
+      f32x4 dq[4];
+#pragma unroll
+      for (int dt = 0; dt < 4; ++dt) dq[dt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+      static_for<0, NKT / 2>([&](auto ic) {
+        constexpr int u = decltype(ic)::value;
+        bf16x8 ka0, ka1, kc0, kc1, va0, va1, vc0, vc1;         // key tiles 2u (a) and 2u+1 (c), k-steps 0 / 1
+        AT_DS_B128_OFF(ka0, kb0, (2 * u) * 2048);     AT_DS_B128_OFF(va0, vb0, (2 * u) * 2048);
+        AT_DS_B128_OFF(kc0, kb0, (2 * u + 1) * 2048); AT_DS_B128_OFF(vc0, vb0, (2 * u + 1) * 2048);
+        AT_DS_B128_OFF(ka1, kb1, (2 * u) * 2048);     AT_DS_B128_OFF(va1, vb1, (2 * u) * 2048);
+        AT_DS_B128_OFF(kc1, kb1, (2 * u + 1) * 2048); AT_DS_B128_OFF(vc1, vb1, (2 * u + 1) * 2048);
+        f32x4 sa = {nl, nl, nl, nl}, sc_ = {nl, nl, nl, nl}, pa = {nd, nd, nd, nd}, pc = {nd, nd, nd, nd};
+        asm volatile("s_waitcnt lgkmcnt(4)" : "+v"(ka0), "+v"(va0), "+v"(kc0), "+v"(vc0));
+        sa = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ka0, qf0, sa, 0, 0, 0);       // S'^T[key][q]
+        pa = __builtin_amdgcn_mfma_f32_16x16x32_bf16(va0, df0, pa, 0, 0, 0);       // dP'^T[key][q]
+        sc_ = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kc0, qf0, sc_, 0, 0, 0);
+        pc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vc0, df0, pc, 0, 0, 0);
+        asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(ka1), "+v"(va1), "+v"(kc1), "+v"(vc1));
+        sa = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ka1, qf1, sa, 0, 0, 0);
+        pa = __builtin_amdgcn_mfma_f32_16x16x32_bf16(va1, df1, pa, 0, 0, 0);
+        sc_ = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kc1, qf1, sc_, 0, 0, 0);
+        pc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vc1, df1, pc, 0, 0, 0);
+        bf16x4 klo[4], khi[4];                       // K^T fragments of the dQ product: in flight under the exponentials
+#pragma unroll
+        for (int dt = 0; dt < 4; ++dt) { AT_DS_TR_OFF(klo[dt], tk[dt], u * 4096); AT_DS_TR_OFF(khi[dt], tk[dt], u * 4096 + 2048); }
+        f32x4 dsa, dsc;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          float xa = sa[r] * c1, xc = sc_[r] * c1;
+          if (u == NKT / 2 - 1) {                    // only the last key pair holds keys beyond S (S > 16 (NKT - 2))
+            xa = (2 * u) * 16 + 4 * g + r < S ? xa : -INFINITY;
+            xc = (2 * u + 1) * 16 + 4 * g + r < S ? xc : -INFINITY;
+          }
+          dsa[r] = __builtin_amdgcn_exp2f(xa) * pa[r];        // p (dP - D); a padded query has lse = +inf -> p = 0
+          dsc[r] = __builtin_amdgcn_exp2f(xc) * pc[r];        // (the score scale is applied to dQ below)
+        }
+        const bf16x8 dsf = pack_pair(dsa, dsc);
+        asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(klo[0]), "+v"(khi[0]), "+v"(klo[1]), "+v"(khi[1]), "+v"(klo[2]), "+v"(khi[2]), "+v"(klo[3]), "+v"(khi[3]));
+#pragma unroll
+        for (int dt = 0; dt < 4; ++dt)
+          dq[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_shufflevector(klo[dt], khi[dt], 0, 1, 2, 3, 4, 5, 6, 7), dsf, dq[dt], 0, 0, 0);   // dQ^T[d][q]
+      });
+      bf16_t* drow = dqkv + ((int64_t)row0 + (q < S ? q : S - 1)) * ld + h * AT_DH;
+#pragma unroll
+      for (int dt = 0; dt < 4; ++dt) {
+        bf16x4 v;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) v[r] = (bf16_t)(dq[dt][r] * scale);
+        if (q < S) *reinterpret_cast<bf16x4*>(drow + dt * 16 + 4 * g) = v;
+      }
+    }
+  };
+
+  // ---- dK / dV: a wave's key tile(s) against every query pair (Q | dO images, row constants in LDS)
+  auto dkv_part = [&]() {
+    unsigned tq[4], td[4];
+#pragma unroll
+    for (int dt = 0; dt < 4; ++dt) {
+      const unsigned o = (4 * g + qq) * 128 + ((dt ^ vsw) << 5) + 8 * pp;
+      tq[dt] = lds0 + QB + o; td[dt] = lds0 + DB + o;
+    }
+    const unsigned qb0 = lds0 + QB + roff0, qb1 = lds0 + QB + roff1, db0 = lds0 + DB + roff0, db1 = lds0 + DB + roff1;
+    const unsigned lb = lds0 + ST + 16 * g, sb = lb + Spad * 4;      // row constants of queries 16 qt + 4 g + r
+    for (int kt = wave; kt < nt; kt += NW) {
+      const int k0 = kt * 16;
+      const int key = k0 + l16;
+      const float kbias = key < S ? 0.f : -INFINITY;                        // this lane's key
+      bf16x8 kf0, kf1, vf0, vf1;
+      if constexpr (SHARE) {
+        kf0 = frag_global(Kp, ld, k0, S, 0, lane); kf1 = frag_global(Kp, ld, k0, S, 1, lane);
+        vf0 = frag_global(Vp, ld, k0, S, 0, lane); vf1 = frag_global(Vp, ld, k0, S, 1, lane);
+      } else {
+        kf0 = frag_rows(sm + KB, IMG_TR, k0, 0, lane); kf1 = frag_rows(sm + KB, IMG_TR, k0, 1, lane);
+        vf0 = frag_rows(sm + VB, IMG_ROW, k0, 0, lane); vf1 = frag_rows(sm + VB, IMG_ROW, k0, 1, lane);
+      }
+      f32x4 dk[4], dv[4];
+#pragma unroll
+      for (int dt = 0; dt < 4; ++dt) { dk[dt] = (f32x4){0.f, 0.f, 0.f, 0.f}; dv[dt] = (f32x4){0.f, 0.f, 0.f, 0.f}; }
+      static_for<0, NKT / 2>([&](auto ic) {
+        constexpr int u = decltype(ic)::value;
+        bf16x8 qa0, qa1, qb0_, qb1_, da0, da1, db0_, db1_;      // row fragments of query tiles 2u (a) and 2u+1 (b), k-steps 0 / 1
+        f32x4 sa, sb_, pa, pb;                                  // S' and dP' accumulators, started from the row constants
+        AT_DS_B128_OFF(qa0, qb0, (2 * u) * 2048);     AT_DS_B128_OFF(da0, db0, (2 * u) * 2048);
+        AT_DS_B128_OFF(qb0_, qb0, (2 * u + 1) * 2048); AT_DS_B128_OFF(db0_, db0, (2 * u + 1) * 2048);
+        AT_DS_B128_OFF(sa, lb, (2 * u) * 64);          AT_DS_B128_OFF(pa, sb, (2 * u) * 64);
+        AT_DS_B128_OFF(sb_, lb, (2 * u + 1) * 64);     AT_DS_B128_OFF(pb, sb, (2 * u + 1) * 64);
+        AT_DS_B128_OFF(qa1, qb1, (2 * u) * 2048);     AT_DS_B128_OFF(da1, db1, (2 * u) * 2048);
+        AT_DS_B128_OFF(qb1_, qb1, (2 * u + 1) * 2048); AT_DS_B128_OFF(db1_, db1, (2 * u + 1) * 2048);
+        asm volatile("s_waitcnt lgkmcnt(4)" : "+v"(qa0), "+v"(da0), "+v"(qb0_), "+v"(db0_), "+v"(sa), "+v"(pa), "+v"(sb_), "+v"(pb));
+        sa = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qa0, kf0, sa, 0, 0, 0);       // S'[q][key]
+        pa = __builtin_amdgcn_mfma_f32_16x16x32_bf16(da0, vf0, pa, 0, 0, 0);       // dP'[q][key]
+        sb_ = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qb0_, kf0, sb_, 0, 0, 0);
+        pb = __builtin_amdgcn_mfma_f32_16x16x32_bf16(db0_, vf0, pb, 0, 0, 0);
+        asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(qa1), "+v"(da1), "+v"(qb1_), "+v"(db1_));
+        sa = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qa1, kf1, sa, 0, 0, 0);
+        pa = __builtin_amdgcn_mfma_f32_16x16x32_bf16(da1, vf1, pa, 0, 0, 0);
+        sb_ = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qb1_, kf1, sb_, 0, 0, 0);
+        pb = __builtin_amdgcn_mfma_f32_16x16x32_bf16(db1_, vf1, pb, 0, 0, 0);
+        bf16x4 dlo[4], dhi[4], qlo[4], qhi[4];
+#pragma unroll
+        for (int dt = 0; dt < 4; ++dt) {
+          AT_DS_TR_OFF(dlo[dt], td[dt], u * 4096); AT_DS_TR_OFF(dhi[dt], td[dt], u * 4096 + 2048);
+          AT_DS_TR_OFF(qlo[dt], tq[dt], u * 4096); AT_DS_TR_OFF(qhi[dt], tq[dt], u * 4096 + 2048);
+        }
+        f32x4 p2a, p2b, dsa, dsb;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          p2a[r] = __builtin_amdgcn_exp2f(fmaf(sa[r], c1, kbias));            // 0 for dead keys and padded queries
+          p2b[r] = __builtin_amdgcn_exp2f(fmaf(sb_[r], c1, kbias));
+          dsa[r] = p2a[r] * pa[r];                                            // (the score scale is applied to dK below)
+          dsb[r] = p2b[r] * pb[r];
+        }
+        const bf16x8 pf = pack_pair(p2a, p2b), dsf = pack_pair(dsa, dsb);
+        asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(dlo[0]), "+v"(dhi[0]), "+v"(dlo[1]), "+v"(dhi[1]), "+v"(dlo[2]), "+v"(dhi[2]), "+v"(dlo[3]), "+v"(dhi[3]),
+                     "+v"(qlo[0]), "+v"(qhi[0]), "+v"(qlo[1]), "+v"(qhi[1]), "+v"(qlo[2]), "+v"(qhi[2]), "+v"(qlo[3]), "+v"(qhi[3]));
+#pragma unroll
+        for (int dt = 0; dt < 4; ++dt) {
+          dv[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_shufflevector(dlo[dt], dhi[dt], 0, 1, 2, 3, 4, 5, 6, 7), pf, dv[dt], 0, 0, 0);    // dV^T[d][key]
+          dk[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_shufflevector(qlo[dt], qhi[dt], 0, 1, 2, 3, 4, 5, 6, 7), dsf, dk[dt], 0, 0, 0);   // dK^T[d][key]
+        }
+      });
+      bf16_t* krow = dqkv + ((int64_t)row0 + (key < S ? key : S - 1)) * ld + (int64_t)H * AT_DH + h * AT_DH;
+      bf16_t* vrow = krow + (int64_t)H * AT_DH;
+#pragma unroll
+      for (int dt = 0; dt < 4; ++dt) {
+        bf16x4 a, c;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) { a[r] = (bf16_t)(dk[dt][r] * scale); c[r] = (bf16_t)dv[dt][r]; }
+        if (key < S) {
+          *reinterpret_cast<bf16x4*>(krow + dt * 16 + 4 * g) = a;
+          *reinterpret_cast<bf16x4*>(vrow + dt * 16 + 4 * g) = c;
+        }
+      }
+    }
+  };
+
+  if constexpr (SHARE) {
+    stage_query_side();
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (stamps) t_staged = __builtin_amdgcn_s_memtime();
+    dkv_part();
+    __syncthreads();                    // every wave is done with the Q | dO images (the row constants stay)
+    stage_key_side();
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (stamps) t_mid = __builtin_amdgcn_s_memtime();
+    dq_part();
+  } else {
+    stage_key_side();
+    stage_query_side();
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (stamps) t_staged = __builtin_amdgcn_s_memtime();
+    dq_part();
+    if (stamps) t_mid = __builtin_amdgcn_s_memtime();
+    dkv_part();
+  }
+  if (stamps && threadIdx.x == 0) {
+    const unsigned long long t_out = __builtin_amdgcn_s_memtime();
+    stamps[4 * blockIdx.x + 0] = t_in; stamps[4 * blockIdx.x + 1] = t_staged; stamps[4 * blockIdx.x + 2] = t_mid; stamps[4 * blockIdx.x + 3] = t_out;
+  }
+}
+
+// ------------------------------------------------------------------------------------------------------
 // host side
 // ------------------------------------------------------------------------------------------------------
 bool mmrca_mha_mfma_ok(int S, int dh, int dtype) { return dtype == MMRCA_BF16 && dh == AT_DH && S >= 1 && S <= AT_MAX_S; }
@@ -881,6 +1133,10 @@ int mmrca_mha_fwd_mfma(const void* qkv, const int32_t* key_mask, void* out, floa
   return 0;
 }
 
+// diagnostic: device buffer [B*H][4] of uint64 that the fused backward fills with its phase stamps (nullptr = off, the default)
+static unsigned long long* g_attn_stamps = nullptr;
+extern "C" int mmrca_debug_attn_stamps(void* buf) { g_attn_stamps = (unsigned long long*)buf; return 0; }
+
 int mmrca_mha_bwd_mfma(const void* qkv, const int32_t* key_mask, const void* out, const void* dout, const float* lse,
                        void* dqkv, int B, int H, int S, int dh, float scale, float drop_p, uint64_t drop_seed,
                        const int32_t* cu, hipStream_t st) {
@@ -890,6 +1146,23 @@ int mmrca_mha_bwd_mfma(const void* qkv, const int32_t* key_mask, const void* out
   const int nkt = pick_nkt(S);
   static const int bwd_v = getenv("MMRCA_ATTN_BWD_V") ? atoi(getenv("MMRCA_ATTN_BWD_V")) : 1;
   const bool use_v = bwd_v && nkt == 14 && drop_p <= 0.f && !key_mask && !cu && S > 16 * 12;      // the ViT's attention
+  static const int bwd_fused = getenv("MMRCA_ATTN_BWD_FUSED") ? atoi(getenv("MMRCA_ATTN_BWD_FUSED")) : 1;
+  if (use_v && bwd_fused == 1) {     // one launch, two workgroups per CU: the Q | dO and K | V images time-share 56 KiB
+    const int ldf = 2 * 14 * 16 * 128 + STAT_EXTRA(14);
+    (void)hipFuncSetAttribute((const void*)mha_bwd_fused_mfma_v_k<14, 8, true>, hipFuncAttributeMaxDynamicSharedMemorySize, ldf);
+    hipLaunchKernelGGL((mha_bwd_fused_mfma_v_k<14, 8, true>), dim3(B * H), dim3(512), ldf, st, (const bf16_t*)qkv, (const bf16_t*)out, (const bf16_t*)dout, lse,
+                       (bf16_t*)dqkv, H, S, scale, g_attn_stamps);
+    MMRCA_CHECK_LAUNCH("mha_bwd(mfma,fused)");
+    return 0;
+  }
+  if (use_v && bwd_fused == 2) {     // one launch, one 16-wave workgroup per CU: all four operand images staged once per (b, h)
+    const int ldf = 4 * 14 * 16 * 128 + STAT_EXTRA(14);
+    (void)hipFuncSetAttribute((const void*)mha_bwd_fused_mfma_v_k<14, 16, false>, hipFuncAttributeMaxDynamicSharedMemorySize, ldf);
+    hipLaunchKernelGGL((mha_bwd_fused_mfma_v_k<14, 16, false>), dim3(B * H), dim3(1024), ldf, st, (const bf16_t*)qkv, (const bf16_t*)out, (const bf16_t*)dout, lse,
+                       (bf16_t*)dqkv, H, S, scale, g_attn_stamps);
+    MMRCA_CHECK_LAUNCH("mha_bwd(mfma,fused16)");
+    return 0;
+  }
   if (use_v) {
     const int ldq = 2 * 14 * 16 * 128, ldkv = 2 * 14 * 16 * 128 + STAT_EXTRA(14);
     (void)hipFuncSetAttribute((const void*)mha_bwd_dq_mfma_v_k<14, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, ldq);

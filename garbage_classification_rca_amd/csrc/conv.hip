@@ -803,12 +803,19 @@ col_moment_v8_k(const bf16_t* __restrict__ x, const float* __restrict__ mean, fl
 }
 
 // Both moments in ONE pass over x (bf16 fast path of mmrca_bn_stats): sums of d and d*d with d = x - shift[c] (fp32 sums).
-// Any shift within a few standard deviations of the channel mean keeps var = E[d^2] - E[d]^2 free of cancellation.  The shift is
-// the mean of BN_SHIFT_ROWS rows spread evenly over the tensor -- a single row (round 2 used row 0: the top-left pixel of image 0,
-// a zero-padded conv border / letterbox region) can sit many standard deviations from the channel mean, and the subtraction then
-// cancels in fp32 over millions of rows.  Both kernels below form it with the same adds in the same order.
+// Any shift within a few standard deviations of the channel mean keeps var = E[d^2] - E[d]^2 free of cancellation.  Round 2
+// used row 0 as the shift -- the top-left pixel of image 0, a zero-padded conv border / letterbox region that can sit hundreds of
+// standard deviations from the channel mean, and the subtraction then cancels in fp32 over millions of rows.  The shift is now a
+// TRIMMED mean (minimum and maximum dropped) of BN_SHIFT_ROWS rows at hashed positions, one per sixteenth of the tensor (evenly
+// spaced rows of a [B*H*W, C] activation are all the same pixel of different images -- e.g. all corners).  Both kernels below
+// form it with the same operations in the same order.
 #define BN_SHIFT_ROWS 16
-__device__ __forceinline__ int64_t bn_shift_row(int k, int64_t rows) { return (int64_t)k * rows / BN_SHIFT_ROWS; }
+__device__ __forceinline__ int64_t bn_shift_row(int k, int64_t rows) {
+  const int64_t seg = rows / BN_SHIFT_ROWS;
+  if (seg <= 0) return k < rows ? k : rows - 1;
+  return (int64_t)k * seg + (int64_t)((2654435761u * (unsigned)(k + 1)) % (unsigned long long)seg);
+}
+__device__ __forceinline__ float bn_trimmed(float sum, float lo, float hi) { return (sum - lo - hi) * (1.0f / (BN_SHIFT_ROWS - 2)); }
 __global__ void __launch_bounds__(256)
 col_moment2_v8_k(const bf16_t* __restrict__ x, float* __restrict__ s1, float* __restrict__ s2, int64_t rows, int C, int64_t ld,
                  int64_t rows_per_block) {
@@ -821,16 +828,16 @@ col_moment2_v8_k(const bf16_t* __restrict__ x, float* __restrict__ s1, float* __
 #pragma unroll
   for (int j = 0; j < 8; ++j) { acc[0][j] = 0.f; acc[1][j] = 0.f; }
   if (c0 < C) {
-    float m[8];
+    float m[8], mlo[8], mhi[8];
 #pragma unroll
-    for (int j = 0; j < 8; ++j) m[j] = 0.f;
+    for (int j = 0; j < 8; ++j) { m[j] = 0.f; mlo[j] = INFINITY; mhi[j] = -INFINITY; }
     for (int k = 0; k < BN_SHIFT_ROWS; ++k) {
       const cm_b8 sv = *reinterpret_cast<const cm_b8*>(x + bn_shift_row(k, rows) * ld + c0);
 #pragma unroll
-      for (int j = 0; j < 8; ++j) m[j] += (float)sv[j];
+      for (int j = 0; j < 8; ++j) { const float v = (float)sv[j]; m[j] += v; mlo[j] = fminf(mlo[j], v); mhi[j] = fmaxf(mhi[j], v); }
     }
 #pragma unroll
-    for (int j = 0; j < 8; ++j) m[j] *= 1.0f / BN_SHIFT_ROWS;
+    for (int j = 0; j < 8; ++j) m[j] = bn_trimmed(m[j], mlo[j], mhi[j]);
     for (int64_t r = r0 + rl; r < r1; r += 32) {
       const cm_b8 v = *reinterpret_cast<const cm_b8*>(x + r * ld + c0);
 #pragma unroll
@@ -846,9 +853,9 @@ __global__ void bn_finish_shifted_k(const bf16_t* __restrict__ x, float* __restr
                                     float momentum, int64_t rows, int64_t ld) {
   const int c = blockIdx.x * blockDim.x + threadIdx.x;
   if (c >= C) return;
-  float shift = 0.f;
-  for (int k = 0; k < BN_SHIFT_ROWS; ++k) shift += (float)x[bn_shift_row(k, rows) * ld + c];
-  shift *= 1.0f / BN_SHIFT_ROWS;
+  float shift = 0.f, slo = INFINITY, shi = -INFINITY;
+  for (int k = 0; k < BN_SHIFT_ROWS; ++k) { const float v = (float)x[bn_shift_row(k, rows) * ld + c]; shift += v; slo = fminf(slo, v); shi = fmaxf(shi, v); }
+  shift = bn_trimmed(shift, slo, shi);
   const float d1 = mean[c] / n;
   const float mu = shift + d1;
   const float var = fmaxf(rstd[c] / n - d1 * d1, 0.f);

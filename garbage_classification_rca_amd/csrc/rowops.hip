@@ -13,7 +13,8 @@ __global__ void __launch_bounds__(256)
 add_ln_fwd_k(const T* __restrict__ x, const T* __restrict__ res, const T* __restrict__ gamma, const T* __restrict__ beta,
              T* __restrict__ sum_out, T* __restrict__ y, float* __restrict__ mean, float* __restrict__ rstd,
              int64_t rows, int D, int64_t ld_x, int64_t ld_y, float eps, float in_p, uint64_t in_seed, float out_p,
-             uint64_t out_seed) {
+             uint64_t out_seed, bf16_t* __restrict__ y_hi = nullptr, bf16_t* __restrict__ y_lo = nullptr) {
+  // y_hi / y_lo (bf16x3 mode): the normalised output also (or, with y == nullptr, only) as two bf16 planes for the GEMMs that read it
   const float in_sc = in_p > 0.f ? 1.f / (1.f - in_p) : 1.f, out_sc = out_p > 0.f ? 1.f / (1.f - out_p) : 1.f;
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   for (int64_t row = (int64_t)blockIdx.x * 4 + wave; row < rows; row += (int64_t)gridDim.x * 4) {
@@ -66,7 +67,14 @@ add_ln_fwd_k(const T* __restrict__ x, const T* __restrict__ res, const T* __rest
 #pragma unroll
           for (int j = 0; j < 4; ++j) o.v[j] = mmrca_uniform(out_seed, (uint64_t)row * D + c + j) >= out_p ? o.v[j] * out_sc : 0.f;
         }
-        o.store(y + row * ld_y + c);
+        if (y) o.store(y + row * ld_y + c);
+        if (y_hi) {
+          Vec4<bf16_t> hi, lo;
+#pragma unroll
+          for (int j = 0; j < 4; ++j) { hi.v[j] = (float)(bf16_t)o.v[j]; lo.v[j] = o.v[j] - hi.v[j]; }
+          hi.store(y_hi + row * ld_y + c);
+          lo.store(y_lo + row * ld_y + c);
+        }
       }
     }
   }
@@ -180,12 +188,13 @@ add_ln_fwd_bf16_k(const bf16_t* __restrict__ x, const bf16_t* __restrict__ res, 
 
 static inline bool aligned16p(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
 
-extern "C" int mmrca_add_layernorm_fwd(const void* x, const void* res, const void* gamma, const void* beta,
-                                       void* sum_out, void* y, float* mean, float* rstd, int64_t rows, int D,
-                                       int64_t ld_x, int64_t ld_y, float eps, float in_drop_p, uint64_t in_drop_seed,
-                                       float out_drop_p, uint64_t out_drop_seed, int dtype, void* stream) {
+static int add_layernorm_fwd_impl(const void* x, const void* res, const void* gamma, const void* beta,
+                                  void* sum_out, void* y, float* mean, float* rstd, int64_t rows, int D,
+                                  int64_t ld_x, int64_t ld_y, float eps, float in_drop_p, uint64_t in_drop_seed,
+                                  float out_drop_p, uint64_t out_drop_seed, int dtype, void* stream, void* y_hi, void* y_lo) {
   MMRCA_REQUIRE(in_drop_p >= 0.f && in_drop_p < 1.f && out_drop_p >= 0.f && out_drop_p < 1.f, "add_layernorm_fwd: dropout p must be in [0,1)");
-  MMRCA_REQUIRE(x && gamma && beta && y, "add_layernorm_fwd: null pointer");
+  MMRCA_REQUIRE(x && gamma && beta && (y || y_hi), "add_layernorm_fwd: null pointer");
+  MMRCA_REQUIRE((y_hi == nullptr) == (y_lo == nullptr) && (!y_hi || dtype == MMRCA_F32), "add_layernorm_fwd: a two-plane output needs both planes and fp32 inputs");
   MMRCA_REQUIRE(D > 0 && D % 4 == 0 && D <= 256 * LN_MAXV, "add_layernorm_fwd: D=%d unsupported (multiple of 4, <= %d)", D, 256 * LN_MAXV);
   MMRCA_REQUIRE(ld_x >= D && ld_y >= D && ld_x % 4 == 0 && ld_y % 4 == 0, "add_layernorm_fwd: bad leading dims");
   if (rows <= 0) return 0;
@@ -206,7 +215,7 @@ extern "C" int mmrca_add_layernorm_fwd(const void* x, const void* res, const voi
 #define LN_FWD_LAUNCH(NV_)                                                                                             \
   hipLaunchKernelGGL((add_ln_fwd_k<T, NV_>), dim3(grid), dim3(256), 0, (hipStream_t)stream, (const T*)x, (const T*)res,  \
                      (const T*)gamma, (const T*)beta, (T*)sum_out, (T*)y, mean, rstd, rows, D, ld_x, ld_y, eps, in_drop_p,  \
-                     in_drop_seed, out_drop_p, out_drop_seed)
+                     in_drop_seed, out_drop_p, out_drop_seed, (bf16_t*)y_hi, (bf16_t*)y_lo)
   const int nv = (D + 255) / 256;        // register slabs of 256 columns actually needed (3 for D=768)
   MMRCA_DISPATCH_DTYPE(dtype, "add_layernorm_fwd",
     if (nv <= 1) LN_FWD_LAUNCH(1); else if (nv <= 2) LN_FWD_LAUNCH(2); else if (nv <= 3) LN_FWD_LAUNCH(3);
@@ -214,6 +223,26 @@ extern "C" int mmrca_add_layernorm_fwd(const void* x, const void* res, const voi
 #undef LN_FWD_LAUNCH
   MMRCA_CHECK_LAUNCH("add_layernorm_fwd");
   return 0;
+}
+
+extern "C" int mmrca_add_layernorm_fwd(const void* x, const void* res, const void* gamma, const void* beta,
+                                       void* sum_out, void* y, float* mean, float* rstd, int64_t rows, int D,
+                                       int64_t ld_x, int64_t ld_y, float eps, float in_drop_p, uint64_t in_drop_seed,
+                                       float out_drop_p, uint64_t out_drop_seed, int dtype, void* stream) {
+  MMRCA_REQUIRE(y, "add_layernorm_fwd: null pointer");
+  return add_layernorm_fwd_impl(x, res, gamma, beta, sum_out, y, mean, rstd, rows, D, ld_x, ld_y, eps, in_drop_p, in_drop_seed,
+                                out_drop_p, out_drop_seed, dtype, stream, nullptr, nullptr);
+}
+
+// bf16x3 mode (fp32 operands): the normalised output as two bf16 planes y_hi + y_lo (what the GEMMs that consume it read; see
+// mmrca_gemm_x3), and as fp32 in y as well when y != NULL (post-LN encoders: the output is also the next residual)
+extern "C" int mmrca_add_layernorm_fwd_x3(const void* x, const void* res, const void* gamma, const void* beta,
+                                          void* sum_out, void* y, void* y_hi, void* y_lo, float* mean, float* rstd, int64_t rows,
+                                          int D, int64_t ld_x, int64_t ld_y, float eps, float in_drop_p, uint64_t in_drop_seed,
+                                          float out_drop_p, uint64_t out_drop_seed, void* stream) {
+  MMRCA_REQUIRE(y_hi && y_lo, "add_layernorm_fwd_x3: null plane");
+  return add_layernorm_fwd_impl(x, res, gamma, beta, sum_out, y, mean, rstd, rows, D, ld_x, ld_y, eps, in_drop_p, in_drop_seed,
+                                out_drop_p, out_drop_seed, MMRCA_F32, stream, y_hi, y_lo);
 }
 
 // --------------------------------------------------------------------------------------------------------

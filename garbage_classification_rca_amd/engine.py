@@ -91,6 +91,14 @@ class Arena:
         return a, off + n
 
 
+class Planes:
+    """An fp32 [rows, cols] matrix stored as two bf16 planes, value = hi + lo (bf16x3 mode, csrc/gemm_x3.hip): what a GEMM epilogue
+    writes when its only consumers are other bf16x3 GEMMs (saves the fp32 store + the consumers' split pass)."""
+
+    def __init__(self, hi, lo):
+        self.hi, self.lo = hi, lo
+
+
 class TextPack:
     """Packed (unpadded) token layout of one caption batch: the rows the text encoder works on are the live tokens of
     every caption stored back to back -- padding rows are dead work under class-token pooling with masked keys (their
@@ -185,7 +193,11 @@ class MMRCAEngine:
             self.conv.init_buffers(self.device)
         self.head_span = self.arena.span(self.head_keys[0][0], self.head_keys[-1][0])
         self._bufs: Dict[Tuple, torch.Tensor] = {}
+        # bf16x3: gelu(h) and its gradient only feed other bf16x3 GEMMs, so their epilogues write them as two bf16 planes
+        self._g_planes = self.x3 and FUSE_GELU_GRAD and os.environ.get("MMRCA_X3_PLANES_OUT", "1") == "1"
         self._plane_valid = set()
+        self._plane_fresh = set()
+        self._ln_planes = self._g_planes
         self._saved = None
         # parameter groups that become final together during backward; they tile the arena exactly (padding included)
         self.groups: Dict[str, Tuple[int, int]] = {}
@@ -278,8 +290,17 @@ class MMRCAEngine:
             self._bufs[key] = pl
         return key, pl
 
+    def planes_buf(self, name, rows, cols, layer=0) -> Planes:
+        return Planes(self.buf(name + "_hi", rows, cols, torch.bfloat16, layer), self.buf(name + "_lo", rows, cols, torch.bfloat16, layer))
+
     def _split(self, x, rows, cols, reuse=False):
+        if isinstance(x, Planes):           # produced as planes by a GEMM epilogue
+            return x.hi, x.lo
         key, pl = self._planes_of(x)
+        if key in self._plane_fresh:        # just written by the LayerNorm that produced x (one consumer in the forward)
+            self._plane_fresh.discard(key)
+            self._plane_valid.add(key)
+            return pl
         if not (reuse and key in self._plane_valid):
             L.split_f32(x, pl[0], pl[1], rows * cols)
             self._plane_valid.add(key)
@@ -368,6 +389,7 @@ class MMRCAEngine:
     def release_buffers(self):
         self._bufs.clear()
         self._plane_valid.clear()
+        self._plane_fresh.clear()
         self._saved = None
         if self.conv is not None:
             self.conv.release()
@@ -376,8 +398,9 @@ class MMRCAEngine:
     def _lin_fwd(self, x, wkey, bkey, out, M, N, K, act=L.ACT_NONE, preact=None, addend=None, wnumel=None):
         if self.x3:
             b = self.arena.view(bkey) if wnumel is None else self.arena.p[self.arena.offsets[bkey][0]:self.arena.offsets[bkey][0] + N]
-            L.gemm_x3(self._split(x, M, K), self.Wx3(wkey, wnumel), out, bias=b, addend=addend, preact=preact, M=M, N=N, K=K, lda=K,
-                      ldb=K, ldc=N, a_layout=L.ROWK, b_layout=L.ROWK, act=act, impl=self.gemm_impl)
+            po = isinstance(out, Planes)
+            L.gemm_x3(self._split(x, M, K), self.Wx3(wkey, wnumel), out.hi if po else out, C_lo=(out.lo if po else None), bias=b, addend=addend,
+                      preact=preact, M=M, N=N, K=K, lda=K, ldb=K, ldc=N, a_layout=L.ROWK, b_layout=L.ROWK, act=act, impl=self.gemm_impl)
             return
         w = self.W(wkey) if wnumel is None else self.Wflat(wkey, wnumel)
         b = self.W(bkey) if wnumel is None else self.Wflat(bkey, N)
@@ -442,6 +465,8 @@ class MMRCAEngine:
             else:
                 L.gemm_x3(dyp, xp, gw, M=N, N=K, K=Mk, lda=N, ldb=K, ldc=K, a_layout=L.KROW, b_layout=L.KROW, accum=True)
             if not bias_done:
+                if isinstance(dy, Planes):
+                    raise L.MmrcaError("bf16x3: the bias gradient of a two-plane dY must come from its producer (bias_done)")
                 L.colsum_accum(dy, gb, M, N, N, self.dt)
 
         if self._side is None:
@@ -456,7 +481,11 @@ class MMRCAEngine:
                     self._first_wgrad_ev.record(self._side)
         if dx is not None:
             fuse = gelu_h is not None and FUSE_GELU_GRAD
-            L.gemm_x3(dyp, self.Wx3(wkey, wnumel), dx, addend=addend, preact=(gelu_h if fuse else None), colsum=(gelu_db if fuse else None),
+            po = isinstance(dx, Planes)
+            if po and gelu_h is not None and not fuse:
+                raise L.MmrcaError("bf16x3 mode with a two-plane FFN gradient needs the fused GELU gradient (MMRCA_FUSE_GELU=1)")
+            L.gemm_x3(dyp, self.Wx3(wkey, wnumel), dx.hi if po else dx, C_lo=(dx.lo if po else None), addend=addend,
+                      preact=(gelu_h if fuse else None), colsum=(gelu_db if fuse else None),
                       M=M, N=K, K=N, lda=N, ldb=K, ldc=K, a_layout=L.ROWK, b_layout=L.KROW, act=(L.ACT_MUL if fuse else L.ACT_NONE),
                       impl=self.gemm_impl)
             if gelu_h is not None and not fuse:
@@ -465,15 +494,34 @@ class MMRCAEngine:
                 else:
                     L.gelu_bwd(dx, gelu_h, dx, M * K, self.dt)
 
-    def _ln_fwd(self, x, res, pfx, sum_out, y, mean, rstd, rows, D, eps, ld_x=None, ld_y=None, in_drop=(0.0, 0), out_drop=(0.0, 0)):
+    def _ln_fwd(self, x, res, pfx, sum_out, y, mean, rstd, rows, D, eps, ld_x=None, ld_y=None, in_drop=(0.0, 0), out_drop=(0.0, 0),
+                to_gemm=False):
+        """to_gemm (bf16x3 mode): the output feeds a GEMM, so the kernel also writes it as two bf16 planes -- ONLY as planes when
+        `y` is a Planes buffer (pre-LN encoders: nothing else reads it); the next _lin_fwd on `y` picks them up instead of
+        running a split pass."""
+        yp = None
+        if isinstance(y, Planes):
+            yp, y = (y.hi, y.lo), None
+        elif self.x3 and to_gemm and self._ln_planes and (ld_y is None or ld_y == D):
+            key, yp = self._planes_of(y)
+            self._plane_fresh.add(key)
         L.add_layernorm_fwd(x, res, self.W(pfx + ".weight"), self.W(pfx + ".bias"), sum_out, y, mean, rstd, rows, D,
-                            ld_x or D, ld_y or D, eps, self.dt, in_drop=in_drop, out_drop=out_drop)
+                            ld_x or D, ld_y or D, eps, self.dt, in_drop=in_drop, out_drop=out_drop, y_planes=yp)
 
     def _ln_bwd(self, dy, s, pfx, mean, rstd, dres, ds, rows, D, ld_dy=None, ld_s=None, ld_ds=None, dy_drop=(0.0, 0),
                 branch_drop=(0.0, 0), dbranch=None, dcol=None, dcol_branch=None):
         L.layernorm_bwd(dy, s, self.W(pfx + ".weight"), mean, rstd, dres, ds, self.G(pfx + ".weight"), self.G(pfx + ".bias"),
                         rows, D, ld_dy or D, ld_s or D, ld_ds or D, self.dt, dy_drop=dy_drop, branch_drop=branch_drop, dbranch=dbranch,
                         dcol=dcol, dcol_branch=dcol_branch)
+
+    def _mha_fwd(self, qkv, mask32, ctx, lse, B, H, S, dh, drop_p=0.0, drop_seed=0, cu=None):
+        if self.x3 and self._ln_planes and self.attn_impl == L.IMPL_AUTO and L.mha_fwd_planes_ok(S, dh):
+            # the context feeds the out-projection GEMM: written as two bf16 planes next to the fp32 copy the backward reads
+            key, pl = self._planes_of(ctx)
+            L.mha_fwd_planes(qkv, mask32, ctx, pl, lse, B, H, S, dh, dh ** -0.5, drop_p=drop_p, drop_seed=drop_seed, cu=cu)
+            self._plane_fresh.add(key)
+            return
+        L.mha_fwd(qkv, mask32, ctx, lse, B, H, S, dh, dh ** -0.5, self.dt, self.attn_impl, drop_p=drop_p, drop_seed=drop_seed, cu=cu)
 
     def _layer_boundary(self):
         """All side-stream weight-gradient work of the finished layer must be done before the next layer re-writes the
@@ -524,7 +572,7 @@ class MMRCAEngine:
         dp = float(drop_p)
         sd = lambda layer, site: self._site_seed(drop_seed, layer, site)
         post_attn_drop = dp if s.name != "distilbert" else 0.0     # BertSelfOutput drops the attention output, DistilBERT does not
-        self._ln_fwd(emb, None, P + "embeddings.LayerNorm", None, x, mean0, rstd0, M, D, s.ln_eps, out_drop=(dp, sd(0, 0)))
+        self._ln_fwd(emb, None, P + "embeddings.LayerNorm", None, x, mean0, rstd0, M, D, s.ln_eps, out_drop=(dp, sd(0, 0)), to_gemm=True)
         layers = []
         for i in range(s.layers):
             K = S.text_layer_keys(s, i)
@@ -541,8 +589,8 @@ class MMRCAEngine:
                 self._lin_fwd(ctx_c, P + K["o"] + ".weight", P + K["o"] + ".bias", att, B, D, D)
                 s1, x1 = cb("s1", D), cb("x1", D)
                 m1, r1 = stat("m1c", i), stat("r1c", i)
-                self._ln_fwd(att, x_c, P + K["ln1"], s1, x1, m1, r1, B, D, s.ln_eps, in_drop=(post_attn_drop, sd(i, 2)))
-                h, g = cb("h", Fd), cb("g", Fd)
+                self._ln_fwd(att, x_c, P + K["ln1"], s1, x1, m1, r1, B, D, s.ln_eps, in_drop=(post_attn_drop, sd(i, 2)), to_gemm=True)
+                h, g = cb("h", Fd), (self.planes_buf("t_g_c", B, Fd, i if save else 0) if self._g_planes else cb("g", Fd))
                 self._lin_fwd(x1, P + K["f1"] + ".weight", P + K["f1"] + ".bias", g, B, Fd, D, act=(L.ACT_GELU_SAVE_GRAD if FUSE_GELU_GRAD else L.ACT_GELU), preact=h)
                 f = cb("f", D)
                 self._lin_fwd(g, P + K["f2"] + ".weight", P + K["f2"] + ".bias", f, B, D, Fd)
@@ -554,19 +602,19 @@ class MMRCAEngine:
                 cls = xn[:B].clone()
                 return cls, dict(B=B, T=T, M=M, cu=cu, first=first, ids32=ids32, pos=pos, mask32=mask32, emb=emb, mean0=mean0, rstd0=rstd0, layers=layers,
                                  drop_p=dp, drop_seed=drop_seed)
-            L.mha_fwd(qkv, mask32, ctx, lse, B, H, T, dh, dh ** -0.5, self.dt, self.attn_impl, drop_p=dp, drop_seed=sd(i, 1), cu=cu)
+            self._mha_fwd(qkv, mask32, ctx, lse, B, H, T, dh, drop_p=dp, drop_seed=sd(i, 1), cu=cu)
             att = fb("tmpD", D)
             self._lin_fwd(ctx, P + K["o"] + ".weight", P + K["o"] + ".bias", att, M, D, D)
             s1, x1 = fb("s1", D, i), fb("x1", D, i)
             m1, r1 = stat("m1", i), stat("r1", i)
-            self._ln_fwd(att, x, P + K["ln1"], s1, x1, m1, r1, M, D, s.ln_eps, in_drop=(post_attn_drop, sd(i, 2)))
-            h, g = fb("h", Fd, i), fb("g", Fd, i)
+            self._ln_fwd(att, x, P + K["ln1"], s1, x1, m1, r1, M, D, s.ln_eps, in_drop=(post_attn_drop, sd(i, 2)), to_gemm=True)
+            h, g = fb("h", Fd, i), (self.planes_buf("t_g", cap, Fd, i if save else 0) if self._g_planes else fb("g", Fd, i))
             self._lin_fwd(x1, P + K["f1"] + ".weight", P + K["f1"] + ".bias", g, M, Fd, D, act=(L.ACT_GELU_SAVE_GRAD if FUSE_GELU_GRAD else L.ACT_GELU), preact=h)   # fused mode: h <- gelu'(pre-activation)
             f = fb("tmpD", D)
             self._lin_fwd(g, P + K["f2"] + ".weight", P + K["f2"] + ".bias", f, M, D, Fd)
             s2, xn = fb("s2", D, i), fb("x", D, i + 1)
             m2, r2 = stat("m2", i), stat("r2", i)
-            self._ln_fwd(f, x1, P + K["ln2"], s2, xn, m2, r2, M, D, s.ln_eps, in_drop=(dp, sd(i, 3)))
+            self._ln_fwd(f, x1, P + K["ln2"], s2, xn, m2, r2, M, D, s.ln_eps, in_drop=(dp, sd(i, 3)), to_gemm=(i + 1 < s.layers))
             layers.append(dict(x=x, qkv=qkv, ctx=ctx, lse=lse, s1=s1, x1=x1, m1=m1, r1=r1, h=h, g=g, s2=s2, m2=m2, r2=r2))
             x = xn
         cls = x.index_select(0, first)
@@ -597,7 +645,7 @@ class MMRCAEngine:
             # the LayerNorm backward also emits the column sums of its output = bias gradient of the linear that fed it
             self._ln_bwd(dx, a["s2"], P + K["ln2"], a["m2"], a["r2"], None, ds2, M, D, branch_drop=(dp, sd(i, 3)), dbranch=df,
                          dcol=(None if df is not None else gb_f2), dcol_branch=(gb_f2 if df is not None else None))
-            dg = gb("dF", Fd)
+            dg = self.planes_buf("tg_dF", B * T, Fd) if self._g_planes else gb("dF", Fd)
             self._lin_bwd(df if df is not None else ds2, a["g"], P + K["f2"] + ".weight", P + K["f2"] + ".bias", dg, M, D, Fd,
                           gelu_h=a["h"], bias_done=True, gelu_db=self.G(P + K["f1"] + ".bias"))
             dx1 = gb("dxB", D)
@@ -646,7 +694,7 @@ class MMRCAEngine:
         gb_f2, gb_o = self.G(P + K["f2"] + ".bias"), self.G(P + K["o"] + ".bias")
         self._ln_bwd(dxc, a["s2"], P + K["ln2"], a["m2"], a["r2"], None, ds2, B, D, branch_drop=(dp, sd(i, 3)), dbranch=df,
                      dcol=(None if df is not None else gb_f2), dcol_branch=(gb_f2 if df is not None else None))
-        dg = gc("dF", Fd)
+        dg = self.planes_buf("tg_dF_c", B, Fd) if self._g_planes else gc("dF", Fd)
         self._lin_bwd(df if df is not None else ds2, a["g"], P + K["f2"] + ".weight", P + K["f2"] + ".bias", dg, B, D, Fd,
                       gelu_h=a["h"], bias_done=True, gelu_db=self.G(P + K["f1"] + ".bias"))
         dx1 = gc("dxB", D)
@@ -692,7 +740,7 @@ class MMRCAEngine:
         pend = None                      # (ffn2 output, x1) of the previous layer whose sum -- this layer's input -- is still to be formed
         for i in range(s.layers):
             Lk = P + f"encoder.layers.encoder_layer_{i}."
-            y1, m1, r1 = fb("y1", M, D, i), stat("m1", i), stat("r1", i)
+            y1, m1, r1 = (self.planes_buf("v_y1", M, D, i if save else 0) if self._ln_planes else fb("y1", M, D, i)), stat("m1", i), stat("r1", i)
             if pend is None:
                 self._ln_fwd(x, None, Lk + "ln_1", None, y1, m1, r1, M, D, s.ln_eps)
             else:
@@ -711,9 +759,9 @@ class MMRCAEngine:
                 x_c[:B].copy_(x[:M].view(B, Tn, D)[:, 0])
                 x1 = cb("x1", D)
                 self._lin_fwd(ctx_c, Lk + "self_attention.out_proj.weight", Lk + "self_attention.out_proj.bias", x1, B, D, D, addend=x_c)
-                y2, m2, r2 = cb("y2", D), stat("m2c", i), stat("r2c", i)
+                y2, m2, r2 = (self.planes_buf("v_y2_c", B, D, i if save else 0) if self._ln_planes else cb("y2", D)), stat("m2c", i), stat("r2c", i)
                 self._ln_fwd(x1, None, Lk + "ln_2", None, y2, m2, r2, B, D, s.ln_eps)
-                h, g = cb("h", Fd), cb("g", Fd)
+                h, g = cb("h", Fd), (self.planes_buf("v_g_c", B, Fd, i if save else 0) if self._g_planes else cb("g", Fd))
                 self._lin_fwd(y2, Lk + "mlp.0.weight", Lk + "mlp.0.bias", g, B, Fd, D, act=(L.ACT_GELU_SAVE_GRAD if FUSE_GELU_GRAD else L.ACT_GELU), preact=h)
                 xn = cb("xout", D)
                 self._lin_fwd(g, Lk + "mlp.3.weight", Lk + "mlp.3.bias", xn, B, D, Fd, addend=x1)
@@ -723,9 +771,9 @@ class MMRCAEngine:
                 mf, rf = stat("mf"), stat("rf")
                 self._ln_fwd(xn, None, P + "encoder.ln", None, feat, mf, rf, B, D, s.ln_eps)
                 return feat[:B], dict(B=B, patches=patches, xL=xn, mf=mf, rf=rf, layers=layers)
-            L.mha_fwd(qkv, None, ctx, lse, B, H, Tn, dh, dh ** -0.5, self.dt, self.attn_impl)
+            self._mha_fwd(qkv, None, ctx, lse, B, H, Tn, dh)
             x1 = fb("x1", M, D, i)
-            y2, m2, r2 = fb("y2", M, D, i), stat("m2", i), stat("r2", i)
+            y2, m2, r2 = (self.planes_buf("v_y2", M, D, i if save else 0) if self._ln_planes else fb("y2", M, D, i)), stat("m2", i), stat("r2", i)
             if fuse_res:
                 ao = fb("attn_o", M, D, 0)
                 self._lin_fwd(ctx, Lk + "self_attention.out_proj.weight", Lk + "self_attention.out_proj.bias", ao, M, D, D)
@@ -733,7 +781,7 @@ class MMRCAEngine:
             else:
                 self._lin_fwd(ctx, Lk + "self_attention.out_proj.weight", Lk + "self_attention.out_proj.bias", x1, M, D, D, addend=x)
                 self._ln_fwd(x1, None, Lk + "ln_2", None, y2, m2, r2, M, D, s.ln_eps)
-            h, g = fb("h", M, Fd, i), fb("g", M, Fd, i)
+            h, g = fb("h", M, Fd, i), (self.planes_buf("v_g", M, Fd, i if save else 0) if self._g_planes else fb("g", M, Fd, i))
             self._lin_fwd(y2, Lk + "mlp.0.weight", Lk + "mlp.0.bias", g, M, Fd, D, act=(L.ACT_GELU_SAVE_GRAD if FUSE_GELU_GRAD else L.ACT_GELU), preact=h)   # fused mode: h <- gelu'(pre-activation)
             layers.append(dict(x=x, y1=y1, m1=m1, r1=r1, qkv=qkv, ctx=ctx, lse=lse, x1=x1, y2=y2, m2=m2, r2=r2, h=h, g=g))
             if fuse_res:
@@ -778,7 +826,7 @@ class MMRCAEngine:
                 self._vision_backward_tail(dxc, sv, dx)
                 continue
             Lk, a = P + f"encoder.layers.encoder_layer_{i}.", sv["layers"][i]
-            dg = gb("dF", M, Fd)
+            dg = self.planes_buf("vg_dF", M, Fd) if self._g_planes else gb("dF", M, Fd)
             self._lin_bwd(dx, a["g"], Lk + "mlp.3.weight", Lk + "mlp.3.bias", dg, M, D, Fd, gelu_h=a["h"], bias_done=True,
                           gelu_db=self.G(Lk + "mlp.0.bias"))
             dy2 = gb("dy", M, D)
@@ -814,7 +862,7 @@ class MMRCAEngine:
         Lk, a = P + f"encoder.layers.encoder_layer_{i}.", sv["layers"][i]
         gb = lambda name, rows, cols: self.buf("vg_" + name, rows, cols)
         gc = lambda name, cols: self.buf("vg_" + name + "_c", B, cols)
-        dg = gc("dF", Fd)
+        dg = self.planes_buf("vg_dF_c", B, Fd) if self._g_planes else gc("dF", Fd)
         self._lin_bwd(dxc, a["g"], Lk + "mlp.3.weight", Lk + "mlp.3.bias", dg, B, D, Fd, gelu_h=a["h"], bias_done=True,
                       gelu_db=self.G(Lk + "mlp.0.bias"))
         dy2 = gc("dy", D)
@@ -854,6 +902,7 @@ class MMRCAEngine:
                 raise L.MmrcaError(f"{nm} must be in HBM; the MM-RCA product path has no CPU fallback")
         self.refresh_working_copy()
         self._plane_valid.clear()
+        self._plane_fresh.clear()
         B = ids.shape[0]
         main = torch.cuda.current_stream()
         if self._text_stream is not None:

@@ -85,12 +85,14 @@ _SIGS = {
     "mmrca_gelu_bwd": [_vp, _vp, _vp, _i64, _i32, _vp],
     "mmrca_gelu_bwd_colsum": [_vp, _vp, _vp, _vp, _i64, _i64, _i64, _i32, _vp],
     "mmrca_mha_fwd": [_vp] * 4 + [_i32] * 4 + [_f32, _f32, _u64, _vp, _i32, _i32, _vp],
+    "mmrca_mha_fwd_planes": [_vp] * 6 + [_i32] * 4 + [_f32, _f32, _u64, _vp, _vp],
     "mmrca_mha_bwd": [_vp] * 6 + [_i32] * 4 + [_f32, _f32, _u64, _vp, _i32, _i32, _vp],
     "mmrca_mha_bwd_colsum": [_vp] * 7 + [_i64] + [_i32] * 4 + [_f32, _f32, _u64, _vp, _i32, _i32, _vp],
     "mmrca_mha_cross_fwd": [_vp, _i64, _vp, _i64, _vp, _i64, _vp, _i64] + [_i32] * 5 + [_f32, _f32, _u64, _i32, _i32, _vp],
     "mmrca_mha_cls_fwd": [_vp] * 4 + [_i32] * 4 + [_f32, _f32, _u64, _vp, _i32, _vp],
     "mmrca_mha_cls_bwd": [_vp] * 6 + [_i32] * 4 + [_f32, _f32, _u64, _vp, _i32, _vp],
     "mmrca_add_layernorm_fwd": [_vp] * 8 + [_i64, _i32, _i64, _i64, _f32, _f32, _u64, _f32, _u64, _i32, _vp],
+    "mmrca_add_layernorm_fwd_x3": [_vp] * 10 + [_i64, _i32, _i64, _i64, _f32, _f32, _u64, _f32, _u64, _vp],
     "mmrca_layernorm_bwd": [_vp] * 9 + [_i64, _i32, _i64, _i64, _i64, _f32, _u64, _f32, _u64, _vp, _vp, _vp, _i32, _vp],
     "mmrca_embed_fwd": [_vp] * 6 + [_i64, _i32, _i32, _vp],
     "mmrca_embed_bwd": [_vp] * 6 + [_i64, _i32, _i32, _i32, _i32, _vp],
@@ -104,7 +106,7 @@ _SIGS = {
     "mmrca_adamw_step": [_vp] * 5 + [_i64] + [_f32] * 5 + [_i32, _f32, _vp],
     "mmrca_cast_f32_to_bf16": [_vp, _vp, _i64, _vp],
 }
-EXPORTS = sorted(list(_SIGS) + ["mmrca_last_error", "mmrca_version", "mmrca_debug_set", "mmrca_gemm_splitk_workspace_bytes",
+EXPORTS = sorted(list(_SIGS) + ["mmrca_last_error", "mmrca_version", "mmrca_debug_set", "mmrca_debug_attn_stamps", "mmrca_gemm_splitk_workspace_bytes",
                                   "mmrca_head_bwd_workspace_bytes"])
 
 
@@ -299,6 +301,18 @@ def mha_fwd(qkv, key_mask, out, lse, B, H, S, dh, scale, dtype, impl=IMPL_AUTO, 
                                     impl, stream_ptr()), "mmrca_mha_fwd")
 
 
+def mha_fwd_planes_ok(S, dh):
+    return dh == 64 and 1 <= S <= 208 and os.environ.get("MMRCA_ATTN_F32_MFMA", "1") != "0"
+
+
+def mha_fwd_planes(qkv, key_mask, out, out_planes, lse, B, H, S, dh, scale, drop_p=0.0, drop_seed=0, cu=None):
+    """fp32 attention forward that also writes the context as (hi, lo) bf16 planes (bf16x3 mode)"""
+    _dev(qkv, "mha qkv")
+    with _Bracket("mha_fwd", (B, H, S, dh, cu is not None)):
+        _check(load().mmrca_mha_fwd_planes(ptr(qkv), ptr(key_mask), ptr(out), ptr(out_planes[0]), ptr(out_planes[1]), ptr(lse), B, H, S, dh,
+                                           scale, drop_p, drop_seed, ptr(cu), stream_ptr()), "mmrca_mha_fwd_planes")
+
+
 def mha_bwd(qkv, key_mask, out, dout, lse, dqkv, B, H, S, dh, scale, dtype, impl=IMPL_AUTO, drop_p=0.0, drop_seed=0, colsum=None,
             cu=None, rows=None):
     """colsum (fp32 [3*H*dh], +=): column sums of dqkv = the in-projection bias gradient, reduced inside the kernels;
@@ -333,8 +347,14 @@ def mha_cls_bwd(qkv, key_mask, out, dout, lse, dqkv, B, H, S, dh, scale, dtype, 
 
 
 def add_layernorm_fwd(x, res, gamma, beta, sum_out, y, mean, rstd, rows, D, ld_x, ld_y, eps, dtype,
-                      in_drop=(0.0, 0), out_drop=(0.0, 0)):
+                      in_drop=(0.0, 0), out_drop=(0.0, 0), y_planes=None):
+    """y_planes = (hi, lo) bf16 tensors (fp32 operands only): the output also -- or, with y None, only -- as two bf16 planes"""
     _dev(x, "layernorm x")
+    if y_planes is not None:
+        _check(load().mmrca_add_layernorm_fwd_x3(ptr(x), ptr(res), ptr(gamma), ptr(beta), ptr(sum_out), ptr(y), ptr(y_planes[0]),
+                                                 ptr(y_planes[1]), ptr(mean), ptr(rstd), rows, D, ld_x, ld_y, eps, in_drop[0], in_drop[1],
+                                                 out_drop[0], out_drop[1], stream_ptr()), "mmrca_add_layernorm_fwd_x3")
+        return
     _check(load().mmrca_add_layernorm_fwd(ptr(x), ptr(res), ptr(gamma), ptr(beta), ptr(sum_out), ptr(y), ptr(mean), ptr(rstd),
                                           rows, D, ld_x, ld_y, eps, in_drop[0], in_drop[1], out_drop[0], out_drop[1],
                                           dtype, stream_ptr()), "mmrca_add_layernorm_fwd")

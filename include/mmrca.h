@@ -47,6 +47,9 @@ const char* mmrca_last_error(void);
 int mmrca_version(void);
 /* timing-only ablation switches for kernel development (0 = normal operation; results are WRONG otherwise) */
 int mmrca_debug_set(int flags);
+/* diagnostic: a device buffer of B*H*4 uint64 that the fused ViT attention backward fills with s_memtime stamps of its phases
+ * (entry, staged, dQ done, exit; tools/attn_stamps.py); NULL (the default) = no stamps */
+int mmrca_debug_attn_stamps(void* buf);
 
 /* K2. C[M,N] = act(A (.) B + bias[N]) + addend[M,N]      (torch.nn.Linear fwd / dgrad / wgrad:
  * transformers modeling_distilbert.py q_lin/k_lin/v_lin/out_lin/ffn.lin1/lin2, torchvision ViT in_proj/
@@ -188,6 +191,12 @@ int mmrca_mha_fwd(const void* qkv, const int32_t* key_mask, void* out, float* ls
 int mmrca_mha_bwd(const void* qkv, const int32_t* key_mask, const void* out, const void* dout, const float* lse,
                   void* dqkv, int B, int H, int S, int dh, float scale, float drop_p, uint64_t drop_seed,
                   const int32_t* cu_seqlens, int dtype, int impl, void* stream);
+/* mmrca_mha_fwd on fp32 operands that ALSO writes the context as two bf16 planes out_hi + out_lo (the operand form of the
+ * bf16x3 out-projection GEMM, mmrca_gemm_x3).  Head dim 64, 1 <= S <= 208 (the fp32-matrix-core kernels of attention_f32.hip);
+ * rejected otherwise -- use mmrca_mha_fwd + mmrca_split_f32 there. */
+int mmrca_mha_fwd_planes(const void* qkv, const int32_t* key_mask, void* out, void* out_hi, void* out_lo, float* lse,
+                         int B, int H, int S, int dh, float scale, float drop_p, uint64_t drop_seed,
+                         const int32_t* cu_seqlens, void* stream);
 /* mmrca_mha_bwd followed by dqkv_colsum[3*H*dh] (fp32) += column sums of the stored dqkv = the bias gradient of the QKV
  * in-projection (one call; the reduction is a separate HBM pass -- fusing it into the MFMA kernels measured slower).
  * total_rows = number of token rows (B*S padded, cu_seqlens[B] packed). */
@@ -228,6 +237,12 @@ int mmrca_add_layernorm_fwd(const void* x, const void* res, const void* gamma, c
                             int64_t rows, int D, int64_t ld_x, int64_t ld_y, float eps,
                             float in_drop_p, uint64_t in_drop_seed, float out_drop_p, uint64_t out_drop_seed,
                             int dtype, void* stream);
+/* The same on fp32 operands with the normalised output ALSO (y != NULL) or ONLY (y == NULL) written as two bf16 planes
+ * y_hi + y_lo: the operand form of the bf16x3 GEMMs that consume it (mmrca_gemm_x3), saving their split pass. */
+int mmrca_add_layernorm_fwd_x3(const void* x, const void* res, const void* gamma, const void* beta,
+                               void* sum_out, void* y, void* y_hi, void* y_lo, float* mean, float* rstd,
+                               int64_t rows, int D, int64_t ld_x, int64_t ld_y, float eps,
+                               float in_drop_p, uint64_t in_drop_seed, float out_drop_p, uint64_t out_drop_seed, void* stream);
 /* ds = LN'(dy) (+ dres);  dgamma/dbeta (fp32) += .   s is the saved LayerNorm input.
  * dy_drop: mask dy like the forward's out_drop.  dbranch (optional) = dropout-mask(LN'(dy)) with (branch_drop_p, seed):
  * the gradient of the branch that the forward's in_drop dropped (ds itself stays the residual-stream gradient).

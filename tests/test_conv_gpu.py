@@ -295,23 +295,27 @@ def test_backbone_bf16_close_to_oracle():
     enc.release()
 
 
-def test_one_pass_batchnorm_statistics_survive_an_outlier_first_row():
+def test_one_pass_batchnorm_statistics_survive_outlier_rows():
     """The bf16 one-pass BatchNorm moments subtract a shift before squaring.  With a single row as the shift (round 2: row 0 --
-    the top-left pixel of image 0, a zero-padded border) a channel whose first row sits 500 sigma from its mean cancels in fp32
-    over many rows; the shift is now the mean of 16 rows spread over the tensor.  Channel mean 50, sigma 0.1, first row 0."""
-    R, C, eps = 400000, 64, 1e-5
+    the top-left pixel of image 0, a zero-padded border) a channel whose first row sits hundreds of sigma from its mean cancels
+    in fp32 over many rows; the shift is now a trimmed mean of 16 hashed rows.  Channel mean 50, sigma 0.25, every image's
+    corner pixel (rows 0, HW, 2 HW, ...: what evenly spaced samples would hit) zero."""
+    B, HW, C, eps = 64, 6400, 64, 1e-5
+    R = B * HW
     g = torch.Generator().manual_seed(5)
-    x = (torch.randn(R, C, generator=g) * 0.1 + 50.0)
-    x[0] = 0.0
+    x = (torch.randn(R, C, generator=g) * 0.25 + 50.0)
+    x[::HW] = 0.0
     xd = x.cuda().to(torch.bfloat16)
     mean, rstd = torch.empty(C, device="cuda"), torch.empty(C, device="cuda")
     rm, rv = torch.zeros(C, device="cuda"), torch.ones(C, device="cuda")
     L.bn_stats(xd, mean, rstd, rm, rv, R, C, C, eps, 0.1, True, L.BF16)
     x64 = xd.double()
     mu, var = x64.mean(0), x64.var(0, unbiased=False)
-    assert rel(mean, mu) < 1e-6
+    assert rel(mean, mu) < 1e-5          # fp32 sums over 409,600 rows
     got_var = 1.0 / rstd.double() ** 2 - eps
-    assert float(((got_var - var).abs() / var).max()) < 1e-3, float(((got_var - var).abs() / var).max())
+    e = float(((got_var - var).abs() / var).max())
+    print("one-pass BatchNorm variance, relative error with outlier corner rows:", e)
+    assert e < 2e-3, e
 
 
 @pytest.mark.parametrize("text_model,image_model,size", [("distilbert", "eff_v2_medium", 64), ("distilbert", "shuffle_net", 64),
