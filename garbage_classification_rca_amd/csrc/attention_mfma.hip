@@ -813,9 +813,9 @@ mha_bwd_dq_mfma_v_k(const bf16_t* __restrict__ qkv, const bf16_t* __restrict__ o
 // instead of the 20 of a single-orientation kernel): the matrix pipe idles ~75 % of these kernels' time, the bytes and the
 // exposed latencies are what count.  No atomics, no cross-wave reduction, same summation order per output element.
 //   SHARE = true (default): two 8-wave workgroups per CU, so one's staging runs under the other's MFMAs.  The image pairs
-//     TIME-SHARE one 56-KiB region: Q | dO (+ the per-query constants, from whole dO / O rows) are staged first for the dK / dV
-//     part, whose key / value fragments come from HBM; after a barrier K | V are staged over them for the dQ part, whose query-side
-//     fragments now hit this XCD's L2 (just staged) and whose row constants sit in LDS.
+//     TIME-SHARE one 56-KiB region: K | V are staged first, together with the per-query constants (from whole dO / O rows), for
+//     the dQ part, whose Q / dO fragments come from global memory; after a barrier Q | dO are staged over them for the dK / dV
+//     part, whose key / value fragments hit this XCD's L2 (staged moments ago).
 //   SHARE = false: one 16-wave workgroup per CU with all four images resident (4 x 28 KiB), no global fragment loads at all;
 //     nothing overlaps its staging, so it is the slower of the two (MMRCA_ATTN_BWD_FUSED=2 selects it).
 template <int NKT, int NW, bool SHARE>
@@ -853,22 +853,27 @@ mha_bwd_fused_mfma_v_k(const bf16_t* __restrict__ qkv, const bf16_t* __restrict_
     stage_rows(sm + KB, IMG_TR, Kp, ld, S, Spad);      // row reads for S^T (2-way), transposed reads for dQ^T
     stage_rows(sm + VB, IMG_ROW, Vp, ld, S, Spad);     // row reads for dP^T
   };
-  auto stage_query_side = [&]() {
+  auto stage_query_images = [&]() {
     stage_rows(sm + QB, IMG_TR, Q, ld, S, Spad);
     stage_rows(sm + DB, IMG_TR, dO, ldo, S, Spad);
-    for (int q = threadIdx.x; q < Spad; q += blockDim.x) {
-      float a = 0.f, L = INFINITY;                 // padded query rows: lse=+inf -> P = 0
+  };
+  auto stage_row_constants = [&]() {
+    // rowsum(dO * O): eight lanes per query row, one 16-byte chunk of each operand per lane (whole 128-byte rows per 8 lanes, two
+    // loads per lane instead of a chain of sixteen), then a three-step butterfly
+    for (int e = threadIdx.x; e < Spad * 8; e += blockDim.x) {
+      const int q = e >> 3, c = e & 7;
+      float a = 0.f;
       if (q < S) {
-        L = lse[((int64_t)b * H + h) * S + q] * LOG2E;
+        const bf16x8 x = *reinterpret_cast<const bf16x8*>(dO + (int64_t)q * ldo + c * 8);
+        const bf16x8 y = *reinterpret_cast<const bf16x8*>(O + (int64_t)q * ldo + c * 8);
 #pragma unroll
-        for (int c = 0; c < 8; ++c) {
-          const bf16x8 x = *reinterpret_cast<const bf16x8*>(dO + (int64_t)q * ldo + c * 8);
-          const bf16x8 y = *reinterpret_cast<const bf16x8*>(O + (int64_t)q * ldo + c * 8);
-#pragma unroll
-          for (int j = 0; j < 8; ++j) a += (float)x[j] * (float)y[j];
-        }
+        for (int j = 0; j < 8; ++j) a += (float)x[j] * (float)y[j];
       }
-      lse_s[q] = -L * inv_c1; dsum_s[q] = -a;
+      a += __shfl_xor(a, 1, 64); a += __shfl_xor(a, 2, 64); a += __shfl_xor(a, 4, 64);
+      if (c == 0) {
+        const float L = q < S ? lse[((int64_t)b * H + h) * S + q] * LOG2E : INFINITY;      // padded query rows: lse=+inf -> P = 0
+        lse_s[q] = -L * inv_c1; dsum_s[q] = -a;
+      }
     }
   };
 
@@ -1027,20 +1032,22 @@ mha_bwd_fused_mfma_v_k(const bf16_t* __restrict__ qkv, const bf16_t* __restrict_
   };
 
   if constexpr (SHARE) {
-    stage_query_side();
+    stage_key_side();
+    stage_row_constants();              // reads whole dO / O rows: the dO fragments of the dQ part then hit L2
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     if (stamps) t_staged = __builtin_amdgcn_s_memtime();
-    dkv_part();
-    __syncthreads();                    // every wave is done with the Q | dO images (the row constants stay)
-    stage_key_side();
+    dq_part();
+    __syncthreads();                    // every wave is done with the K | V images (the row constants stay)
+    stage_query_images();
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     if (stamps) t_mid = __builtin_amdgcn_s_memtime();
-    dq_part();
+    dkv_part();
   } else {
     stage_key_side();
-    stage_query_side();
+    stage_query_images();
+    stage_row_constants();
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     if (stamps) t_staged = __builtin_amdgcn_s_memtime();

@@ -22,7 +22,6 @@ torch.cuda.synchronize()
 lib.mmrca_debug_attn_stamps(None)
 t = st.view(-1, 4).double().cpu()
 d = (t[:, 1:] - t[:, :-1])
-print("cycles per workgroup (wave 0; mean / median): first staging %.0f / %.0f   first part (dK,dV; default form) %.0f / %.0f   restaging + second part (dQ) %.0f / %.0f   total %.0f" % (
+print("cycles per workgroup (wave 0; mean / median): first staging (K|V + row constants) %.0f / %.0f   first part (dQ) %.0f / %.0f   restaging (Q|dO) + second part (dK,dV) %.0f / %.0f   total %.0f" % (
     d[:, 0].mean(), d[:, 0].median(), d[:, 1].mean(), d[:, 1].median(), d[:, 2].mean(), d[:, 2].median(), (t[:, 3] - t[:, 0]).mean()))
-span = (t[:, 3].max() - t[:, 0].min())
-print("kernel span %.0f memtime ticks; sum of workgroup times / (256 CUs x span) = %.2f" % (span, (t[:, 3] - t[:, 0]).sum() / (256 * span)))
+print("(default form MMRCA_ATTN_BWD_FUSED=1: two 8-wave workgroups per CU; =2: one 16-wave workgroup, all four images resident, parts = dQ then dK,dV without restaging)")
