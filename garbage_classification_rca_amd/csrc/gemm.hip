@@ -372,7 +372,9 @@ __device__ __forceinline__ void stage_tile(const bf16_t* __restrict__ base, int6
       const int kr = 4 * i + (lane >> 4);
       const int chp = lane & 15;
       const int c = ((((chp >> 1) ^ krow_f(kr))) << 1) | (chp & 1);
-      src = base + (k0 + kr) * ld + row0 + c * 8;
+      int64_t col = row0 + c * 8;
+      if (col > rows_total - 8) col = rows_total - 8;       // ragged edge (rows_total % 8 == 0): read a valid chunk, results are never stored
+      src = base + (k0 + kr) * ld + col;
     }
     __builtin_amdgcn_global_load_lds((gbl_void*)src, (lds_void*)(lds_tile + i * 1024), 16, 0, 0);
   }
@@ -396,7 +398,9 @@ __device__ __forceinline__ void stage_tile_n(const bf16_t* __restrict__ base, in
       const int kr = 4 * i + (lane >> 4);
       const int chp = lane & 15;
       const int c = ((((chp >> 1) ^ krow_f(kr))) << 1) | (chp & 1);
-      src = base + (k0 + kr) * ld + row0 + c * 8;
+      int64_t col = row0 + c * 8;
+      if (col > rows_total - 8) col = rows_total - 8;       // ragged edge (rows_total % 8 == 0): read a valid chunk, results are never stored
+      src = base + (k0 + kr) * ld + col;
     }
     __builtin_amdgcn_global_load_lds((gbl_void*)src, (lds_void*)(lds_tile + i * 1024), 16, 0, 0);
   }
@@ -567,7 +571,7 @@ gemm_mfma_k(const bf16_t* __restrict__ A, const bf16_t* __restrict__ B, void* __
     const int64_t ncol = n_blk + l32 * 4;
     float bv[4] = {0.f, 0.f, 0.f, 0.f};
     if (bias) {
-      bf16x4 b4 = *reinterpret_cast<const bf16x4*>(bias + ncol);
+      bf16x4 b4 = *reinterpret_cast<const bf16x4*>(bias + (ncol < N ? ncol : N - 4));
 #pragma unroll
       for (int r = 0; r < 4; ++r) bv[r] = (float)b4[r];
     }
@@ -575,7 +579,7 @@ gemm_mfma_k(const bf16_t* __restrict__ A, const bf16_t* __restrict__ B, void* __
     for (int rr = 0; rr < 16; ++rr) {
       const int row = wave * 32 + rr * 2 + half;
       const int64_t m = m_blk + row;
-      if (m < M) {
+      if (m < M && ncol < N) {
         const f32x4 c = *reinterpret_cast<const f32x4*>(smem + row * EP_STRIDE + l32 * 16);
         float v[4] = {c[0] + bv[0], c[1] + bv[1], c[2] + bv[2], c[3] + bv[3]};
         if (act == MMRCA_ACT_MUL) {
@@ -645,7 +649,9 @@ __device__ __forceinline__ void stage_tile32(const bf16_t* __restrict__ base, in
       const int kr = 4 * i + (lane >> 4);
       const int chp = lane & 15;
       const int c = ((((chp >> 1) ^ krow_f(kr))) << 1) | (chp & 1);
-      src = base + (k0 + kr) * ld + row0 + c * 8;
+      int64_t col = row0 + c * 8;
+      if (col > rows_total - 8) col = rows_total - 8;       // ragged edge (rows_total % 8 == 0): read a valid chunk, results are never stored
+      src = base + (k0 + kr) * ld + col;
     }
     __builtin_amdgcn_global_load_lds((gbl_void*)src, (lds_void*)(lds_tile + i * 1024), 16, 0, 0);
   }
@@ -781,7 +787,7 @@ gemm_mfma_k32(const bf16_t* __restrict__ A, const bf16_t* __restrict__ B, void* 
     const int64_t ncol = n_blk + l32 * 4;
     float bv[4] = {0.f, 0.f, 0.f, 0.f};
     if (bias) {
-      bf16x4 b4 = *reinterpret_cast<const bf16x4*>(bias + ncol);
+      bf16x4 b4 = *reinterpret_cast<const bf16x4*>(bias + (ncol < N ? ncol : N - 4));
 #pragma unroll
       for (int r = 0; r < 4; ++r) bv[r] = (float)b4[r];
     }
@@ -795,7 +801,7 @@ gemm_mfma_k32(const bf16_t* __restrict__ A, const bf16_t* __restrict__ B, void* 
       for (int rr = 0; rr < 4; ++rr) {
         const int lrow = wave * 8 + rr * 2 + half;
         const int64_t m = m_blk + (lrow >> 4) * 64 + i * 16 + (lrow & 15);
-        if (m < M) {
+        if (m < M && ncol < N) {
           const f32x4 c = *reinterpret_cast<const f32x4*>(smem + lrow * EP_STRIDE + l32 * 16);
           float v[4] = {c[0] + bv[0], c[1] + bv[1], c[2] + bv[2], c[3] + bv[3]};
           if (act == MMRCA_ACT_MUL) {
@@ -965,7 +971,7 @@ gemm_mfma_k1s(const bf16_t* __restrict__ A, const bf16_t* __restrict__ B, void* 
       for (int rr = 0; rr < 4; ++rr) {
         const int lrow = wave * 8 + rr * 2 + half;
         const int64_t m = m_blk + (lrow >> 4) * 64 + i * 16 + (lrow & 15);
-        if (m < M) {
+        if (m < M && ncol < N) {
           const f32x4 c = *reinterpret_cast<const f32x4*>(smem + lrow * EP_STRIDE + l32 * 16);
           float v[4] = {c[0] + bv[0], c[1] + bv[1], c[2] + bv[2], c[3] + bv[3]};
           if (act == MMRCA_ACT_MUL) {
@@ -1017,7 +1023,7 @@ gemm_mfma_k1s(const bf16_t* __restrict__ A, const bf16_t* __restrict__ B, void* 
         float t = 0.f;
 #pragma unroll
         for (int q = 0; q < 8; ++q) t += red[q * 128 + threadIdx.x];
-        atomicAdd(colsum + n_blk + threadIdx.x, t);
+        if (n_blk + threadIdx.x < N) atomicAdd(colsum + n_blk + threadIdx.x, t);
       }
     }
   } else {
@@ -1027,7 +1033,7 @@ gemm_mfma_k1s(const bf16_t* __restrict__ A, const bf16_t* __restrict__ B, void* 
     const int64_t ncol = n_blk + l32 * 4;
     float bv[4] = {0.f, 0.f, 0.f, 0.f};
     if (bias) {
-      bf16x4 b4 = *reinterpret_cast<const bf16x4*>(bias + ncol);
+      bf16x4 b4 = *reinterpret_cast<const bf16x4*>(bias + (ncol < N ? ncol : N - 4));
 #pragma unroll
       for (int r = 0; r < 4; ++r) bv[r] = (float)b4[r];
     }
@@ -1059,7 +1065,7 @@ gemm_mfma_k1s(const bf16_t* __restrict__ A, const bf16_t* __restrict__ B, void* 
       for (int rr = 0; rr < 4; ++rr) {
         const int lrow = wave * 8 + rr * 2 + half;
         const int64_t m = m_blk + (lrow >> 4) * 64 + i * 16 + (lrow & 15);
-        if (m < M) {
+        if (m < M && ncol < N) {
           const f32x4 c = *reinterpret_cast<const f32x4*>(smem + lrow * EP_STRIDE + l32 * 16);
           float v[4] = {c[0] + bv[0], c[1] + bv[1], c[2] + bv[2], c[3] + bv[3]};
           if (act == MMRCA_ACT_MUL) {
@@ -1114,7 +1120,7 @@ gemm_mfma_k1s(const bf16_t* __restrict__ A, const bf16_t* __restrict__ B, void* 
         float t = 0.f;
 #pragma unroll
         for (int q = 0; q < 8; ++q) t += red[q * 128 + threadIdx.x];
-        atomicAdd(colsum + n_blk + threadIdx.x, t);
+        if (n_blk + threadIdx.x < N) atomicAdd(colsum + n_blk + threadIdx.x, t);
       }
     }
   }
@@ -1205,7 +1211,19 @@ static int gemm_dispatch(const void* A, const void* B, void* C, const void* bias
                  (ldc % 4 == 0) && aligned16(A) && aligned16(B) && aligned16(C) && (!bias || aligned16(bias)) &&
                  (!addend || aligned16(addend)) && (!preact || aligned16(preact)) &&
                  (a_layout == MMRCA_ROWK || M % GBM == 0);
-  const bool ok256 = ok_mfma && !out_f32_accum && mmrca_gemm256_ok(M, N, K, a_layout, act, addend != nullptr, preact != nullptr, colsum_fused != nullptr, bias != nullptr) &&
+  // Ragged shapes on the 128x128 MFMA kernels (the conv backbones' channel counts: 192, 224, 1344, ... -- multiples of 8, not of
+  // 128; contraction a multiple of 32, not of 64): edge tiles stage a clamped (duplicate) chunk and never store it, the 32-deep
+  // kernel takes the odd half K step.  Plain epilogue only (bias allowed): side operands are read per tile and would run
+  // past the last row.  These shapes used to fall to the general kernel at a fifth of the rate.
+  static const bool ragged_on = !(getenv("MMRCA_GEMM_RAGGED") && atoi(getenv("MMRCA_GEMM_RAGGED")) == 0);
+  const bool strict_mfma = ok_mfma;
+  if (!ok_mfma && ragged_on && dtype == MMRCA_BF16 && N % 8 == 0 && N >= 8 && K % 32 == 0 && (a_layout == MMRCA_ROWK || (M % 8 == 0 && M >= 8)) &&
+      lda % 8 == 0 && ldb % 8 == 0 && ldc % 4 == 0 && aligned16(A) && aligned16(B) && aligned16(C) && (!bias || (aligned16(bias) && !out_f32_accum)) &&
+      !addend && !preact && act == MMRCA_ACT_NONE && !colsum_fused && (out_f32_accum ? K % 64 == 0 : true) && M >= 64 &&
+      (impl == MMRCA_GEMM_AUTO || impl == MMRCA_GEMM_MFMA_BK32 || impl == MMRCA_GEMM_MFMA_1STAGE))
+    ok_mfma = true;
+  const bool ragged = ok_mfma && !strict_mfma;
+  const bool ok256 = strict_mfma && !out_f32_accum && mmrca_gemm256_ok(M, N, K, a_layout, act, addend != nullptr, preact != nullptr, colsum_fused != nullptr, bias != nullptr) &&
                      M * lda * 2 < (1ll << 32) && (b_layout == MMRCA_KROW ? K * ldb : N * ldb) * 2 < (1ll << 32) && M * ldc * 2 < (1ll << 32);
   if (impl == MMRCA_GEMM_MFMA256 && !ok256)
     return mmrca_fail(-3, "gemm: shape M=%lld N=%lld K=%lld does not qualify for the 256x256 MFMA kernel", (long long)M, (long long)N, (long long)K);
@@ -1259,7 +1277,7 @@ static int gemm_dispatch(const void* A, const void* B, void* C, const void* bias
   const bool use_mfma = ok_mfma && impl != MMRCA_GEMM_REF;   // 128x128 kernel
 
   if (use_mfma) {
-    const int tiles_m = (int)((M + GBM - 1) / GBM), tiles_n = (int)(N / GBN);
+    const int tiles_m = (int)((M + GBM - 1) / GBM), tiles_n = (int)((N + GBN - 1) / GBN);
     int ksplits = 1;
     int64_t ksplit_len = K;
     if (out_f32_accum) {
@@ -1279,8 +1297,10 @@ static int gemm_dispatch(const void* A, const void* B, void* C, const void* bias
     //   forward (ROWK,ROWK) and dgrad (ROWK,KROW): single-stage 128x128x64 (790-910 TFLOP/s vs 680-875 for the two-stage
     //     kernel at two blocks per CU); 64-deep steps keep the ROWK operands' HBM reads in full 128-byte lines;
     //   wgrad (KROW,KROW, fp32 atomics): two-stage 128x128x32 (800-870 vs 680-740), unless there are too few tiles.
-    const bool auto1s = impl == MMRCA_GEMM_AUTO && !at;
-    const bool auto32 = impl == MMRCA_GEMM_AUTO && at && (int64_t)tiles_m * tiles_n >= 64;
+    const bool need32 = K % 64 != 0;                 // (ragged contraction: only the 32-deep kernel takes it)
+    const bool auto1s = impl == MMRCA_GEMM_AUTO && !at && !need32;
+    const bool auto32 = (impl == MMRCA_GEMM_AUTO && at && (int64_t)tiles_m * tiles_n >= 64) || need32;
+    (void)ragged;
     if ((impl == MMRCA_GEMM_MFMA_BK32 || auto32) && !(at && bias)) {
 #define L32(AK_, BK_, AT_) launch_mfma32<AK_, BK_, AT_>(A, B, C, bias, addend, preact, M, N, K, lda, ldb, ldc, act, tiles_m, tiles_n, ksplits, ksplit_len, st)
       if (!ak && !bk && !at) L32(false, false, false);

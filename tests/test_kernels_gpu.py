@@ -222,6 +222,35 @@ def test_gemm_mfma256_layouts_and_epilogues(bl):
     _gemm_case(33200, 2304, 320, al, bl, torch.bfloat16, L.IMPL_MFMA256)
 
 
+@pytest.mark.parametrize("M,N,K,al,bl,accum,bias", [
+    (1000, 224, 192, 0, 0, False, True),      # ragged N (EfficientNetV2-L's 1x1 projections: 224 / 1344 / 192 channels)
+    (777, 1344, 224, 0, 0, False, False),     # ragged N and a contraction that is a multiple of 32, not of 64
+    (1000, 224, 1344, 0, 1, False, False),    # input gradient: B is [K, N] with ragged N
+    (640, 192, 768, 0, 1, False, False),
+    (1344, 224, 1024, 1, 1, True, False),     # weight gradient: A is [K, M] with ragged M, B is [K, N] with ragged N
+    (224, 1344, 960, 1, 1, True, False),
+    (128, 56, 1344, 0, 0, False, True),       # squeeze-excitation FC (56 output channels)
+])
+def test_gemm_ragged_shapes_run_on_the_mfma_kernels(M, N, K, al, bl, accum, bias):
+    """channel counts that are multiples of 8 but not of 128 (and contractions that are multiples of 32 but not of 64) on the
+    128x128 bf16 MFMA kernels: edge tiles read a clamped chunk and never store it.  AUTO against the fp64 product; the same call
+    with MMRCA_GEMM_RAGGED=0 semantics (impl REF) is the checker's checker."""
+    _gemm_case(M, N, K, al, bl, torch.bfloat16, L.IMPL_AUTO, bias=bias, accum=accum)
+    # the output columns past N and rows past M are untouched: a canary frame around C
+    g = torch.Generator().manual_seed(5)
+    A = dev(torch.randn((M, K) if al == 0 else (K, M), generator=g) * 0.5, torch.bfloat16)
+    B = dev(torch.randn((N, K) if bl == 0 else (K, N), generator=g) * 0.5, torch.bfloat16)
+    if accum:
+        return
+    ldc = N + 8
+    C = torch.full((M + 3, ldc), 7.0, device="cuda", dtype=torch.bfloat16)
+    L.gemm(A, B, C, M=M, N=N, K=K, lda=A.shape[1], ldb=B.shape[1], ldc=ldc, a_layout=al, b_layout=bl, dtype=L.BF16)
+    torch.cuda.synchronize()
+    assert float((C[:, N:] - 7.0).abs().max()) == 0.0 and float((C[M:] - 7.0).abs().max()) == 0.0
+    ref = (A.float() if al == 0 else A.float().t()) @ (B.float().t() if bl == 0 else B.float())
+    assert rel_err(C[:M, :N], ref) < TOL[torch.bfloat16]
+
+
 @pytest.mark.parametrize("bl", [0, 1])
 def test_gemm_mfma256_fused_gelu_epilogues_and_colsum(bl):
     """The 256x256 kernel's compile-time epilogues: GELU with gelu' saved (forward FFN1), multiply by the saved gelu' with
