@@ -27,7 +27,7 @@ import numpy as np
 import torch
 import torch.nn.functional as F
 
-from garbage_classification_rca_amd import spec as S
+from oracle import arch as S          # the checker's own tables (independent of the product's spec.py)
 
 
 class OracleSelfAttention(torch.nn.Module):

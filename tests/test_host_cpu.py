@@ -37,6 +37,27 @@ def test_library_builds_loads_and_exports_every_declared_symbol():
     assert L.load().mmrca_version() >= 1
 
 
+def test_oracle_architecture_tables_are_independent_and_agree_with_transformers_and_the_product():
+    """The oracle builds its modules from oracle/arch.py (restated from the third-party sources, cross-checked against the
+    installed transformers classes key by key), never from the product's spec.py; the product's tables must say the same."""
+    from oracle import arch as A
+    from garbage_classification_rca_amd import spec as S
+    src = open(os.path.join(ROOT, "oracle", "model.py")).read() + open(os.path.join(ROOT, "oracle", "arch.py")).read()
+    assert not re.search(r"^\s*(from|import)\s+garbage_classification_rca_amd", src, re.M)       # no import of the product package
+    seen = A.verify_against_transformers()
+    assert seen["distilbert"] > 90 and seen["bert"] > 190 and seen["roberta"] > 190
+    for name in A.TEXT_SPECS:
+        assert dict(S.text_params(S.TEXT_SPECS[name])) == dict(A.text_params(A.TEXT_SPECS[name])), name
+        a, b = A.TEXT_SPECS[name], S.TEXT_SPECS[name]
+        assert (a.vocab, a.max_pos, a.dim, a.heads, a.ffn, a.layers, a.type_vocab, a.pad_id, a.pos_offset, a.ln_eps) == \
+               (b.vocab, b.max_pos, b.dim, b.heads, b.ffn, b.layers, b.type_vocab, b.pad_id, b.pos_offset, b.ln_eps)
+        for i in range(a.layers):
+            assert A.text_layer_keys(a, i) == S.text_layer_keys(b, i)
+    for name in A.VISION_SPECS:
+        assert dict(S.vision_params(S.VISION_SPECS[name])) == dict(A.vision_params(A.VISION_SPECS[name])), name
+    assert (A.NUM_PATCHES, A.SA_HID, A.SA_OUT, A.CA_HID, A.CA_OUT) == (S.NUM_PATCHES, S.SA_HID, S.SA_OUT, S.CA_HID, S.CA_OUT)
+
+
 def test_product_path_fails_loudly_without_gpu_tensors():
     L.load()
     a = torch.zeros(4, 4)
