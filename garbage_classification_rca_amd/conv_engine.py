@@ -27,6 +27,10 @@ from . import lib as L
 # dense 3x3 convolutions on tap-major patches (see ConvEncoder._tap_major); "0" = torchvision's channel-major order everywhere
 TAP_MAJOR = os.environ.get("MMRCA_CONV_TAP_MAJOR", "1") == "1"
 PAD_TAP_K = os.environ.get("MMRCA_CONV_PAD_K", "1") == "1"
+# dense 3x3 / stride-1 convolutions as implicit GEMMs (csrc/conv_igemm.hip): no patch matrix, BatchNorm moments in the epilogue;
+# "0" keeps im2row + GEMM everywhere (the A/B switch of DESIGN 3d)
+IGEMM = os.environ.get("MMRCA_CONV_IGEMM", "1") == "1"
+IGEMM_DGRAD = os.environ.get("MMRCA_CONV_IGEMM_DGRAD", "1") == "1"
 
 ROWPAD = 256
 
@@ -243,11 +247,19 @@ class ConvEncoder:
         K = 9 * u.cin
         return _ru(K, 128) if (u.cout % 128 == 0 and PAD_TAP_K) else K
 
-    def _tap_weight(self, u: "_Unit", w):
+    def _igemm(self, u: "_Unit") -> bool:
+        """stride-1 dense 3x3 convolutions with cin % 32 == 0 run without a patch matrix (mmrca_conv3x3_fwd / _wgrad)"""
+        return IGEMM and self._tap_major(u) and u.k == 3 and not u.dw and u.stride == 1 and u.cin % 32 == 0 and u.cout % 8 == 0
+
+    def _igemm_dgrad(self, u: "_Unit") -> bool:
+        """... and their input gradient is the same kernel on dz with flipped, transposed weights when cout % 32 == 0"""
+        return IGEMM_DGRAD and self._igemm(u) and u.cout % 32 == 0 and u.cin % 8 == 0
+
+    def _tap_weight(self, u: "_Unit", w, pad=True):
         """[cout, cin, 3, 3] -> [cout, 9, cin] (+ zero columns up to _tap_k) copy in the compute dtype (a few KB..1 MB; rebuilt
         at each use: the weights change every optimizer step)"""
         wt = w.view(u.cout, u.cin, 9).transpose(1, 2)
-        Kp = self._tap_k(u)
+        Kp = self._tap_k(u) if pad else 9 * u.cin
         if Kp == 9 * u.cin:
             return wt.contiguous()
         wp = self.buf(f"tmp.wtap.{u.cout}.{Kp}", u.cout, Kp)[: u.cout]          # pad columns stay zero
@@ -261,10 +273,19 @@ class ConvEncoder:
         rows = B * Ho * Wo
         z = self.buf(tag + ".z", rows, u.cout)
         w = self.W(u.conv_key + ".weight")
+        fused_stats = False
         if u.dw:
             L.dwconv3x3_fwd(x, w, z, B, H, Wd, u.cin, u.stride, dt)
         elif u.k == 1:
             L.gemm(x, w, z, M=rows, N=u.cout, K=u.cin, lda=u.cin, ldb=u.cin, ldc=u.cout, dtype=dt, impl=self.o.gemm_impl)
+        elif self._igemm(u):
+            ns = L.conv3x3_stat_slots(B, H, Wd)
+            parts = None
+            if train:
+                parts = (self.buf("tmp.bnpart.mean", ns, u.cout, torch.float32), self.buf("tmp.bnpart.m2", ns, u.cout, torch.float32),
+                         self.buf("tmp.bnpart.cnt", 1, ns, torch.float32))
+            L.conv3x3_fwd(x, self._tap_weight(u, w, pad=False), z, B, H, Wd, u.cin, u.cout, dt, parts)
+            fused_stats = parts is not None
         else:
             K = 9 * u.cin
             if self._tap_major(u):
@@ -279,7 +300,10 @@ class ConvEncoder:
         mean = self.buf(tag + ".mean", 1, u.cout, torch.float32)
         rstd = self.buf(tag + ".rstd", 1, u.cout, torch.float32)
         rm, rv = self.buffers[u.bn_key + ".running_mean"], self.buffers[u.bn_key + ".running_var"]
-        L.bn_stats(z, mean, rstd, rm, rv, rows, u.cout, u.cout, u.eps, 0.1 if train else 0.0, train, dt)
+        if fused_stats:
+            L.conv_bn_finish(parts, B, H, Wd, mean, rstd, rm, rv, u.cout, u.eps, 0.1)
+        else:
+            L.bn_stats(z, mean, rstd, rm, rv, rows, u.cout, u.cout, u.eps, 0.1 if train else 0.0, train, dt)
         y = self.buf(tag + ".y", rows, u.cout)
         L.bn_act_fwd(z, mean, rstd, self.W(u.bn_key + ".weight"), self.W(u.bn_key + ".bias"), y, rows, u.cout, u.act, dt)
         return y, Ho, Wo, dict(x=x, z=z, mean=mean, rstd=rstd, H=H, W=Wd, Ho=Ho, Wo=Wo, train=train)
@@ -305,6 +329,24 @@ class ConvEncoder:
             if need_dx:
                 L.gemm(dz, w, dx, M=rows, N=u.cin, K=u.cout, lda=u.cout, ldb=u.cin, ldc=u.cin, a_layout=L.ROWK, b_layout=L.KROW, dtype=dt,
                        impl=self.o.gemm_impl)
+        elif self._igemm(u):
+            K = 9 * u.cin
+            gwt = self.buf(f"g.wtap.{u.cout}.{K}", u.cout, K, torch.float32)[: u.cout]
+            gwt.zero_()
+            L.conv3x3_wgrad(dz, sv["x"], gwt, B, H, Wd, u.cin, u.cout, dt)
+            gw.view(u.cout, u.cin, 9).add_(gwt.view(u.cout, 9, u.cin).transpose(1, 2))
+            if need_dx:
+                if self._igemm_dgrad(u):
+                    # dx = conv3x3(dz, w'), w'[ci, tap', co] = w[co, ci, 8 - tap']
+                    wf = self.buf(f"tmp.wflip.{u.cin}.{9 * u.cout}", u.cin, 9 * u.cout)[: u.cin]
+                    wf.view(u.cin, 9, u.cout).copy_(w.view(u.cout, u.cin, 9).flip(2).permute(1, 2, 0))
+                    L.conv3x3_fwd(dz, wf, dx, B, H, Wd, u.cout, u.cin, dt)
+                else:
+                    Kp = self._tap_k(u)
+                    col = self.buf("tmp.col", rows, Kp)
+                    L.gemm(dz, self._tap_weight(u, w), col, M=rows, N=Kp, K=u.cout, lda=u.cout, ldb=Kp, ldc=Kp, a_layout=L.ROWK,
+                           b_layout=L.KROW, dtype=dt, impl=self.o.gemm_impl)
+                    L.col2im3x3_tap(col, dx, B, H, Wd, u.cin, u.stride, Kp, dt)
         else:
             tap = self._tap_major(u)
             K = self._tap_k(u) if tap else 9 * u.cin

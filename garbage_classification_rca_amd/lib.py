@@ -64,6 +64,9 @@ _SIGS = {
     "mmrca_col2im3x3_tap": [_vp, _vp, _i32, _i32, _i32, _i32, _i32, _i64, _i32, _vp],
     "mmrca_dwconv3x3_fwd": [_vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _vp],
     "mmrca_dwconv3x3_bwd": [_vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _vp],
+    "mmrca_conv3x3_fwd": [_vp, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _vp],
+    "mmrca_conv_bn_finish": [_vp, _vp, _vp, _i32, _i32, _i32, _vp, _vp, _vp, _vp, _i32, _f32, _f32, _vp],
+    "mmrca_conv3x3_wgrad": [_vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _vp],
     "mmrca_bn_stats": [_vp, _vp, _vp, _vp, _vp, _i64, _i32, _i64, _f32, _f32, _i32, _i32, _vp],
     "mmrca_bn_act_fwd": [_vp] * 6 + [_i64, _i32, _i32, _i32, _vp],
     "mmrca_bn_act_bwd": [_vp] * 10 + [_i64, _i32, _i32, _i32, _i32, _vp],
@@ -107,7 +110,7 @@ _SIGS = {
     "mmrca_cast_f32_to_bf16": [_vp, _vp, _i64, _vp],
 }
 EXPORTS = sorted(list(_SIGS) + ["mmrca_last_error", "mmrca_version", "mmrca_debug_set", "mmrca_debug_attn_stamps", "mmrca_gemm_splitk_workspace_bytes",
-                                  "mmrca_head_bwd_workspace_bytes"])
+                                  "mmrca_head_bwd_workspace_bytes", "mmrca_conv3x3_stat_slots"])
 
 
 def load(build_if_missing: bool = False):
@@ -127,6 +130,8 @@ def load(build_if_missing: bool = False):
         fn.restype = C.c_int
     lib.mmrca_gemm_splitk_workspace_bytes.argtypes = [_i64, _i64]
     lib.mmrca_gemm_splitk_workspace_bytes.restype = _i64
+    lib.mmrca_conv3x3_stat_slots.argtypes = [_i32, _i32, _i32]
+    lib.mmrca_conv3x3_stat_slots.restype = _i64
     lib.mmrca_last_error.restype = C.c_char_p
     lib.mmrca_version.restype = C.c_int
     _lib = lib
@@ -491,6 +496,28 @@ def dwconv3x3_fwd(x, w, y, B, H, W, C, stride, dtype):
 
 def dwconv3x3_bwd(dy, x, w, dx, dw, B, H, W, C, stride, dtype):
     _c("mmrca_dwconv3x3_bwd", ptr(dy), ptr(x), ptr(w), ptr(dx), ptr(dw), B, H, W, C, stride, dtype)
+
+
+def conv3x3_stat_slots(B, H, W) -> int:
+    """rows of the (mean, M2) slot arrays / length of the count array conv3x3_fwd fills for a [B, H, W] output"""
+    return int(load().mmrca_conv3x3_stat_slots(B, H, W))
+
+
+def conv3x3_fwd(x, w_tap, z, B, H, W, Cin, Cout, dtype, parts=None):
+    """implicit-GEMM 3x3 / stride 1 / pad 1 convolution (no patch matrix); parts = (part_mean, part_m2, part_cnt) collects the
+    BatchNorm moments of z in the epilogue (conv_bn_finish turns them into mean / rstd)"""
+    pm, p2, pc = parts if parts is not None else (None, None, None)
+    _c("mmrca_conv3x3_fwd", ptr(x), ptr(w_tap), ptr(z), ptr(pm), ptr(p2), ptr(pc), B, H, W, Cin, Cout, dtype)
+
+
+def conv_bn_finish(parts, B, H, W, mean, rstd, running_mean, running_var, C, eps, momentum):
+    _c("mmrca_conv_bn_finish", ptr(parts[0]), ptr(parts[1]), ptr(parts[2]), B, H, W, ptr(mean), ptr(rstd), ptr(running_mean),
+       ptr(running_var), C, eps, momentum)
+
+
+def conv3x3_wgrad(dz, x, dw_tap, B, H, W, Cin, Cout, dtype):
+    """dw_tap[Cout, 9*Cin] (fp32) += the weight gradient of the same convolution, patches gathered from x inside the kernel"""
+    _c("mmrca_conv3x3_wgrad", ptr(dz), ptr(x), ptr(dw_tap), B, H, W, Cin, Cout, dtype)
 
 
 def bn_stats(x, mean, rstd, running_mean, running_var, rows, C, ld, eps, momentum, train, dtype):

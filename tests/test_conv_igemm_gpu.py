@@ -1,0 +1,122 @@
+"""Implicit-GEMM 3x3 convolutions (csrc/conv_igemm.hip: no patch matrix) against torch.nn.functional.conv2d on the same bf16
+operands: forward, the BatchNorm moments collected in its epilogue, the input gradient (the same kernel on dz with flipped,
+transposed weights) and the weight gradient.  Reference op: torchvision's Conv2dNormActivation 3x3 of FusedMBConv
+(multimodal_model.py:113-126).  Needs an MI355X."""
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+from garbage_classification_rca_amd import lib as L                     # noqa: E402
+
+BF = torch.bfloat16
+
+
+@pytest.fixture(scope="module", autouse=True)
+def _gpu():
+    assert torch.cuda.is_available()
+    L.load()
+
+
+def rel(a, b):
+    a, b = torch.as_tensor(a).double().cpu(), torch.as_tensor(b).double().cpu()
+    return ((a - b).abs().max() / (b.abs().max() + 1e-30)).item()
+
+
+def rows(t):      # NCHW -> [B*H*W, C]
+    return t.permute(0, 2, 3, 1).reshape(-1, t.shape[1]).contiguous()
+
+
+def nchw(r, B, H, W):
+    return r.view(B, H, W, -1).permute(0, 3, 1, 2).contiguous()
+
+
+def tap_major(w):          # [Cout, Cin, 3, 3] -> [Cout, 9*Cin], column tap*Cin + ci
+    return w.permute(0, 2, 3, 1).reshape(w.shape[0], -1).contiguous()
+
+
+# (B, H, W, Cin, Cout): patch shapes 8x16 / 4x32 / 2x64, ragged patches, ragged channel tiles (NJ = 1..4), several channel
+# tiles, halo in one piece (Cin <= 96) and in 96- / 64- / 32-channel pieces
+SHAPES = [(2, 12, 20, 32, 32), (1, 9, 33, 64, 256), (2, 16, 16, 96, 384), (1, 30, 30, 64, 72), (3, 7, 5, 32, 16),
+          (1, 24, 60, 256, 64), (2, 11, 13, 384, 96), (1, 8, 64, 160, 40), (1, 5, 70, 32, 136)]
+
+
+@pytest.mark.parametrize("B,H,W,Cin,Cout", SHAPES + [(10, 64, 64, 32, 32)])           # the last: 640 slots, two merge levels
+def test_forward_and_batchnorm_moments(B, H, W, Cin, Cout):
+    g = torch.Generator().manual_seed(B * 1000 + H * 10 + Cin)
+    x = (torch.randn(B, Cin, H, W, generator=g) + 0.3).to(BF)
+    w = (torch.randn(Cout, Cin, 3, 3, generator=g) * (2.0 / (9 * Cin)) ** 0.5).to(BF)
+    ref = F.conv2d(x.float(), w.float(), None, 1, 1)
+    z = torch.full((B * H * W, Cout), float("nan"), device="cuda", dtype=BF)
+    ns = L.conv3x3_stat_slots(B, H, W)
+    parts = (torch.full((ns, Cout), float("nan"), device="cuda"), torch.full((ns, Cout), float("nan"), device="cuda"),
+             torch.full((ns,), float("nan"), device="cuda"))
+    L.conv3x3_fwd(rows(x).cuda(), tap_major(w).cuda(), z, B, H, W, Cin, Cout, L.BF16, parts)
+    torch.cuda.synchronize()
+    e = rel(nchw(z.float().cpu(), B, H, W), ref)
+    assert e < 6e-3, e                                   # one bf16 rounding of the output
+    assert float(torch.nan_to_num(parts[2]).sum()) == B * H * W          # (second-level slots are still untouched)
+    mean, rstd = torch.empty(Cout, device="cuda"), torch.empty(Cout, device="cuda")
+    rm, rv = torch.zeros(Cout, device="cuda"), torch.ones(Cout, device="cuda")
+    L.conv_bn_finish(parts, B, H, W, mean, rstd, rm, rv, Cout, 1e-3, 0.1)
+    zf = z.float()
+    n = B * H * W
+    assert rel(mean, zf.mean(0)) < 2e-5
+    var = zf.var(0, unbiased=False)
+    assert rel(rstd, (var + 1e-3).rsqrt()) < 2e-5
+    assert rel(rm, 0.1 * zf.mean(0)) < 2e-5
+    assert rel(rv, 0.9 + 0.1 * var * n / (n - 1)) < 2e-5
+    # without the statistics: same outputs
+    z2 = torch.empty_like(z)
+    L.conv3x3_fwd(rows(x).cuda(), tap_major(w).cuda(), z2, B, H, W, Cin, Cout, L.BF16)
+    assert torch.equal(z2, z)
+
+
+def test_moments_of_a_far_off_centre_channel():
+    """(count, mean, M2) per wave + Chan merge needs no shift: mean 50, sigma 0.1 (the case ADVICE r2 raised for the one-pass sums)"""
+    B, H, W, Cin, Cout = 2, 40, 40, 32, 32
+    g = torch.Generator().manual_seed(5)
+    x = torch.zeros(B, Cin, H + 2, W + 2)
+    x[:, 0] = 1.0                                          # a constant plane: the centre tap of channel 0 carries the offset ...
+    x[:, 1:] = torch.randn(B, Cin - 1, H + 2, W + 2, generator=g)
+    x = x[:, :, 1:-1, 1:-1].contiguous().to(BF)            # (interior only: borders see the zero padding like everything else)
+    w = torch.zeros(Cout, Cin, 3, 3)
+    w[:, 0, 1, 1] = 50.0
+    w[:, 1, 1, 1] = 0.1
+    w = w.to(BF)
+    z = torch.empty(B * H * W, Cout, device="cuda", dtype=BF)
+    ns = L.conv3x3_stat_slots(B, H, W)
+    parts = (torch.empty(ns, Cout, device="cuda"), torch.empty(ns, Cout, device="cuda"), torch.empty(ns, device="cuda"))
+    L.conv3x3_fwd(rows(x).cuda(), tap_major(w).cuda(), z, B, H, W, Cin, Cout, L.BF16, parts)
+    mean, rstd = torch.empty(Cout, device="cuda"), torch.empty(Cout, device="cuda")
+    L.conv_bn_finish(parts, B, H, W, mean, rstd, None, None, Cout, 0.0, 0.0)
+    zd = z.double()
+    assert rel(mean, zd.mean(0)) < 1e-6
+    assert rel(rstd, zd.var(0, unbiased=False).rsqrt()) < 1e-4
+
+
+@pytest.mark.parametrize("B,H,W,Cin,Cout", [(2, 12, 20, 32, 32), (1, 9, 33, 64, 256), (2, 16, 16, 96, 384), (1, 24, 60, 64, 64)])
+def test_input_gradient_is_the_same_kernel_on_flipped_weights(B, H, W, Cin, Cout):
+    g = torch.Generator().manual_seed(Cin + Cout)
+    x = torch.randn(B, Cin, H, W, generator=g).to(BF).float().requires_grad_(True)
+    w = (torch.randn(Cout, Cin, 3, 3, generator=g) * (2.0 / (9 * Cin)) ** 0.5).to(BF).float()
+    dz = torch.randn(B, Cout, H, W, generator=g).to(BF).float()
+    F.conv2d(x, w, None, 1, 1).backward(dz)
+    wflip = w.view(Cout, Cin, 9).flip(2).permute(1, 2, 0).reshape(Cin, 9 * Cout).contiguous().to(BF)     # [Cin, 9*Cout]: tap' * Cout + co
+    dx = torch.empty(B * H * W, Cin, device="cuda", dtype=BF)
+    L.conv3x3_fwd(rows(dz).to(BF).cuda(), wflip.cuda(), dx, B, H, W, Cout, Cin, L.BF16)
+    assert rel(nchw(dx.float().cpu(), B, H, W), x.grad) < 6e-3
+
+
+@pytest.mark.parametrize("B,H,W,Cin,Cout", SHAPES + [(4, 50, 50, 64, 256), (2, 3, 3, 8, 8)])
+def test_weight_gradient(B, H, W, Cin, Cout):
+    g = torch.Generator().manual_seed(Cin * 7 + Cout)
+    x = torch.randn(B, Cin, H, W, generator=g).to(BF).float()
+    w = torch.zeros(Cout, Cin, 3, 3, requires_grad=True)
+    dz = torch.randn(B, Cout, H, W, generator=g).to(BF).float()
+    F.conv2d(x, w, None, 1, 1).backward(dz)
+    ref = tap_major(w.grad)
+    dw = torch.full((Cout, 9 * Cin), 0.5, device="cuda")                    # accumulates: += on top of what is there
+    L.conv3x3_wgrad(rows(dz).to(BF).cuda(), rows(x).to(BF).cuda(), dw, B, H, W, Cin, Cout, L.BF16)
+    assert rel(dw.cpu() - 0.5, ref) < 2e-5
