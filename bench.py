@@ -481,6 +481,14 @@ def main():
             Bm, Hm, Sm, dm, packed = meta
             s2 = float((lens[batch_idx] ** 2).sum()) if packed else float(Bm) * Sm * Sm
             return 4.0 * Hm * dm * s2 * (1.0 if kind == "mha_fwd" else 2.5)
+        esz = 2 if args.dtype == "bf16" else 4
+        def attn_bytes(kind, meta, batch_idx):
+            # algorithmic HBM bytes of one launch: forward reads Q, K, V and writes O (+ the fp32 log-sum-exp); backward reads
+            # Q, K, V, O, dO and writes dQ, dK, dV -- 4 resp. 8 tensors of tokens x H x d elements
+            Bm, Hm, Sm, dm, packed = meta
+            tokens = float(lens[batch_idx].sum()) if packed else float(Bm) * Sm
+            return tokens * Hm * (dm * esz * (4.0 if kind == "mha_fwd" else 8.0) + 4.0)
+        abytes = {"mha_fwd": 0.0, "mha_bwd": 0.0}
         akind = {"mha_fwd": [0.0, 0.0, 0], "mha_bwd": [0.0, 0.0, 0]}
         hk = {"head_fwd": [0.0, 0], "head_bwd": [0.0, 0]}
         per_step = max(1, len(kprof) // replay)
@@ -488,6 +496,7 @@ def main():
             dt_ms = e0.elapsed_time(e1)
             if kind in akind:
                 akind[kind][0] += attn_flops(kind, meta, (idx // per_step) % nb); akind[kind][1] += dt_ms; akind[kind][2] += 1
+                abytes[kind] += attn_bytes(kind, meta, (idx // per_step) % nb)
             elif kind in hk:
                 hk[kind][0] += dt_ms; hk[kind][1] += 1
         a_fl, a_ms = akind["mha_fwd"][0] + akind["mha_bwd"][0], akind["mha_fwd"][1] + akind["mha_bwd"][1]
@@ -498,7 +507,16 @@ def main():
                      "frac": round(a_fl / (a_ms * 1e-3) / 1e12 / PEAK_BF16_TFLOPS, 4) if a_ms > 0 else None,
                      "fwd_TFLOPs": tf(*akind["mha_fwd"][:2]), "bwd_TFLOPs": tf(*akind["mha_bwd"][:2]),
                      "ms_per_step": round(a_ms / replay, 3), "launches_per_step": (akind["mha_fwd"][2] + akind["mha_bwd"][2]) // replay,
-                     "north_star_target_frac": 0.40}
+                     "north_star_target_frac": 0.40,
+                     # the roofline that binds at these sizes (S = 197 / 64, d = 64): one pass over Q, K, V, O is 132 FLOP per byte
+                     # forward -- at the 8 TB/s HBM peak the kernels cannot exceed hbm_ceiling_frac of the MFMA peak
+                     "hbm": {"bytes_per_step": int((abytes["mha_fwd"] + abytes["mha_bwd"]) / replay),
+                             "fwd_TBps": round(abytes["mha_fwd"] / (akind["mha_fwd"][1] * 1e-3) / 1e12, 2) if akind["mha_fwd"][1] > 0 else None,
+                             "bwd_TBps": round(abytes["mha_bwd"] / (akind["mha_bwd"][1] * 1e-3) / 1e12, 2) if akind["mha_bwd"][1] > 0 else None,
+                             "peak_TBps": 8.0,
+                             "frac_of_hbm_peak": round((abytes["mha_fwd"] + abytes["mha_bwd"]) / (a_ms * 1e-3) / 8e12, 4) if a_ms > 0 else None,
+                             "hbm_ceiling_frac_of_mfma_peak": round(a_fl / ((abytes["mha_fwd"] + abytes["mha_bwd"]) / 8e12) / 1e12 / PEAK_BF16_TFLOPS, 4)
+                             if abytes["mha_fwd"] + abytes["mha_bwd"] > 0 else None}}
         # fused RCA head (K1): latency and HBM rate (4,112 B per sample + 190 KB of weights per launch)
         d_i, d_t = eng.d_img, eng.d_txt
         head_bytes = B * ((d_i + d_t) * 2 + 16) + 94820 * 2
