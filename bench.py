@@ -508,7 +508,7 @@ def main():
                      "fwd_TFLOPs": tf(*akind["mha_fwd"][:2]), "bwd_TFLOPs": tf(*akind["mha_bwd"][:2]),
                      "ms_per_step": round(a_ms / replay, 3), "launches_per_step": (akind["mha_fwd"][2] + akind["mha_bwd"][2]) // replay,
                      "north_star_target_frac": 0.40,
-                     # the roofline that binds at these sizes (S = 197 / 64, d = 64): one pass over Q, K, V, O is 132 FLOP per byte
+                     # the roofline that binds at these sizes (S = 197 / 64, d = 64): one pass over Q, K, V, O is 98 FLOP per byte
                      # forward -- at the 8 TB/s HBM peak the kernels cannot exceed hbm_ceiling_frac of the MFMA peak
                      "hbm": {"bytes_per_step": int((abytes["mha_fwd"] + abytes["mha_bwd"]) / replay),
                              "fwd_TBps": round(abytes["mha_fwd"] / (akind["mha_fwd"][1] * 1e-3) / 1e12, 2) if akind["mha_fwd"][1] > 0 else None,
