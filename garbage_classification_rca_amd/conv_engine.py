@@ -322,7 +322,7 @@ class ConvEncoder:
         dx = self.buf(f"{tag}.dx.{u.cin}.{rows_in}", rows_in, u.cin) if need_dx else None
         rows_k = _ru(rows, 64)                       # the contraction of the weight gradient runs over whole 64-row steps (zero pad rows)
         if u.dw:
-            L.dwconv3x3_bwd(dz, sv["x"], w, dx, gw, B, H, Wd, u.cin, u.stride, dt)
+            L.dwconv3x3_bwd(dz, sv["x"], w, dx, gw, B, H, Wd, u.cin, u.stride, dt, ws=self.buf("tmp.dw.ws", 1, 4 << 20, torch.float32))
         elif u.k == 1:
             L.gemm(dz, sv["x"], gw, M=u.cout, N=u.cin, K=rows_k, lda=u.cout, ldb=u.cin, ldc=u.cin, a_layout=L.KROW, b_layout=L.KROW,
                    accum=True, dtype=dt, impl=self.o.gemm_impl)

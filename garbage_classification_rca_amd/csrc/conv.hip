@@ -17,7 +17,7 @@
 #define CONV_ACT_RELU 2
 #define CONV_ACT_SIGMOID 3
 
-__device__ __forceinline__ float sigmoid_f(float x) { return 1.0f / (1.0f + __expf(-x)); }
+__device__ __forceinline__ float sigmoid_f(float x) { return __builtin_amdgcn_rcpf(1.0f + __expf(-x)); }   // (hardware reciprocal, 1 ulp: an IEEE division is ten instructions per element in the BatchNorm passes)
 __device__ __forceinline__ float act_f(float u, int act) {
   if (act == CONV_ACT_SILU) return u * sigmoid_f(u);
   if (act == CONV_ACT_RELU) return u > 0.f ? u : 0.f;
@@ -37,6 +37,16 @@ static inline unsigned blocks_for(int64_t n, int per) { return (unsigned)((n + p
 // ---------------------------------------------------------------------------------------------------------------------
 // NCHW fp32 images -> NHWC rows
 // ---------------------------------------------------------------------------------------------------------------------
+// Stencil kernels over a 1-D grid: hardware deals consecutive workgroups round robin to the 8 XCDs, so the workgroups that
+// read rows y-1, y, y+1 of one image (a few ids apart) sit on different XCDs and each private L2 fetches the same input
+// lines from HBM again -- the depthwise 3x3 kernels moved ~3x their algorithmic reads and ran at 2.1-2.4 TB/s.  xcd_block()
+// gives XCD k the k-th contiguous eighth of the logical blocks instead: neighbouring rows meet in one L2.
+__device__ __forceinline__ int64_t xcd_block() {
+  const unsigned nwg = gridDim.x, orig = blockIdx.x;
+  const unsigned q8 = nwg >> 3, r8 = nwg & 7, xcd = orig & 7;
+  return (int64_t)((xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (orig >> 3));
+}
+
 template <typename T>
 __global__ void nchw_to_rows_k(const float* __restrict__ img, T* __restrict__ x, int B, int C, int HW) {
   const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;          // (b, pix, c), c fastest
@@ -177,7 +187,7 @@ extern "C" int mmrca_im2row3x3(const void* x, void* col, int B, int H, int W, in
 __global__ void __launch_bounds__(256)
 im2row3x3_tap_v8_k(const bf16_t* __restrict__ x, bf16_t* __restrict__ col, int B, int H, int W, int C, int Ho, int Wo, int stride, int64_t ldk) {
   const int C8 = C >> 3;
-  const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int64_t idx = xcd_block() * blockDim.x + threadIdx.x;
   if (idx >= (int64_t)B * Ho * Wo * 9 * C8) return;
   const int c0 = (int)(idx % C8) * 8;
   const int tap = (int)((idx / C8) % 9);
@@ -347,12 +357,12 @@ __global__ void dwconv3x3_bwd_weight_k(const T* __restrict__ dy, const T* __rest
                                        int C, int Ho, int Wo, int stride, int64_t pix_per_block) {
   __shared__ float red[4][64][9];
   const int cl = threadIdx.x & 63, pl = threadIdx.x >> 6;
-  const int c = blockIdx.y * 64 + cl;
+  const int c = blockIdx.x * 64 + cl;
   float acc[9];
 #pragma unroll
   for (int t = 0; t < 9; ++t) acc[t] = 0.f;
   const int64_t npix = (int64_t)B * Ho * Wo;
-  const int64_t p0 = (int64_t)blockIdx.x * pix_per_block;
+  const int64_t p0 = (int64_t)blockIdx.y * pix_per_block;
   const int64_t p1 = p0 + pix_per_block < npix ? p0 + pix_per_block : npix;
   if (c < C) {
     for (int64_t op = p0 + pl; op < p1; op += 4) {
@@ -396,7 +406,7 @@ __global__ void __launch_bounds__(256)
 dwconv3x3_fwd_v8_k(const bf16_t* __restrict__ x, const bf16_t* __restrict__ w, bf16_t* __restrict__ y, int B, int H, int W, int C,
                    int Ho, int Wo, int stride) {
   const int C8 = C >> 3;
-  const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int64_t idx = xcd_block() * blockDim.x + threadIdx.x;
   if (idx >= (int64_t)B * Ho * Wo * C8) return;
   const int c0 = (int)(idx % C8) * 8;
   const int64_t op = idx / C8;
@@ -431,7 +441,7 @@ template <bool FLIP>
 __global__ void __launch_bounds__(256)
 dw3x3_s1_strip_v8_k(const bf16_t* __restrict__ in, const bf16_t* __restrict__ w, bf16_t* __restrict__ out, int B, int H, int W, int C) {
   const int C8 = C >> 3, XG = (W + 3) >> 2;
-  const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int64_t idx = xcd_block() * blockDim.x + threadIdx.x;
   if (idx >= (int64_t)B * H * XG * C8) return;
   const int c0 = (int)(idx % C8) * 8;
   const int64_t g = idx / C8;
@@ -477,7 +487,7 @@ __global__ void __launch_bounds__(256)
 dwconv3x3_bwd_data_v8_k(const bf16_t* __restrict__ dy, const bf16_t* __restrict__ w, bf16_t* __restrict__ dx, int B, int H, int W, int C,
                         int Ho, int Wo, int stride) {
   const int C8 = C >> 3;
-  const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int64_t idx = xcd_block() * blockDim.x + threadIdx.x;
   if (idx >= (int64_t)B * H * W * C8) return;
   const int c0 = (int)(idx % C8) * 8;
   const int64_t ip = idx / C8;
@@ -516,14 +526,14 @@ dwconv3x3_bwd_weight_v8_k(const bf16_t* __restrict__ dy, const bf16_t* __restric
                           int C, int Ho, int Wo, int stride, int64_t pix_per_block) {
   __shared__ float red[4][8][73];             // [wave][channel group][8 x 9 (+1 pad)]: the 8 pixel lanes of a wave are reduced by shuffles first
   const int cg = threadIdx.x & 7, pl = threadIdx.x >> 3;
-  const int c0 = blockIdx.y * 64 + cg * 8;
+  const int c0 = blockIdx.x * 64 + cg * 8;
   float acc[8][9];
 #pragma unroll
   for (int j = 0; j < 8; ++j)
 #pragma unroll
     for (int t = 0; t < 9; ++t) acc[j][t] = 0.f;
   const int64_t npix = (int64_t)B * Ho * Wo;
-  const int64_t p0 = (int64_t)blockIdx.x * pix_per_block;
+  const int64_t p0 = (int64_t)blockIdx.y * pix_per_block;
   const int64_t p1 = p0 + pix_per_block < npix ? p0 + pix_per_block : npix;
   if (c0 < C) {
     for (int64_t op = p0 + pl; op < p1; op += 32) {
@@ -553,7 +563,7 @@ dwconv3x3_bwd_weight_v8_k(const bf16_t* __restrict__ dy, const bf16_t* __restric
   __syncthreads();
   for (int e = threadIdx.x; e < 8 * 72; e += 256) {
     const int g = e / 72, r = e % 72;
-    const int c = blockIdx.y * 64 + g * 8 + r / 9;
+    const int c = blockIdx.x * 64 + g * 8 + r / 9;
     if (c < C) atomicAdd(dw + (int64_t)c * 9 + r % 9, (red[0][g][r] + red[1][g][r]) + (red[2][g][r] + red[3][g][r]));
   }
 }
@@ -565,14 +575,14 @@ dwconv3x3_bwd_weight_s1_strip_v8_k(const bf16_t* __restrict__ dy, const bf16_t* 
                                    int C, int64_t grp_per_block) {
   __shared__ float red[4][8][73];
   const int cg = threadIdx.x & 7, pl = threadIdx.x >> 3;
-  const int c0 = blockIdx.y * 64 + cg * 8, XG = (W + 3) >> 2;
+  const int c0 = blockIdx.x * 64 + cg * 8, XG = (W + 3) >> 2;
   float acc[8][9];
 #pragma unroll
   for (int j = 0; j < 8; ++j)
 #pragma unroll
     for (int t = 0; t < 9; ++t) acc[j][t] = 0.f;
   const int64_t ngrp = (int64_t)B * H * XG;
-  const int64_t g0 = (int64_t)blockIdx.x * grp_per_block;
+  const int64_t g0 = (int64_t)blockIdx.y * grp_per_block;
   const int64_t g1 = g0 + grp_per_block < ngrp ? g0 + grp_per_block : ngrp;
   if (c0 < C) {
     for (int64_t g = g0 + pl; g < g1; g += 32) {
@@ -619,19 +629,236 @@ dwconv3x3_bwd_weight_s1_strip_v8_k(const bf16_t* __restrict__ dy, const bf16_t* 
   __syncthreads();
   for (int e = threadIdx.x; e < 8 * 72; e += 256) {
     const int g = e / 72, r = e % 72;
-    const int c = blockIdx.y * 64 + g * 8 + r / 9;
+    const int c = blockIdx.x * 64 + g * 8 + r / 9;
     if (c < C) atomicAdd(dw + (int64_t)c * 9 + r % 9, (red[0][g][r] + red[1][g][r]) + (red[2][g][r] + red[3][g][r]));
   }
+}
+
+
+// Round 3: the same with TWO output rows per thread and 32-bit index arithmetic.  The kernels above were neither HBM- nor
+// L2-bound (2.1-2.4 TB/s, 47 % VALU-busy): a third of their ~970 VALU instructions per thread were 64-bit divisions / address
+// multiplies of the index decomposition, another quarter the bf16 -> fp32 conversion of the 72 weights, repeated for every
+// four outputs.  Here: unsigned 32-bit indices (tensors below 4 GiB: the launcher checks), eight outputs per thread (the 4 x 6
+// input window serves 72 (pixel, tap) pairs: 3 sixteen-byte loads per output instead of 4.5; weights converted once per eight).
+template <bool FLIP>
+__global__ void __launch_bounds__(256)
+dw3x3_s1_strip2_v8_k(const bf16_t* __restrict__ in, const bf16_t* __restrict__ w, bf16_t* __restrict__ out, unsigned B, unsigned H, unsigned W,
+                     unsigned C) {
+  const unsigned C8 = C >> 3, XG = (W + 3) >> 2, YG = (H + 1) >> 1;
+  const unsigned idx = (unsigned)xcd_block() * 256u + threadIdx.x;
+  if (idx >= B * YG * XG * C8) return;
+  const unsigned c0 = (idx % C8) * 8;
+  unsigned g = idx / C8;
+  const unsigned x0 = (g % XG) * 4;
+  g /= XG;
+  const unsigned y0 = (g % YG) * 2, b = g / YG;
+  // all 24 loads of the 4 x 6 window are issued before anything waits: out-of-image positions load a clamped (valid) address
+  // and are zeroed afterwards -- with the loads inside `if (inside)` regions the compiler waited once per row
+  cv_b8 v[4][6];
+  bool rv[4], cvd[6];
+  unsigned coff[6];
+#pragma unroll
+  for (int col = 0; col < 6; ++col) {
+    const int ix = (int)x0 + col - 1;
+    cvd[col] = ix >= 0 && ix < (int)W;
+    coff[col] = (unsigned)(ix < 0 ? 0 : (ix >= (int)W ? (int)W - 1 : ix)) * C;
+  }
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    const int iy = (int)y0 + r - 1;
+    rv[r] = iy >= 0 && iy < (int)H;
+    const unsigned rowoff = ((b * H + (unsigned)(iy < 0 ? 0 : (iy >= (int)H ? (int)H - 1 : iy))) * W) * C + c0;
+#pragma unroll
+    for (int col = 0; col < 6; ++col) v[r][col] = *reinterpret_cast<const cv_b8*>(in + (rowoff + coff[col]));
+  }
+  float wf[8][9];
+  dw_load_w8(w, (int)c0, wf);
+  float s[2][4][8];
+#pragma unroll
+  for (int oy = 0; oy < 2; ++oy)
+#pragma unroll
+    for (int o = 0; o < 4; ++o)
+#pragma unroll
+      for (int j = 0; j < 8; ++j) s[oy][o][j] = 0.f;
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+#pragma unroll
+    for (int col = 0; col < 6; ++col) {
+      const bool ok = rv[r] && cvd[col];
+      float vf[8];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) vf[j] = ok ? (float)v[r][col][j] : 0.f;
+#pragma unroll
+      for (int oy = 0; oy < 2; ++oy) {
+        const int ky = r - oy;
+        if (ky < 0 || ky > 2) continue;
+#pragma unroll
+        for (int o = 0; o < 4; ++o) {
+          const int kx = col - o;
+          if (kx < 0 || kx > 2) continue;
+          const int tap = FLIP ? (2 - ky) * 3 + (2 - kx) : ky * 3 + kx;
+#pragma unroll
+          for (int j = 0; j < 8; ++j) s[oy][o][j] = fmaf(vf[j], wf[j][tap], s[oy][o][j]);
+        }
+      }
+    }
+  }
+#pragma unroll
+  for (int oy = 0; oy < 2; ++oy) {
+    if (y0 + oy >= H) continue;
+#pragma unroll
+    for (int o = 0; o < 4; ++o) {
+      if (x0 + o >= W) continue;
+      cv_b8 r;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) r[j] = (bf16_t)s[oy][o][j];
+      *reinterpret_cast<cv_b8*>(out + (((b * H + y0 + oy) * W + x0 + o) * C + c0)) = r;
+    }
+  }
+}
+
+// weight gradient, same strip.  A thread owns one 8-channel group (64 consecutive groups per wave: every load instruction is one
+// contiguous KiB) and one of the block's four pixel lanes; a group = 2 rows x 4 pixels: 8 loads of dy and the 4 x 6 window of x,
+// all issued before the first use (clamped addresses, zeroed afterwards), serve 72 (pixel, tap) pairs.  The four pixel lanes
+// meet in LDS (ds_add_f32), then one global atomic per (channel, tap) and block.
+template <int R, bool WS>         // output rows per group (R + 2 input rows): 2 needs ~260 registers, 1 fits two waves per SIMD
+__global__ void __launch_bounds__(256)
+dwconv3x3_bwd_weight_s1_strip2_v8_k(const bf16_t* __restrict__ dy, const bf16_t* __restrict__ x, float* __restrict__ dw, unsigned B, unsigned H,
+                                    unsigned W, unsigned C, unsigned grp_per_block, float* __restrict__ ws) {
+  __shared__ float red[64 * 73];          // pitch 73: the 64 lanes of a ds_add fall on 64 different banks
+  const unsigned cl = threadIdx.x & 63, pl = threadIdx.x >> 6;
+  const unsigned C8 = C >> 3, cgrp = blockIdx.x * 64 + cl, c0 = cgrp * 8;
+  const unsigned XG = (W + 3) >> 2, YG = (H + R - 1) / R;
+  for (unsigned e = threadIdx.x; e < 64 * 73; e += 256) red[e] = 0.f;
+  float acc[8][9];
+#pragma unroll
+  for (int j = 0; j < 8; ++j)
+#pragma unroll
+    for (int t = 0; t < 9; ++t) acc[j][t] = 0.f;
+  const unsigned ngrp = B * YG * XG;
+  const unsigned g0 = blockIdx.y * grp_per_block;
+  const unsigned g1 = g0 + grp_per_block < ngrp ? g0 + grp_per_block : ngrp;
+  if (cgrp < C8) {
+    for (unsigned g = g0 + pl; g < g1; g += 4) {
+      const unsigned x0 = (g % XG) * 4, t = g / XG, y0 = (t % YG) * R, b = t / YG;
+      cv_b8 gvb[R][4], xv[R + 2][6];
+      bool rv[R + 2], cvd[6], gok[R][4];
+      unsigned coff[6];
+#pragma unroll
+      for (int col = 0; col < 6; ++col) {
+        const int ix = (int)x0 + col - 1;
+        cvd[col] = ix >= 0 && ix < (int)W;
+        coff[col] = (unsigned)(ix < 0 ? 0 : (ix >= (int)W ? (int)W - 1 : ix)) * C;
+      }
+#pragma unroll
+      for (int oy = 0; oy < R; ++oy) {
+        const unsigned yy = y0 + oy < H ? y0 + oy : H - 1;
+#pragma unroll
+        for (int o = 0; o < 4; ++o) {
+          gok[oy][o] = y0 + oy < H && x0 + o < W;
+          gvb[oy][o] = *reinterpret_cast<const cv_b8*>(dy + (((b * H + yy) * W) * C + c0 + coff[o + 1]));
+        }
+      }
+#pragma unroll
+      for (int r = 0; r < R + 2; ++r) {
+        const int iy = (int)y0 + r - 1;
+        rv[r] = iy >= 0 && iy < (int)H;
+        const unsigned rowoff = ((b * H + (unsigned)(iy < 0 ? 0 : (iy >= (int)H ? (int)H - 1 : iy))) * W) * C + c0;
+#pragma unroll
+        for (int col = 0; col < 6; ++col) xv[r][col] = *reinterpret_cast<const cv_b8*>(x + (rowoff + coff[col]));
+      }
+      float gv[R][4][8];
+#pragma unroll
+      for (int oy = 0; oy < R; ++oy)
+#pragma unroll
+        for (int o = 0; o < 4; ++o)
+#pragma unroll
+          for (int j = 0; j < 8; ++j) gv[oy][o][j] = gok[oy][o] ? (float)gvb[oy][o][j] : 0.f;
+#pragma unroll
+      for (int r = 0; r < R + 2; ++r) {
+#pragma unroll
+        for (int col = 0; col < 6; ++col) {
+          const bool ok = rv[r] && cvd[col];
+          float xf[8];
+#pragma unroll
+          for (int j = 0; j < 8; ++j) xf[j] = ok ? (float)xv[r][col][j] : 0.f;
+#pragma unroll
+          for (int oy = 0; oy < R; ++oy) {
+            const int ky = r - oy;
+            if (ky < 0 || ky > 2) continue;
+#pragma unroll
+            for (int o = 0; o < 4; ++o) {
+              const int kx = col - o;
+              if (kx < 0 || kx > 2) continue;
+#pragma unroll
+              for (int j = 0; j < 8; ++j) acc[j][ky * 3 + kx] = fmaf(gv[oy][o][j], xf[j], acc[j][ky * 3 + kx]);
+            }
+          }
+        }
+      }
+    }
+  }
+  __syncthreads();
+#pragma unroll
+  for (int j = 0; j < 8; ++j)
+#pragma unroll
+    for (int t = 0; t < 9; ++t) atomicAdd(&red[cl * 73 + j * 9 + t], acc[j][t]);
+  __syncthreads();
+  for (unsigned e = threadIdx.x; e < 64 * 72; e += 256) {
+    const unsigned c = blockIdx.x * 512 + e / 9;           // e = cl * 72 + j * 9 + t -> channel (64 blk + cl) * 8 + j = 512 blk + e / 9
+    const float v = red[(e / 72) * 73 + e % 72];
+    // WS: this block's 4,608 sums go to its own row of the workspace (dw_wg_reduce_k adds the rows up).  Without a workspace they
+    // are device-scope atomics, which the 8 XCDs' L2s cannot absorb: ~50 per ns in all, a third of the kernel's time at 768 blocks.
+    if (WS) ws[((int64_t)blockIdx.y * gridDim.x + blockIdx.x) * 4608 + e] = v;
+    else if (c < C) atomicAdd(dw + (int64_t)c * 9 + e % 9, v);
+  }
+}
+
+// dw[i] += sum over the row ranges of ws[range][i]  (i = channel * 9 + tap; a workspace row holds slices * 512 channels).
+// block = 64 outputs x 4 range lanes, grid.y = 8 range chunks (one atomic per output and chunk): a thread walks at most
+// nranges / 32 rows, several loads in flight -- a single thread per output walked 1,500 rows one load at a time (0.4 ms).
+__global__ void __launch_bounds__(256)
+dw_wg_reduce_k(const float* __restrict__ ws, float* __restrict__ dw, int nranges, int n, int64_t stride) {
+  __shared__ float red[4][64];
+  const int il = threadIdx.x & 63, rl = threadIdx.x >> 6;
+  const int i = blockIdx.x * 64 + il;
+  const int per = (nranges + gridDim.y - 1) / gridDim.y;
+  const int r0 = blockIdx.y * per, r1 = r0 + per < nranges ? r0 + per : nranges;
+  float s = 0.f;
+  if (i < n) {
+    int r = r0 + rl;
+    for (; r + 12 < r1; r += 16) {
+      float v[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) v[u] = ws[(int64_t)(r + 4 * u) * stride + i];
+      s += (v[0] + v[1]) + (v[2] + v[3]);
+    }
+    for (; r < r1; r += 4) s += ws[(int64_t)r * stride + i];
+  }
+  red[rl][il] = s;
+  __syncthreads();
+  if (rl == 0 && i < n) atomicAdd(dw + i, (red[0][il] + red[1][il]) + (red[2][il] + red[3][il]));
 }
 
 static bool dw_v8_ok(int C, int dtype, const void* a, const void* b, const void* c) {
   return dtype == MMRCA_BF16 && C % 8 == 0 && ((((uintptr_t)a) | ((uintptr_t)b) | ((uintptr_t)c)) & 15) == 0;
 }
 
+static const int g_dw_blocks_ws = getenv("MMRCA_DW_WG_BLOCKS_WS") ? atoi(getenv("MMRCA_DW_WG_BLOCKS_WS")) : 768;
+static const int g_dw_blocks = getenv("MMRCA_DW_WG_BLOCKS") ? atoi(getenv("MMRCA_DW_WG_BLOCKS")) : 768;
+static const bool g_dw_strip2 = !(getenv("MMRCA_DW_STRIP2") && atoi(getenv("MMRCA_DW_STRIP2")) == 0);
 static const bool g_dw_strip = !(getenv("MMRCA_DW_STRIP") && atoi(getenv("MMRCA_DW_STRIP")) == 0);
 extern "C" int mmrca_dwconv3x3_fwd(const void* x, const void* w, void* y, int B, int H, int W, int C, int stride, int dtype, void* stream) {
   MMRCA_REQUIRE(x && w && y && B > 0 && H > 0 && W > 0 && C > 0 && (stride == 1 || stride == 2), "dwconv3x3_fwd: bad arguments");
   const int Ho = (H - 1) / stride + 1, Wo = (W - 1) / stride + 1;
+  const bool small32 = (int64_t)B * H * W * C * 2 < (1ll << 32);          // 32-bit element offsets in the two-row strip kernels
+  if (dw_v8_ok(C, dtype, x, w, y) && stride == 1 && g_dw_strip && g_dw_strip2 && small32) {
+    const int64_t n = (int64_t)B * ((H + 1) / 2) * ((W + 3) / 4) * (C / 8);
+    hipLaunchKernelGGL(dw3x3_s1_strip2_v8_k<false>, dim3(blocks_for(n, 256)), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)x,
+                       (const bf16_t*)w, (bf16_t*)y, (unsigned)B, (unsigned)H, (unsigned)W, (unsigned)C);
+    MMRCA_CHECK_LAUNCH("dwconv3x3_fwd(strip2)");
+    return 0;
+  }
   if (dw_v8_ok(C, dtype, x, w, y) && stride == 1 && g_dw_strip) {
     const int64_t n = (int64_t)B * H * ((W + 3) / 4) * (C / 8);
     hipLaunchKernelGGL(dw3x3_s1_strip_v8_k<false>, dim3(blocks_for(n, 256)), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)x,
@@ -654,12 +881,26 @@ extern "C" int mmrca_dwconv3x3_fwd(const void* x, const void* w, void* y, int B,
   return 0;
 }
 
+extern "C" int mmrca_dwconv3x3_bwd_ws(const void* dy, const void* x, const void* w, void* dx, float* dw, int B, int H, int W, int C, int stride,
+                                      int dtype, void* ws, int64_t ws_bytes, void* stream);
 extern "C" int mmrca_dwconv3x3_bwd(const void* dy, const void* x, const void* w, void* dx, float* dw, int B, int H, int W, int C, int stride,
                                    int dtype, void* stream) {
+  return mmrca_dwconv3x3_bwd_ws(dy, x, w, dx, dw, B, H, W, C, stride, dtype, nullptr, 0, stream);
+}
+/* the same with a scratch buffer for the weight gradient's partial sums (any size; >= 16 MiB lets every shape of the conv backbones
+ * use ~3,000 blocks): the stride-1 bf16 kernel then writes per-block sums and a second kernel adds them, instead of fp32 atomics */
+extern "C" int mmrca_dwconv3x3_bwd_ws(const void* dy, const void* x, const void* w, void* dx, float* dw, int B, int H, int W, int C, int stride,
+                                      int dtype, void* ws, int64_t ws_bytes, void* stream) {
   MMRCA_REQUIRE(dy && x && w && B > 0 && H > 0 && W > 0 && C > 0 && (stride == 1 || stride == 2), "dwconv3x3_bwd: bad arguments");
   const int Ho = (H - 1) / stride + 1, Wo = (W - 1) / stride + 1;
   hipStream_t st = (hipStream_t)stream;
-  if (dx && dw_v8_ok(C, dtype, dy, w, dx) && stride == 1 && g_dw_strip) {
+  const bool small32 = (int64_t)B * H * W * C * 2 < (1ll << 32);
+  if (dx && dw_v8_ok(C, dtype, dy, w, dx) && stride == 1 && g_dw_strip && g_dw_strip2 && small32) {
+    const int64_t n = (int64_t)B * ((H + 1) / 2) * ((W + 3) / 4) * (C / 8);
+    hipLaunchKernelGGL(dw3x3_s1_strip2_v8_k<true>, dim3(blocks_for(n, 256)), dim3(256), 0, st, (const bf16_t*)dy, (const bf16_t*)w,
+                       (bf16_t*)dx, (unsigned)B, (unsigned)H, (unsigned)W, (unsigned)C);
+    MMRCA_CHECK_LAUNCH("dwconv3x3_bwd(data,strip2)");
+  } else if (dx && dw_v8_ok(C, dtype, dy, w, dx) && stride == 1 && g_dw_strip) {
     const int64_t n = (int64_t)B * H * ((W + 3) / 4) * (C / 8);
     hipLaunchKernelGGL(dw3x3_s1_strip_v8_k<true>, dim3(blocks_for(n, 256)), dim3(256), 0, st, (const bf16_t*)dy, (const bf16_t*)w,
                        (bf16_t*)dx, B, H, W, C);
@@ -681,24 +922,46 @@ extern "C" int mmrca_dwconv3x3_bwd(const void* dy, const void* x, const void* w,
     int64_t nblk = npix / 512 > 0 ? npix / 512 : 1;
     if (nblk > 1024) nblk = 1024;
     const int64_t per = (npix + nblk - 1) / nblk;
+    if (dw_v8_ok(C, dtype, dy, x, dw) && stride == 1 && g_dw_strip && g_dw_strip2 && small32) {
+      const int64_t ngrp = (int64_t)B * H * ((W + 3) / 4);
+      const int slices = (C / 8 + 63) / 64;                  // 64 channel groups (512 channels) per block
+      const int64_t row_bytes = (int64_t)slices * 4608 * 4;  // one workspace row: every block of one pixel range
+      const bool use_ws = ws && (((uintptr_t)ws) & 15) == 0 && ws_bytes >= 8 * row_bytes;
+      int64_t nb = (use_ws ? g_dw_blocks_ws : g_dw_blocks) / slices;   // blocks in all: ~12 per CU with a workspace, ~3 when every block ends in 4,608 atomics
+      if (use_ws && nb > ws_bytes / row_bytes) nb = ws_bytes / row_bytes;
+      if (nb > ngrp / 8) nb = ngrp / 8 > 0 ? ngrp / 8 : 1;
+      const int64_t gper = (ngrp + nb - 1) / nb;
+      const unsigned nranges = (unsigned)((ngrp + gper - 1) / gper);
+      if (use_ws) {
+        hipLaunchKernelGGL((dwconv3x3_bwd_weight_s1_strip2_v8_k<1, true>), dim3((unsigned)slices, nranges), dim3(256), 0, st,
+                           (const bf16_t*)dy, (const bf16_t*)x, dw, (unsigned)B, (unsigned)H, (unsigned)W, (unsigned)C, (unsigned)gper, (float*)ws);
+        hipLaunchKernelGGL(dw_wg_reduce_k, dim3((unsigned)((C * 9 + 63) / 64), 8), dim3(256), 0, st, (const float*)ws, dw, (int)nranges, C * 9,
+                           (int64_t)slices * 4608);
+      } else {
+        hipLaunchKernelGGL((dwconv3x3_bwd_weight_s1_strip2_v8_k<1, false>), dim3((unsigned)slices, nranges), dim3(256), 0, st,
+                           (const bf16_t*)dy, (const bf16_t*)x, dw, (unsigned)B, (unsigned)H, (unsigned)W, (unsigned)C, (unsigned)gper, (float*)nullptr);
+      }
+      MMRCA_CHECK_LAUNCH("dwconv3x3_bwd(weight,strip2)");
+      return 0;
+    }
     if (dw_v8_ok(C, dtype, dy, x, dw) && stride == 1 && g_dw_strip) {
       const int64_t ngrp = (int64_t)B * H * ((W + 3) / 4);
       int64_t nb = ngrp / 128 > 0 ? ngrp / 128 : 1;
       if (nb > 1024) nb = 1024;
       const int64_t gper = (ngrp + nb - 1) / nb;
-      hipLaunchKernelGGL(dwconv3x3_bwd_weight_s1_strip_v8_k, dim3((unsigned)((ngrp + gper - 1) / gper), (unsigned)((C + 63) / 64)), dim3(256), 0, st,
+      hipLaunchKernelGGL(dwconv3x3_bwd_weight_s1_strip_v8_k, dim3((unsigned)((C + 63) / 64), (unsigned)((ngrp + gper - 1) / gper)), dim3(256), 0, st,
                          (const bf16_t*)dy, (const bf16_t*)x, dw, B, H, W, C, gper);
       MMRCA_CHECK_LAUNCH("dwconv3x3_bwd(weight,strip)");
       return 0;
     }
     if (dw_v8_ok(C, dtype, dy, x, dw)) {
-      hipLaunchKernelGGL(dwconv3x3_bwd_weight_v8_k, dim3((unsigned)nblk, (unsigned)((C + 63) / 64)), dim3(256), 0, st, (const bf16_t*)dy,
+      hipLaunchKernelGGL(dwconv3x3_bwd_weight_v8_k, dim3((unsigned)((C + 63) / 64), (unsigned)nblk), dim3(256), 0, st, (const bf16_t*)dy,
                          (const bf16_t*)x, dw, B, H, W, C, Ho, Wo, stride, per);
       MMRCA_CHECK_LAUNCH("dwconv3x3_bwd(weight,v8)");
       return 0;
     }
     MMRCA_DISPATCH_DTYPE(dtype, "dwconv3x3_bwd",
-      hipLaunchKernelGGL(dwconv3x3_bwd_weight_k<T>, dim3((unsigned)nblk, (unsigned)((C + 63) / 64)), dim3(256), 0, st, (const T*)dy,
+      hipLaunchKernelGGL(dwconv3x3_bwd_weight_k<T>, dim3((unsigned)((C + 63) / 64), (unsigned)nblk), dim3(256), 0, st, (const T*)dy,
                          (const T*)x, dw, B, H, W, C, Ho, Wo, stride, per);)
     MMRCA_CHECK_LAUNCH("dwconv3x3_bwd(weight)");
   }
@@ -715,8 +978,8 @@ __global__ void col_moment_k(const T* __restrict__ x, const float* __restrict__ 
                              int64_t ld, int64_t rows_per_block) {
   __shared__ float red[4][64];
   const int cl = threadIdx.x & 63, rl = threadIdx.x >> 6;
-  const int c = blockIdx.y * 64 + cl;
-  const int64_t r0 = (int64_t)blockIdx.x * rows_per_block;
+  const int c = blockIdx.x * 64 + cl;
+  const int64_t r0 = (int64_t)blockIdx.y * rows_per_block;
   const int64_t r1 = r0 + rows_per_block < rows ? r0 + rows_per_block : rows;
   float s = 0.f;
   if (c < C) {
@@ -782,8 +1045,8 @@ col_moment_v8_k(const bf16_t* __restrict__ x, const float* __restrict__ mean, fl
                 int64_t rows_per_block) {
   __shared__ float red[4][8][9];
   const int cg = threadIdx.x & 7, rl = threadIdx.x >> 3;
-  const int c0 = blockIdx.y * 64 + cg * 8;
-  const int64_t r0 = (int64_t)blockIdx.x * rows_per_block;
+  const int c0 = blockIdx.x * 64 + cg * 8;
+  const int64_t r0 = (int64_t)blockIdx.y * rows_per_block;
   const int64_t r1 = r0 + rows_per_block < rows ? r0 + rows_per_block : rows;
   float acc[1][8];
 #pragma unroll
@@ -799,7 +1062,7 @@ col_moment_v8_k(const bf16_t* __restrict__ x, const float* __restrict__ mean, fl
     }
   }
   float* const outs[1] = {out};
-  col_reduce8<1>(acc, red, outs, blockIdx.y, C);
+  col_reduce8<1>(acc, red, outs, blockIdx.x, C);
 }
 
 // Both moments in ONE pass over x (bf16 fast path of mmrca_bn_stats): sums of d and d*d with d = x - shift[c] (fp32 sums).
@@ -821,8 +1084,8 @@ col_moment2_v8_k(const bf16_t* __restrict__ x, float* __restrict__ s1, float* __
                  int64_t rows_per_block) {
   __shared__ float red[4][8][17];
   const int cg = threadIdx.x & 7, rl = threadIdx.x >> 3;
-  const int c0 = blockIdx.y * 64 + cg * 8;
-  const int64_t r0 = (int64_t)blockIdx.x * rows_per_block;
+  const int c0 = blockIdx.x * 64 + cg * 8;
+  const int64_t r0 = (int64_t)blockIdx.y * rows_per_block;
   const int64_t r1 = r0 + rows_per_block < rows ? r0 + rows_per_block : rows;
   float acc[2][8];
 #pragma unroll
@@ -838,14 +1101,24 @@ col_moment2_v8_k(const bf16_t* __restrict__ x, float* __restrict__ s1, float* __
     }
 #pragma unroll
     for (int j = 0; j < 8; ++j) m[j] = bn_trimmed(m[j], mlo[j], mhi[j]);
-    for (int64_t r = r0 + rl; r < r1; r += 32) {
+    int64_t r = r0 + rl;
+    for (; r + 96 < r1; r += 128) {                    // four rows in flight per thread (one load per iteration ran at 2.6 TB/s)
+      cm_b8 v[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) v[u] = *reinterpret_cast<const cm_b8*>(x + (r + 32 * u) * ld + c0);
+#pragma unroll
+      for (int u = 0; u < 4; ++u)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) { const float d = (float)v[u][j] - m[j]; acc[0][j] += d; acc[1][j] = fmaf(d, d, acc[1][j]); }
+    }
+    for (; r < r1; r += 32) {
       const cm_b8 v = *reinterpret_cast<const cm_b8*>(x + r * ld + c0);
 #pragma unroll
       for (int j = 0; j < 8; ++j) { const float d = (float)v[j] - m[j]; acc[0][j] += d; acc[1][j] = fmaf(d, d, acc[1][j]); }
     }
   }
   float* const outs[2] = {s1, s2};
-  col_reduce8<2>(acc, red, outs, blockIdx.y, C);
+  col_reduce8<2>(acc, red, outs, blockIdx.x, C);
 }
 // (sum d, sum d^2) -> mean, rstd (in place), running stats
 __global__ void bn_finish_shifted_k(const bf16_t* __restrict__ x, float* __restrict__ mean, float* __restrict__ rstd,
@@ -873,8 +1146,8 @@ bn_act_bwd_reduce_v8_k(const bf16_t* __restrict__ dy, const bf16_t* __restrict__
                        float* __restrict__ sum_du, float* __restrict__ sum_duxh, int64_t rows, int C, int act, int64_t rows_per_block) {
   __shared__ float red[4][8][17];
   const int cg = threadIdx.x & 7, rl = threadIdx.x >> 3;
-  const int c0 = blockIdx.y * 64 + cg * 8;
-  const int64_t r0 = (int64_t)blockIdx.x * rows_per_block;
+  const int c0 = blockIdx.x * 64 + cg * 8;
+  const int64_t r0 = (int64_t)blockIdx.y * rows_per_block;
   const int64_t r1 = r0 + rows_per_block < rows ? r0 + rows_per_block : rows;
   float acc[2][8];
 #pragma unroll
@@ -883,7 +1156,24 @@ bn_act_bwd_reduce_v8_k(const bf16_t* __restrict__ dy, const bf16_t* __restrict__
     float m[8], rs[8], g[8], b[8];
 #pragma unroll
     for (int j = 0; j < 8; ++j) { m[j] = mean[c0 + j]; rs[j] = rstd[c0 + j]; g[j] = (float)gamma[c0 + j]; b[j] = (float)beta[c0 + j]; }
-    for (int64_t r = r0 + rl; r < r1; r += 32) {
+    int64_t r = r0 + rl;
+    for (; r + 96 < r1; r += 128) {                    // four rows of both operands in flight per thread
+      cm_b8 xv[4], dv[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        xv[u] = *reinterpret_cast<const cm_b8*>(x + (r + 32 * u) * C + c0);
+        dv[u] = *reinterpret_cast<const cm_b8*>(dy + (r + 32 * u) * C + c0);
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          const float xh = ((float)xv[u][j] - m[j]) * rs[j];
+          const float du = (float)dv[u][j] * act_grad_f(xh * g[j] + b[j], act);
+          acc[0][j] += du; acc[1][j] = fmaf(du, xh, acc[1][j]);
+        }
+    }
+    for (; r < r1; r += 32) {
       const cm_b8 xv = *reinterpret_cast<const cm_b8*>(x + r * C + c0), dv = *reinterpret_cast<const cm_b8*>(dy + r * C + c0);
 #pragma unroll
       for (int j = 0; j < 8; ++j) {
@@ -894,14 +1184,23 @@ bn_act_bwd_reduce_v8_k(const bf16_t* __restrict__ dy, const bf16_t* __restrict__
     }
   }
   float* const outs[2] = {sum_du, sum_duxh};
-  col_reduce8<2>(acc, red, outs, blockIdx.y, C);
+  col_reduce8<2>(acc, red, outs, blockIdx.x, C);
 }
 
 static void col_grid(int64_t rows, int C, dim3* grid, int64_t* per) {
+  // ~3,000 blocks in all (12 per CU): every block pays a prologue (the moments' shift = 16 sampled rows) and a reduction tail, so
+  // 256-row blocks -- 5,000-10,000 of them on the MBConv tensors -- spent most of their time there (moments at 2.6 TB/s)
+  const int64_t slices = (C + 63) / 64;
+  int64_t cap = 3072 / slices;
+  if (cap < 8) cap = 8;
+  if (cap > 2048) cap = 2048;
   int64_t nblk = rows / 256 > 0 ? rows / 256 : 1;
-  if (nblk > 2048) nblk = 2048;
+  if (nblk > cap) nblk = cap;
   *per = (rows + nblk - 1) / nblk;
-  *grid = dim3((unsigned)((rows + *per - 1) / *per), (unsigned)((C + 63) / 64));
+  // x = 64-channel slice (fastest), y = row range: the blocks resident at one time then cover WHOLE rows of a row range.  With the
+  // row ranges in x, the ~2,000 resident blocks all read the same 128-byte slice of every row (stride 2C bytes) -- one DRAM burst
+  // per page: col_moment2 ran at 2.5 TB/s, the depthwise weight gradient at 1.8.
+  *grid = dim3((unsigned)((C + 63) / 64), (unsigned)((rows + *per - 1) / *per));
 }
 
 static const bool g_bn_one_pass = !(getenv("MMRCA_BN_ONE_PASS") && atoi(getenv("MMRCA_BN_ONE_PASS")) == 0);
@@ -1026,8 +1325,8 @@ __global__ void bn_act_bwd_reduce_k(const T* __restrict__ dy, const T* __restric
                                     int64_t rows_per_block) {
   __shared__ float red[2][4][64];
   const int cl = threadIdx.x & 63, rl = threadIdx.x >> 6;
-  const int c = blockIdx.y * 64 + cl;
-  const int64_t r0 = (int64_t)blockIdx.x * rows_per_block;
+  const int c = blockIdx.x * 64 + cl;
+  const int64_t r0 = (int64_t)blockIdx.y * rows_per_block;
   const int64_t r1 = r0 + rows_per_block < rows ? r0 + rows_per_block : rows;
   float s0 = 0.f, s1 = 0.f;
   if (c < C) {

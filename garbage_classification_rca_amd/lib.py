@@ -63,6 +63,7 @@ _SIGS = {
     "mmrca_im2row3x3_tap": [_vp, _vp, _i32, _i32, _i32, _i32, _i32, _i64, _i32, _vp],
     "mmrca_col2im3x3_tap": [_vp, _vp, _i32, _i32, _i32, _i32, _i32, _i64, _i32, _vp],
     "mmrca_dwconv3x3_fwd": [_vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _vp],
+    "mmrca_dwconv3x3_bwd_ws": [_vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _vp, _i64, _vp],
     "mmrca_dwconv3x3_bwd": [_vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _vp],
     "mmrca_conv3x3_fwd": [_vp, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _vp],
     "mmrca_conv_bn_finish": [_vp, _vp, _vp, _i32, _i32, _i32, _vp, _vp, _vp, _vp, _i32, _f32, _f32, _vp],
@@ -494,8 +495,12 @@ def dwconv3x3_fwd(x, w, y, B, H, W, C, stride, dtype):
     _c("mmrca_dwconv3x3_fwd", ptr(x), ptr(w), ptr(y), B, H, W, C, stride, dtype)
 
 
-def dwconv3x3_bwd(dy, x, w, dx, dw, B, H, W, C, stride, dtype):
-    _c("mmrca_dwconv3x3_bwd", ptr(dy), ptr(x), ptr(w), ptr(dx), ptr(dw), B, H, W, C, stride, dtype)
+def dwconv3x3_bwd(dy, x, w, dx, dw, B, H, W, C, stride, dtype, ws=None):
+    """ws: optional scratch tensor for the weight gradient's per-block partial sums (replaces its fp32 atomics)"""
+    if ws is None:
+        _c("mmrca_dwconv3x3_bwd", ptr(dy), ptr(x), ptr(w), ptr(dx), ptr(dw), B, H, W, C, stride, dtype)
+    else:
+        _c("mmrca_dwconv3x3_bwd_ws", ptr(dy), ptr(x), ptr(w), ptr(dx), ptr(dw), B, H, W, C, stride, dtype, ptr(ws), ws.numel() * ws.element_size())
 
 
 def conv3x3_stat_slots(B, H, W) -> int:

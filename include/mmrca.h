@@ -164,6 +164,11 @@ int mmrca_conv3x3_wgrad(const void* dz, const void* x, float* dw_tap, int B, int
 int mmrca_dwconv3x3_fwd(const void* x, const void* w, void* y, int B, int H, int W, int C, int stride, int dtype, void* stream);
 int mmrca_dwconv3x3_bwd(const void* dy, const void* x, const void* w, void* dx, float* dw, int B, int H, int W, int C, int stride,
                         int dtype, void* stream);
+/* the same with a caller-provided scratch buffer (16-byte aligned, any size; 16 MiB serves every shape of the conv backbones): the
+ * stride-1 bf16 weight gradient then writes per-block partial sums there and adds them up in a second kernel instead of issuing
+ * device-scope fp32 atomics */
+int mmrca_dwconv3x3_bwd_ws(const void* dy, const void* x, const void* w, void* dx, float* dw, int B, int H, int W, int C, int stride,
+                           int dtype, void* ws, int64_t ws_bytes, void* stream);
 /* torch.nn.BatchNorm2d over the rows of x [rows, C] (ld): train != 0 -> batch mean / biased variance into mean, rstd and, with
  * momentum > 0, the running statistics update (unbiased variance); train == 0 -> mean / rstd from the running statistics */
 int mmrca_bn_stats(const void* x, float* mean, float* rstd, float* running_mean, float* running_var, int64_t rows, int C,

@@ -67,9 +67,10 @@ def test_im2row_gemm_is_conv3x3_and_col2im_is_its_input_gradient(dt, stride):
 
 @pytest.mark.parametrize("dt", [torch.float32, torch.bfloat16])
 @pytest.mark.parametrize("stride", [1, 2])
-@pytest.mark.parametrize("C", [70, 72])      # 72: the 8-channel kernels (stride 1: four output pixels per thread)
-def test_depthwise_conv_fwd_bwd(dt, stride, C):
-    B, H, W = 3, 8, 11
+@pytest.mark.parametrize("C", [70, 72])      # 72: the 8-channel kernels (stride 1: two rows x four output pixels per thread)
+@pytest.mark.parametrize("H,W", [(8, 11), (15, 15), (7, 4), (1, 9)])      # odd heights: the second row of the last strip is masked
+def test_depthwise_conv_fwd_bwd(dt, stride, C, H, W):
+    B = 3
     g = torch.Generator().manual_seed(2)
     x = torch.randn(B, C, H, W, generator=g).to(dt).float().requires_grad_(True)
     w = (torch.randn(C, 1, 3, 3, generator=g) * 0.3).to(dt).float().requires_grad_(True)
@@ -86,6 +87,10 @@ def test_depthwise_conv_fwd_bwd(dt, stride, C):
     L.dwconv3x3_bwd(rows(dy).cuda().to(dt), xd, wd, dx, dw, B, H, W, C, stride, L.dtype_code(dt))
     assert rel(nchw(dx.float().cpu(), B, H, W), x.grad) < TOL[dt]
     assert rel(dw.cpu().view(C, 1, 3, 3), w.grad) < (1e-4 if dt == torch.float32 else 2e-2)
+    # the same through the workspace form (per-block partial sums + a second kernel instead of atomics); dw accumulates
+    dw2 = torch.full((C, 9), 0.25, device="cuda")
+    L.dwconv3x3_bwd(rows(dy).cuda().to(dt), xd, wd, None, dw2, B, H, W, C, stride, L.dtype_code(dt), ws=torch.empty(1 << 20, device="cuda"))
+    assert rel(dw2.cpu().view(C, 1, 3, 3) - 0.25, w.grad) < (1e-4 if dt == torch.float32 else 2e-2)
 
 
 @pytest.mark.parametrize("dt", [torch.float32, torch.bfloat16])
