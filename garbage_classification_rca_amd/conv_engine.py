@@ -30,6 +30,7 @@ PAD_TAP_K = os.environ.get("MMRCA_CONV_PAD_K", "1") == "1"
 # dense 3x3 / stride-1 convolutions as implicit GEMMs (csrc/conv_igemm.hip): no patch matrix, BatchNorm moments in the epilogue;
 # "0" keeps im2row + GEMM everywhere (the A/B switch of DESIGN 3d)
 IGEMM = os.environ.get("MMRCA_CONV_IGEMM", "1") == "1"
+FUSE_RES = os.environ.get("MMRCA_CONV_FUSE_RES", "1") == "1"       # residual connection inside the block's last BatchNorm pass
 IGEMM_DGRAD = os.environ.get("MMRCA_CONV_IGEMM_DGRAD", "1") == "1"
 
 ROWPAD = 256
@@ -266,8 +267,10 @@ class ConvEncoder:
         wp[:, : 9 * u.cin].view(u.cout, 9, u.cin).copy_(wt)
         return wp
 
-    def _unit_fwd(self, u: _Unit, x, B, H, Wd, tag, train, save):
-        """x: rows [B*H*W, cin] -> y rows [B*Ho*Wo, cout]; returns (y, Ho, Wo, saved)."""
+    def _unit_fwd(self, u: _Unit, x, B, H, Wd, tag, train, save, res=None, rowscale=None, out=None):
+        """x: rows [B*H*W, cin] -> y rows [B*Ho*Wo, cout]; returns (y, Ho, Wo, saved).  With `res` (the block input) the unit is
+        the last one of a residual block and writes out = res + rowscale[sample] * y directly (mmrca_bn_act_fwd_res) when the
+        fused kernel is built for the dtype; the caller checks `saved["fused_res"]`."""
         dt = self.o.dt
         Ho, Wo = (H - 1) // u.stride + 1, (Wd - 1) // u.stride + 1
         rows = B * Ho * Wo
@@ -304,9 +307,15 @@ class ConvEncoder:
             L.conv_bn_finish(parts, B, H, Wd, mean, rstd, rm, rv, u.cout, u.eps, 0.1)
         else:
             L.bn_stats(z, mean, rstd, rm, rv, rows, u.cout, u.cout, u.eps, 0.1 if train else 0.0, train, dt)
-        y = self.buf(tag + ".y", rows, u.cout)
-        L.bn_act_fwd(z, mean, rstd, self.W(u.bn_key + ".weight"), self.W(u.bn_key + ".bias"), y, rows, u.cout, u.act, dt)
-        return y, Ho, Wo, dict(x=x, z=z, mean=mean, rstd=rstd, H=H, W=Wd, Ho=Ho, Wo=Wo, train=train)
+        fused_res = res is not None and FUSE_RES and self.o.dtype == torch.bfloat16 and u.cout % 8 == 0
+        if fused_res:
+            y = out
+            L.bn_act_fwd_res(z, mean, rstd, self.W(u.bn_key + ".weight"), self.W(u.bn_key + ".bias"), res, rowscale, y, rows, u.cout, u.act,
+                             Ho * Wo, dt)
+        else:
+            y = self.buf(tag + ".y", rows, u.cout)
+            L.bn_act_fwd(z, mean, rstd, self.W(u.bn_key + ".weight"), self.W(u.bn_key + ".bias"), y, rows, u.cout, u.act, dt)
+        return y, Ho, Wo, dict(x=x, z=z, mean=mean, rstd=rstd, H=H, W=Wd, Ho=Ho, Wo=Wo, train=train, fused_res=fused_res)
 
     def _unit_bwd(self, u: _Unit, dy, sv, B, need_dx=True, tag="g"):
         """dy: gradient at the unit's output rows; returns dx rows (or None)."""
@@ -322,7 +331,7 @@ class ConvEncoder:
         dx = self.buf(f"{tag}.dx.{u.cin}.{rows_in}", rows_in, u.cin) if need_dx else None
         rows_k = _ru(rows, 64)                       # the contraction of the weight gradient runs over whole 64-row steps (zero pad rows)
         if u.dw:
-            L.dwconv3x3_bwd(dz, sv["x"], w, dx, gw, B, H, Wd, u.cin, u.stride, dt, ws=self.buf("tmp.dw.ws", 1, 4 << 20, torch.float32))
+            L.dwconv3x3_bwd(dz, sv["x"], w, dx, gw, B, H, Wd, u.cin, u.stride, dt, ws=self.buf("tmp.dw.ws", 1, 16 << 20, torch.float32))
         elif u.k == 1:
             L.gemm(dz, sv["x"], gw, M=u.cout, N=u.cin, K=rows_k, lda=u.cout, ldb=u.cin, ldc=u.cin, a_layout=L.KROW, b_layout=L.KROW,
                    accum=True, dtype=dt, impl=self.o.gemm_impl)
@@ -450,17 +459,22 @@ class ConvEncoder:
                 bs = dict(units=[], H=h, W=w, cin=blk["units"][0].cin)
                 y, hh, ww = x, h, w
                 us = blk["units"]
+                rs = rowscale[sd_pos[bi]] if (blk["res"] and rowscale is not None and bi in sd_pos) else None
                 for ui, u in enumerate(us):
                     if blk["se"] is not None and ui == len(us) - 1:
                         y, bs["se"] = self._se_fwd(blk["se"], y, B, hh * ww, tag, save)
-                    y, hh, ww, sv = self._unit_fwd(u, y, B, hh, ww, f"{tag}.u{ui}", train, save)
+                    if blk["res"] and ui == len(us) - 1:      # the last unit adds the residual itself when the fused kernel applies
+                        y, hh, ww, sv = self._unit_fwd(u, y, B, hh, ww, f"{tag}.u{ui}", train, save, res=x, rowscale=rs,
+                                                       out=self.buf(f"{tag}.out", B * hh * ww, u.cout))
+                    else:
+                        y, hh, ww, sv = self._unit_fwd(u, y, B, hh, ww, f"{tag}.u{ui}", train, save)
                     bs["units"].append(sv)
                 if blk["res"]:
-                    rs = rowscale[sd_pos[bi]] if (rowscale is not None and bi in sd_pos) else None
-                    out = self.buf(f"{tag}.out", B * hh * ww, us[-1].cout)
-                    L.residual_add(x, y, rs, out, B, hh * ww * us[-1].cout, dt)
+                    if not bs["units"][-1]["fused_res"]:
+                        out = self.buf(f"{tag}.out", B * hh * ww, us[-1].cout)
+                        L.residual_add(x, y, rs, out, B, hh * ww * us[-1].cout, dt)
+                        y = out
                     bs["rowscale"] = rs
-                    y = out
                 x, h, w = y, hh, ww
             elif blk["kind"] == "shuffle_down":
                 bs = dict(b1=[], b2=[], H=h, W=w)

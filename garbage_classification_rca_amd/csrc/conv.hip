@@ -814,6 +814,78 @@ dwconv3x3_bwd_weight_s1_strip2_v8_k(const bf16_t* __restrict__ dy, const bf16_t*
   }
 }
 
+// Streaming form of the weight gradient (needs a workspace): thread = (8-channel group c8, pixel lane), flat id = lane * C8 + c8, so
+// consecutive threads read consecutive 16-byte chunks and, at any moment, the resident threads cover P_L consecutive pixel
+// groups over ALL channels -- the grid walks the two tensors front to back like the forward kernel does.  The slice form above
+// gives a block one 1-KiB column slice of every pixel row (stride 2C bytes) and measured 1.4-1.8 TB/s whatever its block count or
+// reduction.  Every thread keeps its 72 sums and writes them to ws[lane][c8 * 72 ..]; dw_wg_reduce_k adds the lanes up.
+__global__ void __launch_bounds__(256)
+dwconv3x3_bwd_weight_s1_flat_v8_k(const bf16_t* __restrict__ dy, const bf16_t* __restrict__ x, unsigned B, unsigned H, unsigned W, unsigned C,
+                                  unsigned lanes, float* __restrict__ ws) {
+  const unsigned C8 = C >> 3, XG = (W + 3) >> 2;
+  const unsigned tid = blockIdx.x * 256u + threadIdx.x;
+  if (tid >= C8 * lanes) return;
+  const unsigned c8 = tid % C8, lane = tid / C8, c0 = c8 * 8;
+  const unsigned ngrp = B * H * XG;
+  float acc[8][9];
+#pragma unroll
+  for (int j = 0; j < 8; ++j)
+#pragma unroll
+    for (int t = 0; t < 9; ++t) acc[j][t] = 0.f;
+  for (unsigned g = lane; g < ngrp; g += lanes) {
+    const unsigned x0 = (g % XG) * 4, t = g / XG, y0 = t % H, b = t / H;
+    cv_b8 gvb[4], xv[3][6];
+    bool rv[3], cvd[6], gok[4];
+    unsigned coff[6];
+#pragma unroll
+    for (int col = 0; col < 6; ++col) {
+      const int ix = (int)x0 + col - 1;
+      cvd[col] = ix >= 0 && ix < (int)W;
+      coff[col] = (unsigned)(ix < 0 ? 0 : (ix >= (int)W ? (int)W - 1 : ix)) * C;
+    }
+#pragma unroll
+    for (int o = 0; o < 4; ++o) {
+      gok[o] = x0 + o < W;
+      gvb[o] = *reinterpret_cast<const cv_b8*>(dy + (((b * H + y0) * W) * C + c0 + coff[o + 1]));
+    }
+#pragma unroll
+    for (int r = 0; r < 3; ++r) {
+      const int iy = (int)y0 + r - 1;
+      rv[r] = iy >= 0 && iy < (int)H;
+      const unsigned rowoff = ((b * H + (unsigned)(iy < 0 ? 0 : (iy >= (int)H ? (int)H - 1 : iy))) * W) * C + c0;
+#pragma unroll
+      for (int col = 0; col < 6; ++col) xv[r][col] = *reinterpret_cast<const cv_b8*>(x + (rowoff + coff[col]));
+    }
+    float gv[4][8];
+#pragma unroll
+    for (int o = 0; o < 4; ++o)
+#pragma unroll
+      for (int j = 0; j < 8; ++j) gv[o][j] = gok[o] ? (float)gvb[o][j] : 0.f;
+#pragma unroll
+    for (int r = 0; r < 3; ++r) {
+#pragma unroll
+      for (int col = 0; col < 6; ++col) {
+        const bool ok = rv[r] && cvd[col];
+        float xf[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) xf[j] = ok ? (float)xv[r][col][j] : 0.f;
+#pragma unroll
+        for (int o = 0; o < 4; ++o) {
+          const int kx = col - o;
+          if (kx < 0 || kx > 2) continue;
+#pragma unroll
+          for (int j = 0; j < 8; ++j) acc[j][r * 3 + kx] = fmaf(gv[o][j], xf[j], acc[j][r * 3 + kx]);
+        }
+      }
+    }
+  }
+  float* o = ws + ((int64_t)lane * C8 + c8) * 72;
+#pragma unroll
+  for (int j = 0; j < 8; ++j)
+#pragma unroll
+    for (int t = 0; t < 9; ++t) o[j * 9 + t] = acc[j][t];
+}
+
 // dw[i] += sum over the row ranges of ws[range][i]  (i = channel * 9 + tap; a workspace row holds slices * 512 channels).
 // block = 64 outputs x 4 range lanes, grid.y = 8 range chunks (one atomic per output and chunk): a thread walks at most
 // nranges / 32 rows, several loads in flight -- a single thread per output walked 1,500 rows one load at a time (0.4 ms).
@@ -844,6 +916,8 @@ static bool dw_v8_ok(int C, int dtype, const void* a, const void* b, const void*
   return dtype == MMRCA_BF16 && C % 8 == 0 && ((((uintptr_t)a) | ((uintptr_t)b) | ((uintptr_t)c)) & 15) == 0;
 }
 
+static const bool g_dw_flat = !(getenv("MMRCA_DW_WG_FLAT") && atoi(getenv("MMRCA_DW_WG_FLAT")) == 0);
+static const int g_dw_flat_threads = getenv("MMRCA_DW_WG_FLAT_THREADS") ? atoi(getenv("MMRCA_DW_WG_FLAT_THREADS")) : 196608;
 static const int g_dw_blocks_ws = getenv("MMRCA_DW_WG_BLOCKS_WS") ? atoi(getenv("MMRCA_DW_WG_BLOCKS_WS")) : 768;
 static const int g_dw_blocks = getenv("MMRCA_DW_WG_BLOCKS") ? atoi(getenv("MMRCA_DW_WG_BLOCKS")) : 768;
 static const bool g_dw_strip2 = !(getenv("MMRCA_DW_STRIP2") && atoi(getenv("MMRCA_DW_STRIP2")) == 0);
@@ -932,7 +1006,17 @@ extern "C" int mmrca_dwconv3x3_bwd_ws(const void* dy, const void* x, const void*
       if (nb > ngrp / 8) nb = ngrp / 8 > 0 ? ngrp / 8 : 1;
       const int64_t gper = (ngrp + nb - 1) / nb;
       const unsigned nranges = (unsigned)((ngrp + gper - 1) / gper);
-      if (use_ws) {
+      // streaming form: lanes = as many pixel lanes as threads fit on the chip at three waves per SIMD, bounded by the workspace
+      const int64_t C8 = C / 8;
+      int64_t lanes = g_dw_flat ? (int64_t)g_dw_flat_threads / C8 : 0;
+      if (lanes > ngrp) lanes = ngrp;
+      if (ws && lanes * C8 * 72 * 4 > ws_bytes) lanes = ws_bytes / (C8 * 72 * 4);
+      if (ws && (((uintptr_t)ws) & 15) == 0 && lanes >= 64) {
+        hipLaunchKernelGGL(dwconv3x3_bwd_weight_s1_flat_v8_k, dim3(blocks_for(lanes * C8, 256)), dim3(256), 0, st, (const bf16_t*)dy,
+                           (const bf16_t*)x, (unsigned)B, (unsigned)H, (unsigned)W, (unsigned)C, (unsigned)lanes, (float*)ws);
+        hipLaunchKernelGGL(dw_wg_reduce_k, dim3((unsigned)((C * 9 + 63) / 64), 8), dim3(256), 0, st, (const float*)ws, dw, (int)lanes, C * 9,
+                           (int64_t)C * 9);
+      } else if (use_ws) {
         hipLaunchKernelGGL((dwconv3x3_bwd_weight_s1_strip2_v8_k<1, true>), dim3((unsigned)slices, nranges), dim3(256), 0, st,
                            (const bf16_t*)dy, (const bf16_t*)x, dw, (unsigned)B, (unsigned)H, (unsigned)W, (unsigned)C, (unsigned)gper, (float*)ws);
         hipLaunchKernelGGL(dw_wg_reduce_k, dim3((unsigned)((C * 9 + 63) / 64), 8), dim3(256), 0, st, (const float*)ws, dw, (int)nranges, C * 9,
@@ -1274,6 +1358,26 @@ bn_act_fwd_v8_k(const bf16_t* __restrict__ x, const float* __restrict__ mean, co
   for (int j = 0; j < 8; ++j) o[j] = (bf16_t)act_f(((float)xv[j] - m[j]) * r[j] * (float)g[j] + (float)b[j], act);
   *reinterpret_cast<bn_b8*>(y + idx * 8) = o;
 }
+// the same followed by the block's residual connection: out = res + rowscale[sample] * act(bn(x))  (rowscale NULL = 1): the last
+// unit of an MBConv / FusedMBConv block writes the block output directly -- no y tensor, no separate residual_add pass
+__global__ void __launch_bounds__(256)
+bn_act_fwd_res_v8_k(const bf16_t* __restrict__ x, const float* __restrict__ mean, const float* __restrict__ rstd, const bf16_t* __restrict__ gamma,
+                    const bf16_t* __restrict__ beta, const bf16_t* __restrict__ res, const float* __restrict__ rowscale, bf16_t* __restrict__ out,
+                    int64_t n8, int C8, int act, int64_t per_sample8) {
+  const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= n8) return;
+  const int c0 = (int)(idx % C8) * 8;
+  const bn_b8 xv = *reinterpret_cast<const bn_b8*>(x + idx * 8), rv = *reinterpret_cast<const bn_b8*>(res + idx * 8);
+  const float sc = rowscale ? rowscale[idx / per_sample8] : 1.f;
+  float m[8], r[8];
+  bn_load8(mean + c0, m); bn_load8(rstd + c0, r);
+  const bn_b8 g = *reinterpret_cast<const bn_b8*>(gamma + c0), b = *reinterpret_cast<const bn_b8*>(beta + c0);
+  bn_b8 o;
+#pragma unroll
+  for (int j = 0; j < 8; ++j)
+    o[j] = (bf16_t)((float)rv[j] + sc * act_f(((float)xv[j] - m[j]) * r[j] * (float)g[j] + (float)b[j], act));
+  *reinterpret_cast<bn_b8*>(out + idx * 8) = o;
+}
 __global__ void __launch_bounds__(256)
 bn_act_bwd_apply_v8_k(const bf16_t* __restrict__ dy, const bf16_t* __restrict__ x, const float* __restrict__ mean, const float* __restrict__ rstd,
                       const bf16_t* __restrict__ gamma, const bf16_t* __restrict__ beta, const float* __restrict__ sum_du,
@@ -1314,6 +1418,23 @@ extern "C" int mmrca_bn_act_fwd(const void* x, const float* mean, const float* r
     hipLaunchKernelGGL(bn_act_fwd_k<T>, dim3(blocks_for(n, 256)), dim3(256), 0, (hipStream_t)stream, (const T*)x, mean, rstd, (const T*)gamma,
                        (const T*)beta, (T*)y, n, C, act);)
   MMRCA_CHECK_LAUNCH("bn_act_fwd");
+  return 0;
+}
+
+/* out = res + rowscale[row / rows_per_sample] * act(bn(x)) (rowscale may be NULL): mmrca_bn_act_fwd followed by mmrca_residual_add in
+ * one pass (bf16, C % 8 == 0, 16-byte aligned operands only: other cases return -3 and the caller takes the two calls) */
+extern "C" int mmrca_bn_act_fwd_res(const void* x, const float* mean, const float* rstd, const void* gamma, const void* beta, const void* res,
+                                    const float* rowscale, void* out, int64_t rows, int C, int act, int64_t rows_per_sample, int dtype,
+                                    void* stream) {
+  MMRCA_REQUIRE(x && mean && rstd && gamma && beta && res && out && rows > 0 && C > 0 && act >= 0 && act <= 3 && rows_per_sample > 0,
+                "bn_act_fwd_res: bad arguments");
+  if (!(bn_v8_ok(C, dtype, x, out, gamma, beta) && ((((uintptr_t)mean) | ((uintptr_t)rstd) | ((uintptr_t)res)) & 15) == 0))
+    return mmrca_fail(-3, "bn_act_fwd_res: only the bf16 / C %% 8 == 0 / 16-byte aligned case is built");
+  const int64_t n = rows * C;
+  hipLaunchKernelGGL(bn_act_fwd_res_v8_k, dim3(blocks_for(n / 8, 256)), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)x, mean, rstd,
+                     (const bf16_t*)gamma, (const bf16_t*)beta, (const bf16_t*)res, rowscale, (bf16_t*)out, n / 8, C / 8, act,
+                     rows_per_sample * C / 8);
+  MMRCA_CHECK_LAUNCH("bn_act_fwd_res");
   return 0;
 }
 

@@ -68,6 +68,7 @@ _SIGS = {
     "mmrca_conv3x3_fwd": [_vp, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _vp],
     "mmrca_conv_bn_finish": [_vp, _vp, _vp, _i32, _i32, _i32, _vp, _vp, _vp, _vp, _i32, _f32, _f32, _vp],
     "mmrca_conv3x3_wgrad": [_vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _vp],
+    "mmrca_bn_act_fwd_res": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i32, _i32, _i64, _i32, _vp],
     "mmrca_bn_stats": [_vp, _vp, _vp, _vp, _vp, _i64, _i32, _i64, _f32, _f32, _i32, _i32, _vp],
     "mmrca_bn_act_fwd": [_vp] * 6 + [_i64, _i32, _i32, _i32, _vp],
     "mmrca_bn_act_bwd": [_vp] * 10 + [_i64, _i32, _i32, _i32, _i32, _vp],
@@ -523,6 +524,12 @@ def conv_bn_finish(parts, B, H, W, mean, rstd, running_mean, running_var, C, eps
 def conv3x3_wgrad(dz, x, dw_tap, B, H, W, Cin, Cout, dtype):
     """dw_tap[Cout, 9*Cin] (fp32) += the weight gradient of the same convolution, patches gathered from x inside the kernel"""
     _c("mmrca_conv3x3_wgrad", ptr(dz), ptr(x), ptr(dw_tap), B, H, W, Cin, Cout, dtype)
+
+
+def bn_act_fwd_res(x, mean, rstd, gamma, beta, res, rowscale, out, rows, C, act, rows_per_sample, dtype):
+    """out = res + rowscale[sample] * act(bn(x)): the block's last BatchNorm + activation and its residual connection in one pass"""
+    _c("mmrca_bn_act_fwd_res", ptr(x), ptr(mean), ptr(rstd), ptr(gamma), ptr(beta), ptr(res), ptr(rowscale), ptr(out), rows, C, act,
+       rows_per_sample, dtype)
 
 
 def bn_stats(x, mean, rstd, running_mean, running_var, rows, C, ld, eps, momentum, train, dtype):

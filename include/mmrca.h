@@ -175,6 +175,11 @@ int mmrca_bn_stats(const void* x, float* mean, float* rstd, float* running_mean,
                    int64_t ld, float eps, float momentum, int train, int dtype, void* stream);
 int mmrca_bn_act_fwd(const void* x, const float* mean, const float* rstd, const void* gamma, const void* beta, void* y,
                      int64_t rows, int C, int act, int dtype, void* stream);
+/* out = res + rowscale[row / rows_per_sample] * act(bn(x)): mmrca_bn_act_fwd and the block's residual connection
+ * (mmrca_residual_add, torchvision StochasticDepth "row" scale, NULL = 1) in one pass.  bf16, C % 8 == 0, 16-byte aligned
+ * operands; anything else returns -3 and the caller issues the two calls. */
+int mmrca_bn_act_fwd_res(const void* x, const float* mean, const float* rstd, const void* gamma, const void* beta, const void* res,
+                         const float* rowscale, void* out, int64_t rows, int C, int act, int64_t rows_per_sample, int dtype, void* stream);
 /* backward of y = act(BN(x)); scratch = fp32 [2C]; dx / dgamma+dbeta (fp32, +=) may be NULL; train as in the forward */
 int mmrca_bn_act_bwd(const void* dy, const void* x, const float* mean, const float* rstd, const void* gamma, const void* beta,
                      void* dx, float* dgamma, float* dbeta, float* scratch, int64_t rows, int C, int act, int train, int dtype,

@@ -87,10 +87,12 @@ def test_depthwise_conv_fwd_bwd(dt, stride, C, H, W):
     L.dwconv3x3_bwd(rows(dy).cuda().to(dt), xd, wd, dx, dw, B, H, W, C, stride, L.dtype_code(dt))
     assert rel(nchw(dx.float().cpu(), B, H, W), x.grad) < TOL[dt]
     assert rel(dw.cpu().view(C, 1, 3, 3), w.grad) < (1e-4 if dt == torch.float32 else 2e-2)
-    # the same through the workspace form (per-block partial sums + a second kernel instead of atomics); dw accumulates
-    dw2 = torch.full((C, 9), 0.25, device="cuda")
-    L.dwconv3x3_bwd(rows(dy).cuda().to(dt), xd, wd, None, dw2, B, H, W, C, stride, L.dtype_code(dt), ws=torch.empty(1 << 20, device="cuda"))
-    assert rel(dw2.cpu().view(C, 1, 3, 3) - 0.25, w.grad) < (1e-4 if dt == torch.float32 else 2e-2)
+    # the same through the workspace forms (streaming kernel with per-thread sums, or -- small workspace -- per-block partial sums;
+    # a second kernel adds them up instead of atomics); dw accumulates
+    for ws_floats in (1 << 20, 40000):
+        dw2 = torch.full((C, 9), 0.25, device="cuda")
+        L.dwconv3x3_bwd(rows(dy).cuda().to(dt), xd, wd, None, dw2, B, H, W, C, stride, L.dtype_code(dt), ws=torch.empty(ws_floats, device="cuda"))
+        assert rel(dw2.cpu().view(C, 1, 3, 3) - 0.25, w.grad) < (1e-4 if dt == torch.float32 else 2e-2)
 
 
 @pytest.mark.parametrize("dt", [torch.float32, torch.bfloat16])

@@ -35,7 +35,7 @@ def main():
         mb = P * C * 2 / 1e6
         t0 = timed(lambda: L.dwconv3x3_fwd(x, w, y, B, H, H, C, 1, L.BF16))
         t1 = timed(lambda: L.dwconv3x3_bwd(dy, x, w, dx, None, B, H, H, C, 1, L.BF16))
-        ws = torch.empty(4 << 20, device="cuda")
+        ws = torch.empty(16 << 20, device="cuda")
         t2 = timed(lambda: L.dwconv3x3_bwd(dy, x, w, None, dw, B, H, H, C, 1, L.BF16, ws=ws))
         mean, rstd = torch.empty(C, device="cuda"), torch.empty(C, device="cuda")
         t3 = timed(lambda: L.bn_stats(x, mean, rstd, None, None, P, C, C, 1e-3, 0.0, True, L.BF16))
