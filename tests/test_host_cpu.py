@@ -283,11 +283,19 @@ def _ddp_worker(rank, world, port, q):
     dist.destroy_process_group()
 
 
+def _free_port():
+    """a TCP port nobody is listening on right now (a pid-derived constant collided with a lingering rendezvous once)"""
+    import socket
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as sk:
+        sk.bind(("127.0.0.1", 0))
+        return sk.getsockname()[1]
+
+
 def test_gradient_sync_world2_equals_full_batch_gradient():
     import torch.multiprocessing as mp
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    port = 29600 + os.getpid() % 300
+    port = _free_port()
     procs = [ctx.Process(target=_ddp_worker, args=(r, 2, port, q)) for r in range(2)]
     for p in procs:
         p.start()
@@ -465,7 +473,7 @@ def test_gradient_sync_two_producers_accumulation_and_bf16_wire_world2():
     import torch.multiprocessing as mp
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    port = 29900 + os.getpid() % 90
+    port = _free_port()
     procs = [ctx.Process(target=_ddp_worker2, args=(r, 2, port, q)) for r in range(2)]
     for p in procs:
         p.start()
