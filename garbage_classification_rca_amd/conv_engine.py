@@ -300,8 +300,8 @@ class ConvEncoder:
             else:
                 L.im2row3x3(x, col, B, H, Wd, u.cin, u.stride, K, dt)
             L.gemm(col, w, z, M=rows, N=u.cout, K=K, lda=K, ldb=K, ldc=u.cout, dtype=dt, impl=self.o.gemm_impl)
-        mean = self.buf(tag + ".mean", 1, u.cout, torch.float32)
-        rstd = self.buf(tag + ".rstd", 1, u.cout, torch.float32)
+        stats = self.buf(tag + ".stats", 2, u.cout, torch.float32)          # [mean | rstd] adjacent: bn_stats clears both with one fill
+        mean, rstd = stats[0], stats[1]
         rm, rv = self.buffers[u.bn_key + ".running_mean"], self.buffers[u.bn_key + ".running_var"]
         if fused_stats:
             L.conv_bn_finish(parts, B, H, Wd, mean, rstd, rm, rv, u.cout, u.eps, 0.1)

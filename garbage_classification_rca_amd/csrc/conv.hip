@@ -1303,8 +1303,12 @@ extern "C" int mmrca_bn_stats(const void* x, float* mean, float* rstd, float* ru
   MMRCA_REQUIRE(x, "bn_stats: null input");
   dim3 grid; int64_t per;
   col_grid(rows, C, &grid, &per);
-  (void)hipMemsetAsync(mean, 0, sizeof(float) * C, st);
-  (void)hipMemsetAsync(rstd, 0, sizeof(float) * C, st);
+  if (rstd == mean + C) {               // adjacent (one [2, C] buffer, as the conv engine allocates them): one fill instead of two
+    (void)hipMemsetAsync(mean, 0, sizeof(float) * 2 * C, st);
+  } else {
+    (void)hipMemsetAsync(mean, 0, sizeof(float) * C, st);
+    (void)hipMemsetAsync(rstd, 0, sizeof(float) * C, st);
+  }
   if (dtype == MMRCA_BF16 && C % 8 == 0 && ld % 8 == 0 && (((uintptr_t)x) & 15) == 0) {
     if (g_bn_one_pass) {
       hipLaunchKernelGGL(col_moment2_v8_k, grid, dim3(256), 0, st, (const bf16_t*)x, mean, rstd, rows, C, ld, per);

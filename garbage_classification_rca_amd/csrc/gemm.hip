@@ -866,7 +866,8 @@ __global__ void __launch_bounds__(256, WPE)
 gemm_mfma_k1s(const bf16_t* __restrict__ A, const bf16_t* __restrict__ B, void* __restrict__ Cv, const bf16_t* __restrict__ bias,
               const bf16_t* __restrict__ addend, bf16_t* __restrict__ preact, int64_t M, int64_t N, int64_t K,
               int64_t lda, int64_t ldb, int64_t ldc, int act, int tiles_m, int tiles_n, int64_t ksplit_len, float* __restrict__ colsum,
-              const bf16_t* __restrict__ A_lo = nullptr, const bf16_t* __restrict__ B_lo = nullptr, bf16_t* __restrict__ C_lo = nullptr) {
+              const bf16_t* __restrict__ A_lo = nullptr, const bf16_t* __restrict__ B_lo = nullptr, bf16_t* __restrict__ C_lo = nullptr,
+              int nseg = 3) {
   extern __shared__ __attribute__((aligned(16))) char smem[];   // ONE buffer: [A tile 16 KiB | B tile 16 KiB]
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
   const int wr = wave >> 1, wc = wave & 1;
@@ -890,7 +891,7 @@ gemm_mfma_k1s(const bf16_t* __restrict__ A, const bf16_t* __restrict__ B, void* 
   for (int i = 0; i < 4; ++i)
 #pragma unroll
     for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
-  for (int tt = 0; tt < (X3 ? 3 : 1) * nt; ++tt) {
+  for (int tt = 0; tt < (X3 ? nseg : 1) * nt; ++tt) {      // bf16x3: nseg of the plane pairs (A,B), (A_lo,B), (A,B_lo)
     // single LDS stage: load -> wait -> barrier -> 32 MFMAs -> barrier; the load latency of this block is covered by the
     // other three or four blocks resident on the CU (32 KiB of LDS each) instead of by software prefetch
     int t = tt;
@@ -1130,11 +1131,11 @@ template <bool AK, bool BK2, bool AT, int WPE, bool X3 = false>
 static void launch_mfma1s(const void* A, const void* B, void* C, const void* bias, const void* addend, void* preact,
                           int64_t M, int64_t N, int64_t K, int64_t lda, int64_t ldb, int64_t ldc, int act, int tiles_m,
                           int tiles_n, int ksplits, int64_t ksplit_len, float* colsum, hipStream_t st,
-                          const void* A_lo = nullptr, const void* B_lo = nullptr, void* C_lo = nullptr) {
+                          const void* A_lo = nullptr, const void* B_lo = nullptr, void* C_lo = nullptr, int nseg = 3) {
   hipLaunchKernelGGL((gemm_mfma_k1s<AK, BK2, AT, WPE, X3>), dim3(tiles_m * tiles_n, ksplits), dim3(256), 2 * TILE_BYTES, st,
                      (const bf16_t*)A, (const bf16_t*)B, C, (const bf16_t*)bias, (const bf16_t*)addend, (bf16_t*)preact,
                      M, N, K, lda, ldb, ldc, act, tiles_m, tiles_n, ksplit_len, colsum, (const bf16_t*)A_lo, (const bf16_t*)B_lo,
-                     (bf16_t*)C_lo);
+                     (bf16_t*)C_lo, nseg);
 }
 
 // entry used by gemm_x3.hip: the single-stage 128x128 kernel in its bf16x3 form (any epilogue; accumulate mode = fp32 atomics)
@@ -1154,7 +1155,7 @@ int mmrca_gemm_k1s_x3(const void* A_hi, const void* A_lo, const void* B_hi, cons
     ksplits = (int)((ksteps + steps_per - 1) / steps_per);
   }
   const bool ak = a_layout == MMRCA_KROW, bk = b_layout == MMRCA_KROW, at = accum != 0;
-#define L1SX(AK_, BK_, AT_) launch_mfma1s<AK_, BK_, AT_, 4, true>(A_hi, B_hi, C, bias, addend, preact, M, N, K, lda, ldb, ldc, act, tiles_m, tiles_n, ksplits, ksplit_len, colsum, st, A_lo, B_lo, C_lo)
+#define L1SX(AK_, BK_, AT_) launch_mfma1s<AK_, BK_, AT_, 4, true>(A_hi, B_hi, C, bias, addend, preact, M, N, K, lda, ldb, ldc, act, tiles_m, tiles_n, ksplits, ksplit_len, colsum, st, A_lo, B_lo, C_lo, A_lo ? (B_lo ? 3 : 2) : 1)
   if (!ak && !bk && !at) L1SX(false, false, false);
   else if (!ak && bk && !at) L1SX(false, true, false);
   else if (ak && !bk && !at) L1SX(true, false, false);

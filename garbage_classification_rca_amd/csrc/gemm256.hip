@@ -90,13 +90,14 @@ __device__ __forceinline__ const bf16_t* piece_src(const bf16_t* __restrict__ ba
 // X3 (bf16x3 mode, gemm_x3.hip): operands are (hi, lo) bf16 plane pairs and the contraction is the VIRTUAL one of length 3K --
 // K-tiles [0, K/64) pair (A_hi, B_hi), [K/64, 2K/64) pair (A_lo, B_hi), [2K/64, 3K/64) pair (A_hi, B_lo) -- which the split-K
 // ranges cut like any other contraction; the stream re-points its source pointers when it crosses a segment boundary.
+// nseg < 3 runs only the first nseg plane pairs (2: the B operand's lo plane is dropped, 1: a plain bf16 product into fp32).
 template <bool A_KROW, bool B_KROW, int MODE, bool X3 = false>
 __global__ void __launch_bounds__(512, 2)
 gemm_mfma256_k(const bf16_t* __restrict__ A, const bf16_t* __restrict__ B, bf16_t* __restrict__ C, const bf16_t* __restrict__ bias,
                const bf16_t* __restrict__ addend, bf16_t* __restrict__ preact, int64_t M, int64_t N, int64_t K,
                int64_t lda, int64_t ldb, int64_t ldc, int tiles_m, int tiles_n, int ksteps_base, int ksteps_rem,
                float* __restrict__ slab, float* __restrict__ colsum, int splits,
-               const bf16_t* __restrict__ A_lo = nullptr, const bf16_t* __restrict__ B_lo = nullptr) {
+               const bf16_t* __restrict__ A_lo = nullptr, const bf16_t* __restrict__ B_lo = nullptr, int nseg = 3) {
   constexpr bool SLAB = MODE == MODE_SLAB;
   extern __shared__ __attribute__((aligned(16))) char smem[];     // [2 stages][A0 A1 B0 B1]
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
@@ -157,7 +158,7 @@ gemm_mfma256_k(const bf16_t* __restrict__ A, const bf16_t* __restrict__ B, bf16_
     else if ((which) == 1) { stage_half(pb[0][0], pb[0][1], my_piece + issue_stage + SLOT_B0 * HT_BYTES); pb[0][0] += b_step; pb[0][1] += b_step; } \
     else if ((which) == 2) { stage_half(pb[1][0], pb[1][1], my_piece + issue_stage + SLOT_B1 * HT_BYTES); pb[1][0] += b_step; pb[1][1] += b_step; } \
     else { stage_half(pa[1][0], pa[1][1], my_piece + issue_stage + SLOT_A1 * HT_BYTES); pa[1][0] += a_step; pa[1][1] += a_step; issue_stage ^= STAGE_BYTES; \
-           if constexpr (X3) { if (++issue_kt == ksteps_seg) { issue_kt = 0; if (++issue_seg < 3) repoint(issue_seg, 0); } } } \
+           if constexpr (X3) { if (++issue_kt == ksteps_seg) { issue_kt = 0; if (++issue_seg < nseg) repoint(issue_seg, 0); } } } \
   } while (0)
 
   // ---- fragment read addresses (LDS byte addresses of stage 0; the stage is toggled by XOR per K-tile)
@@ -301,7 +302,8 @@ __global__ void __launch_bounds__(512, 2)
 gemm_p256_k(const bf16_t* __restrict__ A, const bf16_t* __restrict__ B, bf16_t* __restrict__ C, const bf16_t* __restrict__ bias,
             const bf16_t* __restrict__ addend, bf16_t* __restrict__ preact, int64_t M, int64_t N, int64_t K,
             int64_t lda, int64_t ldb, int64_t ldc, int tiles_m, int tiles_n, float* __restrict__ colsum, int skew_ticks, int dbg,
-            const bf16_t* __restrict__ A_lo = nullptr, const bf16_t* __restrict__ B_lo = nullptr, bf16_t* __restrict__ C_lo = nullptr) {
+            const bf16_t* __restrict__ A_lo = nullptr, const bf16_t* __restrict__ B_lo = nullptr, bf16_t* __restrict__ C_lo = nullptr,
+            int nseg = 3) {
   static_assert(!X3 || (!ADD && ACT != MMRCA_ACT_MUL), "the bf16x3 form has no side-operand epilogue");
   constexpr int act = ACT;
   extern __shared__ __attribute__((aligned(16))) char smem[];     // [2 stages][A0 A1 B0 B1] + 32 KiB epilogue staging
@@ -369,7 +371,7 @@ gemm_p256_k(const bf16_t* __restrict__ A, const bf16_t* __restrict__ B, bf16_t* 
       if (++stream_kt == nt) {                                                                                  \
         stream_kt = 0;                                                                                          \
         if constexpr (X3) {                                                                                     \
-          if (++stream_seg == 3) { stream_seg = 0; ++stream_tile; }                                             \
+          if (++stream_seg == nseg) { stream_seg = 0; ++stream_tile; }                                             \
           Acur = stream_seg == 1 ? A_lo : A; Bcur = stream_seg == 2 ? B_lo : B;                                 \
         } else ++stream_tile;                                                                                   \
         if (stream_tile < my_tiles) stream_to(slot + stream_tile * G);                                          \
@@ -429,7 +431,7 @@ gemm_p256_k(const bf16_t* __restrict__ A, const bf16_t* __restrict__ B, bf16_t* 
     frag_bases();
     if (wr) BARRIER();                    // group 1 runs one barrier behind
     __builtin_amdgcn_sched_barrier(0);
-    const int ntv = X3 ? 3 * nt : nt;     // K-tiles per output tile
+    const int ntv = X3 ? nseg * nt : nt;  // K-tiles per output tile (bf16x3: nseg plane pairs)
     if (ti + 1 < my_tiles) {              // the stream runs on into the next tile: every K-tile is a steady-state one
       for (int t = 0; t < ntv; ++t) K_TILE_G(ISSUE_P, 1, 1, 1, 1, 8, 8, 10, 8);
     } else {
@@ -595,7 +597,7 @@ static int g_p256_skew = -1;      // x 10 ns between the four start groups (MMRC
 template <bool AK, bool BK2, int ACT, bool ADD, bool X3 = false, bool PLANES = false>
 static void launch_p256(const void* A, const void* B, void* C, const void* bias, const void* addend, void* preact, int64_t M,
                         int64_t N, int64_t K, int64_t lda, int64_t ldb, int64_t ldc, float* colsum, hipStream_t st,
-                        const void* A_lo = nullptr, const void* B_lo = nullptr, void* C_lo = nullptr) {
+                        const void* A_lo = nullptr, const void* B_lo = nullptr, void* C_lo = nullptr, int nseg = 3) {
   const int tiles_m = (int)((M + 255) / 256), tiles_n = (int)(N / 256);
   if (g_num_cus == 0) {
     int dev = 0, n = 0;
@@ -614,7 +616,7 @@ static void launch_p256(const void* A, const void* B, void* C, const void* bias,
   hipLaunchKernelGGL((gemm_p256_k<AK, BK2, ACT, ADD, X3, PLANES>), dim3(grid), dim3(512), LDS_P, st, (const bf16_t*)A, (const bf16_t*)B,
                      (bf16_t*)C, (const bf16_t*)bias, (const bf16_t*)addend, (bf16_t*)preact, M, N, K, lda, ldb, ldc, tiles_m,
                      tiles_n, colsum, tiles_m * tiles_n >= 2 * g_num_cus ? g_p256_skew : 0, g_mmrca_dbg, (const bf16_t*)A_lo,
-                     (const bf16_t*)B_lo, (bf16_t*)C_lo);
+                     (const bf16_t*)B_lo, (bf16_t*)C_lo, nseg);
 }
 
 int g_mmrca_dbg = 0;
@@ -669,7 +671,7 @@ int mmrca_gemm256_x3(const void* A_hi, const void* A_lo, const void* B_hi, const
   const bool bk = b_layout == MMRCA_KROW;
   MMRCA_REQUIRE(M * lda * 2 < (1ll << 32) && (bk ? K * ldb : N * ldb) * 2 < (1ll << 32) && M * ldc * 4 < (1ll << 32),
                 "gemm_x3(mfma256): operands must be smaller than 4 GiB");
-#define L256X(BK_, ACT_, PL_) launch_p256<false, BK_, ACT_, false, true, PL_>(A_hi, B_hi, C, bias, nullptr, preact, M, N, K, lda, ldb, ldc, nullptr, st, A_lo, B_lo, C_lo)
+#define L256X(BK_, ACT_, PL_) launch_p256<false, BK_, ACT_, false, true, PL_>(A_hi, B_hi, C, bias, nullptr, preact, M, N, K, lda, ldb, ldc, nullptr, st, A_lo, B_lo, C_lo, A_lo ? (B_lo ? 3 : 2) : 1)
   if (act == MMRCA_ACT_GELU_SAVE_GRAD) {
     if (C_lo) { if (bk) L256X(true, MMRCA_ACT_GELU_SAVE_GRAD, true); else L256X(false, MMRCA_ACT_GELU_SAVE_GRAD, true); }
     else { if (bk) L256X(true, MMRCA_ACT_GELU_SAVE_GRAD, false); else L256X(false, MMRCA_ACT_GELU_SAVE_GRAD, false); }
@@ -718,7 +720,8 @@ static int gemm_splitk_impl(const void* A, const void* A_lo, const void* B, cons
                            int64_t workspace_bytes, int64_t M, int64_t N, int64_t K, int64_t lda, int64_t ldb, int64_t ldc,
                            int a_layout, int b_layout, void* stream) {
   const bool x3 = A_lo != nullptr;
-  MMRCA_REQUIRE(A && B && C && workspace && (!x3 || B_lo), "gemm_splitk: null operand");
+  const int nseg = x3 ? (B_lo ? 3 : 2) : 1;
+  MMRCA_REQUIRE(A && B && C && workspace, "gemm_splitk: null operand");
   MMRCA_REQUIRE(M > 0 && N > 0 && M % 256 == 0 && N % 256 == 0 && K >= 128 && K % 64 == 0,
                 "gemm_splitk: needs M %% 256 == 0, N %% 256 == 0, K %% 64 == 0, K >= 128 (got M=%lld N=%lld K=%lld)", (long long)M, (long long)N, (long long)K);
   MMRCA_REQUIRE(lda % 8 == 0 && ldb % 8 == 0 && ldc % 4 == 0 && (((uintptr_t)A | (uintptr_t)B | (uintptr_t)C | (uintptr_t)workspace) & 15) == 0,
@@ -726,7 +729,7 @@ static int gemm_splitk_impl(const void* A, const void* A_lo, const void* B, cons
   MMRCA_REQUIRE(lda >= (a_layout == MMRCA_ROWK ? K : M) && ldb >= (b_layout == MMRCA_ROWK ? K : N) && ldc >= N, "gemm_splitk: leading dimension too small");
   const int tiles_m = (int)(M / 256), tiles_n = (int)(N / 256), tiles = tiles_m * tiles_n;
   MMRCA_REQUIRE(tiles <= 256, "gemm_splitk: more than 256 output tiles (use mmrca_gemm)");
-  const int64_t ksteps = (x3 ? 3 : 1) * (K / 64);   // bf16x3: the virtual contraction [A_hi|A_lo|A_hi] . [B_hi|B_hi|B_lo]
+  const int64_t ksteps = (int64_t)nseg * (K / 64);   // bf16x3: the virtual contraction [A_hi|A_lo|A_hi] . [B_hi|B_hi|B_lo]
   int64_t splits64 = 256 / tiles;                   // one workgroup per CU
   if (splits64 > ksteps / 2) splits64 = ksteps / 2; // the kernel's pipeline needs two K-tiles per range
   const int splits = (int)splits64;
@@ -741,7 +744,7 @@ static int gemm_splitk_impl(const void* A, const void* A_lo, const void* B, cons
     hipLaunchKernelGGL((gemm_mfma256_k<AK_, BK_, MODE_SLAB, X3_>), dim3((tiles * splits + 7) / 8 * 8), dim3(512), LDS256_BYTES, st, (const bf16_t*)A,      \
                        (const bf16_t*)B, (bf16_t*)nullptr, (const bf16_t*)nullptr, (const bf16_t*)nullptr, (bf16_t*)nullptr, M, N, K, \
                        lda, ldb, ldc, tiles_m, tiles_n, ksteps_base, ksteps_rem, (float*)workspace, (float*)nullptr, splits,    \
-                       (const bf16_t*)A_lo, (const bf16_t*)B_lo);                                                               \
+                       (const bf16_t*)A_lo, (const bf16_t*)B_lo, nseg);                                                         \
   } while (0)
   if (x3) {
     if (!ak && !bk) LSLAB(false, false, true);
@@ -770,6 +773,7 @@ extern "C" int mmrca_gemm_splitk(const void* A, const void* B, float* C, void* w
 extern "C" int mmrca_gemm_splitk_x3(const void* A_hi, const void* A_lo, const void* B_hi, const void* B_lo, float* C, void* workspace,
                                     int64_t workspace_bytes, int64_t M, int64_t N, int64_t K, int64_t lda, int64_t ldb, int64_t ldc,
                                     int a_layout, int b_layout, void* stream) {
-  MMRCA_REQUIRE(A_lo && B_lo, "gemm_x3(splitk): null lo plane");
+  // B_lo == NULL: two passes (A_hi B_hi + A_lo B_hi); A_lo == NULL as well: one pass = mmrca_gemm_splitk on the hi planes
+  MMRCA_REQUIRE(A_lo || !B_lo, "gemm_x3(splitk): a B lo plane without an A lo plane is not a supported pass set");
   return gemm_splitk_impl(A_hi, A_lo, B_hi, B_lo, C, workspace, workspace_bytes, M, N, K, lda, ldb, ldc, a_layout, b_layout, stream);
 }

@@ -29,7 +29,10 @@ extern "C" int mmrca_gemm_x3(const void* A_hi, const void* A_lo, const void* B_h
                              const void* bias, const void* addend, void* preact, float* colsum, int64_t M, int64_t N, int64_t K,
                              int64_t lda, int64_t ldb, int64_t ldc, int a_layout, int b_layout, int act, int out_f32_accum,
                              int impl, void* stream) {
-  MMRCA_REQUIRE(A_hi && A_lo && B_hi && B_lo && C, "gemm_x3: null operand");
+  // pass sets: A_lo and B_lo given = the full three-pass product; B_lo == NULL = two passes (A_hi B_hi + A_lo B_hi: the B operand is
+  // taken at bf16 precision); A_lo == NULL too = one pass (a plain bf16 product with fp32 epilogue / outputs).  The engine's
+  // backward may drop passes (MMRCA_X3_DGRAD_PASSES / MMRCA_X3_WGRAD_PASSES); the forward never does.
+  MMRCA_REQUIRE(A_hi && B_hi && C && (A_lo || !B_lo), "gemm_x3: null operand (a B lo plane needs the A lo plane)");
   MMRCA_REQUIRE(M > 0 && N > 0 && K > 0, "gemm_x3: bad shape M=%lld N=%lld K=%lld", (long long)M, (long long)N, (long long)K);
   MMRCA_REQUIRE((a_layout == MMRCA_ROWK || a_layout == MMRCA_KROW) && (b_layout == MMRCA_ROWK || b_layout == MMRCA_KROW), "gemm_x3: bad layout");
   MMRCA_REQUIRE(act >= MMRCA_ACT_NONE && act <= MMRCA_ACT_MUL, "gemm_x3: bad activation");
@@ -64,7 +67,7 @@ extern "C" int mmrca_gemm_x3(const void* A_hi, const void* A_lo, const void* B_h
       const int64_t M1 = m_split * 256;
       if (int rc = mmrca_gemm256_x3(A_hi, A_lo, B_hi, B_lo, C, C_lo, bias, preact, M1, N, K, lda, ldb, ldc, b_layout, act, st)) return rc;
       const int64_t csz = C_lo ? 2 : 4;
-      return mmrca_gemm_k1s_x3((const char*)A_hi + M1 * lda * 2, (const char*)A_lo + M1 * lda * 2, B_hi, B_lo, (char*)C + M1 * ldc * csz,
+      return mmrca_gemm_k1s_x3((const char*)A_hi + M1 * lda * 2, A_lo ? (const char*)A_lo + M1 * lda * 2 : nullptr, B_hi, B_lo, (char*)C + M1 * ldc * csz,
                                C_lo ? (char*)C_lo + M1 * ldc * 2 : nullptr, bias, nullptr, preact ? (char*)preact + M1 * ldc * 4 : nullptr,
                                nullptr, M - M1, N, K, lda, ldb, ldc, a_layout, b_layout, act, 0, st);
     }

@@ -51,6 +51,9 @@ CONCURRENT_ENCODERS = os.environ.get("MMRCA_CONCURRENT_ENCODERS", "1") == "1"
 CLS_TAIL = os.environ.get("MMRCA_CLS_TAIL", "1") == "1"
 # weight gradients on the 256x256 split-K kernel (mmrca_gemm_splitk) wherever the shape qualifies; "0" = 128x128 + fp32 atomics
 SPLITK_WGRAD = os.environ.get("MMRCA_SPLITK_WGRAD", "1") == "1"
+# bf16x3 mode: plane pairs per backward product (3 = full; see _lin_bwd_x3).  The forward always runs all three.
+X3_WGRAD_PASSES = int(os.environ.get("MMRCA_X3_WGRAD_PASSES", "3"))
+X3_DGRAD_PASSES = int(os.environ.get("MMRCA_X3_DGRAD_PASSES", "3"))
 # ViT residual adds ride on the NEXT LayerNorm (add_layernorm: s = x + res, y = LN(s)) instead of the GEMM epilogue: the
 # out-projection and FFN2 forward GEMMs become bias-only and qualify for the persistent 256x256 kernel (1,050-1,150 TFLOP/s
 # against 780 for the 128x128 kernel with its addend read); the LayerNorm reads one more operand and writes the sum.
@@ -458,12 +461,15 @@ class MMRCAEngine:
         """bf16x3 form of _lin_bwd: dy is split once for both products, x's planes are the ones its forward GEMM made"""
         dyp = self._split(dy, M, N)
         xp = self._split(x, M, K, reuse=True)
+        # pass sets of the backward products (csrc/gemm_x3.hip): 3 = hi.hi + lo.hi + hi.lo; 2 drops the lo plane of the non-gradient
+        # operand (x for the weight gradient, W for the input gradient: that operand enters at bf16 precision); 1 = hi.hi only
+        wg_a, wg_b = (dyp, xp) if X3_WGRAD_PASSES >= 3 else ((dyp, (xp[0], None)) if X3_WGRAD_PASSES == 2 else ((dyp[0], None), (xp[0], None)))
 
         def wgrad():
             if SPLITK_WGRAD and self.gemm_impl == L.IMPL_AUTO and L.gemm_splitk_ok(N, K, Mk, L.BF16):
-                L.gemm_splitk_x3(dyp, xp, gw, self._splitk_ws(), M=N, N=K, K=Mk, lda=N, ldb=K, ldc=K)
+                L.gemm_splitk_x3(wg_a, wg_b, gw, self._splitk_ws(), M=N, N=K, K=Mk, lda=N, ldb=K, ldc=K)
             else:
-                L.gemm_x3(dyp, xp, gw, M=N, N=K, K=Mk, lda=N, ldb=K, ldc=K, a_layout=L.KROW, b_layout=L.KROW, accum=True)
+                L.gemm_x3(wg_a, wg_b, gw, M=N, N=K, K=Mk, lda=N, ldb=K, ldc=K, a_layout=L.KROW, b_layout=L.KROW, accum=True)
             if not bias_done:
                 if isinstance(dy, Planes):
                     raise L.MmrcaError("bf16x3: the bias gradient of a two-plane dY must come from its producer (bias_done)")
@@ -484,7 +490,9 @@ class MMRCAEngine:
             po = isinstance(dx, Planes)
             if po and gelu_h is not None and not fuse:
                 raise L.MmrcaError("bf16x3 mode with a two-plane FFN gradient needs the fused GELU gradient (MMRCA_FUSE_GELU=1)")
-            L.gemm_x3(dyp, self.Wx3(wkey, wnumel), dx.hi if po else dx, C_lo=(dx.lo if po else None), addend=addend,
+            wp = self.Wx3(wkey, wnumel)
+            dg_a, dg_b = (dyp, wp) if X3_DGRAD_PASSES >= 3 else ((dyp, (wp[0], None)) if X3_DGRAD_PASSES == 2 else ((dyp[0], None), (wp[0], None)))
+            L.gemm_x3(dg_a, dg_b, dx.hi if po else dx, C_lo=(dx.lo if po else None), addend=addend,
                       preact=(gelu_h if fuse else None), colsum=(gelu_db if fuse else None),
                       M=M, N=K, K=N, lda=N, ldb=K, ldc=K, a_layout=L.ROWK, b_layout=L.KROW, act=(L.ACT_MUL if fuse else L.ACT_NONE),
                       impl=self.gemm_impl)

@@ -137,6 +137,47 @@ def test_weight_gradient_x3_accumulates_into_fp32(M, N, K, splitk):
     assert err < 2e-5
 
 
+@pytest.mark.parametrize("passes", [2, 1])
+@pytest.mark.parametrize("kind", ["p256", "k1s", "splitk", "atomic"])
+def test_reduced_pass_sets_compute_exactly_the_stated_products(passes, kind):
+    """B_lo == None: two passes = (A_hi + A_lo) . B_hi; A_lo == None as well: one pass = A_hi . B_hi -- the opt-in cheaper backward of the
+    bf16x3 mode (MMRCA_X3_WGRAD_PASSES / MMRCA_X3_DGRAD_PASSES; the forward always runs all three).  Checked against float64 products of
+    the planes that are supposed to take part, on each kernel that has the bf16x3 form."""
+    g = torch.Generator(device="cuda").manual_seed(passes * 7 + len(kind))
+    if kind in ("p256", "k1s"):
+        M, N, K = (1024, 768, 768) if kind == "p256" else (384, 256, 1280)
+        A = torch.randn(M, K, device="cuda", generator=g)
+        B = torch.randn(N, K, device="cuda", generator=g) * 0.05
+        (ah, al), (bh, bl) = planes(A), planes(B)
+        C = torch.empty(M, N, device="cuda")
+        L.gemm_x3((ah, al if passes == 2 else None), (bh, None), C, M=M, N=N, K=K, lda=K, ldb=K, ldc=N,
+                  impl=L.IMPL_MFMA256 if kind == "p256" else L.IMPL_MFMA_1STAGE)
+        a_used = ah.double() + (al.double() if passes == 2 else 0.0)
+        ref = a_used @ bh.double().t()
+        full = A.double() @ B.double().t()
+    else:
+        M, N, K = (768, 768, 4096) if kind == "splitk" else (256, 128, 640)
+        dY = torch.randn(K, M, device="cuda", generator=g) * 0.1
+        X = torch.randn(K, N, device="cuda", generator=g)
+        (ah, al), (bh, bl) = planes(dY), planes(X)
+        C = torch.zeros(M, N, device="cuda")
+        a_pl, b_pl = (ah, al if passes == 2 else None), (bh, None)
+        if kind == "splitk":
+            ws = torch.empty(L.SPLITK_WS_BYTES, dtype=torch.uint8, device="cuda")
+            L.gemm_splitk_x3(a_pl, b_pl, C, ws, M=M, N=N, K=K, lda=M, ldb=N, ldc=N)
+        else:
+            L.gemm_x3(a_pl, b_pl, C, M=M, N=N, K=K, lda=M, ldb=N, ldc=N, a_layout=L.KROW, b_layout=L.KROW, accum=True)
+        a_used = ah.double() + (al.double() if passes == 2 else 0.0)
+        ref = a_used.t() @ bh.double()
+        full = dY.double().t() @ X.double()
+    torch.cuda.synchronize()
+    scale = float(full.abs().max())
+    assert float((C.double() - ref).abs().max()) / scale < 3e-6            # fp32 accumulation of exactly these planes
+    dropped = float((C.double() - full).abs().max()) / scale
+    print(f"{kind} with {passes} pass(es): {dropped:.2e} from the full product")
+    assert 1e-4 < dropped < 2e-2                                             # and visibly not the three-pass product
+
+
 def test_explicit_256_kernel_rejects_a_ragged_row_count():
     A = [torch.zeros(512, 128, dtype=torch.bfloat16, device="cuda") for _ in range(2)]
     B = [torch.zeros(256, 128, dtype=torch.bfloat16, device="cuda") for _ in range(2)]
