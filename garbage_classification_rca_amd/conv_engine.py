@@ -30,6 +30,7 @@ PAD_TAP_K = os.environ.get("MMRCA_CONV_PAD_K", "1") == "1"
 # dense 3x3 / stride-1 convolutions as implicit GEMMs (csrc/conv_igemm.hip): no patch matrix, BatchNorm moments in the epilogue;
 # "0" keeps im2row + GEMM everywhere (the A/B switch of DESIGN 3d)
 IGEMM = os.environ.get("MMRCA_CONV_IGEMM", "1") == "1"
+FUSE_SE = os.environ.get("MMRCA_CONV_FUSE_SE", "1") == "1"         # SE backward: dx and the next BatchNorm's backward sums in one pass
 FUSE_RES = os.environ.get("MMRCA_CONV_FUSE_RES", "1") == "1"       # residual connection inside the block's last BatchNorm pass
 IGEMM_DGRAD = os.environ.get("MMRCA_CONV_IGEMM_DGRAD", "1") == "1"
 
@@ -317,15 +318,17 @@ class ConvEncoder:
             L.bn_act_fwd(z, mean, rstd, self.W(u.bn_key + ".weight"), self.W(u.bn_key + ".bias"), y, rows, u.cout, u.act, dt)
         return y, Ho, Wo, dict(x=x, z=z, mean=mean, rstd=rstd, H=H, W=Wd, Ho=Ho, Wo=Wo, train=train, fused_res=fused_res)
 
-    def _unit_bwd(self, u: _Unit, dy, sv, B, need_dx=True, tag="g"):
-        """dy: gradient at the unit's output rows; returns dx rows (or None)."""
+    def _unit_bwd(self, u: _Unit, dy, sv, B, need_dx=True, tag="g", sums_ready=False):
+        """dy: gradient at the unit's output rows; returns dx rows (or None).  sums_ready: the BatchNorm-backward sums of this unit are
+        already in the shared scratch (the squeeze-excitation backward accumulated them while it wrote dy)."""
         dt = self.o.dt
         H, Wd, Ho, Wo = sv["H"], sv["W"], sv["Ho"], sv["Wo"]
         rows = B * Ho * Wo
         dz = self.buf(f"{tag}.dz.{u.cout}", rows, u.cout)
         scratch = self.buf("g.bnscratch", 1, 2 * u.cout, torch.float32)
         L.bn_act_bwd(dy, sv["z"], sv["mean"], sv["rstd"], self.W(u.bn_key + ".weight"), self.W(u.bn_key + ".bias"), dz,
-                     self.G(u.bn_key + ".weight"), self.G(u.bn_key + ".bias"), scratch, rows, u.cout, u.act, sv["train"], dt)
+                     self.G(u.bn_key + ".weight"), self.G(u.bn_key + ".bias"), scratch, rows, u.cout, u.act, sv["train"], dt,
+                     sums_ready=sums_ready)
         w, gw = self.W(u.conv_key + ".weight"), self.G(u.conv_key + ".weight")
         rows_in = B * H * Wd
         dx = self.buf(f"{tag}.dx.{u.cin}.{rows_in}", rows_in, u.cin) if need_dx else None
@@ -395,12 +398,15 @@ class ConvEncoder:
         L.se_scale_fwd(x, s, y, B, HW, se.c, dt)
         return y, dict(x=x, pooled=pooled, h_pre=h_pre, h=h, s_pre=s_pre, s=s, HW=HW)
 
-    def _se_bwd(self, se: _SE, dy, sv, B, gp="g"):
+    def _se_bwd(self, se: _SE, dy, sv, B, gp="g", bn=None):
+        """returns (dx, sums_ready).  bn = (unit, saved) of the BatchNorm + activation that produced the block's SE input: with the
+        fused kernels (bf16, c % 8 == 0) its backward sums are accumulated while dx is written (mmrca_se_dx)."""
         dt = self.o.dt
         HW = sv["HW"]
         g = lambda s, r, c: self.buf(gp + ".se" + s + f".{c}", r, c)
         dx, ds = self.buf(f"{gp}.se.dx.{se.c}.{B * HW}", B * HW, se.c), g(".ds", B, se.c)
-        L.se_scale_bwd(dy, sv["x"], sv["s"], dx, ds, B, HW, se.c, dt)
+        fused = FUSE_SE and self.o.dtype == torch.bfloat16 and se.c % 8 == 0
+        L.se_scale_bwd(dy, sv["x"], sv["s"], None if fused else dx, ds, B, HW, se.c, dt)
         ds_pre = g(".dspre", B, se.c)
         L.bias_act_bwd(ds, sv["s_pre"], self.W(se.key + ".fc2.bias"), ds_pre, self.G(se.key + ".fc2.bias"), B, se.c, L.CONV_SIGMOID, dt)
         Bk = _ru(B, 64)
@@ -416,8 +422,17 @@ class ConvEncoder:
         dpool = g(".dpool", B, se.c)
         L.gemm(dh_pre, self.W(se.key + ".fc1.weight"), dpool, M=B, N=se.c, K=se.sq, lda=se.sq, ldb=se.c, ldc=se.c, a_layout=L.ROWK, b_layout=L.KROW,
                dtype=dt, impl=self.o.gemm_impl)
-        L.rowpool_mean_bwd(dpool, dx, B, HW, se.c, True, dt)
-        return dx
+        if not fused:
+            L.rowpool_mean_bwd(dpool, dx, B, HW, se.c, True, dt)
+            return dx, False
+        bnargs = None
+        if bn is not None and bn[0].cout == se.c and bn[1]["train"]:
+            u, usv = bn
+            scratch = self.buf("g.bnscratch", 1, 2 * u.cout, torch.float32)
+            scratch[0].zero_()
+            bnargs = (usv["z"], usv["mean"], usv["rstd"], self.W(u.bn_key + ".weight"), self.W(u.bn_key + ".bias"), u.act, scratch)
+        L.se_dx(dy, sv["s"], dpool, dx, B, HW, se.c, dt, bn=bnargs)
+        return dx, bnargs is not None
 
     # ------------------------------------------------------------------ whole network
     def forward(self, images, save: bool, train: bool, seed: int = 0):
@@ -559,11 +574,14 @@ class ConvEncoder:
                     d = dbr
                 else:
                     d = dx
+                sums_ready = False
                 for ui in reversed(range(len(us))):
                     first = ui == 0
-                    d = self._unit_bwd(us[ui], d, bs["units"][ui], B, need_dx=True, tag=f"{gp}.u{ui}")
+                    d = self._unit_bwd(us[ui], d, bs["units"][ui], B, need_dx=True, tag=f"{gp}.u{ui}", sums_ready=sums_ready)
+                    sums_ready = False
                     if blk["se"] is not None and ui == len(us) - 1:
-                        d = self._se_bwd(blk["se"], d, bs["se"], B, gp)
+                        # the unit before the squeeze-excitation (the depthwise conv + BN + SiLU) is next: its BatchNorm sums ride along
+                        d, sums_ready = self._se_bwd(blk["se"], d, bs["se"], B, gp, bn=(us[ui - 1], bs["units"][ui - 1]) if ui > 0 else None)
                 if blk["res"]:
                     rows_in = B * bs["H"] * bs["W"]
                     out = self.buf(f"{gp}.sum.{bs['cin']}.{rows_in}", rows_in, bs["cin"])

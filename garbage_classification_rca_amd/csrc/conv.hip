@@ -1492,17 +1492,18 @@ __global__ void bn_param_grads_k(const float* __restrict__ sum_du, const float* 
 
 /* Backward of y = act(BN(x)): dx (may be NULL), dgamma / dbeta (fp32, +=, may be NULL).  scratch: fp32 [2*C] workspace.
  * train != 0: batch statistics took part in the forward (the usual three-term input gradient); 0: statistics were constants. */
-extern "C" int mmrca_bn_act_bwd(const void* dy, const void* x, const float* mean, const float* rstd, const void* gamma, const void* beta,
-                                void* dx, float* dgamma, float* dbeta, float* scratch, int64_t rows, int C, int act, int train, int dtype,
-                                void* stream) {
+static int bn_act_bwd_impl(const void* dy, const void* x, const float* mean, const float* rstd, const void* gamma, const void* beta,
+                           void* dx, float* dgamma, float* dbeta, float* scratch, int64_t rows, int C, int act, int train, int dtype,
+                           void* stream, bool sums_ready) {
   MMRCA_REQUIRE(dy && x && mean && rstd && gamma && beta && scratch && rows > 0 && C > 0 && act >= 0 && act <= 3, "bn_act_bwd: bad arguments");
   hipStream_t st = (hipStream_t)stream;
   dim3 grid; int64_t per;
   col_grid(rows, C, &grid, &per);
-  (void)hipMemsetAsync(scratch, 0, sizeof(float) * 2 * C, st);
+  if (!sums_ready) (void)hipMemsetAsync(scratch, 0, sizeof(float) * 2 * C, st);
   const int64_t n = rows * C;
   MMRCA_DISPATCH_DTYPE(dtype, "bn_act_bwd",
-    if (sizeof(T) == 2 && C % 8 == 0 && ((((uintptr_t)dy) | ((uintptr_t)x)) & 15) == 0)
+    if (sums_ready) {}
+    else if (sizeof(T) == 2 && C % 8 == 0 && ((((uintptr_t)dy) | ((uintptr_t)x)) & 15) == 0)
       hipLaunchKernelGGL(bn_act_bwd_reduce_v8_k, grid, dim3(256), 0, st, (const bf16_t*)dy, (const bf16_t*)x, mean, rstd, (const bf16_t*)gamma,
                          (const bf16_t*)beta, scratch, scratch + C, rows, C, act, per);
     else
@@ -1518,6 +1519,17 @@ extern "C" int mmrca_bn_act_bwd(const void* dy, const void* x, const float* mean
   if (dgamma && dbeta) hipLaunchKernelGGL(bn_param_grads_k, dim3((C + 255) / 256), dim3(256), 0, st, scratch, scratch + C, dgamma, dbeta, C);
   MMRCA_CHECK_LAUNCH("bn_act_bwd");
   return 0;
+}
+extern "C" int mmrca_bn_act_bwd(const void* dy, const void* x, const float* mean, const float* rstd, const void* gamma, const void* beta,
+                                void* dx, float* dgamma, float* dbeta, float* scratch, int64_t rows, int C, int act, int train, int dtype,
+                                void* stream) {
+  return bn_act_bwd_impl(dy, x, mean, rstd, gamma, beta, dx, dgamma, dbeta, scratch, rows, C, act, train, dtype, stream, false);
+}
+/* the same when sums[0..C) = sum du and sums[C..2C) = sum du * xhat are already there (mmrca_se_dx left them): no reduce pass */
+extern "C" int mmrca_bn_act_bwd_sums(const void* dy, const void* x, const float* mean, const float* rstd, const void* gamma, const void* beta,
+                                     void* dx, float* dgamma, float* dbeta, float* sums, int64_t rows, int C, int act, int train, int dtype,
+                                     void* stream) {
+  return bn_act_bwd_impl(dy, x, mean, rstd, gamma, beta, dx, dgamma, dbeta, sums, rows, C, act, train, dtype, stream, true);
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
@@ -1586,7 +1598,7 @@ se_scale_bwd_v8_k(const bf16_t* __restrict__ dy, const bf16_t* __restrict__ x, c
       pl_b8 o;
 #pragma unroll
       for (int j = 0; j < 8; ++j) { acc[j] = fmaf((float)g[j], (float)xv[j], acc[j]); o[j] = (bf16_t)((float)g[j] * (float)s8[j]); }
-      *reinterpret_cast<pl_b8*>(dx + i) = o;
+      if (dx) *reinterpret_cast<pl_b8*>(dx + i) = o;      // dx == NULL: only ds (mmrca_se_dx writes dx with the pooled gradient added)
     }
   }
   pool_reduce8(acc, red, ds + (int64_t)b * C, blockIdx.y, C, 1.0f);
@@ -1715,17 +1727,110 @@ __global__ void se_scale_bwd_k(const T* __restrict__ dy, const T* __restrict__ x
   if (rl == 0 && c < C) ds[(int64_t)b * C + c] = from_f<T>(red[0][cl] + red[1][cl] + red[2][cl] + red[3][cl]);
 }
 extern "C" int mmrca_se_scale_bwd(const void* dy, const void* x, const void* s, void* dx, void* ds, int B, int HW, int C, int dtype, void* stream) {
-  MMRCA_REQUIRE(dy && x && s && dx && ds && B > 0 && HW > 0 && C > 0, "se_scale_bwd: bad arguments");
+  MMRCA_REQUIRE(dy && x && s && ds && B > 0 && HW > 0 && C > 0, "se_scale_bwd: bad arguments");
   if (pool_v8_ok(C, dtype, dy, x, s, dx)) {
     hipLaunchKernelGGL(se_scale_bwd_v8_k, dim3(B, (C + 63) / 64), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)dy, (const bf16_t*)x,
                        (const bf16_t*)s, (bf16_t*)dx, (bf16_t*)ds, HW, C);
     MMRCA_CHECK_LAUNCH("se_scale_bwd(v8)");
     return 0;
   }
+  MMRCA_REQUIRE(dx, "se_scale_bwd: dx == NULL (ds only) is built for the bf16 / C %% 8 == 0 / aligned case only");
   MMRCA_DISPATCH_DTYPE(dtype, "se_scale_bwd",
     hipLaunchKernelGGL(se_scale_bwd_k<T>, dim3(B, (C + 63) / 64), dim3(256), 0, (hipStream_t)stream, (const T*)dy, (const T*)x, (const T*)s,
                        (T*)dx, (T*)ds, HW, C);)
   MMRCA_CHECK_LAUNCH("se_scale_bwd");
+  return 0;
+}
+
+// Second half of the squeeze-excitation backward, in one pass: dx = dy * s[b, c] + dpool[b, c] / HW (the scale path plus the pooled
+// path; the two-kernel form wrote dy * s, then read and re-wrote it to add the pooled term).  dx is the gradient at the output of
+// the depthwise BatchNorm + SiLU that feeds the block, so with BN the sums that BatchNorm backward needs -- sum du and
+// sum du * xhat, du = dx * act'(xhat gamma + beta) -- are accumulated here as well (z = that BatchNorm's input): its separate
+// reduce pass over dx and z disappears.  block = (sample, 64 channels), as se_scale_bwd_v8_k.
+template <bool BN>
+__global__ void __launch_bounds__(256)
+se_dx_v8_k(const bf16_t* __restrict__ dy, const bf16_t* __restrict__ s, const bf16_t* __restrict__ dpool, bf16_t* __restrict__ dx, int HW, int C,
+           float inv_hw, const bf16_t* __restrict__ z, const float* __restrict__ mean, const float* __restrict__ rstd,
+           const bf16_t* __restrict__ gamma, const bf16_t* __restrict__ beta, int act, float* __restrict__ sum_du, float* __restrict__ sum_duxh) {
+  __shared__ float red[4][8][17];
+  const int cg = threadIdx.x & 7, rl = threadIdx.x >> 3;
+  const int c0 = blockIdx.y * 64 + cg * 8, b = blockIdx.x;
+  float acc[2][8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) { acc[0][j] = 0.f; acc[1][j] = 0.f; }
+  if (c0 < C) {
+    const pl_b8 s8 = *reinterpret_cast<const pl_b8*>(s + (int64_t)b * C + c0), p8 = *reinterpret_cast<const pl_b8*>(dpool + (int64_t)b * C + c0);
+    float sc[8], pd[8], m[8], rs[8], ga[8], be[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) { sc[j] = (float)s8[j]; pd[j] = (float)p8[j] * inv_hw; }
+    if (BN) {
+#pragma unroll
+      for (int j = 0; j < 8; ++j) { m[j] = mean[c0 + j]; rs[j] = rstd[c0 + j]; ga[j] = (float)gamma[c0 + j]; be[j] = (float)beta[c0 + j]; }
+    }
+    int p = rl;
+    for (; p + 32 < HW; p += 64) {                       // two rows in flight per thread
+      const int64_t i0 = ((int64_t)b * HW + p) * C + c0, i1 = i0 + (int64_t)32 * C;
+      const pl_b8 g0 = *reinterpret_cast<const pl_b8*>(dy + i0), g1 = *reinterpret_cast<const pl_b8*>(dy + i1);
+      pl_b8 z0, z1;
+      if (BN) { z0 = *reinterpret_cast<const pl_b8*>(z + i0); z1 = *reinterpret_cast<const pl_b8*>(z + i1); }
+      pl_b8 o0, o1;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        o0[j] = (bf16_t)fmaf((float)g0[j], sc[j], pd[j]);
+        o1[j] = (bf16_t)fmaf((float)g1[j], sc[j], pd[j]);
+        if (BN) {
+          const float x0 = ((float)z0[j] - m[j]) * rs[j], x1 = ((float)z1[j] - m[j]) * rs[j];
+          const float d0 = (float)o0[j] * act_grad_f(x0 * ga[j] + be[j], act), d1 = (float)o1[j] * act_grad_f(x1 * ga[j] + be[j], act);
+          acc[0][j] += d0 + d1;
+          acc[1][j] = fmaf(d0, x0, fmaf(d1, x1, acc[1][j]));
+        }
+      }
+      *reinterpret_cast<pl_b8*>(dx + i0) = o0;
+      *reinterpret_cast<pl_b8*>(dx + i1) = o1;
+    }
+    for (; p < HW; p += 32) {
+      const int64_t i0 = ((int64_t)b * HW + p) * C + c0;
+      const pl_b8 g0 = *reinterpret_cast<const pl_b8*>(dy + i0);
+      pl_b8 z0;
+      if (BN) z0 = *reinterpret_cast<const pl_b8*>(z + i0);
+      pl_b8 o0;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        o0[j] = (bf16_t)fmaf((float)g0[j], sc[j], pd[j]);
+        if (BN) {
+          const float x0 = ((float)z0[j] - m[j]) * rs[j];
+          const float d0 = (float)o0[j] * act_grad_f(x0 * ga[j] + be[j], act);
+          acc[0][j] += d0;
+          acc[1][j] = fmaf(d0, x0, acc[1][j]);
+        }
+      }
+      *reinterpret_cast<pl_b8*>(dx + i0) = o0;
+    }
+  }
+  if (BN) {
+    float* const outs[2] = {sum_du, sum_duxh};
+    col_reduce8<2>(acc, red, outs, blockIdx.y, C);
+  }
+}
+
+/* dx[b*HW + p, c] = dy[..] * s[b, c] + dpool[b, c] / HW  (bf16, C % 8 == 0, 16-byte aligned; other cases return -3: the caller keeps
+ * mmrca_se_scale_bwd + mmrca_rowpool_mean_bwd).  With z given, sums[0..C) += sum du and sums[C..2C) += sum du * xhat of the BatchNorm
+ * + activation whose output gradient dx is (du = dx * act'(xhat gamma + beta), xhat = (z - mean) rstd): exactly what
+ * mmrca_bn_act_bwd's first pass computes, for mmrca_bn_act_bwd_sums. */
+extern "C" int mmrca_se_dx(const void* dy, const void* s, const void* dpool, void* dx, int B, int HW, int C, int dtype, const void* z,
+                           const float* mean, const float* rstd, const void* gamma, const void* beta, int act, float* sums, void* stream) {
+  MMRCA_REQUIRE(dy && s && dpool && dx && B > 0 && HW > 0 && C > 0, "se_dx: bad arguments");
+  MMRCA_REQUIRE(!z || (mean && rstd && gamma && beta && sums && act >= 0 && act <= 3), "se_dx: the BatchNorm sums need mean, rstd, gamma, beta, sums");
+  if (!(pool_v8_ok(C, dtype, dy, s, dpool, dx) && (!z || ((((uintptr_t)z) & 15) == 0))))
+    return mmrca_fail(-3, "se_dx: only the bf16 / C %% 8 == 0 / 16-byte aligned case is built");
+  const dim3 grid(B, (C + 63) / 64);
+  if (z) hipLaunchKernelGGL(se_dx_v8_k<true>, grid, dim3(256), 0, (hipStream_t)stream, (const bf16_t*)dy, (const bf16_t*)s, (const bf16_t*)dpool,
+                            (bf16_t*)dx, HW, C, 1.0f / (float)HW, (const bf16_t*)z, mean, rstd, (const bf16_t*)gamma, (const bf16_t*)beta, act,
+                            sums, sums + C);
+  else hipLaunchKernelGGL(se_dx_v8_k<false>, grid, dim3(256), 0, (hipStream_t)stream, (const bf16_t*)dy, (const bf16_t*)s, (const bf16_t*)dpool,
+                          (bf16_t*)dx, HW, C, 1.0f / (float)HW, (const bf16_t*)nullptr, (const float*)nullptr, (const float*)nullptr,
+                          (const bf16_t*)nullptr, (const bf16_t*)nullptr, 0, (float*)nullptr, (float*)nullptr);
+  MMRCA_CHECK_LAUNCH("se_dx");
   return 0;
 }
 

@@ -68,6 +68,8 @@ _SIGS = {
     "mmrca_conv3x3_fwd": [_vp, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _vp],
     "mmrca_conv_bn_finish": [_vp, _vp, _vp, _i32, _i32, _i32, _vp, _vp, _vp, _vp, _i32, _f32, _f32, _vp],
     "mmrca_conv3x3_wgrad": [_vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _vp],
+    "mmrca_bn_act_bwd_sums": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i32, _i32, _i32, _i32, _vp],
+    "mmrca_se_dx": [_vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _vp, _vp, _vp, _vp, _vp, _i32, _vp, _vp],
     "mmrca_bn_act_fwd_res": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i32, _i32, _i64, _i32, _vp],
     "mmrca_bn_stats": [_vp, _vp, _vp, _vp, _vp, _i64, _i32, _i64, _f32, _f32, _i32, _i32, _vp],
     "mmrca_bn_act_fwd": [_vp] * 6 + [_i64, _i32, _i32, _i32, _vp],
@@ -541,8 +543,9 @@ def bn_act_fwd(x, mean, rstd, gamma, beta, y, rows, C, act, dtype):
     _c("mmrca_bn_act_fwd", ptr(x), ptr(mean), ptr(rstd), ptr(gamma), ptr(beta), ptr(y), rows, C, act, dtype)
 
 
-def bn_act_bwd(dy, x, mean, rstd, gamma, beta, dx, dgamma, dbeta, scratch, rows, C, act, train, dtype):
-    _c("mmrca_bn_act_bwd", ptr(dy), ptr(x), ptr(mean), ptr(rstd), ptr(gamma), ptr(beta), ptr(dx), ptr(dgamma), ptr(dbeta), ptr(scratch),
+def bn_act_bwd(dy, x, mean, rstd, gamma, beta, dx, dgamma, dbeta, scratch, rows, C, act, train, dtype, sums_ready=False):
+    """sums_ready: scratch already holds the first pass's sums (se_dx accumulated them): no reduce pass"""
+    _c("mmrca_bn_act_bwd_sums" if sums_ready else "mmrca_bn_act_bwd", ptr(dy), ptr(x), ptr(mean), ptr(rstd), ptr(gamma), ptr(beta), ptr(dx), ptr(dgamma), ptr(dbeta), ptr(scratch),
        rows, C, act, int(train), dtype)
 
 
@@ -560,7 +563,15 @@ def se_scale_fwd(x, s, y, B, HW, C, dtype):
 
 
 def se_scale_bwd(dy, x, s, dx, ds, B, HW, C, dtype):
+    """dx may be None (bf16 / C % 8 == 0 only): only ds; se_dx then writes dx with the pooled gradient added"""
     _c("mmrca_se_scale_bwd", ptr(dy), ptr(x), ptr(s), ptr(dx), ptr(ds), B, HW, C, dtype)
+
+
+def se_dx(dy, s, dpool, dx, B, HW, C, dtype, bn=None):
+    """dx = dy * s + dpool / HW in one pass; bn = (z, mean, rstd, gamma, beta, act, sums): also accumulates the BatchNorm-backward
+    sums of the layer whose output gradient dx is (bn_act_bwd(..., sums_ready=True) then skips its reduce pass)"""
+    z, mean, rstd, gamma, beta, act, sums = bn if bn is not None else (None, None, None, None, None, 0, None)
+    _c("mmrca_se_dx", ptr(dy), ptr(s), ptr(dpool), ptr(dx), B, HW, C, dtype, ptr(z), ptr(mean), ptr(rstd), ptr(gamma), ptr(beta), act, ptr(sums))
 
 
 def bias_act_fwd(x, bias, y, rows, C, act, dtype):

@@ -184,12 +184,22 @@ int mmrca_bn_act_fwd_res(const void* x, const float* mean, const float* rstd, co
 int mmrca_bn_act_bwd(const void* dy, const void* x, const float* mean, const float* rstd, const void* gamma, const void* beta,
                      void* dx, float* dgamma, float* dbeta, float* scratch, int64_t rows, int C, int act, int train, int dtype,
                      void* stream);
+/* the same when sums[0..C) = sum du and sums[C..2C) = sum du * xhat already hold the first pass's result (mmrca_se_dx computes them
+ * while it writes dy): no reduce pass over dy and x */
+int mmrca_bn_act_bwd_sums(const void* dy, const void* x, const float* mean, const float* rstd, const void* gamma, const void* beta,
+                          void* dx, float* dgamma, float* dbeta, float* sums, int64_t rows, int C, int act, int train, int dtype,
+                          void* stream);
 /* AdaptiveAvgPool2d(1) / x.mean([2,3]) over the HW rows of each sample, and its backward (dx (+)= dpool / HW) */
 int mmrca_rowpool_mean(const void* x, void* out, int B, int HW, int C, int dtype, void* stream);
 int mmrca_rowpool_mean_bwd(const void* dpool, void* dx, int B, int HW, int C, int accumulate, int dtype, void* stream);
 /* squeeze-excitation scaling y = x * s[b, c] and its backward (dx = dy * s, ds[b, c] = sum_rows dy * x) */
 int mmrca_se_scale_fwd(const void* x, const void* s, void* y, int B, int HW, int C, int dtype, void* stream);
 int mmrca_se_scale_bwd(const void* dy, const void* x, const void* s, void* dx, void* ds, int B, int HW, int C, int dtype, void* stream);
+/* Second half of the squeeze-excitation backward in one pass: dx = dy * s[b, c] + dpool[b, c] / HW (mmrca_se_scale_bwd with
+ * dx == NULL computes only ds first).  With z / mean / rstd / gamma / beta / sums given, the first-pass sums of the BatchNorm +
+ * activation whose output gradient dx is are accumulated on the way (for mmrca_bn_act_bwd_sums).  bf16, C % 8 == 0, aligned: -3 otherwise. */
+int mmrca_se_dx(const void* dy, const void* s, const void* dpool, void* dx, int B, int HW, int C, int dtype, const void* z,
+                const float* mean, const float* rstd, const void* gamma, const void* beta, int act, float* sums, void* stream);
 /* y = act(x + bias[c]) on small [rows, C] matrices (the biased 1x1 convolutions of squeeze-excitation) and its backward */
 int mmrca_bias_act_fwd(const void* x, const void* bias, void* y, int64_t rows, int C, int act, int dtype, void* stream);
 int mmrca_bias_act_bwd(const void* dy, const void* x, const void* bias, void* dx, float* dbias, int64_t rows, int C, int act,

@@ -131,6 +131,45 @@ def test_batchnorm_act_fwd_bwd_and_running_stats(dt, act, train):
     assert rel(dx, x.grad) < tol and rel(dg, gam.grad) < tol and rel(db, bet.grad) < tol
 
 
+@pytest.mark.parametrize("HW", [35, 64, 100])        # odd / even row counts of the two-rows-in-flight loop
+@pytest.mark.parametrize("act", [L.CONV_SILU, L.CONV_NONE])
+def test_se_backward_second_half_with_the_batchnorm_sums_in_one_pass(HW, act):
+    """mmrca_se_dx: dx = dy * s + dpool / HW, and -- for the BatchNorm + activation whose output gradient dx is -- the sums that
+    mmrca_bn_act_bwd's first pass would compute from dx and z; mmrca_bn_act_bwd_sums then gives the same dz / dgamma / dbeta."""
+    B, C = 3, 72
+    g = torch.Generator().manual_seed(HW)
+    dy = torch.randn(B * HW, C, generator=g).bfloat16().cuda()
+    s = torch.rand(B, C, generator=g).bfloat16().cuda()
+    dpool = torch.randn(B, C, generator=g).bfloat16().cuda()
+    z = (torch.randn(B * HW, C, generator=g) * 1.5 + 0.3).bfloat16().cuda()
+    gam, bet = (1 + 0.2 * torch.randn(C, generator=g)).bfloat16().cuda(), (0.1 * torch.randn(C, generator=g)).bfloat16().cuda()
+    mean, rstd = torch.empty(C, device="cuda"), torch.empty(C, device="cuda")
+    L.bn_stats(z, mean, rstd, None, None, B * HW, C, C, 1e-3, 0.0, True, L.BF16)
+    # two-kernel reference path
+    dx_ref, ds = torch.empty(B * HW, C, device="cuda", dtype=torch.bfloat16), torch.empty(B, C, device="cuda", dtype=torch.bfloat16)
+    L.se_scale_bwd(dy, z, s, dx_ref, ds, B, HW, C, L.BF16)                 # (x only feeds ds here)
+    L.rowpool_mean_bwd(dpool, dx_ref, B, HW, C, True, L.BF16)
+    ds2 = torch.empty_like(ds)
+    L.se_scale_bwd(dy, z, s, None, ds2, B, HW, C, L.BF16)                   # ds only
+    assert torch.equal(ds, ds2)
+    dx = torch.full_like(dx_ref, float("nan"))
+    sums = torch.zeros(2 * C, device="cuda")
+    L.se_dx(dy, s, dpool, dx, B, HW, C, L.BF16, bn=(z, mean, rstd, gam, bet, act, sums))
+    exact = dy.float().view(B, HW, C) * s.float()[:, None] + dpool.float()[:, None] / HW
+    assert rel(dx.view(B, HW, C), exact) < 6e-3 and rel(dx, dx_ref) < 1.2e-2          # (the one-pass form rounds once, the old one twice)
+    dx2 = torch.empty_like(dx)
+    L.se_dx(dy, s, dpool, dx2, B, HW, C, L.BF16)
+    assert torch.equal(dx, dx2)
+    # BatchNorm backward from the accumulated sums == the two-pass backward on the same dx
+    dz_a, dz_b = torch.empty_like(dx), torch.empty_like(dx)
+    dg_a, db_a, dg_b, db_b = (torch.zeros(C, device="cuda") for _ in range(4))
+    scratch = torch.empty(2 * C, device="cuda")
+    L.bn_act_bwd(dx, z, mean, rstd, gam, bet, dz_a, dg_a, db_a, scratch, B * HW, C, act, True, L.BF16)
+    assert rel(sums, scratch) < 1e-5
+    L.bn_act_bwd(dx, z, mean, rstd, gam, bet, dz_b, dg_b, db_b, sums, B * HW, C, act, True, L.BF16, sums_ready=True)
+    assert rel(dz_b, dz_a) < 1e-3 and rel(dg_b, dg_a) < 1e-5 and rel(db_b, db_a) < 1e-5
+
+
 @pytest.mark.parametrize("dt", [torch.float32, torch.bfloat16])
 @pytest.mark.parametrize("C", [70, 72])      # 72: the 8-channel kernels
 def test_pool_se_residual_maxpool_gather(dt, C):
