@@ -250,12 +250,25 @@ class ConvEncoder:
         return _ru(K, 128) if (u.cout % 128 == 0 and PAD_TAP_K) else K
 
     def _igemm(self, u: "_Unit") -> bool:
-        """stride-1 dense 3x3 convolutions with cin % 32 == 0 run without a patch matrix (mmrca_conv3x3_fwd / _wgrad)"""
-        return IGEMM and self._tap_major(u) and u.k == 3 and not u.dw and u.stride == 1 and u.cin % 32 == 0 and u.cout % 8 == 0
+        """stride-1 dense 3x3 convolutions with cin % 8 == 0 run without a patch matrix (mmrca_conv3x3_fwd / _wgrad); channel counts
+        that are not multiples of 32 (EfficientNetV2-M: 24 / 48 / 80) are padded to one per tap in the weight copy only"""
+        return IGEMM and self._tap_major(u) and u.k == 3 and not u.dw and u.stride == 1 and u.cin % 8 == 0 and u.cout % 8 == 0
 
     def _igemm_dgrad(self, u: "_Unit") -> bool:
         """... and their input gradient is the same kernel on dz with flipped, transposed weights when cout % 32 == 0"""
-        return IGEMM_DGRAD and self._igemm(u) and u.cout % 32 == 0 and u.cin % 8 == 0
+        return IGEMM_DGRAD and self._igemm(u)
+
+    def _tap_weight_igemm(self, u: "_Unit", w, flip=False):
+        """weight copy of the implicit-GEMM kernels: [cout, 9, Cp] with Cp = cin rounded up to 32 (zero pad channels); flip: the
+        input-gradient form [cin, 9, Cout_p], w'[ci, tap', co] = w[co, ci, 8 - tap']"""
+        if flip:
+            n, k, src = u.cin, u.cout, w.view(u.cout, u.cin, 9).flip(2).permute(1, 2, 0)
+        else:
+            n, k, src = u.cout, u.cin, w.view(u.cout, u.cin, 9).transpose(1, 2)
+        kp = _ru(k, 32)
+        wp = self.buf(f"tmp.wig.{int(flip)}.{n}.{kp}", n, 9 * kp)[:n]           # pad columns stay zero
+        wp.view(n, 9, kp)[:, :, :k].copy_(src)
+        return wp
 
     def _tap_weight(self, u: "_Unit", w, pad=True):
         """[cout, cin, 3, 3] -> [cout, 9, cin] (+ zero columns up to _tap_k) copy in the compute dtype (a few KB..1 MB; rebuilt
@@ -288,7 +301,7 @@ class ConvEncoder:
             if train:
                 parts = (self.buf("tmp.bnpart.mean", ns, u.cout, torch.float32), self.buf("tmp.bnpart.m2", ns, u.cout, torch.float32),
                          self.buf("tmp.bnpart.cnt", 1, ns, torch.float32))
-            L.conv3x3_fwd(x, self._tap_weight(u, w, pad=False), z, B, H, Wd, u.cin, u.cout, dt, parts)
+            L.conv3x3_fwd(x, self._tap_weight_igemm(u, w), z, B, H, Wd, u.cin, u.cout, dt, parts)
             fused_stats = parts is not None
         else:
             K = 9 * u.cin
@@ -350,9 +363,7 @@ class ConvEncoder:
             if need_dx:
                 if self._igemm_dgrad(u):
                     # dx = conv3x3(dz, w'), w'[ci, tap', co] = w[co, ci, 8 - tap']
-                    wf = self.buf(f"tmp.wflip.{u.cin}.{9 * u.cout}", u.cin, 9 * u.cout)[: u.cin]
-                    wf.view(u.cin, 9, u.cout).copy_(w.view(u.cout, u.cin, 9).flip(2).permute(1, 2, 0))
-                    L.conv3x3_fwd(dz, wf, dx, B, H, Wd, u.cout, u.cin, dt)
+                    L.conv3x3_fwd(dz, self._tap_weight_igemm(u, w, flip=True), dx, B, H, Wd, u.cout, u.cin, dt)
                 else:
                     Kp = self._tap_k(u)
                     col = self.buf("tmp.col", rows, Kp)

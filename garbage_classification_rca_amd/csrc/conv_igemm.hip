@@ -40,9 +40,10 @@ __device__ __forceinline__ float row16_sum(float v) {
 
 struct ConvGeom {
   int B, H, W, Cin, Cout;
+  int Cp;                     // Cin rounded up to 32: channels per tap in the weight copy and in the K loop (pad channels are zero)
   int PH, PW;                 // output patch of a block (PH * PW = 128)
   int tiles_y, tiles_x;       // patches per image
-  int CK;                     // input channels resident per halo load (Cin % CK == 0, CK % 32 == 0, CK <= 96)
+  int CK;                     // input channels resident per halo load (Cp % CK == 0, CK % 32 == 0, CK <= 96)
   int tiles_n;                // Cout tiles of NT channels
 };
 
@@ -97,7 +98,7 @@ conv3x3_igemm_k(const bf16_t* __restrict__ x, const bf16_t* __restrict__ w, bf16
       const int px = idx / slots, ch = idx - px * slots;
       const int hy = px / HWp, hx = px - hy * HWp;
       const int yy = y0 - 1 + hy, xx = x0 - 1 + hx;
-      const bool ok = ch < chunks && px < npx && (unsigned)yy < (unsigned)gm.H && (unsigned)xx < (unsigned)gm.W;
+      const bool ok = ch < chunks && c0 + ch * 8 < gm.Cin && px < npx && (unsigned)yy < (unsigned)gm.H && (unsigned)xx < (unsigned)gm.W;
       const bf16_t* src = ok ? x + (((int64_t)b * gm.H + yy) * gm.W + xx) * gm.Cin + c0 + ch * 8 : g_conv_zero_page;
       __builtin_amdgcn_global_load_lds((gbl_void_c*)src, (lds_void_c*)(smem + base * 16), 16, 0, 0);
     }
@@ -108,7 +109,7 @@ conv3x3_igemm_k(const bf16_t* __restrict__ x, const bf16_t* __restrict__ w, bf16
       const int c = (lane & 3) ^ ((4 - (r >> 2)) & 3);
       int gr = n_blk + r;
       if (gr > gm.Cout - 1) gr = gm.Cout - 1;       // ragged channel tile: a valid row, never stored
-      const bf16_t* src = w + (int64_t)gr * (9 * gm.Cin) + k0 + c * 8;
+      const bf16_t* src = w + (int64_t)gr * (9 * gm.Cp) + k0 + c * 8;
       __builtin_amdgcn_global_load_lds((gbl_void_c*)src, (lds_void_c*)(dst + i * 1024), 16, 0, 0);
     }
   };
@@ -121,7 +122,7 @@ conv3x3_igemm_k(const bf16_t* __restrict__ x, const bf16_t* __restrict__ w, bf16
 
   const int kc_n = gm.CK >> 5;                     // 32-deep steps per tap within one halo chunk
   const int steps = 9 * kc_n;
-  for (int c0 = 0; c0 < gm.Cin; c0 += gm.CK) {
+  for (int c0 = 0; c0 < gm.Cp; c0 += gm.CK) {
     // (every wave passed the barrier that closes the previous chunk's last step: halo and both weight stages are free)
     load_halo(c0);
     stage_w(c0, bst);
@@ -132,7 +133,7 @@ conv3x3_igemm_k(const bf16_t* __restrict__ x, const bf16_t* __restrict__ w, bf16
       const unsigned cur = (unsigned)((s & 1) * BST);
       int ntap = tap, nkc = kc + 1;
       if (nkc == kc_n) { nkc = 0; ++ntap; }
-      if (s + 1 < steps) stage_w((int64_t)ntap * gm.Cin + c0 + nkc * 32, bst + ((s + 1) & 1) * BST);
+      if (s + 1 < steps) stage_w((int64_t)ntap * gm.Cp + c0 + nkc * 32, bst + ((s + 1) & 1) * BST);
       const int dy = tap / 3, dx = tap - 3 * dy;
       const unsigned aoff = (unsigned)(((dy * HWp + dx) * slots + kc * 4) * 16);
       Frag<false> af[4], bf[NJ];
@@ -292,7 +293,8 @@ static int conv_geom(ConvGeom* gm, int B, int H, int W, int Cin, int Cout, int N
   conv_patch(H, W, &gm->PH, &gm->PW);
   gm->tiles_y = (H + gm->PH - 1) / gm->PH;
   gm->tiles_x = (W + gm->PW - 1) / gm->PW;
-  gm->CK = Cin <= 96 ? Cin : (Cin % 96 == 0 ? 96 : (Cin % 64 == 0 ? 64 : 32));
+  gm->Cp = (Cin + 31) / 32 * 32;
+  gm->CK = gm->Cp <= 96 ? gm->Cp : (gm->Cp % 96 == 0 ? 96 : (gm->Cp % 64 == 0 ? 64 : 32));
   gm->tiles_n = (Cout + NT - 1) / NT;
   return 0;
 }
@@ -315,14 +317,16 @@ extern "C" int64_t mmrca_conv3x3_stat_slots(int B, int H, int W) {
 }
 
 /* z[B*H*W, Cout] = conv3x3(x[B*H*W, Cin], w_tap[Cout, 9*Cin]) (stride 1, zero padding 1; bf16, NHWC rows, tap-major weights:
- * column tap*Cin + ci, tap = 3*ky + kx).  Cin % 32 == 0, Cout % 8 == 0, 16-byte aligned operands.  With part_* given, the
+ * column tap*Cp + ci, tap = 3*ky + kx, Cp = Cin rounded up to a multiple of 32 with zero pad columns -- Cp == Cin for the
+ * FusedMBConv layers of EfficientNetV2-L (32 / 64 / 96 channels), 24 -> 32, 48 -> 64, 80 -> 96 for V2-M).  Cin % 8 == 0,
+ * Cout % 8 == 0, 16-byte aligned operands.  With part_* given, the
  * BatchNorm moments of the stored outputs are left in mmrca_conv3x3_stat_slots() slots for mmrca_conv_bn_finish.
  * The input-gradient of the same convolution is this call on dz with the flipped, transposed weights [Cin, 9*Cout]. */
 extern "C" int mmrca_conv3x3_fwd(const void* x, const void* w_tap, void* z, float* part_mean, float* part_m2, float* part_cnt,
                                  int B, int H, int W, int Cin, int Cout, int dtype, void* stream) {
   MMRCA_REQUIRE(dtype == MMRCA_BF16, "conv3x3_fwd: bf16 only (the fp32 modes keep im2row + GEMM)");
   MMRCA_REQUIRE(x && w_tap && z && B > 0 && H > 0 && W > 0, "conv3x3_fwd: bad arguments");
-  MMRCA_REQUIRE(Cin % 32 == 0 && Cin >= 32, "conv3x3_fwd: Cin must be a multiple of 32 (got %d)", Cin);
+  MMRCA_REQUIRE(Cin % 8 == 0 && Cin >= 8, "conv3x3_fwd: Cin must be a multiple of 8 (got %d)", Cin);
   MMRCA_REQUIRE(Cout % 8 == 0 && Cout >= 8, "conv3x3_fwd: Cout must be a multiple of 8 (got %d)", Cout);
   MMRCA_REQUIRE((((uintptr_t)x | (uintptr_t)w_tap | (uintptr_t)z) & 15) == 0, "conv3x3_fwd: operands must be 16-byte aligned");
   const bool stats = part_mean != nullptr;

@@ -143,7 +143,8 @@ int mmrca_col2im3x3(const void* dcol, void* dx, int B, int H, int W, int C, int 
 int mmrca_im2row3x3_tap(const void* x, void* col, int B, int H, int W, int C, int stride, int64_t ldk, int dtype, void* stream);
 int mmrca_col2im3x3_tap(const void* dcol, void* dx, int B, int H, int W, int C, int stride, int64_t ldk, int dtype, void* stream);
 /* Dense 3x3 / stride 1 / padding 1 convolution WITHOUT a patch matrix (conv_igemm.hip; bf16, NHWC rows, tap-major weights
- * w_tap[Cout, 9*Cin], column tap*Cin + ci with tap = 3*ky + kx; Cin % 32 == 0, Cout % 8 == 0, 16-byte aligned operands).
+ * w_tap[Cout, 9*Cp], column tap*Cp + ci with tap = 3*ky + kx and Cp = Cin rounded up to a multiple of 32 (zero pad columns);
+ * Cin % 8 == 0, Cout % 8 == 0, 16-byte aligned operands).
  * Replaces mmrca_im2row3x3_tap + mmrca_gemm for torchvision's Conv2dNormActivation 3x3 inside FusedMBConv
  * (multimodal_model.py:113-126 -> models.efficientnet_v2_*).
  *   fwd:   z[B*H*W, Cout] = conv(x[B*H*W, Cin], w_tap).  With part_mean / part_m2 / part_cnt given
@@ -151,7 +152,7 @@ int mmrca_col2im3x3_tap(const void* dcol, void* dx, int B, int H, int W, int C, 
  *          outputs are left there as per-wave (count, mean, M2) triples; mmrca_conv_bn_finish merges them (Chan) into mean,
  *          rstd and -- momentum > 0 -- the running statistics, exactly as mmrca_bn_stats(train = 1) would from z.
  *          The input gradient of the same convolution is this call on dz with the flipped, transposed weights
- *          w'[Cin, 9*Cout], w'[ci, tap', co] = w[co, ci, 8 - tap'] (then Cout % 32 == 0 is required of the layer).
+ *          w'[Cin, 9*Cout_p], w'[ci, tap', co] = w[co, ci, 8 - tap'].
  *   wgrad: dw_tap[Cout, 9*Cin] (fp32) += dz^T * patches(x); Cin % 8 == 0, Cout % 8 == 0; reads no padding rows. */
 int64_t mmrca_conv3x3_stat_slots(int B, int H, int W);
 int mmrca_conv3x3_fwd(const void* x, const void* w_tap, void* z, float* part_mean, float* part_m2, float* part_cnt, int B, int H,

