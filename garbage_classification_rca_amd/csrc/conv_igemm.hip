@@ -12,7 +12,9 @@
 //     pixels of a patch row is one ds_read_b128 per lane at a tap-dependent scalar offset.  Pixel pitch in LDS = CK/8 + 1
 //     16-byte slots (odd), so the 16 lanes of a read group fall on 16 distinct slots of a bank row.  Only the weights stream
 //     through a double-buffered 32-deep stage per step.  With more than 96 input channels (the input-gradient form: the
-//     "input" is dz with Cout channels) the halo is loaded CK channels at a time.
+//     "input" is dz with Cout channels) the halo is loaded CK channels at a time.  Channel counts that are multiples of 8 but
+//     not of 32 (EfficientNetV2-M: 24 / 48 / 80) take the same path: the weight copy carries Cp = round_up(Cin, 32) channels
+//     per tap (zeros), the halo's missing chunks come from the zero page.
 //   statistics  BatchNorm moments of the bf16-rounded outputs ride in the epilogue: every wave reduces its 64 pixels to a
 //     per-channel (count, mean, M2) triple (two in-register passes, so no shift is needed) and writes it to a per-wave slot;
 //     conv_bn_finish_k merges the slots with Chan's formula.  No atomics, bit-reproducible.

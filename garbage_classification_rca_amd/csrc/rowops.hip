@@ -596,7 +596,14 @@ __global__ void __launch_bounds__(256) colsum_k(const T* __restrict__ dY, float*
   int64_t r1 = r0 + rows_per_block; if (r1 > M) r1 = M;
   float a[4] = {0.f, 0.f, 0.f, 0.f};
   if (c < N) {
-    for (int64_t r = r0 + wave; r < r1; r += 4) {
+    int64_t r = r0 + wave;
+    for (; r + 12 < r1; r += 16) {                      // four rows in flight per thread (one load per iteration: 2.1 TB/s)
+      Vec4<T> v0 = Vec4<T>::load(dY + r * ld + c), v1 = Vec4<T>::load(dY + (r + 4) * ld + c);
+      Vec4<T> v2 = Vec4<T>::load(dY + (r + 8) * ld + c), v3 = Vec4<T>::load(dY + (r + 12) * ld + c);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) a[j] += (v0.v[j] + v1.v[j]) + (v2.v[j] + v3.v[j]);
+    }
+    for (; r < r1; r += 4) {
       Vec4<T> v = Vec4<T>::load(dY + r * ld + c);
 #pragma unroll
       for (int j = 0; j < 4; ++j) a[j] += v.v[j];
