@@ -1347,62 +1347,100 @@ __device__ __forceinline__ void bn_load8(const float* __restrict__ p, float (&v)
   const float4 a = *reinterpret_cast<const float4*>(p), b = *reinterpret_cast<const float4*>(p + 4);
   v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w; v[4] = b.x; v[5] = b.y; v[6] = b.z; v[7] = b.w;
 }
+// BatchNorm passes, 8 channels x BN_R rows per thread: thread t -> channel group t % C8, rows BN_R * (t / C8) ...  The per-channel
+// constants (mean, rstd, gamma, beta, and the backward's two sums: up to 160 bytes) are loaded once per BN_R row vectors instead of
+// once per 16-byte vector -- with one vector per thread they were 3-5x the data loads and held the kernels at 4.2-4.7 TB/s --
+// and the BN_R data loads are issued together.
+#define BN_R 4
 __global__ void __launch_bounds__(256)
 bn_act_fwd_v8_k(const bf16_t* __restrict__ x, const float* __restrict__ mean, const float* __restrict__ rstd, const bf16_t* __restrict__ gamma,
-                const bf16_t* __restrict__ beta, bf16_t* __restrict__ y, int64_t n8, int C8, int act) {
-  const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (idx >= n8) return;
-  const int c0 = (int)(idx % C8) * 8;
+                const bf16_t* __restrict__ beta, bf16_t* __restrict__ y, int64_t rows, int C8, int act) {
+  const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int64_t r0 = t / C8 * BN_R;
+  if (r0 >= rows) return;
+  const int c0 = (int)(t % C8) * 8;
+  const int64_t i0 = (r0 * C8 + c0 / 8) * 8, rs8 = (int64_t)C8 * 8;
+  bn_b8 xv[BN_R];
+#pragma unroll
+  for (int k = 0; k < BN_R; ++k) xv[k] = *reinterpret_cast<const bn_b8*>(x + i0 + (r0 + k < rows ? k : 0) * rs8);
   float m[8], r[8];
   bn_load8(mean + c0, m); bn_load8(rstd + c0, r);
   const bn_b8 g = *reinterpret_cast<const bn_b8*>(gamma + c0), b = *reinterpret_cast<const bn_b8*>(beta + c0);
-  const bn_b8 xv = *reinterpret_cast<const bn_b8*>(x + idx * 8);
-  bn_b8 o;
 #pragma unroll
-  for (int j = 0; j < 8; ++j) o[j] = (bf16_t)act_f(((float)xv[j] - m[j]) * r[j] * (float)g[j] + (float)b[j], act);
-  *reinterpret_cast<bn_b8*>(y + idx * 8) = o;
+  for (int k = 0; k < BN_R; ++k) {
+    if (r0 + k >= rows) break;
+    bn_b8 o;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) o[j] = (bf16_t)act_f(((float)xv[k][j] - m[j]) * r[j] * (float)g[j] + (float)b[j], act);
+    *reinterpret_cast<bn_b8*>(y + i0 + k * rs8) = o;
+  }
 }
 // the same followed by the block's residual connection: out = res + rowscale[sample] * act(bn(x))  (rowscale NULL = 1): the last
 // unit of an MBConv / FusedMBConv block writes the block output directly -- no y tensor, no separate residual_add pass
 __global__ void __launch_bounds__(256)
 bn_act_fwd_res_v8_k(const bf16_t* __restrict__ x, const float* __restrict__ mean, const float* __restrict__ rstd, const bf16_t* __restrict__ gamma,
                     const bf16_t* __restrict__ beta, const bf16_t* __restrict__ res, const float* __restrict__ rowscale, bf16_t* __restrict__ out,
-                    int64_t n8, int C8, int act, int64_t per_sample8) {
-  const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (idx >= n8) return;
-  const int c0 = (int)(idx % C8) * 8;
-  const bn_b8 xv = *reinterpret_cast<const bn_b8*>(x + idx * 8), rv = *reinterpret_cast<const bn_b8*>(res + idx * 8);
-  const float sc = rowscale ? rowscale[idx / per_sample8] : 1.f;
+                    int64_t rows, int C8, int act, int64_t rows_per_sample) {
+  const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int64_t r0 = t / C8 * BN_R;
+  if (r0 >= rows) return;
+  const int c0 = (int)(t % C8) * 8;
+  const int64_t i0 = (r0 * C8 + c0 / 8) * 8, rs8 = (int64_t)C8 * 8;
+  bn_b8 xv[BN_R], rv[BN_R];
+  float sc[BN_R];
+#pragma unroll
+  for (int k = 0; k < BN_R; ++k) {
+    const int64_t kk = r0 + k < rows ? k : 0;
+    xv[k] = *reinterpret_cast<const bn_b8*>(x + i0 + kk * rs8);
+    rv[k] = *reinterpret_cast<const bn_b8*>(res + i0 + kk * rs8);
+    sc[k] = rowscale ? rowscale[(r0 + kk) / rows_per_sample] : 1.f;
+  }
   float m[8], r[8];
   bn_load8(mean + c0, m); bn_load8(rstd + c0, r);
   const bn_b8 g = *reinterpret_cast<const bn_b8*>(gamma + c0), b = *reinterpret_cast<const bn_b8*>(beta + c0);
-  bn_b8 o;
 #pragma unroll
-  for (int j = 0; j < 8; ++j)
-    o[j] = (bf16_t)((float)rv[j] + sc * act_f(((float)xv[j] - m[j]) * r[j] * (float)g[j] + (float)b[j], act));
-  *reinterpret_cast<bn_b8*>(out + idx * 8) = o;
+  for (int k = 0; k < BN_R; ++k) {
+    if (r0 + k >= rows) break;
+    bn_b8 o;
+#pragma unroll
+    for (int j = 0; j < 8; ++j)
+      o[j] = (bf16_t)((float)rv[k][j] + sc[k] * act_f(((float)xv[k][j] - m[j]) * r[j] * (float)g[j] + (float)b[j], act));
+    *reinterpret_cast<bn_b8*>(out + i0 + k * rs8) = o;
+  }
 }
 __global__ void __launch_bounds__(256)
 bn_act_bwd_apply_v8_k(const bf16_t* __restrict__ dy, const bf16_t* __restrict__ x, const float* __restrict__ mean, const float* __restrict__ rstd,
                       const bf16_t* __restrict__ gamma, const bf16_t* __restrict__ beta, const float* __restrict__ sum_du,
-                      const float* __restrict__ sum_duxh, bf16_t* __restrict__ dx, int64_t n8, int C8, int act, float inv_rows, int train) {
-  const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (idx >= n8) return;
-  const int c0 = (int)(idx % C8) * 8;
+                      const float* __restrict__ sum_duxh, bf16_t* __restrict__ dx, int64_t rows, int C8, int act, float inv_rows, int train) {
+  const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int64_t r0 = t / C8 * BN_R;
+  if (r0 >= rows) return;
+  const int c0 = (int)(t % C8) * 8;
+  const int64_t i0 = (r0 * C8 + c0 / 8) * 8, rs8 = (int64_t)C8 * 8;
+  bn_b8 xv[BN_R], dv[BN_R];
+#pragma unroll
+  for (int k = 0; k < BN_R; ++k) {
+    const int64_t kk = r0 + k < rows ? k : 0;
+    xv[k] = *reinterpret_cast<const bn_b8*>(x + i0 + kk * rs8);
+    dv[k] = *reinterpret_cast<const bn_b8*>(dy + i0 + kk * rs8);
+  }
   float m[8], r[8], sd[8], sx[8];
   bn_load8(mean + c0, m); bn_load8(rstd + c0, r); bn_load8(sum_du + c0, sd); bn_load8(sum_duxh + c0, sx);
   const bn_b8 g = *reinterpret_cast<const bn_b8*>(gamma + c0), b = *reinterpret_cast<const bn_b8*>(beta + c0);
-  const bn_b8 xv = *reinterpret_cast<const bn_b8*>(x + idx * 8), dv = *reinterpret_cast<const bn_b8*>(dy + idx * 8);
-  bn_b8 o;
 #pragma unroll
-  for (int j = 0; j < 8; ++j) {
-    const float gj = (float)g[j];
-    const float xh = ((float)xv[j] - m[j]) * r[j];
-    float du = (float)dv[j] * act_grad_f(xh * gj + (float)b[j], act);
-    if (train) du -= (sd[j] + xh * sx[j]) * inv_rows;
-    o[j] = (bf16_t)(gj * r[j] * du);
+  for (int k = 0; k < BN_R; ++k) {
+    if (r0 + k >= rows) break;
+    bn_b8 o;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const float gj = (float)g[j];
+      const float xh = ((float)xv[k][j] - m[j]) * r[j];
+      float du = (float)dv[k][j] * act_grad_f(xh * gj + (float)b[j], act);
+      if (train) du -= (sd[j] + xh * sx[j]) * inv_rows;
+      o[j] = (bf16_t)(gj * r[j] * du);
+    }
+    *reinterpret_cast<bn_b8*>(dx + i0 + k * rs8) = o;
   }
-  *reinterpret_cast<bn_b8*>(dx + idx * 8) = o;
 }
 static bool bn_v8_ok(int C, int dtype, const void* a, const void* b, const void* c, const void* d) {
   return dtype == MMRCA_BF16 && C % 8 == 0 && ((((uintptr_t)a) | ((uintptr_t)b) | ((uintptr_t)c) | ((uintptr_t)d)) & 15) == 0;
@@ -1413,8 +1451,8 @@ extern "C" int mmrca_bn_act_fwd(const void* x, const float* mean, const float* r
   MMRCA_REQUIRE(x && mean && rstd && gamma && beta && y && rows > 0 && C > 0 && act >= 0 && act <= 3, "bn_act_fwd: bad arguments");
   const int64_t n = rows * C;
   if (bn_v8_ok(C, dtype, x, y, gamma, beta) && ((((uintptr_t)mean) | ((uintptr_t)rstd)) & 15) == 0) {
-    hipLaunchKernelGGL(bn_act_fwd_v8_k, dim3(blocks_for(n / 8, 256)), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)x, mean, rstd,
-                       (const bf16_t*)gamma, (const bf16_t*)beta, (bf16_t*)y, n / 8, C / 8, act);
+    hipLaunchKernelGGL(bn_act_fwd_v8_k, dim3(blocks_for((rows + BN_R - 1) / BN_R * (C / 8), 256)), dim3(256), 0, (hipStream_t)stream,
+                       (const bf16_t*)x, mean, rstd, (const bf16_t*)gamma, (const bf16_t*)beta, (bf16_t*)y, rows, C / 8, act);
     MMRCA_CHECK_LAUNCH("bn_act_fwd(v8)");
     return 0;
   }
@@ -1434,10 +1472,9 @@ extern "C" int mmrca_bn_act_fwd_res(const void* x, const float* mean, const floa
                 "bn_act_fwd_res: bad arguments");
   if (!(bn_v8_ok(C, dtype, x, out, gamma, beta) && ((((uintptr_t)mean) | ((uintptr_t)rstd) | ((uintptr_t)res)) & 15) == 0))
     return mmrca_fail(-3, "bn_act_fwd_res: only the bf16 / C %% 8 == 0 / 16-byte aligned case is built");
-  const int64_t n = rows * C;
-  hipLaunchKernelGGL(bn_act_fwd_res_v8_k, dim3(blocks_for(n / 8, 256)), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)x, mean, rstd,
-                     (const bf16_t*)gamma, (const bf16_t*)beta, (const bf16_t*)res, rowscale, (bf16_t*)out, n / 8, C / 8, act,
-                     rows_per_sample * C / 8);
+    hipLaunchKernelGGL(bn_act_fwd_res_v8_k, dim3(blocks_for((rows + BN_R - 1) / BN_R * (C / 8), 256)), dim3(256), 0, (hipStream_t)stream,
+                     (const bf16_t*)x, mean, rstd, (const bf16_t*)gamma, (const bf16_t*)beta, (const bf16_t*)res, rowscale, (bf16_t*)out, rows,
+                     C / 8, act, rows_per_sample);
   MMRCA_CHECK_LAUNCH("bn_act_fwd_res");
   return 0;
 }
@@ -1510,9 +1547,9 @@ static int bn_act_bwd_impl(const void* dy, const void* x, const float* mean, con
     hipLaunchKernelGGL(bn_act_bwd_reduce_k<T>, grid, dim3(256), 0, st, (const T*)dy, (const T*)x, mean, rstd, (const T*)gamma, (const T*)beta,
                        scratch, scratch + C, rows, C, act, per);
     const bool v8 = dx && bn_v8_ok(C, dtype, dy, x, dx, gamma) && ((((uintptr_t)mean) | ((uintptr_t)rstd) | ((uintptr_t)scratch) | ((uintptr_t)beta)) & 15) == 0;
-    if (v8) hipLaunchKernelGGL(bn_act_bwd_apply_v8_k, dim3(blocks_for(n / 8, 256)), dim3(256), 0, st, (const bf16_t*)dy, (const bf16_t*)x, mean, rstd,
-                               (const bf16_t*)gamma, (const bf16_t*)beta, (const float*)scratch, (const float*)(scratch + C), (bf16_t*)dx,
-                               n / 8, C / 8, act, 1.0f / (float)rows, train);
+    if (v8) hipLaunchKernelGGL(bn_act_bwd_apply_v8_k, dim3(blocks_for((rows + BN_R - 1) / BN_R * (C / 8), 256)), dim3(256), 0, st, (const bf16_t*)dy,
+                               (const bf16_t*)x, mean, rstd, (const bf16_t*)gamma, (const bf16_t*)beta, (const float*)scratch,
+                               (const float*)(scratch + C), (bf16_t*)dx, rows, C / 8, act, 1.0f / (float)rows, train);
     else if (dx) hipLaunchKernelGGL(bn_act_bwd_apply_k<T>, dim3(blocks_for(n, 256)), dim3(256), 0, st, (const T*)dy, (const T*)x, mean, rstd,
                                (const T*)gamma, (const T*)beta, (const float*)scratch, (const float*)(scratch + C), (T*)dx, n, C, act,
                                1.0f / (float)rows, train);)
