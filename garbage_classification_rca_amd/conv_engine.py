@@ -30,6 +30,10 @@ PAD_TAP_K = os.environ.get("MMRCA_CONV_PAD_K", "1") == "1"
 # dense 3x3 / stride-1 convolutions as implicit GEMMs (csrc/conv_igemm.hip): no patch matrix, BatchNorm moments in the epilogue;
 # "0" keeps im2row + GEMM everywhere (the A/B switch of DESIGN 3d)
 IGEMM = os.environ.get("MMRCA_CONV_IGEMM", "1") == "1"
+# 1x1 convolutions: BatchNorm moments in the GEMM epilogue (mmrca_gemm_bnstats).  OFF by default: measured 604 -> 592 samples/s on
+# configs[2] -- the separate moments pass reads z straight after the GEMM wrote it (Infinity-Cache hits, ~5 TB/s) and costs less than the
+# extra LDS reduction + barrier per 128x128 tile in the epilogue does.
+FUSE_GEMM_BN = os.environ.get("MMRCA_CONV_FUSE_GEMM_BN", "0") == "1"
 FUSE_SE = os.environ.get("MMRCA_CONV_FUSE_SE", "1") == "1"         # SE backward: dx and the next BatchNorm's backward sums in one pass
 FUSE_RES = os.environ.get("MMRCA_CONV_FUSE_RES", "1") == "1"       # residual connection inside the block's last BatchNorm pass
 IGEMM_DGRAD = os.environ.get("MMRCA_CONV_IGEMM_DGRAD", "1") == "1"
@@ -291,10 +295,18 @@ class ConvEncoder:
         z = self.buf(tag + ".z", rows, u.cout)
         w = self.W(u.conv_key + ".weight")
         fused_stats = False
+        sums = None
         if u.dw:
             L.dwconv3x3_fwd(x, w, z, B, H, Wd, u.cin, u.stride, dt)
         elif u.k == 1:
-            L.gemm(x, w, z, M=rows, N=u.cout, K=u.cin, lda=u.cin, ldb=u.cin, ldc=u.cout, dtype=dt, impl=self.o.gemm_impl)
+            if train and FUSE_GEMM_BN and self.o.gemm_impl == L.IMPL_AUTO and L.gemm_bnstats_ok(rows, u.cout, u.cin, dt):
+                # BatchNorm moments of z in the GEMM's epilogue: shifted sums per 128-row block (shift = the running mean)
+                nsl = (rows + 127) // 128
+                sums = (self.buf("tmp.bnsum.s1", nsl, u.cout, torch.float32), self.buf("tmp.bnsum.s2", nsl, u.cout, torch.float32), nsl)
+                L.gemm_bnstats(x, w, z, M=rows, N=u.cout, K=u.cin, lda=u.cin, ldb=u.cin, ldc=u.cout, dtype=dt,
+                               shift=self.buffers[u.bn_key + ".running_mean"], s1=sums[0], s2=sums[1])
+            else:
+                L.gemm(x, w, z, M=rows, N=u.cout, K=u.cin, lda=u.cin, ldb=u.cin, ldc=u.cout, dtype=dt, impl=self.o.gemm_impl)
         elif self._igemm(u):
             ns = L.conv3x3_stat_slots(B, H, Wd)
             parts = None
@@ -319,6 +331,8 @@ class ConvEncoder:
         rm, rv = self.buffers[u.bn_key + ".running_mean"], self.buffers[u.bn_key + ".running_var"]
         if fused_stats:
             L.conv_bn_finish(parts, B, H, Wd, mean, rstd, rm, rv, u.cout, u.eps, 0.1)
+        elif sums is not None:
+            L.bn_finish_sums(sums[0], sums[1], rm, sums[2], rows, mean, rstd, rm, rv, u.cout, u.eps, 0.1)
         else:
             L.bn_stats(z, mean, rstd, rm, rv, rows, u.cout, u.cout, u.eps, 0.1 if train else 0.0, train, dt)
         fused_res = res is not None and FUSE_RES and self.o.dtype == torch.bfloat16 and u.cout % 8 == 0

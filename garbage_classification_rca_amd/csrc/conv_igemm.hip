@@ -279,6 +279,48 @@ conv_bn_finish_k(const float* __restrict__ part_mean, const float* __restrict__ 
   }
 }
 
+// mean / rstd (+ running statistics) from the shifted sums mmrca_gemm_bnstats left: s1 / s2 [nslots, C], shift [C] or NULL.
+// block = 32 channels x 8 slot lanes, sums in double.  (shift may alias running_mean: it is read before the update.)
+__global__ void __launch_bounds__(256)
+bn_finish_sums_k(const float* __restrict__ s1, const float* __restrict__ s2, const float* __restrict__ shift, int64_t nslots, double rows,
+                 float* __restrict__ mean, float* __restrict__ rstd, float* __restrict__ running_mean, float* __restrict__ running_var, int C,
+                 float eps, float momentum) {
+  __shared__ double red[2][8][33];
+  const int cl = threadIdx.x & 31, sl = threadIdx.x >> 5;
+  const int c = blockIdx.x * 32 + cl;
+  double a = 0.0, b = 0.0;
+  if (c < C)
+    for (int64_t t = sl; t < nslots; t += 8) { a += (double)s1[t * C + c]; b += (double)s2[t * C + c]; }
+  red[0][sl][cl] = a; red[1][sl][cl] = b;
+  __syncthreads();
+  if (sl == 0 && c < C) {
+    double S1 = 0.0, S2 = 0.0;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) { S1 += red[0][k][cl]; S2 += red[1][k][cl]; }
+    const double d1 = S1 / rows;
+    const float mu = (float)((shift ? (double)shift[c] : 0.0) + d1);
+    double v = S2 / rows - d1 * d1;
+    if (v < 0.0) v = 0.0;
+    const float var = (float)v;
+    mean[c] = mu;
+    rstd[c] = rsqrtf(var + eps);
+    if (running_mean && momentum > 0.f) {
+      const float nf = (float)rows;
+      running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * mu;
+      running_var[c] = (1.f - momentum) * running_var[c] + momentum * (nf > 1.f ? var * nf / (nf - 1.f) : var);
+    }
+  }
+}
+/* mean[C], rstd[C] (+ running statistics when momentum > 0) from mmrca_gemm_bnstats' s1 / s2 [nslots, C] over `rows` rows in all */
+extern "C" int mmrca_bn_finish_sums(const float* s1, const float* s2, const float* shift, int64_t nslots, int64_t rows, float* mean, float* rstd,
+                                    float* running_mean, float* running_var, int C, float eps, float momentum, void* stream) {
+  MMRCA_REQUIRE(s1 && s2 && mean && rstd && nslots > 0 && rows > 0 && C > 0, "bn_finish_sums: bad arguments");
+  hipLaunchKernelGGL(bn_finish_sums_k, dim3((C + 31) / 32), dim3(256), 0, (hipStream_t)stream, s1, s2, shift, nslots, (double)rows, mean, rstd,
+                     running_mean, running_var, C, eps, momentum);
+  MMRCA_CHECK_LAUNCH("bn_finish_sums");
+  return 0;
+}
+
 // patch shape: PW in {16, 32, 64} (PH = 128 / PW), whichever covers the image with the fewest padded pixels (ties: the squarer
 // patch, whose halo is smaller)
 static void conv_patch(int H, int W, int* PH, int* PW) {

@@ -632,6 +632,12 @@ gemm_mfma_k(const bf16_t* __restrict__ A, const bf16_t* __restrict__ B, void* __
 // ======================================================================================================
 #define TILE32_BYTES (128 * 32 * 2)
 
+// BatchNorm moments of the stored output tile in the epilogue of the plain bf16 kernels (mmrca_gemm_bnstats: the 1x1 convolutions
+// of the conv backbones): per output tile row block `tm` and column, s1 = sum (c - shift), s2 = sum (c - shift)^2 over the tile's
+// valid rows of the ROUNDED outputs, written (not added) to s1 / s2 [tiles_m, N]; mmrca_bn_finish_sums merges the row blocks.
+// shift = the layer's running mean keeps s2 - s1^2 / n free of cancellation.
+struct BnStat { const float* shift; float* s1; float* s2; };
+
 template <bool KROW>
 __device__ __forceinline__ void stage_tile32(const bf16_t* __restrict__ base, int64_t ld, int64_t row0, int64_t rows_total,
                                              int64_t k0, char* lds_tile, int wave, int lane) {
@@ -679,11 +685,12 @@ __device__ __forceinline__ void frag_addr32(const char* lds_tile, int rb, int la
   }
 }
 
-template <bool A_KROW, bool B_KROW, bool ATOMIC_F32, bool FUSE_DB>
+template <bool A_KROW, bool B_KROW, bool ATOMIC_F32, bool FUSE_DB, bool BNS = false>
 __global__ void __launch_bounds__(256, 4)
 gemm_mfma_k32(const bf16_t* __restrict__ A, const bf16_t* __restrict__ B, void* __restrict__ Cv, const bf16_t* __restrict__ bias,
               const bf16_t* __restrict__ addend, bf16_t* __restrict__ preact, int64_t M, int64_t N, int64_t K,
-              int64_t lda, int64_t ldb, int64_t ldc, int act, int tiles_m, int tiles_n, int64_t ksplit_len, float* __restrict__ dbias) {
+              int64_t lda, int64_t ldb, int64_t ldc, int act, int tiles_m, int tiles_n, int64_t ksplit_len, float* __restrict__ dbias,
+              const BnStat bst = BnStat{nullptr, nullptr, nullptr}) {
   extern __shared__ __attribute__((aligned(16))) char smem[];   // [2 buffers][A tile 8 KiB | B tile 8 KiB]
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
   const int wr = wave >> 1, wc = wave & 1;
@@ -791,6 +798,13 @@ gemm_mfma_k32(const bf16_t* __restrict__ A, const bf16_t* __restrict__ B, void* 
 #pragma unroll
       for (int r = 0; r < 4; ++r) bv[r] = (float)b4[r];
     }
+    [[maybe_unused]] float st1[4] = {0.f, 0.f, 0.f, 0.f}, st2[4] = {0.f, 0.f, 0.f, 0.f}, stsh[4] = {0.f, 0.f, 0.f, 0.f};
+    if constexpr (BNS) {
+      if (bst.shift && ncol < N) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) stsh[r] = bst.shift[ncol + r];
+      }
+    }
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
 #pragma unroll
@@ -839,20 +853,36 @@ gemm_mfma_k32(const bf16_t* __restrict__ A, const bf16_t* __restrict__ B, void* 
 #pragma unroll
           for (int r = 0; r < 4; ++r) o[r] = (bf16_t)v[r];
           *reinterpret_cast<bf16x4*>(C + m * ldc + ncol) = o;
+          if constexpr (BNS) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) { const float d = (float)o[r] - stsh[r]; st1[r] += d; st2[r] = fmaf(d, d, st2[r]); }
+          }
         }
       }
       __syncthreads();
     }
+    if constexpr (BNS) {   // 8 row groups (4 waves x 2 half-waves) -> LDS -> one plain store per column and moment
+      float* red = reinterpret_cast<float*>(smem);
+#pragma unroll
+      for (int r = 0; r < 4; ++r) { red[(wave * 2 + half) * 128 + l32 * 4 + r] = st1[r]; red[1024 + (wave * 2 + half) * 128 + l32 * 4 + r] = st2[r]; }
+      __syncthreads();
+      const int col = threadIdx.x & 127, which = threadIdx.x >> 7;
+      float t = 0.f;
+#pragma unroll
+      for (int q = 0; q < 8; ++q) t += red[which * 1024 + q * 128 + col];
+      if (n_blk + col < N) (which ? bst.s2 : bst.s1)[(int64_t)tm * N + n_blk + col] = t;
+    }
   }
 }
 
-template <bool AK, bool BK2, bool AT, bool DB = false>
+template <bool AK, bool BK2, bool AT, bool DB = false, bool BNS = false>
 static void launch_mfma32(const void* A, const void* B, void* C, const void* bias, const void* addend, void* preact,
                           int64_t M, int64_t N, int64_t K, int64_t lda, int64_t ldb, int64_t ldc, int act, int tiles_m,
-                          int tiles_n, int ksplits, int64_t ksplit_len, hipStream_t st, float* dbias = nullptr) {
-  hipLaunchKernelGGL((gemm_mfma_k32<AK, BK2, AT, DB>), dim3(tiles_m * tiles_n, ksplits), dim3(256), 4 * TILE32_BYTES, st,
+                          int tiles_n, int ksplits, int64_t ksplit_len, hipStream_t st, float* dbias = nullptr,
+                          BnStat bst = BnStat{nullptr, nullptr, nullptr}) {
+  hipLaunchKernelGGL((gemm_mfma_k32<AK, BK2, AT, DB, BNS>), dim3(tiles_m * tiles_n, ksplits), dim3(256), 4 * TILE32_BYTES, st,
                      (const bf16_t*)A, (const bf16_t*)B, C, (const bf16_t*)bias, (const bf16_t*)addend, (bf16_t*)preact,
-                     M, N, K, lda, ldb, ldc, act, tiles_m, tiles_n, ksplit_len, dbias);
+                     M, N, K, lda, ldb, ldc, act, tiles_m, tiles_n, ksplit_len, dbias, bst);
 }
 
 // single-stage 128x128x64 variant (32 KiB LDS, four to five blocks per CU): full 128-byte lines for ROWK operands
@@ -861,13 +891,13 @@ static void launch_mfma32(const void* A, const void* B, void* C, const void* bia
 // (A_lo, B_hi), (A_hi, B_lo); lo x lo is below fp32 resolution -- into the same fp32 accumulators, and the epilogue's
 // bias / side operands / outputs are fp32 (biasv / addendv / preactv / Cv point at floats), or, with C_lo given, the output is
 // written as two bf16 planes (Cv = hi plane) for a consumer that is another X3 GEMM.
-template <bool A_KROW, bool B_KROW, bool ATOMIC_F32, int WPE, bool X3 = false>
+template <bool A_KROW, bool B_KROW, bool ATOMIC_F32, int WPE, bool X3 = false, bool BNS = false>
 __global__ void __launch_bounds__(256, WPE)
 gemm_mfma_k1s(const bf16_t* __restrict__ A, const bf16_t* __restrict__ B, void* __restrict__ Cv, const bf16_t* __restrict__ bias,
               const bf16_t* __restrict__ addend, bf16_t* __restrict__ preact, int64_t M, int64_t N, int64_t K,
               int64_t lda, int64_t ldb, int64_t ldc, int act, int tiles_m, int tiles_n, int64_t ksplit_len, float* __restrict__ colsum,
               const bf16_t* __restrict__ A_lo = nullptr, const bf16_t* __restrict__ B_lo = nullptr, bf16_t* __restrict__ C_lo = nullptr,
-              int nseg = 3) {
+              int nseg = 3, const BnStat bst = BnStat{nullptr, nullptr, nullptr}) {
   extern __shared__ __attribute__((aligned(16))) char smem[];   // ONE buffer: [A tile 16 KiB | B tile 16 KiB]
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
   const int wr = wave >> 1, wc = wave & 1;
@@ -1056,6 +1086,13 @@ gemm_mfma_k1s(const bf16_t* __restrict__ A, const bf16_t* __restrict__ B, void* 
         }
     }
     float cs[4] = {0.f, 0.f, 0.f, 0.f};      // column sums of what this lane stores (colsum != nullptr)
+    [[maybe_unused]] float st2[4] = {0.f, 0.f, 0.f, 0.f}, stsh[4] = {0.f, 0.f, 0.f, 0.f};     // BNS: cs = sum d, st2 = sum d^2, d = c - shift
+    if constexpr (BNS) {
+      if (bst.shift && ncol < N) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) stsh[r] = bst.shift[ncol + r];
+      }
+    }
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
 #pragma unroll
@@ -1104,13 +1141,27 @@ gemm_mfma_k1s(const bf16_t* __restrict__ A, const bf16_t* __restrict__ B, void* 
           }
           bf16x4 o;
 #pragma unroll
-          for (int r = 0; r < 4; ++r) { o[r] = (bf16_t)v[r]; cs[r] += (float)o[r]; }
+          for (int r = 0; r < 4; ++r) {
+            o[r] = (bf16_t)v[r];
+            if constexpr (BNS) { const float d = (float)o[r] - stsh[r]; cs[r] += d; st2[r] = fmaf(d, d, st2[r]); }
+            else cs[r] += (float)o[r];
+          }
           *reinterpret_cast<bf16x4*>(C + m * ldc + ncol) = o;
         }
       }
       __syncthreads();
     }
-    if (colsum) {
+    if constexpr (BNS) {   // 8 row groups (4 waves x 2 half-waves) -> LDS -> one plain store per column and moment
+      float* red = reinterpret_cast<float*>(smem);
+#pragma unroll
+      for (int r = 0; r < 4; ++r) { red[(wave * 2 + half) * 128 + l32 * 4 + r] = cs[r]; red[1024 + (wave * 2 + half) * 128 + l32 * 4 + r] = st2[r]; }
+      __syncthreads();
+      const int col = threadIdx.x & 127, which = threadIdx.x >> 7;
+      float t = 0.f;
+#pragma unroll
+      for (int q = 0; q < 8; ++q) t += red[which * 1024 + q * 128 + col];
+      if (n_blk + col < N) (which ? bst.s2 : bst.s1)[(int64_t)tm * N + n_blk + col] = t;
+    } else if (colsum) {
       // column sums of the stored tile (the bias gradient of the layer below, when this GEMM is its input gradient):
       // 8 row groups (4 waves x 2 half-waves) -> LDS -> one atomic per column per block
       float* red = reinterpret_cast<float*>(smem);
@@ -1127,15 +1178,16 @@ gemm_mfma_k1s(const bf16_t* __restrict__ A, const bf16_t* __restrict__ B, void* 
   }
 }
 
-template <bool AK, bool BK2, bool AT, int WPE, bool X3 = false>
+template <bool AK, bool BK2, bool AT, int WPE, bool X3 = false, bool BNS = false>
 static void launch_mfma1s(const void* A, const void* B, void* C, const void* bias, const void* addend, void* preact,
                           int64_t M, int64_t N, int64_t K, int64_t lda, int64_t ldb, int64_t ldc, int act, int tiles_m,
                           int tiles_n, int ksplits, int64_t ksplit_len, float* colsum, hipStream_t st,
-                          const void* A_lo = nullptr, const void* B_lo = nullptr, void* C_lo = nullptr, int nseg = 3) {
-  hipLaunchKernelGGL((gemm_mfma_k1s<AK, BK2, AT, WPE, X3>), dim3(tiles_m * tiles_n, ksplits), dim3(256), 2 * TILE_BYTES, st,
+                          const void* A_lo = nullptr, const void* B_lo = nullptr, void* C_lo = nullptr, int nseg = 3,
+                          BnStat bst = BnStat{nullptr, nullptr, nullptr}) {
+  hipLaunchKernelGGL((gemm_mfma_k1s<AK, BK2, AT, WPE, X3, BNS>), dim3(tiles_m * tiles_n, ksplits), dim3(256), 2 * TILE_BYTES, st,
                      (const bf16_t*)A, (const bf16_t*)B, C, (const bf16_t*)bias, (const bf16_t*)addend, (bf16_t*)preact,
                      M, N, K, lda, ldb, ldc, act, tiles_m, tiles_n, ksplit_len, colsum, (const bf16_t*)A_lo, (const bf16_t*)B_lo,
-                     (bf16_t*)C_lo, nseg);
+                     (bf16_t*)C_lo, nseg, bst);
 }
 
 // entry used by gemm_x3.hip: the single-stage 128x128 kernel in its bf16x3 form (any epilogue; accumulate mode = fp32 atomics)
@@ -1415,6 +1467,32 @@ extern "C" int mmrca_gemm_colsum(const void* A, const void* B, void* C, const vo
                              stream, colsum, &done))
     return rc;
   if (!done) return mmrca_colsum_accum(C, colsum, M, N, ldc, dtype, stream);    // kernels without the fused sums: one more pass
+  return 0;
+}
+
+// C[M,N] = A[M,K] . B[N,K]^T (bf16, both row-major in K, no epilogue) with the BatchNorm moments of the stored C in the epilogue:
+// s1[tm, n] = sum over the valid rows of 128-row block tm of (c - shift[n]), s2 likewise of the squares; s1 / s2 are
+// [mmrca_gemm_bnstats_slots(M), N] fp32 and are WRITTEN.  shift may be NULL (= 0).  Runs on the 128x128 single-stage kernel
+// (K % 64 == 0) or the 32-deep one (K % 32 == 0); ragged M / N (N % 8 == 0) as in mmrca_gemm.  Returns -3 for shapes it does not take.
+extern "C" int64_t mmrca_gemm_bnstats_slots(int64_t M) { return M > 0 ? (M + GBM - 1) / GBM : 0; }
+extern "C" int mmrca_gemm_bnstats(const void* A, const void* B, void* C, int64_t M, int64_t N, int64_t K, int64_t lda, int64_t ldb, int64_t ldc,
+                                  int dtype, const float* shift, float* s1, float* s2, void* stream) {
+  MMRCA_REQUIRE(A && B && C && s1 && s2 && M > 0 && N > 0 && K > 0, "gemm_bnstats: bad arguments");
+  MMRCA_REQUIRE(lda >= K && ldb >= K && ldc >= N, "gemm_bnstats: leading dimension too small");
+  if (!(dtype == MMRCA_BF16 && N % 8 == 0 && N >= 8 && K % 32 == 0 && M >= 64 && lda % 8 == 0 && ldb % 8 == 0 && ldc % 4 == 0 &&
+        aligned16(A) && aligned16(B) && aligned16(C) && (!shift || aligned16(shift))))
+    return mmrca_fail(-3, "gemm_bnstats: shape M=%lld N=%lld K=%lld / dtype %d is not taken by the 128x128 bf16 kernels", (long long)M,
+                      (long long)N, (long long)K, dtype);
+  const int tiles_m = (int)((M + GBM - 1) / GBM), tiles_n = (int)((N + GBN - 1) / GBN);
+  hipStream_t st = (hipStream_t)stream;
+  const BnStat bst{shift, s1, s2};
+  if (K % 64 == 0)
+    launch_mfma1s<false, false, false, 4, false, true>(A, B, C, nullptr, nullptr, nullptr, M, N, K, lda, ldb, ldc, MMRCA_ACT_NONE, tiles_m, tiles_n, 1, K,
+                                          nullptr, st, nullptr, nullptr, nullptr, 3, bst);
+  else
+    launch_mfma32<false, false, false, false, true>(A, B, C, nullptr, nullptr, nullptr, M, N, K, lda, ldb, ldc, MMRCA_ACT_NONE, tiles_m, tiles_n, 1, K, st,
+                                       nullptr, bst);
+  MMRCA_CHECK_LAUNCH("gemm_bnstats");
   return 0;
 }
 

@@ -68,6 +68,8 @@ _SIGS = {
     "mmrca_conv3x3_fwd": [_vp, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _vp],
     "mmrca_conv_bn_finish": [_vp, _vp, _vp, _i32, _i32, _i32, _vp, _vp, _vp, _vp, _i32, _f32, _f32, _vp],
     "mmrca_conv3x3_wgrad": [_vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _vp],
+    "mmrca_gemm_bnstats": [_vp, _vp, _vp, _i64, _i64, _i64, _i64, _i64, _i64, _i32, _vp, _vp, _vp, _vp],
+    "mmrca_bn_finish_sums": [_vp, _vp, _vp, _i64, _i64, _vp, _vp, _vp, _vp, _i32, _f32, _f32, _vp],
     "mmrca_bn_act_bwd_sums": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i32, _i32, _i32, _i32, _vp],
     "mmrca_se_dx": [_vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _vp, _vp, _vp, _vp, _vp, _i32, _vp, _vp],
     "mmrca_bn_act_fwd_res": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i32, _i32, _i64, _i32, _vp],
@@ -114,7 +116,7 @@ _SIGS = {
     "mmrca_cast_f32_to_bf16": [_vp, _vp, _i64, _vp],
 }
 EXPORTS = sorted(list(_SIGS) + ["mmrca_last_error", "mmrca_version", "mmrca_debug_set", "mmrca_debug_attn_stamps", "mmrca_gemm_splitk_workspace_bytes",
-                                  "mmrca_head_bwd_workspace_bytes", "mmrca_conv3x3_stat_slots"])
+                                  "mmrca_head_bwd_workspace_bytes", "mmrca_conv3x3_stat_slots", "mmrca_gemm_bnstats_slots"])
 
 
 def load(build_if_missing: bool = False):
@@ -526,6 +528,20 @@ def conv_bn_finish(parts, B, H, W, mean, rstd, running_mean, running_var, C, eps
 def conv3x3_wgrad(dz, x, dw_tap, B, H, W, Cin, Cout, dtype):
     """dw_tap[Cout, 9*Cin] (fp32) += the weight gradient of the same convolution, patches gathered from x inside the kernel"""
     _c("mmrca_conv3x3_wgrad", ptr(dz), ptr(x), ptr(dw_tap), B, H, W, Cin, Cout, dtype)
+
+
+def gemm_bnstats_ok(M, N, K, dtype):
+    return dtype == BF16 and N % 8 == 0 and K % 32 == 0 and M >= 64
+
+
+def gemm_bnstats(A, B, Cout, *, M, N, K, lda, ldb, ldc, dtype, shift, s1, s2):
+    """plain bf16 GEMM with the BatchNorm moments of its output in the epilogue (s1 / s2: [ceil(M / 128), N] fp32, written)"""
+    _c("mmrca_gemm_bnstats", ptr(A), ptr(B), ptr(Cout), M, N, K, lda, ldb, ldc, dtype, ptr(shift), ptr(s1), ptr(s2))
+
+
+def bn_finish_sums(s1, s2, shift, nslots, rows, mean, rstd, running_mean, running_var, C, eps, momentum):
+    _c("mmrca_bn_finish_sums", ptr(s1), ptr(s2), ptr(shift), nslots, rows, ptr(mean), ptr(rstd), ptr(running_mean), ptr(running_var), C, eps,
+       momentum)
 
 
 def bn_act_fwd_res(x, mean, rstd, gamma, beta, res, rowscale, out, rows, C, act, rows_per_sample, dtype):

@@ -72,6 +72,16 @@ int mmrca_gemm_colsum(const void* A, const void* B, void* C, const void* bias, c
                       float* colsum, int64_t M, int64_t N, int64_t K, int64_t lda, int64_t ldb, int64_t ldc,
                       int a_layout, int b_layout, int act, int dtype, int impl, void* stream);
 
+/* C[M,N] = A[M,K] . B[N,K]^T (bf16, no epilogue) with the BatchNorm moments of the stored C collected in the epilogue (the 1x1
+ * convolutions of the conv backbones, multimodal_model.py:113-126): s1[tm, n] / s2[tm, n] ([mmrca_gemm_bnstats_slots(M), N] fp32,
+ * written) = sum / sum of squares of (c - shift[n]) over the valid rows of 128-row block tm; shift (the layer's running mean, or
+ * NULL = 0) keeps the variance free of cancellation.  mmrca_bn_finish_sums turns them into mean / rstd / running statistics exactly
+ * as mmrca_bn_stats(train = 1) would from C.  Returns -3 for shapes the 128x128 bf16 kernels do not take (N % 8, K % 32, M >= 64). */
+int64_t mmrca_gemm_bnstats_slots(int64_t M);
+int mmrca_gemm_bnstats(const void* A, const void* B, void* C, int64_t M, int64_t N, int64_t K, int64_t lda, int64_t ldb, int64_t ldc,
+                       int dtype, const float* shift, float* s1, float* s2, void* stream);
+int mmrca_bn_finish_sums(const float* s1, const float* s2, const float* shift, int64_t nslots, int64_t rows, float* mean, float* rstd,
+                         float* running_mean, float* running_var, int C, float eps, float momentum, void* stream);
 /* mmrca_gemm (colsum == NULL) / mmrca_gemm_colsum with the row contract of MMRCA_GEMM_MFMA256 made explicit.  That kernel
  * streams whole 256-row tiles: with M % 256 != 0 it READS (never stores) rows M .. round_up(M, 256) - 1 of A and of the side
  * operand (addend, or preact under MMRCA_ACT_MUL).  mmrca_gemm / mmrca_gemm_colsum therefore reject impl = MMRCA_GEMM_MFMA256

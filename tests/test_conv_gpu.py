@@ -131,6 +131,34 @@ def test_batchnorm_act_fwd_bwd_and_running_stats(dt, act, train):
     assert rel(dx, x.grad) < tol and rel(dg, gam.grad) < tol and rel(db, bet.grad) < tol
 
 
+@pytest.mark.parametrize("M,N,K", [(1000, 72, 64), (300, 256, 224), (4096, 768, 192), (777, 200, 96), (128, 128, 64)])
+def test_gemm_with_batchnorm_moments_in_the_epilogue(M, N, K):
+    """mmrca_gemm_bnstats + mmrca_bn_finish_sums == mmrca_gemm + mmrca_bn_stats (the 1x1 convolutions of the conv backbones): same z bit
+    for bit, mean / rstd / running statistics to fp32 rounding; both 128x128 kernels (K % 64 == 0 and the 32-deep one), ragged M and N,
+    a shift far from the channel means included."""
+    g = torch.Generator().manual_seed(M + N)
+    A = torch.randn(M, K, generator=g).bfloat16().cuda()
+    Bw = (torch.randn(N, K, generator=g) * 0.2 + 0.05).bfloat16().cuda()
+    z_ref = torch.empty(M, N, device="cuda", dtype=torch.bfloat16)
+    L.gemm(A, Bw, z_ref, M=M, N=N, K=K, lda=K, ldb=K, ldc=N, dtype=L.BF16)
+    mean_r, rstd_r = torch.empty(N, device="cuda"), torch.empty(N, device="cuda")
+    rm_r, rv_r = torch.full((N,), 0.3, device="cuda"), torch.ones(N, device="cuda")
+    L.bn_stats(z_ref, mean_r, rstd_r, rm_r, rv_r, M, N, N, 1e-3, 0.1, True, L.BF16)
+    for shift_kind in ("running", "none", "far"):
+        z = torch.full((M, N), float("nan"), device="cuda", dtype=torch.bfloat16)
+        ns = (M + 127) // 128
+        s1, s2 = torch.full((ns, N), float("nan"), device="cuda"), torch.full((ns, N), float("nan"), device="cuda")
+        rm, rv = torch.full((N,), 0.3, device="cuda"), torch.ones(N, device="cuda")
+        shift = {"running": rm, "none": None, "far": torch.full((N,), 25.0, device="cuda")}[shift_kind]
+        L.gemm_bnstats(A, Bw, z, M=M, N=N, K=K, lda=K, ldb=K, ldc=N, dtype=L.BF16, shift=shift, s1=s1, s2=s2)
+        assert torch.equal(z, z_ref)
+        mean, rstd = torch.empty(N, device="cuda"), torch.empty(N, device="cuda")
+        L.bn_finish_sums(s1, s2, shift, ns, M, mean, rstd, rm, rv, N, 1e-3, 0.1)
+        tol = 2e-5 if shift_kind != "far" else 2e-3           # (a shift 25 sigma off costs digits, as it must; the engine passes the running mean)
+        assert rel(mean, mean_r) < tol and rel(rstd, rstd_r) < tol, shift_kind
+        assert rel(rm, rm_r) < tol and rel(rv, rv_r) < tol
+
+
 @pytest.mark.parametrize("HW", [35, 64, 100])        # odd / even row counts of the two-rows-in-flight loop
 @pytest.mark.parametrize("act", [L.CONV_SILU, L.CONV_NONE])
 def test_se_backward_second_half_with_the_batchnorm_sums_in_one_pass(HW, act):
