@@ -819,6 +819,7 @@ dwconv3x3_bwd_weight_s1_strip2_v8_k(const bf16_t* __restrict__ dy, const bf16_t*
 // groups over ALL channels -- the grid walks the two tensors front to back like the forward kernel does.  The slice form above
 // gives a block one 1-KiB column slice of every pixel row (stride 2C bytes) and measured 1.4-1.8 TB/s whatever its block count or
 // reduction.  Every thread keeps its 72 sums and writes them to ws[lane][c8 * 72 ..]; dw_wg_reduce_k adds the lanes up.
+template <int R>
 __global__ void __launch_bounds__(256)
 dwconv3x3_bwd_weight_s1_flat_v8_k(const bf16_t* __restrict__ dy, const bf16_t* __restrict__ x, unsigned B, unsigned H, unsigned W, unsigned C,
                                   unsigned lanes, float* __restrict__ ws) {
@@ -826,16 +827,16 @@ dwconv3x3_bwd_weight_s1_flat_v8_k(const bf16_t* __restrict__ dy, const bf16_t* _
   const unsigned tid = blockIdx.x * 256u + threadIdx.x;
   if (tid >= C8 * lanes) return;
   const unsigned c8 = tid % C8, lane = tid / C8, c0 = c8 * 8;
-  const unsigned ngrp = B * H * XG;
+  const unsigned YG = (H + R - 1) / R, ngrp = B * YG * XG;
   float acc[8][9];
 #pragma unroll
   for (int j = 0; j < 8; ++j)
 #pragma unroll
     for (int t = 0; t < 9; ++t) acc[j][t] = 0.f;
   for (unsigned g = lane; g < ngrp; g += lanes) {
-    const unsigned x0 = (g % XG) * 4, t = g / XG, y0 = t % H, b = t / H;
-    cv_b8 gvb[4], xv[3][6];
-    bool rv[3], cvd[6], gok[4];
+    const unsigned x0 = (g % XG) * 4, t = g / XG, y0 = (t % YG) * R, b = t / YG;
+    cv_b8 gvb[R][4], xv[R + 2][6];
+    bool rv[R + 2], cvd[6], gok[R][4];
     unsigned coff[6];
 #pragma unroll
     for (int col = 0; col < 6; ++col) {
@@ -844,25 +845,31 @@ dwconv3x3_bwd_weight_s1_flat_v8_k(const bf16_t* __restrict__ dy, const bf16_t* _
       coff[col] = (unsigned)(ix < 0 ? 0 : (ix >= (int)W ? (int)W - 1 : ix)) * C;
     }
 #pragma unroll
-    for (int o = 0; o < 4; ++o) {
-      gok[o] = x0 + o < W;
-      gvb[o] = *reinterpret_cast<const cv_b8*>(dy + (((b * H + y0) * W) * C + c0 + coff[o + 1]));
+    for (int oy = 0; oy < R; ++oy) {
+      const unsigned yy = y0 + oy < H ? y0 + oy : H - 1;
+#pragma unroll
+      for (int o = 0; o < 4; ++o) {
+        gok[oy][o] = y0 + oy < H && x0 + o < W;
+        gvb[oy][o] = *reinterpret_cast<const cv_b8*>(dy + (((b * H + yy) * W) * C + c0 + coff[o + 1]));
+      }
     }
 #pragma unroll
-    for (int r = 0; r < 3; ++r) {
+    for (int r = 0; r < R + 2; ++r) {
       const int iy = (int)y0 + r - 1;
       rv[r] = iy >= 0 && iy < (int)H;
       const unsigned rowoff = ((b * H + (unsigned)(iy < 0 ? 0 : (iy >= (int)H ? (int)H - 1 : iy))) * W) * C + c0;
 #pragma unroll
       for (int col = 0; col < 6; ++col) xv[r][col] = *reinterpret_cast<const cv_b8*>(x + (rowoff + coff[col]));
     }
-    float gv[4][8];
+    float gv[R][4][8];
 #pragma unroll
-    for (int o = 0; o < 4; ++o)
+    for (int oy = 0; oy < R; ++oy)
 #pragma unroll
-      for (int j = 0; j < 8; ++j) gv[o][j] = gok[o] ? (float)gvb[o][j] : 0.f;
+      for (int o = 0; o < 4; ++o)
 #pragma unroll
-    for (int r = 0; r < 3; ++r) {
+        for (int j = 0; j < 8; ++j) gv[oy][o][j] = gok[oy][o] ? (float)gvb[oy][o][j] : 0.f;
+#pragma unroll
+    for (int r = 0; r < R + 2; ++r) {
 #pragma unroll
       for (int col = 0; col < 6; ++col) {
         const bool ok = rv[r] && cvd[col];
@@ -870,11 +877,16 @@ dwconv3x3_bwd_weight_s1_flat_v8_k(const bf16_t* __restrict__ dy, const bf16_t* _
 #pragma unroll
         for (int j = 0; j < 8; ++j) xf[j] = ok ? (float)xv[r][col][j] : 0.f;
 #pragma unroll
-        for (int o = 0; o < 4; ++o) {
-          const int kx = col - o;
-          if (kx < 0 || kx > 2) continue;
+        for (int oy = 0; oy < R; ++oy) {
+          const int ky = r - oy;
+          if (ky < 0 || ky > 2) continue;
 #pragma unroll
-          for (int j = 0; j < 8; ++j) acc[j][r * 3 + kx] = fmaf(gv[o][j], xf[j], acc[j][r * 3 + kx]);
+          for (int o = 0; o < 4; ++o) {
+            const int kx = col - o;
+            if (kx < 0 || kx > 2) continue;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) acc[j][ky * 3 + kx] = fmaf(gv[oy][o][j], xf[j], acc[j][ky * 3 + kx]);
+          }
         }
       }
     }
@@ -917,7 +929,10 @@ static bool dw_v8_ok(int C, int dtype, const void* a, const void* b, const void*
 }
 
 static const bool g_dw_flat = !(getenv("MMRCA_DW_WG_FLAT") && atoi(getenv("MMRCA_DW_WG_FLAT")) == 0);
-static const int g_dw_flat_threads = getenv("MMRCA_DW_WG_FLAT_THREADS") ? atoi(getenv("MMRCA_DW_WG_FLAT_THREADS")) : 196608;
+static const int g_dw_flat_rows = getenv("MMRCA_DW_WG_FLAT_ROWS") ? atoi(getenv("MMRCA_DW_WG_FLAT_ROWS")) : 2;
+// threads of the streaming weight gradient = what is resident at once: the two-row form needs > 128 registers (one wave per SIMD:
+// 256 CUs x 4 x 64 lanes), the one-row form fits three
+static const int g_dw_flat_threads = getenv("MMRCA_DW_WG_FLAT_THREADS") ? atoi(getenv("MMRCA_DW_WG_FLAT_THREADS")) : (g_dw_flat_rows == 2 ? 65536 : 196608);
 static const int g_dw_blocks_ws = getenv("MMRCA_DW_WG_BLOCKS_WS") ? atoi(getenv("MMRCA_DW_WG_BLOCKS_WS")) : 768;
 static const int g_dw_blocks = getenv("MMRCA_DW_WG_BLOCKS") ? atoi(getenv("MMRCA_DW_WG_BLOCKS")) : 768;
 static const bool g_dw_strip2 = !(getenv("MMRCA_DW_STRIP2") && atoi(getenv("MMRCA_DW_STRIP2")) == 0);
@@ -1009,11 +1024,16 @@ extern "C" int mmrca_dwconv3x3_bwd_ws(const void* dy, const void* x, const void*
       // streaming form: lanes = as many pixel lanes as threads fit on the chip at three waves per SIMD, bounded by the workspace
       const int64_t C8 = C / 8;
       int64_t lanes = g_dw_flat ? (int64_t)g_dw_flat_threads / C8 : 0;
-      if (lanes > ngrp) lanes = ngrp;
+      const int64_t ngrp_f = g_dw_flat_rows == 2 ? (int64_t)B * ((H + 1) / 2) * ((W + 3) / 4) : ngrp;
+      if (lanes > ngrp_f) lanes = ngrp_f;
       if (ws && lanes * C8 * 72 * 4 > ws_bytes) lanes = ws_bytes / (C8 * 72 * 4);
       if (ws && (((uintptr_t)ws) & 15) == 0 && lanes >= 64) {
-        hipLaunchKernelGGL(dwconv3x3_bwd_weight_s1_flat_v8_k, dim3(blocks_for(lanes * C8, 256)), dim3(256), 0, st, (const bf16_t*)dy,
-                           (const bf16_t*)x, (unsigned)B, (unsigned)H, (unsigned)W, (unsigned)C, (unsigned)lanes, (float*)ws);
+        if (g_dw_flat_rows == 2)
+          hipLaunchKernelGGL(dwconv3x3_bwd_weight_s1_flat_v8_k<2>, dim3(blocks_for(lanes * C8, 256)), dim3(256), 0, st, (const bf16_t*)dy,
+                             (const bf16_t*)x, (unsigned)B, (unsigned)H, (unsigned)W, (unsigned)C, (unsigned)lanes, (float*)ws);
+        else
+          hipLaunchKernelGGL(dwconv3x3_bwd_weight_s1_flat_v8_k<1>, dim3(blocks_for(lanes * C8, 256)), dim3(256), 0, st, (const bf16_t*)dy,
+                             (const bf16_t*)x, (unsigned)B, (unsigned)H, (unsigned)W, (unsigned)C, (unsigned)lanes, (float*)ws);
         hipLaunchKernelGGL(dw_wg_reduce_k, dim3((unsigned)((C * 9 + 63) / 64), 8), dim3(256), 0, st, (const float*)ws, dw, (int)lanes, C * 9,
                            (int64_t)C * 9);
       } else if (use_ws) {
@@ -1186,12 +1206,12 @@ col_moment2_v8_k(const bf16_t* __restrict__ x, float* __restrict__ s1, float* __
 #pragma unroll
     for (int j = 0; j < 8; ++j) m[j] = bn_trimmed(m[j], mlo[j], mhi[j]);
     int64_t r = r0 + rl;
-    for (; r + 96 < r1; r += 128) {                    // four rows in flight per thread (one load per iteration ran at 2.6 TB/s)
-      cm_b8 v[4];
+    for (; r + 224 < r1; r += 256) {                   // eight rows in flight per thread (one load per iteration ran at 2.6 TB/s)
+      cm_b8 v[8];
 #pragma unroll
-      for (int u = 0; u < 4; ++u) v[u] = *reinterpret_cast<const cm_b8*>(x + (r + 32 * u) * ld + c0);
+      for (int u = 0; u < 8; ++u) v[u] = *reinterpret_cast<const cm_b8*>(x + (r + 32 * u) * ld + c0);
 #pragma unroll
-      for (int u = 0; u < 4; ++u)
+      for (int u = 0; u < 8; ++u)
 #pragma unroll
         for (int j = 0; j < 8; ++j) { const float d = (float)v[u][j] - m[j]; acc[0][j] += d; acc[1][j] = fmaf(d, d, acc[1][j]); }
     }
@@ -1241,15 +1261,15 @@ bn_act_bwd_reduce_v8_k(const bf16_t* __restrict__ dy, const bf16_t* __restrict__
 #pragma unroll
     for (int j = 0; j < 8; ++j) { m[j] = mean[c0 + j]; rs[j] = rstd[c0 + j]; g[j] = (float)gamma[c0 + j]; b[j] = (float)beta[c0 + j]; }
     int64_t r = r0 + rl;
-    for (; r + 96 < r1; r += 128) {                    // four rows of both operands in flight per thread
-      cm_b8 xv[4], dv[4];
+    for (; r + 224 < r1; r += 256) {                   // eight rows of both operands in flight per thread
+      cm_b8 xv[8], dv[8];
 #pragma unroll
-      for (int u = 0; u < 4; ++u) {
+      for (int u = 0; u < 8; ++u) {
         xv[u] = *reinterpret_cast<const cm_b8*>(x + (r + 32 * u) * C + c0);
         dv[u] = *reinterpret_cast<const cm_b8*>(dy + (r + 32 * u) * C + c0);
       }
 #pragma unroll
-      for (int u = 0; u < 4; ++u)
+      for (int u = 0; u < 8; ++u)
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
           const float xh = ((float)xv[u][j] - m[j]) * rs[j];
@@ -1629,7 +1649,21 @@ se_scale_bwd_v8_k(const bf16_t* __restrict__ dy, const bf16_t* __restrict__ x, c
   for (int j = 0; j < 8; ++j) acc[j] = 0.f;
   if (c0 < C) {
     const pl_b8 s8 = *reinterpret_cast<const pl_b8*>(s + (int64_t)b * C + c0);
-    for (int p = rl; p < HW; p += 32) {
+    int p = rl;
+    for (; p + 96 < HW; p += 128) {                      // four rows of both operands in flight per thread
+      const int64_t i0 = ((int64_t)b * HW + p) * C + c0;
+      pl_b8 g[4], xv[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) { g[u] = *reinterpret_cast<const pl_b8*>(dy + i0 + (int64_t)32 * u * C); xv[u] = *reinterpret_cast<const pl_b8*>(x + i0 + (int64_t)32 * u * C); }
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        pl_b8 o;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) { acc[j] = fmaf((float)g[u][j], (float)xv[u][j], acc[j]); o[j] = (bf16_t)((float)g[u][j] * (float)s8[j]); }
+        if (dx) *reinterpret_cast<pl_b8*>(dx + i0 + (int64_t)32 * u * C) = o;
+      }
+    }
+    for (; p < HW; p += 32) {
       const int64_t i = ((int64_t)b * HW + p) * C + c0;
       const pl_b8 g = *reinterpret_cast<const pl_b8*>(dy + i), xv = *reinterpret_cast<const pl_b8*>(x + i);
       pl_b8 o;
