@@ -300,6 +300,7 @@ def main():
 
     from garbage_classification_rca_amd import lib as L
     from garbage_classification_rca_amd import distributed as D
+    from garbage_classification_rca_amd import engine as ENG
     from garbage_classification_rca_amd.multimodal_model import MM_RCA
     from garbage_classification_rca_amd.optim import FlatSGD
     from garbage_classification_rca_amd.procedural import synth_captions
@@ -546,7 +547,11 @@ def main():
                        "optimizer": "sgd lr=1e-3 wd=1e-2", "random_init": True, "caption_rows_processed": round(live, 3),
                        "dead_row_elimination": {"class_token_tail": bool(E_CLS_TAIL), "packed_captions": bool(PACK_TEXT),
                                                 "note": "identical logits and gradients; MMRCA_CLS_TAIL=0 MMRCA_PACK_TEXT=0 runs every row"}, "final_loss": round(final_loss, 4),
-                       "host_enqueue_ms_per_step": round(host_enqueue / args.steps * 1e3, 2)},
+                       "host_enqueue_ms_per_step": round(host_enqueue / args.steps * 1e3, 2),
+                       **({"x3_backward_passes": {"weight_gradient": ENG.X3_WGRAD_PASSES, "input_gradient": ENG.X3_DGRAD_PASSES,
+                                                  "note": "3 / 3 = every product with all three plane pairs (default: gradients 3e-5 from float64); fewer "
+                                                          "= opt-in cheaper backward (MMRCA_X3_*_PASSES), forward logits unchanged, gradients at 5e-3 .. 1e-2"}}
+                          if args.dtype == "bf16x3" else {})},
             "roofline": {"bound": "mfma", "achieved": round(achieved, 2), "peak": gemm_peak, "unit": "TFLOP/s",
                          "frac": round(achieved / gemm_peak, 4), "traffic": traffic if args.dtype == "bf16" else None,
                          "traffic_unit": "bytes per GEMM KERNEL launch (mean; a call that AUTO splits into whole persistent rounds + a 128x128 tail is two "
