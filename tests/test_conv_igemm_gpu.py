@@ -128,3 +128,50 @@ def test_weight_gradient(B, H, W, Cin, Cout):
     dw = torch.full((Cout, 9 * Cin), 0.5, device="cuda")                    # accumulates: += on top of what is there
     L.conv3x3_wgrad(rows(dz).to(BF).cuda(), rows(x).to(BF).cuda(), dw, B, H, W, Cin, Cout, L.BF16)
     assert rel(dw.cpu() - 0.5, ref) < 2e-5
+
+
+@pytest.mark.parametrize("H,Cin,Cout", [(240, 32, 32), (120, 64, 256)])
+def test_full_size_layers_agree_with_the_patch_matrix_path(H, Cin, Cout):
+    """BASELINE configs[2] sizes (B = 128, EfficientNetV2-L stage 1 / stage 2: 7.4 M / 1.8 M pixels): the implicit-GEMM forward,
+    weight gradient and input gradient against im2row + mmrca_gemm (+ col2im) on the same bf16 operands -- two bf16 paths, so the
+    bound is a few bf16 roundings; what it guards is the index arithmetic at full size (pixel x channel offsets past 2^31 bytes)."""
+    B = 128
+    W = H
+    P = B * H * W
+    g = torch.Generator(device="cuda").manual_seed(H)
+    x = torch.randn(P, Cin, device="cuda", generator=g).to(BF)
+    w = (torch.randn(Cout, Cin, 3, 3, device="cuda", generator=g) * (2.0 / (9 * Cin)) ** 0.5).to(BF)
+    wt = tap_major(w)
+    K = 9 * Cin
+    col = torch.empty(P, K, device="cuda", dtype=BF)
+    L.im2row3x3_tap(x, col, B, H, W, Cin, 1, K, L.BF16)
+    z_ref = torch.empty(P, Cout, device="cuda", dtype=BF)
+    L.gemm(col, wt, z_ref, M=P, N=Cout, K=K, lda=K, ldb=K, ldc=Cout, dtype=L.BF16)
+    z = torch.empty(P, Cout, device="cuda", dtype=BF)
+    ns = L.conv3x3_stat_slots(B, H, W)
+    parts = (torch.empty(ns, Cout, device="cuda"), torch.empty(ns, Cout, device="cuda"), torch.empty(ns, device="cuda"))
+    L.conv3x3_fwd(x, wt, z, B, H, W, Cin, Cout, L.BF16, parts)
+    assert rel(z[-4096:], z_ref[-4096:]) < 1.5e-2 and rel(z[:4096], z_ref[:4096]) < 1.5e-2
+    assert float((z.float() - z_ref.float()).abs().max()) / float(z_ref.float().abs().max()) < 1.5e-2
+    mean, rstd = torch.empty(Cout, device="cuda"), torch.empty(Cout, device="cuda")
+    L.conv_bn_finish(parts, B, H, W, mean, rstd, None, None, Cout, 1e-3, 0.0)
+    assert rel(mean, z.float().mean(0)) < 1e-4
+    # weight gradient (fp32 accumulation in both paths)
+    dz = torch.randn(P, Cout, device="cuda", generator=g).to(BF)
+    dw = torch.zeros(Cout, K, device="cuda")
+    L.conv3x3_wgrad(dz, x, dw, B, H, W, Cin, Cout, L.BF16)
+    dw_ref = torch.zeros(Cout, K, device="cuda")
+    Pk = (P + 63) // 64 * 64
+    dzp = torch.zeros(Pk, Cout, device="cuda", dtype=BF); dzp[:P] = dz
+    colp = torch.zeros(Pk, K, device="cuda", dtype=BF); colp[:P] = col
+    L.gemm(dzp, colp, dw_ref, M=Cout, N=K, K=Pk, lda=Cout, ldb=K, ldc=K, a_layout=L.KROW, b_layout=L.KROW, accum=True, dtype=L.BF16)
+    assert rel(dw, dw_ref) < 2e-3
+    del colp, dzp
+    # input gradient: the forward kernel on dz with flipped weights vs GEMM + col2im
+    wflip = w.float().view(Cout, Cin, 9).flip(2).permute(1, 2, 0).reshape(Cin, 9 * Cout).contiguous().to(BF)
+    dx = torch.empty(P, Cin, device="cuda", dtype=BF)
+    L.conv3x3_fwd(dz, wflip, dx, B, H, W, Cout, Cin, L.BF16)
+    L.gemm(dz, wt, col, M=P, N=K, K=Cout, lda=Cout, ldb=K, ldc=K, a_layout=L.ROWK, b_layout=L.KROW, dtype=L.BF16)
+    dx_ref = torch.empty(P, Cin, device="cuda", dtype=BF)
+    L.col2im3x3_tap(col, dx_ref, B, H, W, Cin, 1, K, L.BF16)
+    assert float((dx.float() - dx_ref.float()).abs().max()) / float(dx_ref.float().abs().max()) < 3e-2     # (col2im sums nine bf16-rounded terms)
