@@ -123,13 +123,13 @@ def parity_check(model, ids, mask, images, n=8):
         ref = orc(i_h, m_h, x_h, eval=True)
     rel = lambda a: float(((a.float().cpu() - ref).abs().max() / ref.abs().max()).item())
     pack = make_text_pack(m_h.numpy(), ids.device)
-    own = "bf16x3" if eng.x3 else ("bf16" if eng.dtype == torch.bfloat16 else "fp32")
+    own = "bf16x3f" if eng.x3f else ("bf16x3" if eng.x3 else ("bf16" if eng.dtype == torch.bfloat16 else "fp32"))
     eng.refresh_working_copy(force=True)
     out = {own + "_logits_rel": round(rel(eng.forward(ids[:n], mask[:n], images[:n], save=False, text_pack=pack)), 8), "samples": n,
            "benchmarked_mode": own,
            "reference": "oracle (CPU fp32 restatement pinned by the reference's goldens), same weights, eval mode"}
     for name, dt in (("bf16", torch.bfloat16), ("bf16x3", "bf16x3"), ("fp32", torch.float32)):
-        if name == own:
+        if name == own or (name == "bf16x3" and own == "bf16x3f"):      # (bf16x3f's forward IS the bf16x3 forward)
             continue
         e2 = MMRCAEngine(eng.ts.name, img_name, eng.n_classes, eng.reverse, eng.mode, dt, eng.device)
         e2.load_arrays(sd)
@@ -284,7 +284,7 @@ def main():
     ap.add_argument("--batch", type=int, default=256, help="per-GPU batch (BASELINE config: 256)")
     ap.add_argument("--seq_len", type=int, default=64)
     ap.add_argument("--no_cpu_baseline", action="store_true")
-    ap.add_argument("--dtype", default="bf16", choices=("bf16", "fp32", "bf16x3"),
+    ap.add_argument("--dtype", default="bf16", choices=("bf16", "fp32", "bf16x3", "bf16x3f"),
                     help="bf16 (the benchmarked configuration) | bf16x3: the fast <= 1e-3 mode -- fp32 storage / residual stream / LayerNorm / "
                          "attention, every nn.Linear as a three-pass split-bf16 product on the bf16 matrix cores | fp32: every GEMM on the fp32 matrix cores")
     ap.add_argument("--frozen", action="store_true", help="time the frozen-backbone phase instead (reported separately)")
@@ -319,7 +319,7 @@ def main():
     import io
     with contextlib.redirect_stdout(io.StringIO()):
         model = MM_RCA(4, 0.6, 0.0, 0.7, 256, args.text_model, B, True, False, args.cross_attention_only,
-                       image_model_name=args.image_model, dtype={"bf16": torch.bfloat16, "fp32": torch.float32, "bf16x3": "bf16x3"}[args.dtype], device=dev, init_seed=0,
+                       image_model_name=args.image_model, dtype={"bf16": torch.bfloat16, "fp32": torch.float32}.get(args.dtype, args.dtype), device=dev, init_seed=0,
                        image_size=args.image_size)
     model.train()
     if not args.frozen:
@@ -470,7 +470,7 @@ def main():
                 print(f"[bench] gemm a{kind[0]}b{kind[1]}acc{kind[2]} M={shp[0]} N={shp[1]} K={shp[2]} act={shp[3]}: {v[2] // replay}/step, "
                       f"{v[1] / v[2] * 1e3:.0f} us, {v[0] / (v[1] * 1e-3) / 1e12:.0f} TF, {v[1] / replay:.2f} ms/step", file=sys.stderr, flush=True)
         value = B * world * args.steps / elapsed
-        gemm_peak = PEAK_BF16_TFLOPS if args.dtype in ("bf16", "bf16x3") else PEAK_F32_TFLOPS
+        gemm_peak = PEAK_BF16_TFLOPS if args.dtype in ("bf16", "bf16x3", "bf16x3f") else PEAK_F32_TFLOPS
         fwd_gflop = FWD_GFLOP_PER_SAMPLE if (args.text_model, args.image_model, S) == ("distilbert", "transformer_B16", 64) else (
             145.5 if (args.text_model, args.image_model, S) == ("bert", "transformer_L16", 128) else float("nan"))
         train_flop_per_sample = (fwd_gflop * (1.0 if args.frozen else 3.0)) * 1e9
@@ -536,7 +536,8 @@ def main():
             "metric": "train samples/sec (image+text pairs), MM-RCA ViT-B16+DistilBERT", "value": round(value, 2),
             "unit": "samples/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(elapsed / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None, "dtype": {"bf16": "bf16", "fp32": "f32", "bf16x3": "bf16x3 (fp32 values as two bf16 planes, three MFMA passes per product)"}[args.dtype], "data": "synthetic",
+            "vs_baseline": None, "dtype": {"bf16": "bf16", "fp32": "f32", "bf16x3": "bf16x3 (fp32 values as two bf16 planes, three MFMA passes per product)",
+                                                "bf16x3f": "bf16x3f (forward: fp32 values as two bf16 planes, three MFMA passes per product; backward: bf16)"}[args.dtype], "data": "synthetic",
             "config": {"workload": "MM_RCA --reverse" + (" --cross_attention_only " if args.cross_attention_only else " ")
                        + {"transformer_B16": "ViT-B/16", "transformer_L16": "ViT-L/16", "eff_v2_medium": "EfficientNetV2-M", "eff_v2_large": "EfficientNetV2-L",
                           "shuffle_net": "ShuffleNetV2-x2.0"}[args.image_model] + " + "
@@ -561,7 +562,7 @@ def main():
                                     "forward / input gradient, gemm_mfma256_k + splitk_reduce256_k (256x256 split-K) for the weight gradient; "
                                     "every nn.Linear fwd/dgrad/wgrad") if args.dtype == "bf16" else
                                    ("the same bf16 MFMA kernels in their bf16x3 form (gemm_x3.hip): three plane-pair passes per product into one fp32 "
-                                    "accumulator; achieved / flops count the EXECUTED bf16 matrix-core work = 3 x 2MNK") if args.dtype == "bf16x3" else
+                                    "accumulator; achieved / flops count the EXECUTED bf16 matrix-core work = 3 x 2MNK") if args.dtype in ("bf16x3", "bf16x3f") else
                                    "fp32 32x32x2 MFMA GEMM gemm_gen_k (128x64 tiles, three-level fp32 summation); every nn.Linear fwd/dgrad/wgrad",
                          "launches_per_step": len(prof) // replay, "gemm_ms_per_step": round(ms / replay, 3),
                          "measured_in": f"single-stream replay of {replay} steps after the timed region ({round(serial_ms, 2)} ms/step serialized)",

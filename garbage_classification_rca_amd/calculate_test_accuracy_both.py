@@ -114,7 +114,7 @@ def main(argv=None):
     image_model = args.image_model if (args.image_model in S.VISION_SPECS or args.image_model in CONV_MODELS) else "EffNetv2-Medium"
     model = MM_RCA(_num_classes, args.model_dropout, args.image_text_dropout, args.image_prob_dropout, args.num_neurons_FC,
                    args.text_model, _batch_size, args.reverse, args.features_only, args.cross_attention_only,
-                   image_model_name=image_model, dtype={"bf16": torch.bfloat16, "fp32": torch.float32, "bf16x3": "bf16x3"}[args.dtype], device=device,
+                   image_model_name=image_model, dtype={"bf16": torch.bfloat16, "fp32": torch.float32}.get(args.dtype, args.dtype), device=device,
                    image_size=args.image_size)
     model.load_state_dict(torch.load(args.model_path, map_location=device))
     model.eval()

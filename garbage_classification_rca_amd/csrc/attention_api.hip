@@ -7,7 +7,7 @@ int mmrca_mha_bwd_ref(const void*, const int32_t*, const void*, const void*, con
 bool mmrca_mha_mfma_ok(int S, int dh, int dtype);
 // fp32 on the fp32 matrix cores (attention_f32.hip): what the fp32 / bf16x3 modes run for head dim 64, S <= 208
 bool mmrca_mha_f32m_ok(int S, int dh, int dtype);
-int mmrca_mha_fwd_f32m(const void*, const int32_t*, void*, float*, int, int, int, int, float, float, uint64_t, const int32_t*, hipStream_t, void*, void*);
+int mmrca_mha_fwd_f32m(const void*, const int32_t*, void*, float*, int, int, int, int, float, float, uint64_t, const int32_t*, hipStream_t, void*, void*, const void*);
 int mmrca_mha_bwd_f32m(const void*, const int32_t*, const void*, const void*, const float*, void*, int, int, int, int, float, float, uint64_t, const int32_t*, hipStream_t);
 int mmrca_mha_fwd_mfma(const void*, const int32_t*, void*, float*, int, int, int, int, float, float, uint64_t, const int32_t*, hipStream_t);
 int mmrca_mha_bwd_mfma(const void*, const int32_t*, const void*, const void*, const float*, void*, int, int, int, int, float, float, uint64_t, const int32_t*, hipStream_t);
@@ -22,7 +22,7 @@ extern "C" int mmrca_mha_fwd(const void* qkv, const int32_t* key_mask, void* out
   if (impl == MMRCA_GEMM_MFMA && !ok && !mmrca_mha_f32m_ok(S, dh, dtype)) return mmrca_fail(-3, "mha_fwd: S=%d dh=%d dtype=%d does not qualify for the MFMA kernel", S, dh, dtype);
   if (ok && impl != MMRCA_GEMM_REF) return mmrca_mha_fwd_mfma(qkv, key_mask, out, lse, B, H, S, dh, scale, drop_p, drop_seed, cu_seqlens, (hipStream_t)stream);
   if (impl != MMRCA_GEMM_REF && mmrca_mha_f32m_ok(S, dh, dtype))
-    return mmrca_mha_fwd_f32m(qkv, key_mask, out, lse, B, H, S, dh, scale, drop_p, drop_seed, cu_seqlens, (hipStream_t)stream, nullptr, nullptr);
+    return mmrca_mha_fwd_f32m(qkv, key_mask, out, lse, B, H, S, dh, scale, drop_p, drop_seed, cu_seqlens, (hipStream_t)stream, nullptr, nullptr, nullptr);
   return mmrca_mha_fwd_ref(qkv, key_mask, out, lse, B, H, S, dh, scale, drop_p, drop_seed, cu_seqlens, dtype, (hipStream_t)stream);
 }
 
@@ -35,7 +35,19 @@ extern "C" int mmrca_mha_fwd_planes(const void* qkv, const int32_t* key_mask, vo
   MMRCA_REQUIRE(qkv && out && out_hi && out_lo && lse, "mha_fwd_planes: null pointer");
   MMRCA_REQUIRE(drop_p >= 0.f && drop_p < 1.f, "mha_fwd_planes: dropout p must be in [0,1)");
   MMRCA_REQUIRE(B > 0 && H > 0 && mmrca_mha_f32m_ok(S, dh, MMRCA_F32), "mha_fwd_planes: needs head dim 64 and 1 <= S <= 208 (got S=%d dh=%d)", S, dh);
-  return mmrca_mha_fwd_f32m(qkv, key_mask, out, lse, B, H, S, dh, scale, drop_p, drop_seed, cu_seqlens, (hipStream_t)stream, out_hi, out_lo);
+  return mmrca_mha_fwd_f32m(qkv, key_mask, out, lse, B, H, S, dh, scale, drop_p, drop_seed, cu_seqlens, (hipStream_t)stream, out_hi, out_lo, nullptr);
+}
+
+// The same with q|k|v ALSO given as two bf16 planes (qkv_hi + qkv_lo = the fp32 projection to 2^-17: what mmrca_gemm_x3 writes
+// with C_lo != NULL): the bf16x3f mode, whose bf16 backward reads the hi plane as its bf16 q|k|v -- no fp32 copy, no cast pass.
+extern "C" int mmrca_mha_fwd_planes_in(const void* qkv_hi, const void* qkv_lo, const int32_t* key_mask, void* out, void* out_hi,
+                                       void* out_lo, float* lse, int B, int H, int S, int dh, float scale, float drop_p,
+                                       uint64_t drop_seed, const int32_t* cu_seqlens, void* stream) {
+  MMRCA_REQUIRE(qkv_hi && qkv_lo && out_hi && out_lo && lse, "mha_fwd_planes_in: null pointer");      // out (fp32) is optional
+  MMRCA_REQUIRE(drop_p >= 0.f && drop_p < 1.f, "mha_fwd_planes_in: dropout p must be in [0,1)");
+  MMRCA_REQUIRE(B > 0 && H > 0 && mmrca_mha_f32m_ok(S, dh, MMRCA_F32), "mha_fwd_planes_in: needs head dim 64 and 1 <= S <= 208 (got S=%d dh=%d)", S, dh);
+  MMRCA_REQUIRE((((uintptr_t)qkv_lo) & 7) == 0, "mha_fwd_planes_in: planes must be 8-byte aligned");
+  return mmrca_mha_fwd_f32m(qkv_hi, key_mask, out, lse, B, H, S, dh, scale, drop_p, drop_seed, cu_seqlens, (hipStream_t)stream, out_hi, out_lo, qkv_lo);
 }
 
 static int mha_bwd_impl(const void* qkv, const int32_t* key_mask, const void* out, const void* dout, const float* lse,

@@ -35,13 +35,26 @@ __device__ __forceinline__ float xlane_sum(float x) { x += __shfl_xor(x, 16, 64)
 // swizzled image address (in floats) of 16-byte slot `slot` of row `row`
 __device__ __forceinline__ int img(int row, int slot) { return row * 64 + ((slot ^ (row & 15)) << 2); }
 
-// stage `rows` rows of 64 floats (global row stride ld) into a swizzled (or linear) image; rows [rows, rows_pad) are zero-filled
+// four consecutive fp32 values at element offset `off`: from an fp32 array (lo == nullptr), or rebuilt from the two bf16 planes
+// hi + lo of a bf16x3 GEMM's two-plane output (`src` then points at the hi plane; same element offsets)
+__device__ __forceinline__ f4 load4(const float* __restrict__ src, const bf16_t* __restrict__ lo, int64_t off) {
+  if (lo) {
+    typedef __attribute__((ext_vector_type(4))) __bf16 b4;
+    const b4 h = *reinterpret_cast<const b4*>(reinterpret_cast<const bf16_t*>(src) + off), l = *reinterpret_cast<const b4*>(lo + off);
+    return (f4){(float)h[0] + (float)l[0], (float)h[1] + (float)l[1], (float)h[2] + (float)l[2], (float)h[3] + (float)l[3]};
+  }
+  return *reinterpret_cast<const f4*>(src + off);
+}
+
+// stage `rows` rows of 64 floats (global row stride ld, first element at offset off0) into a swizzled (or linear) image; rows
+// [rows, rows_pad) are zero-filled
 template <bool SWZ>
-__device__ __forceinline__ void stage_rows(float* dst, const float* __restrict__ src, int64_t ld, int rows, int rows_pad) {
+__device__ __forceinline__ void stage_rows(float* dst, const float* __restrict__ src, int64_t ld, int rows, int rows_pad,
+                                           const bf16_t* __restrict__ lo = nullptr, int64_t off0 = 0) {
   for (int e = threadIdx.x; e < rows_pad * 16; e += blockDim.x) {
     const int r = e >> 4, s = e & 15;
     f4 v = (f4){0.f, 0.f, 0.f, 0.f};
-    if (r < rows) v = *reinterpret_cast<const f4*>(src + (int64_t)r * ld + s * 4);
+    if (r < rows) v = load4(src, lo, off0 + (int64_t)r * ld + s * 4);
     *reinterpret_cast<f4*>(dst + (SWZ ? img(r, s) : r * 64 + s * 4)) = v;
   }
 }
@@ -57,7 +70,8 @@ template <int NKT, bool DROP>
 __global__ void __launch_bounds__(64 * (NKT < F32A_MAX_WAVES ? NKT : F32A_MAX_WAVES))
 mha_fwd_f32m_k(const float* __restrict__ qkv, const int32_t* __restrict__ key_mask, float* __restrict__ out, float* __restrict__ lse,
                int H, int Smax, float scale, float drop_p, uint64_t drop_seed, const int32_t* __restrict__ cu,
-               bf16_t* __restrict__ out_hi, bf16_t* __restrict__ out_lo) {
+               bf16_t* __restrict__ out_hi, bf16_t* __restrict__ out_lo, const bf16_t* __restrict__ qkv_lo) {
+  // qkv_lo != nullptr: q|k|v arrive as the two bf16 planes a bf16x3 GEMM wrote (`qkv` = hi plane); the fp32 values are rebuilt on load
   extern __shared__ __attribute__((aligned(16))) float sm[];      // K image (swizzled) | V image (linear) | key bias
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
   const int g = lane >> 4, c = lane & 15;
@@ -67,9 +81,9 @@ mha_fwd_f32m_k(const float* __restrict__ qkv, const int32_t* __restrict__ key_ma
   const int nt = (S + 15) >> 4, Sp = nt * 16;
   float* Ks = sm; float* Vs = Ks + NKT * 16 * 64; float* bias = Vs + NKT * 16 * 64;
   const int64_t ld = 3LL * H * F32A_DH, ldo = (int64_t)H * F32A_DH;
-  const float* Q = qkv + (int64_t)row0 * ld + h * F32A_DH;
-  stage_rows<true>(Ks, Q + H * F32A_DH, ld, S, Sp);
-  stage_rows<false>(Vs, Q + 2 * H * F32A_DH, ld, S, Sp);
+  const int64_t q0 = (int64_t)row0 * ld + h * F32A_DH;            // element offset of this head's first query row
+  stage_rows<true>(Ks, qkv, ld, S, Sp, qkv_lo, q0 + H * F32A_DH);
+  stage_rows<false>(Vs, qkv, ld, S, Sp, qkv_lo, q0 + 2 * H * F32A_DH);
   for (int j = threadIdx.x; j < Sp; j += blockDim.x) bias[j] = (j < S && (!key_mask || key_mask[row0 + j] != 0)) ? 0.f : -INFINITY;
   __syncthreads();
   const float c1 = scale * LOG2E;
@@ -79,7 +93,7 @@ mha_fwd_f32m_k(const float* __restrict__ qkv, const int32_t* __restrict__ key_ma
     f4 qf[4];
 #pragma unroll
     for (int j = 0; j < 4; ++j)
-      qf[j] = qi < S ? *reinterpret_cast<const f4*>(Q + (int64_t)qi * ld + 16 * j + 4 * g) : (f4){0.f, 0.f, 0.f, 0.f};
+      qf[j] = qi < S ? load4(qkv, qkv_lo, q0 + (int64_t)qi * ld + 16 * j + 4 * g) : (f4){0.f, 0.f, 0.f, 0.f};
     f4 s[NKT];
     float m = -INFINITY;
 #pragma unroll
@@ -135,9 +149,11 @@ mha_fwd_f32m_k(const float* __restrict__ qkv, const int32_t* __restrict__ key_ma
       }
     }
     if (qi < S) {
-      float* orow = out + ((int64_t)row0 + qi) * ldo + h * F32A_DH + 16 * g;
+      if (out) {           // (nullptr: only the planes are wanted -- bf16x3f, whose backward reads the hi plane)
+        float* orow = out + ((int64_t)row0 + qi) * ldo + h * F32A_DH + 16 * g;
 #pragma unroll
-      for (int r = 0; r < 4; ++r) *reinterpret_cast<f4*>(orow + 4 * r) = (f4){o[0][r] * inv, o[1][r] * inv, o[2][r] * inv, o[3][r] * inv};
+        for (int r = 0; r < 4; ++r) *reinterpret_cast<f4*>(orow + 4 * r) = (f4){o[0][r] * inv, o[1][r] * inv, o[2][r] * inv, o[3][r] * inv};
+      }
       if (out_hi) {        // bf16x3 mode: the context also as two bf16 planes, the operand form of the out-projection GEMM
         typedef __attribute__((ext_vector_type(4))) __bf16 b4;
         const int64_t off = ((int64_t)row0 + qi) * ldo + h * F32A_DH + 16 * g;
@@ -334,7 +350,7 @@ bool mmrca_mha_f32m_ok(int S, int dh, int dtype) {
 static int nkt_for(int S) { return S <= 64 ? 4 : (S <= 128 ? 8 : 13); }
 
 int mmrca_mha_fwd_f32m(const void* qkv, const int32_t* key_mask, void* out, float* lse, int B, int H, int S, int dh, float scale,
-                       float drop_p, uint64_t drop_seed, const int32_t* cu, hipStream_t st, void* out_hi, void* out_lo) {
+                       float drop_p, uint64_t drop_seed, const int32_t* cu, hipStream_t st, void* out_hi, void* out_lo, const void* qkv_lo) {
   MMRCA_REQUIRE(mmrca_mha_f32m_ok(S, dh, MMRCA_F32), "mha_fwd(f32 mfma): S=%d dh=%d unsupported", S, dh);
   MMRCA_REQUIRE((((uintptr_t)qkv | (uintptr_t)out) & 15) == 0, "mha_fwd(f32 mfma): operands must be 16-byte aligned");
   const int nkt = nkt_for(S);
@@ -344,7 +360,7 @@ int mmrca_mha_fwd_f32m(const void* qkv, const int32_t* key_mask, void* out, floa
     (void)hipFuncSetAttribute((const void*)mha_fwd_f32m_k<NKT_, DROP_>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);     \
     hipLaunchKernelGGL((mha_fwd_f32m_k<NKT_, DROP_>), dim3(B * H), dim3(64 * (NKT_ < F32A_MAX_WAVES ? NKT_ : F32A_MAX_WAVES)), lds, st, \
                        (const float*)qkv, key_mask, (float*)out, lse, H, S, scale, drop_p, drop_seed, cu, (bf16_t*)out_hi,         \
-                       (bf16_t*)out_lo);                                                                                           \
+                       (bf16_t*)out_lo, (const bf16_t*)qkv_lo);                                                                    \
   } while (0)
   const bool drop = drop_p > 0.f;
   if (nkt == 4) { if (drop) LF(4, true); else LF(4, false); }

@@ -897,7 +897,8 @@ gemm_mfma_k1s(const bf16_t* __restrict__ A, const bf16_t* __restrict__ B, void* 
               const bf16_t* __restrict__ addend, bf16_t* __restrict__ preact, int64_t M, int64_t N, int64_t K,
               int64_t lda, int64_t ldb, int64_t ldc, int act, int tiles_m, int tiles_n, int64_t ksplit_len, float* __restrict__ colsum,
               const bf16_t* __restrict__ A_lo = nullptr, const bf16_t* __restrict__ B_lo = nullptr, bf16_t* __restrict__ C_lo = nullptr,
-              int nseg = 3, const BnStat bst = BnStat{nullptr, nullptr, nullptr}) {
+              int nseg = 3, const BnStat bst = BnStat{nullptr, nullptr, nullptr}, int pre16 = 0) {
+  // pre16 (X3, MMRCA_ACT_GELU_SAVE_GRAD_BF16): gelu' goes to `preact` as bf16 (what a bf16 backward reads) instead of fp32
   extern __shared__ __attribute__((aligned(16))) char smem[];   // ONE buffer: [A tile 16 KiB | B tile 16 KiB]
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
   const int wr = wave >> 1, wc = wave & 1;
@@ -1011,7 +1012,14 @@ gemm_mfma_k1s(const bf16_t* __restrict__ A, const bf16_t* __restrict__ B, void* 
           } else if (act == MMRCA_ACT_GELU_SAVE_GRAD) {
             float dg[4];
             gelu_and_grad_fast4(v, dg);
-            *reinterpret_cast<f32x4*>(pref + m * ldc + ncol) = (f32x4){dg[0], dg[1], dg[2], dg[3]};
+            if (pre16) {
+              bf16x4 o16;
+#pragma unroll
+              for (int r = 0; r < 4; ++r) o16[r] = (bf16_t)dg[r];
+              *reinterpret_cast<bf16x4*>(preact + m * ldc + ncol) = o16;
+            } else {
+              *reinterpret_cast<f32x4*>(pref + m * ldc + ncol) = (f32x4){dg[0], dg[1], dg[2], dg[3]};
+            }
           } else if (act == MMRCA_ACT_GELU_BWD) {
             const f32x4 h4 = *reinterpret_cast<const f32x4*>(pref + m * ldc + ncol);
 #pragma unroll
@@ -1183,17 +1191,17 @@ static void launch_mfma1s(const void* A, const void* B, void* C, const void* bia
                           int64_t M, int64_t N, int64_t K, int64_t lda, int64_t ldb, int64_t ldc, int act, int tiles_m,
                           int tiles_n, int ksplits, int64_t ksplit_len, float* colsum, hipStream_t st,
                           const void* A_lo = nullptr, const void* B_lo = nullptr, void* C_lo = nullptr, int nseg = 3,
-                          BnStat bst = BnStat{nullptr, nullptr, nullptr}) {
+                          BnStat bst = BnStat{nullptr, nullptr, nullptr}, int pre16 = 0) {
   hipLaunchKernelGGL((gemm_mfma_k1s<AK, BK2, AT, WPE, X3, BNS>), dim3(tiles_m * tiles_n, ksplits), dim3(256), 2 * TILE_BYTES, st,
                      (const bf16_t*)A, (const bf16_t*)B, C, (const bf16_t*)bias, (const bf16_t*)addend, (bf16_t*)preact,
                      M, N, K, lda, ldb, ldc, act, tiles_m, tiles_n, ksplit_len, colsum, (const bf16_t*)A_lo, (const bf16_t*)B_lo,
-                     (bf16_t*)C_lo, nseg, bst);
+                     (bf16_t*)C_lo, nseg, bst, pre16);
 }
 
 // entry used by gemm_x3.hip: the single-stage 128x128 kernel in its bf16x3 form (any epilogue; accumulate mode = fp32 atomics)
 int mmrca_gemm_k1s_x3(const void* A_hi, const void* A_lo, const void* B_hi, const void* B_lo, void* C, void* C_lo, const void* bias,
                       const void* addend, void* preact, float* colsum, int64_t M, int64_t N, int64_t K, int64_t lda, int64_t ldb,
-                      int64_t ldc, int a_layout, int b_layout, int act, int accum, hipStream_t st) {
+                      int64_t ldc, int a_layout, int b_layout, int act, int accum, hipStream_t st, int pre16) {
   const int tiles_m = (int)((M + GBM - 1) / GBM), tiles_n = (int)(N / GBN);
   int ksplits = 1;
   int64_t ksplit_len = K;
@@ -1207,7 +1215,7 @@ int mmrca_gemm_k1s_x3(const void* A_hi, const void* A_lo, const void* B_hi, cons
     ksplits = (int)((ksteps + steps_per - 1) / steps_per);
   }
   const bool ak = a_layout == MMRCA_KROW, bk = b_layout == MMRCA_KROW, at = accum != 0;
-#define L1SX(AK_, BK_, AT_) launch_mfma1s<AK_, BK_, AT_, 4, true>(A_hi, B_hi, C, bias, addend, preact, M, N, K, lda, ldb, ldc, act, tiles_m, tiles_n, ksplits, ksplit_len, colsum, st, A_lo, B_lo, C_lo, A_lo ? (B_lo ? 3 : 2) : 1)
+#define L1SX(AK_, BK_, AT_) launch_mfma1s<AK_, BK_, AT_, 4, true>(A_hi, B_hi, C, bias, addend, preact, M, N, K, lda, ldb, ldc, act, tiles_m, tiles_n, ksplits, ksplit_len, colsum, st, A_lo, B_lo, C_lo, A_lo ? (B_lo ? 3 : 2) : 1, BnStat{nullptr, nullptr, nullptr}, pre16)
   if (!ak && !bk && !at) L1SX(false, false, false);
   else if (!ak && bk && !at) L1SX(false, true, false);
   else if (ak && !bk && !at) L1SX(true, false, false);

@@ -303,7 +303,8 @@ gemm_p256_k(const bf16_t* __restrict__ A, const bf16_t* __restrict__ B, bf16_t* 
             const bf16_t* __restrict__ addend, bf16_t* __restrict__ preact, int64_t M, int64_t N, int64_t K,
             int64_t lda, int64_t ldb, int64_t ldc, int tiles_m, int tiles_n, float* __restrict__ colsum, int skew_ticks, int dbg,
             const bf16_t* __restrict__ A_lo = nullptr, const bf16_t* __restrict__ B_lo = nullptr, bf16_t* __restrict__ C_lo = nullptr,
-            int nseg = 3) {
+            int nseg = 3, int pre16 = 0) {
+  // pre16 (X3 only; MMRCA_ACT_GELU_SAVE_GRAD_BF16): gelu' is stored as bf16 -- the form a bf16 backward reads (bf16x3f mode)
   static_assert(!X3 || (!ADD && ACT != MMRCA_ACT_MUL), "the bf16x3 form has no side-operand epilogue");
   constexpr int act = ACT;
   extern __shared__ __attribute__((aligned(16))) char smem[];     // [2 stages][A0 A1 B0 B1] + 32 KiB epilogue staging
@@ -559,7 +560,10 @@ gemm_p256_k(const bf16_t* __restrict__ A, const bf16_t* __restrict__ B, bf16_t* 
               if constexpr (X3) {
                 // fp32 outputs: 16 bytes per lane (a wave instruction writes four whole 256-byte row segments); the byte
                 // offsets above are those of 2-byte elements
-                if (store_pre) *reinterpret_cast<f32x4*>(reinterpret_cast<char*>(preact) + 2 * (ub + lane_off)) = (f32x4){pf[0], pf[1], pf[2], pf[3]};
+                if (store_pre) {
+                  if (pre16) *reinterpret_cast<bf16x4*>(reinterpret_cast<char*>(preact) + ub + lane_off) = po;
+                  else *reinterpret_cast<f32x4*>(reinterpret_cast<char*>(preact) + 2 * (ub + lane_off)) = (f32x4){pf[0], pf[1], pf[2], pf[3]};
+                }
                 if constexpr (PLANES) {
                   bf16x4 lo;
 #pragma unroll
@@ -597,7 +601,7 @@ static int g_p256_skew = -1;      // x 10 ns between the four start groups (MMRC
 template <bool AK, bool BK2, int ACT, bool ADD, bool X3 = false, bool PLANES = false>
 static void launch_p256(const void* A, const void* B, void* C, const void* bias, const void* addend, void* preact, int64_t M,
                         int64_t N, int64_t K, int64_t lda, int64_t ldb, int64_t ldc, float* colsum, hipStream_t st,
-                        const void* A_lo = nullptr, const void* B_lo = nullptr, void* C_lo = nullptr, int nseg = 3) {
+                        const void* A_lo = nullptr, const void* B_lo = nullptr, void* C_lo = nullptr, int nseg = 3, int pre16 = 0) {
   const int tiles_m = (int)((M + 255) / 256), tiles_n = (int)(N / 256);
   if (g_num_cus == 0) {
     int dev = 0, n = 0;
@@ -616,7 +620,7 @@ static void launch_p256(const void* A, const void* B, void* C, const void* bias,
   hipLaunchKernelGGL((gemm_p256_k<AK, BK2, ACT, ADD, X3, PLANES>), dim3(grid), dim3(512), LDS_P, st, (const bf16_t*)A, (const bf16_t*)B,
                      (bf16_t*)C, (const bf16_t*)bias, (const bf16_t*)addend, (bf16_t*)preact, M, N, K, lda, ldb, ldc, tiles_m,
                      tiles_n, colsum, tiles_m * tiles_n >= 2 * g_num_cus ? g_p256_skew : 0, g_mmrca_dbg, (const bf16_t*)A_lo,
-                     (const bf16_t*)B_lo, (bf16_t*)C_lo, nseg);
+                     (const bf16_t*)B_lo, (bf16_t*)C_lo, nseg, pre16);
 }
 
 int g_mmrca_dbg = 0;
@@ -667,11 +671,11 @@ bool mmrca_gemm256_x3_ok(int64_t M, int64_t N, int64_t K, int a_layout, int act,
 
 int mmrca_gemm256_x3(const void* A_hi, const void* A_lo, const void* B_hi, const void* B_lo, void* C, void* C_lo, const void* bias,
                      void* preact, int64_t M, int64_t N, int64_t K, int64_t lda, int64_t ldb, int64_t ldc, int b_layout, int act,
-                     hipStream_t st) {
+                     hipStream_t st, int pre16) {
   const bool bk = b_layout == MMRCA_KROW;
   MMRCA_REQUIRE(M * lda * 2 < (1ll << 32) && (bk ? K * ldb : N * ldb) * 2 < (1ll << 32) && M * ldc * 4 < (1ll << 32),
                 "gemm_x3(mfma256): operands must be smaller than 4 GiB");
-#define L256X(BK_, ACT_, PL_) launch_p256<false, BK_, ACT_, false, true, PL_>(A_hi, B_hi, C, bias, nullptr, preact, M, N, K, lda, ldb, ldc, nullptr, st, A_lo, B_lo, C_lo, A_lo ? (B_lo ? 3 : 2) : 1)
+#define L256X(BK_, ACT_, PL_) launch_p256<false, BK_, ACT_, false, true, PL_>(A_hi, B_hi, C, bias, nullptr, preact, M, N, K, lda, ldb, ldc, nullptr, st, A_lo, B_lo, C_lo, A_lo ? (B_lo ? 3 : 2) : 1, pre16)
   if (act == MMRCA_ACT_GELU_SAVE_GRAD) {
     if (C_lo) { if (bk) L256X(true, MMRCA_ACT_GELU_SAVE_GRAD, true); else L256X(false, MMRCA_ACT_GELU_SAVE_GRAD, true); }
     else { if (bk) L256X(true, MMRCA_ACT_GELU_SAVE_GRAD, false); else L256X(false, MMRCA_ACT_GELU_SAVE_GRAD, false); }

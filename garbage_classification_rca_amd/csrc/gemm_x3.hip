@@ -16,11 +16,11 @@
 
 int mmrca_gemm_k1s_x3(const void* A_hi, const void* A_lo, const void* B_hi, const void* B_lo, void* C, void* C_lo, const void* bias,
                       const void* addend, void* preact, float* colsum, int64_t M, int64_t N, int64_t K, int64_t lda, int64_t ldb,
-                      int64_t ldc, int a_layout, int b_layout, int act, int accum, hipStream_t st);
+                      int64_t ldc, int a_layout, int b_layout, int act, int accum, hipStream_t st, int pre16);
 bool mmrca_gemm256_x3_ok(int64_t M, int64_t N, int64_t K, int a_layout, int act, bool has_addend, bool has_colsum);
 int mmrca_gemm256_x3(const void* A_hi, const void* A_lo, const void* B_hi, const void* B_lo, void* C, void* C_lo, const void* bias,
                      void* preact, int64_t M, int64_t N, int64_t K, int64_t lda, int64_t ldb, int64_t ldc, int b_layout, int act,
-                     hipStream_t st);
+                     hipStream_t st, int pre16);
 
 static bool al16(const void* p) { return (((uintptr_t)p) & 15) == 0; }
 static const int g_x3_tail_pct = getenv("MMRCA_AUTO256_TAIL_PCT") ? atoi(getenv("MMRCA_AUTO256_TAIL_PCT")) : 60;
@@ -35,6 +35,9 @@ extern "C" int mmrca_gemm_x3(const void* A_hi, const void* A_lo, const void* B_h
   MMRCA_REQUIRE(A_hi && B_hi && C && (A_lo || !B_lo), "gemm_x3: null operand (a B lo plane needs the A lo plane)");
   MMRCA_REQUIRE(M > 0 && N > 0 && K > 0, "gemm_x3: bad shape M=%lld N=%lld K=%lld", (long long)M, (long long)N, (long long)K);
   MMRCA_REQUIRE((a_layout == MMRCA_ROWK || a_layout == MMRCA_KROW) && (b_layout == MMRCA_ROWK || b_layout == MMRCA_KROW), "gemm_x3: bad layout");
+  // MMRCA_ACT_GELU_SAVE_GRAD_BF16: MMRCA_ACT_GELU_SAVE_GRAD with gelu' stored as bf16 (the operand of a bf16 backward: bf16x3f mode)
+  const int pre16 = act == MMRCA_ACT_GELU_SAVE_GRAD_BF16;
+  if (pre16) act = MMRCA_ACT_GELU_SAVE_GRAD;
   MMRCA_REQUIRE(act >= MMRCA_ACT_NONE && act <= MMRCA_ACT_MUL, "gemm_x3: bad activation");
   MMRCA_REQUIRE(act < MMRCA_ACT_GELU_BWD || preact, "gemm_x3: this activation needs the `preact` buffer");
   MMRCA_REQUIRE(lda >= (a_layout == MMRCA_ROWK ? K : M) && ldb >= (b_layout == MMRCA_ROWK ? K : N) && ldc >= N, "gemm_x3: leading dimension too small");
@@ -52,7 +55,7 @@ extern "C" int mmrca_gemm_x3(const void* A_hi, const void* A_lo, const void* B_h
     // the persistent kernel streams whole 256-row tiles of A: an explicit request must come with whole tiles (AUTO checks the same)
     MMRCA_REQUIRE(ok256 && M % 256 == 0, "gemm_x3: shape M=%lld N=%lld K=%lld / epilogue does not qualify for the 256x256 kernel (needs M %% 256 == 0, "
                   "N %% 256 == 0, no side operand)", (long long)M, (long long)N, (long long)K);
-    return mmrca_gemm256_x3(A_hi, A_lo, B_hi, B_lo, C, C_lo, bias, preact, M, N, K, lda, ldb, ldc, b_layout, act, st);
+    return mmrca_gemm256_x3(A_hi, A_lo, B_hi, B_lo, C, C_lo, bias, preact, M, N, K, lda, ldb, ldc, b_layout, act, st, pre16);
   }
   if (impl == MMRCA_GEMM_AUTO && ok256 && M % 256 == 0 && (M / 256) * (N / 256) >= 256) {
     // whole rounds of one 256x256 tile per CU on the persistent kernel, a 25-60 % partial round on the 128x128 kernel (gemm.hip AUTO)
@@ -65,14 +68,14 @@ extern "C" int mmrca_gemm_x3(const void* A_hi, const void* A_lo, const void* B_h
     const int64_t m_split = rounds * ncu / tn;
     if (rounds >= 1 && rem * 100 >= 25 * (int64_t)ncu && rem * 100 < (int64_t)g_x3_tail_pct * ncu && m_split >= 1 && m_split < tm) {
       const int64_t M1 = m_split * 256;
-      if (int rc = mmrca_gemm256_x3(A_hi, A_lo, B_hi, B_lo, C, C_lo, bias, preact, M1, N, K, lda, ldb, ldc, b_layout, act, st)) return rc;
+      if (int rc = mmrca_gemm256_x3(A_hi, A_lo, B_hi, B_lo, C, C_lo, bias, preact, M1, N, K, lda, ldb, ldc, b_layout, act, st, pre16)) return rc;
       const int64_t csz = C_lo ? 2 : 4;
       return mmrca_gemm_k1s_x3((const char*)A_hi + M1 * lda * 2, A_lo ? (const char*)A_lo + M1 * lda * 2 : nullptr, B_hi, B_lo, (char*)C + M1 * ldc * csz,
-                               C_lo ? (char*)C_lo + M1 * ldc * 2 : nullptr, bias, nullptr, preact ? (char*)preact + M1 * ldc * 4 : nullptr,
-                               nullptr, M - M1, N, K, lda, ldb, ldc, a_layout, b_layout, act, 0, st);
+                               C_lo ? (char*)C_lo + M1 * ldc * 2 : nullptr, bias, nullptr, preact ? (char*)preact + M1 * ldc * (pre16 ? 2 : 4) : nullptr,
+                               nullptr, M - M1, N, K, lda, ldb, ldc, a_layout, b_layout, act, 0, st, pre16);
     }
-    return mmrca_gemm256_x3(A_hi, A_lo, B_hi, B_lo, C, C_lo, bias, preact, M, N, K, lda, ldb, ldc, b_layout, act, st);
+    return mmrca_gemm256_x3(A_hi, A_lo, B_hi, B_lo, C, C_lo, bias, preact, M, N, K, lda, ldb, ldc, b_layout, act, st, pre16);
   }
   return mmrca_gemm_k1s_x3(A_hi, A_lo, B_hi, B_lo, C, C_lo, bias, addend, preact, colsum, M, N, K, lda, ldb, ldc, a_layout, b_layout,
-                           act, out_f32_accum, st);
+                           act, out_f32_accum, st, pre16);
 }

@@ -2,6 +2,7 @@
 // (column) gradient, text embeddings, ViT patchify/assemble, loss, optimizers.  All are HBM-bound: one wave
 // per row, 8- or 16-byte accesses per lane, fp32 statistics, wave-shuffle reductions.
 #include "common.h"
+#include <type_traits>
 
 #define LN_MAXV 8   // row kept in registers: D <= 256 * LN_MAXV
 
@@ -343,9 +344,11 @@ ln_bwd_k(const T* __restrict__ dy, const T* __restrict__ s, const T* __restrict_
 // bf16 fast path of ln_bwd_k: 16-byte lanes over 512-column slabs, gamma resident in registers, the raw vectors (and
 // row statistics) of the next row fetched before the current row's two wave reductions; accumulators that a call site
 // does not ask for are compiled out (COLS = dcol, BRANCH = dbranch / dcol_branch).
-template <int NV2, bool COLS, bool BRANCH>
+// SF32 (mmrca_layernorm_bwd_mixed): the saved pre-normalisation sum `s` is fp32 -- the residual stream of a forward that keeps
+// it in fp32 (the bf16x3f mode) -- while every gradient stays bf16.
+template <int NV2, bool COLS, bool BRANCH, bool SF32 = false>
 __global__ void __launch_bounds__(256)
-ln_bwd_bf16_k(const bf16_t* __restrict__ dy, const bf16_t* __restrict__ s, const bf16_t* __restrict__ gamma,
+ln_bwd_bf16_k(const bf16_t* __restrict__ dy, const void* __restrict__ s_, const bf16_t* __restrict__ gamma,
               const float* __restrict__ mean, const float* __restrict__ rstd, const bf16_t* __restrict__ dres,
               bf16_t* __restrict__ ds, float* __restrict__ dgamma, float* __restrict__ dbeta, int64_t rows, int D,
               int64_t ld_dy, int64_t ld_s, int64_t ld_ds, float dy_p, uint64_t dy_seed, float br_p, uint64_t br_seed,
@@ -367,7 +370,11 @@ ln_bwd_bf16_k(const bf16_t* __restrict__ dy, const bf16_t* __restrict__ s, const
   for (int it = 0; it < NB; ++it)
 #pragma unroll
     for (int j = 0; j < 8; ++j) adcb[it][j] = 0.f;
-  raw8 gm[NV2], ndy[NV2], ns[NV2], nres[NV2];
+  typedef typename std::conditional<SF32, float, bf16_t>::type ST;
+  typedef ST sraw8 __attribute__((ext_vector_type(8)));
+  const ST* __restrict__ s = reinterpret_cast<const ST*>(s_);
+  raw8 gm[NV2], ndy[NV2], nres[NV2];
+  sraw8 ns[NV2];
   float nmu = 0.f, nrs = 0.f;
 #pragma unroll
   for (int it = 0; it < NV2; ++it) {
@@ -379,7 +386,7 @@ ln_bwd_bf16_k(const bf16_t* __restrict__ dy, const bf16_t* __restrict__ s, const
     const int c = it * 512 + lane * 8;                                                           \
     if (c < D) {                                                                                 \
       ndy[it] = *reinterpret_cast<const raw8*>(dy + (r_) * ld_dy + c);                           \
-      ns[it] = *reinterpret_cast<const raw8*>(s + (r_) * ld_s + c);                              \
+      ns[it] = *reinterpret_cast<const sraw8*>(s + (r_) * ld_s + c);                             \
       if (dres) nres[it] = *reinterpret_cast<const raw8*>(dres + (r_) * ld_ds + c);              \
     }                                                                                            \
   }                                                                                              \
@@ -480,7 +487,7 @@ extern "C" int mmrca_layernorm_bwd(const void* dy, const void* s, const void* ga
       (!dbranch || aligned16p(dbranch))) {
 #define LN_BWD16(NV2_, C_, B_)                                                                                              \
     hipLaunchKernelGGL((ln_bwd_bf16_k<NV2_, C_, B_>), dim3(grid), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)dy,      \
-                       (const bf16_t*)s, (const bf16_t*)gamma, mean, rstd, (const bf16_t*)dres, (bf16_t*)ds, dgamma, dbeta,  \
+                       (const void*)s, (const bf16_t*)gamma, mean, rstd, (const bf16_t*)dres, (bf16_t*)ds, dgamma, dbeta,    \
                        rows, D, ld_dy, ld_s, ld_ds, dy_drop_p, dy_drop_seed, branch_drop_p, branch_drop_seed,              \
                        (bf16_t*)dbranch, dcol, dcol_branch)
 #define LN_BWD16_NV(NV2_)                                                                                                   \
@@ -503,6 +510,38 @@ extern "C" int mmrca_layernorm_bwd(const void* dy, const void* s, const void* ga
     else if (nv <= 4) LN_BWD_LAUNCH(4); else LN_BWD_LAUNCH(8);)
 #undef LN_BWD_LAUNCH
   MMRCA_CHECK_LAUNCH("layernorm_bwd");
+  return 0;
+}
+
+// LayerNorm backward of the bf16x3f mode: bf16 gradients (dy, dres, ds, dbranch) and bf16 gamma against the fp32 sum `s` that the
+// fp32-stream forward saved.  Same argument meaning as mmrca_layernorm_bwd; D % 8 == 0, D <= 1024, 16-byte aligned operands.
+extern "C" int mmrca_layernorm_bwd_mixed(const void* dy, const float* s, const void* gamma, const float* mean, const float* rstd,
+                                         const void* dres, void* ds, float* dgamma, float* dbeta, int64_t rows, int D,
+                                         int64_t ld_dy, int64_t ld_s, int64_t ld_ds, float dy_drop_p, uint64_t dy_drop_seed,
+                                         float branch_drop_p, uint64_t branch_drop_seed, void* dbranch, float* dcol, float* dcol_branch,
+                                         void* stream) {
+  MMRCA_REQUIRE(dy_drop_p >= 0.f && dy_drop_p < 1.f && branch_drop_p >= 0.f && branch_drop_p < 1.f, "layernorm_bwd_mixed: dropout p must be in [0,1)");
+  MMRCA_REQUIRE(dy && s && gamma && mean && rstd && ds && dgamma && dbeta, "layernorm_bwd_mixed: null pointer");
+  MMRCA_REQUIRE(D > 0 && D % 8 == 0 && D <= 1024, "layernorm_bwd_mixed: D=%d unsupported (multiple of 8, <= 1024)", D);
+  MMRCA_REQUIRE(ld_dy >= D && ld_s >= D && ld_ds >= D && ld_dy % 8 == 0 && ld_s % 8 == 0 && ld_ds % 8 == 0, "layernorm_bwd_mixed: bad leading dims");
+  MMRCA_REQUIRE(aligned16p(dy) && aligned16p(s) && aligned16p(gamma) && aligned16p(ds) && (!dres || aligned16p(dres)) && (!dbranch || aligned16p(dbranch)),
+                "layernorm_bwd_mixed: operands must be 16-byte aligned");
+  MMRCA_REQUIRE(!(dcol_branch && !dbranch), "layernorm_bwd_mixed: dcol_branch needs dbranch");
+  if (rows <= 0) return 0;
+  int64_t want = (rows + 3) / 4;
+  const int grid = (int)(want < 1024 ? want : 1024);
+#define LN_BWDM(NV2_, C_, B_)                                                                                               \
+  hipLaunchKernelGGL((ln_bwd_bf16_k<NV2_, C_, B_, true>), dim3(grid), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)dy,  \
+                     (const void*)s, (const bf16_t*)gamma, mean, rstd, (const bf16_t*)dres, (bf16_t*)ds, dgamma, dbeta,      \
+                     rows, D, ld_dy, ld_s, ld_ds, dy_drop_p, dy_drop_seed, branch_drop_p, branch_drop_seed,                \
+                     (bf16_t*)dbranch, dcol, dcol_branch)
+#define LN_BWDM_NV(NV2_)                                                                                                    \
+  do { if (dbranch) { if (dcol) LN_BWDM(NV2_, true, true); else LN_BWDM(NV2_, false, true); }                               \
+       else { if (dcol) LN_BWDM(NV2_, true, false); else LN_BWDM(NV2_, false, false); } } while (0)
+  if (D <= 512) LN_BWDM_NV(1); else LN_BWDM_NV(2);
+#undef LN_BWDM_NV
+#undef LN_BWDM
+  MMRCA_CHECK_LAUNCH("layernorm_bwd_mixed");
   return 0;
 }
 

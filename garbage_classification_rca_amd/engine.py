@@ -158,9 +158,16 @@ class MMRCAEngine:
         """dtype: torch.bfloat16 (the benchmarked mode) | torch.float32 (every GEMM on the fp32 matrix cores) | "bf16x3": fp32
         storage, residual stream, LayerNorm, attention and head, with every encoder nn.Linear (forward, input gradient, weight
         gradient) as a three-pass split-bf16 product on the bf16 matrix cores (csrc/gemm_x3.hip): the reference's fp32
-        arithmetic (multimodal_model.py:651-726) to ~1e-6 on the logits at several times the fp32 mode's speed."""
+        arithmetic (multimodal_model.py:651-726) to ~1e-6 on the logits at several times the fp32 mode's speed.
+        "bf16x3f": the bf16x3 FORWARD (same logits) with the bf16 mode's BACKWARD -- single-pass bf16 products and the bf16 attention
+        backward on the hi planes of the saved fp32 activations, bf16 gradient buffers, fp32 gradient accumulation: the fastest
+        mode whose logits meet the north-star bound; its gradients are the bf16 mode's, evaluated at fp32-accurate activations."""
         L.load()
-        self.x3 = isinstance(dtype, str) and dtype.lower() in ("bf16x3", "x3")
+        name = dtype.lower() if isinstance(dtype, str) else ""
+        self.x3 = name in ("bf16x3", "x3", "bf16x3f", "x3f")
+        self.x3f = name in ("bf16x3f", "x3f")
+        if self.x3f and not FUSE_GELU_GRAD:
+            raise L.MmrcaError("bf16x3f needs the fused GELU gradient (MMRCA_FUSE_GELU=1)")
         if self.x3:
             dtype = torch.float32
         elif isinstance(dtype, str):
@@ -179,6 +186,9 @@ class MMRCAEngine:
         self.n_classes, self.reverse, self.mode = n_classes, bool(reverse), int(mode)
         self.dtype, self.device = dtype, torch.device(device)
         self.dt = L.dtype_code(dtype)
+        # dtype of the gradient buffers / of every backward kernel (bf16x3f: a bf16 backward behind an fp32-accurate forward)
+        self.gdtype = torch.bfloat16 if self.x3f else dtype
+        self.bdt = L.BF16 if self.x3f else self.dt
         self.gemm_impl, self.attn_impl = gemm_impl, attn_impl
         # conv image backbones (EfficientNetV2-M/L, ShuffleNetV2): conv_engine.ConvEncoder over csrc/conv.hip
         self.conv = ConvEncoder(image_model, self, image_size) if self.vs is None else None
@@ -201,6 +211,9 @@ class MMRCAEngine:
         self._plane_valid = set()
         self._plane_fresh = set()
         self._ln_planes = self._g_planes
+        # FFN1's epilogue: gelu + gelu' (bf16x3f: gelu' as bf16, what its bf16 backward multiplies by)
+        self._gelu_act = (L.ACT_GELU_SAVE_GRAD_BF16 if self.x3f else L.ACT_GELU_SAVE_GRAD) if FUSE_GELU_GRAD else L.ACT_GELU
+        self._hdt = torch.bfloat16 if self.x3f else None
         self._saved = None
         # parameter groups that become final together during backward; they tile the arena exactly (padding included)
         self.groups: Dict[str, Tuple[int, int]] = {}
@@ -308,6 +321,27 @@ class MMRCAEngine:
             L.split_f32(x, pl[0], pl[1], rows * cols)
             self._plane_valid.add(key)
         return pl
+
+    def _hi(self, x, rows, cols):
+        """bf16 (hi-plane) form of a saved fp32 activation: the operand of the bf16x3f mode's bf16 backward.  The forward's GEMMs /
+        LayerNorms / attention already wrote it for everything they consumed; anything else is rounded here."""
+        if isinstance(x, Planes):
+            return x.hi
+        key, pl = self._planes_of(x)
+        if key in self._plane_fresh:
+            self._plane_fresh.discard(key)
+            self._plane_valid.add(key)
+        elif key not in self._plane_valid:
+            L.cast_f32_to_bf16(x, pl[0], rows * cols)
+            self._plane_valid.add(key)
+        return pl[0]
+
+    def Wb(self, key, numel=None):
+        """parameter view in the dtype of the backward kernels (bf16x3f: the hi plane = bf16 rounding of the fp32 master)"""
+        if not self.x3f:
+            return self.W(key) if numel is None else self.Wflat(key, numel)
+        off, shp, n = self.arena.offsets[key]
+        return self.arena.lp[off:off + n].view(shp) if numel is None else self.arena.lp[off:off + numel]
 
     def G(self, key):
         return self.arena.view(key, "g")
@@ -417,19 +451,22 @@ class MMRCAEngine:
         Mk = _round_up(M, 64)
         gw = self.G(wkey) if wnumel is None else self.Gflat(wkey, wnumel)
         gb = self.G(bkey) if wnumel is None else self.Gflat(bkey, N)
-        if self.x3:
+        if self.x3 and not self.x3f:
             return self._lin_bwd_x3(dy, x, wkey, dx, M, N, K, Mk, gw, gb, addend, wnumel, gelu_h, bias_done, gelu_db)
+        if self.x3f:
+            x = self._hi(x, M, K)
+        bdt = self.bdt
 
         def wgrad():
             fused = (FUSE_BIAS_GRAD or fuse_db) and not bias_done
-            if SPLITK_WGRAD and not fused and self.gemm_impl == L.IMPL_AUTO and L.gemm_splitk_ok(N, K, Mk, self.dt):
+            if SPLITK_WGRAD and not fused and self.gemm_impl == L.IMPL_AUTO and L.gemm_splitk_ok(N, K, Mk, bdt):
                 # 256x256 tiles, partial tiles through a per-stream workspace, no atomics (1,020-1,150 vs 800-870 TFLOP/s)
                 L.gemm_splitk(dy, x, gw, self._splitk_ws(), M=N, N=K, K=Mk, lda=N, ldb=K, ldc=K)
             else:
                 L.gemm(dy, x, gw, bias=(gb if fused else None), M=N, N=K, K=Mk, lda=N, ldb=K, ldc=K, a_layout=L.KROW,
-                       b_layout=L.KROW, accum=True, dtype=self.dt, impl=self.gemm_impl)
+                       b_layout=L.KROW, accum=True, dtype=bdt, impl=self.gemm_impl)
             if not fused and not bias_done:     # bias_done: the producer of dy already accumulated its column sums
-                L.colsum_accum(dy, gb, M, N, N, self.dt)
+                L.colsum_accum(dy, gb, M, N, N, bdt)
 
         if self._side is None:
             wgrad()
@@ -445,17 +482,17 @@ class MMRCAEngine:
                     self._first_wgrad_ev = torch.cuda.Event()
                     self._first_wgrad_ev.record(self._side)
         if dx is not None:
-            w = self.W(wkey) if wnumel is None else self.Wflat(wkey, wnumel)
+            w = self.Wb(wkey, wnumel)
             fuse = gelu_h is not None and FUSE_GELU_GRAD
             # fused: dh = (dy W) * gelu'(h) in the epilogue (h holds gelu' then) and the FFN1 bias gradient = its column sums
             L.gemm(dy, w, dx, addend=addend, preact=(gelu_h if fuse else None), M=M, N=K, K=N, lda=N, ldb=K, ldc=K,
-                   a_layout=L.ROWK, b_layout=L.KROW, act=(L.ACT_MUL if fuse else L.ACT_NONE), dtype=self.dt,
+                   a_layout=L.ROWK, b_layout=L.KROW, act=(L.ACT_MUL if fuse else L.ACT_NONE), dtype=bdt,
                    impl=self.gemm_impl, colsum=(gelu_db if fuse else None))
             if gelu_h is not None and not fuse:
                 if gelu_db is not None:     # dh = dg * gelu'(h) and the FFN1 bias gradient (column sums of dh) in one pass
-                    L.gelu_bwd_colsum(dx, gelu_h, dx, gelu_db, M, K, K, self.dt)
+                    L.gelu_bwd_colsum(dx, gelu_h, dx, gelu_db, M, K, K, bdt)
                 else:
-                    L.gelu_bwd(dx, gelu_h, dx, M * K, self.dt)
+                    L.gelu_bwd(dx, gelu_h, dx, M * K, bdt)
 
     def _lin_bwd_x3(self, dy, x, wkey, dx, M, N, K, Mk, gw, gb, addend, wnumel, gelu_h, bias_done, gelu_db):
         """bf16x3 form of _lin_bwd: dy is split once for both products, x's planes are the ones its forward GEMM made"""
@@ -518,11 +555,39 @@ class MMRCAEngine:
 
     def _ln_bwd(self, dy, s, pfx, mean, rstd, dres, ds, rows, D, ld_dy=None, ld_s=None, ld_ds=None, dy_drop=(0.0, 0),
                 branch_drop=(0.0, 0), dbranch=None, dcol=None, dcol_branch=None):
+        if self.x3f:        # bf16 gradients against the fp32 residual stream the forward saved
+            L.layernorm_bwd_mixed(dy, s, self.Wb(pfx + ".weight"), mean, rstd, dres, ds, self.G(pfx + ".weight"), self.G(pfx + ".bias"),
+                                  rows, D, ld_dy or D, ld_s or D, ld_ds or D, dy_drop=dy_drop, branch_drop=branch_drop, dbranch=dbranch,
+                                  dcol=dcol, dcol_branch=dcol_branch)
+            return
         L.layernorm_bwd(dy, s, self.W(pfx + ".weight"), mean, rstd, dres, ds, self.G(pfx + ".weight"), self.G(pfx + ".bias"),
                         rows, D, ld_dy or D, ld_s or D, ld_ds or D, self.dt, dy_drop=dy_drop, branch_drop=branch_drop, dbranch=dbranch,
                         dcol=dcol, dcol_branch=dcol_branch)
 
+    def _attn_bwd_operands(self, a, rows, D, name, cap, B):
+        """(qkv, context) as the attention backward reads them: the saved tensors, or in bf16x3f their bf16 roundings (q|k|v through
+        one scratch buffer of `cap` rows shared by all layers, the context's hi plane); a["tail"]: the class-token context [B, D]"""
+        tail = bool(a.get("tail"))
+        c = a["ctx_c"] if tail else a["ctx"]
+        if not self.x3f:
+            return a["qkv"], c
+        if isinstance(a["qkv"], Planes):
+            return a["qkv"].hi, self._hi(c, B if tail else rows, D)
+        qkv16 = self.buf(name + "_qkv16", cap, 3 * D, torch.bfloat16)
+        L.cast_f32_to_bf16(a["qkv"], qkv16, rows * 3 * D)
+        return qkv16, self._hi(c, B if tail else rows, D)
+
+    def _qkv_planes_ok(self, S, dh):
+        """bf16x3f: the q|k|v projection is written as two bf16 planes -- the fp32 attention forward rebuilds the fp32 values from
+        them and the bf16 attention backward reads the hi plane, so no fp32 copy and no cast pass exist"""
+        return self.x3f and self._ln_planes and self.attn_impl == L.IMPL_AUTO and L.mha_fwd_planes_ok(S, dh)
+
     def _mha_fwd(self, qkv, mask32, ctx, lse, B, H, S, dh, drop_p=0.0, drop_seed=0, cu=None):
+        if isinstance(qkv, Planes):
+            key, pl = self._planes_of(ctx)
+            L.mha_fwd_planes_in((qkv.hi, qkv.lo), mask32, None, pl, lse, B, H, S, dh, dh ** -0.5, drop_p=drop_p, drop_seed=drop_seed, cu=cu)
+            self._plane_fresh.add(key)
+            return
         if self.x3 and self._ln_planes and self.attn_impl == L.IMPL_AUTO and L.mha_fwd_planes_ok(S, dh):
             # the context feeds the out-projection GEMM: written as two bf16 planes next to the fp32 copy the backward reads
             key, pl = self._planes_of(ctx)
@@ -584,7 +649,9 @@ class MMRCAEngine:
         layers = []
         for i in range(s.layers):
             K = S.text_layer_keys(s, i)
-            qkv, ctx, lse = fb("qkv", 3 * D, i), fb("ctx", D, i), self.buf("t_lse", 1, _round_up(B * H * T, ROWPAD), torch.float32, i if save else 0)
+            last_tail = CLS_TAIL and i == s.layers - 1          # (the class-token attention reads fp32 q|k|v)
+            qkv = self.planes_buf("t_qkv", cap, 3 * D, i if save else 0) if (self._qkv_planes_ok(T, dh) and not last_tail) else fb("qkv", 3 * D, i)
+            ctx, lse = fb("ctx", D, i), self.buf("t_lse", 1, _round_up(B * H * T, ROWPAD), torch.float32, i if save else 0)
             self._lin_fwd(x, P + K["q"] + ".weight", P + K["q"] + ".bias", qkv, M, 3 * D, D, wnumel=3 * D * D)
             if CLS_TAIL and i == s.layers - 1:
                 # class-token tail: the class-token query's attention, then rows b*T only (see CLS_TAIL above)
@@ -598,8 +665,8 @@ class MMRCAEngine:
                 s1, x1 = cb("s1", D), cb("x1", D)
                 m1, r1 = stat("m1c", i), stat("r1c", i)
                 self._ln_fwd(att, x_c, P + K["ln1"], s1, x1, m1, r1, B, D, s.ln_eps, in_drop=(post_attn_drop, sd(i, 2)), to_gemm=True)
-                h, g = cb("h", Fd), (self.planes_buf("t_g_c", B, Fd, i if save else 0) if self._g_planes else cb("g", Fd))
-                self._lin_fwd(x1, P + K["f1"] + ".weight", P + K["f1"] + ".bias", g, B, Fd, D, act=(L.ACT_GELU_SAVE_GRAD if FUSE_GELU_GRAD else L.ACT_GELU), preact=h)
+                h, g = cb("h", Fd, self._hdt), (self.planes_buf("t_g_c", B, Fd, i if save else 0) if self._g_planes else cb("g", Fd))
+                self._lin_fwd(x1, P + K["f1"] + ".weight", P + K["f1"] + ".bias", g, B, Fd, D, act=self._gelu_act, preact=h)
                 f = cb("f", D)
                 self._lin_fwd(g, P + K["f2"] + ".weight", P + K["f2"] + ".bias", f, B, D, Fd)
                 s2, xn = cb("s2", D), cb("xout", D)
@@ -616,8 +683,8 @@ class MMRCAEngine:
             s1, x1 = fb("s1", D, i), fb("x1", D, i)
             m1, r1 = stat("m1", i), stat("r1", i)
             self._ln_fwd(att, x, P + K["ln1"], s1, x1, m1, r1, M, D, s.ln_eps, in_drop=(post_attn_drop, sd(i, 2)), to_gemm=True)
-            h, g = fb("h", Fd, i), (self.planes_buf("t_g", cap, Fd, i if save else 0) if self._g_planes else fb("g", Fd, i))
-            self._lin_fwd(x1, P + K["f1"] + ".weight", P + K["f1"] + ".bias", g, M, Fd, D, act=(L.ACT_GELU_SAVE_GRAD if FUSE_GELU_GRAD else L.ACT_GELU), preact=h)   # fused mode: h <- gelu'(pre-activation)
+            h, g = fb("h", Fd, i, self._hdt), (self.planes_buf("t_g", cap, Fd, i if save else 0) if self._g_planes else fb("g", Fd, i))
+            self._lin_fwd(x1, P + K["f1"] + ".weight", P + K["f1"] + ".bias", g, M, Fd, D, act=self._gelu_act, preact=h)   # fused mode: h <- gelu'(pre-activation)
             f = fb("tmpD", D)
             self._lin_fwd(g, P + K["f2"] + ".weight", P + K["f2"] + ".bias", f, M, D, Fd)
             s2, xn = fb("s2", D, i), fb("x", D, i + 1)
@@ -634,7 +701,8 @@ class MMRCAEngine:
         B, T = sv["B"], sv["T"]
         M, D, Fd, H = sv["M"], s.dim, s.ffn, s.heads
         dh, cu, first = D // H, sv["cu"], sv["first"]
-        gb = lambda name, cols: self.buf("tg_" + name, B * T, cols)
+        gb = lambda name, cols: self.buf("tg_" + name, B * T, cols, self.gdtype)
+        gplanes = self._g_planes and not self.x3f
         dx = gb("dxA", D)
         tail = bool(sv["layers"][-1].get("tail"))
         if not tail:
@@ -653,7 +721,7 @@ class MMRCAEngine:
             # the LayerNorm backward also emits the column sums of its output = bias gradient of the linear that fed it
             self._ln_bwd(dx, a["s2"], P + K["ln2"], a["m2"], a["r2"], None, ds2, M, D, branch_drop=(dp, sd(i, 3)), dbranch=df,
                          dcol=(None if df is not None else gb_f2), dcol_branch=(gb_f2 if df is not None else None))
-            dg = self.planes_buf("tg_dF", B * T, Fd) if self._g_planes else gb("dF", Fd)
+            dg = self.planes_buf("tg_dF", B * T, Fd) if gplanes else gb("dF", Fd)
             self._lin_bwd(df if df is not None else ds2, a["g"], P + K["f2"] + ".weight", P + K["f2"] + ".bias", dg, M, D, Fd,
                           gelu_h=a["h"], bias_done=True, gelu_db=self.G(P + K["f1"] + ".bias"))
             dx1 = gb("dxB", D)
@@ -667,7 +735,8 @@ class MMRCAEngine:
                           bias_done=True)
             dqkv = gb("dqkv", 3 * D)
             # the attention backward also reduces the q|k|v bias gradients (adjacent in the arena) while it has the tiles
-            L.mha_bwd(a["qkv"], sv["mask32"], a["ctx"], dctx, a["lse"], dqkv, B, H, T, dh, dh ** -0.5, self.dt, self.attn_impl,
+            qkv_b, ctx_b = self._attn_bwd_operands(a, M, D, "tg", B * T, B)
+            L.mha_bwd(qkv_b, sv["mask32"], ctx_b, dctx, a["lse"], dqkv, B, H, T, dh, dh ** -0.5, self.bdt, self.attn_impl,
                       drop_p=dp, drop_seed=sd(i, 1), cu=cu)
             self._wait_first_wgrad()       # (the FFN2 weight gradient does not read dx in the post-LN layout; harmless)
             self._lin_bwd(dqkv, a["x"], P + K["q"] + ".weight", P + K["q"] + ".bias", dx, M, 3 * D, D, addend=ds1, wnumel=3 * D * D,
@@ -679,7 +748,7 @@ class MMRCAEngine:
                      dy_drop=(sv["drop_p"], self._site_seed(sv["drop_seed"], 0, 0)))
         dtype_row = self.Gflat(P + "embeddings.token_type_embeddings.weight", D) if s.type_vocab else None
         L.embed_bwd(ds0, sv["ids32"], sv["pos"], self.G(P + "embeddings.word_embeddings.weight"),
-                    self.G(P + "embeddings.position_embeddings.weight"), dtype_row, M, D, self.dt,
+                    self.G(P + "embeddings.position_embeddings.weight"), dtype_row, M, D, self.bdt,
                     pad_id=s.pad_id, pos_pad_id=(s.pad_id if s.pos_offset else -1))
         self._layer_boundary()
         self._ready("text_emb", flush=True)
@@ -691,8 +760,8 @@ class MMRCAEngine:
         M, D, Fd, H = sv["M"], s.dim, s.ffn, s.heads
         dh, i, cu, first = D // H, s.layers - 1, sv["cu"], sv["first"]
         K, a = S.text_layer_keys(s, i), sv["layers"][i]
-        gb = lambda name, cols: self.buf("tg_" + name, B * T, cols)
-        gc = lambda name, cols: self.buf("tg_" + name + "_c", B, cols)
+        gb = lambda name, cols: self.buf("tg_" + name, B * T, cols, self.gdtype)
+        gc = lambda name, cols: self.buf("tg_" + name + "_c", B, cols, self.gdtype)
         dp, sd = sv["drop_p"], (lambda layer, site: self._site_seed(sv["drop_seed"], layer, site))
         post_attn_drop = dp if s.name != "distilbert" else 0.0
         dxc = gc("dx", D)
@@ -702,7 +771,7 @@ class MMRCAEngine:
         gb_f2, gb_o = self.G(P + K["f2"] + ".bias"), self.G(P + K["o"] + ".bias")
         self._ln_bwd(dxc, a["s2"], P + K["ln2"], a["m2"], a["r2"], None, ds2, B, D, branch_drop=(dp, sd(i, 3)), dbranch=df,
                      dcol=(None if df is not None else gb_f2), dcol_branch=(gb_f2 if df is not None else None))
-        dg = self.planes_buf("tg_dF_c", B, Fd) if self._g_planes else gc("dF", Fd)
+        dg = self.planes_buf("tg_dF_c", B, Fd) if (self._g_planes and not self.x3f) else gc("dF", Fd)
         self._lin_bwd(df if df is not None else ds2, a["g"], P + K["f2"] + ".weight", P + K["f2"] + ".bias", dg, B, D, Fd,
                       gelu_h=a["h"], bias_done=True, gelu_db=self.G(P + K["f1"] + ".bias"))
         dx1 = gc("dxB", D)
@@ -719,7 +788,8 @@ class MMRCAEngine:
         ds1_full[:M].zero_()
         ds1_full.index_copy_(0, first, ds1[:B])
         dqkv = gb("dqkv", 3 * D)
-        L.mha_cls_bwd(a["qkv"], sv["mask32"], a["ctx_c"], dctx_c, a["lse"], dqkv, B, H, T, dh, dh ** -0.5, self.dt,
+        qkv_b, ctx_b = self._attn_bwd_operands(a, M, D, "tg", B * T, B)
+        L.mha_cls_bwd(qkv_b, sv["mask32"], ctx_b, dctx_c, a["lse"], dqkv, B, H, T, dh, dh ** -0.5, self.bdt,
                       drop_p=dp, drop_seed=sd(i, 1), cu=cu)
         self._lin_bwd(dqkv, a["x"], P + K["q"] + ".weight", P + K["q"] + ".bias", dx, M, 3 * D, D, addend=ds1_full, wnumel=3 * D * D,
                       fuse_db=QKV_BIAS_IN_WGRAD)
@@ -755,12 +825,14 @@ class MMRCAEngine:
                 x = fb("x", M, D, i)
                 self._ln_fwd(pend[0], pend[1], Lk + "ln_1", x, y1, m1, r1, M, D, s.ln_eps)       # x = ffn2 + x1 (previous layer), y1 = LN(x)
                 pend = None
-            qkv, ctx = fb("qkv", M, 3 * D, i), fb("ctx", M, D, i)
+            last_tail = CLS_TAIL and i == s.layers - 1          # (the class-token attention reads fp32 q|k|v)
+            qkv = self.planes_buf("v_qkv", M, 3 * D, i if save else 0) if (self._qkv_planes_ok(Tn, dh) and not last_tail) else fb("qkv", M, 3 * D, i)
+            ctx = fb("ctx", M, D, i)
             lse = self.buf("v_lse", 1, _round_up(B * H * Tn, ROWPAD), torch.float32, i if save else 0)
             self._lin_fwd(y1, Lk + "self_attention.in_proj_weight", Lk + "self_attention.in_proj_bias", qkv, M, 3 * D, D)
             if CLS_TAIL and i == s.layers - 1:
                 # class-token tail: the class-token query's attention, then rows b*Tn only (see CLS_TAIL above)
-                cb = lambda name, cols: fb(name + "_c", B, cols, i)
+                cb = lambda name, cols, dt=None: fb(name + "_c", B, cols, i, dt)
                 ctx_c, x_c = cb("ctx", D), cb("xin", D)
                 lse = self.buf("v_lse_c", 1, _round_up(B * H, ROWPAD), torch.float32, i if save else 0)
                 L.mha_cls_fwd(qkv, None, ctx_c, lse, B, H, Tn, dh, dh ** -0.5, self.dt)
@@ -769,8 +841,8 @@ class MMRCAEngine:
                 self._lin_fwd(ctx_c, Lk + "self_attention.out_proj.weight", Lk + "self_attention.out_proj.bias", x1, B, D, D, addend=x_c)
                 y2, m2, r2 = (self.planes_buf("v_y2_c", B, D, i if save else 0) if self._ln_planes else cb("y2", D)), stat("m2c", i), stat("r2c", i)
                 self._ln_fwd(x1, None, Lk + "ln_2", None, y2, m2, r2, B, D, s.ln_eps)
-                h, g = cb("h", Fd), (self.planes_buf("v_g_c", B, Fd, i if save else 0) if self._g_planes else cb("g", Fd))
-                self._lin_fwd(y2, Lk + "mlp.0.weight", Lk + "mlp.0.bias", g, B, Fd, D, act=(L.ACT_GELU_SAVE_GRAD if FUSE_GELU_GRAD else L.ACT_GELU), preact=h)
+                h, g = cb("h", Fd, self._hdt), (self.planes_buf("v_g_c", B, Fd, i if save else 0) if self._g_planes else cb("g", Fd))
+                self._lin_fwd(y2, Lk + "mlp.0.weight", Lk + "mlp.0.bias", g, B, Fd, D, act=self._gelu_act, preact=h)
                 xn = cb("xout", D)
                 self._lin_fwd(g, Lk + "mlp.3.weight", Lk + "mlp.3.bias", xn, B, D, Fd, addend=x1)
                 layers.append(dict(x=x, y1=y1, m1=m1, r1=r1, qkv=qkv, ctx=ctx, lse=lse, x1=x1, y2=y2, m2=m2, r2=r2, h=h, g=g,
@@ -789,8 +861,8 @@ class MMRCAEngine:
             else:
                 self._lin_fwd(ctx, Lk + "self_attention.out_proj.weight", Lk + "self_attention.out_proj.bias", x1, M, D, D, addend=x)
                 self._ln_fwd(x1, None, Lk + "ln_2", None, y2, m2, r2, M, D, s.ln_eps)
-            h, g = fb("h", M, Fd, i), (self.planes_buf("v_g", M, Fd, i if save else 0) if self._g_planes else fb("g", M, Fd, i))
-            self._lin_fwd(y2, Lk + "mlp.0.weight", Lk + "mlp.0.bias", g, M, Fd, D, act=(L.ACT_GELU_SAVE_GRAD if FUSE_GELU_GRAD else L.ACT_GELU), preact=h)   # fused mode: h <- gelu'(pre-activation)
+            h, g = fb("h", M, Fd, i, self._hdt), (self.planes_buf("v_g", M, Fd, i if save else 0) if self._g_planes else fb("g", M, Fd, i))
+            self._lin_fwd(y2, Lk + "mlp.0.weight", Lk + "mlp.0.bias", g, M, Fd, D, act=self._gelu_act, preact=h)   # fused mode: h <- gelu'(pre-activation)
             layers.append(dict(x=x, y1=y1, m1=m1, r1=r1, qkv=qkv, ctx=ctx, lse=lse, x1=x1, y2=y2, m2=m2, r2=r2, h=h, g=g))
             if fuse_res:
                 f2 = fb("ffn_o", M, D, 0)
@@ -814,14 +886,15 @@ class MMRCAEngine:
         B = sv["B"]
         nP, Tn, D, Fd, H = s.tokens - 1, s.tokens, s.dim, s.ffn, s.heads
         dh, M, Kp = D // H, B * Tn, 3 * s.patch * s.patch
-        gb = lambda name, rows, cols: self.buf("vg_" + name, rows, cols)
+        gb = lambda name, rows, cols: self.buf("vg_" + name, rows, cols, self.gdtype)
+        gplanes = self._g_planes and not self.x3f
         dx = gb("dxA", M, D)
-        dfe = self.buf("vg_dfeat", B, D)
+        dfe = gb("dfeat", B, D)
         dfe[:B].copy_(dfeat)
         top = P + f"encoder.layers.encoder_layer_{s.layers - 1}."
         tail = bool(sv["layers"][-1].get("tail"))
         if tail:
-            dxc = self.buf("vg_dx_c", B, D)
+            dxc = gb("dx_c", B, D)
             self._ln_bwd(dfe, sv["xL"], P + "encoder.ln", sv["mf"], sv["rf"], None, dxc, B, D, dcol=self.G(top + "mlp.3.bias"))
         else:
             dx[:M].zero_()
@@ -834,7 +907,7 @@ class MMRCAEngine:
                 self._vision_backward_tail(dxc, sv, dx)
                 continue
             Lk, a = P + f"encoder.layers.encoder_layer_{i}.", sv["layers"][i]
-            dg = self.planes_buf("vg_dF", M, Fd) if self._g_planes else gb("dF", M, Fd)
+            dg = self.planes_buf("vg_dF", M, Fd) if gplanes else gb("dF", M, Fd)
             self._lin_bwd(dx, a["g"], Lk + "mlp.3.weight", Lk + "mlp.3.bias", dg, M, D, Fd, gelu_h=a["h"], bias_done=True,
                           gelu_db=self.G(Lk + "mlp.0.bias"))
             dy2 = gb("dy", M, D)
@@ -845,7 +918,8 @@ class MMRCAEngine:
             self._lin_bwd(dx1, a["ctx"], Lk + "self_attention.out_proj.weight", Lk + "self_attention.out_proj.bias", dctx, M, D, D,
                           bias_done=True)
             dqkv = gb("dqkv", M, 3 * D)
-            L.mha_bwd(a["qkv"], None, a["ctx"], dctx, a["lse"], dqkv, B, H, Tn, dh, dh ** -0.5, self.dt, self.attn_impl)
+            qkv_b, ctx_b = self._attn_bwd_operands(a, M, D, "vg", M, B)
+            L.mha_bwd(qkv_b, None, ctx_b, dctx, a["lse"], dqkv, B, H, Tn, dh, dh ** -0.5, self.bdt, self.attn_impl)
             dy1 = gb("dy", M, D)
             self._lin_bwd(dqkv, a["y1"], Lk + "self_attention.in_proj_weight", Lk + "self_attention.in_proj_bias", dy1, M, 3 * D, D,
                           fuse_db=QKV_BIAS_IN_WGRAD)
@@ -855,7 +929,7 @@ class MMRCAEngine:
             self._layer_boundary()
             self._ready(f"image_layer_{i}")
         dproj = gb("dproj", B * nP, D)
-        L.vit_assemble_bwd(dx, dproj, self.Gflat(P + "class_token", D), self.Gflat(P + "encoder.pos_embedding", Tn * D), B, nP, D, self.dt)
+        L.vit_assemble_bwd(dx, dproj, self.Gflat(P + "class_token", D), self.Gflat(P + "encoder.pos_embedding", Tn * D), B, nP, D, self.bdt)
         self._lin_bwd(dproj, sv["patches"], P + "conv_proj.weight", P + "conv_proj.bias", None, B * nP, D, Kp, wnumel=D * Kp)
         self._layer_boundary()
         self._ready("image_emb", flush=True)
@@ -868,9 +942,9 @@ class MMRCAEngine:
         Tn, D, Fd, H = s.tokens, s.dim, s.ffn, s.heads
         dh, M, i = D // H, B * Tn, s.layers - 1
         Lk, a = P + f"encoder.layers.encoder_layer_{i}.", sv["layers"][i]
-        gb = lambda name, rows, cols: self.buf("vg_" + name, rows, cols)
-        gc = lambda name, cols: self.buf("vg_" + name + "_c", B, cols)
-        dg = self.planes_buf("vg_dF_c", B, Fd) if self._g_planes else gc("dF", Fd)
+        gb = lambda name, rows, cols: self.buf("vg_" + name, rows, cols, self.gdtype)
+        gc = lambda name, cols: self.buf("vg_" + name + "_c", B, cols, self.gdtype)
+        dg = self.planes_buf("vg_dF_c", B, Fd) if (self._g_planes and not self.x3f) else gc("dF", Fd)
         self._lin_bwd(dxc, a["g"], Lk + "mlp.3.weight", Lk + "mlp.3.bias", dg, B, D, Fd, gelu_h=a["h"], bias_done=True,
                       gelu_db=self.G(Lk + "mlp.0.bias"))
         dy2 = gc("dy", D)
@@ -886,7 +960,8 @@ class MMRCAEngine:
         dx1[:M].zero_()
         dx1[:M].view(B, Tn, D)[:, 0] = dx1c[:B]
         dqkv = gb("dqkv", M, 3 * D)
-        L.mha_cls_bwd(a["qkv"], None, a["ctx_c"], dctx_c, a["lse"], dqkv, B, H, Tn, dh, dh ** -0.5, self.dt)
+        qkv_b, ctx_b = self._attn_bwd_operands(a, M, D, "vg", M, B)
+        L.mha_cls_bwd(qkv_b, None, ctx_b, dctx_c, a["lse"], dqkv, B, H, Tn, dh, dh ** -0.5, self.bdt)
         dy1 = gb("dy", M, D)
         self._lin_bwd(dqkv, a["y1"], Lk + "self_attention.in_proj_weight", Lk + "self_attention.in_proj_bias", dy1, M, 3 * D, D,
                       fuse_db=QKV_BIAS_IN_WGRAD)

@@ -16,7 +16,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libmmrca.so")
 
 F32, BF16 = 0, 1
-ACT_NONE, ACT_GELU, ACT_GELU_BWD, ACT_GELU_SAVE_GRAD, ACT_MUL = 0, 1, 2, 3, 4
+ACT_NONE, ACT_GELU, ACT_GELU_BWD, ACT_GELU_SAVE_GRAD, ACT_MUL, ACT_GELU_SAVE_GRAD_BF16 = 0, 1, 2, 3, 4, 5
 ROWK, KROW = 0, 1
 IMPL_AUTO, IMPL_REF, IMPL_MFMA, IMPL_MFMA256, IMPL_MFMA_PERSIST, IMPL_MFMA_BK32, IMPL_MFMA_1STAGE, IMPL_MFMA_TALL, IMPL_MFMA_256W, IMPL_MFMA_256X4 = 0, 1, 2, 3, 4, 5, 6, 7, 8, 9
 
@@ -95,6 +95,7 @@ _SIGS = {
     "mmrca_gelu_bwd_colsum": [_vp, _vp, _vp, _vp, _i64, _i64, _i64, _i32, _vp],
     "mmrca_mha_fwd": [_vp] * 4 + [_i32] * 4 + [_f32, _f32, _u64, _vp, _i32, _i32, _vp],
     "mmrca_mha_fwd_planes": [_vp] * 6 + [_i32] * 4 + [_f32, _f32, _u64, _vp, _vp],
+    "mmrca_mha_fwd_planes_in": [_vp] * 7 + [_i32] * 4 + [_f32, _f32, _u64, _vp, _vp],
     "mmrca_mha_bwd": [_vp] * 6 + [_i32] * 4 + [_f32, _f32, _u64, _vp, _i32, _i32, _vp],
     "mmrca_mha_bwd_colsum": [_vp] * 7 + [_i64] + [_i32] * 4 + [_f32, _f32, _u64, _vp, _i32, _i32, _vp],
     "mmrca_mha_cross_fwd": [_vp, _i64, _vp, _i64, _vp, _i64, _vp, _i64] + [_i32] * 5 + [_f32, _f32, _u64, _i32, _i32, _vp],
@@ -103,6 +104,7 @@ _SIGS = {
     "mmrca_add_layernorm_fwd": [_vp] * 8 + [_i64, _i32, _i64, _i64, _f32, _f32, _u64, _f32, _u64, _i32, _vp],
     "mmrca_add_layernorm_fwd_x3": [_vp] * 10 + [_i64, _i32, _i64, _i64, _f32, _f32, _u64, _f32, _u64, _vp],
     "mmrca_layernorm_bwd": [_vp] * 9 + [_i64, _i32, _i64, _i64, _i64, _f32, _u64, _f32, _u64, _vp, _vp, _vp, _i32, _vp],
+    "mmrca_layernorm_bwd_mixed": [_vp] * 9 + [_i64, _i32, _i64, _i64, _i64, _f32, _u64, _f32, _u64, _vp, _vp, _vp, _vp],
     "mmrca_embed_fwd": [_vp] * 6 + [_i64, _i32, _i32, _vp],
     "mmrca_embed_bwd": [_vp] * 6 + [_i64, _i32, _i32, _i32, _i32, _vp],
     "mmrca_patchify_fwd": [_vp, _vp] + [_i32] * 6 + [_vp],
@@ -324,6 +326,15 @@ def mha_fwd_planes(qkv, key_mask, out, out_planes, lse, B, H, S, dh, scale, drop
                                            scale, drop_p, drop_seed, ptr(cu), stream_ptr()), "mmrca_mha_fwd_planes")
 
 
+def mha_fwd_planes_in(qkv_planes, key_mask, out, out_planes, lse, B, H, S, dh, scale, drop_p=0.0, drop_seed=0, cu=None):
+    """mha_fwd_planes with q|k|v given as (hi, lo) bf16 planes (bf16x3f mode)"""
+    _dev(qkv_planes[0], "mha qkv")
+    with _Bracket("mha_fwd", (B, H, S, dh, cu is not None)):
+        _check(load().mmrca_mha_fwd_planes_in(ptr(qkv_planes[0]), ptr(qkv_planes[1]), ptr(key_mask), ptr(out), ptr(out_planes[0]),
+                                              ptr(out_planes[1]), ptr(lse), B, H, S, dh, scale, drop_p, drop_seed, ptr(cu), stream_ptr()),
+               "mmrca_mha_fwd_planes_in")
+
+
 def mha_bwd(qkv, key_mask, out, dout, lse, dqkv, B, H, S, dh, scale, dtype, impl=IMPL_AUTO, drop_p=0.0, drop_seed=0, colsum=None,
             cu=None, rows=None):
     """colsum (fp32 [3*H*dh], +=): column sums of dqkv = the in-projection bias gradient, reduced inside the kernels;
@@ -376,6 +387,14 @@ def layernorm_bwd(dy, s, gamma, mean, rstd, dres, ds, dgamma, dbeta, rows, D, ld
     _check(load().mmrca_layernorm_bwd(ptr(dy), ptr(s), ptr(gamma), ptr(mean), ptr(rstd), ptr(dres), ptr(ds), ptr(dgamma),
                                       ptr(dbeta), rows, D, ld_dy, ld_s, ld_ds, dy_drop[0], dy_drop[1], branch_drop[0],
                                       branch_drop[1], ptr(dbranch), ptr(dcol), ptr(dcol_branch), dtype, stream_ptr()), "mmrca_layernorm_bwd")
+
+
+def layernorm_bwd_mixed(dy, s, gamma, mean, rstd, dres, ds, dgamma, dbeta, rows, D, ld_dy, ld_s, ld_ds,
+                        dy_drop=(0.0, 0), branch_drop=(0.0, 0), dbranch=None, dcol=None, dcol_branch=None):
+    """layernorm_bwd with bf16 gradients / gamma against the fp32 saved sum `s` (bf16x3f mode)"""
+    _check(load().mmrca_layernorm_bwd_mixed(ptr(dy), ptr(s), ptr(gamma), ptr(mean), ptr(rstd), ptr(dres), ptr(ds), ptr(dgamma),
+                                            ptr(dbeta), rows, D, ld_dy, ld_s, ld_ds, dy_drop[0], dy_drop[1], branch_drop[0],
+                                            branch_drop[1], ptr(dbranch), ptr(dcol), ptr(dcol_branch), stream_ptr()), "mmrca_layernorm_bwd_mixed")
 
 
 def embed_fwd(ids, pos_ids, word, pos, type_row, out, rows, D, dtype):

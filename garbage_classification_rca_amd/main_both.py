@@ -161,7 +161,7 @@ def main(argv=None):
     global_model = MM_RCA(_num_classes, args.model_dropout, args.image_text_dropout, args.image_prob_dropout,
                           args.num_neurons_FC, args.text_model, _batch_size, args.reverse, args.features_only,
                           args.cross_attention_only, image_model_name=args.image_model,
-                          dtype={"bf16": torch.bfloat16, "fp32": torch.float32, "bf16x3": "bf16x3"}[args.dtype], device=device, image_size=args.image_size)
+                          dtype={"bf16": torch.bfloat16, "fp32": torch.float32}.get(args.dtype, args.dtype), device=device, image_size=args.image_size)
     print("Num total parameters of the model: {}".format(count_parameters(global_model)))
     wandb = _wandb() if is_main else _NoWandb()
     wandb.init(project="Garbage Classification Both - MI355X", config=dict(args.__dict__))

@@ -28,7 +28,9 @@ enum { MMRCA_F32 = 0, MMRCA_BF16 = 1 };
 enum { MMRCA_ACT_NONE = 0, MMRCA_ACT_GELU = 1,
        MMRCA_ACT_GELU_BWD = 2,        /* C = (A.B) * gelu'(preact); preact (the saved pre-activation) is an INPUT */
        MMRCA_ACT_GELU_SAVE_GRAD = 3,  /* C = gelu(v), preact <- gelu'(v): the forward emits the derivative (shares the erf) */
-       MMRCA_ACT_MUL = 4 };           /* C = (A.B) * preact; preact is an INPUT (pairs with GELU_SAVE_GRAD) */
+       MMRCA_ACT_MUL = 4,             /* C = (A.B) * preact; preact is an INPUT (pairs with GELU_SAVE_GRAD) */
+       MMRCA_ACT_GELU_SAVE_GRAD_BF16 = 5 }; /* mmrca_gemm_x3 only: GELU_SAVE_GRAD with gelu' stored as bf16 (not fp32) -- the form the bf16
+                                              * backward of the bf16x3f mode reads */
 /* operand layouts of mmrca_gemm: ROWK = [rows][contraction] (contraction contiguous),
  * KROW = [contraction][rows] (rows contiguous) */
 enum { MMRCA_ROWK = 0, MMRCA_KROW = 1 };
@@ -246,6 +248,12 @@ int mmrca_mha_bwd(const void* qkv, const int32_t* key_mask, const void* out, con
 int mmrca_mha_fwd_planes(const void* qkv, const int32_t* key_mask, void* out, void* out_hi, void* out_lo, float* lse,
                          int B, int H, int S, int dh, float scale, float drop_p, uint64_t drop_seed,
                          const int32_t* cu_seqlens, void* stream);
+/* The same with q|k|v given as the two bf16 planes a bf16x3 GEMM wrote (qkv_hi + qkv_lo; mmrca_gemm_x3 with C_lo != NULL): the
+ * fp32 values are rebuilt on load.  The bf16x3f mode uses it so that its bf16 backward can read qkv_hi as the bf16 q|k|v.
+ * out (the fp32 context) may be NULL: only the planes are written. */
+int mmrca_mha_fwd_planes_in(const void* qkv_hi, const void* qkv_lo, const int32_t* key_mask, void* out, void* out_hi, void* out_lo,
+                            float* lse, int B, int H, int S, int dh, float scale, float drop_p, uint64_t drop_seed,
+                            const int32_t* cu_seqlens, void* stream);
 /* mmrca_mha_bwd followed by dqkv_colsum[3*H*dh] (fp32) += column sums of the stored dqkv = the bias gradient of the QKV
  * in-projection (one call; the reduction is a separate HBM pass -- fusing it into the MFMA kernels measured slower).
  * total_rows = number of token rows (B*S padded, cu_seqlens[B] packed). */
@@ -302,6 +310,14 @@ int mmrca_layernorm_bwd(const void* dy, const void* s, const void* gamma, const 
                         int64_t rows, int D, int64_t ld_dy, int64_t ld_s, int64_t ld_ds,
                         float dy_drop_p, uint64_t dy_drop_seed, float branch_drop_p, uint64_t branch_drop_seed,
                         void* dbranch, float* dcol, float* dcol_branch, int dtype, void* stream);
+/* The same with bf16 gradients / gamma (dy, dres, ds, dbranch, gamma) against an fp32 saved sum `s`: the LayerNorm backward of the
+ * bf16x3f mode, whose forward keeps the residual stream in fp32 (as the reference does, CVPR_code/multimodal_model.py:651-659)
+ * while its backward runs at bf16 precision.  D % 8 == 0, D <= 1024, 16-byte aligned operands. */
+int mmrca_layernorm_bwd_mixed(const void* dy, const float* s, const void* gamma, const float* mean, const float* rstd,
+                              const void* dres, void* ds, float* dgamma, float* dbeta,
+                              int64_t rows, int D, int64_t ld_dy, int64_t ld_s, int64_t ld_ds,
+                              float dy_drop_p, uint64_t dy_drop_seed, float branch_drop_p, uint64_t branch_drop_seed,
+                              void* dbranch, float* dcol, float* dcol_branch, void* stream);
 
 /* K5a. text embeddings: out[r] = word[ids[r]] + pos[pos_ids[r]] (+ type_row)   (modeling_distilbert.py:82-118,
  * BertEmbeddings; LayerNorm follows via mmrca_add_layernorm_fwd).  ids/pos_ids int32 [rows]. */

@@ -291,9 +291,26 @@ def _free_port():
         return sk.getsockname()[1]
 
 
+_RENDEZVOUS_ERRORS = ("address already in use", "eaddrinuse", "errno 98", "rendezvous", "connection refused", "failed to connect",
+                      "the server socket has failed", "could not connect", "connection reset by peer")
+
+
+def _guarded_rank(worker, rank, world, port, q):
+    """runs in the spawned process: a failure travels to the parent as text, so that it can tell a rendezvous problem (retry on a
+    fresh port) from a real failure of the code under test (no retry)"""
+    try:
+        worker(rank, world, port, q)
+    except BaseException as e:          # noqa: BLE001 -- reported, then re-raised
+        import traceback
+        q.put(("__error__", rank, f"{type(e).__name__}: {e}\n{traceback.format_exc()}"))
+        raise
+
+
 def _run_world2(worker, attempts=3):
-    """start two spawned ranks of `worker(rank, world, port, queue)` and collect their two results; a rendezvous that does not come
-    up (the probed port was taken in the meantime by another process on the host) is retried on a fresh port"""
+    """start two spawned ranks of `worker(rank, world, port, queue)` and collect their two results.  ONLY a rendezvous that does not
+    come up (the probed port was taken in the meantime: address-in-use / connection errors from the store) is retried, on a fresh
+    port; any other exception, a non-zero exit without such a message, or a timeout fails the test at once -- an intermittent
+    failure of the code under test (stream ordering, bucket merging in GradSync) must not be retried away."""
     import queue as _queue
     import torch.multiprocessing as mp
     last = None
@@ -301,23 +318,46 @@ def _run_world2(worker, attempts=3):
         ctx = mp.get_context("spawn")
         q = ctx.Queue()
         port = _free_port()
-        procs = [ctx.Process(target=worker, args=(r, 2, port, q)) for r in range(2)]
+        procs = [ctx.Process(target=_guarded_rank, args=(worker, r, 2, port, q)) for r in range(2)]
         for p in procs:
             p.start()
+        res, errors = [], []
         try:
-            res = [q.get(timeout=120) for _ in range(2)]
+            while len(res) + len(errors) < 2:
+                item = q.get(timeout=120)
+                (errors if isinstance(item, tuple) and len(item) == 3 and item[0] == "__error__" else res).append(item)
+        except _queue.Empty:
             for p in procs:
-                p.join(60)
-            if all(p.exitcode == 0 for p in procs):
-                return res
-            last = [p.exitcode for p in procs]
-        except _queue.Empty as e:
-            last = e
+                if p.is_alive():
+                    p.terminate()
+                p.join(10)
+            if not errors:
+                raise AssertionError(f"world-2 workers timed out (exit codes {[p.exitcode for p in procs]}): not retried")
         for p in procs:
+            p.join(60)
             if p.is_alive():
                 p.terminate()
-            p.join(10)
-    raise AssertionError(f"world-2 workers did not complete: {last}")
+                p.join(10)
+        if not errors and all(p.exitcode == 0 for p in procs):
+            return res
+        text = "\n".join(e[2] for e in errors)
+        if errors and any(pat in text.lower() for pat in _RENDEZVOUS_ERRORS):
+            last = text
+            continue                    # the only retried case
+        raise AssertionError(f"world-2 worker failed (exit codes {[p.exitcode for p in procs]}), not a rendezvous error, not retried:\n{text}")
+    raise AssertionError(f"world-2 rendezvous did not come up in {attempts} attempts: {last}")
+
+
+def _always_fails_worker(rank, world, port, q):
+    raise ValueError("a real failure of the code under test")
+
+
+def test_run_world2_does_not_retry_a_real_failure():
+    import time
+    t0 = time.time()
+    with pytest.raises(AssertionError, match="not a rendezvous error"):
+        _run_world2(_always_fails_worker)
+    assert time.time() - t0 < 100      # one attempt, not three
 
 
 def test_gradient_sync_world2_equals_full_batch_gradient():

@@ -14,8 +14,14 @@ from oracle import model as O                            # noqa: E402
 def main():
     from tests.test_x3_gpu import _pair_init_weights
     from tests.test_engine_gpu import _inputs, rel
+    from garbage_classification_rca_amd.engine import MMRCAEngine
     B, S_len = 3, 24
     eng, orc, sd = _pair_init_weights(0)
+    if len(sys.argv) > 1:          # another precision mode on the same weights: python tools/x3_grad_error.py bf16x3f | bf16 | fp32
+        dt = {"bf16": torch.bfloat16, "fp32": torch.float32}.get(sys.argv[1], sys.argv[1])
+        eng.release_buffers()
+        eng = MMRCAEngine("distilbert", "transformer_B16", 4, True, 0, dt)
+        eng.load_arrays(sd)
     ids, mask, images = _inputs(B, S_len)
     logits = eng.forward(ids.cuda(), mask.cuda(), images.cuda())
     orc = orc.double()
