@@ -98,7 +98,7 @@ def cpu_baseline(batches=(4, 32), steps=3, seq_len=64, text_model="distilbert", 
                       f"torch.set_num_threads({n}) = min(affinity, cgroup quota) of this box"}
 
 
-def parity_check(model, ids, mask, images, n=8):
+def parity_check(model, ids, mask, images, n=8, others=True):
     """Logits of all three precision modes of the engine against the oracle (CPU fp32) on the first `n` synthetic pairs, with
     the benchmarked model's CURRENT weights (eval mode: no dropout).  Runs after the timed region; the oracle is the checker
     here, never the thing measured."""
@@ -128,7 +128,7 @@ def parity_check(model, ids, mask, images, n=8):
     out = {own + "_logits_rel": round(rel(eng.forward(ids[:n], mask[:n], images[:n], save=False, text_pack=pack)), 8), "samples": n,
            "benchmarked_mode": own,
            "reference": "oracle (CPU fp32 restatement pinned by the reference's goldens), same weights, eval mode"}
-    for name, dt in (("bf16", torch.bfloat16), ("bf16x3", "bf16x3"), ("fp32", torch.float32)):
+    for name, dt in (("bf16", torch.bfloat16), ("bf16x3", "bf16x3"), ("fp32", torch.float32)) if others else ():
         if name == own or (name == "bf16x3" and own == "bf16x3f"):      # (bf16x3f's forward IS the bf16x3 forward)
             continue
         e2 = MMRCAEngine(eng.ts.name, img_name, eng.n_classes, eng.reverse, eng.mode, dt, eng.device)
@@ -140,6 +140,71 @@ def parity_check(model, ids, mask, images, n=8):
         del e2
     out["north_star_bound"] = 1e-3
     out["modes_meeting_the_bound"] = [k[:-len("_logits_rel")] for k, v in out.items() if k.endswith("_logits_rel") and v <= 1e-3]
+    if "bf16x3" in out["modes_meeting_the_bound"] and "bf16x3f" not in out["modes_meeting_the_bound"]:
+        out["modes_meeting_the_bound"].append("bf16x3f")          # its forward IS the bf16x3 forward (same kernels, same logits)
+    return out
+
+
+def compliant_leg(args, dev, parity, steps=12, warmup=3):
+    """A second, short timed leg of the SAME workload (same batch, shapes, optimizer, synthetic tensors, packed captions) in the
+    fastest precision mode whose forward logits meet north_star's bound (<= 1e-3 relative to the fp32 reference,
+    CVPR_code/multimodal_model.py:651-726), so that the driver's own line carries a timed number for a compliant mode next to the
+    bf16 headline.  Candidates in order of speed: bf16x3f (the bf16x3 forward with the bf16 backward), bf16x3, fp32; the choice is
+    made on the parity object measured on the headline's weights.  The leg trains its own replica from the same seed; its
+    `logits_rel` is measured on ITS weights after ITS steps (8 pairs against the oracle), and the figure on the headline's
+    post-run weights is repeated next to it."""
+    from garbage_classification_rca_amd.engine import make_text_pack
+    from garbage_classification_rca_amd.multimodal_model import MM_RCA
+    from garbage_classification_rca_amd.optim import FlatSGD
+    from garbage_classification_rca_amd.procedural import synth_captions
+    from garbage_classification_rca_amd.training import FusedCrossEntropy, hip_train_step, PACK_TEXT
+    import contextlib
+    import io
+    fwd_of = {"bf16x3f": "bf16x3", "bf16x3": "bf16x3", "fp32": "fp32"}
+    mode = next((m for m in ("bf16x3f", "bf16x3", "fp32") if parity.get(fwd_of[m] + "_logits_rel", 1.0) <= 1e-3), None)
+    if mode is None:
+        return {"dtype": None, "note": "no mode met the bound on the headline's weights"}
+    B, S = args.batch, args.seq_len
+    print(f"[bench] compliant leg: {mode}, {warmup} + {steps} steps at batch {B} ...", file=sys.stderr, flush=True)
+    with contextlib.redirect_stdout(io.StringIO()):
+        model = MM_RCA(4, 0.6, 0.0, 0.7, 256, args.text_model, B, True, False, args.cross_attention_only, image_model_name=args.image_model,
+                       dtype={"fp32": torch.float32}.get(mode, mode), device=dev, init_seed=0, image_size=args.image_size)
+    model.train()
+    for p in model.parameters():
+        p.requires_grad = True
+    opt, crit = FlatSGD(model, lr=1e-3, weight_decay=1e-2), FusedCrossEntropy(None, 0.0)
+    nb = 2
+    ids, mask_host = synth_captions(B * nb, S, seed=4321)
+    if args.text_model == "roberta":
+        ids[mask_host == 0] = 1
+    ids, mask = torch.from_numpy(ids).to(dev), torch.from_numpy(mask_host).to(dev)
+    images = torch.randn(B * nb, 3, args.image_size, args.image_size, device=dev, generator=torch.Generator(device=dev).manual_seed(1234))
+    labels = (torch.arange(B * nb, device=dev) % 4).to(torch.int32)
+
+    def step(i):
+        j = (i % nb) * B
+        return hip_train_step(model, ids[j:j + B], mask[j:j + B], images[j:j + B], labels[j:j + B], crit, opt, None,
+                              text_pack=(make_text_pack(mask_host[j:j + B], dev) if PACK_TEXT else None))
+    with contextlib.redirect_stdout(io.StringIO()):
+        for i in range(warmup):
+            step(i)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for i in range(steps):
+            loss = step(i)
+        torch.cuda.synchronize()
+        elapsed = time.perf_counter() - t0
+        own = parity_check(model, ids, mask, images, others=False)
+    model.engine.release_buffers()
+    key = mode + "_logits_rel"
+    out = {"dtype": mode, "value": round(B * steps / elapsed, 2), "unit": "samples/s", "ms_per_step": round(elapsed / steps * 1e3, 3), "steps": steps,
+           "warmup": warmup, "per_gpu_batch": B, "logits_rel": own[key], "logits_rel_measured_on": f"this leg's weights after its {warmup + steps} steps, 8 pairs vs the oracle",
+           "logits_rel_on_headline_weights": parity.get(fwd_of[mode] + "_logits_rel"), "north_star_bound": 1e-3, "final_loss": round(float(loss.item()), 4),
+           "what": {"bf16x3f": "forward: fp32 residual stream / LayerNorm / attention (fp32 matrix cores), every nn.Linear as a three-pass split-bf16 product "
+                               "(the bf16x3 forward, same logits); backward: the bf16 mode's (single-pass bf16 products and bf16 attention backward on the hi planes "
+                               "of the saved activations, bf16 gradient buffers, fp32 gradient accumulation and optimizer)",
+                    "bf16x3": "fp32 storage, every nn.Linear (forward and backward) as a three-pass split-bf16 product, fp32 attention",
+                    "fp32": "every GEMM and the attention on the fp32 matrix cores"}[mode]}
     return out
 
 
@@ -284,6 +349,7 @@ def main():
     ap.add_argument("--batch", type=int, default=256, help="per-GPU batch (BASELINE config: 256)")
     ap.add_argument("--seq_len", type=int, default=64)
     ap.add_argument("--no_cpu_baseline", action="store_true")
+    ap.add_argument("--no_compliant", action="store_true", help="skip the second timed leg in the fastest mode that meets the 1e-3 logits bound")
     ap.add_argument("--dtype", default="bf16", choices=("bf16", "fp32", "bf16x3", "bf16x3f"),
                     help="bf16 (the benchmarked configuration) | bf16x3: the fast <= 1e-3 mode -- fp32 storage / residual stream / LayerNorm / "
                          "attention, every nn.Linear as a three-pass split-bf16 product on the bf16 matrix cores | fp32: every GEMM on the fp32 matrix cores")
@@ -579,6 +645,9 @@ def main():
         if not args.no_cpu_baseline and world == 1:
             with contextlib.redirect_stdout(io.StringIO()):
                 out["parity"] = parity_check(model, ids, mask, images)
+            if args.dtype == "bf16" and not args.frozen and eng.conv is None and not args.no_compliant:
+                eng.release_buffers()
+                out["compliant"] = compliant_leg(args, dev, out["parity"])
             out["cpu_baseline"] = cpu_baseline(seq_len=S, text_model=args.text_model, image_model=args.image_model, image_size=args.image_size)
         print(json.dumps(out), flush=True)
     if world > 1:
