@@ -119,7 +119,7 @@ class ConvEncoder:
                 ci, st = (cin if i == 0 else cout), (stride if i == 0 else 1)
                 cexp = ci * expand
                 P = f"{sname}.{i}.block"
-                blk = dict(kind="fused" if fused else "mb", res=(st == 1 and ci == cout), sd=spec["sd"] * bid / total, units=[], se=None)
+                blk = dict(kind="fused" if fused else "mb", res=(st == 1 and ci == cout), sd=spec["sd"] * bid / total, units=[], se=None, stage=sname)
                 if fused:
                     if cexp != ci:
                         blk["units"] = [_Unit(P + ".0.0", P + ".0.1", ci, cexp, 3, st, L.CONV_SILU), _Unit(P + ".1.0", P + ".1.1", cexp, cout, 1, 1, L.CONV_NONE)]
@@ -151,12 +151,12 @@ class ConvEncoder:
                     b2 = [U(P + ".branch2.0", P + ".branch2.1", inp, bf, 1, 1, L.CONV_RELU),
                           U(P + ".branch2.3", P + ".branch2.4", bf, bf, 3, 2, L.CONV_NONE, dw=True),
                           U(P + ".branch2.5", P + ".branch2.6", bf, bf, 1, 1, L.CONV_RELU)]
-                    self.blocks.append(dict(kind="shuffle_down", b1=b1, b2=b2, cin=inp, cout=oup))
+                    self.blocks.append(dict(kind="shuffle_down", b1=b1, b2=b2, cin=inp, cout=oup, stage=sname))
                 else:
                     b2 = [U(P + ".branch2.0", P + ".branch2.1", bf, bf, 1, 1, L.CONV_RELU),
                           U(P + ".branch2.3", P + ".branch2.4", bf, bf, 3, 1, L.CONV_NONE, dw=True),
                           U(P + ".branch2.5", P + ".branch2.6", bf, bf, 1, 1, L.CONV_RELU)]
-                    self.blocks.append(dict(kind="shuffle", b2=b2, cin=oup, cout=oup))
+                    self.blocks.append(dict(kind="shuffle", b2=b2, cin=oup, cout=oup, stage=sname))
             inp = oup
         self.final = U("conv5.0", "conv5.1", inp, ch[4], 1, 1, L.CONV_RELU)
 
@@ -585,6 +585,10 @@ class ConvEncoder:
         dy = self.buf("g.dfinal", B * HW, self.dim)
         L.rowpool_mean_bwd(dpool, dy, B, HW, self.dim, False, dt)
         dx = self._unit_bwd(self.final, dy, sv["final"], B)
+        # the gradients of a stage are final once its first block's backward is queued: hand them to the data-parallel exchange
+        # stage by stage (engine._ready -> GradSync.span_ready), so that it overlaps the backward of the stages below
+        ready = getattr(self.o, "_ready", None) or (lambda group: None)      # (a bare owner in the kernel tests has no exchange)
+        ready("image_stage_" + ("conv5" if self.name == "shuffle_net" else "final_conv"))
         for bi in reversed(range(len(self.blocks))):
             blk, bs = self.blocks[bi], sv["blocks"][bi]
             gp = f"g{bi % 2}"          # gradient buffers alternate between two pools: the incoming gradient (written by block
@@ -635,6 +639,8 @@ class ConvEncoder:
                 L.channel_gather(d1, self._cmap(("id", bf), list(range(bf))), out, rows, bf, bf, Cc, 0, dt)
                 L.channel_gather(d2, self._cmap(("id", bf), list(range(bf))), out, rows, bf, bf, Cc, bf, dt)
                 dx = out
+            if bi == 0 or self.blocks[bi - 1]["stage"] != blk["stage"]:
+                ready("image_stage_" + blk["stage"])
         if self.name == "shuffle_net":
             p = sv["pool"]
             c0 = self.stem.cout

@@ -119,11 +119,14 @@ class GradSync:
     """Overlapped gradient averaging over contiguous slices of a flat gradient buffer."""
 
     def __init__(self, flat_grads: torch.Tensor, world: Optional[int] = None, bucket_bytes: int = 32 << 20,
-                 wire_dtype: Optional[torch.dtype] = None):
+                 wire_dtype: Optional[torch.dtype] = None, force: bool = False):
         """wire_dtype=torch.bfloat16 (or MMRCA_GRAD_WIRE=bf16): each span is cast to bf16 on the producer stream, reduced in
         bf16 (half the bytes on xGMI: 304 MB instead of 609 MB per step for configs[1]) and written back into the fp32
-        arena by finish().  Default: fp32 on the wire (bit-identical replicas, exact average)."""
+        arena by finish().  Default: fp32 on the wire (bit-identical replicas, exact average).
+        force: issue the collectives even when world == 1 (a one-GPU box can then drive the RCCL path itself -- ReduceOp.AVG, the
+        bf16 wire, producer streams -- which is what tests/test_rccl_gpu.py does)."""
         self.g = flat_grads
+        self.force = force
         if wire_dtype is None and os.environ.get("MMRCA_GRAD_WIRE", "fp32") == "bf16":
             wire_dtype = torch.bfloat16
         self.wire_dtype = wire_dtype
@@ -140,7 +143,7 @@ class GradSync:
     def span_ready(self, lo: int, hi: int, flush: bool = False):
         """Called by the engine when grads in [lo, hi) are final.  Adjacent ready spans are merged until a bucket is
         full (spans arrive in descending address order within an encoder)."""
-        if not self.enabled or self.world == 1 or hi <= lo:
+        if not self.enabled or (self.world == 1 and not self.force) or hi <= lo:
             return
         if self._acc_lo is not None and hi == self._acc_lo:
             self._acc_lo = lo

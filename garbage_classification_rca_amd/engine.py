@@ -257,6 +257,11 @@ class MMRCAEngine:
             return f"image_layer_{int(m.group(1))}"
         if key.startswith("image_model.encoder.ln"):
             return "image_ln"
+        # conv backbones (conv_engine.py): one group per stage, so that the gradient exchange of stage k overlaps the backward of the
+        # stages below it (the stem stays "image_emb": the group the encoder's backward finishes with)
+        m = re.match(r"image_model\.(stem\.1|stage\d+|final_conv|conv5)\.", key)
+        if m:
+            return "image_stage_" + m.group(1)
         if key.startswith("image_model."):
             return "image_emb"
         return "head"

@@ -16,6 +16,13 @@
  *     accumulation and fp32 softmax/LayerNorm statistics (the benchmarked mode).
  *   - parameter gradients are always fp32 and are ACCUMULATED (+=) into the caller's gradient arena,
  *     which is what main_both.py:112-124 relies on for its sum-not-mean gradient accumulation.
+ *   - NO communication entry points, by decision (SURVEY section 8(b) sketched mmrca_comm_init / mmrca_allreduce /
+ *     mmrca_comm_destroy): the one exchange step of the path -- the data-parallel gradient average that replaces
+ *     nn.DataParallel, main_both.py:386-388 -- runs on RCCL through torch.distributed (backend "nccl"), one process per GPU,
+ *     directly over contiguous slices of the same flat fp32 gradient arena these kernels accumulate into
+ *     (garbage_classification_rca_amd/distributed.py::GradSync: asynchronous all-reduce per finished parameter group, fp32 or
+ *     bf16 on the wire).  A second, library-private RCCL communicator would duplicate the rendezvous torch already made and buy
+ *     no bytes or launches; tests/test_rccl_gpu.py executes that path on the real library.
  */
 #ifndef MMRCA_H
 #define MMRCA_H
