@@ -476,6 +476,13 @@ def main():
             step(i)
         torch.cuda.synchronize()
         serial_ms = (time.perf_counter() - ts0) / replay * 1e3
+        cprof = None
+        if eng.conv is not None:       # conv image encoder: a third replay with every launch's ALGORITHMIC bytes and HIP-event time
+            L.CONV_PROFILE = []
+            for i in range(replay):
+                step(i)
+            torch.cuda.synchronize()
+            cprof, L.CONV_PROFILE = L.CONV_PROFILE, None
     prof, L.GEMM_PROFILE = L.GEMM_PROFILE, None
     kprof, L.KERNEL_PROFILE = L.KERNEL_PROFILE, None
     eng._side_v, eng._side_t, eng._side, eng._text_stream = saved_streams
@@ -640,6 +647,31 @@ def main():
                          "whole_step_nominal_model_TFLOPs": round(value / world * train_flop_per_sample / 1e12, 2),
                          "attention": attention, "head": head},
         }
+        if cprof is not None:
+            # The conv step is HBM-shaped (BatchNorm / depthwise / squeeze-excitation passes, wide-output 1x1 GEMMs): its binding
+            # roofline is bytes, not FLOPs.  Algorithmic bytes = every operand an op must read once + every result it must write once,
+            # from the launch arguments (lib._CONV_BYTES), summed over the step as it is decomposed into kernels today.
+            fam = {}
+            for name, nbytes, e0, e1 in cprof:
+                d = fam.setdefault(name, [0, 0.0, 0])
+                d[0] += nbytes; d[2] += 1
+                if e0 is not None:
+                    d[1] += e0.elapsed_time(e1)
+            gemm_ms = sum(p[2].elapsed_time(p[3]) for p in prof) / replay
+            tot_b = sum(v[0] for v in fam.values()) / replay
+            table = {}
+            for name, (nb, ms_, n) in sorted(fam.items(), key=lambda kv: -kv[1][0]):
+                ms1 = (ms_ / replay) if ms_ > 0 else (gemm_ms if name.startswith("GEMM") else None)
+                table[name] = {"GB_per_step": round(nb / replay / 1e9, 2), "launches_per_step": n // replay, "ms_per_step": None if ms1 is None else round(ms1, 2),
+                               "TBps": None if not ms1 else round(nb / replay / (ms1 * 1e-3) / 1e12, 2)}
+            floor_ms = tot_b / 8e12 * 1e3
+            out["roofline"]["hbm"] = {
+                "bound": "hbm", "what": "whole train step of the conv image encoder + text encoder: algorithmic HBM bytes of every launch (operands read once + results "
+                                        "written once, per launch arguments; GEMM ms = HIP events of the matrix-core launches, a few small GEMMs excluded) against the 8 TB/s peak",
+                "algorithmic_GB_per_step": round(tot_b / 1e9, 2), "floor_ms_at_8TBps": round(floor_ms, 2), "floor_ms_at_6.3TBps_achievable": round(tot_b / 6.3e12 * 1e3, 2),
+                "step_ms": round(elapsed / args.steps * 1e3, 2), "achieved_TBps": round(tot_b / (elapsed / args.steps) / 1e12, 3), "peak_TBps": 8.0,
+                "frac": round(floor_ms / (elapsed / args.steps * 1e3), 4), "families": table,
+                "note": "frac = byte floor / measured step: how far the step is from the roofline that binds it; the MFMA frac above covers the GEMM launches only"}
         if comm is not None:
             out["comm"] = comm
         if not args.no_cpu_baseline and world == 1:

@@ -198,6 +198,13 @@ class _Bracket:
         return False
 
 
+def _esz(dt):
+    return 2 if dt == BF16 else 4
+
+
+CONV_PROFILE = None     # bench.py sets this to a list: (kernel family, algorithmic HBM bytes, start event, end event) of every conv-path launch
+
+
 def gemm_is_mfma(M, N, K, a_layout, dtype, impl):
     return dtype == BF16 and impl != IMPL_REF and N % 128 == 0 and K % 64 == 0 and (a_layout == ROWK or M % 128 == 0)
 
@@ -231,6 +238,10 @@ def gemm(A, B, Cout, *, bias=None, addend=None, preact=None, M, N, K, lda, ldb, 
     if prof:
         e1.record()
         GEMM_PROFILE.append((2.0 * M * N * K, (a_layout, b_layout, int(accum)), e0, e1, (M, N, K, act)))
+    if CONV_PROFILE is not None:         # byte accounting of the conv step (every GEMM, matrix-core qualified or not)
+        es = _esz(dtype)
+        side = (1 if addend is not None else 0) + (1 if preact is not None else 0)
+        CONV_PROFILE.append(("GEMM (1x1 conv / patch matrix / text encoder)", int((M * K + N * K) * es + M * N * ((4 if accum else es) + side * es)), None, None))
 
 
 SPLITK_WS_BYTES = 64 << 20      # 256 partial tiles of 256x256 fp32: enough for every shape mmrca_gemm_splitk accepts
@@ -252,6 +263,8 @@ def gemm_splitk(A, B, Cout, workspace, *, M, N, K, lda, ldb, ldc, a_layout=KROW,
     if prof:
         e1.record()
         GEMM_PROFILE.append((2.0 * M * N * K, (a_layout, b_layout, 1), e0, e1, (M, N, K, ACT_NONE)))
+    if CONV_PROFILE is not None:
+        CONV_PROFILE.append(("GEMM (1x1 conv / patch matrix / text encoder)", int((M * K + N * K) * 2 + M * N * 4), None, None))
 
 
 def gemm_x3(A, B, Cout, *, C_lo=None, bias=None, addend=None, preact=None, colsum=None, M, N, K, lda, ldb, ldc, a_layout=ROWK,
@@ -486,7 +499,58 @@ def cast_f32_to_bf16(src, dst, n):
 CONV_NONE, CONV_SILU, CONV_RELU, CONV_SIGMOID = 0, 1, 2, 3
 
 
+def _out_hw(H, W, s):
+    return (H - 1) // s + 1, (W - 1) // s + 1
+
+
+def _patch_bytes(a):          # (x, col, B, H, W, C, stride, ldk, dtype): the input rows once + the patch matrix once
+    Ho, Wo = _out_hw(a[3], a[4], a[6])
+    return (a[2] * a[3] * a[4] * a[5] + a[2] * Ho * Wo * a[7]) * _esz(a[8])
+
+
+def _dw_bwd_bytes(a):         # (dy, x, w, dx, dw, B, H, W, C, stride, dtype, ...): dy (output rows) + x + dx (input rows)
+    Ho, Wo = _out_hw(a[6], a[7], a[9])
+    return a[5] * a[8] * (Ho * Wo + 2 * a[6] * a[7]) * _esz(a[10])
+
+
+# ALGORITHMIC HBM bytes of one launch (every operand the op must read once + every result it must write once, per-channel
+# vectors ignored), from the launch arguments: the byte roofline of the conv step in bench.py
+_CONV_BYTES = {
+    "mmrca_nchw_to_rows": ("layout", lambda a: a[2] * a[3] * a[4] * a[5] * (4 + _esz(a[6]))),
+    "mmrca_im2row3x3": ("patches", _patch_bytes), "mmrca_col2im3x3": ("patches", _patch_bytes),
+    "mmrca_im2row3x3_tap": ("patches", _patch_bytes), "mmrca_col2im3x3_tap": ("patches", _patch_bytes),
+    "mmrca_dwconv3x3_fwd": ("depthwise", lambda a: a[3] * a[6] * (a[4] * a[5] + _out_hw(a[4], a[5], a[7])[0] * _out_hw(a[4], a[5], a[7])[1]) * _esz(a[8])),
+    "mmrca_dwconv3x3_bwd": ("depthwise", _dw_bwd_bytes), "mmrca_dwconv3x3_bwd_ws": ("depthwise", _dw_bwd_bytes),
+    "mmrca_conv3x3_fwd": ("conv3x3 implicit GEMM", lambda a: (a[6] * a[7] * a[8] * (a[9] + a[10]) + 9 * a[9] * a[10]) * _esz(a[11])),
+    "mmrca_conv3x3_wgrad": ("conv3x3 implicit GEMM", lambda a: a[3] * a[4] * a[5] * (a[6] + a[7]) * _esz(a[8]) + 9 * a[6] * a[7] * 4),
+    "mmrca_gemm_bnstats": ("GEMM (1x1 / patch)", lambda a: (a[3] * a[5] + a[4] * a[5] + a[3] * a[4]) * _esz(a[9])),
+    "mmrca_bn_stats": ("BatchNorm", lambda a: a[5] * a[6] * _esz(a[11]) if a[10] else 0),
+    "mmrca_bn_act_fwd": ("BatchNorm", lambda a: 2 * a[6] * a[7] * _esz(a[9])),
+    "mmrca_bn_act_fwd_res": ("BatchNorm", lambda a: 3 * a[8] * a[9] * _esz(a[12])),
+    # backward with batch statistics: the sums need dy and z once, the apply pass needs them again and writes dx
+    "mmrca_bn_act_bwd": ("BatchNorm", lambda a: (5 if a[13] else 3) * a[10] * a[11] * _esz(a[14])),
+    "mmrca_bn_act_bwd_sums": ("BatchNorm", lambda a: 3 * a[10] * a[11] * _esz(a[14])),
+    "mmrca_rowpool_mean": ("pool / squeeze-excitation", lambda a: a[2] * a[3] * a[4] * _esz(a[5])),
+    "mmrca_rowpool_mean_bwd": ("pool / squeeze-excitation", lambda a: a[2] * a[3] * a[4] * _esz(a[6]) * (2 if a[5] else 1)),
+    "mmrca_se_scale_fwd": ("pool / squeeze-excitation", lambda a: 2 * a[3] * a[4] * a[5] * _esz(a[6])),
+    "mmrca_se_scale_bwd": ("pool / squeeze-excitation", lambda a: (3 if a[3] else 2) * a[5] * a[6] * a[7] * _esz(a[8])),
+    "mmrca_se_dx": ("pool / squeeze-excitation", lambda a: (3 if a[8] else 2) * a[4] * a[5] * a[6] * _esz(a[7])),
+    "mmrca_residual_add": ("residual", lambda a: (3 if a[0] else 2) * a[4] * a[5] * _esz(a[6])),
+    "mmrca_maxpool3x3s2_fwd": ("pool / squeeze-excitation", lambda a: a[3] * a[6] * (a[4] * a[5] * _esz(a[7]) + _out_hw(a[4], a[5], 2)[0] * _out_hw(a[4], a[5], 2)[1] * (_esz(a[7]) + 1))),
+    "mmrca_maxpool3x3s2_bwd": ("pool / squeeze-excitation", lambda a: a[3] * a[6] * (a[4] * a[5] * _esz(a[7]) + _out_hw(a[4], a[5], 2)[0] * _out_hw(a[4], a[5], 2)[1] * (_esz(a[7]) + 1))),
+    "mmrca_channel_gather": ("layout", lambda a: 2 * a[3] * a[5] * _esz(a[8])),
+}
+
+
 def _c(name, *args):
+    if CONV_PROFILE is not None:
+        fam, fn = _CONV_BYTES.get(name, ("other", lambda a: 0))
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        _check(getattr(load(), name)(*args, stream_ptr()), name)
+        e1.record()
+        CONV_PROFILE.append((fam, int(fn(args)), e0, e1))
+        return
     _check(getattr(load(), name)(*args, stream_ptr()), name)
 
 
