@@ -822,7 +822,7 @@ template <int NKT, int NW, bool SHARE>
 __global__ void __launch_bounds__(64 * NW, SHARE ? NW / 2 : NW / 4)
 mha_bwd_fused_mfma_v_k(const bf16_t* __restrict__ qkv, const bf16_t* __restrict__ out, const bf16_t* __restrict__ dout,
                        const float* __restrict__ lse, bf16_t* __restrict__ dqkv, int H, int S, float scale,
-                       unsigned long long* __restrict__ stamps) {
+                       unsigned long long* __restrict__ stamps, int prefetch) {
   // stamps (tools/attn_stamps.py only, nullptr otherwise): s_memtime of wave 0 at kernel entry, after the first staging barrier,
   // between the two parts and at exit, [block][4]; written to a buffer nothing else reads
   unsigned long long t_in = 0, t_staged = 0, t_mid = 0;
@@ -877,6 +877,19 @@ mha_bwd_fused_mfma_v_k(const bf16_t* __restrict__ qkv, const bf16_t* __restrict_
     }
   };
 
+  // SHARE: the per-tile operand fragments that come straight from global memory are PREFETCHED -- a wave's first query tile
+  // (Q | dO rows) at kernel entry, under the staging DMA; its first key tile (K | V rows) before the second staging -- so that their latency (in-kernel stamps: ~25 k of a workgroup's ~57 k
+  // cycles were spent waiting for exactly these loads) is not exposed for the first tiles (8 of the 13 per part).
+  bf16x8 pq0, pq1, pd0, pd1, pk0, pk1, pv0, pv1;
+  auto fetch_q = [&](int qt) {
+    pq0 = frag_global(Q, ld, qt * 16, S, 0, lane); pq1 = frag_global(Q, ld, qt * 16, S, 1, lane);
+    pd0 = frag_global(dO, ldo, qt * 16, S, 0, lane); pd1 = frag_global(dO, ldo, qt * 16, S, 1, lane);
+  };
+  auto fetch_k = [&](int kt) {
+    pk0 = frag_global(Kp, ld, kt * 16, S, 0, lane); pk1 = frag_global(Kp, ld, kt * 16, S, 1, lane);
+    pv0 = frag_global(Vp, ld, kt * 16, S, 0, lane); pv1 = frag_global(Vp, ld, kt * 16, S, 1, lane);
+  };
+
   // ---- dQ: a wave's query tile(s) against every key pair (K | V images, row constants in LDS)
   auto dq_part = [&]() {
     const unsigned kb0 = lds0 + KB + roff0, kb1 = lds0 + KB + roff1;
@@ -884,17 +897,9 @@ mha_bwd_fused_mfma_v_k(const bf16_t* __restrict__ qkv, const bf16_t* __restrict_
     unsigned tk[4];
 #pragma unroll
     for (int dt = 0; dt < 4; ++dt) tk[dt] = lds0 + KB + (4 * g + qq) * 128 + ((dt ^ vsw) << 5) + 8 * pp;
-    for (int qt = wave; qt < nt; qt += NW) {
+    auto dq_tile = [&](int qt, bf16x8 qf0, bf16x8 qf1, bf16x8 df0, bf16x8 df1) {
       const int q0 = qt * 16;
       const int q = q0 + l16;
-      bf16x8 qf0, qf1, df0, df1;
-      if constexpr (SHARE) {                          // the Q | dO images are gone: fragments from global memory (L2: staged moments ago)
-        qf0 = frag_global(Q, ld, q0, S, 0, lane); qf1 = frag_global(Q, ld, q0, S, 1, lane);
-        df0 = frag_global(dO, ldo, q0, S, 0, lane); df1 = frag_global(dO, ldo, q0, S, 1, lane);
-      } else {
-        qf0 = frag_rows(sm + QB, IMG_TR, q0, 0, lane); qf1 = frag_rows(sm + QB, IMG_TR, q0, 1, lane);
-        df0 = frag_rows(sm + DB, IMG_TR, q0, 0, lane); df1 = frag_rows(sm + DB, IMG_TR, q0, 1, lane);
-      }
       const float nl = lse_s[q], nd = dsum_s[q];      // row constants as the initial accumulators: S' = S - L/c1, dP' = dP - D
       f32x4 dq[4];
 #pragma unroll
@@ -945,6 +950,18 @@ mha_bwd_fused_mfma_v_k(const bf16_t* __restrict__ qkv, const bf16_t* __restrict_
         for (int r = 0; r < 4; ++r) v[r] = (bf16_t)(dq[dt][r] * scale);
         if (q < S) *reinterpret_cast<bf16x4*>(drow + dt * 16 + 4 * g) = v;
       }
+    };
+    if constexpr (SHARE) {
+      // the Q | dO images are gone: fragments from global memory -- the first tile's were prefetched at kernel entry; a second
+      // tile's are loaded here (prefetching them too costs 16 live registers inside the loop: spills)
+      if (wave < nt) { if (!prefetch) fetch_q(wave); dq_tile(wave, pq0, pq1, pd0, pd1); }
+      for (int qt = wave + NW; qt < nt; qt += NW)
+        dq_tile(qt, frag_global(Q, ld, qt * 16, S, 0, lane), frag_global(Q, ld, qt * 16, S, 1, lane), frag_global(dO, ldo, qt * 16, S, 0, lane),
+                frag_global(dO, ldo, qt * 16, S, 1, lane));
+    } else {
+      for (int qt = wave; qt < nt; qt += NW)
+        dq_tile(qt, frag_rows(sm + QB, IMG_TR, qt * 16, 0, lane), frag_rows(sm + QB, IMG_TR, qt * 16, 1, lane), frag_rows(sm + DB, IMG_TR, qt * 16, 0, lane),
+                frag_rows(sm + DB, IMG_TR, qt * 16, 1, lane));
     }
   };
 
@@ -958,18 +975,10 @@ mha_bwd_fused_mfma_v_k(const bf16_t* __restrict__ qkv, const bf16_t* __restrict_
     }
     const unsigned qb0 = lds0 + QB + roff0, qb1 = lds0 + QB + roff1, db0 = lds0 + DB + roff0, db1 = lds0 + DB + roff1;
     const unsigned lb = lds0 + ST + 16 * g, sb = lb + Spad * 4;      // row constants of queries 16 qt + 4 g + r
-    for (int kt = wave; kt < nt; kt += NW) {
+    auto dkv_tile = [&](int kt, bf16x8 kf0, bf16x8 kf1, bf16x8 vf0, bf16x8 vf1) {
       const int k0 = kt * 16;
       const int key = k0 + l16;
       const float kbias = key < S ? 0.f : -INFINITY;                        // this lane's key
-      bf16x8 kf0, kf1, vf0, vf1;
-      if constexpr (SHARE) {
-        kf0 = frag_global(Kp, ld, k0, S, 0, lane); kf1 = frag_global(Kp, ld, k0, S, 1, lane);
-        vf0 = frag_global(Vp, ld, k0, S, 0, lane); vf1 = frag_global(Vp, ld, k0, S, 1, lane);
-      } else {
-        kf0 = frag_rows(sm + KB, IMG_TR, k0, 0, lane); kf1 = frag_rows(sm + KB, IMG_TR, k0, 1, lane);
-        vf0 = frag_rows(sm + VB, IMG_ROW, k0, 0, lane); vf1 = frag_rows(sm + VB, IMG_ROW, k0, 1, lane);
-      }
       f32x4 dk[4], dv[4];
 #pragma unroll
       for (int dt = 0; dt < 4; ++dt) { dk[dt] = (f32x4){0.f, 0.f, 0.f, 0.f}; dv[dt] = (f32x4){0.f, 0.f, 0.f, 0.f}; }
@@ -1028,16 +1037,28 @@ mha_bwd_fused_mfma_v_k(const bf16_t* __restrict__ qkv, const bf16_t* __restrict_
           *reinterpret_cast<bf16x4*>(vrow + dt * 16 + 4 * g) = c;
         }
       }
+    };
+    if constexpr (SHARE) {
+      if (wave < nt) { if (!prefetch) fetch_k(wave); dkv_tile(wave, pk0, pk1, pv0, pv1); }
+      for (int kt = wave + NW; kt < nt; kt += NW)
+        dkv_tile(kt, frag_global(Kp, ld, kt * 16, S, 0, lane), frag_global(Kp, ld, kt * 16, S, 1, lane), frag_global(Vp, ld, kt * 16, S, 0, lane),
+                 frag_global(Vp, ld, kt * 16, S, 1, lane));
+    } else {
+      for (int kt = wave; kt < nt; kt += NW)
+        dkv_tile(kt, frag_rows(sm + KB, IMG_TR, kt * 16, 0, lane), frag_rows(sm + KB, IMG_TR, kt * 16, 1, lane), frag_rows(sm + VB, IMG_ROW, kt * 16, 0, lane),
+                 frag_rows(sm + VB, IMG_ROW, kt * 16, 1, lane));
     }
   };
 
   if constexpr (SHARE) {
+    if (prefetch && wave < nt) fetch_q(wave);       // lands under the staging below
     stage_key_side();
     stage_row_constants();              // reads whole dO / O rows: the dO fragments of the dQ part then hit L2
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     if (stamps) t_staged = __builtin_amdgcn_s_memtime();
     dq_part();
+    if (prefetch && wave < nt) fetch_k(wave);       // lands under the second staging
     __syncthreads();                    // every wave is done with the K | V images (the row constants stay)
     stage_query_images();
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -1107,6 +1128,384 @@ static int pick_nkt(int S) {
     case 16: AT_LAUNCH8(KERNEL, 16, W8_PLAIN, W8_DROP, 2 * 16 * 16 * 128 + EXTRA(16), __VA_ARGS__); break;         \
     default: AT_LAUNCH8(KERNEL, 32, (W8_PLAIN && W8_32), (W8_DROP && W8_32), 2 * 32 * 16 * 128 + EXTRA(32), __VA_ARGS__); break; \
   }
+// ------------------------------------------------------------------------------------------------------
+// backward for the ViT, PERSISTENT over heads: every operand crosses the fabric ONCE
+// ------------------------------------------------------------------------------------------------------
+// The fused kernel above time-shares one 56-KiB region between the K | V and the Q | dO images, so each of Q, K, V, dO is read
+// twice (once as an image, once as per-tile fragments) and most of the second reads miss L2 (64 resident workgroups x ~126 KB per
+// XCD against 4 MiB): PMC, corrected for 16-byte lanes: 689 MB fetched per launch against 389 MB of operands.
+// The kernel is then bandwidth-shaped (3.9 TB/s of fabric traffic over its 235 us), so the re-reads are its time.
+// Here ONE 16-wave workgroup per CU walks heads bh = blockIdx.x, + gridDim.x, ... with SIX image slots of 13 tiles (208 rows,
+// 26 KiB; the seventh key / query pair of the loops reads 16 rows past an image, i.e. the first rows of the next slot or the
+// zeroed pad behind the last one: finite values that every consumer multiplies by an exact zero):
+//     slots 0,1 / 2,3: K | V of the even / odd heads of this workgroup;  slots 4,5: Q | dO of the current head
+//   top of an iteration (vmcnt(0) + barrier): K | V, Q | dO and the row constants of head i are in LDS
+//   1. the DMA of head i+1's K | V is issued into the other K | V pair            (lands under the dK / dV part)
+//   2. dK / dV part: a wave's key tile against every query pair (Q | dO images; its K / V fragments from the K | V images)
+//   3. every wave takes the Q | dO fragments and row constants of its query tile into registers; barrier (LDS only)
+//   4. the DMA of head i+1's Q | dO is issued over slots 4,5 and the three waves without a tile compute head i+1's row constants
+//      (from whole dO / O rows)                                                   (both land under the dQ part)
+//   5. dQ part: a wave's query tile (fragments in registers) against every key pair (K | V images)
+// All LDS reads of the loop are inline asm and nothing spills, so no compiler-made vmcnt(0) waits for the DMA in flight.
+// QT = tiles per wave: with one tile per wave (16 waves) the kernel is bound by LDS reads -- every wave streams the whole opposite
+// side's images (20 KB of fragment reads per pair and wave: ~23 k cycles of LDS bandwidth per head against ~12 k of MFMA); with
+// QT = 2 (8 waves, 256 registers each) every fragment read feeds two tiles and the LDS traffic halves.
+template <int NKT, int NW, int QT>
+__global__ void __launch_bounds__(64 * NW, 1)
+mha_bwd_p_mfma_v_k(const bf16_t* __restrict__ qkv, const bf16_t* __restrict__ out, const bf16_t* __restrict__ dout,
+                   const float* __restrict__ lse, bf16_t* __restrict__ dqkv, int H, int S, float scale, int nbh) {
+  extern __shared__ __attribute__((aligned(16))) char sm[];
+  constexpr int SROWS = (NKT - 1) * 16, IMG = SROWS * 128, NCONST = NKT * 16, CONSTB = 2 * NCONST * 4;
+  constexpr int TOTAL = CONSTB + 6 * IMG + 2048;
+  float* lse_s = reinterpret_cast<float*>(sm);               // -lse / c1 in the exp2 domain
+  float* dsum_s = lse_s + NCONST;                            // -rowsum(dO * O)
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
+  const int64_t ld = 3LL * H * AT_DH, ldo = (int64_t)H * AT_DH;
+  const float c1 = scale * LOG2E, inv_c1 = 1.f / c1;
+  const unsigned lds0 = (unsigned)(uintptr_t)(at_lds_void*)sm;
+  constexpr int TW = NKT / QT;                               // waves that own tiles QT w .. QT w + QT - 1 (a tile past S is all padding)
+  static_assert(NKT % QT == 0 && TW < NW, "at least one wave without tiles computes the row constants");
+  const bool has_tile = wave < TW;
+  int bh = blockIdx.x;
+  if (bh >= nbh) return;
+  // LDS is zeroed once: the rows an image's last pair over-reads must be finite from the first head on
+  for (int i = threadIdx.x * 16; i < TOTAL; i += 64 * NW * 16) *reinterpret_cast<f32x4*>(sm + i) = (f32x4){0.f, 0.f, 0.f, 0.f};
+  __syncthreads();
+  const unsigned QB = lds0 + CONSTB + 4 * IMG, DB = lds0 + CONSTB + 5 * IMG;
+  // Per-lane image offsets are re-derived at the start of every phase from an OPAQUE copy of the lane id: computed once up here
+  // they (and the staging loops' per-lane source offsets, which LICM hoists out of the head loop) stay live across the whole
+  // loop and the kernel spills -- and a scratch reload counts in vmcnt, i.e. it waits for the next head's DMA.
+#define BWDP_LANE_OFFSETS()                                                                                                         \
+  int lane_o = lane;                                                                                                                \
+  asm volatile("" : "+v"(lane_o));                                                                                                  \
+  const int g = lane_o >> 4, l16 = lane_o & 15;                                                                                     \
+  const unsigned rsw = (l16 >> 1) & 3, ksw = (l16 >> 1) & 7;                                                                        \
+  [[maybe_unused]] const unsigned roff0 = l16 * 128 + ((((unsigned)(g >> 1)) ^ rsw) << 5) + ((g & 1) << 4);       /* TR image rows, k-step 0 */ \
+  [[maybe_unused]] const unsigned roff1 = l16 * 128 + ((((unsigned)(2 + (g >> 1))) ^ rsw) << 5) + ((g & 1) << 4); /* k-step 1 */   \
+  [[maybe_unused]] const unsigned voff0 = l16 * 128 + (((unsigned)g ^ ksw) << 4), voff1 = l16 * 128 + (((unsigned)(4 + g) ^ ksw) << 4); /* ROW image rows */ \
+  const int qq = l16 >> 2, pp = l16 & 3, vsw = (2 * g + (qq >> 1)) & 3;                                                             \
+  unsigned toff[4];                                          /* transposed reads of a TR image */                                   \
+  _Pragma("unroll") for (int dt = 0; dt < 4; ++dt) toff[dt] = (4 * g + qq) * 128 + ((dt ^ vsw) << 5) + 8 * pp;
+
+  // stage_rows with the lane id made opaque at every call (see BWDP_LANE_OFFSETS)
+  auto stage_img = [&](int slot, int mode, const bf16_t* __restrict__ src, int64_t ld_) {
+    int lane_s = lane;
+    asm volatile("" : "+v"(lane_s));
+    char* img = sm + CONSTB + slot * IMG;
+    for (int j = wave; j < (SROWS >> 3); j += NW) {
+      const int row = 8 * j + (lane_s >> 3), slot8 = lane_s & 7;
+      const int c = mode == IMG_ROW ? (slot8 ^ ((row >> 1) & 7)) : ((((slot8 >> 1) ^ ((row >> 1) & 3)) << 1) | (slot8 & 1));
+      const int r = row < S ? row : S - 1;
+      __builtin_amdgcn_global_load_lds((at_gbl_void*)(src + (int64_t)r * ld_ + c * 8), (at_lds_void*)(img + j * 1024), 16, 0, 0);
+    }
+  };
+  auto stage_kv = [&](int pair, int bh_) {
+    const bf16_t* Kp = qkv + (int64_t)(bh_ / H) * S * ld + (int64_t)H * AT_DH + (bh_ % H) * AT_DH;
+    stage_img(2 * pair, IMG_TR, Kp, ld);
+    stage_img(2 * pair + 1, IMG_ROW, Kp + (int64_t)H * AT_DH, ld);
+  };
+  auto stage_qd = [&](int bh_) {
+    stage_img(4, IMG_TR, qkv + (int64_t)(bh_ / H) * S * ld + (bh_ % H) * AT_DH, ld);
+    stage_img(5, IMG_TR, dout + (int64_t)(bh_ / H) * S * ldo + (bh_ % H) * AT_DH, ldo);
+  };
+  // row constants of head bh_ by the threads [t0, t0 + nthr) of the workgroup: eight lanes per query row, one 16-byte chunk of dO
+  // and O per lane, a three-step butterfly; rows >= S get lse = +inf (P = 0).  The loads are inline asm in batches of RCB rows
+  // per lane with ONE wait per batch: a C++ global load in a kernel that also uses global_load_lds is followed by s_waitcnt
+  // vmcnt(0) at once (the ISA showed it), i.e. twenty serialized round trips per head for the three waves that do this.
+  constexpr int RCB = QT == 1 ? 5 : 13;                     // rows per lane and batch
+  auto row_constants = [&](int bh_, int t0, int nthr) {
+    const bf16_t* O = out + (int64_t)(bh_ / H) * S * ldo + (bh_ % H) * AT_DH;
+    const bf16_t* dO = dout + (int64_t)(bh_ / H) * S * ldo + (bh_ % H) * AT_DH;
+    const float* Lp = lse + (int64_t)bh_ * S;
+    int tid_o = threadIdx.x;
+    asm volatile("" : "+v"(tid_o));
+    for (int base = tid_o - t0; base < NCONST * 8; base += RCB * nthr) {
+      bf16x8 x[RCB], y[RCB];
+      float Lr[RCB];
+#pragma unroll
+      for (int i = 0; i < RCB; ++i) {
+        const int e = base + i * nthr;
+        int q = e >> 3;
+        q = q < S ? q : S - 1;                      // (rows past S: a valid address, the value is not used)
+        const bf16_t* pd = dO + (int64_t)q * ldo + (e & 7) * 8;
+        const bf16_t* po = O + (int64_t)q * ldo + (e & 7) * 8;
+        const float* pl = Lp + q;
+        asm volatile("global_load_dwordx4 %0, %1, off" : "=&v"(x[i]) : "v"(pd) : "memory");
+        asm volatile("global_load_dwordx4 %0, %1, off" : "=&v"(y[i]) : "v"(po) : "memory");
+        asm volatile("global_load_dword %0, %1, off" : "=&v"(Lr[i]) : "v"(pl) : "memory");
+      }
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#pragma unroll
+      for (int i = 0; i < RCB; ++i) asm volatile("" : "+v"(x[i]), "+v"(y[i]), "+v"(Lr[i]));
+#pragma unroll
+      for (int i = 0; i < RCB; ++i) {
+        const int e = base + i * nthr;
+        const int q = e >> 3, c = e & 7;
+        float a = 0.f;
+#pragma unroll
+        for (int jj = 0; jj < 8; ++jj) a += (float)x[i][jj] * (float)y[i][jj];
+        a += __shfl_xor(a, 1, 64); a += __shfl_xor(a, 2, 64); a += __shfl_xor(a, 4, 64);
+        if (c == 0 && e < NCONST * 8) {
+          const float L = q < S ? Lr[i] * LOG2E : INFINITY;
+          lse_s[q] = -L * inv_c1; dsum_s[q] = q < S ? -a : 0.f;
+        }
+      }
+    }
+  };
+
+  // ---- dK / dV of key tiles QT wave + t (fragments from the K | V images at kvb), against every query pair
+  auto dkv_tile = [&](int bh_, unsigned kvb) {
+    BWDP_LANE_OFFSETS()
+    bf16x8 kf0[QT], kf1[QT], vf0[QT], vf1[QT];
+    float kbias[QT];
+#pragma unroll
+    for (int t = 0; t < QT; ++t) {
+      const int k0 = (QT * wave + t) * 16;
+      kbias[t] = k0 + l16 < S ? 0.f : -INFINITY;                          // this lane's key of tile t
+      AT_DS_B128_OFF(kf0[t], kvb + roff0 + k0 * 128, 0);       AT_DS_B128_OFF(kf1[t], kvb + roff1 + k0 * 128, 0);
+      AT_DS_B128_OFF(vf0[t], kvb + IMG + voff0 + k0 * 128, 0); AT_DS_B128_OFF(vf1[t], kvb + IMG + voff1 + k0 * 128, 0);
+    }
+    // (the dO image sits IMG bytes behind the Q image and dsum_s NCONST floats behind lse_s: immediate offsets, no second address)
+    unsigned tq[4];
+#pragma unroll
+    for (int dt = 0; dt < 4; ++dt) tq[dt] = QB + toff[dt];
+    const unsigned qb0 = QB + roff0, qb1 = QB + roff1;
+    const unsigned lb = lds0 + 16 * g;                            // row constants of queries 16 qt + 4 g + r
+    f32x4 dk[QT][4], dv[QT][4];
+#pragma unroll
+    for (int t = 0; t < QT; ++t)
+#pragma unroll
+      for (int dt = 0; dt < 4; ++dt) { dk[t][dt] = (f32x4){0.f, 0.f, 0.f, 0.f}; dv[t][dt] = (f32x4){0.f, 0.f, 0.f, 0.f}; }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+    for (int t = 0; t < QT; ++t) asm volatile("" : "+v"(kf0[t]), "+v"(kf1[t]), "+v"(vf0[t]), "+v"(vf1[t]));
+    static_for<0, NKT / 2>([&](auto ic) {
+      constexpr int u = decltype(ic)::value;
+      bf16x8 qa0, qa1, qb0_, qb1_, da0, da1, db0_, db1_;      // row fragments of query tiles 2u (a) and 2u+1 (b), k-steps 0 / 1
+      f32x4 ca, cb, ea, eb;                                   // the row constants S' and dP' start from (same for every key tile)
+      AT_DS_B128_OFF(qa0, qb0, (2 * u) * 2048);     AT_DS_B128_OFF(da0, qb0, IMG + (2 * u) * 2048);
+      AT_DS_B128_OFF(qb0_, qb0, (2 * u + 1) * 2048); AT_DS_B128_OFF(db0_, qb0, IMG + (2 * u + 1) * 2048);
+      AT_DS_B128_OFF(ca, lb, (2 * u) * 64);          AT_DS_B128_OFF(ea, lb, NCONST * 4 + (2 * u) * 64);
+      AT_DS_B128_OFF(cb, lb, (2 * u + 1) * 64);      AT_DS_B128_OFF(eb, lb, NCONST * 4 + (2 * u + 1) * 64);
+      AT_DS_B128_OFF(qa1, qb1, (2 * u) * 2048);     AT_DS_B128_OFF(da1, qb1, IMG + (2 * u) * 2048);
+      AT_DS_B128_OFF(qb1_, qb1, (2 * u + 1) * 2048); AT_DS_B128_OFF(db1_, qb1, IMG + (2 * u + 1) * 2048);
+      bf16x4 dlo[4], dhi[4], qlo[4], qhi[4];                  // the transposed fragments of the second products: in flight under the first
+#pragma unroll
+      for (int dt = 0; dt < 4; ++dt) {
+        AT_DS_TR_OFF(dlo[dt], tq[dt], IMG + u * 4096); AT_DS_TR_OFF(dhi[dt], tq[dt], IMG + u * 4096 + 2048);
+        AT_DS_TR_OFF(qlo[dt], tq[dt], u * 4096); AT_DS_TR_OFF(qhi[dt], tq[dt], u * 4096 + 2048);
+      }
+      // 12 + 16 LDS reads were issued (the 4-bit counter stalls the issue past 15 in flight); they complete in order, so at most 15
+      // outstanding means the twelve row / constant reads have landed
+      asm volatile("s_waitcnt lgkmcnt(15)" : "+v"(qa0), "+v"(da0), "+v"(qb0_), "+v"(db0_), "+v"(ca), "+v"(ea), "+v"(cb), "+v"(eb), "+v"(qa1), "+v"(da1),
+                   "+v"(qb1_), "+v"(db1_));
+      bf16x8 pf[QT], dsf[QT];
+#pragma unroll
+      for (int t = 0; t < QT; ++t) {
+        f32x4 sa = ca, sb_ = cb, pa = ea, pb = eb;
+        sa = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qa0, kf0[t], sa, 0, 0, 0);       // S'[q][key]
+        pa = __builtin_amdgcn_mfma_f32_16x16x32_bf16(da0, vf0[t], pa, 0, 0, 0);       // dP'[q][key]
+        sb_ = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qb0_, kf0[t], sb_, 0, 0, 0);
+        pb = __builtin_amdgcn_mfma_f32_16x16x32_bf16(db0_, vf0[t], pb, 0, 0, 0);
+        sa = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qa1, kf1[t], sa, 0, 0, 0);
+        pa = __builtin_amdgcn_mfma_f32_16x16x32_bf16(da1, vf1[t], pa, 0, 0, 0);
+        sb_ = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qb1_, kf1[t], sb_, 0, 0, 0);
+        pb = __builtin_amdgcn_mfma_f32_16x16x32_bf16(db1_, vf1[t], pb, 0, 0, 0);
+        f32x4 p2a, p2b, dsa, dsb;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          p2a[r] = __builtin_amdgcn_exp2f(fmaf(sa[r], c1, kbias[t]));          // 0 for dead keys and padded queries
+          p2b[r] = __builtin_amdgcn_exp2f(fmaf(sb_[r], c1, kbias[t]));
+          dsa[r] = p2a[r] * pa[r];                                            // (the score scale is applied to dK below)
+          dsb[r] = p2b[r] * pb[r];
+        }
+        pf[t] = pack_pair(p2a, p2b); dsf[t] = pack_pair(dsa, dsb);
+      }
+      asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(dlo[0]), "+v"(dhi[0]), "+v"(dlo[1]), "+v"(dhi[1]), "+v"(dlo[2]), "+v"(dhi[2]), "+v"(dlo[3]), "+v"(dhi[3]),
+                   "+v"(qlo[0]), "+v"(qhi[0]), "+v"(qlo[1]), "+v"(qhi[1]), "+v"(qlo[2]), "+v"(qhi[2]), "+v"(qlo[3]), "+v"(qhi[3]));
+#pragma unroll
+      for (int t = 0; t < QT; ++t)
+#pragma unroll
+        for (int dt = 0; dt < 4; ++dt) {
+          dv[t][dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_shufflevector(dlo[dt], dhi[dt], 0, 1, 2, 3, 4, 5, 6, 7), pf[t], dv[t][dt], 0, 0, 0);    // dV^T[d][key]
+          dk[t][dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_shufflevector(qlo[dt], qhi[dt], 0, 1, 2, 3, 4, 5, 6, 7), dsf[t], dk[t][dt], 0, 0, 0);   // dK^T[d][key]
+        }
+    });
+#pragma unroll
+    for (int t = 0; t < QT; ++t) {
+      const int key = (QT * wave + t) * 16 + l16;
+      bf16_t* krow = dqkv + ((int64_t)(bh_ / H) * S + (key < S ? key : S - 1)) * ld + (int64_t)H * AT_DH + (bh_ % H) * AT_DH;
+      bf16_t* vrow = krow + (int64_t)H * AT_DH;
+#pragma unroll
+      for (int dt = 0; dt < 4; ++dt) {
+        bf16x4 a, c;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) { a[r] = (bf16_t)(dk[t][dt][r] * scale); c[r] = (bf16_t)dv[t][dt][r]; }
+        if (key < S) {
+          *reinterpret_cast<bf16x4*>(krow + dt * 16 + 4 * g) = a;
+          *reinterpret_cast<bf16x4*>(vrow + dt * 16 + 4 * g) = c;
+        }
+      }
+    }
+  };
+
+  // ---- dQ of query tiles QT wave + t (their Q | dO fragments and row constants in registers), against every key pair at kvb
+  auto dq_tile = [&](int bh_, unsigned kvb, const bf16x8 (&qf0)[QT], const bf16x8 (&qf1)[QT], const bf16x8 (&df0)[QT], const bf16x8 (&df1)[QT],
+                     const float (&nl)[QT], const float (&nd)[QT]) {
+    BWDP_LANE_OFFSETS()
+    const unsigned kb0 = kvb + roff0, kb1 = kvb + roff1, vb0 = kvb + IMG + voff0, vb1 = kvb + IMG + voff1;
+    unsigned tk[4];
+#pragma unroll
+    for (int dt = 0; dt < 4; ++dt) tk[dt] = kvb + toff[dt];
+    f32x4 dq[QT][4];
+#pragma unroll
+    for (int t = 0; t < QT; ++t)
+#pragma unroll
+      for (int dt = 0; dt < 4; ++dt) dq[t][dt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    static_for<0, NKT / 2>([&](auto ic) {
+      constexpr int u = decltype(ic)::value;
+      bf16x8 ka0, ka1, kc0, kc1, va0, va1, vc0, vc1;         // key tiles 2u (a) and 2u+1 (c), k-steps 0 / 1
+      AT_DS_B128_OFF(ka0, kb0, (2 * u) * 2048);     AT_DS_B128_OFF(va0, vb0, (2 * u) * 2048);
+      AT_DS_B128_OFF(kc0, kb0, (2 * u + 1) * 2048); AT_DS_B128_OFF(vc0, vb0, (2 * u + 1) * 2048);
+      AT_DS_B128_OFF(ka1, kb1, (2 * u) * 2048);     AT_DS_B128_OFF(va1, vb1, (2 * u) * 2048);
+      AT_DS_B128_OFF(kc1, kb1, (2 * u + 1) * 2048); AT_DS_B128_OFF(vc1, vb1, (2 * u + 1) * 2048);
+      bf16x4 klo[4], khi[4];                       // K^T fragments of the dQ product: in flight under the first products
+#pragma unroll
+      for (int dt = 0; dt < 4; ++dt) { AT_DS_TR_OFF(klo[dt], tk[dt], u * 4096); AT_DS_TR_OFF(khi[dt], tk[dt], u * 4096 + 2048); }
+      asm volatile("s_waitcnt lgkmcnt(8)" : "+v"(ka0), "+v"(va0), "+v"(kc0), "+v"(vc0), "+v"(ka1), "+v"(va1), "+v"(kc1), "+v"(vc1));
+      bf16x8 dsf[QT];
+#pragma unroll
+      for (int t = 0; t < QT; ++t) {
+        f32x4 sa = {nl[t], nl[t], nl[t], nl[t]}, sc_ = sa, pa = {nd[t], nd[t], nd[t], nd[t]}, pc = pa;
+        sa = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ka0, qf0[t], sa, 0, 0, 0);       // S'^T[key][q]
+        pa = __builtin_amdgcn_mfma_f32_16x16x32_bf16(va0, df0[t], pa, 0, 0, 0);       // dP'^T[key][q]
+        sc_ = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kc0, qf0[t], sc_, 0, 0, 0);
+        pc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vc0, df0[t], pc, 0, 0, 0);
+        sa = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ka1, qf1[t], sa, 0, 0, 0);
+        pa = __builtin_amdgcn_mfma_f32_16x16x32_bf16(va1, df1[t], pa, 0, 0, 0);
+        sc_ = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kc1, qf1[t], sc_, 0, 0, 0);
+        pc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vc1, df1[t], pc, 0, 0, 0);
+        f32x4 dsa, dsc;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          float xa = sa[r] * c1, xc = sc_[r] * c1;
+          if (u == NKT / 2 - 1) {                    // only the last key pair holds keys beyond S (S > 16 (NKT - 2))
+            xa = (2 * u) * 16 + 4 * g + r < S ? xa : -INFINITY;
+            xc = (2 * u + 1) * 16 + 4 * g + r < S ? xc : -INFINITY;
+          }
+          dsa[r] = __builtin_amdgcn_exp2f(xa) * pa[r];        // p (dP - D); a padded query has lse = +inf -> p = 0
+          dsc[r] = __builtin_amdgcn_exp2f(xc) * pc[r];        // (the score scale is applied to dQ below)
+        }
+        dsf[t] = pack_pair(dsa, dsc);
+      }
+      asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(klo[0]), "+v"(khi[0]), "+v"(klo[1]), "+v"(khi[1]), "+v"(klo[2]), "+v"(khi[2]), "+v"(klo[3]), "+v"(khi[3]));
+#pragma unroll
+      for (int t = 0; t < QT; ++t)
+#pragma unroll
+        for (int dt = 0; dt < 4; ++dt)
+          dq[t][dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_shufflevector(klo[dt], khi[dt], 0, 1, 2, 3, 4, 5, 6, 7), dsf[t], dq[t][dt], 0, 0, 0);   // dQ^T[d][q]
+    });
+#pragma unroll
+    for (int t = 0; t < QT; ++t) {
+      const int q = (QT * wave + t) * 16 + l16;
+      bf16_t* drow = dqkv + ((int64_t)(bh_ / H) * S + (q < S ? q : S - 1)) * ld + (bh_ % H) * AT_DH;
+#pragma unroll
+      for (int dt = 0; dt < 4; ++dt) {
+        bf16x4 v;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) v[r] = (bf16_t)(dq[t][dt][r] * scale);
+        if (q < S) *reinterpret_cast<bf16x4*>(drow + dt * 16 + 4 * g) = v;
+      }
+    }
+  };
+
+  // The same split in two for the steady state: EVERY thread issues the loads of its RC2 rows of head i+1 right after the mid
+  // barrier (inline asm, destinations untouched until the wait) and reduces them after its dQ part, when they have long landed --
+  // one wave alone needs three round trips per head for the 1,576 row chunks, which made IT the critical path (measured).
+  constexpr int RC2 = (NCONST * 8 + 64 * NW - 1) / (64 * NW);
+  auto rc_issue = [&](int bh_, bf16x8 (&x)[RC2], bf16x8 (&y)[RC2], float (&Lr)[RC2]) {
+    const bf16_t* O = out + (int64_t)(bh_ / H) * S * ldo + (bh_ % H) * AT_DH;
+    const bf16_t* dO = dout + (int64_t)(bh_ / H) * S * ldo + (bh_ % H) * AT_DH;
+    const float* Lp = lse + (int64_t)bh_ * S;
+    int tid_o = threadIdx.x;
+    asm volatile("" : "+v"(tid_o));
+#pragma unroll
+    for (int i = 0; i < RC2; ++i) {
+      const int e = tid_o + i * 64 * NW;
+      int q = e >> 3;
+      q = q < S ? q : S - 1;
+      const bf16_t* pd = dO + (int64_t)q * ldo + (e & 7) * 8;
+      const bf16_t* po = O + (int64_t)q * ldo + (e & 7) * 8;
+      const float* pl = Lp + q;
+      asm volatile("global_load_dwordx4 %0, %1, off" : "=&v"(x[i]) : "v"(pd) : "memory");
+      asm volatile("global_load_dwordx4 %0, %1, off" : "=&v"(y[i]) : "v"(po) : "memory");
+      asm volatile("global_load_dword %0, %1, off" : "=&v"(Lr[i]) : "v"(pl) : "memory");
+    }
+  };
+  auto rc_finish = [&](bf16x8 (&x)[RC2], bf16x8 (&y)[RC2], float (&Lr)[RC2]) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#pragma unroll
+    for (int i = 0; i < RC2; ++i) asm volatile("" : "+v"(x[i]), "+v"(y[i]), "+v"(Lr[i]));
+    int tid_o = threadIdx.x;
+    asm volatile("" : "+v"(tid_o));
+#pragma unroll
+    for (int i = 0; i < RC2; ++i) {
+      const int e = tid_o + i * 64 * NW;
+      const int q = e >> 3, c = e & 7;
+      float a = 0.f;
+#pragma unroll
+      for (int jj = 0; jj < 8; ++jj) a += (float)x[i][jj] * (float)y[i][jj];
+      a += __shfl_xor(a, 1, 64); a += __shfl_xor(a, 2, 64); a += __shfl_xor(a, 4, 64);
+      if (c == 0 && e < NCONST * 8) {
+        const float L = q < S ? Lr[i] * LOG2E : INFINITY;
+        lse_s[q] = -L * inv_c1; dsum_s[q] = q < S ? -a : 0.f;
+      }
+    }
+  };
+
+  // prologue: head 0 of this workgroup
+  stage_kv(0, bh);
+  stage_qd(bh);
+  row_constants(bh, 0, 64 * NW);
+  int cur = 0;
+  for (;;) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();                    // K | V (pair cur), Q | dO and the row constants of head bh are complete
+    const int nxt = bh + (int)gridDim.x;
+    const unsigned kvb = lds0 + CONSTB + (2 * cur) * IMG;
+    if (nxt < nbh) stage_kv(cur ^ 1, nxt);
+    if (has_tile) dkv_tile(bh, kvb);
+    bf16x8 qf0[QT], qf1[QT], df0[QT], df1[QT];
+    float nl[QT], nd[QT];
+    if (has_tile) {                     // this wave's Q | dO fragments and row constants leave LDS before slots 4,5 are refilled
+      BWDP_LANE_OFFSETS()
+#pragma unroll
+      for (int t = 0; t < QT; ++t) {
+        const unsigned q0b = (QT * wave + t) * 16 * 128;
+        AT_DS_B128_OFF(qf0[t], QB + roff0 + q0b, 0); AT_DS_B128_OFF(qf1[t], QB + roff1 + q0b, 0);
+        AT_DS_B128_OFF(df0[t], DB + roff0 + q0b, 0); AT_DS_B128_OFF(df1[t], DB + roff1 + q0b, 0);
+        asm volatile("ds_read_b32 %0, %1" : "=v"(nl[t]) : "v"(lds0 + ((QT * wave + t) * 16 + l16) * 4));
+        asm volatile("ds_read_b32 %0, %1" : "=v"(nd[t]) : "v"(lds0 + (NCONST + (QT * wave + t) * 16 + l16) * 4));
+      }
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+      for (int t = 0; t < QT; ++t) asm volatile("" : "+v"(qf0[t]), "+v"(qf1[t]), "+v"(df0[t]), "+v"(df1[t]), "+v"(nl[t]), "+v"(nd[t]));
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");       // LDS only: the K | V DMA of head nxt stays in flight
+    bf16x8 rx[RC2], ry[RC2];
+    float rl[RC2];
+    if (nxt < nbh) {
+      stage_qd(nxt);
+      rc_issue(nxt, rx, ry, rl);
+    }
+    if (has_tile) dq_tile(bh, kvb, qf0, qf1, df0, df1, nl, nd);
+    if (nxt >= nbh) break;
+    rc_finish(rx, ry, rl);
+    bh = nxt; cur ^= 1;
+  }
+#undef BWDP_LANE_OFFSETS
+}
+
 #define BIAS_EXTRA(n) ((n) * 16 * 4)
 #define STAT_EXTRA(n) (2 * (n) * 16 * 4)
 
@@ -1153,12 +1552,33 @@ int mmrca_mha_bwd_mfma(const void* qkv, const int32_t* key_mask, const void* out
   const int nkt = pick_nkt(S);
   static const int bwd_v = getenv("MMRCA_ATTN_BWD_V") ? atoi(getenv("MMRCA_ATTN_BWD_V")) : 1;
   const bool use_v = bwd_v && nkt == 14 && drop_p <= 0.f && !key_mask && !cu && S > 16 * 12;      // the ViT's attention
-  static const int bwd_fused = getenv("MMRCA_ATTN_BWD_FUSED") ? atoi(getenv("MMRCA_ATTN_BWD_FUSED")) : 1;
-  if (use_v && bwd_fused == 1) {     // one launch, two workgroups per CU: the Q | dO and K | V images time-share 56 KiB
+  // 3 (default): persistent workgroups, every operand read once (mha_bwd_p_mfma_v_k); 1: one launch, two time-sharing workgroups per
+  // CU (round 3's default; also what S in (208, 224] runs); 2: one 16-wave workgroup per CU; 0: the two-kernel form
+  static const int bwd_fused = getenv("MMRCA_ATTN_BWD_FUSED") ? atoi(getenv("MMRCA_ATTN_BWD_FUSED")) : 3;
+  static const int bwd_prefetch = getenv("MMRCA_ATTN_BWD_PREFETCH") ? atoi(getenv("MMRCA_ATTN_BWD_PREFETCH")) : 1;      // A/B switch of the first-tile fragment prefetch
+  if (use_v && bwd_fused == 3 && S <= 16 * 13) {
+    // persistent 8-wave workgroups (two tiles per wave), six image slots: every operand crosses the fabric once
+    static int ncu_b = 0;
+    if (ncu_b == 0) {
+      int dev = 0, n = 0;
+      (void)hipGetDevice(&dev);
+      if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n < 1) n = 256;
+      ncu_b = n;
+    }
+    const int nbh = B * H;
+    const int grid = nbh < ncu_b ? nbh : ncu_b;
+    const int ldp = 2 * 14 * 16 * 4 + 6 * 13 * 16 * 128 + 2048;
+    (void)hipFuncSetAttribute((const void*)mha_bwd_p_mfma_v_k<14, 8, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, ldp);
+    hipLaunchKernelGGL((mha_bwd_p_mfma_v_k<14, 8, 2>), dim3(grid), dim3(512), ldp, st, (const bf16_t*)qkv, (const bf16_t*)out, (const bf16_t*)dout, lse,
+                       (bf16_t*)dqkv, H, S, scale, nbh);
+    MMRCA_CHECK_LAUNCH("mha_bwd(mfma,persistent)");
+    return 0;
+  }
+  if (use_v && (bwd_fused == 1 || bwd_fused == 3)) {     // one launch, two workgroups per CU: the Q | dO and K | V images time-share 56 KiB
     const int ldf = 2 * 14 * 16 * 128 + STAT_EXTRA(14);
     (void)hipFuncSetAttribute((const void*)mha_bwd_fused_mfma_v_k<14, 8, true>, hipFuncAttributeMaxDynamicSharedMemorySize, ldf);
     hipLaunchKernelGGL((mha_bwd_fused_mfma_v_k<14, 8, true>), dim3(B * H), dim3(512), ldf, st, (const bf16_t*)qkv, (const bf16_t*)out, (const bf16_t*)dout, lse,
-                       (bf16_t*)dqkv, H, S, scale, g_attn_stamps);
+                       (bf16_t*)dqkv, H, S, scale, g_attn_stamps, bwd_prefetch);
     MMRCA_CHECK_LAUNCH("mha_bwd(mfma,fused)");
     return 0;
   }
@@ -1166,7 +1586,7 @@ int mmrca_mha_bwd_mfma(const void* qkv, const int32_t* key_mask, const void* out
     const int ldf = 4 * 14 * 16 * 128 + STAT_EXTRA(14);
     (void)hipFuncSetAttribute((const void*)mha_bwd_fused_mfma_v_k<14, 16, false>, hipFuncAttributeMaxDynamicSharedMemorySize, ldf);
     hipLaunchKernelGGL((mha_bwd_fused_mfma_v_k<14, 16, false>), dim3(B * H), dim3(1024), ldf, st, (const bf16_t*)qkv, (const bf16_t*)out, (const bf16_t*)dout, lse,
-                       (bf16_t*)dqkv, H, S, scale, g_attn_stamps);
+                       (bf16_t*)dqkv, H, S, scale, g_attn_stamps, bwd_prefetch);
     MMRCA_CHECK_LAUNCH("mha_bwd(mfma,fused16)");
     return 0;
   }
