@@ -56,6 +56,13 @@ __device__ __forceinline__ void stage_half(const bf16_t* src0, const bf16_t* src
   __builtin_amdgcn_global_load_lds((gbl_void*)src1, (lds_void*)(lds_piece0 + 1024), 16, 0, 0);
 }
 
+// the same as a template: F4 = the fused four-plane form, whose second piece (the lo plane's 16 rows) lands 8 KiB behind the first
+template <bool F4>
+__device__ __forceinline__ void stage_half_t(const bf16_t* src0, const bf16_t* src1, char* lds_piece0) {
+  __builtin_amdgcn_global_load_lds((gbl_void*)src0, (lds_void*)(lds_piece0), 16, 0, 0);
+  __builtin_amdgcn_global_load_lds((gbl_void*)src1, (lds_void*)(lds_piece0 + (F4 ? 8192 : 1024)), 16, 0, 0);
+}
+
 // per-lane source pointer of piece `i` (0..15) of a half-tile at K offset 0.
 // STRIPE (B operand of the persistent kernel): half-tile h holds the 32-row stripes {64w + 32h + [0,32) : w = 0..3} of the
 // 256-row tile instead of rows 128h + [0,128), so that a wave's two 32-column pieces are ADJACENT in the output (columns
@@ -243,6 +250,56 @@ gemm_mfma256_k(const bf16_t* __restrict__ A, const bf16_t* __restrict__ B, bf16_
     bbase[0] ^= STAGE_BYTES; bbase[1] ^= STAGE_BYTES; read_stage ^= STAGE_BYTES;                              \
   } while (0)
 
+  // The fused four-plane form of a K step (gemm_p256_k<..., F4>): fragment index [f][pl] = plane pl (0 hi, 1 lo) of 16-row piece f
+  // (1 KiB apart in a 64-byte-row image); a quadrant is three products -- hi.hi, lo.hi, hi.lo -- of 8 MFMAs each.
+#define A_FRAG4(SLOT, f, pl) read_frag<false, (SLOT) * HT_BYTES + (f) * 1024>(af[f][pl], abase[pl])
+#define B_FRAG4(BF, SLOT, f, pl) read_frag<false, (SLOT) * HT_BYTES + (f) * 1024>(BF[f][pl], bbase[pl])
+#define LOAD_A4(SLOT)                                                                                         \
+  do {                                                                                                        \
+    A_FRAG4(SLOT, 0, 0); A_FRAG4(SLOT, 0, 1); A_FRAG4(SLOT, 1, 0); A_FRAG4(SLOT, 1, 1);                       \
+    A_FRAG4(SLOT, 2, 0); A_FRAG4(SLOT, 2, 1); A_FRAG4(SLOT, 3, 0); A_FRAG4(SLOT, 3, 1);                       \
+  } while (0)
+#define LOAD_B4(BF, SLOT)                                                                                     \
+  do {                                                                                                        \
+    B_FRAG4(BF, SLOT, 0, 0); B_FRAG4(BF, SLOT, 0, 1); B_FRAG4(BF, SLOT, 1, 0); B_FRAG4(BF, SLOT, 1, 1);       \
+  } while (0)
+#define MFMA_QUAD4(AH, BH, BF)                                                                                \
+  do {                                                                                                        \
+    __builtin_amdgcn_s_setprio(1);                                                                            \
+    _Pragma("unroll") for (int pr = 0; pr < 3; ++pr)      /* (B plane, A plane): (hi, hi), (hi, lo), (lo, hi) */ \
+      _Pragma("unroll") for (int i = 0; i < 4; ++i)                                                           \
+        _Pragma("unroll") for (int j = 0; j < 2; ++j)                                                         \
+          acc[AH][BH][i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_val(BF[j][pr == 2 ? 1 : 0]), frag_val(af[i][pr == 1 ? 1 : 0]), acc[AH][BH][i][j], 0, 0, 0); \
+    __builtin_amdgcn_s_setprio(0);                                                                            \
+  } while (0)
+#define K_TILE_G4(ISS, I0, I1, I2, I3, W0, W1, W2, W3)                                                        \
+  do {                                                                                                        \
+    if (I0) ISS(2);                                                                                           \
+    LOAD_B4(b0f, SLOT_B0); LOAD_A4(SLOT_A0);                                                                  \
+    END_LOAD(W0);                                                                                             \
+    LGKM0_B(b0f); LGKM0_A();                                                                                  \
+    MFMA_QUAD4(0, 0, b0f);                                                                                    \
+    END_COMPUTE(W0);                                                                                          \
+    if (I1) ISS(3);                                                                                           \
+    LOAD_B4(b1f, SLOT_B1);                                                                                    \
+    END_LOAD(W1);                                                                                             \
+    LGKM0_B(b1f);                                                                                             \
+    MFMA_QUAD4(0, 1, b1f);                                                                                    \
+    END_COMPUTE(W1);                                                                                          \
+    if (I2) ISS(0);                                                                                           \
+    LOAD_A4(SLOT_A1);                                                                                         \
+    END_LOAD(W2);                                                                                             \
+    LGKM0_A();                                                                                                \
+    MFMA_QUAD4(1, 1, b1f);                                                                                    \
+    END_COMPUTE(W2);                                                                                          \
+    if (I3) ISS(1);                                                                                           \
+    END_LOAD(W3);                                                                                             \
+    MFMA_QUAD4(1, 0, b0f);                                                                                    \
+    END_COMPUTE(W3);                                                                                          \
+    _Pragma("unroll") for (int x = 0; x < 4; ++x) abase[x] ^= STAGE_BYTES;                                    \
+    bbase[0] ^= STAGE_BYTES; bbase[1] ^= STAGE_BYTES; read_stage ^= STAGE_BYTES;                              \
+  } while (0)
+
   // prologue: seq 0..5 (K-tile 0 and A0, B0 of K-tile 1); phase 0 needs seq 0, 1 -> four half-tiles may stay in flight
   ISSUE(0); ISSUE(1); ISSUE(2); ISSUE(3); ISSUE(0); ISSUE(1);
   VMCNT(8);
@@ -297,7 +354,15 @@ gemm_mfma256_k(const bf16_t* __restrict__ A, const bf16_t* __restrict__ B, bf16_
 // X3 (bf16x3 mode, gemm_x3.hip): A / B are the hi planes, A_lo / B_lo the lo planes of fp32 operands; every output tile runs
 // the K loop three times -- (A_hi, B_hi), (A_lo, B_hi), (A_hi, B_lo) -- the stream switching planes where it used to switch
 // tiles; bias / preact / C are fp32, or, with PLANES, C is written as two bf16 planes (C = hi, C_lo = lo).  No side operands.
-template <bool A_KROW, bool B_KROW, int ACT, bool ADD, bool X3 = false, bool PLANES = false>
+// F4 (X3, row-major A and B, all three plane pairs): the FUSED form of the bf16x3 product.  The plain X3 form walks the K loop
+// three times per output tile -- (A_hi, B_hi), (A_lo, B_hi), (A_hi, B_lo) -- i.e. it stages A_hi and B_hi twice: 3 x 64 KiB of
+// LDS-DMA and 3 x 24 fragment reads per wave for every 64 columns of K, and this kernel is co-bound by LDS bandwidth and the
+// matrix pipe.  Here a K step is 32 columns of ALL FOUR planes -- a 16-KiB slot holds the hi image [128 rows x 64 B] and the lo
+// image of one half-tile -- and every staged plane is used by two of the three products: per 64 columns of K 2 x 64 KiB staged and
+// 2 x 24 fragment reads for the same 192 MFMAs, a third less LDS traffic per flop.  The schedule (slots, issue order, two DMA
+// instructions per wave and half-tile, counted waits, phases) is unchanged: "half-tile X of K-tile t" now reads "half-tile X, planes
+// hi | lo, of K step t".  64-byte image rows: 16-byte chunk index XOR (row >> 2) & 3 (conflict-free for the 16 rows of a fragment).
+template <bool A_KROW, bool B_KROW, int ACT, bool ADD, bool X3 = false, bool PLANES = false, bool F4 = false>
 __global__ void __launch_bounds__(512, 2)
 gemm_p256_k(const bf16_t* __restrict__ A, const bf16_t* __restrict__ B, bf16_t* __restrict__ C, const bf16_t* __restrict__ bias,
             const bf16_t* __restrict__ addend, bf16_t* __restrict__ preact, int64_t M, int64_t N, int64_t K,
@@ -306,6 +371,7 @@ gemm_p256_k(const bf16_t* __restrict__ A, const bf16_t* __restrict__ B, bf16_t* 
             int nseg = 3, int pre16 = 0) {
   // pre16 (X3 only; MMRCA_ACT_GELU_SAVE_GRAD_BF16): gelu' is stored as bf16 -- the form a bf16 backward reads (bf16x3f mode)
   static_assert(!X3 || (!ADD && ACT != MMRCA_ACT_MUL), "the bf16x3 form has no side-operand epilogue");
+  static_assert(!F4 || (X3 && !A_KROW && !B_KROW), "the fused four-plane form is the row-major bf16x3 forward product");
   constexpr int act = ACT;
   extern __shared__ __attribute__((aligned(16))) char smem[];     // [2 stages][A0 A1 B0 B1] + 32 KiB epilogue staging
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
@@ -323,7 +389,7 @@ gemm_p256_k(const bf16_t* __restrict__ A, const bf16_t* __restrict__ B, bf16_t* 
     const uint64_t wait = (uint64_t)skew_ticks * (((unsigned)blockIdx.x >> 3) & 3);
     while (__builtin_amdgcn_s_memrealtime() - t0 < wait) __builtin_amdgcn_s_sleep(32);
   }
-  const int nt = (int)(K / 64);                                               // >= 2 (host-checked)
+  const int nt = (int)(K / (F4 ? 32 : 64));                                   // K steps per plane pair (F4: per tile); >= 2 (host-checked)
   const int GROUP = 4;
   auto tile_origin = [&](int id, int64_t& m_blk, int64_t& n_blk) {
     const int group = id / (GROUP * tiles_n);
@@ -339,16 +405,24 @@ gemm_p256_k(const bf16_t* __restrict__ A, const bf16_t* __restrict__ B, bf16_t* 
   // half-tile 0, advanced per K-tile; half-tile 1 is a wave-uniform distance away (128 rows of A; 32 rows of the striped B).
   // Rows of A past M (last row tile) are read as they are -- the caller provides round_up(M, 256) readable rows -- and the
   // output rows they produce are never stored.
-  const unsigned a_step = (unsigned)(A_KROW ? 128 * lda : 128), b_step = (unsigned)(B_KROW ? 128 * ldb : 128);
+  const unsigned a_step = (unsigned)(F4 ? 64 : (A_KROW ? 128 * lda : 128)), b_step = (unsigned)(F4 ? 64 : (B_KROW ? 128 * ldb : 128));
   const int64_t a_half = A_KROW ? 256 : 256 * lda, b_half = B_KROW ? 64 : 64 * ldb;       // bytes
   unsigned oa[2], ob[2];
   auto stream_to = [&](int id) {
     int64_t mb, nb;
     tile_origin(id, mb, nb);
+    if constexpr (F4) {
+      // one DMA instruction = 16 image rows of 64 B: lane -> row 16 wave + (lane >> 2), chunk slot lane & 3; the hi and the lo
+      // plane share the geometry (oa[0] == oa[1]); B in the striped order of the epilogue (image row r = tile row 64 (r >> 5) + (r & 31))
+      const int r = 16 * wave + (lane >> 2), c = (lane & 3) ^ ((r >> 2) & 3);
+      oa[0] = oa[1] = (unsigned)(((mb + r) * lda) * 2 + c * 16);
+      ob[0] = ob[1] = (unsigned)(((nb + 64 * (r >> 5) + (r & 31)) * ldb) * 2 + c * 16);
+    } else {
 #pragma unroll
-    for (int ii = 0; ii < 2; ++ii) {
-      oa[ii] = (unsigned)(2 * (piece_src<A_KROW>(A, lda, mb, (int64_t)1 << 40, wave * 2 + ii, lane) - A));
-      ob[ii] = (unsigned)(2 * (piece_src<B_KROW, true>(B, ldb, nb, (int64_t)1 << 40, wave * 2 + ii, lane, 0) - B));
+      for (int ii = 0; ii < 2; ++ii) {
+        oa[ii] = (unsigned)(2 * (piece_src<A_KROW>(A, lda, mb, (int64_t)1 << 40, wave * 2 + ii, lane) - A));
+        ob[ii] = (unsigned)(2 * (piece_src<B_KROW, true>(B, ldb, nb, (int64_t)1 << 40, wave * 2 + ii, lane, 0) - B));
+      }
     }
   };
   stream_to(slot);
@@ -356,22 +430,23 @@ gemm_p256_k(const bf16_t* __restrict__ A, const bf16_t* __restrict__ B, bf16_t* 
   [[maybe_unused]] int stream_seg = 0;         // X3: which plane pair the stream is in
   const bf16_t* Acur = A;
   const bf16_t* Bcur = B;
-  char* const my_piece = smem + wave * 2048;
+  char* const my_piece = smem + wave * (F4 ? 1024 : 2048);
   int issue_stage = 0;
   // the issue slot of half-tile A1 closes a K-tile of the stream: after the last K-tile of a tile, move on to the next tile
-#define SRC_A(h, ii) reinterpret_cast<const bf16_t*>(reinterpret_cast<const char*>(Acur) + (h) * a_half + oa[ii])
-#define SRC_B(h, ii) reinterpret_cast<const bf16_t*>(reinterpret_cast<const char*>(Bcur) + (h) * b_half + ob[ii])
+  // (F4: piece 0 comes from the hi plane, piece 1 from the lo plane, and lands 8 KiB behind piece 0)
+#define SRC_A(h, ii) reinterpret_cast<const bf16_t*>(reinterpret_cast<const char*>(F4 ? ((ii) ? A_lo : A) : Acur) + (h) * a_half + oa[ii])
+#define SRC_B(h, ii) reinterpret_cast<const bf16_t*>(reinterpret_cast<const char*>(F4 ? ((ii) ? B_lo : B) : Bcur) + (h) * b_half + ob[ii])
 #define ISSUE_P(which)                                                                                          \
   do {                                                                                                          \
-    if ((which) == 0) { stage_half(SRC_A(0, 0), SRC_A(0, 1), my_piece + issue_stage + SLOT_A0 * HT_BYTES); }    \
-    else if ((which) == 1) { stage_half(SRC_B(0, 0), SRC_B(0, 1), my_piece + issue_stage + SLOT_B0 * HT_BYTES); } \
-    else if ((which) == 2) { stage_half(SRC_B(1, 0), SRC_B(1, 1), my_piece + issue_stage + SLOT_B1 * HT_BYTES); ob[0] += b_step; ob[1] += b_step; } \
+    if ((which) == 0) { stage_half_t<F4>(SRC_A(0, 0), SRC_A(0, 1), my_piece + issue_stage + SLOT_A0 * HT_BYTES); }    \
+    else if ((which) == 1) { stage_half_t<F4>(SRC_B(0, 0), SRC_B(0, 1), my_piece + issue_stage + SLOT_B0 * HT_BYTES); } \
+    else if ((which) == 2) { stage_half_t<F4>(SRC_B(1, 0), SRC_B(1, 1), my_piece + issue_stage + SLOT_B1 * HT_BYTES); ob[0] += b_step; ob[1] += b_step; } \
     else {                                                                                                      \
-      stage_half(SRC_A(1, 0), SRC_A(1, 1), my_piece + issue_stage + SLOT_A1 * HT_BYTES); oa[0] += a_step; oa[1] += a_step;  \
+      stage_half_t<F4>(SRC_A(1, 0), SRC_A(1, 1), my_piece + issue_stage + SLOT_A1 * HT_BYTES); oa[0] += a_step; oa[1] += a_step;  \
       issue_stage ^= STAGE_BYTES;                                                                               \
       if (++stream_kt == nt) {                                                                                  \
         stream_kt = 0;                                                                                          \
-        if constexpr (X3) {                                                                                     \
+        if constexpr (X3 && !F4) {                                                                              \
           if (++stream_seg == nseg) { stream_seg = 0; ++stream_tile; }                                             \
           Acur = stream_seg == 1 ? A_lo : A; Bcur = stream_seg == 2 ? B_lo : B;                                 \
         } else ++stream_tile;                                                                                   \
@@ -389,6 +464,16 @@ gemm_p256_k(const bf16_t* __restrict__ A, const bf16_t* __restrict__ B, bf16_t* 
     int lane_f = lane;
     asm volatile("" : "+v"(lane_f));
     const int g = lane_f >> 4, l16 = lane_f & 15;
+    if constexpr (F4) {           // index = plane (0: hi image, 1: lo image, 8 KiB behind); 64-byte rows
+      const int ra = 64 * wr + l16, rb = 32 * wc + l16;
+#pragma unroll
+      for (int pl = 0; pl < 2; ++pl) {
+        abase[pl] = (lds0 + pl * 8192 + ra * 64 + ((g ^ ((ra >> 2) & 3)) << 4)) ^ read_stage;
+        bbase[pl] = (lds0 + pl * 8192 + rb * 64 + ((g ^ ((rb >> 2) & 3)) << 4)) ^ read_stage;
+      }
+      abase[2] = abase[3] = 0;
+      return;
+    }
     if (!A_KROW) {
       const int r0 = 64 * wr + l16;
 #pragma unroll
@@ -432,7 +517,16 @@ gemm_p256_k(const bf16_t* __restrict__ A, const bf16_t* __restrict__ B, bf16_t* 
     frag_bases();
     if (wr) BARRIER();                    // group 1 runs one barrier behind
     __builtin_amdgcn_sched_barrier(0);
-    const int ntv = X3 ? nseg * nt : nt;  // K-tiles per output tile (bf16x3: nseg plane pairs)
+    const int ntv = (X3 && !F4) ? nseg * nt : nt;  // K-tiles per output tile (bf16x3: nseg plane pairs; fused: K / 32 steps of all planes)
+    if constexpr (F4) {
+      if (ti + 1 < my_tiles) {
+        for (int t = 0; t < ntv; ++t) K_TILE_G4(ISSUE_P, 1, 1, 1, 1, 8, 8, 10, 8);
+      } else {
+        for (int t = 0; t < ntv - 2; ++t) K_TILE_G4(ISSUE_P, 1, 1, 1, 1, 8, 8, 10, 8);
+        K_TILE_G4(ISSUE_P, 1, 1, 0, 0, 8, 8, 8, 4);
+        K_TILE_G4(ISSUE_P, 0, 0, 0, 0, 2, 0, 0, 0);
+      }
+    } else
     if (ti + 1 < my_tiles) {              // the stream runs on into the next tile: every K-tile is a steady-state one
       for (int t = 0; t < ntv; ++t) K_TILE_G(ISSUE_P, 1, 1, 1, 1, 8, 8, 10, 8);
     } else {
@@ -598,7 +692,7 @@ gemm_p256_k(const bf16_t* __restrict__ A, const bf16_t* __restrict__ B, bf16_t* 
 extern int g_mmrca_dbg;
 static int g_num_cus = 0;
 static int g_p256_skew = -1;      // x 10 ns between the four start groups (MMRCA_P256_SKEW; see gemm_p256_k)
-template <bool AK, bool BK2, int ACT, bool ADD, bool X3 = false, bool PLANES = false>
+template <bool AK, bool BK2, int ACT, bool ADD, bool X3 = false, bool PLANES = false, bool F4 = false>
 static void launch_p256(const void* A, const void* B, void* C, const void* bias, const void* addend, void* preact, int64_t M,
                         int64_t N, int64_t K, int64_t lda, int64_t ldb, int64_t ldc, float* colsum, hipStream_t st,
                         const void* A_lo = nullptr, const void* B_lo = nullptr, void* C_lo = nullptr, int nseg = 3, int pre16 = 0) {
@@ -616,8 +710,8 @@ static void launch_p256(const void* A, const void* B, void* C, const void* bias,
   int grid = tiles_m * tiles_n < g_num_cus ? ((tiles_m * tiles_n) & ~7) : g_num_cus;
   if (grid < 8) grid = 8;
   constexpr int LDS_P = 2 * STAGE_BYTES + 32768;       // all 160 KiB of the CU
-  (void)hipFuncSetAttribute((const void*)gemm_p256_k<AK, BK2, ACT, ADD, X3, PLANES>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_P);
-  hipLaunchKernelGGL((gemm_p256_k<AK, BK2, ACT, ADD, X3, PLANES>), dim3(grid), dim3(512), LDS_P, st, (const bf16_t*)A, (const bf16_t*)B,
+  (void)hipFuncSetAttribute((const void*)gemm_p256_k<AK, BK2, ACT, ADD, X3, PLANES, F4>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_P);
+  hipLaunchKernelGGL((gemm_p256_k<AK, BK2, ACT, ADD, X3, PLANES, F4>), dim3(grid), dim3(512), LDS_P, st, (const bf16_t*)A, (const bf16_t*)B,
                      (bf16_t*)C, (const bf16_t*)bias, (const bf16_t*)addend, (bf16_t*)preact, M, N, K, lda, ldb, ldc, tiles_m,
                      tiles_n, colsum, tiles_m * tiles_n >= 2 * g_num_cus ? g_p256_skew : 0, g_mmrca_dbg, (const bf16_t*)A_lo,
                      (const bf16_t*)B_lo, (bf16_t*)C_lo, nseg, pre16);
@@ -675,6 +769,16 @@ int mmrca_gemm256_x3(const void* A_hi, const void* A_lo, const void* B_hi, const
   const bool bk = b_layout == MMRCA_KROW;
   MMRCA_REQUIRE(M * lda * 2 < (1ll << 32) && (bk ? K * ldb : N * ldb) * 2 < (1ll << 32) && M * ldc * 4 < (1ll << 32),
                 "gemm_x3(mfma256): operands must be smaller than 4 GiB");
+  // the fused four-plane form (gemm_p256_k<..., F4>): row-major B, all three plane pairs, K % 32 == 0 (MMRCA_X3_FUSED=0: the three-pass form)
+  static const int x3_fused = getenv("MMRCA_X3_FUSED") ? atoi(getenv("MMRCA_X3_FUSED")) : 1;
+  if (x3_fused && !bk && A_lo && B_lo && K % 32 == 0 && K >= 64) {
+#define L256F(ACT_, PL_) launch_p256<false, false, ACT_, false, true, PL_, true>(A_hi, B_hi, C, bias, nullptr, preact, M, N, K, lda, ldb, ldc, nullptr, st, A_lo, B_lo, C_lo, 3, pre16)
+    if (act == MMRCA_ACT_GELU_SAVE_GRAD) { if (C_lo) L256F(MMRCA_ACT_GELU_SAVE_GRAD, true); else L256F(MMRCA_ACT_GELU_SAVE_GRAD, false); }
+    else { if (C_lo) L256F(MMRCA_ACT_NONE, true); else L256F(MMRCA_ACT_NONE, false); }
+#undef L256F
+    MMRCA_CHECK_LAUNCH("gemm_x3(mfma256,fused)");
+    return 0;
+  }
 #define L256X(BK_, ACT_, PL_) launch_p256<false, BK_, ACT_, false, true, PL_>(A_hi, B_hi, C, bias, nullptr, preact, M, N, K, lda, ldb, ldc, nullptr, st, A_lo, B_lo, C_lo, A_lo ? (B_lo ? 3 : 2) : 1, pre16)
   if (act == MMRCA_ACT_GELU_SAVE_GRAD) {
     if (C_lo) { if (bk) L256X(true, MMRCA_ACT_GELU_SAVE_GRAD, true); else L256X(false, MMRCA_ACT_GELU_SAVE_GRAD, true); }
