@@ -213,8 +213,18 @@ class ConvEncoder:
                 t.copy_(torch.as_tensor(sd[prefix + k]).to(t.device, t.dtype))
 
     # ------------------------------------------------------------------ storage helpers
+    # compute dtype of the backbone: the owner's, unless the owner runs its conv encoder in another precision than its transformer
+    # encoders (engine.MMRCAEngine in bf16x3f mode: bf16 conv kernels next to the fp32-accurate text encoder)
+    @property
+    def cdtype(self):
+        return getattr(self.o, "conv_dtype", None) or self.o.dtype
+
+    @property
+    def cdt(self):
+        return L.dtype_code(self.cdtype)
+
     def buf(self, name, rows, cols, dtype=None):
-        dtype = dtype or self.o.dtype
+        dtype = dtype or self.cdtype
         key = (name, rows, cols, dtype)
         t = self._bufs.get(key)
         if t is None:
@@ -227,7 +237,8 @@ class ConvEncoder:
         self.saved = None
 
     def W(self, key):
-        return self.o.W("image_model." + key)
+        convW = getattr(self.o, "convW", None)        # (parameter view in the conv encoder's compute dtype when that differs from the owner's)
+        return convW("image_model." + key) if convW is not None else self.o.W("image_model." + key)
 
     def G(self, key):
         return self.o.G("image_model." + key)
@@ -243,7 +254,7 @@ class ConvEncoder:
     def _tap_major(self, u: "_Unit") -> bool:
         """dense 3x3 convolutions in bf16 with cin % 8 == 0 run on tap-major patches (k = tap*cin + c: every im2row / col2im
         access is a contiguous 16-byte vector); the 3-channel stem and the fp32 mode keep torchvision's channel-major order"""
-        return TAP_MAJOR and self.o.dtype == torch.bfloat16 and u.cin % 8 == 0
+        return TAP_MAJOR and self.cdtype == torch.bfloat16 and u.cin % 8 == 0
 
     def _tap_k(self, u: "_Unit") -> int:
         """Patch width of a tap-major dense 3x3 convolution.  With cout % 128 == 0 the 9*cin columns are padded with zeros to a
@@ -289,7 +300,7 @@ class ConvEncoder:
         """x: rows [B*H*W, cin] -> y rows [B*Ho*Wo, cout]; returns (y, Ho, Wo, saved).  With `res` (the block input) the unit is
         the last one of a residual block and writes out = res + rowscale[sample] * y directly (mmrca_bn_act_fwd_res) when the
         fused kernel is built for the dtype; the caller checks `saved["fused_res"]`."""
-        dt = self.o.dt
+        dt = self.cdt
         Ho, Wo = (H - 1) // u.stride + 1, (Wd - 1) // u.stride + 1
         rows = B * Ho * Wo
         z = self.buf(tag + ".z", rows, u.cout)
@@ -335,7 +346,7 @@ class ConvEncoder:
             L.bn_finish_sums(sums[0], sums[1], rm, sums[2], rows, mean, rstd, rm, rv, u.cout, u.eps, 0.1)
         else:
             L.bn_stats(z, mean, rstd, rm, rv, rows, u.cout, u.cout, u.eps, 0.1 if train else 0.0, train, dt)
-        fused_res = res is not None and FUSE_RES and self.o.dtype == torch.bfloat16 and u.cout % 8 == 0
+        fused_res = res is not None and FUSE_RES and self.cdtype == torch.bfloat16 and u.cout % 8 == 0
         if fused_res:
             y = out
             L.bn_act_fwd_res(z, mean, rstd, self.W(u.bn_key + ".weight"), self.W(u.bn_key + ".bias"), res, rowscale, y, rows, u.cout, u.act,
@@ -348,7 +359,7 @@ class ConvEncoder:
     def _unit_bwd(self, u: _Unit, dy, sv, B, need_dx=True, tag="g", sums_ready=False):
         """dy: gradient at the unit's output rows; returns dx rows (or None).  sums_ready: the BatchNorm-backward sums of this unit are
         already in the shared scratch (the squeeze-excitation backward accumulated them while it wrote dy)."""
-        dt = self.o.dt
+        dt = self.cdt
         H, Wd, Ho, Wo = sv["H"], sv["W"], sv["Ho"], sv["Wo"]
         rows = B * Ho * Wo
         dz = self.buf(f"{tag}.dz.{u.cout}", rows, u.cout)
@@ -410,7 +421,7 @@ class ConvEncoder:
 
     # ------------------------------------------------------------------ squeeze-excitation
     def _se_fwd(self, se: _SE, x, B, HW, tag, save):
-        dt = self.o.dt
+        dt = self.cdt
         n = lambda s, r, c: self.buf(tag + s, r, c)
         pooled, h_pre, h = n(".se.pool", B, se.c), n(".se.hpre", B, se.sq), n(".se.h", B, se.sq)
         s_pre, s = n(".se.spre", B, se.c), n(".se.s", B, se.c)
@@ -426,11 +437,11 @@ class ConvEncoder:
     def _se_bwd(self, se: _SE, dy, sv, B, gp="g", bn=None):
         """returns (dx, sums_ready).  bn = (unit, saved) of the BatchNorm + activation that produced the block's SE input: with the
         fused kernels (bf16, c % 8 == 0) its backward sums are accumulated while dx is written (mmrca_se_dx)."""
-        dt = self.o.dt
+        dt = self.cdt
         HW = sv["HW"]
         g = lambda s, r, c: self.buf(gp + ".se" + s + f".{c}", r, c)
         dx, ds = self.buf(f"{gp}.se.dx.{se.c}.{B * HW}", B * HW, se.c), g(".ds", B, se.c)
-        fused = FUSE_SE and self.o.dtype == torch.bfloat16 and se.c % 8 == 0
+        fused = FUSE_SE and self.cdtype == torch.bfloat16 and se.c % 8 == 0
         L.se_scale_bwd(dy, sv["x"], sv["s"], None if fused else dx, ds, B, HW, se.c, dt)
         ds_pre = g(".dspre", B, se.c)
         L.bias_act_bwd(ds, sv["s_pre"], self.W(se.key + ".fc2.bias"), ds_pre, self.G(se.key + ".fc2.bias"), B, se.c, L.CONV_SIGMOID, dt)
@@ -462,7 +473,7 @@ class ConvEncoder:
     # ------------------------------------------------------------------ whole network
     def forward(self, images, save: bool, train: bool, seed: int = 0):
         """images [B,3,H,W] fp32 in HBM -> features [B, dim] (the pooled vector MM_RCA consumes, multimodal_model.py:659)."""
-        dt = self.o.dt
+        dt = self.cdt
         B, C, H, Wd = images.shape
         if C != 3:
             raise ValueError(f"images must be [B,3,H,W], got {tuple(images.shape)}")
@@ -551,7 +562,7 @@ class ConvEncoder:
     def _shuffle_cat(self, a, b, rows, Cc, name, first_is_full=False):
         """channel_shuffle(cat(a', b), groups=2): out[:, 2j] = a'[:, j], out[:, 2j+1] = b[:, j]  (a' = first half of a when
         first_is_full).  Two gathers into the interleaved columns are written as one gather each over a [rows, Cc] view."""
-        dt = self.o.dt
+        dt = self.cdt
         bf = Cc // 2
         out = self.buf(name + f".{Cc}.{rows}", rows, Cc)
         # out[r, j] = src[r, map[j]] needs ONE source: assemble through a contiguous concat buffer first
@@ -565,7 +576,7 @@ class ConvEncoder:
 
     def _shuffle_cat_bwd(self, dout, rows, Cc, gp="g"):
         """inverse of _shuffle_cat: returns (d first half [rows, bf], d second half [rows, bf])."""
-        dt = self.o.dt
+        dt = self.cdt
         bf = Cc // 2
         d1, d2 = self.buf(f"{gp}.sh1.{bf}.{rows}", rows, bf), self.buf(f"{gp}.sh2.{bf}.{rows}", rows, bf)
         L.channel_gather(dout, self._cmap(("unshuf_a", Cc), [2 * j for j in range(bf)]), d1, rows, Cc, bf, bf, 0, dt)
@@ -577,7 +588,7 @@ class ConvEncoder:
         sv = self.saved
         if sv is None:
             raise L.MmrcaError("conv backbone: backward() needs forward(save=True)")
-        dt = self.o.dt
+        dt = self.cdt
         B = sv["B"]
         HW = sv["HW"]
         dpool = self.buf("g.dfeat", B, self.dim)

@@ -190,6 +190,12 @@ class MMRCAEngine:
         self.gdtype = torch.bfloat16 if self.x3f else dtype
         self.bdt = L.BF16 if self.x3f else self.dt
         self.gemm_impl, self.attn_impl = gemm_impl, attn_impl
+        # bf16x3f with a conv image backbone: the conv kernels run in bf16 (on the hi planes of the weights) next to the fp32-accurate text
+        # encoder.  Measured on the initialisation the model trains from (tools/conv_feature_error.py, 480 x 480): of the bf16 mode's
+        # logits error (1.0e-3 EfficientNetV2-M, 1.5e-3 -L) the TEXT encoder's bf16 feature carries 7.8e-4 / 1.3e-3 and the conv backbone's
+        # 3.9e-4 / 5.4e-4 -- BatchNorm renormalises every layer -- so this split meets the 1e-3 bound at nearly the bf16 mode's speed,
+        # where the all-fp32 conv kernels of bf16x3 run at a fifth of it.
+        self.conv_dtype = torch.bfloat16 if (self.x3f and image_model in CONV_MODELS) else None
         # conv image backbones (EfficientNetV2-M/L, ShuffleNetV2): conv_engine.ConvEncoder over csrc/conv.hip
         self.conv = ConvEncoder(image_model, self, image_size) if self.vs is None else None
         self.d_txt, self.d_img = self.ts.dim, (self.vs.dim if self.vs is not None else self.conv.dim)
@@ -288,6 +294,10 @@ class MMRCAEngine:
     def W(self, key):
         """parameter view in the compute dtype"""
         return self.arena.view(key, "lp" if self.dtype == torch.bfloat16 else "p")
+
+    def convW(self, key):
+        """parameter view in the conv encoder's compute dtype (bf16x3f: the bf16 hi plane while W() hands out the fp32 masters)"""
+        return self.arena.view(key, "lp") if self.conv_dtype == torch.bfloat16 else self.W(key)
 
     def Wflat(self, key, numel):
         off = self.arena.offsets[key][0]
@@ -978,7 +988,8 @@ class MMRCAEngine:
     # ------------------------------------------------------------------ whole model
     def _image_forward(self, images, save, bn_train, seed):
         if self.conv is not None:
-            return self.conv.forward(images, save, bn_train, seed), None
+            feat = self.conv.forward(images, save, bn_train, seed)
+            return (feat.to(self.dtype) if feat.dtype != self.dtype else feat), None       # (bf16 conv features under an fp32 head)
         return self._vision_forward(images, save)
 
     def forward(self, ids, mask, images, drop_p: float = 0.0, seed: int = 0, save: bool = True, enc_drop_p: float = 0.0,

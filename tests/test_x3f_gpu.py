@@ -245,3 +245,61 @@ def test_x3f_train_steps_follow_the_fp32_mode_and_keep_the_planes():
     assert abs(l3[0] - l32[0]) < 2e-5                  # the forward is the fp32-accurate one
     assert max(abs(a - b) for a, b in zip(l3, l32)) < 5e-3
     assert float((p3 - p32).abs().max()) < 2e-3
+
+
+@pytest.mark.parametrize("text_model,image_model,size,B", [("distilbert", "eff_v2_medium", 224, 4), ("roberta", "eff_v2_large", 160, 3)])
+def test_x3f_with_a_conv_backbone_runs_the_conv_kernels_in_bf16_and_meets_the_bound(text_model, image_model, size, B):
+    """bf16x3f over a conv image backbone (the reference's default model, multimodal_model.py:11-36, 113-126, and configs[2]'s pairing):
+    the text encoder is the fp32-accurate bf16x3 forward, the conv backbone runs its bf16 kernels on the hi planes of the weights.
+    Logits <= 1e-3 against the oracle (eval-mode BatchNorm) -- the bf16 mode itself does not meet it on these weights because of its
+    TEXT encoder -- and a train-mode step reaches every parameter group with finite gradients that match the bf16 mode's conv gradients."""
+    from garbage_classification_rca_amd.procedural import synth_captions
+    from tests.test_engine_gpu import rel
+    eng = MMRCAEngine(text_model, image_model, 4, True, 0, "bf16x3f", image_size=size)
+    assert eng.x3f and eng.conv_dtype == torch.bfloat16 and eng.conv.cdtype == torch.bfloat16
+    eng.init_parameters(0)
+    sd = {k: eng.arena.view(k).detach().cpu().clone() for k in eng.param_keys}
+    orc = O.build_oracle(text_model, image_model, True, False, False, drop_ratio=0.0, enc_dropout=0.0).eval()
+    orc.text_model.load_flat(sd, "text_model.")
+    orc.image_model.load_state_dict({k[len("image_model."):]: v for k, v in sd.items() if k.startswith("image_model.")}, strict=False)
+    orc.load_state_dict({k: v for k, v in sd.items() if not k.startswith(("text_model.", "image_model."))}, strict=False)
+    ids, mask = (torch.from_numpy(a) for a in synth_captions(B, 32, seed=1))
+    if text_model == "roberta":
+        ids = ids.clone(); ids[mask == 0] = 1
+    images = torch.randn(B, 3, size, size, generator=torch.Generator().manual_seed(3))
+    logits = eng.forward(ids.cuda(), mask.cuda(), images.cuda(), save=False, bn_train=False)
+    with torch.no_grad():
+        ref = orc(ids, mask, images, eval=True)
+    e = rel(logits, ref)
+    e16 = MMRCAEngine(text_model, image_model, 4, True, 0, torch.bfloat16, image_size=size)
+    e16.load_arrays(sd)
+    eb = rel(e16.forward(ids.cuda(), mask.cuda(), images.cuda(), save=False, bn_train=False), ref)
+    print(f"{image_model} + {text_model} {size}^2: logits vs oracle bf16x3f {e:.2e}, bf16 {eb:.2e}")
+    assert e < 1e-3 and e < eb
+    # one train-mode step: every group is reached with finite gradients; and for the SAME gradient at the backbone's output the conv
+    # gradients of the two modes coincide (the same bf16 kernels on the same bf16 weights and activations)
+    dl = torch.randn(B, 4, generator=torch.Generator().manual_seed(5)).cuda() * 0.1
+    dfeat = torch.randn(B, eng.d_img, generator=torch.Generator().manual_seed(6)).cuda() * 0.1
+    grads = {}
+    for name, en in (("x3f", eng), ("bf16", e16)):
+        en.conv.injected_keep = torch.ones(sum(1 for b in en.conv.blocks if b.get("res") and b.get("sd", 0) > 0), B)
+        en.forward(ids.cuda(), mask.cuda(), images.cuda(), drop_p=0.0, seed=5, save=True, bn_train=True)
+        en.arena.g.zero_()
+        en.backward(dl)
+        torch.cuda.synchronize()
+        assert torch.isfinite(en.arena.g).all()
+        for grp in ("image_emb", "text_emb", "head"):
+            lo, hi = en.groups[grp]
+            assert float(en.arena.g[lo:hi].abs().max()) > 0, (name, grp)
+        # (BatchNorm on running statistics for the comparison: with batch statistics a randomly initialised EfficientNetV2 amplifies
+        # the summation-order noise of its own fp32 atomics ~30x -- test_fullsize_gpu.py -- so two runs of ONE engine already differ)
+        en.forward(ids.cuda(), mask.cuda(), images.cuda(), drop_p=0.0, seed=5, save=True, bn_train=False)
+        en.arena.g.zero_()
+        en.conv.backward(dfeat)
+        torch.cuda.synchronize()
+        grads[name] = en.arena.g.clone()
+    lo, hi = eng.image_span[0], eng.groups["head"][0]
+    cos = float(torch.nn.functional.cosine_similarity(grads["x3f"][lo:hi].double(), grads["bf16"][lo:hi].double(), dim=0))
+    print("conv-backbone gradients for the same upstream gradient, bf16x3f vs bf16 mode: cosine", cos)
+    assert cos > 0.999            # (fp32 atomics order + the bf16 rounding of the other mode's upstream activations)
+    eng.release_buffers(); e16.release_buffers()
