@@ -518,7 +518,7 @@ def main():
         # rocprofv3 --pmc passes over THIS command (tools/pmc_traffic.py) is quoted, next to the algorithmic bytes
         # (operands once + outputs once, from the launch shapes of this run)
         traffic, traffic_src = None, None
-        for pmc_name in ("r03_pmc_hbm_traffic.json", "r02_pmc_hbm_traffic.json", "r01_pmc_hbm_traffic.json"):
+        for pmc_name in ("r04_pmc_hbm_traffic.json", "r03_pmc_hbm_traffic.json", "r02_pmc_hbm_traffic.json", "r01_pmc_hbm_traffic.json"):
             pmc_json = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", pmc_name)
             if os.path.exists(pmc_json):
                 with open(pmc_json) as fh:
@@ -526,7 +526,7 @@ def main():
                 # the summary names the GEMM sources it was measured on (tools/pmc_traffic.py); a kernel edit since then makes it stale
                 if pj.get("gemm_sources_sha256") != gemm_sources_sha256():
                     traffic_src = (f"profiles/{pmc_name} is STALE (measured on other GEMM sources: {str(pj.get('gemm_sources_sha256'))[:12]} vs "
-                                   f"{gemm_sources_sha256()[:12]} now); not quoted -- re-run tools/r03_artifacts.sh")
+                                   f"{gemm_sources_sha256()[:12]} now); not quoted -- re-run tools/r04_artifacts.sh")
                     break
                 traffic = pj.get("gemm_hbm_bytes_per_launch_mean")
                 traffic_src = (f"profiles/{pmc_name} (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes, x2 gfx950 fetch correction; "

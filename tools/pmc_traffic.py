@@ -29,7 +29,7 @@ for k in sorted(fe, key=lambda k: -fe[k][0]):
     n = fe[k][1]
     f, w = fe[k][0] / n, (wr[k][0] / wr[k][1] if k in wr and wr[k][1] else 0.0)
     is_gemm = k.startswith(("gemm_mfma", "gemm_p256"))
-    wide16 = is_gemm or k.startswith(("mha_fwd_mfma", "mha_bwd_", "mha_fwd_f32m", "ln_bwd_bf16_k", "add_ln_fwd_bf16_k"))
+    wide16 = is_gemm or any(t in k for t in ("mha_fwd_mfma", "mha_bwd_", "mha_fwd_f32m", "ln_bwd_bf16_k", "add_ln_fwd_bf16_k"))      # (some names arrive mangled)
     row = {"launches_seen": n, "fetch_bytes_per_launch_reported": round(f), "write_bytes_per_launch": round(w)}
     if wide16:
         row["fetch_bytes_per_launch_corrected_x2"] = round(2 * f)
