@@ -50,6 +50,18 @@ extern "C" int mmrca_mha_fwd_planes_in(const void* qkv_hi, const void* qkv_lo, c
   return mmrca_mha_fwd_f32m(qkv_hi, key_mask, out, lse, B, H, S, dh, scale, drop_p, drop_seed, cu_seqlens, (hipStream_t)stream, out_hi, out_lo, qkv_lo);
 }
 
+// The same arithmetic on the bf16 matrix cores: every product three-pass over the planes (attention_mfma.hip::mha_fwd_x3_k), S <= 224.
+// q|k|v AND the context as two bf16 planes; no fp32 tensor is read or written.  What the bf16x3f mode runs.
+int mmrca_mha_fwd_x3_launch(const void*, const void*, const int32_t*, void*, void*, float*, int, int, int, int, float, float, uint64_t, const int32_t*, hipStream_t);
+extern "C" int mmrca_mha_fwd_x3(const void* qkv_hi, const void* qkv_lo, const int32_t* key_mask, void* out_hi, void* out_lo, float* lse,
+                                int B, int H, int S, int dh, float scale, float drop_p, uint64_t drop_seed, const int32_t* cu_seqlens,
+                                void* stream) {
+  MMRCA_REQUIRE(qkv_hi && qkv_lo && out_hi && out_lo && lse, "mha_fwd_x3: null pointer");
+  MMRCA_REQUIRE(drop_p >= 0.f && drop_p < 1.f, "mha_fwd_x3: dropout p must be in [0,1)");
+  MMRCA_REQUIRE(B > 0 && H > 0, "mha_fwd_x3: bad shape");
+  return mmrca_mha_fwd_x3_launch(qkv_hi, qkv_lo, key_mask, out_hi, out_lo, lse, B, H, S, dh, scale, drop_p, drop_seed, cu_seqlens, (hipStream_t)stream);
+}
+
 static int mha_bwd_impl(const void* qkv, const int32_t* key_mask, const void* out, const void* dout, const float* lse,
                         void* dqkv, float* dqkv_colsum, int64_t rows, int B, int H, int S, int dh, float scale, float drop_p,
                         uint64_t drop_seed, const int32_t* cu_seqlens, int dtype, int impl, void* stream) {

@@ -233,6 +233,119 @@ mha_fwd_mfma_k(const bf16_t* __restrict__ qkv, const int32_t* __restrict__ key_m
 }
 
 // ------------------------------------------------------------------------------------------------------
+// forward with fp32 ACCURACY on the bf16 matrix cores ("bf16x3" attention: the bf16x3f mode's forward)
+// ------------------------------------------------------------------------------------------------------
+// q | k | v arrive as the two bf16 planes a bf16x3 GEMM wrote (value = hi + lo to 2^-17) and every product is formed as in
+// gemm_x3.hip: S = K_hi Q_hi + K_lo Q_hi + K_hi Q_lo, O = V_hi P_hi + V_lo P_hi + V_hi P_lo with P = P_hi + P_lo split in registers
+// (lo x lo is below fp32 resolution), fp32 softmax statistics in between -- the arithmetic of the fp32-matrix-core kernels of
+// attention_f32.hip to ~1e-6, at the bf16 MFMA rate (the fp32 pipe is 1/16 of it: those kernels spend half of their 495 us per
+// ViT layer in MFMAs).  Four LDS images (K_hi, K_lo, V_hi, V_lo) by LDS-DMA; same mask / packed-layout / dropout / lse contract as
+// mha_fwd_mfma_k; the context is written as two planes (what the out-projection GEMM and the bf16 backward read).
+template <int NKT, bool DROP, int NW>
+__global__ void __launch_bounds__(64 * NW)
+mha_fwd_x3_k(const bf16_t* __restrict__ qkv, const bf16_t* __restrict__ qkv_lo, const int32_t* __restrict__ key_mask,
+             bf16_t* __restrict__ out_hi, bf16_t* __restrict__ out_lo, float* __restrict__ lse, int H, int Smax, float scale,
+             float drop_p, uint64_t drop_seed, const int32_t* __restrict__ cu) {
+  const float drop_sc = DROP ? 1.f / (1.f - drop_p) : 1.f;
+  extern __shared__ __attribute__((aligned(16))) char sm[];
+  constexpr int Spad = NKT * 16, IMG = Spad * 128;
+  char* Kh = sm; char* Kl = sm + IMG; char* Vh = sm + 2 * IMG; char* Vl = sm + 3 * IMG;
+  float* kb = reinterpret_cast<float*>(sm + 4 * IMG);
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, g = lane >> 4, l16 = lane & 15;
+  const int b = blockIdx.x / H, h = blockIdx.x % H;
+  AT_SEQ(b, Smax, cu)
+  const int64_t ld = 3LL * H * AT_DH;
+  const int64_t q_off = (int64_t)row0 * ld + h * AT_DH, k_off = q_off + H * AT_DH, v_off = k_off + H * AT_DH;
+  stage_rows(Kh, IMG_ROW, qkv + k_off, ld, S, Spad);
+  stage_rows(Kl, IMG_ROW, qkv_lo + k_off, ld, S, Spad);
+  stage_rows(Vh, IMG_TR, qkv + v_off, ld, S, Spad);
+  stage_rows(Vl, IMG_TR, qkv_lo + v_off, ld, S, Spad);
+  stage_key_bias(kb, key_mask ? key_mask + row0 : nullptr, S, Spad);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  const float c1 = scale * LOG2E;                    // scores live in the exp2 domain
+  const int nqt = (S + 15) / 16;
+  for (int qt = wave; qt < nqt; qt += NW) {
+    const int q0 = qt * 16;
+    const bf16x8 qh0 = frag_global(qkv + q_off, ld, q0, S, 0, lane), qh1 = frag_global(qkv + q_off, ld, q0, S, 1, lane);
+    const bf16x8 ql0 = frag_global(qkv_lo + q_off, ld, q0, S, 0, lane), ql1 = frag_global(qkv_lo + q_off, ld, q0, S, 1, lane);
+    f32x4 s[NKT];
+#pragma unroll
+    for (int kt = 0; kt < NKT; ++kt) {
+      const bf16x8 kh0 = frag_rows(Kh, IMG_ROW, kt * 16, 0, lane), kh1 = frag_rows(Kh, IMG_ROW, kt * 16, 1, lane);
+      const bf16x8 kl0 = frag_rows(Kl, IMG_ROW, kt * 16, 0, lane), kl1 = frag_rows(Kl, IMG_ROW, kt * 16, 1, lane);
+      f32x4 a = {0.f, 0.f, 0.f, 0.f};
+      a = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kl0, qh0, a, 0, 0, 0);      // the small terms first
+      a = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kl1, qh1, a, 0, 0, 0);
+      a = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kh0, ql0, a, 0, 0, 0);
+      a = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kh1, ql1, a, 0, 0, 0);
+      a = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kh0, qh0, a, 0, 0, 0);
+      a = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kh1, qh1, a, 0, 0, 0);
+      s[kt] = a;
+      if (kt & 1) __builtin_amdgcn_sched_barrier(0);
+    }
+    float mm = -INFINITY;
+#pragma unroll
+    for (int kt = 0; kt < NKT; ++kt) {
+      const f32x4 bias = *reinterpret_cast<const f32x4*>(kb + kt * 16 + 4 * g);     // keys 16kt + 4g + r
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const float v = fmaf(s[kt][r], c1, bias[r]);
+        s[kt][r] = v;
+        mm = fmaxf(mm, v);
+      }
+    }
+    mm = colgroup_max(mm);
+    float ll = 0.f;
+    const float msafe = mm > -INFINITY ? mm : 0.f;
+#pragma unroll
+    for (int kt = 0; kt < NKT; ++kt)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) { const float e = __builtin_amdgcn_exp2f(s[kt][r] - msafe); s[kt][r] = e; ll += e; }
+    ll = colgroup_sum(ll);
+    if (DROP) {      // dropout acts on the normalised probabilities: mask the numerators, keep the denominator
+#pragma unroll
+      for (int kt = 0; kt < NKT; ++kt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) s[kt][r] *= attn_keep(drop_p, drop_sc, drop_seed, blockIdx.x, Smax, q0 + l16, kt * 16 + 4 * g + r);
+    }
+    f32x4 o[4];
+#pragma unroll
+    for (int dt = 0; dt < 4; ++dt) o[dt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int u = 0; u < NKT / 2; ++u) {
+      const bf16x8 ph = pack_pair(s[2 * u], s[2 * u + 1]);
+      f32x4 ra, rb;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) { ra[r] = s[2 * u][r] - (float)ph[r]; rb[r] = s[2 * u + 1][r] - (float)ph[4 + r]; }
+      const bf16x8 pl = pack_pair(ra, rb);
+#pragma unroll
+      for (int dt = 0; dt < 4; ++dt) {
+        const bf16x8 vh = frag_cols_tr(Vh, u, dt, lane), vl = frag_cols_tr(Vl, u, dt, lane);
+        o[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vl, ph, o[dt], 0, 0, 0);
+        o[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vh, pl, o[dt], 0, 0, 0);
+        o[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vh, ph, o[dt], 0, 0, 0);   // O^T[d][q]
+      }
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    const int q = q0 + l16;
+    if (q < S) {
+      const float inv = ll > 0.f ? 1.f / ll : 0.f;
+      const int64_t off = ((int64_t)row0 + q) * (H * AT_DH) + h * AT_DH;
+#pragma unroll
+      for (int dt = 0; dt < 4; ++dt) {
+        bf16x4 vh, vl;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) { const float v = o[dt][r] * inv; vh[r] = (bf16_t)v; vl[r] = (bf16_t)(v - (float)vh[r]); }
+        *reinterpret_cast<bf16x4*>(out_hi + off + dt * 16 + 4 * g) = vh;
+        *reinterpret_cast<bf16x4*>(out_lo + off + dt * 16 + 4 * g) = vl;
+      }
+      if (g == 0) lse[((int64_t)b * H + h) * Smax + q] = ll > 0.f ? mm * LN2 + __logf(ll) : INFINITY;
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------------
 // forward, persistent over heads (unmasked, no dropout, padded layout: the ViT's attention)
 // ------------------------------------------------------------------------------------------------------
 // The per-head kernel above spends half of its waves' lifetime parked: all waves of a (b,h) wait for the 50 KB K/V staging and
@@ -1536,6 +1649,32 @@ int mmrca_mha_fwd_mfma(const void* qkv, const int32_t* key_mask, void* out, floa
   }
   AT_SWITCH(K_FWD, BIAS_EXTRA, true, false, false, (const bf16_t*)qkv, key_mask, (bf16_t*)out, lse, H, S, scale, drop_p, drop_seed, cu);
   MMRCA_CHECK_LAUNCH("mha_fwd(mfma)");
+  return 0;
+}
+
+// bf16x3 attention forward (mha_fwd_x3_k): head dim 64, S <= 224
+bool mmrca_mha_x3_ok(int S, int dh) { return dh == AT_DH && S >= 1 && S <= 224; }
+int mmrca_mha_fwd_x3_launch(const void* qkv_hi, const void* qkv_lo, const int32_t* key_mask, void* out_hi, void* out_lo, float* lse, int B, int H,
+                            int S, int dh, float scale, float drop_p, uint64_t drop_seed, const int32_t* cu, hipStream_t st) {
+  MMRCA_REQUIRE(mmrca_mha_x3_ok(S, dh), "mha_fwd_x3: needs head dim 64 and 1 <= S <= 224 (got S=%d dh=%d)", S, dh);
+  MMRCA_REQUIRE(((((uintptr_t)qkv_hi) | ((uintptr_t)qkv_lo)) & 15) == 0 && ((((uintptr_t)out_hi) | ((uintptr_t)out_lo)) & 7) == 0, "mha_fwd_x3: alignment");
+  const int nkt = pick_nkt(S);
+#define LX3(NKT_, DROP_, NW_)                                                                                                      \
+  do {                                                                                                                             \
+    const int ldsb = 4 * NKT_ * 16 * 128 + BIAS_EXTRA(NKT_);                                                                       \
+    (void)hipFuncSetAttribute((const void*)mha_fwd_x3_k<NKT_, DROP_, NW_>, hipFuncAttributeMaxDynamicSharedMemorySize, ldsb);      \
+    hipLaunchKernelGGL((mha_fwd_x3_k<NKT_, DROP_, NW_>), dim3(B * H), dim3(64 * NW_), ldsb, st, (const bf16_t*)qkv_hi, (const bf16_t*)qkv_lo, key_mask, \
+                       (bf16_t*)out_hi, (bf16_t*)out_lo, lse, H, S, scale, drop_p, drop_seed, cu);                                 \
+  } while (0)
+  const bool drop = drop_p > 0.f;
+  switch (nkt) {
+    case 2: if (drop) LX3(2, true, 4); else LX3(2, false, 4); break;
+    case 4: if (drop) LX3(4, true, 4); else LX3(4, false, 4); break;
+    case 8: if (drop) LX3(8, true, 8); else LX3(8, false, 8); break;
+    default: if (drop) LX3(14, true, 8); else LX3(14, false, 8); break;
+  }
+#undef LX3
+  MMRCA_CHECK_LAUNCH("mha_fwd_x3");
   return 0;
 }
 

@@ -600,7 +600,10 @@ class MMRCAEngine:
     def _mha_fwd(self, qkv, mask32, ctx, lse, B, H, S, dh, drop_p=0.0, drop_seed=0, cu=None):
         if isinstance(qkv, Planes):
             key, pl = self._planes_of(ctx)
-            L.mha_fwd_planes_in((qkv.hi, qkv.lo), mask32, None, pl, lse, B, H, S, dh, dh ** -0.5, drop_p=drop_p, drop_seed=drop_seed, cu=cu)
+            if L.mha_fwd_x3_ok(S, dh):      # three-pass products on the bf16 matrix cores (the fp32 pipe is 1/16 of their rate)
+                L.mha_fwd_x3((qkv.hi, qkv.lo), mask32, pl, lse, B, H, S, dh, dh ** -0.5, drop_p=drop_p, drop_seed=drop_seed, cu=cu)
+            else:
+                L.mha_fwd_planes_in((qkv.hi, qkv.lo), mask32, None, pl, lse, B, H, S, dh, dh ** -0.5, drop_p=drop_p, drop_seed=drop_seed, cu=cu)
             self._plane_fresh.add(key)
             return
         if self.x3 and self._ln_planes and self.attn_impl == L.IMPL_AUTO and L.mha_fwd_planes_ok(S, dh):

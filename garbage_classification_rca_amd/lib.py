@@ -96,6 +96,7 @@ _SIGS = {
     "mmrca_mha_fwd": [_vp] * 4 + [_i32] * 4 + [_f32, _f32, _u64, _vp, _i32, _i32, _vp],
     "mmrca_mha_fwd_planes": [_vp] * 6 + [_i32] * 4 + [_f32, _f32, _u64, _vp, _vp],
     "mmrca_mha_fwd_planes_in": [_vp] * 7 + [_i32] * 4 + [_f32, _f32, _u64, _vp, _vp],
+    "mmrca_mha_fwd_x3": [_vp] * 6 + [_i32] * 4 + [_f32, _f32, _u64, _vp, _vp],
     "mmrca_mha_bwd": [_vp] * 6 + [_i32] * 4 + [_f32, _f32, _u64, _vp, _i32, _i32, _vp],
     "mmrca_mha_bwd_colsum": [_vp] * 7 + [_i64] + [_i32] * 4 + [_f32, _f32, _u64, _vp, _i32, _i32, _vp],
     "mmrca_mha_cross_fwd": [_vp, _i64, _vp, _i64, _vp, _i64, _vp, _i64] + [_i32] * 5 + [_f32, _f32, _u64, _i32, _i32, _vp],
@@ -346,6 +347,18 @@ def mha_fwd_planes_in(qkv_planes, key_mask, out, out_planes, lse, B, H, S, dh, s
         _check(load().mmrca_mha_fwd_planes_in(ptr(qkv_planes[0]), ptr(qkv_planes[1]), ptr(key_mask), ptr(out), ptr(out_planes[0]),
                                               ptr(out_planes[1]), ptr(lse), B, H, S, dh, scale, drop_p, drop_seed, ptr(cu), stream_ptr()),
                "mmrca_mha_fwd_planes_in")
+
+
+def mha_fwd_x3_ok(S, dh):
+    return dh == 64 and 1 <= S <= 224 and os.environ.get("MMRCA_ATTN_X3", "1") != "0"
+
+
+def mha_fwd_x3(qkv_planes, key_mask, out_planes, lse, B, H, S, dh, scale, drop_p=0.0, drop_seed=0, cu=None):
+    """bf16x3 attention forward on the bf16 matrix cores: q|k|v and the context as (hi, lo) bf16 planes"""
+    _dev(qkv_planes[0], "mha qkv")
+    with _Bracket("mha_fwd", (B, H, S, dh, cu is not None)):
+        _check(load().mmrca_mha_fwd_x3(ptr(qkv_planes[0]), ptr(qkv_planes[1]), ptr(key_mask), ptr(out_planes[0]), ptr(out_planes[1]), ptr(lse),
+                                       B, H, S, dh, scale, drop_p, drop_seed, ptr(cu), stream_ptr()), "mmrca_mha_fwd_x3")
 
 
 def mha_bwd(qkv, key_mask, out, dout, lse, dqkv, B, H, S, dh, scale, dtype, impl=IMPL_AUTO, drop_p=0.0, drop_seed=0, colsum=None,

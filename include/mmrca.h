@@ -261,6 +261,12 @@ int mmrca_mha_fwd_planes(const void* qkv, const int32_t* key_mask, void* out, vo
 int mmrca_mha_fwd_planes_in(const void* qkv_hi, const void* qkv_lo, const int32_t* key_mask, void* out, void* out_hi, void* out_lo,
                             float* lse, int B, int H, int S, int dh, float scale, float drop_p, uint64_t drop_seed,
                             const int32_t* cu_seqlens, void* stream);
+/* The bf16x3 attention forward: q|k|v and the context as two bf16 planes each, every product (QK^T, PV) three-pass on the bf16 matrix
+ * cores with P split in registers, fp32 softmax statistics -- the fp32 arithmetic of the kernels above to ~1e-6 at the bf16 MFMA
+ * rate.  Head dim 64, 1 <= S <= 224; mask / packed layout / dropout / lse as mmrca_mha_fwd.  The forward of the bf16x3f mode
+ * (transformers modeling_distilbert.py:122-203 / torchvision MultiheadAttention under CVPR_code/multimodal_model.py:651-659). */
+int mmrca_mha_fwd_x3(const void* qkv_hi, const void* qkv_lo, const int32_t* key_mask, void* out_hi, void* out_lo, float* lse,
+                     int B, int H, int S, int dh, float scale, float drop_p, uint64_t drop_seed, const int32_t* cu_seqlens, void* stream);
 /* mmrca_mha_bwd followed by dqkv_colsum[3*H*dh] (fp32) += column sums of the stored dqkv = the bias gradient of the QKV
  * in-projection (one call; the reduction is a separate HBM pass -- fusing it into the MFMA kernels measured slower).
  * total_rows = number of token rows (B*S padded, cu_seqlens[B] packed). */

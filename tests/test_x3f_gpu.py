@@ -114,6 +114,52 @@ def test_attention_forward_from_planes_equals_fp32_input(B, H, S, packed):
     assert float(out["planes"][0].abs().max()) == 0.0          # the fp32 context is optional and was not asked for
 
 
+@pytest.mark.parametrize("B,H,S,packed,drop", [(3, 12, 197, False, 0.0), (5, 12, 64, True, 0.0), (2, 16, 128, False, 0.1), (4, 12, 64, False, 0.1),
+                                               (2, 12, 224, False, 0.0), (3, 12, 17, True, 0.0)])
+def test_attention_forward_x3_on_the_bf16_matrix_cores_matches_the_fp32_kernels(B, H, S, packed, drop):
+    """mmrca_mha_fwd_x3 (three-pass products over the q|k|v planes, P split in registers) against the fp32-matrix-core forward
+    on the values the planes encode -- and, for S <= 208 only (the fp32 kernel's limit), a float64 softmax(QK^T)V otherwise:
+    context within 2e-5 of the largest entry, log-sum-exp within 1e-5; masks, packed layout and dropout (same counter masks)"""
+    dh = 64
+    D = H * dh
+    g = torch.Generator(device="cuda").manual_seed(S + B)
+    if packed:
+        lens = torch.tensor([S, 9, 33, 1, 50][:B]).clamp(max=S)
+        cu = torch.cat([torch.zeros(1, dtype=torch.int64), lens.cumsum(0)]).int().cuda()
+        rows = int(lens.sum())
+        mask = torch.ones(rows, dtype=torch.int32, device="cuda")
+    else:
+        cu, rows = None, B * S
+        mask = (torch.rand(rows, device="cuda", generator=g) > 0.2).int()
+        mask.view(B, S)[:, 0] = 1
+    hi, lo = _planes(torch.randn(rows, 3 * D, device="cuda", generator=g))
+    qkv = hi.float() + lo.float()
+    pl = (torch.zeros(rows, D, dtype=torch.bfloat16, device="cuda"), torch.zeros(rows, D, dtype=torch.bfloat16, device="cuda"))
+    lse = torch.zeros(B * H * S, device="cuda")
+    L.mha_fwd_x3((hi, lo), mask, pl, lse, B, H, S, dh, dh ** -0.5, drop_p=drop, drop_seed=77, cu=cu)
+    got = pl[0].float() + pl[1].float()
+    if S <= 208:
+        o = torch.zeros(rows, D, device="cuda")
+        pr = (torch.zeros(rows, D, dtype=torch.bfloat16, device="cuda"), torch.zeros(rows, D, dtype=torch.bfloat16, device="cuda"))
+        lr = torch.zeros(B * H * S, device="cuda")
+        L.mha_fwd_planes(qkv, mask, o, pr, lr, B, H, S, dh, dh ** -0.5, drop_p=drop, drop_seed=77, cu=cu)
+        torch.cuda.synchronize()
+        ref = o
+        live = torch.isfinite(lr)
+        assert torch.equal(torch.isfinite(lse), live)
+        assert float((lse[live] - lr[live]).abs().max()) <= 1e-5 * max(1.0, float(lr[live].abs().max()))
+    else:
+        x = qkv.double().view(B, S, 3, H, dh)
+        q, k, v = (x[:, :, i].transpose(1, 2) for i in range(3))
+        sc = (q @ k.transpose(2, 3)) * dh ** -0.5
+        sc = sc.masked_fill(mask.view(B, 1, 1, S) == 0, float("-inf"))
+        ref = (torch.softmax(sc, -1) @ v).transpose(1, 2).reshape(rows, D).float()
+    torch.cuda.synchronize()
+    e = float((got - ref).abs().max()) / float(ref.abs().max())
+    print(f"bf16x3 attention forward B={B} H={H} S={S} packed={packed} drop={drop}: context error {e:.2e}")
+    assert e < 2e-5
+
+
 def _grads_vs_oracle(eng, orc, B=3, S_len=24):
     from tests.test_engine_gpu import _inputs, rel
     ids, mask, images = _inputs(B, S_len)
