@@ -3,6 +3,7 @@
 // per row, 8- or 16-byte accesses per lane, fp32 statistics, wave-shuffle reductions.
 #include "common.h"
 #include <type_traits>
+#include <stdlib.h>
 
 #define LN_MAXV 8   // row kept in registers: D <= 256 * LN_MAXV
 
@@ -346,15 +347,20 @@ ln_bwd_k(const T* __restrict__ dy, const T* __restrict__ s, const T* __restrict_
 // does not ask for are compiled out (COLS = dcol, BRANCH = dbranch / dcol_branch).
 // SF32 (mmrca_layernorm_bwd_mixed): the saved pre-normalisation sum `s` is fp32 -- the residual stream of a forward that keeps
 // it in fp32 (the bf16x3f mode) -- while every gradient stays bf16.
+// LNB_WAVES waves per block: the column sums (dgamma, dbeta, bias gradients) leave a block as one fp32 atomic per column and array --
+// 2.4 M atomics on 2,304 addresses per launch with 1,024 blocks of four waves, which a sweep of the grid size showed to cost more than
+// the rows in flight they bought (86 us at 1,024 blocks, 78 at 512, 98 at 256 where latency takes over); eight waves per block at one block per CU keep half the
+// rows in flight of the 1,024-block launch with a quarter of the atomics: 69 us (tools/rowops_bench.py, operands rotated past the MALL).
+#define LNB_WAVES 8
 template <int NV2, bool COLS, bool BRANCH, bool SF32 = false>
-__global__ void __launch_bounds__(256)
+__global__ void __launch_bounds__(64 * LNB_WAVES)
 ln_bwd_bf16_k(const bf16_t* __restrict__ dy, const void* __restrict__ s_, const bf16_t* __restrict__ gamma,
               const float* __restrict__ mean, const float* __restrict__ rstd, const bf16_t* __restrict__ dres,
               bf16_t* __restrict__ ds, float* __restrict__ dgamma, float* __restrict__ dbeta, int64_t rows, int D,
               int64_t ld_dy, int64_t ld_s, int64_t ld_ds, float dy_p, uint64_t dy_seed, float br_p, uint64_t br_seed,
               bf16_t* __restrict__ dbranch, float* __restrict__ dcol, float* __restrict__ dcol_branch) {
   const float dy_sc = dy_p > 0.f ? 1.f / (1.f - dy_p) : 1.f, br_sc = br_p > 0.f ? 1.f / (1.f - br_p) : 1.f;
-  __shared__ float red[4][512];
+  __shared__ float red[LNB_WAVES][512];
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   constexpr int NC = COLS ? NV2 : 1, NB = BRANCH ? NV2 : 1;
   float adg[NV2][8], adb[NV2][8], adc[NC][8], adcb[NB][8];
@@ -391,8 +397,8 @@ ln_bwd_bf16_k(const bf16_t* __restrict__ dy, const void* __restrict__ s_, const 
     }                                                                                            \
   }                                                                                              \
   nmu = mean[r_]; nrs = rstd[r_];
-  const int64_t stride = (int64_t)gridDim.x * 4;
-  int64_t row = (int64_t)blockIdx.x * 4 + wave;
+  const int64_t stride = (int64_t)gridDim.x * LNB_WAVES;
+  int64_t row = (int64_t)blockIdx.x * LNB_WAVES + wave;
   if (row < rows) { LNB_FETCH(row) }
   for (; row < rows; row += stride) {
     const float mu = nmu, rs = nrs;
@@ -461,9 +467,14 @@ ln_bwd_bf16_k(const bf16_t* __restrict__ dy, const void* __restrict__ s_, const 
       for (int j = 0; j < 8; ++j)
         red[wave][lane * 8 + j] = q == 0 ? adg[it][j] : q == 1 ? adb[it][j] : q == 2 ? adc[COLS ? it : 0][j] : adcb[BRANCH ? it : 0][j];
       __syncthreads();
-      for (int cc = threadIdx.x; cc < 512; cc += 256) {
+      for (int cc = threadIdx.x; cc < 512; cc += 64 * LNB_WAVES) {
         const int c = it * 512 + cc;
-        if (c < D) atomicAdd(dst + c, red[0][cc] + red[1][cc] + red[2][cc] + red[3][cc]);
+        if (c < D) {
+          float t = 0.f;
+#pragma unroll
+          for (int w = 0; w < LNB_WAVES; ++w) t += red[w][cc];
+          atomicAdd(dst + c, t);
+        }
       }
     }
   }
@@ -480,13 +491,16 @@ extern "C" int mmrca_layernorm_bwd(const void* dy, const void* s, const void* ga
   MMRCA_REQUIRE(ld_dy >= D && ld_s >= D && ld_ds >= D && ld_dy % 4 == 0 && ld_s % 4 == 0 && ld_ds % 4 == 0, "layernorm_bwd: bad leading dims");
   if (rows <= 0) return 0;
   int64_t want = (rows + 3) / 4;
+  static const int ln_bwd_grid = getenv("MMRCA_LN_BWD_GRID") ? atoi(getenv("MMRCA_LN_BWD_GRID")) : 256;       // blocks of the bf16 fast path (LNB_WAVES waves each): one per CU
   const int grid = (int)(want < 1024 ? want : 1024);
+  const int64_t want16 = (rows + LNB_WAVES - 1) / LNB_WAVES;
+  const int grid16 = (int)(want16 < ln_bwd_grid ? want16 : ln_bwd_grid);
   MMRCA_REQUIRE(!(dcol_branch && !dbranch), "layernorm_bwd: dcol_branch needs dbranch");
   if (dtype == MMRCA_BF16 && D % 8 == 0 && D <= 1024 && ld_dy % 8 == 0 && ld_s % 8 == 0 && ld_ds % 8 == 0 && dgamma && dbeta &&
       aligned16p(dy) && aligned16p(s) && aligned16p(gamma) && aligned16p(ds) && (!dres || aligned16p(dres)) &&
       (!dbranch || aligned16p(dbranch))) {
 #define LN_BWD16(NV2_, C_, B_)                                                                                              \
-    hipLaunchKernelGGL((ln_bwd_bf16_k<NV2_, C_, B_>), dim3(grid), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)dy,      \
+    hipLaunchKernelGGL((ln_bwd_bf16_k<NV2_, C_, B_>), dim3(grid16), dim3(64 * LNB_WAVES), 0, (hipStream_t)stream, (const bf16_t*)dy,      \
                        (const void*)s, (const bf16_t*)gamma, mean, rstd, (const bf16_t*)dres, (bf16_t*)ds, dgamma, dbeta,    \
                        rows, D, ld_dy, ld_s, ld_ds, dy_drop_p, dy_drop_seed, branch_drop_p, branch_drop_seed,              \
                        (bf16_t*)dbranch, dcol, dcol_branch)
@@ -528,10 +542,10 @@ extern "C" int mmrca_layernorm_bwd_mixed(const void* dy, const float* s, const v
                 "layernorm_bwd_mixed: operands must be 16-byte aligned");
   MMRCA_REQUIRE(!(dcol_branch && !dbranch), "layernorm_bwd_mixed: dcol_branch needs dbranch");
   if (rows <= 0) return 0;
-  int64_t want = (rows + 3) / 4;
-  const int grid = (int)(want < 1024 ? want : 1024);
+  int64_t want = (rows + LNB_WAVES - 1) / LNB_WAVES;
+  const int grid = (int)(want < 256 ? want : 256);
 #define LN_BWDM(NV2_, C_, B_)                                                                                               \
-  hipLaunchKernelGGL((ln_bwd_bf16_k<NV2_, C_, B_, true>), dim3(grid), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)dy,  \
+  hipLaunchKernelGGL((ln_bwd_bf16_k<NV2_, C_, B_, true>), dim3(grid), dim3(64 * LNB_WAVES), 0, (hipStream_t)stream, (const bf16_t*)dy,  \
                      (const void*)s, (const bf16_t*)gamma, mean, rstd, (const bf16_t*)dres, (bf16_t*)ds, dgamma, dbeta,      \
                      rows, D, ld_dy, ld_s, ld_ds, dy_drop_p, dy_drop_seed, branch_drop_p, branch_drop_seed,                \
                      (bf16_t*)dbranch, dcol, dcol_branch)
