@@ -516,12 +516,13 @@ def test_two_rank_data_parallel_rehearsal_keeps_replicas_identical():
     assert d["n_gpus"] == 2 and d["config"]["global_batch"] == 16 and d["scaling"] == "weak"
 
 
-@pytest.mark.parametrize("image_model", ["transformer_B16", "shuffle_net"])
-def test_end_to_end_training_driver_and_evaluator_on_a_tiny_folder(tmp_path, image_model):
+@pytest.mark.parametrize("image_model,dtype", [("transformer_B16", "bf16"), ("shuffle_net", "bf16"), ("transformer_B16", "bf16x3f"), ("eff_v2_medium", "bf16x3f")])
+def test_end_to_end_training_driver_and_evaluator_on_a_tiny_folder(tmp_path, image_model, dtype):
     """Drop-in plumbing on real files: folder dataset -> main_both.py two-phase loop (frozen epoch, fine-tune epoch, four
     accuracy passes, best-val checkpoint with the reference's file-name pattern) -> calculate_test_accuracy_both.py on that
     checkpoint.  Once with ViT-B/16 (BASELINE configs[1]'s image model) and once with BASELINE configs[0]'s actual pairing,
-    shuffle_net + distilbert at batch 4 (main_image.py:295-302 naming)."""
+    shuffle_net + distilbert at batch 4 (main_image.py:295-302 naming); and in the bf16x3f mode (the fastest one that meets the reference's
+    fp32 logits to 1e-3) with ViT-B/16 and with the reference's default image model, EfficientNetV2-M (bf16 conv kernels + bf16x3 text encoder)."""
     import glob
     import subprocess
     import sys
@@ -537,8 +538,8 @@ def test_end_to_end_training_driver_and_evaluator_on_a_tiny_folder(tmp_path, ima
                 arr[:, :, ci % 3] = 255 - 40 * ci
                 Image.fromarray(arr).save(d / f"{['chip_bag','pizza_box','banana_peel','aa_batteries'][ci]}_{k}.png")
     env = dict(os.environ, PYTHONPATH=root)
-    common = ["--late_fusion=MM_RCA", "--reverse", f"--image_model={image_model}", "--text_model=distilbert", "--image_size", "64" if image_model == "shuffle_net" else "224",
-              "--tokens_max_len", "16", "--num_workers", "0", "--dtype", "bf16"]
+    common = ["--late_fusion=MM_RCA", "--reverse", f"--image_model={image_model}", "--text_model=distilbert", "--image_size", "224" if image_model == "transformer_B16" else "64",
+              "--tokens_max_len", "16", "--num_workers", "0", "--dtype", dtype]
     r = subprocess.run([sys.executable, os.path.join(root, "main_both.py"), *common, "--dataset_folder_name=Train",
                         "--dataset_folder_name_val=Val", "--epochs", "1", "--ft_epochs", "1", "--batch_size", "4",
                         "--batch_size_FT", "4", "--acc_steps_FT", "2", "--balance_weights", "--label_smoothing", "0.1", "--seed", "1", "--prob_aug", "0.8",
