@@ -357,6 +357,9 @@ def main():
     ap.add_argument("--dtype", default="bf16", choices=("bf16", "fp32", "bf16x3", "bf16x3f"),
                     help="bf16 (the benchmarked configuration) | bf16x3: the fast <= 1e-3 mode -- fp32 storage / residual stream / LayerNorm / "
                          "attention, every nn.Linear as a three-pass split-bf16 product on the bf16 matrix cores | fp32: every GEMM on the fp32 matrix cores")
+    ap.add_argument("--graph", default="auto", choices=("auto", "on", "off"),
+                    help="replay the step's forward/backward launches from a HIP graph (training.GraphedTrainStep); auto = per-GPU batch <= 16 on one GPU "
+                         "(the launch-bound regime: configs[0])")
     ap.add_argument("--frozen", action="store_true", help="time the frozen-backbone phase instead (reported separately)")
     ap.add_argument("--text_model", default="distilbert", help="distilbert (BASELINE configs[1]) | bert | roberta")
     ap.add_argument("--image_model", default="transformer_B16", help="transformer_B16 (configs[1]) | transformer_L16 | eff_v2_medium | eff_v2_large (configs[2]) | shuffle_net")
@@ -428,8 +431,18 @@ def main():
 
     pack_in_loop = os.environ.get("MMRCA_BENCH_PACK_IN_LOOP", "1") == "1" and PACK_TEXT
 
+    use_graph = args.graph == "on" or (args.graph == "auto" and B <= 16 and world == 1 and args.dtype == "bf16")
+    graphed = None
+    if use_graph:
+        from garbage_classification_rca_amd.training import GraphedTrainStep
+        graphed = GraphedTrainStep(model, crit, opt, sync, warmup=2)
+        live = 1.0                             # the captured launches run the padded caption layout
+    graph_on = [graphed is not None]
+
     def step(i):
         j = (i % nb) * B
+        if graph_on[0]:
+            return graphed(ids[j:j + B], mask[j:j + B], images[j:j + B], labels[j:j + B])
         # the packed layout is rebuilt from the host mask INSIDE the timed step, as a DataLoader-fed loop does per batch
         # (numpy + two small pinned async copies; MMRCA_BENCH_PACK_IN_LOOP=0 reuses the ones built above)
         pack = make_text_pack(mask_host[j:j + B], dev) if pack_in_loop else packs[i % nb]
@@ -437,7 +450,7 @@ def main():
                               text_pack=pack)
 
     with contextlib.redirect_stdout(io.StringIO()):
-        for i in range(args.warmup):
+        for i in range(max(args.warmup, 4) if graphed is not None else args.warmup):    # (2 eager calls + the capture happen untimed)
             step(i)
     torch.cuda.synchronize()
     if world > 1:
@@ -467,6 +480,7 @@ def main():
     # are not separable.  The same steps are therefore replayed on ONE stream right after the timed region, with every
     # MFMA GEMM launch bracketed by HIP events on its launch stream; `achieved` = sum(2MNK) / sum(durations).
     eng = model.engine
+    graph_on[0] = False                        # the per-launch measurements below bracket eager launches with HIP events
     saved_streams = (eng._side_v, eng._side_t, eng._side, eng._text_stream)
     eng._side_v = eng._side_t = eng._side = eng._text_stream = None
     replay = max(2, min(4, args.steps))
@@ -623,9 +637,11 @@ def main():
                        + f" train step (fwd+loss+bwd+allreduce+SGD), {args.image_size}x{args.image_size} images, {S}-token captions",
                        "per_gpu_batch": B, "global_batch": B * world, "seq_len": S, "image": args.image_size, "parallelism": f"dp{world}",
                        "optimizer": "sgd lr=1e-3 wd=1e-2", "random_init": True, "caption_rows_processed": round(live, 3),
-                       "dead_row_elimination": {"class_token_tail": bool(E_CLS_TAIL), "packed_captions": bool(PACK_TEXT),
+                       "dead_row_elimination": {"class_token_tail": bool(E_CLS_TAIL), "packed_captions": bool(PACK_TEXT) and graphed is None,
                                                 "note": "identical logits and gradients; MMRCA_CLS_TAIL=0 MMRCA_PACK_TEXT=0 runs every row"}, "final_loss": round(final_loss, 4),
                        "host_enqueue_ms_per_step": round(host_enqueue / args.steps * 1e3, 2),
+                       "hip_graph": (None if graphed is None else {"replays_in_timed_region": args.steps, "graphs": len(graphed._graphs),
+                                                                   "outside_the_graph": "input copies, mask-epoch word, loss copy, SGD step, gradient memset"}),
                        **({"x3_backward_passes": {"weight_gradient": ENG.X3_WGRAD_PASSES, "input_gradient": ENG.X3_DGRAD_PASSES,
                                                   "note": "3 / 3 = every product with all three plane pairs (default: gradients 3e-5 from float64); fewer "
                                                           "= opt-in cheaper backward (MMRCA_X3_*_PASSES), forward logits unchanged, gradients at 5e-3 .. 1e-2"}}

@@ -103,6 +103,7 @@ class ConvEncoder:
         self._bufs: Dict[Tuple, torch.Tensor] = {}
         self._maps: Dict[Tuple, torch.Tensor] = {}
         self.saved = None
+        self._sd_p = None
         self.injected_keep = None             # tests: [n_sd_blocks, B] 0/1 keep masks instead of drawing them
         self.n_train_forwards = 0             # = every BatchNorm's num_batches_tracked (written out by sync_buffers())
 
@@ -493,9 +494,15 @@ class ConvEncoder:
         rowscale = None
         sd_idx = [i for i, b in enumerate(self.blocks) if b.get("res") and b.get("sd", 0.0) > 0.0]
         if train and sd_idx:
-            p = torch.tensor([self.blocks[i]["sd"] for i in sd_idx], dtype=torch.float32, device=self.o.device).view(-1, 1)
+            if self._sd_p is None:             # (a constant of the architecture; built once -- a host-to-device copy cannot be captured)
+                self._sd_p = torch.tensor([self.blocks[i]["sd"] for i in sd_idx], dtype=torch.float32, device=self.o.device).view(-1, 1)
+            p = self._sd_p
             if self.injected_keep is not None:
                 keep = self.injected_keep.to(self.o.device, torch.float32)
+            elif torch.cuda.is_current_stream_capturing():
+                # inside a HIP-graph capture (training.GraphedTrainStep): torch's default generator is graph-safe (its Philox offset
+                # advances per replay); a generator seeded here would be frozen into the graph with its one draw
+                keep = (torch.rand(len(sd_idx), B, device=self.o.device) >= p).float()
             else:
                 gen = torch.Generator(device=self.o.device).manual_seed(int(seed) & 0x7FFFFFFFFFFFFFFF)
                 keep = (torch.rand(len(sd_idx), B, device=self.o.device, generator=gen) >= p).float()

@@ -191,3 +191,5 @@ extern "C" int mmrca_mha_cls_bwd(const void* qkv, const int32_t* key_mask, const
   MMRCA_CHECK_LAUNCH("mha_cls_bwd");
   return 0;
 }
+
+MMRCA_SEED_EPOCH_EXPORT(attention_cls)   // this translation unit's copy of the mask epoch (common.h)

@@ -253,3 +253,5 @@ extern "C" int mmrca_mha_cross_fwd(const void* q, int64_t ldq, const void* k, in
   MMRCA_CHECK_LAUNCH("mha_cross_fwd(ref)");
   return 0;
 }
+
+MMRCA_SEED_EPOCH_EXPORT(attention_cross)   // this translation unit's copy of the mask epoch (common.h)

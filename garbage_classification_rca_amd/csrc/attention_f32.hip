@@ -392,3 +392,5 @@ int mmrca_mha_bwd_f32m(const void* qkv, const int32_t* key_mask, const void* out
   MMRCA_CHECK_LAUNCH("mha_bwd(f32 mfma)");
   return 0;
 }
+
+MMRCA_SEED_EPOCH_EXPORT(attention_f32)   // this translation unit's copy of the mask epoch (common.h)

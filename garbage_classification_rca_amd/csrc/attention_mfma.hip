@@ -1745,3 +1745,5 @@ int mmrca_mha_bwd_mfma(const void* qkv, const int32_t* key_mask, const void* out
   MMRCA_CHECK_LAUNCH("mha_bwd(mfma)");
   return 0;
 }
+
+MMRCA_SEED_EPOCH_EXPORT(attention_mfma)   // this translation unit's copy of the mask epoch (common.h)

@@ -402,3 +402,5 @@ int mmrca_mha_bwd_ref(const void* qkv, const int32_t* key_mask, const void* out,
   MMRCA_CHECK_LAUNCH("mha_bwd(ref)");
   return 0;
 }
+
+MMRCA_SEED_EPOCH_EXPORT(attention_ref)   // this translation unit's copy of the mask epoch (common.h)

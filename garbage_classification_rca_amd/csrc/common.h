@@ -61,9 +61,23 @@ __device__ __forceinline__ float wave_max(float x) {
   return x;
 }
 
+// Step epoch of the counter-based masks.  Every launch carries its mask seed BY VALUE, so a launch captured in a HIP graph
+// (training.GraphedTrainStep) would redraw the captured step's masks at every replay.  The hash therefore runs on
+// seed + epoch * MMRCA_SEED_EPOCH_STRIDE, where the epoch is a device-side word that one node at the head of the graph refreshes
+// from a counter in HBM (mmrca_seed_epoch_set): replay r of a step captured at step s draws exactly the masks the eager step
+// s + r draws (the engine's seeds advance by the same stride per step, engine._site_seed).  0 outside graph replays.  One copy per
+// translation unit (no relocatable device code in this build); constant address space, so kernels read it once.
+#define MMRCA_SEED_EPOCH_STRIDE 1000003ull
+__attribute__((unused)) static __constant__ unsigned long long mmrca_seed_epoch_v = 0ull;
+#define MMRCA_SEED_EPOCH_EXPORT(tag)                                                       \
+  extern "C" void* mmrca_seed_epoch_addr_##tag() {                                          \
+    void* p = nullptr;                                                                     \
+    return hipGetSymbolAddress(&p, HIP_SYMBOL(mmrca_seed_epoch_v)) == hipSuccess ? p : nullptr; \
+  }
+
 // counter-based uniform in [0,1): splitmix64 of (seed, index)
 __device__ __forceinline__ float mmrca_uniform(uint64_t seed, uint64_t idx) {
-  uint64_t z = seed + 0x9E3779B97F4A7C15ull * (idx + 1);
+  uint64_t z = seed + mmrca_seed_epoch_v * MMRCA_SEED_EPOCH_STRIDE + 0x9E3779B97F4A7C15ull * (idx + 1);
   z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
   z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
   z = z ^ (z >> 31);

@@ -1008,8 +1008,11 @@ extern "C" int mmrca_dwconv3x3_bwd_ws(const void* dy, const void* x, const void*
   }
   if (dw) {
     const int64_t npix = (int64_t)B * Ho * Wo;
-    int64_t nblk = npix / 512 > 0 ? npix / 512 : 1;
-    if (nblk > 1024) nblk = 1024;
+    // pixel ranges of the two general kernels below: ~2,048 blocks in all (a small-batch layer -- configs[0]: 4 x 28 x 28 pixels --
+    // used to get 6 ranges of 523 pixels, i.e. 131 dependent iterations per thread: 365 us for 0.8 MB), at least 32 pixels each
+    const int64_t cslices = (C + 63) / 64;
+    int64_t nblk = npix / 32 > 0 ? npix / 32 : 1;
+    if (nblk > 2048 / cslices) nblk = 2048 / cslices > 0 ? 2048 / cslices : 1;
     const int64_t per = (npix + nblk - 1) / nblk;
     if (dw_v8_ok(C, dtype, dy, x, dw) && stride == 1 && g_dw_strip && g_dw_strip2 && small32) {
       const int64_t ngrp = (int64_t)B * H * ((W + 3) / 4);
@@ -1300,6 +1303,10 @@ static void col_grid(int64_t rows, int C, dim3* grid, int64_t* per) {
   if (cap > 2048) cap = 2048;
   int64_t nblk = rows / 256 > 0 ? rows / 256 : 1;
   if (nblk > cap) nblk = cap;
+  if (nblk * slices < 512) {      // a small-batch tensor (configs[0]: 3,136 rows x 122 channels = 24 blocks of 64 dependent iterations, 18-23 us
+    nblk = rows / 32 > 0 ? rows / 32 : 1;                     // for 0.8 MB): 32-row blocks, still at most ~1,024 of them
+    if (nblk * slices > 1024) nblk = 1024 / slices > 0 ? 1024 / slices : 1;
+  }
   *per = (rows + nblk - 1) / nblk;
   // x = 64-channel slice (fastest), y = row range: the blocks resident at one time then cover WHOLE rows of a row range.  With the
   // row ranges in x, the ~2,000 resident blocks all read the same 128-byte slice of every row (stride 2C bytes) -- one DRAM burst

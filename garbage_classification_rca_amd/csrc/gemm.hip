@@ -1431,9 +1431,9 @@ static int gemm_dispatch(const void* A, const void* B, void* C, const void* bias
     const int64_t tm = (M + 127) / 128, tn = (N + 63) / 64;
     MMRCA_REQUIRE(tm * tn < (1ll << 31), "gemm(gen): too many tiles");
     int64_t splits = 1, ksplit_len = K;
-    if (out_f32_accum && tm * tn < 128 && K >= 4096) {       // fill ~512 workgroup slots, at least 1024 k per range
-      splits = (512 + tm * tn - 1) / (tm * tn);
-      if (splits > K / 1024) splits = K / 1024;
+    if (out_f32_accum && tm * tn < 128 && K >= 512) {        // fill ~512 workgroup slots, at least 128 k per range (a small-batch weight
+      splits = (512 + tm * tn - 1) / (tm * tn);               // gradient -- configs[0]: 122 x 122 over K = 3,136 -- ran on TWO workgroups)
+      if (splits > K / 128) splits = K / 128;
       ksplit_len = ((K + splits - 1) / splits + 15) / 16 * 16;
       splits = (K + ksplit_len - 1) / ksplit_len;
     }

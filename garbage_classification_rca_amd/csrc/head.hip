@@ -820,3 +820,5 @@ extern "C" int mmrca_head_bwd(const float* dlogits, const void* img, const void*
   MMRCA_CHECK_LAUNCH("head_wgrad");
   return 0;
 }
+
+MMRCA_SEED_EPOCH_EXPORT(head)   // this translation unit's copy of the mask epoch (common.h)

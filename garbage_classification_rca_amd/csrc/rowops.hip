@@ -1134,3 +1134,5 @@ extern "C" int mmrca_split_f32(const float* src, void* hi, void* lo, int64_t n, 
   MMRCA_CHECK_LAUNCH("split_f32");
   return 0;
 }
+
+MMRCA_SEED_EPOCH_EXPORT(rowops)   // this translation unit's copy of the mask epoch (common.h)

@@ -1018,9 +1018,12 @@ class MMRCAEngine:
             cls, tsv = self._text_forward(ids, mask, save, enc_drop_p, int(seed), text_pack)
             feat, vsv = self._image_forward(images, save, bn_train, int(seed))
         logits = torch.empty(B, self.n_classes, dtype=torch.float32, device=self.device)
+        # the head's mask seed advances by the same stride per step as the encoders' site seeds: a HIP-graph replay r of this step then
+        # draws the masks of step seed + r everywhere (lib.seed_epoch_set)
+        head_seed = self._site_seed(int(seed), 255, 0)
         L.head_fwd(feat, cls, self._head_w, logits, B, self.d_img, self.d_txt, self.n_classes, self.reverse, self.mode,
-                   float(drop_p), int(seed), self.dt)
-        self._saved = dict(B=B, cls=cls, feat=feat, text=tsv, vision=vsv, drop_p=float(drop_p), seed=int(seed), full=save)
+                   float(drop_p), head_seed, self.dt)
+        self._saved = dict(B=B, cls=cls, feat=feat, text=tsv, vision=vsv, drop_p=float(drop_p), seed=head_seed, full=save)
         return logits
 
     def _image_backward(self, dimg, vsv):

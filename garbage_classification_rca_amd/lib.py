@@ -117,6 +117,7 @@ _SIGS = {
     "mmrca_sgd_step": [_vp, _vp, _vp, _i64, _f32, _f32, _f32, _vp],
     "mmrca_adamw_step": [_vp] * 5 + [_i64] + [_f32] * 5 + [_i32, _f32, _vp],
     "mmrca_cast_f32_to_bf16": [_vp, _vp, _i64, _vp],
+    "mmrca_seed_epoch_set": [_vp, _u64, _vp],
 }
 EXPORTS = sorted(list(_SIGS) + ["mmrca_last_error", "mmrca_version", "mmrca_debug_set", "mmrca_debug_attn_stamps", "mmrca_gemm_splitk_workspace_bytes",
                                   "mmrca_head_bwd_workspace_bytes", "mmrca_conv3x3_stat_slots", "mmrca_gemm_bnstats_slots"])
@@ -499,6 +500,32 @@ def adamw_step(p, g, m, v, lp, n, lr, b1, b2, eps, wd, step, grad_scale=1.0, lp_
                                           stream_ptr()), "mmrca_adamw_step_x3")
         return
     _check(load().mmrca_adamw_step(ptr(p), ptr(g), ptr(m), ptr(v), ptr(lp), n, lr, b1, b2, eps, wd, step, grad_scale, stream_ptr()), "mmrca_adamw_step")
+
+
+SEED_EPOCH_STRIDE = 1000003      # = MMRCA_SEED_EPOCH_STRIDE (csrc/common.h) = the per-step stride of engine._site_seed
+_seed_epoch = 0                  # host view of the device-side mask epoch (0 = eager launches draw the seeds they are given)
+
+
+def seed_epoch_set(value: int = 0, device_value: Optional[torch.Tensor] = None):
+    """Mask epoch of every dropout kernel (include/mmrca.h).  device_value: int64 [1] tensor in HBM, read when the launch executes
+    (captured in a HIP graph it follows the tensor from replay to replay); else the immediate `value`."""
+    global _seed_epoch
+    if device_value is not None:
+        _dev(device_value, "seed_epoch_set")
+        if device_value.dtype != torch.int64 or device_value.numel() < 1:
+            raise MmrcaError("seed_epoch_set: device_value must be an int64 tensor")
+    _check(load().mmrca_seed_epoch_set(ptr(device_value), int(value) & 0xFFFFFFFFFFFFFFFF, stream_ptr()), "mmrca_seed_epoch_set")
+    _seed_epoch = None if device_value is not None else int(value)
+
+
+def seed_epoch_host():
+    """the epoch the device holds as far as the host knows (None: it follows a device counter -- GraphedTrainStep keeps track)"""
+    return _seed_epoch
+
+
+def seed_epoch_note(value):
+    global _seed_epoch
+    _seed_epoch = value
 
 
 def cast_f32_to_bf16(src, dst, n):

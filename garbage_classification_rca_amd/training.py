@@ -50,20 +50,11 @@ class FusedCrossEntropy:
         return loss, dlogits
 
 
-def hip_train_step(model, ids, mask, images, labels, criterion: FusedCrossEntropy, optimizer=None, grad_sync=None,
-                   do_step: bool = True, text_pack=None):
-    """forward -> loss -> backward (-> gradient all-reduce) -> optimizer step -> zero grads, all on the current
-    stream without a host sync.  Returns the device loss tensor.
-    text_pack: ``engine.make_text_pack(host_mask, device)`` of this batch -- the text encoder then skips the padding rows."""
+def _enqueue_step(model, ids, mask, images, labels, criterion, grad_sync, do_step, text_pack, seed, tt, ti):
+    """forward -> loss -> backward (the gradient exchange rides on the backward) of one prepared batch on the current stream; no host
+    sync, no host-side randomness -- which is what makes the sequence capturable (GraphedTrainStep).  Returns the device loss."""
     eng = model.engine
-    model._images, model._input_ids, model._attention_mask = images, ids, mask
-    model.drop_modalities(False, False, False)
-    if model._input_ids is not ids:
-        text_pack = None                       # modality dropout zeroed the captions: the pack no longer describes them
-    tt, ti = model._train_flags()
-    model._fwd_count += 1
-    logits = eng.forward(model._input_ids, model._attention_mask, model._images,
-                         model.drop_ratio if model.training else 0.0, model._drop_seed + model._fwd_count, save=(tt or ti),
+    logits = eng.forward(ids, mask, images, model.drop_ratio if model.training else 0.0, seed, save=(tt or ti),
                          enc_drop_p=(model.enc_dropout if model.training else 0.0), text_pack=text_pack, bn_train=model.training)
     loss, dlogits = criterion(logits, labels)
     if grad_sync is not None and grad_sync.world > 1 and criterion.weight is not None:
@@ -79,12 +70,106 @@ def hip_train_step(model, ids, mask, images, labels, criterion: FusedCrossEntrop
         grad_sync.enabled = bool(do_step)
     eng.grad_sync = grad_sync
     eng.backward(dlogits, train_text=tt, train_image=ti)
+    return loss
+
+
+def _prepare_step(model, ids, mask, images, text_pack):
+    """the host-side part of a step: modality dropout (the reference's numpy draws, multimodal_model.py:420-455), the trainable
+    flags and the step's mask seed"""
+    model._images, model._input_ids, model._attention_mask = images, ids, mask
+    model.drop_modalities(False, False, False)
+    if model._input_ids is not ids:
+        text_pack = None                       # modality dropout zeroed the captions: the pack no longer describes them
+    tt, ti = model._train_flags()
+    model._fwd_count += 1
+    return model._input_ids, model._attention_mask, model._images, text_pack, model._drop_seed + model._fwd_count, tt, ti
+
+
+def hip_train_step(model, ids, mask, images, labels, criterion: FusedCrossEntropy, optimizer=None, grad_sync=None,
+                   do_step: bool = True, text_pack=None):
+    """forward -> loss -> backward (-> gradient all-reduce) -> optimizer step -> zero grads, all on the current
+    stream without a host sync.  Returns the device loss tensor.
+    text_pack: ``engine.make_text_pack(host_mask, device)`` of this batch -- the text encoder then skips the padding rows."""
+    ids, mask, images, text_pack, seed, tt, ti = _prepare_step(model, ids, mask, images, text_pack)
+    loss = _enqueue_step(model, ids, mask, images, labels, criterion, grad_sync, do_step, text_pack, seed, tt, ti)
     if do_step and optimizer is not None:
         if grad_sync is not None:
             grad_sync.finish()
         optimizer.step()
         optimizer.zero_grad()
     return loss
+
+
+class GraphedTrainStep:
+    """``hip_train_step`` with the forward -> loss -> backward launches of a batch shape captured ONCE in a HIP graph and replayed
+    (the launch-bound regime).  A small-batch step is ~1,000 launches of a few microseconds each -- configs[0]
+    (ShuffleNetV2 + DistilBERT, B = 4): 14 ms of Python + ctypes + hipLaunchKernel per step against 11 ms of kernels -- and the
+    reference pays the same from its own Python loop (main_both.py:81-134); one hipGraphLaunch replaces them.
+
+    What a replay must not freeze, and how it does not:
+      * dropout masks -- seeds are launch arguments; the graph's first node loads the replay's distance to the captured step into
+        the kernels' mask epoch (lib.seed_epoch_set), its last node resets it: replay r draws the masks of eager step s + r;
+      * inputs -- copied into the static buffers the captured launches read;
+      * modality dropout and the trainable flags -- decided on the host BEFORE the graph (a different flag set is a different graph);
+      * the optimizer -- stays outside (2-4 launches): learning-rate schedules and AdamW's step count are host values;
+      * stochastic depth (EfficientNetV2) -- drawn from torch's graph-safe default generator while capturing (conv_engine.forward).
+    Captions run in the padded layout (a packed layout changes launch shapes per batch).  The first `warmup` calls of a shape run
+    eagerly (they allocate the engine's buffers), the next one captures.  With a multi-rank GradSync the step stays eager: the
+    exchange is launched span by span from Python while the backward runs."""
+
+    def __init__(self, model, criterion: FusedCrossEntropy, optimizer=None, grad_sync=None, warmup: int = 2):
+        self.model, self.criterion, self.optimizer, self.grad_sync, self.warmup = model, criterion, optimizer, grad_sync, int(warmup)
+        self._graphs, self._eager_left = {}, {}
+        self._epoch = torch.zeros(1, dtype=torch.int64, device=model.engine.device)
+        self.replays = 0
+        L.seed_epoch_set(0)                    # resolves the epoch words' addresses outside any capture
+
+    def _eager(self):
+        return self.grad_sync is not None and self.grad_sync.world > 1
+
+    def __call__(self, ids, mask, images, labels, do_step: bool = True):
+        model, eng = self.model, self.model.engine
+        ids, mask, images, _, seed, tt, ti = _prepare_step(model, ids, mask, images, None)
+        key = (tuple(ids.shape), tuple(images.shape), images.dtype, labels.dtype, tt, ti, bool(model.training),
+               float(model.drop_ratio), float(model.enc_dropout))
+        ent = self._graphs.get(key)
+        if ent is None and (self._eager() or self._eager_left.setdefault(key, self.warmup) > 0):
+            self._eager_left[key] = self._eager_left.get(key, self.warmup) - 1
+            loss = _enqueue_step(model, ids, mask, images, labels, self.criterion, self.grad_sync, do_step, None, seed, tt, ti)
+        else:
+            if ent is None:
+                ent = self._capture(key, ids, mask, images, labels, seed, tt, ti)
+            else:
+                eng.refresh_working_copy()     # (a no-op unless parameters were loaded since the last step)
+                for dst, src in zip(ent["inputs"], (ids, mask, images, labels)):
+                    dst.copy_(src, non_blocking=True)
+            self._epoch.fill_(seed - ent["seed"])
+            ent["graph"].replay()
+            self.replays += 1
+            if eng.conv is not None and model.training and ent["replayed"]:
+                eng.conv.n_train_forwards += 1          # (the capturing call ran conv.forward's host side once already)
+            ent["replayed"] = True
+            loss = ent["loss"].clone()         # the graph's loss word is rewritten by the next replay
+        if do_step and self.optimizer is not None:
+            if self.grad_sync is not None:
+                self.grad_sync.finish()
+            self.optimizer.step()
+            self.optimizer.zero_grad()
+        return loss
+
+    def _capture(self, key, ids, mask, images, labels, seed, tt, ti):
+        model, eng = self.model, self.model.engine
+        eng.refresh_working_copy()
+        inputs = [t.clone() for t in (ids, mask, images, labels)]
+        torch.cuda.synchronize()
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g):
+            L.seed_epoch_set(device_value=self._epoch)
+            loss = _enqueue_step(model, inputs[0], inputs[1], inputs[2], inputs[3], self.criterion, None, True, None, seed, tt, ti)
+            L.seed_epoch_set(0)
+        ent = dict(graph=g, inputs=inputs, loss=loss, seed=seed, replayed=False)
+        self._graphs[key] = ent
+        return ent
 
 
 def stage_images(raw, hw_device, image_pipeline=None, aug_params=None):

@@ -54,6 +54,13 @@ enum { MMRCA_GEMM_AUTO = 0, MMRCA_GEMM_REF = 1, MMRCA_GEMM_MFMA = 2 /* 128x128 t
 
 const char* mmrca_last_error(void);
 int mmrca_version(void);
+
+/* Step epoch of the counter-based dropout masks.  Mask seeds are launch arguments, so the launches of a step captured in a HIP graph
+ * (the small-batch path of training.GraphedTrainStep; the reference has no counterpart -- main_both.py:81-134 launches every op from
+ * Python each step) would redraw the captured step's masks at every replay.  Every mask hash runs on seed + epoch * 1000003; this
+ * call sets the epoch of all kernels from *device_value (read when the launch EXECUTES: captured once, it follows a counter in HBM
+ * from replay to replay) or, with device_value == NULL, from `value`.  0 (the initial state) outside graph replays. */
+int mmrca_seed_epoch_set(const uint64_t* device_value, uint64_t value, void* stream);
 /* timing-only ablation switches for kernel development (0 = normal operation; results are WRONG otherwise) */
 int mmrca_debug_set(int flags);
 /* diagnostic: a device buffer of B*H*4 uint64 that the fused ViT attention backward fills with s_memtime stamps of its phases
