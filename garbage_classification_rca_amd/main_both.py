@@ -235,15 +235,17 @@ def main(argv=None):
     sync = D.GradSync(global_model.engine.arena.g, world) if world > 1 else None
     scheduler = torch.optim.lr_scheduler.ReduceLROnPlateau(optimizer, 'max', factor=0.4)
     state = dict(max_val=0.0, max_img=0.0, max_txt=0.0, best_epoch=0)
+    graphs = {}                                # --hip_graph: the captured train steps, one per batch shape, kept across epochs
 
     def one_phase(n_epochs, dl_tr, sampler, dl_v, bs, acc_steps, fine_tuning):
         for epoch in range(n_epochs):
             sampler.set_epoch(epoch + (1000 if fine_tuning else 0))
             global_model.train()
             st = time.time()
+            use_graph = args.hip_graph == "on" or (args.hip_graph == "auto" and bs <= 16 and world == 1)
             _, losses = run_one_epoch(epoch, global_model, dl_tr, len(sampler), device, bs, optimizer, class_weights,
                                       args.balance_weights, acc_steps, args.label_smoothing, grad_sync=sync, verbose=is_main,
-                                      image_pipeline=image_pipeline, aug_params=aug_params)
+                                      image_pipeline=image_pipeline, aug_params=aug_params, hip_graph=(graphs if use_graph else None))
             elapsed = time.time() - st
             train_loss_avg = float(np.average([float(l) for l in losses])) if losses else float("nan")
             global_model.eval()

@@ -167,6 +167,7 @@ class GraphedTrainStep:
             L.seed_epoch_set(device_value=self._epoch)
             loss = _enqueue_step(model, inputs[0], inputs[1], inputs[2], inputs[3], self.criterion, None, True, None, seed, tt, ti)
             L.seed_epoch_set(0)
+        print(f"HIP graph captured for the train step of batch shape {key[0]} x {key[1]} (trainable text / image encoder: {tt} / {ti})")
         ent = dict(graph=g, inputs=inputs, loss=loss, seed=seed, replayed=False)
         self._graphs[key] = ent
         return ent
@@ -185,9 +186,12 @@ def stage_images(raw, hw_device, image_pipeline=None, aug_params=None):
 
 
 def run_one_epoch(epoch_num, model, data_loader, len_train_data, hw_device, batch_size, train_optimizer, weights,
-                  use_class_weights, acc_steps, smoothing, grad_sync=None, verbose=True, image_pipeline=None, aug_params=None):
+                  use_class_weights, acc_steps, smoothing, grad_sync=None, verbose=True, image_pipeline=None, aug_params=None,
+                  hip_graph=None):
     """main_both.py:81-134 (same argument order).  Works with any model exposing the MM_RCA forward; with the HIP
-    module the criterion is the fused kernel and the backward is the engine's."""
+    module the criterion is the fused kernel and the backward is the engine's.
+    hip_graph: a dict the caller keeps across epochs (--hip_graph): the steps then replay HIP graphs (GraphedTrainStep), one per batch
+    shape; the dict owns them together with the criterion (its class-weight tensor is read by the captured launches)."""
     batch_loss = []
     n_batches = math.ceil(len_train_data / batch_size)
     fused = hasattr(model, "engine")
@@ -199,12 +203,18 @@ def run_one_epoch(epoch_num, model, data_loader, len_train_data, hw_device, batc
         criterion = FusedCrossEntropy(opt_weights, smoothing)
     else:
         criterion = torch.nn.CrossEntropyLoss(weight=opt_weights, label_smoothing=smoothing).to(hw_device)
+    graphed = None
+    if fused and hip_graph is not None:
+        gkey = (tuple(float(w) for w in weights) if use_class_weights else None, float(smoothing), id(train_optimizer), id(grad_sync))
+        graphed = hip_graph.get(gkey)
+        if graphed is None:
+            graphed = hip_graph[gkey] = GraphedTrainStep(model, criterion, train_optimizer, grad_sync)
     n_loader = len(data_loader)
     for batch_idx, (data, labels) in enumerate(data_loader):
         images = stage_images(data['image']['raw_image'], hw_device, image_pipeline, aug_params)
         texts = data['text']
         # the mask is still on the host here: build the packed token layout without a device sync
-        pack = make_text_pack(texts['attention_mask'], hw_device) if (fused and PACK_TEXT and not texts['attention_mask'].is_cuda) else None
+        pack = make_text_pack(texts['attention_mask'], hw_device) if (fused and graphed is None and PACK_TEXT and not texts['attention_mask'].is_cuda) else None
         ids = texts['tokens'].to(hw_device, non_blocking=True)
         mask = texts['attention_mask'].to(hw_device, non_blocking=True)
         labels = labels.to(hw_device, non_blocking=True)
@@ -212,7 +222,9 @@ def run_one_epoch(epoch_num, model, data_loader, len_train_data, hw_device, batc
             do_step = ((batch_idx + 1) % acc_steps == 0) or (batch_idx + 1 == n_loader)
         else:
             do_step = True
-        if fused:
+        if graphed is not None:
+            loss = graphed(ids, mask, images, labels, do_step)[0]
+        elif fused:
             loss = hip_train_step(model, ids, mask, images, labels, criterion, train_optimizer, grad_sync, do_step, text_pack=pack)[0]
         else:
             out = model(_input_ids=ids, _attention_mask=mask, _images=images)

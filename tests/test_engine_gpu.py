@@ -541,12 +541,14 @@ def test_end_to_end_training_driver_and_evaluator_on_a_tiny_folder(tmp_path, ima
     common = ["--late_fusion=MM_RCA", "--reverse", f"--image_model={image_model}", "--text_model=distilbert", "--image_size", "224" if image_model == "transformer_B16" else "64",
               "--tokens_max_len", "16", "--num_workers", "0", "--dtype", dtype]
     r = subprocess.run([sys.executable, os.path.join(root, "main_both.py"), *common, "--dataset_folder_name=Train",
-                        "--dataset_folder_name_val=Val", "--epochs", "1", "--ft_epochs", "1", "--batch_size", "4",
+                        "--dataset_folder_name_val=Val", "--epochs", "2" if image_model == "shuffle_net" else "1", "--ft_epochs", "1", "--batch_size", "4",
                         "--batch_size_FT", "4", "--acc_steps_FT", "2", "--balance_weights", "--label_smoothing", "0.1", "--seed", "1", "--prob_aug", "0.8",
                         "--balanced_sampler"],
                        cwd=tmp_path, env=env, capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stdout[-1500:] + r.stderr[-3000:]
     assert "Starting Fine tuning!!" in r.stdout and "Optimizer step on batch idx" in r.stdout
+    if image_model == "shuffle_net":           # batch 4 on one GPU: --hip_graph auto replays the frozen-phase step from its second epoch on
+        assert "HIP graph captured" in r.stdout, r.stdout[-2000:]
     assert "Using balanced sampler for training and validation sets" in r.stdout
     assert "CPU image transforms" not in r.stdout          # default: decoded uint8 images -> GpuImagePipeline (all augmentations)
     ckpts = glob.glob(str(tmp_path / "model_weights" / f"distilbert_{image_model}" / "BEST_model_*_MM_RCA_*.pth"))
