@@ -233,6 +233,10 @@ class ConvEncoder:
             self._bufs[key] = t
         return t
 
+    def _bn_ws(self):
+        """16 MiB of fp32 words for the flat BatchNorm reductions (one 64-byte record per streaming thread, csrc/conv.hip)"""
+        return self.buf("tmp.bnws", 4096, 1024, torch.float32) if self.cdtype == torch.bfloat16 else None
+
     def release(self):
         self._bufs.clear()
         self.saved = None
@@ -346,7 +350,7 @@ class ConvEncoder:
         elif sums is not None:
             L.bn_finish_sums(sums[0], sums[1], rm, sums[2], rows, mean, rstd, rm, rv, u.cout, u.eps, 0.1)
         else:
-            L.bn_stats(z, mean, rstd, rm, rv, rows, u.cout, u.cout, u.eps, 0.1 if train else 0.0, train, dt)
+            L.bn_stats(z, mean, rstd, rm, rv, rows, u.cout, u.cout, u.eps, 0.1 if train else 0.0, train, dt, ws=self._bn_ws())
         fused_res = res is not None and FUSE_RES and self.cdtype == torch.bfloat16 and u.cout % 8 == 0
         if fused_res:
             y = out
@@ -367,7 +371,7 @@ class ConvEncoder:
         scratch = self.buf("g.bnscratch", 1, 2 * u.cout, torch.float32)
         L.bn_act_bwd(dy, sv["z"], sv["mean"], sv["rstd"], self.W(u.bn_key + ".weight"), self.W(u.bn_key + ".bias"), dz,
                      self.G(u.bn_key + ".weight"), self.G(u.bn_key + ".bias"), scratch, rows, u.cout, u.act, sv["train"], dt,
-                     sums_ready=sums_ready)
+                     sums_ready=sums_ready, ws=self._bn_ws())
         w, gw = self.W(u.conv_key + ".weight"), self.G(u.conv_key + ".weight")
         rows_in = B * H * Wd
         dx = self.buf(f"{tag}.dx.{u.cin}.{rows_in}", rows_in, u.cin) if need_dx else None

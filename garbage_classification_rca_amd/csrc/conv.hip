@@ -1227,6 +1227,152 @@ col_moment2_v8_k(const bf16_t* __restrict__ x, float* __restrict__ s1, float* __
   float* const outs[2] = {s1, s2};
   col_reduce8<2>(acc, red, outs, blockIdx.x, C);
 }
+// ---- FLAT column reductions (round 4).  The kernels above give a workgroup a 64-channel slice (128 bytes) of many rows; measured
+// on the MBConv tensors (tools/bn_bench.sh) they stream at 3.1-3.7 TB/s while the element-wise BatchNorm passes next to them, whose
+// waves read 1 KiB of consecutive addresses per instruction, reach 5.8-6.6.  Same access pattern here: the tensor is a flat array of
+// 16-byte chunks (8 channels), thread t takes chunks t, t + T, t + 2T, ... with T a multiple of C/8 -- so its channel group never
+// changes and its partial sums stay in registers for the whole pass -- eight chunks in flight.  Every thread writes its sums as one
+// 64-byte record to a caller workspace ([T][16] floats); bn_flat_reduce_k adds the records of a channel group up (64 groups x 4
+// lane subsets per block, one atomic per channel and block).  No atomics in the streaming pass, no shared memory.
+__global__ void __launch_bounds__(256)
+col_moment2_flat_k(const bf16_t* __restrict__ x, float* __restrict__ ws, int64_t rows, int C8, int64_t T) {
+  const int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (t >= T) return;
+  const int c0 = (int)(t % C8) * 8;
+  const int64_t ld = (int64_t)C8 * 8;
+  float m[8], mlo[8], mhi[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) { m[j] = 0.f; mlo[j] = INFINITY; mhi[j] = -INFINITY; }
+  for (int k = 0; k < BN_SHIFT_ROWS; ++k) {            // the shift: same rows, same operations, same order as col_moment2_v8_k / bn_finish_shifted_k
+    const cm_b8 sv = *reinterpret_cast<const cm_b8*>(x + bn_shift_row(k, rows) * ld + c0);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) { const float v = (float)sv[j]; m[j] += v; mlo[j] = fminf(mlo[j], v); mhi[j] = fmaxf(mhi[j], v); }
+  }
+#pragma unroll
+  for (int j = 0; j < 8; ++j) m[j] = bn_trimmed(m[j], mlo[j], mhi[j]);
+  float a0[8], a1[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) { a0[j] = 0.f; a1[j] = 0.f; }
+  const int64_t nchunk = rows * C8;
+  int64_t q = t;
+  for (; q + 7 * T < nchunk; q += 8 * T) {
+    cm_b8 v[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) v[u] = *reinterpret_cast<const cm_b8*>(x + (q + u * T) * 8);
+#pragma unroll
+    for (int u = 0; u < 8; ++u)
+#pragma unroll
+      for (int j = 0; j < 8; ++j) { const float d = (float)v[u][j] - m[j]; a0[j] += d; a1[j] = fmaf(d, d, a1[j]); }
+  }
+  for (; q < nchunk; q += T) {
+    const cm_b8 v = *reinterpret_cast<const cm_b8*>(x + q * 8);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) { const float d = (float)v[j] - m[j]; a0[j] += d; a1[j] = fmaf(d, d, a1[j]); }
+  }
+  float4* o = reinterpret_cast<float4*>(ws + t * 16);
+  o[0] = make_float4(a0[0], a0[1], a0[2], a0[3]); o[1] = make_float4(a0[4], a0[5], a0[6], a0[7]);
+  o[2] = make_float4(a1[0], a1[1], a1[2], a1[3]); o[3] = make_float4(a1[4], a1[5], a1[6], a1[7]);
+}
+__global__ void __launch_bounds__(256)
+bn_act_bwd_reduce_flat_k(const bf16_t* __restrict__ dy, const bf16_t* __restrict__ x, const float* __restrict__ mean,
+                         const float* __restrict__ rstd, const bf16_t* __restrict__ gamma, const bf16_t* __restrict__ beta,
+                         float* __restrict__ ws, int64_t rows, int C8, int act, int64_t T) {
+  const int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (t >= T) return;
+  const int c0 = (int)(t % C8) * 8;
+  float m[8], rs[8], g[8], b[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) { m[j] = mean[c0 + j]; rs[j] = rstd[c0 + j]; g[j] = (float)gamma[c0 + j]; b[j] = (float)beta[c0 + j]; }
+  float a0[8], a1[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) { a0[j] = 0.f; a1[j] = 0.f; }
+  const int64_t nchunk = rows * C8;
+  int64_t q = t;
+  for (; q + 7 * T < nchunk; q += 8 * T) {
+    cm_b8 xv[8], dv[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      xv[u] = *reinterpret_cast<const cm_b8*>(x + (q + u * T) * 8);
+      dv[u] = *reinterpret_cast<const cm_b8*>(dy + (q + u * T) * 8);
+    }
+#pragma unroll
+    for (int u = 0; u < 8; ++u)
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const float xh = ((float)xv[u][j] - m[j]) * rs[j];
+        const float du = (float)dv[u][j] * act_grad_f(xh * g[j] + b[j], act);
+        a0[j] += du; a1[j] = fmaf(du, xh, a1[j]);
+      }
+  }
+  for (; q < nchunk; q += T) {
+    const cm_b8 xv = *reinterpret_cast<const cm_b8*>(x + q * 8), dv = *reinterpret_cast<const cm_b8*>(dy + q * 8);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const float xh = ((float)xv[j] - m[j]) * rs[j];
+      const float du = (float)dv[j] * act_grad_f(xh * g[j] + b[j], act);
+      a0[j] += du; a1[j] = fmaf(du, xh, a1[j]);
+    }
+  }
+  float4* o = reinterpret_cast<float4*>(ws + t * 16);
+  o[0] = make_float4(a0[0], a0[1], a0[2], a0[3]); o[1] = make_float4(a0[4], a0[5], a0[6], a0[7]);
+  o[2] = make_float4(a1[0], a1[1], a1[2], a1[3]); o[3] = make_float4(a1[4], a1[5], a1[6], a1[7]);
+}
+// out0[c] += sum over lanes of record[lane * C8 + c / 8][c % 8], out1 likewise from the record's second half.  grid = (C8 / 64, lane ranges)
+__global__ void __launch_bounds__(256)
+bn_flat_reduce_k(const float* __restrict__ ws, int lanes, int C8, float* __restrict__ out0, float* __restrict__ out1, int lanes_per_block) {
+  __shared__ float red[4][64][17];
+  const int cl = threadIdx.x & 63, sub = threadIdx.x >> 6;
+  const int c8 = blockIdx.x * 64 + cl;
+  const int l0 = blockIdx.y * lanes_per_block, l1 = l0 + lanes_per_block < lanes ? l0 + lanes_per_block : lanes;
+  float acc[16];
+#pragma unroll
+  for (int j = 0; j < 16; ++j) acc[j] = 0.f;
+  if (c8 < C8)
+    for (int l = l0 + sub; l < l1; l += 4) {
+      const float4* p = reinterpret_cast<const float4*>(ws + ((int64_t)l * C8 + c8) * 16);
+      const float4 v0 = p[0], v1 = p[1], v2 = p[2], v3 = p[3];
+      acc[0] += v0.x; acc[1] += v0.y; acc[2] += v0.z; acc[3] += v0.w; acc[4] += v1.x; acc[5] += v1.y; acc[6] += v1.z; acc[7] += v1.w;
+      acc[8] += v2.x; acc[9] += v2.y; acc[10] += v2.z; acc[11] += v2.w; acc[12] += v3.x; acc[13] += v3.y; acc[14] += v3.z; acc[15] += v3.w;
+    }
+#pragma unroll
+  for (int j = 0; j < 16; ++j) red[sub][cl][j] = acc[j];
+  __syncthreads();
+  for (int e = threadIdx.x; e < 64 * 16; e += 256) {
+    const int g = e >> 4, j = e & 15, cc = blockIdx.x * 64 + g;
+    if (cc < C8) {
+      const float v = (red[0][g][j] + red[1][g][j]) + (red[2][g][j] + red[3][g][j]);
+      atomicAdd((j < 8 ? out0 : out1) + cc * 8 + (j & 7), v);
+    }
+  }
+}
+// Measured (tools/bn_bench.sh, 354 MB tensor): backward reduce 207 -> 178 + 9 us (3.4 -> 4.0 TB/s), moments 100 -> 94 + 9 us.  Neither gets
+// near the 5.8-6.6 TB/s of the element-wise passes, and that is not the access pattern: those passes WRITE a third to a half of their
+// bytes.  Every read-only pass here tops out at 3.7-4.3 TB/s, and the reads of the read+write passes run at 3.0-4.2 TB/s too -- the
+// read path of this part saturates near 4.2 TB/s, the quoted ~6.3 TB/s "achievable" is a read + write mix.  BatchNorm on batch
+// statistics reads 6 tensors and writes 2 per layer: its floor is the 6 reads at ~4.2 TB/s, and the four passes are within ~17 % of it.
+// plan of a flat pass: T threads (a multiple of C/8), or 0 when the tensor is too small / not eligible / the workspace is missing
+// In situ (configs[2], B = 128) the flat backward reduce measured 607 samples/s against 612 without it: its dy operand was written by the
+// launch before and the slice form finds more of it in the caches, and the second launch costs what the faster stream gains on the many
+// mid-sized layers.  OFF by default (MMRCA_BN_FLAT=1 turns it on; read per call: the tests switch it).
+static bool bn_flat_on() { const char* e = getenv("MMRCA_BN_FLAT"); return e && atoi(e) == 1; }
+static const int64_t g_bn_flat_threads = getenv("MMRCA_BN_FLAT_THREADS") ? atoll(getenv("MMRCA_BN_FLAT_THREADS")) : 262144;
+static int64_t bn_flat_threads(int64_t rows, int C, int64_t ld, int dtype, const void* a, const void* b, const void* ws, int64_t ws_bytes) {
+  if (!bn_flat_on() || !ws || dtype != MMRCA_BF16 || C % 8 || ld != C || ((((uintptr_t)a) | ((uintptr_t)b) | ((uintptr_t)ws)) & 15)) return 0;
+  const int64_t C8 = C / 8, nchunk = rows * C8;
+  int64_t T = g_bn_flat_threads;
+  if (T > nchunk / 16) T = nchunk / 16;                 // at least 16 chunks per thread
+  if (T * 64 > ws_bytes) T = ws_bytes / 64;
+  T = T / C8 * C8;
+  return T >= 4096 && T / C8 >= 4 ? T : 0;
+}
+static void bn_flat_reduce(const float* ws, int64_t T, int C8, float* out0, float* out1, hipStream_t st) {
+  const int lanes = (int)(T / C8);
+  int per = (lanes + 31) / 32;                          // <= 32 lane ranges
+  if (per < 16) per = 16;
+  hipLaunchKernelGGL(bn_flat_reduce_k, dim3((unsigned)((C8 + 63) / 64), (unsigned)((lanes + per - 1) / per)), dim3(256), 0, st, ws, lanes, C8,
+                     out0, out1, per);
+}
+
 // (sum d, sum d^2) -> mean, rstd (in place), running stats
 __global__ void bn_finish_shifted_k(const bf16_t* __restrict__ x, float* __restrict__ mean, float* __restrict__ rstd,
                                     float* __restrict__ running_mean, float* __restrict__ running_var, int C, float n, float eps,
@@ -1317,8 +1463,8 @@ static void col_grid(int64_t rows, int C, dim3* grid, int64_t* per) {
 static const bool g_bn_one_pass = !(getenv("MMRCA_BN_ONE_PASS") && atoi(getenv("MMRCA_BN_ONE_PASS")) == 0);
 /* mean[C], rstd[C] (fp32) of x[rows, C] (two passes: mean, then centred second moment; the bf16 fast path: one pass of shifted sums); momentum > 0 also updates the running
  * statistics (torch semantics).  train == 0: mean / rstd are derived from the running statistics instead. */
-extern "C" int mmrca_bn_stats(const void* x, float* mean, float* rstd, float* running_mean, float* running_var, int64_t rows, int C,
-                              int64_t ld, float eps, float momentum, int train, int dtype, void* stream) {
+static int bn_stats_impl(const void* x, float* mean, float* rstd, float* running_mean, float* running_var, int64_t rows, int C,
+                         int64_t ld, float eps, float momentum, int train, int dtype, void* ws, int64_t ws_bytes, void* stream) {
   MMRCA_REQUIRE(mean && rstd && rows > 0 && C > 0 && ld >= C, "bn_stats: bad arguments");
   hipStream_t st = (hipStream_t)stream;
   if (!train) {
@@ -1338,6 +1484,15 @@ extern "C" int mmrca_bn_stats(const void* x, float* mean, float* rstd, float* ru
   }
   if (dtype == MMRCA_BF16 && C % 8 == 0 && ld % 8 == 0 && (((uintptr_t)x) & 15) == 0) {
     if (g_bn_one_pass) {
+      // flat form of the moments: measured 94 + 9 us against 100 us for the slice form on a 354 MB tensor -- both sit at the ~4 TB/s that a
+      // READ-ONLY pass reaches on this part (see bn_flat_threads) and the flat one pays a second launch: off unless MMRCA_BN_FLAT_MOMENTS=1
+      const char* fm = getenv("MMRCA_BN_FLAT_MOMENTS");            // (read per call: the tests switch it)
+      const bool flat_moments = fm && atoi(fm) == 1;
+      const int64_t T = flat_moments ? bn_flat_threads(rows, C, ld, dtype, x, x, ws, ws_bytes) : 0;
+      if (T) {
+        hipLaunchKernelGGL(col_moment2_flat_k, dim3(blocks_for(T, 256)), dim3(256), 0, st, (const bf16_t*)x, (float*)ws, rows, C / 8, T);
+        bn_flat_reduce((const float*)ws, T, C / 8, mean, rstd, st);
+      } else
       hipLaunchKernelGGL(col_moment2_v8_k, grid, dim3(256), 0, st, (const bf16_t*)x, mean, rstd, rows, C, ld, per);
       hipLaunchKernelGGL(bn_finish_shifted_k, dim3((C + 255) / 256), dim3(256), 0, st, (const bf16_t*)x, mean, rstd, running_mean, running_var, C,
                          (float)rows, eps, momentum, rows, ld);
@@ -1355,6 +1510,15 @@ extern "C" int mmrca_bn_stats(const void* x, float* mean, float* rstd, float* ru
   hipLaunchKernelGGL(bn_finish_var_k, dim3((C + 255) / 256), dim3(256), 0, st, mean, rstd, running_mean, running_var, C, (float)rows, eps, momentum);
   MMRCA_CHECK_LAUNCH("bn_stats");
   return 0;
+}
+extern "C" int mmrca_bn_stats(const void* x, float* mean, float* rstd, float* running_mean, float* running_var, int64_t rows, int C,
+                              int64_t ld, float eps, float momentum, int train, int dtype, void* stream) {
+  return bn_stats_impl(x, mean, rstd, running_mean, running_var, rows, C, ld, eps, momentum, train, dtype, nullptr, 0, stream);
+}
+/* the same with a workspace (fp32, 16-byte aligned, >= 256 KiB; 16 MiB serves every size): large bf16 tensors take the flat streaming pass */
+extern "C" int mmrca_bn_stats_ws(const void* x, float* mean, float* rstd, float* running_mean, float* running_var, int64_t rows, int C,
+                                 int64_t ld, float eps, float momentum, int train, int dtype, void* ws, int64_t ws_bytes, void* stream) {
+  return bn_stats_impl(x, mean, rstd, running_mean, running_var, rows, C, ld, eps, momentum, train, dtype, ws, ws_bytes, stream);
 }
 
 template <typename T>
@@ -1558,7 +1722,7 @@ __global__ void bn_param_grads_k(const float* __restrict__ sum_du, const float* 
  * train != 0: batch statistics took part in the forward (the usual three-term input gradient); 0: statistics were constants. */
 static int bn_act_bwd_impl(const void* dy, const void* x, const float* mean, const float* rstd, const void* gamma, const void* beta,
                            void* dx, float* dgamma, float* dbeta, float* scratch, int64_t rows, int C, int act, int train, int dtype,
-                           void* stream, bool sums_ready) {
+                           void* stream, bool sums_ready, void* ws = nullptr, int64_t ws_bytes = 0) {
   MMRCA_REQUIRE(dy && x && mean && rstd && gamma && beta && scratch && rows > 0 && C > 0 && act >= 0 && act <= 3, "bn_act_bwd: bad arguments");
   hipStream_t st = (hipStream_t)stream;
   dim3 grid; int64_t per;
@@ -1566,7 +1730,13 @@ static int bn_act_bwd_impl(const void* dy, const void* x, const float* mean, con
   if (!sums_ready) (void)hipMemsetAsync(scratch, 0, sizeof(float) * 2 * C, st);
   const int64_t n = rows * C;
   MMRCA_DISPATCH_DTYPE(dtype, "bn_act_bwd",
+    const int64_t Tf = sums_ready ? 0 : bn_flat_threads(rows, C, C, dtype, dy, x, ws, ws_bytes);
     if (sums_ready) {}
+    else if (Tf) {
+      hipLaunchKernelGGL(bn_act_bwd_reduce_flat_k, dim3(blocks_for(Tf, 256)), dim3(256), 0, st, (const bf16_t*)dy, (const bf16_t*)x, mean, rstd,
+                         (const bf16_t*)gamma, (const bf16_t*)beta, (float*)ws, rows, C / 8, act, Tf);
+      bn_flat_reduce((const float*)ws, Tf, C / 8, scratch, scratch + C, st);
+    }
     else if (sizeof(T) == 2 && C % 8 == 0 && ((((uintptr_t)dy) | ((uintptr_t)x)) & 15) == 0)
       hipLaunchKernelGGL(bn_act_bwd_reduce_v8_k, grid, dim3(256), 0, st, (const bf16_t*)dy, (const bf16_t*)x, mean, rstd, (const bf16_t*)gamma,
                          (const bf16_t*)beta, scratch, scratch + C, rows, C, act, per);
@@ -1588,6 +1758,12 @@ extern "C" int mmrca_bn_act_bwd(const void* dy, const void* x, const float* mean
                                 void* dx, float* dgamma, float* dbeta, float* scratch, int64_t rows, int C, int act, int train, int dtype,
                                 void* stream) {
   return bn_act_bwd_impl(dy, x, mean, rstd, gamma, beta, dx, dgamma, dbeta, scratch, rows, C, act, train, dtype, stream, false);
+}
+/* the same with a workspace (as mmrca_bn_stats_ws): the reduce pass of large bf16 tensors runs in the flat streaming form */
+extern "C" int mmrca_bn_act_bwd_ws(const void* dy, const void* x, const float* mean, const float* rstd, const void* gamma, const void* beta,
+                                   void* dx, float* dgamma, float* dbeta, float* scratch, int64_t rows, int C, int act, int train, int dtype,
+                                   void* ws, int64_t ws_bytes, void* stream) {
+  return bn_act_bwd_impl(dy, x, mean, rstd, gamma, beta, dx, dgamma, dbeta, scratch, rows, C, act, train, dtype, stream, false, ws, ws_bytes);
 }
 /* the same when sums[0..C) = sum du and sums[C..2C) = sum du * xhat are already there (mmrca_se_dx left them): no reduce pass */
 extern "C" int mmrca_bn_act_bwd_sums(const void* dy, const void* x, const float* mean, const float* rstd, const void* gamma, const void* beta,

@@ -74,6 +74,8 @@ _SIGS = {
     "mmrca_se_dx": [_vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _vp, _vp, _vp, _vp, _vp, _i32, _vp, _vp],
     "mmrca_bn_act_fwd_res": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i32, _i32, _i64, _i32, _vp],
     "mmrca_bn_stats": [_vp, _vp, _vp, _vp, _vp, _i64, _i32, _i64, _f32, _f32, _i32, _i32, _vp],
+    "mmrca_bn_stats_ws": [_vp, _vp, _vp, _vp, _vp, _i64, _i32, _i64, _f32, _f32, _i32, _i32, _vp, _i64, _vp],
+    "mmrca_bn_act_bwd_ws": [_vp] * 10 + [_i64, _i32, _i32, _i32, _i32, _vp, _i64, _vp],
     "mmrca_bn_act_fwd": [_vp] * 6 + [_i64, _i32, _i32, _i32, _vp],
     "mmrca_bn_act_bwd": [_vp] * 10 + [_i64, _i32, _i32, _i32, _i32, _vp],
     "mmrca_rowpool_mean": [_vp, _vp, _i32, _i32, _i32, _i32, _vp],
@@ -565,10 +567,12 @@ _CONV_BYTES = {
     "mmrca_conv3x3_wgrad": ("conv3x3 implicit GEMM", lambda a: a[3] * a[4] * a[5] * (a[6] + a[7]) * _esz(a[8]) + 9 * a[6] * a[7] * 4),
     "mmrca_gemm_bnstats": ("GEMM (1x1 / patch)", lambda a: (a[3] * a[5] + a[4] * a[5] + a[3] * a[4]) * _esz(a[9])),
     "mmrca_bn_stats": ("BatchNorm", lambda a: a[5] * a[6] * _esz(a[11]) if a[10] else 0),
+    "mmrca_bn_stats_ws": ("BatchNorm", lambda a: a[5] * a[6] * _esz(a[11]) if a[10] else 0),
     "mmrca_bn_act_fwd": ("BatchNorm", lambda a: 2 * a[6] * a[7] * _esz(a[9])),
     "mmrca_bn_act_fwd_res": ("BatchNorm", lambda a: 3 * a[8] * a[9] * _esz(a[12])),
     # backward with batch statistics: the sums need dy and z once, the apply pass needs them again and writes dx
     "mmrca_bn_act_bwd": ("BatchNorm", lambda a: (5 if a[13] else 3) * a[10] * a[11] * _esz(a[14])),
+    "mmrca_bn_act_bwd_ws": ("BatchNorm", lambda a: (5 if a[13] else 3) * a[10] * a[11] * _esz(a[14])),
     "mmrca_bn_act_bwd_sums": ("BatchNorm", lambda a: 3 * a[10] * a[11] * _esz(a[14])),
     "mmrca_rowpool_mean": ("pool / squeeze-excitation", lambda a: a[2] * a[3] * a[4] * _esz(a[5])),
     "mmrca_rowpool_mean_bwd": ("pool / squeeze-excitation", lambda a: a[2] * a[3] * a[4] * _esz(a[6]) * (2 if a[5] else 1)),
@@ -673,7 +677,12 @@ def bn_act_fwd_res(x, mean, rstd, gamma, beta, res, rowscale, out, rows, C, act,
        rows_per_sample, dtype)
 
 
-def bn_stats(x, mean, rstd, running_mean, running_var, rows, C, ld, eps, momentum, train, dtype):
+def bn_stats(x, mean, rstd, running_mean, running_var, rows, C, ld, eps, momentum, train, dtype, ws=None):
+    """ws: fp32 workspace tensor (the flat streaming reduction of large bf16 tensors, include/mmrca.h)"""
+    if ws is not None:
+        _c("mmrca_bn_stats_ws", ptr(x), ptr(mean), ptr(rstd), ptr(running_mean), ptr(running_var), rows, C, ld, eps, momentum, int(train), dtype,
+           ptr(ws), ws.numel() * ws.element_size())
+        return
     _c("mmrca_bn_stats", ptr(x), ptr(mean), ptr(rstd), ptr(running_mean), ptr(running_var), rows, C, ld, eps, momentum, int(train), dtype)
 
 
@@ -682,8 +691,12 @@ def bn_act_fwd(x, mean, rstd, gamma, beta, y, rows, C, act, dtype):
     _c("mmrca_bn_act_fwd", ptr(x), ptr(mean), ptr(rstd), ptr(gamma), ptr(beta), ptr(y), rows, C, act, dtype)
 
 
-def bn_act_bwd(dy, x, mean, rstd, gamma, beta, dx, dgamma, dbeta, scratch, rows, C, act, train, dtype, sums_ready=False):
-    """sums_ready: scratch already holds the first pass's sums (se_dx accumulated them): no reduce pass"""
+def bn_act_bwd(dy, x, mean, rstd, gamma, beta, dx, dgamma, dbeta, scratch, rows, C, act, train, dtype, sums_ready=False, ws=None):
+    """sums_ready: scratch already holds the first pass's sums (se_dx accumulated them): no reduce pass.  ws: as in bn_stats"""
+    if ws is not None and not sums_ready:
+        _c("mmrca_bn_act_bwd_ws", ptr(dy), ptr(x), ptr(mean), ptr(rstd), ptr(gamma), ptr(beta), ptr(dx), ptr(dgamma), ptr(dbeta), ptr(scratch),
+           rows, C, act, int(train), dtype, ptr(ws), ws.numel() * ws.element_size())
+        return
     _c("mmrca_bn_act_bwd_sums" if sums_ready else "mmrca_bn_act_bwd", ptr(dy), ptr(x), ptr(mean), ptr(rstd), ptr(gamma), ptr(beta), ptr(dx), ptr(dgamma), ptr(dbeta), ptr(scratch),
        rows, C, act, int(train), dtype)
 

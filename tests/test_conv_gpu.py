@@ -131,6 +131,45 @@ def test_batchnorm_act_fwd_bwd_and_running_stats(dt, act, train):
     assert rel(dx, x.grad) < tol and rel(dg, gam.grad) < tol and rel(db, bet.grad) < tol
 
 
+@pytest.mark.parametrize("R,C", [(20000, 72), (9001, 384), (3000, 3840), (70000, 8)])
+@pytest.mark.parametrize("act", [L.CONV_NONE, L.CONV_SILU])
+def test_flat_streaming_batchnorm_reductions(R, C, act, monkeypatch):
+    """mmrca_bn_stats_ws / mmrca_bn_act_bwd_ws: the flat form of the two column reductions (thread = fixed channel group, chunks t,
+    t + T, ...; per-thread records in a workspace, second launch adds them) against torch.nn.functional.batch_norm and -- tightly --
+    against the slice-per-workgroup kernels it replaces on large tensors (same fp32 sums in another order).  Odd row counts, the
+    narrowest (8) and widest (3,840: EfficientNetV2-L's last expand) channel counts, a workspace too small for the default thread count."""
+    eps, dt = 1e-3, torch.bfloat16
+    monkeypatch.setenv("MMRCA_BN_FLAT", "1")              # (both flat forms are opt-in: faster in isolation, no gain in the conv step)
+    monkeypatch.setenv("MMRCA_BN_FLAT_MOMENTS", "1")
+    g = torch.Generator().manual_seed(R + C)
+    x = (torch.randn(R, C, generator=g) * 1.5 + 0.7).to(dt).float().requires_grad_(True)
+    gam = (torch.rand(C, generator=g) + 0.5).to(dt).float().requires_grad_(True)
+    bet = (torch.randn(C, generator=g) * 0.3).to(dt).float().requires_grad_(True)
+    u = F.batch_norm(x, torch.zeros(C), torch.ones(C), gam, bet, True, 0.1, eps)
+    ref = F.silu(u) if act == L.CONV_SILU else u
+    dy = torch.randn(R, C, generator=g).to(dt).float()
+    ref.backward(dy)
+    xd, dyd, gd, bd = x.detach().cuda().to(dt), dy.cuda().to(dt), gam.detach().cuda().to(dt), bet.detach().cuda().to(dt)
+    out = {}
+    for name, ws in (("slices", None), ("flat", torch.empty(4 << 20, device="cuda")), ("flat, small workspace", torch.empty(72 * 1024, device="cuda"))):
+        stats = torch.empty(2, C, device="cuda")
+        rm, rv = torch.zeros(C, device="cuda"), torch.ones(C, device="cuda")
+        L.bn_stats(xd, stats[0], stats[1], rm, rv, R, C, C, eps, 0.1, True, L.BF16, ws=ws)
+        dx = torch.empty(R, C, device="cuda", dtype=dt)
+        dg, db = torch.zeros(C, device="cuda"), torch.zeros(C, device="cuda")
+        scratch = torch.empty(2 * C, device="cuda")
+        L.bn_act_bwd(dyd, xd, stats[0], stats[1], gd, bd, dx, dg, db, scratch, R, C, act, True, L.BF16, ws=ws)
+        torch.cuda.synchronize()
+        out[name] = (stats.clone(), rm, rv, dx, dg, db)
+        mean_ref, var_ref = x.detach().mean(0), x.detach().var(0, unbiased=False)
+        assert rel(stats[0], mean_ref) < 1e-5 and rel(stats[1], (var_ref + eps).rsqrt()) < 1e-5, name
+        assert rel(rv, 0.9 + 0.1 * x.detach().var(0, unbiased=True)) < 1e-5, name
+        assert rel(dx, x.grad) < 3e-2 and rel(dg, gam.grad) < 3e-2 and rel(db, bet.grad) < 3e-2, name
+    for name in ("flat", "flat, small workspace"):
+        for a, b in zip(out["slices"], out[name]):
+            assert rel(a, b) < (2e-5 if a.dtype == torch.float32 else 4e-3), name
+
+
 @pytest.mark.parametrize("M,N,K", [(1000, 72, 64), (300, 256, 224), (4096, 768, 192), (777, 200, 96), (128, 128, 64)])
 def test_gemm_with_batchnorm_moments_in_the_epilogue(M, N, K):
     """mmrca_gemm_bnstats + mmrca_bn_finish_sums == mmrca_gemm + mmrca_bn_stats (the 1x1 convolutions of the conv backbones): same z bit

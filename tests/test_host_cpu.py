@@ -96,7 +96,7 @@ def test_cli_defaults_match_reference_parser():
     for k, v in gold["example"].items():
         assert ex[k] == v
     extra = set(mine) - set(gold["defaults"])
-    assert extra == {"tokens_max_len", "dtype", "synthetic", "num_workers", "seed", "image_size", "gpu_preprocess", "blip2_checkpoint"}     # additive flags only
+    assert extra == {"tokens_max_len", "dtype", "synthetic", "num_workers", "seed", "image_size", "gpu_preprocess", "blip2_checkpoint", "hip_graph"}     # additive flags only
 
 
 # ------------------------------------------------------------------------------------------------ dataset
