@@ -439,6 +439,7 @@ class MMRCAEngine:
         return t
 
     def release_buffers(self):
+        self.buffer_generation = getattr(self, "buffer_generation", 0) + 1     # captured HIP graphs point into these buffers (GraphedTrainStep checks)
         self._bufs.clear()
         self._plane_valid.clear()
         self._plane_fresh.clear()

@@ -122,6 +122,7 @@ class GraphedTrainStep:
         self._graphs, self._eager_left = {}, {}
         self._epoch = torch.zeros(1, dtype=torch.int64, device=model.engine.device)
         self.replays = 0
+        self._generation = getattr(model.engine, "buffer_generation", 0)
         L.seed_epoch_set(0)                    # resolves the epoch words' addresses outside any capture
 
     def _eager(self):
@@ -132,6 +133,10 @@ class GraphedTrainStep:
         ids, mask, images, _, seed, tt, ti = _prepare_step(model, ids, mask, images, None)
         key = (tuple(ids.shape), tuple(images.shape), images.dtype, labels.dtype, tt, ti, bool(model.training),
                float(model.drop_ratio), float(model.enc_dropout))
+        if getattr(eng, "buffer_generation", 0) != self._generation:       # engine.release_buffers() freed what the graphs point into
+            self._graphs.clear()
+            self._eager_left.clear()
+            self._generation = getattr(eng, "buffer_generation", 0)
         ent = self._graphs.get(key)
         if ent is None and (self._eager() or self._eager_left.setdefault(key, self.warmup) > 0):
             self._eager_left[key] = self._eager_left.get(key, self.warmup) - 1

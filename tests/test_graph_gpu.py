@@ -155,4 +155,10 @@ def test_graphed_step_draws_stochastic_depth_inside_the_graph():
         losses = [float(graphed(*data[k % 2])) for k in range(6)]
     assert graphed.replays == 5 and all(l == l and abs(l) < 1e3 for l in losses), losses
     assert len({round(l, 4) for l in losses}) >= 4, losses
+    # the engine frees its buffers (a new image size, an evaluation at another batch size ...): the graphs that point into them are
+    # dropped and the step warms up and captures again
+    m.engine.release_buffers()
+    with contextlib.redirect_stdout(io.StringIO()):
+        more = [float(graphed(*data[k % 2])) for k in range(3)]
+    assert graphed.replays == 7 and len(graphed._graphs) == 1 and all(l == l for l in more), more
     m.engine.release_buffers()
