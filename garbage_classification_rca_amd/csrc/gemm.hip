@@ -1359,9 +1359,12 @@ static int gemm_dispatch(const void* A, const void* B, void* C, const void* bias
     //     kernel at two blocks per CU); 64-deep steps keep the ROWK operands' HBM reads in full 128-byte lines;
     //   wgrad (KROW,KROW, fp32 atomics): two-stage 128x128x32 (800-870 vs 680-740), unless there are too few tiles.
     const bool need32 = K % 64 != 0;                 // (ragged contraction: only the 32-deep kernel takes it)
-    const bool auto1s = impl == MMRCA_GEMM_AUTO && !at && !need32;
+    // (experiment, round 4: below this many 128x128 tiles -- an under-filled chip, where the single-stage kernel has no sibling blocks to
+    // hide its load -> barrier -> compute sequence -- AUTO takes the two-stage kernel; 0 = never.  Result in DESIGN K2.)
+    static const int g_auto_2stage_below = getenv("MMRCA_AUTO_2STAGE_BELOW") ? atoi(getenv("MMRCA_AUTO_2STAGE_BELOW")) : 512;
+    const bool auto1s = impl == MMRCA_GEMM_AUTO && !at && !need32 &&
+                        !((int64_t)tiles_m * tiles_n < g_auto_2stage_below && K >= 768 && !colsum_fused && !ragged);
     const bool auto32 = (impl == MMRCA_GEMM_AUTO && at && (int64_t)tiles_m * tiles_n >= 64) || need32;
-    (void)ragged;
     if ((impl == MMRCA_GEMM_MFMA_BK32 || auto32) && !(at && bias)) {
 #define L32(AK_, BK_, AT_) launch_mfma32<AK_, BK_, AT_>(A, B, C, bias, addend, preact, M, N, K, lda, ldb, ldc, act, tiles_m, tiles_n, ksplits, ksplit_len, st)
       if (!ak && !bk && !at) L32(false, false, false);
