@@ -147,6 +147,8 @@ def load(build_if_missing: bool = False):
     lib.mmrca_last_error.restype = C.c_char_p
     lib.mmrca_version.restype = C.c_int
     _lib = lib
+    if os.environ.get("MMRCA_DBG"):            # kernel ablation / probe bits (csrc: g_mmrca_dbg); never set in production runs
+        lib.mmrca_debug_set(int(os.environ["MMRCA_DBG"]))
     return lib
 
 

@@ -292,6 +292,35 @@ def test_gemm_mfma256_fused_gelu_epilogues_and_colsum(bl):
     assert rel_err(C2, X.double() @ Wf.t() + bias.double() + add.double()) < TOL[dt]
 
 
+@pytest.mark.parametrize("M", [256 * 150, 256 * 150 + 100])
+def test_gemm_mfma256_mul_epilogue_over_several_tiles_per_workgroup(M):
+    """ACT_MUL on the persistent kernel with MORE tiles than workgroups (453 on 256 CUs): the gelu' factor is fetched one pass ahead by asm
+    loads with counted waits, next to the stores of the passes and the operand stream of the NEXT tile -- every tile, whole and
+    ragged, must come out right, and so must the column sums that ride on it."""
+    dt = torch.bfloat16
+    N, K = 768, 768
+    g = torch.Generator(device="cuda").manual_seed(M)
+    Mp = (M + 255) // 256 * 256
+    Xp = torch.full((Mp, K), float("nan"), device="cuda", dtype=dt)
+    Xp[:M] = (torch.randn(M, K, device="cuda", generator=g) * 0.3).to(dt)
+    W = (torch.randn(K, N, device="cuda", generator=g) * 0.2).to(dt)            # KROW: the input-gradient form, dX = dY W
+    Gp = torch.full((Mp, N), float("nan"), device="cuda", dtype=dt)
+    Gp[:M] = (torch.rand(M, N, device="cuda", generator=g) + 0.25).to(dt)
+    C = torch.empty(M, N, device="cuda", dtype=dt)
+    db = torch.zeros(N, device="cuda")
+    L.gemm(Xp, W, C, preact=Gp, M=M, N=N, K=K, lda=K, ldb=N, ldc=N, b_layout=L.KROW, act=L.ACT_MUL, dtype=L.BF16, impl=L.IMPL_MFMA256,
+           colsum=db, rows_readable=(Mp, Mp))
+    torch.cuda.synchronize()
+    ref = (Xp[:M].float() @ W.float()) * Gp[:M].float()
+    err = (C.float() - ref).abs().max() / ref.abs().max()
+    assert float(err) < TOL[dt], float(err)
+    # every 256-row tile on its own (an error confined to one tile must not hide behind the largest entry of the whole matrix)
+    per_tile = ((C.float() - ref).abs().view(-1, N)[: (M // 256) * 256].view(-1, 256, N).amax(dim=(1, 2)) /
+                ref.abs().view(-1, N)[: (M // 256) * 256].view(-1, 256, N).amax(dim=(1, 2)))
+    assert float(per_tile.max()) < TOL[dt], float(per_tile.max())
+    assert rel_err(db, C.float().sum(0)) < 1e-4
+
+
 @pytest.mark.parametrize("dt,impl", [(torch.float32, L.IMPL_REF), (torch.bfloat16, L.IMPL_REF), (torch.bfloat16, L.IMPL_MFMA),
                                      (torch.bfloat16, L.IMPL_MFMA_BK32), (torch.bfloat16, L.IMPL_AUTO)])
 def test_gemm_fused_bias_gradient_and_gelu_backward(dt, impl):
