@@ -624,3 +624,19 @@ def test_balanced_sampler_weights_draws_and_rank_striding():
     a.set_epoch(3); one.set_epoch(3)
     assert list(iter(a)) == list(iter(one))[0::2]
     assert len(BalancedShardedSampler([], 0, 1)) == 0 and list(iter(BalancedShardedSampler([], 0, 1))) == []
+
+
+def test_split_phase_asm_loads_are_not_touched_before_their_wait():
+    """The attention backward fetches its row constants with inline-asm loads whose destination registers the COMPILER picks and which are
+    awaited by a later inline-asm s_waitcnt (csrc/attention_mfma.hip, rc_issue / rc_finish).  hipcc believes such an output is valid
+    the moment the asm statement ends; under register pressure it may copy it before the wait -- seen once (round 4, GEMM side-operand
+    experiment, DESIGN K2): right on a warm cache, garbage on a cold one.  This compiles the file to gfx950 ISA (no GPU needed) and
+    checks that nothing reads or writes an in-flight destination register."""
+    import importlib.util
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location("check_inflight_regs", os.path.join(root, "tools", "check_inflight_regs.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    kernels, loads, bad = mod.main(os.path.join(root, "garbage_classification_rca_amd", "csrc", "attention_mfma.hip"), "_Z")
+    assert kernels > 10 and loads >= 30, (kernels, loads)          # (the persistent backward alone issues 51 such loads)
+    assert not bad, bad[:5]
