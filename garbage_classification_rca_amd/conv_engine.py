@@ -104,6 +104,7 @@ class ConvEncoder:
         self._maps: Dict[Tuple, torch.Tensor] = {}
         self.saved = None
         self._sd_p = None
+        self._bn_arena, self._bn_off, self._bn_used, self._bn_bwd_seen = None, {}, 0, set()
         self.injected_keep = None             # tests: [n_sd_blocks, B] 0/1 keep masks instead of drawing them
         self.n_train_forwards = 0             # = every BatchNorm's num_batches_tracked (written out by sync_buffers())
 
@@ -233,6 +234,32 @@ class ConvEncoder:
             self._bufs[key] = t
         return t
 
+    # BatchNorm statistics ([mean | rstd]) and backward sums ([sum du | sum du xhat]) of EVERY layer live in one fp32 arena that forward()
+    # clears with a single fill: the kernels accumulate into them with atomics, and a fill per layer and direction was 2 of the ~18
+    # launches a conv -> bn -> act unit costs per step -- the small-batch step is bound by its launch count
+    BN_ARENA_FLOATS = 4 << 20
+
+    def _bn_slices(self, u: "_Unit"):
+        if self._bn_arena is None:
+            self._bn_arena = torch.zeros(self.BN_ARENA_FLOATS, dtype=torch.float32, device=self.o.device)
+        off = self._bn_off.get(u.bn_key)
+        if off is None:
+            off = self._bn_used
+            self._bn_used += 4 * _ru(u.cout, 4)              # (16-byte aligned slices)
+            if self._bn_used > self.BN_ARENA_FLOATS:
+                raise L.MmrcaError("conv_engine: BatchNorm arena exhausted")
+            self._bn_off[u.bn_key] = off
+        c = u.cout
+        return self._bn_arena[off: off + 2 * c].view(2, c), self._bn_arena[off + 2 * _ru(c, 4): off + 2 * _ru(c, 4) + 2 * c].view(1, 2 * c)
+
+    def _bn_scratch(self, u: "_Unit"):
+        """the backward sums of u, clear: by forward()'s fill, or -- a second backward over the same forward -- by a fill of its own"""
+        scratch = self._bn_slices(u)[1]
+        if u.bn_key in self._bn_bwd_seen:
+            scratch.zero_()
+        self._bn_bwd_seen.add(u.bn_key)
+        return scratch
+
     def _bn_ws(self):
         """16 MiB of fp32 words for the flat BatchNorm reductions (one 64-byte record per streaming thread, csrc/conv.hip)"""
         return self.buf("tmp.bnws", 4096, 1024, torch.float32) if self.cdtype == torch.bfloat16 else None
@@ -342,7 +369,7 @@ class ConvEncoder:
             else:
                 L.im2row3x3(x, col, B, H, Wd, u.cin, u.stride, K, dt)
             L.gemm(col, w, z, M=rows, N=u.cout, K=K, lda=K, ldb=K, ldc=u.cout, dtype=dt, impl=self.o.gemm_impl)
-        stats = self.buf(tag + ".stats", 2, u.cout, torch.float32)          # [mean | rstd] adjacent: bn_stats clears both with one fill
+        stats, _ = self._bn_slices(u)                                       # [mean | rstd] in the per-step arena (cleared by forward())
         mean, rstd = stats[0], stats[1]
         rm, rv = self.buffers[u.bn_key + ".running_mean"], self.buffers[u.bn_key + ".running_var"]
         if fused_stats:
@@ -350,7 +377,7 @@ class ConvEncoder:
         elif sums is not None:
             L.bn_finish_sums(sums[0], sums[1], rm, sums[2], rows, mean, rstd, rm, rv, u.cout, u.eps, 0.1)
         else:
-            L.bn_stats(z, mean, rstd, rm, rv, rows, u.cout, u.cout, u.eps, 0.1 if train else 0.0, train, dt, ws=self._bn_ws())
+            L.bn_stats(z, mean, rstd, rm, rv, rows, u.cout, u.cout, u.eps, 0.1 if train else 0.0, train, dt, ws=self._bn_ws(), prezeroed=True)
         fused_res = res is not None and FUSE_RES and self.cdtype == torch.bfloat16 and u.cout % 8 == 0
         if fused_res:
             y = out
@@ -368,10 +395,10 @@ class ConvEncoder:
         H, Wd, Ho, Wo = sv["H"], sv["W"], sv["Ho"], sv["Wo"]
         rows = B * Ho * Wo
         dz = self.buf(f"{tag}.dz.{u.cout}", rows, u.cout)
-        scratch = self.buf("g.bnscratch", 1, 2 * u.cout, torch.float32)
+        scratch = self._bn_slices(u)[1] if sums_ready else self._bn_scratch(u)      # this layer's backward sums (clear since forward(), or filled by se_dx)
         L.bn_act_bwd(dy, sv["z"], sv["mean"], sv["rstd"], self.W(u.bn_key + ".weight"), self.W(u.bn_key + ".bias"), dz,
                      self.G(u.bn_key + ".weight"), self.G(u.bn_key + ".bias"), scratch, rows, u.cout, u.act, sv["train"], dt,
-                     sums_ready=sums_ready, ws=self._bn_ws())
+                     sums_ready=sums_ready, ws=self._bn_ws(), prezeroed=True)
         w, gw = self.W(u.conv_key + ".weight"), self.G(u.conv_key + ".weight")
         rows_in = B * H * Wd
         dx = self.buf(f"{tag}.dx.{u.cin}.{rows_in}", rows_in, u.cin) if need_dx else None
@@ -469,8 +496,7 @@ class ConvEncoder:
         bnargs = None
         if bn is not None and bn[0].cout == se.c and bn[1]["train"]:
             u, usv = bn
-            scratch = self.buf("g.bnscratch", 1, 2 * u.cout, torch.float32)
-            scratch[0].zero_()
+            scratch = self._bn_scratch(u)                                   # (clear since forward(); _unit_bwd reads the sums from the same slice)
             bnargs = (usv["z"], usv["mean"], usv["rstd"], self.W(u.bn_key + ".weight"), self.W(u.bn_key + ".bias"), u.act, scratch)
         L.se_dx(dy, sv["s"], dpool, dx, B, HW, se.c, dt, bn=bnargs)
         return dx, bnargs is not None
@@ -482,6 +508,9 @@ class ConvEncoder:
         B, C, H, Wd = images.shape
         if C != 3:
             raise ValueError(f"images must be [B,3,H,W], got {tuple(images.shape)}")
+        if self._bn_arena is not None:
+            self._bn_arena.zero_()
+        self._bn_bwd_seen.clear()
         x0 = self.buf("in.rows", B * H * Wd, 3)
         L.nchw_to_rows(images.to(torch.float32).contiguous(), x0, B, 3, H, Wd, dt)
         saved = dict(B=B, blocks=[], train=train)

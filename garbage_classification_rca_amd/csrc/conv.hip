@@ -1464,7 +1464,7 @@ static const bool g_bn_one_pass = !(getenv("MMRCA_BN_ONE_PASS") && atoi(getenv("
 /* mean[C], rstd[C] (fp32) of x[rows, C] (two passes: mean, then centred second moment; the bf16 fast path: one pass of shifted sums); momentum > 0 also updates the running
  * statistics (torch semantics).  train == 0: mean / rstd are derived from the running statistics instead. */
 static int bn_stats_impl(const void* x, float* mean, float* rstd, float* running_mean, float* running_var, int64_t rows, int C,
-                         int64_t ld, float eps, float momentum, int train, int dtype, void* ws, int64_t ws_bytes, void* stream) {
+                         int64_t ld, float eps, float momentum, int train, int dtype, void* ws, int64_t ws_bytes, int flags, void* stream) {
   MMRCA_REQUIRE(mean && rstd && rows > 0 && C > 0 && ld >= C, "bn_stats: bad arguments");
   hipStream_t st = (hipStream_t)stream;
   if (!train) {
@@ -1476,7 +1476,8 @@ static int bn_stats_impl(const void* x, float* mean, float* rstd, float* running
   MMRCA_REQUIRE(x, "bn_stats: null input");
   dim3 grid; int64_t per;
   col_grid(rows, C, &grid, &per);
-  if (rstd == mean + C) {               // adjacent (one [2, C] buffer, as the conv engine allocates them): one fill instead of two
+  if (flags & 1) {                      // the caller zeroed mean / rstd (one fill for every layer of the step: conv_engine's arena)
+  } else if (rstd == mean + C) {        // adjacent (one [2, C] buffer): one fill instead of two
     (void)hipMemsetAsync(mean, 0, sizeof(float) * 2 * C, st);
   } else {
     (void)hipMemsetAsync(mean, 0, sizeof(float) * C, st);
@@ -1513,12 +1514,13 @@ static int bn_stats_impl(const void* x, float* mean, float* rstd, float* running
 }
 extern "C" int mmrca_bn_stats(const void* x, float* mean, float* rstd, float* running_mean, float* running_var, int64_t rows, int C,
                               int64_t ld, float eps, float momentum, int train, int dtype, void* stream) {
-  return bn_stats_impl(x, mean, rstd, running_mean, running_var, rows, C, ld, eps, momentum, train, dtype, nullptr, 0, stream);
+  return bn_stats_impl(x, mean, rstd, running_mean, running_var, rows, C, ld, eps, momentum, train, dtype, nullptr, 0, 0, stream);
 }
 /* the same with a workspace (fp32, 16-byte aligned, >= 256 KiB; 16 MiB serves every size): large bf16 tensors take the flat streaming pass */
 extern "C" int mmrca_bn_stats_ws(const void* x, float* mean, float* rstd, float* running_mean, float* running_var, int64_t rows, int C,
-                                 int64_t ld, float eps, float momentum, int train, int dtype, void* ws, int64_t ws_bytes, void* stream) {
-  return bn_stats_impl(x, mean, rstd, running_mean, running_var, rows, C, ld, eps, momentum, train, dtype, ws, ws_bytes, stream);
+                                 int64_t ld, float eps, float momentum, int train, int dtype, void* ws, int64_t ws_bytes, int flags,
+                                 void* stream) {
+  return bn_stats_impl(x, mean, rstd, running_mean, running_var, rows, C, ld, eps, momentum, train, dtype, ws, ws_bytes, flags, stream);
 }
 
 template <typename T>
@@ -1722,12 +1724,12 @@ __global__ void bn_param_grads_k(const float* __restrict__ sum_du, const float* 
  * train != 0: batch statistics took part in the forward (the usual three-term input gradient); 0: statistics were constants. */
 static int bn_act_bwd_impl(const void* dy, const void* x, const float* mean, const float* rstd, const void* gamma, const void* beta,
                            void* dx, float* dgamma, float* dbeta, float* scratch, int64_t rows, int C, int act, int train, int dtype,
-                           void* stream, bool sums_ready, void* ws = nullptr, int64_t ws_bytes = 0) {
+                           void* stream, bool sums_ready, void* ws = nullptr, int64_t ws_bytes = 0, int flags = 0) {
   MMRCA_REQUIRE(dy && x && mean && rstd && gamma && beta && scratch && rows > 0 && C > 0 && act >= 0 && act <= 3, "bn_act_bwd: bad arguments");
   hipStream_t st = (hipStream_t)stream;
   dim3 grid; int64_t per;
   col_grid(rows, C, &grid, &per);
-  if (!sums_ready) (void)hipMemsetAsync(scratch, 0, sizeof(float) * 2 * C, st);
+  if (!sums_ready && !(flags & 1)) (void)hipMemsetAsync(scratch, 0, sizeof(float) * 2 * C, st);      // (flags & 1: the caller zeroed the scratch)
   const int64_t n = rows * C;
   MMRCA_DISPATCH_DTYPE(dtype, "bn_act_bwd",
     const int64_t Tf = sums_ready ? 0 : bn_flat_threads(rows, C, C, dtype, dy, x, ws, ws_bytes);
@@ -1762,8 +1764,8 @@ extern "C" int mmrca_bn_act_bwd(const void* dy, const void* x, const float* mean
 /* the same with a workspace (as mmrca_bn_stats_ws): the reduce pass of large bf16 tensors runs in the flat streaming form */
 extern "C" int mmrca_bn_act_bwd_ws(const void* dy, const void* x, const float* mean, const float* rstd, const void* gamma, const void* beta,
                                    void* dx, float* dgamma, float* dbeta, float* scratch, int64_t rows, int C, int act, int train, int dtype,
-                                   void* ws, int64_t ws_bytes, void* stream) {
-  return bn_act_bwd_impl(dy, x, mean, rstd, gamma, beta, dx, dgamma, dbeta, scratch, rows, C, act, train, dtype, stream, false, ws, ws_bytes);
+                                   void* ws, int64_t ws_bytes, int flags, void* stream) {
+  return bn_act_bwd_impl(dy, x, mean, rstd, gamma, beta, dx, dgamma, dbeta, scratch, rows, C, act, train, dtype, stream, false, ws, ws_bytes, flags);
 }
 /* the same when sums[0..C) = sum du and sums[C..2C) = sum du * xhat are already there (mmrca_se_dx left them): no reduce pass */
 extern "C" int mmrca_bn_act_bwd_sums(const void* dy, const void* x, const float* mean, const float* rstd, const void* gamma, const void* beta,

@@ -74,8 +74,8 @@ _SIGS = {
     "mmrca_se_dx": [_vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _vp, _vp, _vp, _vp, _vp, _i32, _vp, _vp],
     "mmrca_bn_act_fwd_res": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i32, _i32, _i64, _i32, _vp],
     "mmrca_bn_stats": [_vp, _vp, _vp, _vp, _vp, _i64, _i32, _i64, _f32, _f32, _i32, _i32, _vp],
-    "mmrca_bn_stats_ws": [_vp, _vp, _vp, _vp, _vp, _i64, _i32, _i64, _f32, _f32, _i32, _i32, _vp, _i64, _vp],
-    "mmrca_bn_act_bwd_ws": [_vp] * 10 + [_i64, _i32, _i32, _i32, _i32, _vp, _i64, _vp],
+    "mmrca_bn_stats_ws": [_vp, _vp, _vp, _vp, _vp, _i64, _i32, _i64, _f32, _f32, _i32, _i32, _vp, _i64, _i32, _vp],
+    "mmrca_bn_act_bwd_ws": [_vp] * 10 + [_i64, _i32, _i32, _i32, _i32, _vp, _i64, _i32, _vp],
     "mmrca_bn_act_fwd": [_vp] * 6 + [_i64, _i32, _i32, _i32, _vp],
     "mmrca_bn_act_bwd": [_vp] * 10 + [_i64, _i32, _i32, _i32, _i32, _vp],
     "mmrca_rowpool_mean": [_vp, _vp, _i32, _i32, _i32, _i32, _vp],
@@ -679,11 +679,12 @@ def bn_act_fwd_res(x, mean, rstd, gamma, beta, res, rowscale, out, rows, C, act,
        rows_per_sample, dtype)
 
 
-def bn_stats(x, mean, rstd, running_mean, running_var, rows, C, ld, eps, momentum, train, dtype, ws=None):
-    """ws: fp32 workspace tensor (the flat streaming reduction of large bf16 tensors, include/mmrca.h)"""
-    if ws is not None:
+def bn_stats(x, mean, rstd, running_mean, running_var, rows, C, ld, eps, momentum, train, dtype, ws=None, prezeroed=False):
+    """ws: fp32 workspace tensor (the flat streaming reduction of large bf16 tensors, include/mmrca.h); prezeroed: the caller cleared
+    mean / rstd (conv_engine's per-step arena): no fill launch"""
+    if ws is not None or prezeroed:
         _c("mmrca_bn_stats_ws", ptr(x), ptr(mean), ptr(rstd), ptr(running_mean), ptr(running_var), rows, C, ld, eps, momentum, int(train), dtype,
-           ptr(ws), ws.numel() * ws.element_size())
+           ptr(ws), 0 if ws is None else ws.numel() * ws.element_size(), int(prezeroed))
         return
     _c("mmrca_bn_stats", ptr(x), ptr(mean), ptr(rstd), ptr(running_mean), ptr(running_var), rows, C, ld, eps, momentum, int(train), dtype)
 
@@ -693,11 +694,11 @@ def bn_act_fwd(x, mean, rstd, gamma, beta, y, rows, C, act, dtype):
     _c("mmrca_bn_act_fwd", ptr(x), ptr(mean), ptr(rstd), ptr(gamma), ptr(beta), ptr(y), rows, C, act, dtype)
 
 
-def bn_act_bwd(dy, x, mean, rstd, gamma, beta, dx, dgamma, dbeta, scratch, rows, C, act, train, dtype, sums_ready=False, ws=None):
-    """sums_ready: scratch already holds the first pass's sums (se_dx accumulated them): no reduce pass.  ws: as in bn_stats"""
-    if ws is not None and not sums_ready:
+def bn_act_bwd(dy, x, mean, rstd, gamma, beta, dx, dgamma, dbeta, scratch, rows, C, act, train, dtype, sums_ready=False, ws=None, prezeroed=False):
+    """sums_ready: scratch already holds the first pass's sums (se_dx accumulated them): no reduce pass.  ws / prezeroed: as in bn_stats"""
+    if (ws is not None or prezeroed) and not sums_ready:
         _c("mmrca_bn_act_bwd_ws", ptr(dy), ptr(x), ptr(mean), ptr(rstd), ptr(gamma), ptr(beta), ptr(dx), ptr(dgamma), ptr(dbeta), ptr(scratch),
-           rows, C, act, int(train), dtype, ptr(ws), ws.numel() * ws.element_size())
+           rows, C, act, int(train), dtype, ptr(ws), 0 if ws is None else ws.numel() * ws.element_size(), int(prezeroed))
         return
     _c("mmrca_bn_act_bwd_sums" if sums_ready else "mmrca_bn_act_bwd", ptr(dy), ptr(x), ptr(mean), ptr(rstd), ptr(gamma), ptr(beta), ptr(dx), ptr(dgamma), ptr(dbeta), ptr(scratch),
        rows, C, act, int(train), dtype)

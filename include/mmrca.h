@@ -204,8 +204,10 @@ int mmrca_bn_stats(const void* x, float* mean, float* rstd, float* running_mean,
  * MMRCA_BN_FLAT=1 large bf16 tensors take the FLAT streaming reduction -- every wave instruction reads 1 KiB of consecutive addresses,
  * per-thread partial sums go to the workspace and a second small launch adds them up (3.8-4.3 TB/s against 3.1-3.7 for the
  * slice-per-workgroup form in isolation; no gain inside the conv step, hence opt-in -- csrc/conv.hip) */
+/* flags bit 0: mean / rstd (scratch for the backward) were zeroed by the caller -- the conv engine keeps every layer's statistics and
+ * backward sums in ONE arena and clears it with one fill per step instead of two per layer (the small-batch step is bound by its launch count) */
 int mmrca_bn_stats_ws(const void* x, float* mean, float* rstd, float* running_mean, float* running_var, int64_t rows, int C,
-                      int64_t ld, float eps, float momentum, int train, int dtype, void* ws, int64_t ws_bytes, void* stream);
+                      int64_t ld, float eps, float momentum, int train, int dtype, void* ws, int64_t ws_bytes, int flags, void* stream);
 int mmrca_bn_act_fwd(const void* x, const float* mean, const float* rstd, const void* gamma, const void* beta, void* y,
                      int64_t rows, int C, int act, int dtype, void* stream);
 /* out = res + rowscale[row / rows_per_sample] * act(bn(x)): mmrca_bn_act_fwd and the block's residual connection
@@ -220,7 +222,7 @@ int mmrca_bn_act_bwd(const void* dy, const void* x, const float* mean, const flo
 /* the same with a workspace, as mmrca_bn_stats_ws: the reduce pass over dy and x in the flat streaming form */
 int mmrca_bn_act_bwd_ws(const void* dy, const void* x, const float* mean, const float* rstd, const void* gamma, const void* beta,
                         void* dx, float* dgamma, float* dbeta, float* scratch, int64_t rows, int C, int act, int train, int dtype,
-                        void* ws, int64_t ws_bytes, void* stream);
+                        void* ws, int64_t ws_bytes, int flags, void* stream);
 /* the same when sums[0..C) = sum du and sums[C..2C) = sum du * xhat already hold the first pass's result (mmrca_se_dx computes them
  * while it writes dy): no reduce pass over dy and x */
 int mmrca_bn_act_bwd_sums(const void* dy, const void* x, const float* mean, const float* rstd, const void* gamma, const void* beta,
