@@ -151,21 +151,23 @@ def test_flat_streaming_batchnorm_reductions(R, C, act, monkeypatch):
     ref.backward(dy)
     xd, dyd, gd, bd = x.detach().cuda().to(dt), dy.cuda().to(dt), gam.detach().cuda().to(dt), bet.detach().cuda().to(dt)
     out = {}
-    for name, ws in (("slices", None), ("flat", torch.empty(4 << 20, device="cuda")), ("flat, small workspace", torch.empty(72 * 1024, device="cuda"))):
-        stats = torch.empty(2, C, device="cuda")
+    for name, ws in (("slices", None), ("flat", torch.empty(4 << 20, device="cuda")), ("flat, small workspace", torch.empty(72 * 1024, device="cuda")),
+                     ("caller-zeroed buffers", None)):
+        pz = name == "caller-zeroed buffers"           # flag bit 0 of the _ws entry points: no fill launch inside (conv_engine's per-step arena)
+        stats = torch.zeros(2, C, device="cuda") if pz else torch.full((2, C), 7.0, device="cuda")
         rm, rv = torch.zeros(C, device="cuda"), torch.ones(C, device="cuda")
-        L.bn_stats(xd, stats[0], stats[1], rm, rv, R, C, C, eps, 0.1, True, L.BF16, ws=ws)
+        L.bn_stats(xd, stats[0], stats[1], rm, rv, R, C, C, eps, 0.1, True, L.BF16, ws=ws, prezeroed=pz)
         dx = torch.empty(R, C, device="cuda", dtype=dt)
         dg, db = torch.zeros(C, device="cuda"), torch.zeros(C, device="cuda")
-        scratch = torch.empty(2 * C, device="cuda")
-        L.bn_act_bwd(dyd, xd, stats[0], stats[1], gd, bd, dx, dg, db, scratch, R, C, act, True, L.BF16, ws=ws)
+        scratch = torch.zeros(2 * C, device="cuda") if pz else torch.full((2 * C,), 7.0, device="cuda")
+        L.bn_act_bwd(dyd, xd, stats[0], stats[1], gd, bd, dx, dg, db, scratch, R, C, act, True, L.BF16, ws=ws, prezeroed=pz)
         torch.cuda.synchronize()
         out[name] = (stats.clone(), rm, rv, dx, dg, db)
         mean_ref, var_ref = x.detach().mean(0), x.detach().var(0, unbiased=False)
         assert rel(stats[0], mean_ref) < 1e-5 and rel(stats[1], (var_ref + eps).rsqrt()) < 1e-5, name
         assert rel(rv, 0.9 + 0.1 * x.detach().var(0, unbiased=True)) < 1e-5, name
         assert rel(dx, x.grad) < 3e-2 and rel(dg, gam.grad) < 3e-2 and rel(db, bet.grad) < 3e-2, name
-    for name in ("flat", "flat, small workspace"):
+    for name in ("flat", "flat, small workspace", "caller-zeroed buffers"):
         for a, b in zip(out["slices"], out[name]):
             assert rel(a, b) < (2e-5 if a.dtype == torch.float32 else 4e-3), name
 
