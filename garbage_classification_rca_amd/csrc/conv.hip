@@ -1082,7 +1082,7 @@ extern "C" int mmrca_dwconv3x3_bwd_ws(const void* dy, const void* x, const void*
 // ---------------------------------------------------------------------------------------------------------------------
 template <typename T, bool CENTERED>
 __global__ void col_moment_k(const T* __restrict__ x, const float* __restrict__ mean, float* __restrict__ out, int64_t rows, int C,
-                             int64_t ld, int64_t rows_per_block) {
+                             int64_t ld, int64_t rows_per_block, float mscale) {      // CENTERED: mean[] holds the raw column SUMS, mscale = 1 / rows
   __shared__ float red[4][64];
   const int cl = threadIdx.x & 63, rl = threadIdx.x >> 6;
   const int c = blockIdx.x * 64 + cl;
@@ -1090,7 +1090,7 @@ __global__ void col_moment_k(const T* __restrict__ x, const float* __restrict__ 
   const int64_t r1 = r0 + rows_per_block < rows ? r0 + rows_per_block : rows;
   float s = 0.f;
   if (c < C) {
-    const float m = CENTERED ? mean[c] : 0.f;
+    const float m = CENTERED ? mean[c] * mscale : 0.f;
     for (int64_t r = r0 + rl; r < r1; r += 4) {
       const float v = to_f(x[r * ld + c]) - m;
       s += CENTERED ? v * v : v;
@@ -1101,19 +1101,19 @@ __global__ void col_moment_k(const T* __restrict__ x, const float* __restrict__ 
   if (rl == 0 && c < C) atomicAdd(out + c, red[0][cl] + red[1][cl] + red[2][cl] + red[3][cl]);
 }
 
-__global__ void bn_finish_mean_k(float* __restrict__ mean, int C, float inv_n) {
-  const int c = blockIdx.x * blockDim.x + threadIdx.x;
-  if (c < C) mean[c] *= inv_n;
-}
 // var_sum -> rstd (in place), running stats
-__global__ void bn_finish_var_k(const float* __restrict__ mean, float* __restrict__ rstd, float* __restrict__ running_mean,
-                                float* __restrict__ running_var, int C, float n, float eps, float momentum) {
+// (mean[] arrives as the raw column sums: the mean is formed here and -- with the same multiplication -- by the centred pass that ran
+// before; a separate "sums -> mean" launch between the two passes was one of the nine launches of a two-pass BatchNorm)
+__global__ void bn_finish_var_k(float* __restrict__ mean, float* __restrict__ rstd, float* __restrict__ running_mean,
+                                float* __restrict__ running_var, int C, float n, float eps, float momentum, float mscale) {
   const int c = blockIdx.x * blockDim.x + threadIdx.x;
   if (c >= C) return;
+  const float mu = mean[c] * mscale;
+  mean[c] = mu;
   const float var = rstd[c] / n;
   rstd[c] = rsqrtf(var + eps);
   if (running_mean && momentum > 0.f) {
-    running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * mean[c];
+    running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * mu;
     running_var[c] = (1.f - momentum) * running_var[c] + momentum * (n > 1.f ? var * n / (n - 1.f) : var);
   }
 }
@@ -1149,7 +1149,7 @@ __device__ __forceinline__ void col_reduce8(float (&acc)[NV][8], float (*red)[8]
 template <bool CENTERED>
 __global__ void __launch_bounds__(256)
 col_moment_v8_k(const bf16_t* __restrict__ x, const float* __restrict__ mean, float* __restrict__ out, int64_t rows, int C, int64_t ld,
-                int64_t rows_per_block) {
+                int64_t rows_per_block, float mscale) {
   __shared__ float red[4][8][9];
   const int cg = threadIdx.x & 7, rl = threadIdx.x >> 3;
   const int c0 = blockIdx.x * 64 + cg * 8;
@@ -1161,7 +1161,7 @@ col_moment_v8_k(const bf16_t* __restrict__ x, const float* __restrict__ mean, fl
   if (c0 < C) {
     float m[8];
 #pragma unroll
-    for (int j = 0; j < 8; ++j) m[j] = CENTERED ? mean[c0 + j] : 0.f;
+    for (int j = 0; j < 8; ++j) m[j] = CENTERED ? mean[c0 + j] * mscale : 0.f;
     for (int64_t r = r0 + rl; r < r1; r += 32) {
       const cm_b8 v = *reinterpret_cast<const cm_b8*>(x + r * ld + c0);
 #pragma unroll
@@ -1500,15 +1500,14 @@ static int bn_stats_impl(const void* x, float* mean, float* rstd, float* running
       MMRCA_CHECK_LAUNCH("bn_stats(one pass)");
       return 0;
     }
-    hipLaunchKernelGGL((col_moment_v8_k<false>), grid, dim3(256), 0, st, (const bf16_t*)x, (const float*)nullptr, mean, rows, C, ld, per);
-    hipLaunchKernelGGL(bn_finish_mean_k, dim3((C + 255) / 256), dim3(256), 0, st, mean, C, 1.0f / (float)rows);
-    hipLaunchKernelGGL((col_moment_v8_k<true>), grid, dim3(256), 0, st, (const bf16_t*)x, (const float*)mean, rstd, rows, C, ld, per);
+    hipLaunchKernelGGL((col_moment_v8_k<false>), grid, dim3(256), 0, st, (const bf16_t*)x, (const float*)nullptr, mean, rows, C, ld, per, 1.0f);
+    hipLaunchKernelGGL((col_moment_v8_k<true>), grid, dim3(256), 0, st, (const bf16_t*)x, (const float*)mean, rstd, rows, C, ld, per, 1.0f / (float)rows);
   } else
   MMRCA_DISPATCH_DTYPE(dtype, "bn_stats",
-    hipLaunchKernelGGL((col_moment_k<T, false>), grid, dim3(256), 0, st, (const T*)x, (const float*)nullptr, mean, rows, C, ld, per);
-    hipLaunchKernelGGL(bn_finish_mean_k, dim3((C + 255) / 256), dim3(256), 0, st, mean, C, 1.0f / (float)rows);
-    hipLaunchKernelGGL((col_moment_k<T, true>), grid, dim3(256), 0, st, (const T*)x, (const float*)mean, rstd, rows, C, ld, per);)
-  hipLaunchKernelGGL(bn_finish_var_k, dim3((C + 255) / 256), dim3(256), 0, st, mean, rstd, running_mean, running_var, C, (float)rows, eps, momentum);
+    hipLaunchKernelGGL((col_moment_k<T, false>), grid, dim3(256), 0, st, (const T*)x, (const float*)nullptr, mean, rows, C, ld, per, 1.0f);
+    hipLaunchKernelGGL((col_moment_k<T, true>), grid, dim3(256), 0, st, (const T*)x, (const float*)mean, rstd, rows, C, ld, per, 1.0f / (float)rows);)
+  hipLaunchKernelGGL(bn_finish_var_k, dim3((C + 255) / 256), dim3(256), 0, st, mean, rstd, running_mean, running_var, C, (float)rows, eps, momentum,
+                     1.0f / (float)rows);
   MMRCA_CHECK_LAUNCH("bn_stats");
   return 0;
 }
@@ -1604,7 +1603,10 @@ bn_act_fwd_res_v8_k(const bf16_t* __restrict__ x, const float* __restrict__ mean
 __global__ void __launch_bounds__(256)
 bn_act_bwd_apply_v8_k(const bf16_t* __restrict__ dy, const bf16_t* __restrict__ x, const float* __restrict__ mean, const float* __restrict__ rstd,
                       const bf16_t* __restrict__ gamma, const bf16_t* __restrict__ beta, const float* __restrict__ sum_du,
-                      const float* __restrict__ sum_duxh, bf16_t* __restrict__ dx, int64_t rows, int C8, int act, float inv_rows, int train) {
+                      const float* __restrict__ sum_duxh, bf16_t* __restrict__ dx, int64_t rows, int C8, int act, float inv_rows, int train,
+                      float* __restrict__ dgamma, float* __restrict__ dbeta) {
+  if (dgamma && blockIdx.x == 0)
+    for (int c = threadIdx.x; c < C8 * 8; c += blockDim.x) { dgamma[c] += sum_duxh[c]; dbeta[c] += sum_du[c]; }
   const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   const int64_t r0 = t / C8 * BN_R;
   if (r0 >= rows) return;
@@ -1704,7 +1706,10 @@ template <typename T>
 __global__ void bn_act_bwd_apply_k(const T* __restrict__ dy, const T* __restrict__ x, const float* __restrict__ mean,
                                    const float* __restrict__ rstd, const T* __restrict__ gamma, const T* __restrict__ beta,
                                    const float* __restrict__ sum_du, const float* __restrict__ sum_duxh, T* __restrict__ dx, int64_t n,
-                                   int C, int act, float inv_rows, int train) {
+                                   int C, int act, float inv_rows, int train, float* __restrict__ dgamma, float* __restrict__ dbeta) {
+  // (the parameter gradients ride on block 0: the sums are complete before this launch starts -- it was a launch of its own)
+  if (dgamma && blockIdx.x == 0)
+    for (int c = threadIdx.x; c < C; c += blockDim.x) { dgamma[c] += sum_duxh[c]; dbeta[c] += sum_du[c]; }
   const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (idx >= n) return;
   const int c = (int)(idx % C);
@@ -1748,11 +1753,11 @@ static int bn_act_bwd_impl(const void* dy, const void* x, const float* mean, con
     const bool v8 = dx && bn_v8_ok(C, dtype, dy, x, dx, gamma) && ((((uintptr_t)mean) | ((uintptr_t)rstd) | ((uintptr_t)scratch) | ((uintptr_t)beta)) & 15) == 0;
     if (v8) hipLaunchKernelGGL(bn_act_bwd_apply_v8_k, dim3(blocks_for((rows + BN_R - 1) / BN_R * (C / 8), 256)), dim3(256), 0, st, (const bf16_t*)dy,
                                (const bf16_t*)x, mean, rstd, (const bf16_t*)gamma, (const bf16_t*)beta, (const float*)scratch,
-                               (const float*)(scratch + C), (bf16_t*)dx, rows, C / 8, act, 1.0f / (float)rows, train);
+                               (const float*)(scratch + C), (bf16_t*)dx, rows, C / 8, act, 1.0f / (float)rows, train, dgamma && dbeta ? dgamma : nullptr, dbeta);
     else if (dx) hipLaunchKernelGGL(bn_act_bwd_apply_k<T>, dim3(blocks_for(n, 256)), dim3(256), 0, st, (const T*)dy, (const T*)x, mean, rstd,
                                (const T*)gamma, (const T*)beta, (const float*)scratch, (const float*)(scratch + C), (T*)dx, n, C, act,
-                               1.0f / (float)rows, train);)
-  if (dgamma && dbeta) hipLaunchKernelGGL(bn_param_grads_k, dim3((C + 255) / 256), dim3(256), 0, st, scratch, scratch + C, dgamma, dbeta, C);
+                               1.0f / (float)rows, train, dgamma && dbeta ? dgamma : nullptr, dbeta);)
+  if (dgamma && dbeta && !dx) hipLaunchKernelGGL(bn_param_grads_k, dim3((C + 255) / 256), dim3(256), 0, st, scratch, scratch + C, dgamma, dbeta, C);
   MMRCA_CHECK_LAUNCH("bn_act_bwd");
   return 0;
 }
