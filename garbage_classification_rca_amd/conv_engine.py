@@ -601,26 +601,22 @@ class ConvEncoder:
 
     def _shuffle_cat(self, a, b, rows, Cc, name, first_is_full=False):
         """channel_shuffle(cat(a', b), groups=2): out[:, 2j] = a'[:, j], out[:, 2j+1] = b[:, j]  (a' = first half of a when
-        first_is_full).  Two gathers into the interleaved columns are written as one gather each over a [rows, Cc] view."""
-        dt = self.cdt
+        first_is_full) -- one launch (round 3: two gathers into a concat buffer and a third for the shuffle)."""
         bf = Cc // 2
         out = self.buf(name + f".{Cc}.{rows}", rows, Cc)
-        # out[r, j] = src[r, map[j]] needs ONE source: assemble through a contiguous concat buffer first
-        cat = self.buf(f"tmp.cat.{Cc}.{rows}", rows, Cc)
-        ca = a.shape[1]
-        L.channel_gather(a, self._cmap(("lo", ca, bf), list(range(bf))), cat, rows, ca, bf, Cc, 0, dt)
-        L.channel_gather(b, self._cmap(("id", bf), list(range(bf))), cat, rows, bf, bf, Cc, bf, dt)
-        shuf = [(j % 2) * bf + j // 2 for j in range(Cc)]
-        L.channel_gather(cat, self._cmap(("shuf", Cc), shuf), out, rows, Cc, Cc, Cc, 0, dt)
+        L.channel_interleave2(a, a.shape[1], b, out, rows, bf, self.cdt)
         return out
 
-    def _shuffle_cat_bwd(self, dout, rows, Cc, gp="g"):
-        """inverse of _shuffle_cat: returns (d first half [rows, bf], d second half [rows, bf])."""
-        dt = self.cdt
+    def _shuffle_cat_bwd(self, dout, rows, Cc, gp="g", d1_into=None):
+        """inverse of _shuffle_cat in one launch: returns (d first half, d second half [rows, bf]).  d1_into: a [rows, Cc] buffer whose
+        first bf columns receive the first half (the stride-1 unit: that IS the first half of its input gradient)."""
         bf = Cc // 2
-        d1, d2 = self.buf(f"{gp}.sh1.{bf}.{rows}", rows, bf), self.buf(f"{gp}.sh2.{bf}.{rows}", rows, bf)
-        L.channel_gather(dout, self._cmap(("unshuf_a", Cc), [2 * j for j in range(bf)]), d1, rows, Cc, bf, bf, 0, dt)
-        L.channel_gather(dout, self._cmap(("unshuf_b", Cc), [2 * j + 1 for j in range(bf)]), d2, rows, Cc, bf, bf, 0, dt)
+        d2 = self.buf(f"{gp}.sh2.{bf}.{rows}", rows, bf)
+        if d1_into is not None:
+            L.channel_deinterleave2(dout, d1_into, Cc, d2, rows, bf, self.cdt)
+            return None, d2
+        d1 = self.buf(f"{gp}.sh1.{bf}.{rows}", rows, bf)
+        L.channel_deinterleave2(dout, d1, bf, d2, rows, bf, self.cdt)
         return d1, d2
 
     def backward(self, dfeat):
@@ -683,11 +679,10 @@ class ConvEncoder:
                 Cc = blk["cout"]
                 bf = Cc // 2
                 rows = B * bs["H"] * bs["W"]
-                d1, d2 = self._shuffle_cat_bwd(dx, rows, Cc, gp)
+                out = self.buf(f"{gp}.cat.{Cc}.{rows}", rows, Cc)                 # the unit's input gradient = [d x1 | d x2]
+                _, d2 = self._shuffle_cat_bwd(dx, rows, Cc, gp, d1_into=out)           # x1 passed straight through: its gradient lands in place
                 for ui in reversed(range(len(blk["b2"]))):
                     d2 = self._unit_bwd(blk["b2"][ui], d2, bs["b2"][ui], B, tag=f"{gp}.c{ui}")
-                out = self.buf(f"{gp}.cat.{Cc}.{rows}", rows, Cc)
-                L.channel_gather(d1, self._cmap(("id", bf), list(range(bf))), out, rows, bf, bf, Cc, 0, dt)
                 L.channel_gather(d2, self._cmap(("id", bf), list(range(bf))), out, rows, bf, bf, Cc, bf, dt)
                 dx = out
             if bi == 0 or self.blocks[bi - 1]["stage"] != blk["stage"]:

@@ -2296,6 +2296,44 @@ __global__ void channel_gather_k(const T* __restrict__ in, const int* __restrict
   const int64_t r = idx / Cout;
   out[r * ld_out + col0 + j] = in[r * Cin + map[j]];
 }
+// torch channel_shuffle(cat(a', b), groups = 2) of ShuffleNetV2 in ONE launch (it was three gathers through a concat buffer):
+// out[r, 2j] = a[r, j], out[r, 2j + 1] = b[r, j], j in [0, bf); a has row pitch lda (its first bf columns are used), b and out are contiguous
+template <typename T>
+__global__ void channel_interleave2_k(const T* __restrict__ a, int64_t lda, const T* __restrict__ b, T* __restrict__ out, int64_t n, int bf) {
+  const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= n) return;
+  const int c = (int)(idx % (2 * bf));
+  const int64_t r = idx / (2 * bf);
+  out[idx] = (c & 1) ? b[r * bf + (c >> 1)] : a[r * lda + (c >> 1)];
+}
+// its backward in one launch (it was two gathers): d_even[r, j] = dout[r, 2j] (row pitch ld_even: the caller may aim it at the first half of
+// the concatenated input gradient), d_odd[r, j] = dout[r, 2j + 1] (contiguous)
+template <typename T>
+__global__ void channel_deinterleave2_k(const T* __restrict__ dout, T* __restrict__ d_even, int64_t ld_even, T* __restrict__ d_odd, int64_t n, int bf) {
+  const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= n) return;
+  const int c = (int)(idx % (2 * bf));
+  const int64_t r = idx / (2 * bf);
+  const T v = dout[idx];
+  if (c & 1) d_odd[r * bf + (c >> 1)] = v; else d_even[r * ld_even + (c >> 1)] = v;
+}
+extern "C" int mmrca_channel_interleave2(const void* a, int64_t lda, const void* b, void* out, int64_t rows, int bf, int dtype, void* stream) {
+  MMRCA_REQUIRE(a && b && out && rows > 0 && bf > 0 && lda >= bf, "channel_interleave2: bad arguments");
+  const int64_t n = rows * 2 * bf;
+  MMRCA_DISPATCH_DTYPE(dtype, "channel_interleave2",
+    hipLaunchKernelGGL(channel_interleave2_k<T>, dim3(blocks_for(n, 256)), dim3(256), 0, (hipStream_t)stream, (const T*)a, lda, (const T*)b, (T*)out, n, bf);)
+  MMRCA_CHECK_LAUNCH("channel_interleave2");
+  return 0;
+}
+extern "C" int mmrca_channel_deinterleave2(const void* dout, void* d_even, int64_t ld_even, void* d_odd, int64_t rows, int bf, int dtype, void* stream) {
+  MMRCA_REQUIRE(dout && d_even && d_odd && rows > 0 && bf > 0 && ld_even >= bf, "channel_deinterleave2: bad arguments");
+  const int64_t n = rows * 2 * bf;
+  MMRCA_DISPATCH_DTYPE(dtype, "channel_deinterleave2",
+    hipLaunchKernelGGL(channel_deinterleave2_k<T>, dim3(blocks_for(n, 256)), dim3(256), 0, (hipStream_t)stream, (const T*)dout, (T*)d_even, ld_even,
+                       (T*)d_odd, n, bf);)
+  MMRCA_CHECK_LAUNCH("channel_deinterleave2");
+  return 0;
+}
 /* out[r, col0 + j] = in[r, map[j]], j in [0, Cout): in is [rows, Cin] contiguous, out has leading dimension ld_out */
 extern "C" int mmrca_channel_gather(const void* in, const int* map, void* out, int64_t rows, int Cin, int Cout, int64_t ld_out, int col0,
                                     int dtype, void* stream) {

@@ -88,6 +88,8 @@ _SIGS = {
     "mmrca_maxpool3x3s2_fwd": [_vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _vp],
     "mmrca_maxpool3x3s2_bwd": [_vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _vp],
     "mmrca_channel_gather": [_vp, _vp, _vp, _i64, _i32, _i32, _i64, _i32, _i32, _vp],
+    "mmrca_channel_interleave2": [_vp, _i64, _vp, _vp, _i64, _i32, _i32, _vp],
+    "mmrca_channel_deinterleave2": [_vp, _vp, _i64, _vp, _i64, _i32, _i32, _vp],
     "mmrca_image_preprocess": [_vp, _vp, _vp, _i32, _i32, _i32, _vp, _vp, _vp],
     "mmrca_image_rotate_crop": [_vp, _vp, _i32, _i32, _vp],
     "mmrca_image_resize_u8": [_vp, _vp, _vp, _i32, _i32, _i32, _vp],
@@ -568,6 +570,8 @@ _CONV_BYTES = {
     "mmrca_conv3x3_fwd": ("conv3x3 implicit GEMM", lambda a: (a[6] * a[7] * a[8] * (a[9] + a[10]) + 9 * a[9] * a[10]) * _esz(a[11])),
     "mmrca_conv3x3_wgrad": ("conv3x3 implicit GEMM", lambda a: a[3] * a[4] * a[5] * (a[6] + a[7]) * _esz(a[8]) + 9 * a[6] * a[7] * 4),
     "mmrca_gemm_bnstats": ("GEMM (1x1 / patch)", lambda a: (a[3] * a[5] + a[4] * a[5] + a[3] * a[4]) * _esz(a[9])),
+    "mmrca_channel_interleave2": ("layout", lambda a: 2 * a[4] * 2 * a[5] * _esz(a[6])),
+    "mmrca_channel_deinterleave2": ("layout", lambda a: 2 * a[4] * 2 * a[5] * _esz(a[6])),
     "mmrca_bn_stats": ("BatchNorm", lambda a: a[5] * a[6] * _esz(a[11]) if a[10] else 0),
     "mmrca_bn_stats_ws": ("BatchNorm", lambda a: a[5] * a[6] * _esz(a[11]) if a[10] else 0),
     "mmrca_bn_act_fwd": ("BatchNorm", lambda a: 2 * a[6] * a[7] * _esz(a[9])),
@@ -747,6 +751,15 @@ def maxpool3x3s2_fwd(x, y, argmax, B, H, W, C, dtype):
 
 def maxpool3x3s2_bwd(dy, argmax, dx, B, H, W, C, dtype):
     _c("mmrca_maxpool3x3s2_bwd", ptr(dy), ptr(argmax), ptr(dx), B, H, W, C, dtype)
+
+
+def channel_interleave2(a, lda, b, out, rows, bf, dtype):
+    """out[r, 2j] = a[r, j], out[r, 2j + 1] = b[r, j]: ShuffleNetV2's concat + channel shuffle"""
+    _c("mmrca_channel_interleave2", ptr(a), lda, ptr(b), ptr(out), rows, bf, dtype)
+
+
+def channel_deinterleave2(dout, d_even, ld_even, d_odd, rows, bf, dtype):
+    _c("mmrca_channel_deinterleave2", ptr(dout), ptr(d_even), ld_even, ptr(d_odd), rows, bf, dtype)
 
 
 def channel_gather(inp, cmap, out, rows, Cin, Cout, ld_out, col0, dtype):

@@ -249,6 +249,11 @@ int mmrca_residual_add(const void* a, const void* branch, const float* rowscale,
 /* MaxPool2d(3, 2, 1) with the argmax tap (uint8) kept for the backward */
 int mmrca_maxpool3x3s2_fwd(const void* x, void* y, void* argmax, int B, int H, int W, int C, int dtype, void* stream);
 int mmrca_maxpool3x3s2_bwd(const void* dy, const void* argmax, void* dx, int B, int H, int W, int C, int dtype, void* stream);
+/* torch channel_shuffle(cat(a[:, :bf], b), groups = 2) (ShuffleNetV2: torchvision shufflenetv2.py channel_shuffle after the unit's concat) in
+ * one launch: out[r, 2j] = a[r, j], out[r, 2j + 1] = b[r, j]; a has row pitch lda.  And its backward: d_even[r, j] = dout[r, 2j] (row pitch
+ * ld_even), d_odd[r, j] = dout[r, 2j + 1]. */
+int mmrca_channel_interleave2(const void* a, int64_t lda, const void* b, void* out, int64_t rows, int bf, int dtype, void* stream);
+int mmrca_channel_deinterleave2(const void* dout, void* d_even, int64_t ld_even, void* d_odd, int64_t rows, int bf, int dtype, void* stream);
 /* out[r, col0 + j] = in[r, map[j]] (channel split / concat / shuffle and their backward) */
 int mmrca_channel_gather(const void* in, const int* map, void* out, int64_t rows, int Cin, int Cout, int64_t ld_out, int col0,
                          int dtype, void* stream);
