@@ -27,6 +27,9 @@ from . import lib as L
 # dense 3x3 convolutions on tap-major patches (see ConvEncoder._tap_major); "0" = torchvision's channel-major order everywhere
 TAP_MAJOR = os.environ.get("MMRCA_CONV_TAP_MAJOR", "1") == "1"
 PAD_TAP_K = os.environ.get("MMRCA_CONV_PAD_K", "1") == "1"
+# ShuffleNetV2 stride-1 units: branch2's first 1x1 convolution reads the second half of the unit's input in place and its input gradient is
+# written straight into the unit's input gradient (row pitch = the unit's channel count); "0" restores the split / concat copies
+SHUFFLE_INPLACE = os.environ.get("MMRCA_SHUFFLE_INPLACE", "1") == "1"
 # dense 3x3 / stride-1 convolutions as implicit GEMMs (csrc/conv_igemm.hip): no patch matrix, BatchNorm moments in the epilogue;
 # "0" keeps im2row + GEMM everywhere (the A/B switch of DESIGN 3d)
 IGEMM = os.environ.get("MMRCA_CONV_IGEMM", "1") == "1"
@@ -328,7 +331,7 @@ class ConvEncoder:
         wp[:, : 9 * u.cin].view(u.cout, 9, u.cin).copy_(wt)
         return wp
 
-    def _unit_fwd(self, u: _Unit, x, B, H, Wd, tag, train, save, res=None, rowscale=None, out=None):
+    def _unit_fwd(self, u: _Unit, x, B, H, Wd, tag, train, save, res=None, rowscale=None, out=None, ld_in=None):
         """x: rows [B*H*W, cin] -> y rows [B*Ho*Wo, cout]; returns (y, Ho, Wo, saved).  With `res` (the block input) the unit is
         the last one of a residual block and writes out = res + rowscale[sample] * y directly (mmrca_bn_act_fwd_res) when the
         fused kernel is built for the dtype; the caller checks `saved["fused_res"]`."""
@@ -349,7 +352,8 @@ class ConvEncoder:
                 L.gemm_bnstats(x, w, z, M=rows, N=u.cout, K=u.cin, lda=u.cin, ldb=u.cin, ldc=u.cout, dtype=dt,
                                shift=self.buffers[u.bn_key + ".running_mean"], s1=sums[0], s2=sums[1])
             else:
-                L.gemm(x, w, z, M=rows, N=u.cout, K=u.cin, lda=u.cin, ldb=u.cin, ldc=u.cout, dtype=dt, impl=self.o.gemm_impl)
+                # ld_in: x is a column window of a wider row buffer (ShuffleNetV2's second half, read in place instead of through a split copy)
+                L.gemm(x, w, z, M=rows, N=u.cout, K=u.cin, lda=(ld_in or u.cin), ldb=u.cin, ldc=u.cout, dtype=dt, impl=self.o.gemm_impl)
         elif self._igemm(u):
             ns = L.conv3x3_stat_slots(B, H, Wd)
             parts = None
@@ -386,9 +390,9 @@ class ConvEncoder:
         else:
             y = self.buf(tag + ".y", rows, u.cout)
             L.bn_act_fwd(z, mean, rstd, self.W(u.bn_key + ".weight"), self.W(u.bn_key + ".bias"), y, rows, u.cout, u.act, dt)
-        return y, Ho, Wo, dict(x=x, z=z, mean=mean, rstd=rstd, H=H, W=Wd, Ho=Ho, Wo=Wo, train=train, fused_res=fused_res)
+        return y, Ho, Wo, dict(x=x, z=z, mean=mean, rstd=rstd, H=H, W=Wd, Ho=Ho, Wo=Wo, train=train, fused_res=fused_res, ld_x=(ld_in or u.cin))
 
-    def _unit_bwd(self, u: _Unit, dy, sv, B, need_dx=True, tag="g", sums_ready=False):
+    def _unit_bwd(self, u: _Unit, dy, sv, B, need_dx=True, tag="g", sums_ready=False, dx_into=None):
         """dy: gradient at the unit's output rows; returns dx rows (or None).  sums_ready: the BatchNorm-backward sums of this unit are
         already in the shared scratch (the squeeze-excitation backward accumulated them while it wrote dy)."""
         dt = self.cdt
@@ -406,10 +410,13 @@ class ConvEncoder:
         if u.dw:
             L.dwconv3x3_bwd(dz, sv["x"], w, dx, gw, B, H, Wd, u.cin, u.stride, dt, ws=self.buf("tmp.dw.ws", 1, 16 << 20, torch.float32))
         elif u.k == 1:
-            L.gemm(dz, sv["x"], gw, M=u.cout, N=u.cin, K=rows_k, lda=u.cout, ldb=u.cin, ldc=u.cin, a_layout=L.KROW, b_layout=L.KROW,
+            L.gemm(dz, sv["x"], gw, M=u.cout, N=u.cin, K=rows_k, lda=u.cout, ldb=sv.get("ld_x", u.cin), ldc=u.cin, a_layout=L.KROW, b_layout=L.KROW,
                    accum=True, dtype=dt, impl=self.o.gemm_impl)
             if need_dx:
-                L.gemm(dz, w, dx, M=rows, N=u.cin, K=u.cout, lda=u.cout, ldb=u.cin, ldc=u.cin, a_layout=L.ROWK, b_layout=L.KROW, dtype=dt,
+                ldc = u.cin
+                if dx_into is not None:          # (view of a wider row buffer, its row pitch): the input gradient lands in its column window
+                    dx, ldc = dx_into
+                L.gemm(dz, w, dx, M=rows, N=u.cin, K=u.cout, lda=u.cout, ldb=u.cin, ldc=ldc, a_layout=L.ROWK, b_layout=L.KROW, dtype=dt,
                        impl=self.o.gemm_impl)
         elif self._igemm(u):
             K = 9 * u.cin
@@ -583,13 +590,18 @@ class ConvEncoder:
                 Cc = blk["cout"]
                 bf = Cc // 2
                 rows = B * h * w
-                x2 = self.buf(f"{tag}.x2", rows, bf)
-                L.channel_gather(x, self._cmap(("hi", Cc), list(range(bf, Cc))), x2, rows, Cc, bf, bf, 0, dt)
                 bs = dict(b2=[], H=h, W=w)
-                y2, h2, w2 = x2, h, w
+                inplace = SHUFFLE_INPLACE and blk["b2"][0].k == 1 and not blk["b2"][0].dw and not (train and FUSE_GEMM_BN)
+                if inplace:                      # branch2's first 1x1 convolution reads x[:, bf:] where it lies (row pitch Cc): no split copy
+                    y2, h2, w2 = x[:, bf:], h, w
+                else:
+                    x2 = self.buf(f"{tag}.x2", rows, bf)
+                    L.channel_gather(x, self._cmap(("hi", Cc), list(range(bf, Cc))), x2, rows, Cc, bf, bf, 0, dt)
+                    y2, h2, w2 = x2, h, w
                 for ui, u in enumerate(blk["b2"]):
-                    y2, h2, w2, sv = self._unit_fwd(u, y2, B, h2, w2, f"{tag}.c{ui}", train, save)
+                    y2, h2, w2, sv = self._unit_fwd(u, y2, B, h2, w2, f"{tag}.c{ui}", train, save, ld_in=(Cc if (inplace and ui == 0) else None))
                     bs["b2"].append(sv)
+                bs["inplace"] = inplace
                 x = self._shuffle_cat(x, y2, rows, Cc, f"{tag}.out", first_is_full=True)
             saved["blocks"].append(bs)
         y, h, w, saved["final"] = self._unit_fwd(self.final, x, B, h, w, "final", train, save)
@@ -682,8 +694,10 @@ class ConvEncoder:
                 out = self.buf(f"{gp}.cat.{Cc}.{rows}", rows, Cc)                 # the unit's input gradient = [d x1 | d x2]
                 _, d2 = self._shuffle_cat_bwd(dx, rows, Cc, gp, d1_into=out)           # x1 passed straight through: its gradient lands in place
                 for ui in reversed(range(len(blk["b2"]))):
-                    d2 = self._unit_bwd(blk["b2"][ui], d2, bs["b2"][ui], B, tag=f"{gp}.c{ui}")
-                L.channel_gather(d2, self._cmap(("id", bf), list(range(bf))), out, rows, bf, bf, Cc, bf, dt)
+                    into = (out[:, bf:], Cc) if (ui == 0 and bs.get("inplace")) else None      # the first unit's input gradient IS d x2
+                    d2 = self._unit_bwd(blk["b2"][ui], d2, bs["b2"][ui], B, tag=f"{gp}.c{ui}", dx_into=into)
+                if not bs.get("inplace"):
+                    L.channel_gather(d2, self._cmap(("id", bf), list(range(bf))), out, rows, bf, bf, Cc, bf, dt)
                 dx = out
             if bi == 0 or self.blocks[bi - 1]["stage"] != blk["stage"]:
                 ready("image_stage_" + blk["stage"])
