@@ -119,7 +119,7 @@ class GraphedTrainStep:
 
     def __init__(self, model, criterion: FusedCrossEntropy, optimizer=None, grad_sync=None, warmup: int = 2):
         self.model, self.criterion, self.optimizer, self.grad_sync, self.warmup = model, criterion, optimizer, grad_sync, int(warmup)
-        self._graphs, self._eager_left = {}, {}
+        self._graphs, self._eager_left, self._no_graph = {}, {}, set()
         self._epoch = torch.zeros(1, dtype=torch.int64, device=model.engine.device)
         self.replays = 0
         self._generation = getattr(model.engine, "buffer_generation", 0)
@@ -138,12 +138,23 @@ class GraphedTrainStep:
             self._eager_left.clear()
             self._generation = getattr(eng, "buffer_generation", 0)
         ent = self._graphs.get(key)
-        if ent is None and (self._eager() or self._eager_left.setdefault(key, self.warmup) > 0):
-            self._eager_left[key] = self._eager_left.get(key, self.warmup) - 1
+        if ent is None and key not in self._no_graph and not self._eager() and self._eager_left.setdefault(key, self.warmup) <= 0:
+            try:
+                ent = self._capture(key, ids, mask, images, labels, seed, tt, ti)
+                captured_now = True
+            except Exception as e:             # a step that cannot be captured keeps working, launched from Python
+                print(f"HIP graph capture failed for batch shape {key[0]} x {key[1]} ({type(e).__name__}: {str(e)[:200]}); this shape stays eager")
+                self._no_graph.add(key)
+                L.seed_epoch_set(0)
+        else:
+            captured_now = False
+        if ent is None:
+            if key in self._eager_left:
+                self._eager_left[key] -= 1
             loss = _enqueue_step(model, ids, mask, images, labels, self.criterion, self.grad_sync, do_step, None, seed, tt, ti)
         else:
-            if ent is None:
-                ent = self._capture(key, ids, mask, images, labels, seed, tt, ti)
+            if captured_now:
+                pass                           # (_capture cloned this call's inputs into the static buffers)
             else:
                 eng.refresh_working_copy()     # (a no-op unless parameters were loaded since the last step)
                 for dst, src in zip(ent["inputs"], (ids, mask, images, labels)):
