@@ -37,6 +37,7 @@ IGEMM = os.environ.get("MMRCA_CONV_IGEMM", "1") == "1"
 # configs[2] -- the separate moments pass reads z straight after the GEMM wrote it (Infinity-Cache hits, ~5 TB/s) and costs less than the
 # extra LDS reduction + barrier per 128x128 tile in the epilogue does.
 FUSE_GEMM_BN = os.environ.get("MMRCA_CONV_FUSE_GEMM_BN", "0") == "1"
+BN_FLAT = os.environ.get("MMRCA_BN_FLAT", "0") == "1"               # flat BatchNorm reductions (csrc/conv.hip, opt-in): need a 16 MiB workspace
 FUSE_SE = os.environ.get("MMRCA_CONV_FUSE_SE", "1") == "1"         # SE backward: dx and the next BatchNorm's backward sums in one pass
 FUSE_RES = os.environ.get("MMRCA_CONV_FUSE_RES", "1") == "1"       # residual connection inside the block's last BatchNorm pass
 IGEMM_DGRAD = os.environ.get("MMRCA_CONV_IGEMM_DGRAD", "1") == "1"
@@ -265,7 +266,9 @@ class ConvEncoder:
 
     def _bn_ws(self):
         """16 MiB of fp32 words for the flat BatchNorm reductions (one 64-byte record per streaming thread, csrc/conv.hip)"""
-        return self.buf("tmp.bnws", 4096, 1024, torch.float32) if self.cdtype == torch.bfloat16 else None
+        if not BN_FLAT or self.cdtype != torch.bfloat16:      # the flat reductions are opt-in (MMRCA_BN_FLAT=1): no workspace otherwise
+            return None
+        return self.buf("tmp.bnws", 4096, 1024, torch.float32)
 
     def release(self):
         self._bufs.clear()
@@ -515,8 +518,11 @@ class ConvEncoder:
         B, C, H, Wd = images.shape
         if C != 3:
             raise ValueError(f"images must be [B,3,H,W], got {tuple(images.shape)}")
-        if self._bn_arena is not None:
-            self._bn_arena.zero_()
+        # the statistics / backward sums of a pending forward(save=True) are views into the arena cleared below: that forward's
+        # backward() can no longer run (it fails loudly on saved = None instead of reading zeros)
+        self.saved = None
+        if self._bn_arena is not None and self._bn_used:
+            self._bn_arena[: self._bn_used].zero_()            # (the used prefix only: a few hundred KB of the 16 MiB)
         self._bn_bwd_seen.clear()
         x0 = self.buf("in.rows", B * H * Wd, 3)
         L.nchw_to_rows(images.to(torch.float32).contiguous(), x0, B, 3, H, Wd, dt)
@@ -538,15 +544,12 @@ class ConvEncoder:
                 self._sd_p = torch.tensor([self.blocks[i]["sd"] for i in sd_idx], dtype=torch.float32, device=self.o.device).view(-1, 1)
             p = self._sd_p
             if self.injected_keep is not None:
-                keep = self.injected_keep.to(self.o.device, torch.float32)
-            elif torch.cuda.is_current_stream_capturing():
-                # inside a HIP-graph capture (training.GraphedTrainStep): torch's default generator is graph-safe (its Philox offset
-                # advances per replay); a generator seeded here would be frozen into the graph with its one draw
-                keep = (torch.rand(len(sd_idx), B, device=self.o.device) >= p).float()
+                rowscale = (self.injected_keep.to(self.o.device, torch.float32) / (1.0 - p)).contiguous()
             else:
-                gen = torch.Generator(device=self.o.device).manual_seed(int(seed) & 0x7FFFFFFFFFFFFFFF)
-                keep = (torch.rand(len(sd_idx), B, device=self.o.device, generator=gen) >= p).float()
-            rowscale = (keep / (1.0 - p)).contiguous()
+                # counter-based draw from (step seed, mask epoch) like the dropout masks: a HIP-graph replay and the eager step of the
+                # same index keep the same blocks (--hip_graph does not change which masks a --seed run draws)
+                rowscale = self.buf("sd.rowscale", len(sd_idx), B, torch.float32)[: len(sd_idx)]
+                L.sd_rowscale(p, rowscale, len(sd_idx), B, self.o._site_seed(int(seed), 254, 0) if hasattr(self.o, "_site_seed") else int(seed))
         sd_pos = {i: j for j, i in enumerate(sd_idx)}
         if train:
             self.n_train_forwards += 1

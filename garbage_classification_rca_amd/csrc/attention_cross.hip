@@ -199,7 +199,7 @@ static int ax_launch_d(const void* q, int64_t ldq, const void* k, int64_t ldk, c
   constexpr int PITCH = 32 * DHS * 2 + 16;
   const int lds = 2 * NKT * 16 * PITCH + NKT * 16 * 4;
   const int nw = Sq > 64 ? 8 : 4;
-  (void)hipFuncSetAttribute((const void*)mha_cross_mfma_k<NKT, DHS, DROP>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+  MMRCA_MAX_LDS(lds, mha_cross_mfma_k<NKT, DHS, DROP>);
   hipLaunchKernelGGL((mha_cross_mfma_k<NKT, DHS, DROP>), dim3(B * H), dim3(64 * nw), lds, st, (const bf16_t*)q, ldq, (const bf16_t*)k, ldk,
                      (const bf16_t*)v, ldv, (bf16_t*)out, ldo, H, Sq, Skv, dh, scale, drop_p, seed);
   MMRCA_CHECK_LAUNCH("mha_cross_fwd(mfma)");

@@ -357,7 +357,7 @@ int mmrca_mha_fwd_f32m(const void* qkv, const int32_t* key_mask, void* out, floa
   const size_t lds = ((size_t)2 * nkt * 16 * 64 + nkt * 16) * sizeof(float);
 #define LF(NKT_, DROP_)                                                                                                            \
   do {                                                                                                                             \
-    (void)hipFuncSetAttribute((const void*)mha_fwd_f32m_k<NKT_, DROP_>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);     \
+    MMRCA_MAX_LDS((int)lds, mha_fwd_f32m_k<NKT_, DROP_>);     \
     hipLaunchKernelGGL((mha_fwd_f32m_k<NKT_, DROP_>), dim3(B * H), dim3(64 * (NKT_ < F32A_MAX_WAVES ? NKT_ : F32A_MAX_WAVES)), lds, st, \
                        (const float*)qkv, key_mask, (float*)out, lse, H, S, scale, drop_p, drop_seed, cu, (bf16_t*)out_hi,         \
                        (bf16_t*)out_lo, (const bf16_t*)qkv_lo);                                                                    \
@@ -380,8 +380,8 @@ int mmrca_mha_bwd_f32m(const void* qkv, const int32_t* key_mask, const void* out
   const size_t lds1 = ((size_t)2 * nkt * 16 * 64 + nkt * 16) * sizeof(float), lds2 = ((size_t)2 * nkt * 16 * 64 + 2 * nkt * 16) * sizeof(float);
 #define LB(DROP_)                                                                                                                  \
   do {                                                                                                                             \
-    (void)hipFuncSetAttribute((const void*)mha_bwd_dq_f32m_k<DROP_>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds1);       \
-    (void)hipFuncSetAttribute((const void*)mha_bwd_dkv_f32m_k<DROP_>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2);      \
+    MMRCA_MAX_LDS((int)lds1, mha_bwd_dq_f32m_k<DROP_>);       \
+    MMRCA_MAX_LDS((int)lds2, mha_bwd_dkv_f32m_k<DROP_>);      \
     hipLaunchKernelGGL((mha_bwd_dq_f32m_k<DROP_>), dim3(B * H), dim3(64 * nw), lds1, st, (const float*)qkv, key_mask, (const float*)out, \
                        (const float*)dout, lse, (float*)dqkv, H, S, nkt, scale, drop_p, drop_seed, cu);                            \
     hipLaunchKernelGGL((mha_bwd_dkv_f32m_k<DROP_>), dim3(B * H), dim3(64 * nw), lds2, st, (const float*)qkv, key_mask, (const float*)out, \

@@ -1212,7 +1212,7 @@ static int pick_nkt(int S) {
 #define K_DKV(N_, D_, W_) mha_bwd_dkv_mfma_k<N_, D_, W_>
 #define AT_LAUNCH1(KERNEL, NKT, DROP, NW, LDSBYTES, ...)                                                                        \
   do {                                                                                                                         \
-    (void)hipFuncSetAttribute((const void*)KERNEL(NKT, DROP, NW), hipFuncAttributeMaxDynamicSharedMemorySize, (int)(LDSBYTES)); \
+    MMRCA_MAX_LDS((int)(LDSBYTES), KERNEL(NKT, DROP, NW)); \
     hipLaunchKernelGGL((KERNEL(NKT, DROP, NW)), dim3(B * H), dim3(64 * NW), LDSBYTES, st, __VA_ARGS__);                         \
   } while (0)
 // small S: 4 waves.  S > 128: 8 waves when the kernel fits 128 VGPRs without spilling (W8_PLAIN / W8_DROP, per kernel)
@@ -1633,7 +1633,7 @@ int mmrca_mha_fwd_mfma(const void* qkv, const int32_t* key_mask, void* out, floa
     if (ncu == 0) { int d = 0; (void)hipGetDevice(&d); if (hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, d) != hipSuccess || ncu < 1) ncu = 256; }
     const int ldsb = 4 * 14 * 16 * 128;
     const int nbh = B * H, grid = nbh < ncu ? nbh : ncu;
-    (void)hipFuncSetAttribute((const void*)mha_fwd_mfma_p_k<14, 16>, hipFuncAttributeMaxDynamicSharedMemorySize, ldsb);
+    MMRCA_MAX_LDS(ldsb, mha_fwd_mfma_p_k<14, 16>);
     hipLaunchKernelGGL((mha_fwd_mfma_p_k<14, 16>), dim3(grid), dim3(1024), ldsb, st, (const bf16_t*)qkv, (bf16_t*)out, lse, H, S, scale, nbh);
     MMRCA_CHECK_LAUNCH("mha_fwd(mfma,persistent)");
     return 0;
@@ -1641,7 +1641,7 @@ int mmrca_mha_fwd_mfma(const void* qkv, const int32_t* key_mask, void* out, floa
   static const int qt2 = getenv("MMRCA_ATTN_QT2") ? atoi(getenv("MMRCA_ATTN_QT2")) : 0;
   if (qt2 && nkt == 14 && drop_p <= 0.f) {        // two query tiles per wave (S in 193..224: the ViT's 197 tokens)
     const int ldsb = 2 * 14 * 16 * 128 + BIAS_EXTRA(14);
-    (void)hipFuncSetAttribute((const void*)mha_fwd_mfma_k<14, false, 8, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, ldsb);
+    MMRCA_MAX_LDS(ldsb, mha_fwd_mfma_k<14, false, 8, 2>);
     hipLaunchKernelGGL((mha_fwd_mfma_k<14, false, 8, 2>), dim3(B * H), dim3(512), ldsb, st, (const bf16_t*)qkv, key_mask, (bf16_t*)out, lse, H, S,
                        scale, drop_p, drop_seed, cu);
     MMRCA_CHECK_LAUNCH("mha_fwd(mfma,qt2)");
@@ -1662,7 +1662,7 @@ int mmrca_mha_fwd_x3_launch(const void* qkv_hi, const void* qkv_lo, const int32_
 #define LX3(NKT_, DROP_, NW_)                                                                                                      \
   do {                                                                                                                             \
     const int ldsb = 4 * NKT_ * 16 * 128 + BIAS_EXTRA(NKT_);                                                                       \
-    (void)hipFuncSetAttribute((const void*)mha_fwd_x3_k<NKT_, DROP_, NW_>, hipFuncAttributeMaxDynamicSharedMemorySize, ldsb);      \
+    MMRCA_MAX_LDS(ldsb, mha_fwd_x3_k<NKT_, DROP_, NW_>);      \
     hipLaunchKernelGGL((mha_fwd_x3_k<NKT_, DROP_, NW_>), dim3(B * H), dim3(64 * NW_), ldsb, st, (const bf16_t*)qkv_hi, (const bf16_t*)qkv_lo, key_mask, \
                        (bf16_t*)out_hi, (bf16_t*)out_lo, lse, H, S, scale, drop_p, drop_seed, cu);                                 \
   } while (0)
@@ -1707,7 +1707,7 @@ int mmrca_mha_bwd_mfma(const void* qkv, const int32_t* key_mask, const void* out
     const int nbh = B * H;
     const int grid = nbh < ncu_b ? nbh : ncu_b;
     const int ldp = 2 * 14 * 16 * 4 + 6 * 13 * 16 * 128 + 2048;
-    (void)hipFuncSetAttribute((const void*)mha_bwd_p_mfma_v_k<14, 8, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, ldp);
+    MMRCA_MAX_LDS(ldp, mha_bwd_p_mfma_v_k<14, 8, 2>);
     hipLaunchKernelGGL((mha_bwd_p_mfma_v_k<14, 8, 2>), dim3(grid), dim3(512), ldp, st, (const bf16_t*)qkv, (const bf16_t*)out, (const bf16_t*)dout, lse,
                        (bf16_t*)dqkv, H, S, scale, nbh);
     MMRCA_CHECK_LAUNCH("mha_bwd(mfma,persistent)");
@@ -1715,7 +1715,7 @@ int mmrca_mha_bwd_mfma(const void* qkv, const int32_t* key_mask, const void* out
   }
   if (use_v && (bwd_fused == 1 || bwd_fused == 3)) {     // one launch, two workgroups per CU: the Q | dO and K | V images time-share 56 KiB
     const int ldf = 2 * 14 * 16 * 128 + STAT_EXTRA(14);
-    (void)hipFuncSetAttribute((const void*)mha_bwd_fused_mfma_v_k<14, 8, true>, hipFuncAttributeMaxDynamicSharedMemorySize, ldf);
+    MMRCA_MAX_LDS(ldf, mha_bwd_fused_mfma_v_k<14, 8, true>);
     hipLaunchKernelGGL((mha_bwd_fused_mfma_v_k<14, 8, true>), dim3(B * H), dim3(512), ldf, st, (const bf16_t*)qkv, (const bf16_t*)out, (const bf16_t*)dout, lse,
                        (bf16_t*)dqkv, H, S, scale, g_attn_stamps, bwd_prefetch);
     MMRCA_CHECK_LAUNCH("mha_bwd(mfma,fused)");
@@ -1723,7 +1723,7 @@ int mmrca_mha_bwd_mfma(const void* qkv, const int32_t* key_mask, const void* out
   }
   if (use_v && bwd_fused == 2) {     // one launch, one 16-wave workgroup per CU: all four operand images staged once per (b, h)
     const int ldf = 4 * 14 * 16 * 128 + STAT_EXTRA(14);
-    (void)hipFuncSetAttribute((const void*)mha_bwd_fused_mfma_v_k<14, 16, false>, hipFuncAttributeMaxDynamicSharedMemorySize, ldf);
+    MMRCA_MAX_LDS(ldf, mha_bwd_fused_mfma_v_k<14, 16, false>);
     hipLaunchKernelGGL((mha_bwd_fused_mfma_v_k<14, 16, false>), dim3(B * H), dim3(1024), ldf, st, (const bf16_t*)qkv, (const bf16_t*)out, (const bf16_t*)dout, lse,
                        (bf16_t*)dqkv, H, S, scale, g_attn_stamps, bwd_prefetch);
     MMRCA_CHECK_LAUNCH("mha_bwd(mfma,fused16)");
@@ -1731,10 +1731,10 @@ int mmrca_mha_bwd_mfma(const void* qkv, const int32_t* key_mask, const void* out
   }
   if (use_v) {
     const int ldq = 2 * 14 * 16 * 128, ldkv = 2 * 14 * 16 * 128 + STAT_EXTRA(14);
-    (void)hipFuncSetAttribute((const void*)mha_bwd_dq_mfma_v_k<14, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, ldq);
+    MMRCA_MAX_LDS(ldq, mha_bwd_dq_mfma_v_k<14, 8>);
     hipLaunchKernelGGL((mha_bwd_dq_mfma_v_k<14, 8>), dim3(B * H), dim3(512), ldq, st, (const bf16_t*)qkv, (const bf16_t*)out, (const bf16_t*)dout, lse,
                        (bf16_t*)dqkv, H, S, scale);
-    (void)hipFuncSetAttribute((const void*)mha_bwd_dkv_mfma_v_k<14, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, ldkv);
+    MMRCA_MAX_LDS(ldkv, mha_bwd_dkv_mfma_v_k<14, 8>);
     hipLaunchKernelGGL((mha_bwd_dkv_mfma_v_k<14, 8>), dim3(B * H), dim3(512), ldkv, st, (const bf16_t*)qkv, (const bf16_t*)out, (const bf16_t*)dout, lse,
                        (bf16_t*)dqkv, H, S, scale);
     MMRCA_CHECK_LAUNCH("mha_bwd(mfma,v)");

@@ -367,7 +367,7 @@ int mmrca_mha_fwd_ref(const void* qkv, const int32_t* key_mask, void* out, float
   const size_t ldsl = atl_bytes(S, dh, ATT_MAX_DH + S, 0);
   if (g_att_lds && ldsl <= 160 * 1024) {
     MMRCA_DISPATCH_DTYPE(dtype, "mha_fwd",
-      (void)hipFuncSetAttribute((const void*)mha_fwd_lds_k<T>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsl);
+      MMRCA_MAX_LDS((int)ldsl, mha_fwd_lds_k<T>);
       hipLaunchKernelGGL(mha_fwd_lds_k<T>, dim3(B * H), dim3(64 * ATL_WAVES), ldsl, st, (const T*)qkv, key_mask, (T*)out, lse, B, H, S, dh, scale, drop_p, drop_seed, cu);)
     MMRCA_CHECK_LAUNCH("mha_fwd(lds)");
     return 0;
@@ -387,8 +387,8 @@ int mmrca_mha_bwd_ref(const void* qkv, const int32_t* key_mask, const void* out,
   const size_t ll1 = atl_bytes(S, dh, 2 * ATT_MAX_DH + S, 0), ll2 = atl_bytes(S, dh, 2 * ATT_MAX_DH + 2 * S, S);
   if (g_att_lds && ll1 <= 160 * 1024 && ll2 <= 160 * 1024) {
     MMRCA_DISPATCH_DTYPE(dtype, "mha_bwd",
-      (void)hipFuncSetAttribute((const void*)mha_bwd_dq_lds_k<T>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ll1);
-      (void)hipFuncSetAttribute((const void*)mha_bwd_dkv_lds_k<T>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ll2);
+      MMRCA_MAX_LDS((int)ll1, mha_bwd_dq_lds_k<T>);
+      MMRCA_MAX_LDS((int)ll2, mha_bwd_dkv_lds_k<T>);
       hipLaunchKernelGGL(mha_bwd_dq_lds_k<T>, dim3(B * H), dim3(64 * ATL_WAVES), ll1, st, (const T*)qkv, key_mask, (const T*)out, (const T*)dout, lse, (T*)dqkv, B, H, S, dh, scale, drop_p, drop_seed, cu);
       hipLaunchKernelGGL(mha_bwd_dkv_lds_k<T>, dim3(B * H), dim3(64 * ATL_WAVES), ll2, st, (const T*)qkv, key_mask, (const T*)out, (const T*)dout, lse, (T*)dqkv, B, H, S, dh, scale, drop_p, drop_seed, cu);)
     MMRCA_CHECK_LAUNCH("mha_bwd(lds)");

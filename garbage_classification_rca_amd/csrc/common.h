@@ -61,6 +61,23 @@ __device__ __forceinline__ float wave_max(float x) {
   return x;
 }
 
+// Largest dynamic-LDS size a kernel may be launched with (hipFuncAttributeMaxDynamicSharedMemorySize).  The attribute is sticky per
+// (kernel, device): it is raised when a launch needs more than any launch before it did, not re-issued in front of every launch
+// (the step is ~500 launches; the driver call costs about as much as the launch itself).  One cache per expansion site = per kernel
+// instantiation; a racing first call from two host threads sets the same value twice, which is harmless.
+struct MmrcaLdsAttr { int v[64]; };
+static inline void mmrca_max_lds(const void* fn, int bytes, MmrcaLdsAttr& c) {
+  int dev = 0;
+  (void)hipGetDevice(&dev);
+  int& have = c.v[dev & 63];
+  if (bytes > have && hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, bytes) == hipSuccess) have = bytes;
+}
+#define MMRCA_MAX_LDS(bytes, ...) /* (bytes, kernel): the kernel last, it may be a template-id with commas */ \
+  do {                                                                           \
+    static MmrcaLdsAttr mmrca_lds_attr_;                                         \
+    mmrca_max_lds((const void*)(__VA_ARGS__), (int)(bytes), mmrca_lds_attr_);    \
+  } while (0)
+
 // Step epoch of the counter-based masks.  Every launch carries its mask seed BY VALUE, so a launch captured in a HIP graph
 // (training.GraphedTrainStep) would redraw the captured step's masks at every replay.  The hash therefore runs on
 // seed + epoch * MMRCA_SEED_EPOCH_STRIDE, where the epoch is a device-side word that one node at the head of the graph refreshes

@@ -1353,8 +1353,13 @@ bn_flat_reduce_k(const float* __restrict__ ws, int lanes, int C8, float* __restr
 // plan of a flat pass: T threads (a multiple of C/8), or 0 when the tensor is too small / not eligible / the workspace is missing
 // In situ (configs[2], B = 128) the flat backward reduce measured 607 samples/s against 612 without it: its dy operand was written by the
 // launch before and the slice form finds more of it in the caches, and the second launch costs what the faster stream gains on the many
-// mid-sized layers.  OFF by default (MMRCA_BN_FLAT=1 turns it on; read per call: the tests switch it).
-static bool bn_flat_on() { const char* e = getenv("MMRCA_BN_FLAT"); return e && atoi(e) == 1; }
+// mid-sized layers.  OFF by default.  The switch is read from the environment ONCE (MMRCA_BN_FLAT=1: both backward-sum and statistics
+// reductions eligible; MMRCA_BN_FLAT_MOMENTS=1: the one-pass moments too) -- BatchNorm launches sit in the launch-bound small-batch
+// path, a getenv per launch does not belong there -- and mmrca_bn_flat_set() lets the tests flip it at run time.
+static int g_bn_flat = ((getenv("MMRCA_BN_FLAT") && atoi(getenv("MMRCA_BN_FLAT")) == 1) ? 1 : 0) |
+                       ((getenv("MMRCA_BN_FLAT_MOMENTS") && atoi(getenv("MMRCA_BN_FLAT_MOMENTS")) == 1) ? 2 : 0);
+extern "C" int mmrca_bn_flat_set(int mode) { g_bn_flat = mode & 3; return 0; }
+static bool bn_flat_on() { return (g_bn_flat & 1) != 0; }
 static const int64_t g_bn_flat_threads = getenv("MMRCA_BN_FLAT_THREADS") ? atoll(getenv("MMRCA_BN_FLAT_THREADS")) : 262144;
 static int64_t bn_flat_threads(int64_t rows, int C, int64_t ld, int dtype, const void* a, const void* b, const void* ws, int64_t ws_bytes) {
   if (!bn_flat_on() || !ws || dtype != MMRCA_BF16 || C % 8 || ld != C || ((((uintptr_t)a) | ((uintptr_t)b) | ((uintptr_t)ws)) & 15)) return 0;
@@ -1487,8 +1492,7 @@ static int bn_stats_impl(const void* x, float* mean, float* rstd, float* running
     if (g_bn_one_pass) {
       // flat form of the moments: measured 94 + 9 us against 100 us for the slice form on a 354 MB tensor -- both sit at the ~4 TB/s that a
       // READ-ONLY pass reaches on this part (see bn_flat_threads) and the flat one pays a second launch: off unless MMRCA_BN_FLAT_MOMENTS=1
-      const char* fm = getenv("MMRCA_BN_FLAT_MOMENTS");            // (read per call: the tests switch it)
-      const bool flat_moments = fm && atoi(fm) == 1;
+      const bool flat_moments = (g_bn_flat & 2) != 0;
       const int64_t T = flat_moments ? bn_flat_threads(rows, C, ld, dtype, x, x, ws, ws_bytes) : 0;
       if (T) {
         hipLaunchKernelGGL(col_moment2_flat_k, dim3(blocks_for(T, 256)), dim3(256), 0, st, (const bf16_t*)x, (float*)ws, rows, C / 8, T);

@@ -386,7 +386,7 @@ extern "C" int mmrca_conv3x3_fwd(const void* x, const void* w_tap, void* z, floa
   hipStream_t st = (hipStream_t)stream;
 #define CONV_LAUNCH(NJ_, ST_)                                                                                                       \
   do {                                                                                                                              \
-    (void)hipFuncSetAttribute((const void*)conv3x3_igemm_k<NJ_, ST_>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);             \
+    MMRCA_MAX_LDS(lds, conv3x3_igemm_k<NJ_, ST_>);             \
     hipLaunchKernelGGL((conv3x3_igemm_k<NJ_, ST_>), dim3((unsigned)nblk), dim3(256), lds, st, (const bf16_t*)x, (const bf16_t*)w_tap, \
                        (bf16_t*)z, part_mean, part_m2, part_cnt, gm);                                                               \
   } while (0)

@@ -1246,7 +1246,7 @@ template <bool AK, bool BK2, bool AT, bool DB>
 static void launch_mfma(const void* A, const void* B, void* C, const void* bias, const void* addend, void* preact,
                         int64_t M, int64_t N, int64_t K, int64_t lda, int64_t ldb, int64_t ldc, int act, int tiles_m,
                         int tiles_n, int ksplits, int64_t ksplit_len, float* dbias, hipStream_t st) {
-  (void)hipFuncSetAttribute((const void*)gemm_mfma_k<AK, BK2, AT, DB>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS128_BYTES);
+  MMRCA_MAX_LDS(LDS128_BYTES, gemm_mfma_k<AK, BK2, AT, DB>);
   hipLaunchKernelGGL((gemm_mfma_k<AK, BK2, AT, DB>), dim3(tiles_m * tiles_n, ksplits), dim3(256), LDS128_BYTES, st,
                      (const bf16_t*)A, (const bf16_t*)B, C, (const bf16_t*)bias, (const bf16_t*)addend, (bf16_t*)preact,
                      M, N, K, lda, ldb, ldc, act, tiles_m, tiles_n, ksplit_len, dbias);

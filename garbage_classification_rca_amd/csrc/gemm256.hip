@@ -710,7 +710,7 @@ static void launch_p256(const void* A, const void* B, void* C, const void* bias,
   int grid = tiles_m * tiles_n < g_num_cus ? ((tiles_m * tiles_n) & ~7) : g_num_cus;
   if (grid < 8) grid = 8;
   constexpr int LDS_P = 2 * STAGE_BYTES + 32768;       // all 160 KiB of the CU
-  (void)hipFuncSetAttribute((const void*)gemm_p256_k<AK, BK2, ACT, ADD, X3, PLANES, F4>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_P);
+  MMRCA_MAX_LDS(LDS_P, gemm_p256_k<AK, BK2, ACT, ADD, X3, PLANES, F4>);
   hipLaunchKernelGGL((gemm_p256_k<AK, BK2, ACT, ADD, X3, PLANES, F4>), dim3(grid), dim3(512), LDS_P, st, (const bf16_t*)A, (const bf16_t*)B,
                      (bf16_t*)C, (const bf16_t*)bias, (const bf16_t*)addend, (bf16_t*)preact, M, N, K, lda, ldb, ldc, tiles_m,
                      tiles_n, colsum, tiles_m * tiles_n >= 2 * g_num_cus ? g_p256_skew : 0, g_mmrca_dbg, (const bf16_t*)A_lo,
@@ -848,7 +848,7 @@ static int gemm_splitk_impl(const void* A, const void* A_lo, const void* B, cons
   const bool ak = a_layout == MMRCA_KROW, bk = b_layout == MMRCA_KROW;
 #define LSLAB(AK_, BK_, X3_)                                                                                                     \
   do {                                                                                                                           \
-    (void)hipFuncSetAttribute((const void*)gemm_mfma256_k<AK_, BK_, MODE_SLAB, X3_>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS256_BYTES); \
+    MMRCA_MAX_LDS(LDS256_BYTES, gemm_mfma256_k<AK_, BK_, MODE_SLAB, X3_>); \
     hipLaunchKernelGGL((gemm_mfma256_k<AK_, BK_, MODE_SLAB, X3_>), dim3((tiles * splits + 7) / 8 * 8), dim3(512), LDS256_BYTES, st, (const bf16_t*)A,      \
                        (const bf16_t*)B, (bf16_t*)nullptr, (const bf16_t*)nullptr, (const bf16_t*)nullptr, (bf16_t*)nullptr, M, N, K, \
                        lda, ldb, ldc, tiles_m, tiles_n, ksteps_base, ksteps_rem, (float*)workspace, (float*)nullptr, splits,    \

@@ -752,7 +752,7 @@ extern "C" int mmrca_head_fwd(const void* img, const void* txt, const MmrcaHeadW
   const size_t lds = (size_t)L.total * 4;
   MMRCA_REQUIRE(lds <= 160 * 1024, "head_fwd: LDS budget exceeded");
   MMRCA_DISPATCH_DTYPE(dtype, "head_fwd",
-    hipFuncSetAttribute((const void*)head_fwd_k<T>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    MMRCA_MAX_LDS((int)lds, head_fwd_k<T>);
     hipLaunchKernelGGL(head_fwd_k<T>, dim3(B), dim3(HEAD_THREADS), lds, (hipStream_t)stream, (const T*)img, (const T*)txt, *w, logits, d, L,
                        drop_p, seed);)
   MMRCA_CHECK_LAUNCH("head_fwd");
@@ -784,7 +784,7 @@ extern "C" int mmrca_head_bwd(const float* dlogits, const void* img, const void*
   MMRCA_REQUIRE(lds <= 160 * 1024, "head_bwd: LDS budget exceeded");
   const HeadScratch sc = carve_scratch((float*)workspace, B, d);
   MMRCA_DISPATCH_DTYPE(dtype, "head_bwd",
-    hipFuncSetAttribute((const void*)head_bwd_k<T>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    MMRCA_MAX_LDS((int)lds, head_bwd_k<T>);
     hipLaunchKernelGGL(head_bwd_k<T>, dim3(B), dim3(HEAD_THREADS), lds, (hipStream_t)stream, dlogits, (const T*)img, (const T*)txt, *w, *g,
                        (T*)dimg, (T*)dtxt, d, L, sc, drop_p, seed);)
   MMRCA_CHECK_LAUNCH("head_bwd");
@@ -815,7 +815,7 @@ extern "C" int mmrca_head_bwd(const float* dlogits, const void* img, const void*
   const int fin_blocks = p.fin_colblocks * ((B + FIN_CHUNK - 1) / FIN_CHUNK);
   const int grid = p.n_blocks * p.ksplit + fin_blocks;
   if (head_stop >= 100) return 0;
-  hipFuncSetAttribute((const void*)head_wgrad_k, hipFuncAttributeMaxDynamicSharedMemorySize, 65536);
+  MMRCA_MAX_LDS(65536, head_wgrad_k);
   hipLaunchKernelGGL(head_wgrad_k, dim3(grid), dim3(256), 65536, (hipStream_t)stream, p);
   MMRCA_CHECK_LAUNCH("head_wgrad");
   return 0;

@@ -1135,4 +1135,22 @@ extern "C" int mmrca_split_f32(const float* src, void* hi, void* lo, int64_t n, 
   return 0;
 }
 
+// Stochastic depth of the conv image encoders (torchvision StochasticDepth, mode "row", train only): out[i][b] = keep / (1 - p[i]) with
+// keep = uniform(seed; i * B + b) >= p[i].  A counter-based draw like every other mask of the step, so a HIP-graph replay (mask epoch,
+// common.h) and the eager step of the same index apply the SAME masks.
+__global__ void sd_rowscale_k(const float* __restrict__ p, float* __restrict__ out, int n, int B, uint64_t seed) {
+  const int t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= n * B) return;
+  const float pi = p[t / B];
+  out[t] = mmrca_uniform(seed, (uint64_t)t) >= pi ? 1.0f / (1.0f - pi) : 0.0f;
+}
+extern "C" int mmrca_sd_rowscale(const float* p, float* out, int n, int B, uint64_t seed, void* stream) {
+  MMRCA_REQUIRE(p && out, "sd_rowscale: null pointer");
+  MMRCA_REQUIRE(n >= 0 && B >= 0, "sd_rowscale: bad shape");
+  if (n == 0 || B == 0) return 0;
+  hipLaunchKernelGGL(sd_rowscale_k, dim3((n * B + 255) / 256), dim3(256), 0, (hipStream_t)stream, p, out, n, B, seed);
+  MMRCA_CHECK_LAUNCH("sd_rowscale");
+  return 0;
+}
+
 MMRCA_SEED_EPOCH_EXPORT(rowops)   // this translation unit's copy of the mask epoch (common.h)

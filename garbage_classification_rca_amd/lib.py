@@ -122,8 +122,9 @@ _SIGS = {
     "mmrca_adamw_step": [_vp] * 5 + [_i64] + [_f32] * 5 + [_i32, _f32, _vp],
     "mmrca_cast_f32_to_bf16": [_vp, _vp, _i64, _vp],
     "mmrca_seed_epoch_set": [_vp, _u64, _vp],
+    "mmrca_sd_rowscale": [_vp, _vp, _i32, _i32, _u64, _vp],
 }
-EXPORTS = sorted(list(_SIGS) + ["mmrca_last_error", "mmrca_version", "mmrca_debug_set", "mmrca_debug_attn_stamps", "mmrca_gemm_splitk_workspace_bytes",
+EXPORTS = sorted(list(_SIGS) + ["mmrca_last_error", "mmrca_version", "mmrca_debug_set", "mmrca_bn_flat_set", "mmrca_debug_attn_stamps", "mmrca_gemm_splitk_workspace_bytes",
                                   "mmrca_head_bwd_workspace_bytes", "mmrca_conv3x3_stat_slots", "mmrca_gemm_bnstats_slots"])
 
 
@@ -522,6 +523,14 @@ def seed_epoch_set(value: int = 0, device_value: Optional[torch.Tensor] = None):
             raise MmrcaError("seed_epoch_set: device_value must be an int64 tensor")
     _check(load().mmrca_seed_epoch_set(ptr(device_value), int(value) & 0xFFFFFFFFFFFFFFFF, stream_ptr()), "mmrca_seed_epoch_set")
     _seed_epoch = None if device_value is not None else int(value)
+
+
+def sd_rowscale(p: torch.Tensor, out: torch.Tensor, n: int, B: int, seed: int):
+    """stochastic-depth row scales of n residual blocks x B samples (include/mmrca.h): out = keep / (1 - p), fp32"""
+    _dev(p, "sd_rowscale"); _dev(out, "sd_rowscale")
+    if p.dtype != torch.float32 or out.dtype != torch.float32 or p.numel() < n or out.numel() < n * B:
+        raise MmrcaError("sd_rowscale: p [n] and out [n, B] must be fp32 tensors of at least those sizes")
+    _check(load().mmrca_sd_rowscale(ptr(p), ptr(out), int(n), int(B), int(seed) & 0xFFFFFFFFFFFFFFFF, stream_ptr()), "mmrca_sd_rowscale")
 
 
 def seed_epoch_host():

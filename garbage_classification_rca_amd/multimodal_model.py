@@ -8,10 +8,16 @@ attributes and the same ``state_dict()`` key names -- but the arithmetic runs in
 autograd node whose backward runs the HIP backward and accumulates into ``param.grad`` (views of the flat
 gradient arena).
 
-Differences from the reference, all additive:
-* ``image_model_name`` (11th argument; the reference ignores ``--image_model`` and hard-codes EfficientNetV2-M,
-  main_both.py:259).  HIP backbones today: ``transformer_B16`` and ``transformer_L16``.
-* ``dtype`` (torch.bfloat16 default; torch.float32 = parity mode).
+The reference's own ten-positional call (main_both.py:306-317) builds the reference's model here too: EfficientNetV2-M
+at 480 x 480 (multimodal_model.py:113-126, 188, 407-408) + the named text encoder, in the fastest compute mode whose
+logits stay within 1e-3 of the reference's fp32 arithmetic (``bf16x3f``).
+
+Differences from the reference, all additive keyword arguments:
+* ``image_model_name`` (11th argument, default ``"eff_v2_medium"`` = what the reference hard-codes whatever ``--image_model``
+  says, main_both.py:259).  HIP backbones: ``eff_v2_medium`` / ``EffNetv2-Medium``, ``eff_v2_large``, ``shuffle_net``
+  (conv, ``conv_engine.py``), ``transformer_B16``, ``transformer_L16`` (ViT, ``engine.py``).
+* ``dtype``: ``"bf16x3f"`` (default: three-pass split-bf16 forward, logits ~1e-5..5e-4 from fp32; bf16 backward) |
+  ``torch.bfloat16`` (fastest, logits ~1e-2 from fp32: opt-in) | ``"bf16x3"`` (fp32-grade gradients too) | ``torch.float32``.
 * train-mode dropout (head p=model_dropout; text encoder p=0.1 on embeddings / attention probabilities / FFN output)
   uses counter-based masks instead of torch's Philox stream: same distribution, different random bits.
 """
@@ -100,7 +106,7 @@ class EffV2MediumAndDistilbertGated(torch.nn.Module):
 
     def __init__(self, n_classes, drop_ratio, image_or_text_dropout_chance, img_prob_dropout, num_neurons_fc,
                  text_model_name, batch_size, reverse, features_only, cross_attention_only,
-                 image_model_name: str = "transformer_B16", dtype=torch.bfloat16,
+                 image_model_name: str = "eff_v2_medium", dtype="bf16x3f",
                  device="cuda", init_seed: int = 0, build_unused_parameters: bool = True, image_size: Optional[int] = None):
         super().__init__()
         self.text_model_name = text_model_name
@@ -119,6 +125,8 @@ class EffV2MediumAndDistilbertGated(torch.nn.Module):
         # input size: ViT 224 (fixed by its position table); the conv backbones take any size -- the reference feeds its
         # EfficientNetV2-M 480x480 (multimodal_model.py:407-408), BASELINE.json's synthetic workloads use 224x224
         self.image_size = 224 if image_model_name in S.VISION_SPECS else int(image_size or (480 if image_model_name in ("eff_v2_medium", "EffNetv2-Medium") else 224))
+        if isinstance(dtype, str) and dtype.lower() in ("bf16", "fp32", "f32"):
+            dtype = torch.bfloat16 if dtype.lower() == "bf16" else torch.float32
         self.engine = MMRCAEngine(text_model_name, image_model_name, n_classes, reverse, mode, dtype, device, image_size=self.image_size)
         self.engine.init_parameters(init_seed)
         self.drop_ratio = float(drop_ratio)

@@ -112,7 +112,7 @@ class GraphedTrainStep:
       * inputs -- copied into the static buffers the captured launches read;
       * modality dropout and the trainable flags -- decided on the host BEFORE the graph (a different flag set is a different graph);
       * the optimizer -- stays outside (2-4 launches): learning-rate schedules and AdamW's step count are host values;
-      * stochastic depth (EfficientNetV2) -- drawn from torch's graph-safe default generator while capturing (conv_engine.forward).
+      * stochastic depth (EfficientNetV2) -- a counter-based draw of the step seed like the dropout masks (mmrca_sd_rowscale).
     Captions run in the padded layout (a packed layout changes launch shapes per batch).  The first `warmup` calls of a shape run
     eagerly (they allocate the engine's buffers), the next one captures.  With a multi-rank GradSync the step stays eager: the
     exchange is launched span by span from Python while the backward runs."""
@@ -142,7 +142,9 @@ class GraphedTrainStep:
             try:
                 ent = self._capture(key, ids, mask, images, labels, seed, tt, ti)
                 captured_now = True
-            except Exception as e:             # a step that cannot be captured keeps working, launched from Python
+            except L.MmrcaError:               # a kernel / argument error is an error, not a slowdown
+                raise
+            except RuntimeError as e:          # a step that cannot be captured keeps working, launched from Python
                 print(f"HIP graph capture failed for batch shape {key[0]} x {key[1]} ({type(e).__name__}: {str(e)[:200]}); this shape stays eager")
                 self._no_graph.add(key)
                 L.seed_epoch_set(0)
@@ -179,10 +181,33 @@ class GraphedTrainStep:
         inputs = [t.clone() for t in (ids, mask, images, labels)]
         torch.cuda.synchronize()
         g = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(g):
-            L.seed_epoch_set(device_value=self._epoch)
-            loss = _enqueue_step(model, inputs[0], inputs[1], inputs[2], inputs[3], self.criterion, None, True, None, seed, tt, ti)
-            L.seed_epoch_set(0)
+        # host-side state the captured (never executed) enqueue advances: restored if the capture fails, so that the eager step that
+        # follows starts from where this call started
+        conv = eng.conv
+        snap = dict(saved=eng._saved, bufs=set(eng._bufs), n_fwd=(conv.n_train_forwards if conv is not None else 0),
+                    conv_saved=(conv.saved if conv is not None else None), conv_bufs=(set(conv._bufs) if conv is not None else set()),
+                    no_arena=(conv is not None and conv._bn_arena is None))
+        try:
+            # thread_local: only THIS thread's HIP calls are illegal while capturing.  The DataLoader's pin-memory thread
+            # (main_both.py's loaders: num_workers 16, pin_memory) calls hipHostMalloc / event queries meanwhile; in the default
+            # "global" mode those would invalidate the capture or raise in that thread.  The engine launches from this thread only.
+            with torch.cuda.graph(g, capture_error_mode="thread_local"):
+                L.seed_epoch_set(device_value=self._epoch)
+                loss = _enqueue_step(model, inputs[0], inputs[1], inputs[2], inputs[3], self.criterion, None, True, None, seed, tt, ti)
+                L.seed_epoch_set(0)
+        except BaseException:
+            # buffers first created inside the dead capture were "zeroed" by a fill that never ran (padding rows are assumed zero by
+            # the Mk-rounded weight-gradient GEMMs): drop them, the eager step allocates them afresh
+            for k in set(eng._bufs) - snap["bufs"]:
+                del eng._bufs[k]
+            eng._saved = snap["saved"]
+            if conv is not None:
+                for k in set(conv._bufs) - snap["conv_bufs"]:
+                    del conv._bufs[k]
+                conv.n_train_forwards, conv.saved = snap["n_fwd"], snap["conv_saved"]
+                if snap["no_arena"]:           # (the BatchNorm arena itself was born in the dead capture)
+                    conv._bn_arena, conv._bn_off, conv._bn_used = None, {}, 0
+            raise
         print(f"HIP graph captured for the train step of batch shape {key[0]} x {key[1]} (trainable text / image encoder: {tt} / {ti})")
         ent = dict(graph=g, inputs=inputs, loss=loss, seed=seed, replayed=False)
         self._graphs[key] = ent

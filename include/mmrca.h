@@ -61,8 +61,16 @@ int mmrca_version(void);
  * call sets the epoch of all kernels from *device_value (read when the launch EXECUTES: captured once, it follows a counter in HBM
  * from replay to replay) or, with device_value == NULL, from `value`.  0 (the initial state) outside graph replays. */
 int mmrca_seed_epoch_set(const uint64_t* device_value, uint64_t value, void* stream);
+/* Stochastic depth of the conv image encoders (torchvision.ops.StochasticDepth(p, "row") inside efficientnet_v2_*'s blocks, which the
+ * reference builds at multimodal_model.py:113-126): out[i*B + b] = (u >= p[i]) / (1 - p[i]) for n residual blocks and B samples, u the
+ * counter-based uniform of (seed + epoch, i*B + b).  p, out: fp32 in HBM; p[i] < 1. */
+int mmrca_sd_rowscale(const float* p, float* out, int n, int B, uint64_t seed, void* stream);
 /* timing-only ablation switches for kernel development (0 = normal operation; results are WRONG otherwise) */
 int mmrca_debug_set(int flags);
+/* opt-in flat (streaming) forms of the BatchNorm column reductions: bit 0 = statistics / backward sums, bit 1 = one-pass moments.
+ * Initial value: MMRCA_BN_FLAT / MMRCA_BN_FLAT_MOMENTS read once at load; 0 (off) in production.  Needs the `ws` workspace of the
+ * mmrca_bn_*_ws entry points. */
+int mmrca_bn_flat_set(int mode);
 /* diagnostic: a device buffer of B*H*4 uint64 that the fused ViT attention backward fills with s_memtime stamps of its phases
  * (entry, staged, dQ done, exit; tools/attn_stamps.py); NULL (the default) = no stamps */
 int mmrca_debug_attn_stamps(void* buf);

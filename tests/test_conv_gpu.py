@@ -131,16 +131,23 @@ def test_batchnorm_act_fwd_bwd_and_running_stats(dt, act, train):
     assert rel(dx, x.grad) < tol and rel(dg, gam.grad) < tol and rel(db, bet.grad) < tol
 
 
+@pytest.fixture
+def bn_flat_on():
+    """both flat forms are opt-in (faster in isolation, no gain in the conv step): switched on for one test through the library's
+    run-time switch (the environment is read once at load)"""
+    L.load().mmrca_bn_flat_set(3)
+    yield
+    L.load().mmrca_bn_flat_set(0)
+
+
 @pytest.mark.parametrize("R,C", [(20000, 72), (9001, 384), (3000, 3840), (70000, 8)])
 @pytest.mark.parametrize("act", [L.CONV_NONE, L.CONV_SILU])
-def test_flat_streaming_batchnorm_reductions(R, C, act, monkeypatch):
+def test_flat_streaming_batchnorm_reductions(R, C, act, bn_flat_on):
     """mmrca_bn_stats_ws / mmrca_bn_act_bwd_ws: the flat form of the two column reductions (thread = fixed channel group, chunks t,
     t + T, ...; per-thread records in a workspace, second launch adds them) against torch.nn.functional.batch_norm and -- tightly --
     against the slice-per-workgroup kernels it replaces on large tensors (same fp32 sums in another order).  Odd row counts, the
     narrowest (8) and widest (3,840: EfficientNetV2-L's last expand) channel counts, a workspace too small for the default thread count."""
     eps, dt = 1e-3, torch.bfloat16
-    monkeypatch.setenv("MMRCA_BN_FLAT", "1")              # (both flat forms are opt-in: faster in isolation, no gain in the conv step)
-    monkeypatch.setenv("MMRCA_BN_FLAT_MOMENTS", "1")
     g = torch.Generator().manual_seed(R + C)
     x = (torch.randn(R, C, generator=g) * 1.5 + 0.7).to(dt).float().requires_grad_(True)
     gam = (torch.rand(C, generator=g) + 0.5).to(dt).float().requires_grad_(True)
@@ -523,6 +530,48 @@ def test_facade_state_dict_of_the_default_image_model_has_the_reference_layout_a
         out = m(_input_ids=ids.cuda(), _attention_mask=mask.cuda(), _images=images.cuda(), eval=True)
         ref = orc(ids, mask, images, eval=True)
     assert rel(out, ref) < 1e-3, rel(out, ref)
+    m.engine.release_buffers()
+
+
+def test_the_references_own_ten_argument_call_builds_the_references_model_within_tolerance():
+    """the reference constructs its model with ten positionals and nothing else (main_both.py:306-317).
+    That exact call must land on the reference's model -- EfficientNetV2-M at 480 x 480 (multimodal_model.py:113-126, 188,
+    257-258, 407-408; main_both.py:259) + DistilBERT -- carry the ``image_model.*`` key set of the reference's
+    ``EfficientNetV2MFullFeatureExtractor`` (:11-36), and compute logits within north_star's 1e-3 of the fp32 oracle in its
+    DEFAULT compute mode."""
+    from garbage_classification_rca_amd.multimodal_model import MM_RCA
+    from garbage_classification_rca_amd.procedural import synth_captions
+    m = MM_RCA(4, .6, 0., .7, 256, "distilbert", 16, True, False, False)
+    assert m.get_image_size() == (480, 480)
+    assert m.get_max_token_size() == 512
+    assert m.image_model_name == "eff_v2_medium" and m.engine.x3f and m.engine.d_img == 1280 and m.engine.d_txt == 768
+    assert (m.img_patch_size, m.txt_patch_size) == (80, 48)                       # multimodal_model.py:257-261
+    orc = O.build_oracle("distilbert", "eff_v2_medium", True, False, False, drop_ratio=0.6, enc_dropout=0.1).eval()
+    ref_img = {("image_model." + k): tuple(v.shape) for k, v in orc.image_model.state_dict().items()}
+    sd = {k: v.detach().cpu() for k, v in m.state_dict().items()}
+    own = {k: tuple(v.shape) for k, v in sd.items() if k.startswith("image_model.")}
+    assert own == ref_img, (sorted(set(own) ^ set(ref_img))[:10])
+    # frozen at construction, like the reference's backbones (:117-118, 132-133)
+    assert not any(p.requires_grad for p in m.text_model.parameters()) and not any(p.requires_grad for p in m.image_model.parameters())
+    orc.text_model.load_flat(sd, "text_model.")
+    orc.image_model.load_state_dict({k[len("image_model."):]: v for k, v in sd.items() if k.startswith("image_model.")})
+    orc.load_state_dict({k: v for k, v in sd.items() if not k.startswith(("text_model.", "image_model."))}, strict=False)
+    B = 4
+    ids, mask = (torch.from_numpy(a) for a in synth_captions(B, 64, seed=11))
+    images = torch.randn(B, 3, 480, 480, generator=torch.Generator().manual_seed(12))
+    m.eval()
+    with torch.no_grad():
+        out = m(ids.cuda(), mask.cuda(), images.cuda(), eval=True)
+        ref = orc(ids, mask, images, eval=True)
+    e = rel(out, ref)
+    print("ten-argument MM_RCA call, default mode: logits vs fp32 oracle", e)
+    assert out.shape == (B, 4) and e < 1e-3, e
+    # and the reference's training call on it (main_both.py:106-112): the head trains, the frozen backbones get no gradient
+    m.train()
+    loss = torch.nn.CrossEntropyLoss()(m(ids.cuda(), mask.cuda(), images.cuda()), torch.tensor([0, 1, 2, 3]).cuda())
+    loss.backward()
+    torch.cuda.synchronize()
+    assert torch.isfinite(loss) and float(m.final_with_everything.weight.grad.abs().max()) > 0
     m.engine.release_buffers()
 
 

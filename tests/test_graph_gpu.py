@@ -5,6 +5,7 @@ import contextlib
 import io
 
 import pytest
+import numpy as np
 import torch
 
 pytestmark = pytest.mark.gpu
@@ -68,13 +69,8 @@ def test_graphed_step_computes_the_eager_step(image_model, size, dtype):
     B, n = 4, 6
     data = _batches(n + 1, B, size)
     ma, mb, mc = (_model(image_model, B, size, dtype=dtype) for _ in range(3))
-    if image_model.startswith("eff_"):
-        # stochastic depth: the eager step seeds a generator per step, a captured step draws from torch's graph-safe default generator
-        # (conv_engine.forward) -- different bits by design, so the comparison pins the keep masks; the drawn form is run further down
-        for m in (ma, mb, mc):
-            conv = m.engine.conv
-            n_sd = sum(1 for b in conv.blocks if b.get("res") and b.get("sd", 0.0) > 0.0)
-            conv.injected_keep = (torch.rand(n_sd, B, generator=torch.Generator().manual_seed(5)) >= 0.2).float().cuda()
+    # (stochastic depth of the EfficientNetV2 blocks is drawn, not injected: its keep masks are counter-based draws of the step seed like
+    # the dropout masks -- round 5, mmrca_sd_rowscale -- so the replay of step s and the eager step s keep the same blocks)
     oa, ob, oc = (FlatSGD(m, lr=2e-3, weight_decay=1e-2) for m in (ma, mb, mc))
     crit = FusedCrossEntropy(None, 0.0)
     graphed = GraphedTrainStep(mb, crit, ob, warmup=2)
@@ -143,8 +139,9 @@ def test_frozen_masks_would_be_caught():
 
 
 def test_graphed_step_draws_stochastic_depth_inside_the_graph():
-    """EfficientNetV2 under capture: the keep masks come from torch's default generator, whose Philox offset a replay advances -- the
-    step captures, replays, and keeps producing finite, moving losses"""
+    """EfficientNetV2 under capture: the keep masks are drawn by a captured launch from (step seed, mask epoch) -- the step captures,
+    replays, and keeps producing finite, moving losses; and the masks of replay r are the masks the host mirror of the hash gives for
+    eager step r"""
     from garbage_classification_rca_amd.optim import FlatSGD
     from garbage_classification_rca_amd.training import FusedCrossEntropy, GraphedTrainStep
     B, size = 4, 128
@@ -155,6 +152,14 @@ def test_graphed_step_draws_stochastic_depth_inside_the_graph():
         losses = [float(graphed(*data[k % 2])) for k in range(6)]
     assert graphed.replays == 5 and all(l == l and abs(l) < 1e3 for l in losses), losses
     assert len({round(l, 4) for l in losses}) >= 4, losses
+    from garbage_classification_rca_amd.procedural import counter_uniform
+    conv, eng = m.engine.conv, m.engine
+    n_sd = int(conv._sd_p.numel())
+    got = conv._bufs[("sd.rowscale", n_sd, B, torch.float32)][:n_sd].cpu().numpy()          # the masks of the LAST replay (step 6)
+    p = conv._sd_p.cpu().numpy()
+    u = counter_uniform(eng._site_seed(m._drop_seed + m._fwd_count, 254, 0), np.arange(n_sd * B, dtype=np.uint64)).reshape(n_sd, B)
+    want = np.where(u >= p, 1.0 / (1.0 - p), 0.0).astype(np.float32)
+    assert m._fwd_count == 6 and np.array_equal(got, want) and 0 < (got == 0).sum() < got.size
     # the engine frees its buffers (a new image size, an evaluation at another batch size ...): the graphs that point into them are
     # dropped and the step warms up and captures again
     m.engine.release_buffers()

@@ -97,6 +97,29 @@ def test_cli_defaults_match_reference_parser():
         assert ex[k] == v
     extra = set(mine) - set(gold["defaults"])
     assert extra == {"tokens_max_len", "dtype", "synthetic", "num_workers", "seed", "image_size", "gpu_preprocess", "blip2_checkpoint", "hip_graph"}     # additive flags only
+    # the reference's launch line (slurm_files/multimodal/MM_RCA.sh:15-30) must compute within the 1e-3 bound: the default compute
+    # mode is the fastest one that does (bf16 is opt-in)
+    assert mine["dtype"] == "bf16x3f"
+
+
+def test_facade_defaults_are_the_references_model():
+    """``MM_RCA`` called with the reference's ten positionals (main_both.py:306-317) must build what the
+    reference builds -- EfficientNetV2-M (multimodal_model.py:113-126, 188) -- in a mode inside the tolerance; the additive
+    keyword arguments may not change that.  (The construction itself needs HBM: tests/test_conv_gpu.py makes the call.)"""
+    import inspect
+    from garbage_classification_rca_amd.multimodal_model import MM_RCA, EffV2MediumAndDistilbertGated
+    sig = inspect.signature(MM_RCA.__init__)
+    names = list(sig.parameters)[1:]
+    assert names[:10] == ["n_classes", "drop_ratio", "image_or_text_dropout_chance", "img_prob_dropout", "num_neurons_fc",
+                          "text_model_name", "batch_size", "reverse", "features_only", "cross_attention_only"]
+    assert all(sig.parameters[n].default is inspect.Parameter.empty for n in names[:10])          # :158-168: all required
+    assert all(sig.parameters[n].default is not inspect.Parameter.empty for n in names[10:])      # additive ones all optional
+    assert sig.parameters["image_model_name"].default == "eff_v2_medium"
+    assert sig.parameters["dtype"].default == "bf16x3f"
+    assert sig.parameters["image_size"].default is None             # -> 480 for EfficientNetV2-M (:407-408)
+    assert issubclass(MM_RCA, EffV2MediumAndDistilbertGated)
+    fwd = list(inspect.signature(MM_RCA.forward).parameters)[1:]
+    assert fwd == ["_input_ids", "_attention_mask", "_images", "eval", "remove_image", "remove_text"]       # :638-644
 
 
 # ------------------------------------------------------------------------------------------------ dataset
