@@ -1263,8 +1263,9 @@ static int pick_nkt(int S) {
 // QT = tiles per wave: with one tile per wave (16 waves) the kernel is bound by LDS reads -- every wave streams the whole opposite
 // side's images (20 KB of fragment reads per pair and wave: ~23 k cycles of LDS bandwidth per head against ~12 k of MFMA); with
 // QT = 2 (8 waves, 256 registers each) every fragment read feeds two tiles and the LDS traffic halves.
+#define BWDP_VGPRS 216          // registers the compiler may allocate; v216 .. v251 are the row constants' landing registers (rc_issue)
 template <int NKT, int NW, int QT>
-__global__ void __launch_bounds__(64 * NW, 1)
+__global__ void __launch_bounds__(64 * NW, 1) __attribute__((amdgpu_num_vgpr(BWDP_VGPRS)))
 mha_bwd_p_mfma_v_k(const bf16_t* __restrict__ qkv, const bf16_t* __restrict__ out, const bf16_t* __restrict__ dout,
                    const float* __restrict__ lse, bf16_t* __restrict__ dqkv, int H, int S, float scale, int nbh) {
   extern __shared__ __attribute__((aligned(16))) char sm[];
@@ -1535,30 +1536,56 @@ mha_bwd_p_mfma_v_k(const bf16_t* __restrict__ qkv, const bf16_t* __restrict__ ou
   // The same split in two for the steady state: EVERY thread issues the loads of its RC2 rows of head i+1 right after the mid
   // barrier (inline asm, destinations untouched until the wait) and reduces them after its dQ part, when they have long landed --
   // one wave alone needs three round trips per head for the 1,576 row chunks, which made IT the critical path (measured).
+  // The loads stay in flight across the whole dQ part, so their destinations must be registers the COMPILER never touches: with "=v"
+  // outputs it is free to copy a "defined" value before the wait (live-range split under pressure: seen once, DESIGN K2 round 4).
+  // The kernel is therefore compiled for v0 .. v[BWDP_VGPRS - 1] (amdgpu_num_vgpr) and the loads land in FIXED registers above that
+  // range, named in the asm text; they enter the compiler's view only through the v_movs of rc_finish, which sit BEHIND the
+  // s_waitcnt in the same asm statement.  tools/check_inflight_regs.py verifies the ISA (CPU test).
   constexpr int RC2 = (NCONST * 8 + 64 * NW - 1) / (64 * NW);
-  auto rc_issue = [&](int bh_, bf16x8 (&x)[RC2], bf16x8 (&y)[RC2], float (&Lr)[RC2]) {
+  static_assert(RC2 == 4 && BWDP_VGPRS == 216, "the landing registers below are written out for four row chunks per thread: v216 .. v251");
+#define RC_CLOB "v216", "v217", "v218", "v219", "v220", "v221", "v222", "v223", "v224", "v225", "v226", "v227", "v228", "v229", "v230", "v231", \
+                "v232", "v233", "v234", "v235", "v236", "v237", "v238", "v239", "v240", "v241", "v242", "v243", "v244", "v245", "v246", "v247", \
+                "v248", "v249", "v250", "v251"
+#define RC_ISSUE(i, XR, YR, LR)                                                                                           \
+  {                                                                                                                       \
+    const int e = tid_o + (i) * 64 * NW;                                                                                  \
+    int q = e >> 3;                                                                                                       \
+    q = q < S ? q : S - 1;                                                                                                \
+    const bf16_t* pd = dO + (int64_t)q * ldo + (e & 7) * 8;                                                               \
+    const bf16_t* po = O + (int64_t)q * ldo + (e & 7) * 8;                                                                \
+    const float* pl = Lp + q;                                                                                             \
+    asm volatile("global_load_dwordx4 " XR ", %0, off\n\tglobal_load_dwordx4 " YR ", %1, off\n\tglobal_load_dword " LR ", %2, off" \
+                 :: "v"(pd), "v"(po), "v"(pl) : "memory", RC_CLOB);                                                       \
+  }
+  auto rc_issue = [&](int bh_) {
     const bf16_t* O = out + (int64_t)(bh_ / H) * S * ldo + (bh_ % H) * AT_DH;
     const bf16_t* dO = dout + (int64_t)(bh_ / H) * S * ldo + (bh_ % H) * AT_DH;
     const float* Lp = lse + (int64_t)bh_ * S;
     int tid_o = threadIdx.x;
     asm volatile("" : "+v"(tid_o));
-#pragma unroll
-    for (int i = 0; i < RC2; ++i) {
-      const int e = tid_o + i * 64 * NW;
-      int q = e >> 3;
-      q = q < S ? q : S - 1;
-      const bf16_t* pd = dO + (int64_t)q * ldo + (e & 7) * 8;
-      const bf16_t* po = O + (int64_t)q * ldo + (e & 7) * 8;
-      const float* pl = Lp + q;
-      asm volatile("global_load_dwordx4 %0, %1, off" : "=&v"(x[i]) : "v"(pd) : "memory");
-      asm volatile("global_load_dwordx4 %0, %1, off" : "=&v"(y[i]) : "v"(po) : "memory");
-      asm volatile("global_load_dword %0, %1, off" : "=&v"(Lr[i]) : "v"(pl) : "memory");
-    }
+    RC_ISSUE(0, "v[216:219]", "v[232:235]", "v248")
+    RC_ISSUE(1, "v[220:223]", "v[236:239]", "v249")
+    RC_ISSUE(2, "v[224:227]", "v[240:243]", "v250")
+    RC_ISSUE(3, "v[228:231]", "v[244:247]", "v251")
   };
-  auto rc_finish = [&](bf16x8 (&x)[RC2], bf16x8 (&y)[RC2], float (&Lr)[RC2]) {
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-#pragma unroll
-    for (int i = 0; i < RC2; ++i) asm volatile("" : "+v"(x[i]), "+v"(y[i]), "+v"(Lr[i]));
+  typedef uint32_t rc_u32x4 __attribute__((ext_vector_type(4)));
+#define RC_TAKE(i, X0, X1, X2, X3, Y0, Y1, Y2, Y3, LR)                                                                    \
+  {                                                                                                                       \
+    rc_u32x4 xw, yw;                                                                                                      \
+    asm volatile("s_waitcnt vmcnt(0)\n\tv_mov_b32 %0, " X0 "\n\tv_mov_b32 %1, " X1 "\n\tv_mov_b32 %2, " X2 "\n\tv_mov_b32 %3, " X3 "\n\t" \
+                 "v_mov_b32 %4, " Y0 "\n\tv_mov_b32 %5, " Y1 "\n\tv_mov_b32 %6, " Y2 "\n\tv_mov_b32 %7, " Y3 "\n\tv_mov_b32 %8, " LR         \
+                 : "=&v"(xw[0]), "=&v"(xw[1]), "=&v"(xw[2]), "=&v"(xw[3]), "=&v"(yw[0]), "=&v"(yw[1]), "=&v"(yw[2]), "=&v"(yw[3]), "=&v"(Lr[i]) \
+                 :: "memory");                                                                                            \
+    x[i] = __builtin_bit_cast(bf16x8, xw);                                                                                \
+    y[i] = __builtin_bit_cast(bf16x8, yw);                                                                                \
+  }
+  auto rc_finish = [&]() {
+    bf16x8 x[RC2], y[RC2];
+    float Lr[RC2];
+    RC_TAKE(0, "v216", "v217", "v218", "v219", "v232", "v233", "v234", "v235", "v248")
+    RC_TAKE(1, "v220", "v221", "v222", "v223", "v236", "v237", "v238", "v239", "v249")
+    RC_TAKE(2, "v224", "v225", "v226", "v227", "v240", "v241", "v242", "v243", "v250")
+    RC_TAKE(3, "v228", "v229", "v230", "v231", "v244", "v245", "v246", "v247", "v251")
     int tid_o = threadIdx.x;
     asm volatile("" : "+v"(tid_o));
 #pragma unroll
@@ -1575,6 +1602,9 @@ mha_bwd_p_mfma_v_k(const bf16_t* __restrict__ qkv, const bf16_t* __restrict__ ou
       }
     }
   };
+#undef RC_ISSUE
+#undef RC_TAKE
+#undef RC_CLOB
 
   // prologue: head 0 of this workgroup
   stage_kv(0, bh);
@@ -1605,15 +1635,13 @@ mha_bwd_p_mfma_v_k(const bf16_t* __restrict__ qkv, const bf16_t* __restrict__ ou
       for (int t = 0; t < QT; ++t) asm volatile("" : "+v"(qf0[t]), "+v"(qf1[t]), "+v"(df0[t]), "+v"(df1[t]), "+v"(nl[t]), "+v"(nd[t]));
     }
     asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");       // LDS only: the K | V DMA of head nxt stays in flight
-    bf16x8 rx[RC2], ry[RC2];
-    float rl[RC2];
     if (nxt < nbh) {
       stage_qd(nxt);
-      rc_issue(nxt, rx, ry, rl);
+      rc_issue(nxt);
     }
     if (has_tile) dq_tile(bh, kvb, qf0, qf1, df0, df1, nl, nd);
     if (nxt >= nbh) break;
-    rc_finish(rx, ry, rl);
+    rc_finish();
     bh = nxt; cur ^= 1;
   }
 #undef BWDP_LANE_OFFSETS

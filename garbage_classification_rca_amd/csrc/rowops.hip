@@ -87,8 +87,14 @@ add_ln_fwd_k(const T* __restrict__ x, const T* __restrict__ res, const T* __rest
 // loads in flight (the plain kernel above reached 3.0 TB/s at 50432 x 768; HBM-bound work wants ~2x the bytes in flight)
 typedef __attribute__((ext_vector_type(8))) __bf16 raw8;
 
-template <int NV2, int RP>
-__global__ void __launch_bounds__(256)
+// PACK (round 5): the row is kept as the bf16 values it is normalised from (4 registers per 8 columns) instead of as fp32 (8): with
+// the fp32 copy the <2,2> form needed 193 registers = TWO waves per SIMD, 48 KB of loads in flight per CU, and ran at 3.4 TB/s
+// (Little's law at ~3.5 us of loaded latency); packed it fits four waves per SIMD.  Exact whenever the normalised values ARE bf16
+// numbers: a stored sum (the backward re-reads the rounded sum, so the statistics are taken from it anyway) or a plain x.
+// gamma | beta sit in LDS (16 registers less than a per-lane copy); DROP = either dropout site active (its 64-bit counters cost
+// registers too, and the ViT has none).
+template <int NV2, int RP, bool PACK, bool DROP>
+__global__ void __launch_bounds__(256, PACK ? 4 : 1)
 add_ln_fwd_bf16_k(const bf16_t* __restrict__ x, const bf16_t* __restrict__ res, const bf16_t* __restrict__ gamma,
                   const bf16_t* __restrict__ beta, bf16_t* __restrict__ sum_out, bf16_t* __restrict__ y,
                   float* __restrict__ mean, float* __restrict__ rstd, int64_t rows, int D, int64_t ld_x, int64_t ld_y,
@@ -98,12 +104,11 @@ add_ln_fwd_bf16_k(const bf16_t* __restrict__ x, const bf16_t* __restrict__ res, 
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const int64_t stride = (int64_t)gridDim.x * 4;
   int64_t row = (int64_t)blockIdx.x * 4 + wave;
-  raw8 gm[NV2], bt[NV2], nx[RP][NV2], nr[RP][NV2];
-#pragma unroll
-  for (int it = 0; it < NV2; ++it) {
-    const int c = it * 512 + lane * 8;
-    if (c < D) { gm[it] = *reinterpret_cast<const raw8*>(gamma + c); bt[it] = *reinterpret_cast<const raw8*>(beta + c); }
-  }
+  raw8 nx[RP][NV2], nr[RP][NV2];
+  __shared__ raw8 gb_s[2][NV2 * 64];
+  for (int i = threadIdx.x; i < NV2 * 64; i += 256)
+    if (i * 8 < D) { gb_s[0][i] = *reinterpret_cast<const raw8*>(gamma + i * 8); gb_s[1][i] = *reinterpret_cast<const raw8*>(beta + i * 8); }
+  __syncthreads();
 #define LNF_FETCH(r0_)                                                                           \
   _Pragma("unroll") for (int p = 0; p < RP; ++p) {                                               \
     const int64_t r_ = (r0_) + p * stride;                                                       \
@@ -119,8 +124,10 @@ add_ln_fwd_bf16_k(const bf16_t* __restrict__ x, const bf16_t* __restrict__ res, 
   }
   LNF_FETCH(row)
   for (; row < rows; row += RP * stride) {
-    float v[RP][NV2][8];
+    float v[PACK ? 1 : RP][PACK ? 1 : NV2][8];
+    raw8 sv[PACK ? RP : 1][PACK ? NV2 : 1];
     float s[RP], q[RP], mu[RP], rs[RP];
+#define LNF_VAL(p_, it_, j_) (PACK ? (float)sv[PACK ? (p_) : 0][PACK ? (it_) : 0][j_] : v[PACK ? 0 : (p_)][PACK ? 0 : (it_)][j_])
 #pragma unroll
     for (int p = 0; p < RP; ++p) {
       const int64_t r = row + p * stride;
@@ -134,11 +141,13 @@ add_ln_fwd_bf16_k(const bf16_t* __restrict__ x, const bf16_t* __restrict__ res, 
 #pragma unroll
             for (int j = 0; j < 8; ++j) {
               float a = (float)nx[p][it][j];
-              if (in_p > 0.f) a = mmrca_uniform(in_seed, (uint64_t)r * D + c + j) >= in_p ? a * in_sc : 0.f;
+              if (DROP && in_p > 0.f) a = mmrca_uniform(in_seed, (uint64_t)r * D + c + j) >= in_p ? a * in_sc : 0.f;
               if (res) a += (float)nr[p][it][j];
-              if (sum_out) { so[j] = (bf16_t)a; a = (float)so[j]; }   // the stored sum is what the backward re-reads
-              v[p][it][j] = a; s[p] += a;
+              if (sum_out || PACK) { so[j] = (bf16_t)a; a = (float)so[j]; }   // the stored sum is what the backward re-reads
+              if constexpr (!PACK) v[p][it][j] = a;
+              s[p] += a;
             }
+            if constexpr (PACK) sv[p][it] = so;
             if (sum_out) *reinterpret_cast<raw8*>(sum_out + r * ld_x + c) = so;
           }
         }
@@ -156,7 +165,7 @@ add_ln_fwd_bf16_k(const bf16_t* __restrict__ x, const bf16_t* __restrict__ res, 
           const int c = it * 512 + lane * 8;
           if (c < D) {
 #pragma unroll
-            for (int j = 0; j < 8; ++j) { const float d = v[p][it][j] - mu[p]; q[p] += d * d; }
+            for (int j = 0; j < 8; ++j) { const float d = LNF_VAL(p, it, j) - mu[p]; q[p] += d * d; }
           }
         }
       }
@@ -173,10 +182,11 @@ add_ln_fwd_bf16_k(const bf16_t* __restrict__ x, const bf16_t* __restrict__ res, 
           const int c = it * 512 + lane * 8;
           if (c < D) {
             raw8 o;
+            const raw8 gm = gb_s[0][it * 64 + lane], bt = gb_s[1][it * 64 + lane];
 #pragma unroll
             for (int j = 0; j < 8; ++j) {
-              float t = (v[p][it][j] - mu[p]) * rs[p] * (float)gm[it][j] + (float)bt[it][j];
-              if (out_p > 0.f) t = mmrca_uniform(out_seed, (uint64_t)r * D + c + j) >= out_p ? t * out_sc : 0.f;
+              float t = (LNF_VAL(p, it, j) - mu[p]) * rs[p] * (float)gm[j] + (float)bt[j];
+              if (DROP && out_p > 0.f) t = mmrca_uniform(out_seed, (uint64_t)r * D + c + j) >= out_p ? t * out_sc : 0.f;
               o[j] = (bf16_t)t;
             }
             *reinterpret_cast<raw8*>(y + r * ld_y + c) = o;
@@ -186,6 +196,7 @@ add_ln_fwd_bf16_k(const bf16_t* __restrict__ x, const bf16_t* __restrict__ res, 
     }
   }
 #undef LNF_FETCH
+#undef LNF_VAL
 }
 
 static inline bool aligned16p(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
@@ -203,12 +214,22 @@ static int add_layernorm_fwd_impl(const void* x, const void* res, const void* ga
   if (dtype == MMRCA_BF16 && D % 8 == 0 && D <= 1536 && ld_x % 8 == 0 && ld_y % 8 == 0 && aligned16p(x) && aligned16p(y) &&
       aligned16p(gamma) && aligned16p(beta) && (!res || aligned16p(res)) && (!sum_out || aligned16p(sum_out))) {
     const int g2 = (int)((rows + 7) / 8 < 1024 ? (rows + 7) / 8 : 1024);
-#define LN_FWD16(NV2_, RP_)                                                                                                  \
-    hipLaunchKernelGGL((add_ln_fwd_bf16_k<NV2_, RP_>), dim3(g2), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)x,              \
+#define LN_FWD16(NV2_, RP_, PACK_, DROP_)                                                                                    \
+    hipLaunchKernelGGL((add_ln_fwd_bf16_k<NV2_, RP_, PACK_, DROP_>), dim3(g2), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)x, \
                        (const bf16_t*)res, (const bf16_t*)gamma, (const bf16_t*)beta, (bf16_t*)sum_out, (bf16_t*)y, mean, rstd, \
                        rows, D, ld_x, ld_y, eps, in_drop_p, in_drop_seed, out_drop_p, out_drop_seed)
+#define LN_FWD16_PD(NV2_, RP_)                                                                                               \
+    do {                                                                                                                     \
+      if (pack) { if (drop) LN_FWD16(NV2_, RP_, true, true); else LN_FWD16(NV2_, RP_, true, false); }                        \
+      else { if (drop) LN_FWD16(NV2_, RP_, false, true); else LN_FWD16(NV2_, RP_, false, false); }                           \
+    } while (0)
     const int nv2 = (D + 511) / 512;
-    if (nv2 <= 1) LN_FWD16(1, 2); else if (nv2 == 2) LN_FWD16(2, 2); else LN_FWD16(3, 1);      // 3: BLIP-2's ViT-g rows (D = 1408); one row per wave in flight keeps four waves per SIMD
+    // packed rows whenever the normalised values are bf16 numbers anyway (see the kernel); MMRCA_LN_PACK=0: the fp32-row form
+    static const bool pack_on = !(getenv("MMRCA_LN_PACK") && atoi(getenv("MMRCA_LN_PACK")) == 0);
+    const bool pack = pack_on && (sum_out || (!res && in_drop_p == 0.f));
+    const bool drop = in_drop_p > 0.f || out_drop_p > 0.f;
+    if (nv2 <= 1) LN_FWD16_PD(1, 2); else if (nv2 == 2) LN_FWD16_PD(2, 2); else LN_FWD16_PD(3, 1);      // 3: BLIP-2's ViT-g rows (D = 1408)
+#undef LN_FWD16_PD
 #undef LN_FWD16
     MMRCA_CHECK_LAUNCH("add_layernorm_fwd(bf16)");
     return 0;
