@@ -18,11 +18,60 @@ import torch
 import torch.distributed as dist
 
 
+def cpu_slice(local_rank: int, local_world: int, cpus=None) -> List[int]:
+    """The CPU set of one rank on a node that runs `local_world` ranks: the `local_rank`-th of `local_world` contiguous slices of
+    the CPUs this process may use (sorted ids).  Contiguous, because Linux numbers the cores of a socket contiguously and the GPUs of
+    an MI355X node are split the same way (GPUs 0-3 on socket 0, 4-7 on socket 1): rank r's launch thread and its DataLoader workers
+    then share the socket -- and the L3 -- next to their GPU instead of migrating across the fabric.  Never empty: with fewer CPUs
+    than ranks the slices wrap."""
+    cpus = sorted(os.sched_getaffinity(0) if cpus is None else cpus)
+    local_world = max(int(local_world), 1)
+    n = len(cpus)
+    if n == 0:
+        return []
+    if n < local_world:
+        return [cpus[local_rank % n]]
+    per = n // local_world
+    return cpus[local_rank * per: (local_rank + 1) * per]
+
+
+def bind_rank_to_cpus(local_rank: int, local_world: int) -> Optional[List[int]]:
+    """Pin this process (and the DataLoader workers it will fork) to its rank's CPU slice; MMRCA_CPU_BIND=0 leaves the affinity
+    alone.  Returns the slice, or None when nothing was changed (one rank per node, binding off, or no sched_setaffinity)."""
+    if local_world <= 1 or os.environ.get("MMRCA_CPU_BIND", "1") != "1" or not hasattr(os, "sched_setaffinity"):
+        return None
+    sl = cpu_slice(local_rank, local_world)
+    if not sl:
+        return None
+    try:
+        os.sched_setaffinity(0, sl)
+    except OSError:
+        return None
+    return sl
+
+
+def loader_workers(requested: int) -> int:
+    """DataLoader worker processes of this rank: the requested count (main_both.py:476-492 asks for 16), capped by the CPUs this
+    process may run on minus one for the launch thread -- after bind_rank_to_cpus that is the rank's own slice, so eight ranks on a
+    64-core node start 8 x 7 workers, not 8 x 16 that time-share."""
+    if requested <= 0:
+        return 0
+    try:
+        have = len(os.sched_getaffinity(0))
+    except AttributeError:
+        have = os.cpu_count() or 1
+    return max(1, min(int(requested), have - 1))
+
+
 def init_from_env(backend: Optional[str] = None):
-    """RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* from torchrun; returns (rank, local_rank, world)."""
+    """RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* from torchrun; returns (rank, local_rank, world).  With several ranks on the node
+    (LOCAL_WORLD_SIZE) the process is pinned to its slice of the node's CPUs first (bind_rank_to_cpus)."""
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
+    bound = bind_rank_to_cpus(local, int(os.environ.get("LOCAL_WORLD_SIZE", str(world))))
+    if bound is not None and rank == 0:
+        print(f"[mmrca] rank -> CPU binding on: {len(bound)} CPUs per rank (rank 0: {bound[0]}..{bound[-1]}); MMRCA_CPU_BIND=0 disables")
     if world > 1 and not dist.is_initialized():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29500")
@@ -140,6 +189,17 @@ class GradSync:
         # bench.py's self-diagnosis: with `timing` on, finish() brackets its waits with events on the compute stream
         self.timing, self.wait_events = False, []
 
+    def active(self) -> bool:
+        """does this exchange launch collectives at all (more than one rank, or forced on one)"""
+        return self.world > 1 or self.force
+
+    def capturable(self) -> bool:
+        """can the exchange be recorded INSIDE a HIP graph of the train step (training.GraphedTrainStep)?  RCCL collectives can (the
+        all-reduces run on RCCL's stream, forked from and joined back into the capturing stream by events: graph nodes like any
+        other); gloo's cannot.  MMRCA_GRAPH_DP=0 keeps multi-rank steps eager."""
+        return (dist.is_initialized() and dist.get_backend() == "nccl" and self.g.is_cuda
+                and os.environ.get("MMRCA_GRAPH_DP", "1") == "1")
+
     def span_ready(self, lo: int, hi: int, flush: bool = False):
         """Called by the engine when grads in [lo, hi) are final.  Adjacent ready spans are merged until a bucket is
         full (spans arrive in descending address order within an encoder)."""
@@ -169,7 +229,8 @@ class GradSync:
 
     def finish(self):
         self._flush()
-        timed = self.timing and self.pending and torch.cuda.is_available() and self.g.is_cuda
+        timed = (self.timing and self.pending and torch.cuda.is_available() and self.g.is_cuda
+                 and not torch.cuda.is_current_stream_capturing())
         if timed:
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()

@@ -83,10 +83,16 @@ class Arena:
         # bf16x3 mode: p = lp + lp_lo (hi / lo bf16 planes of the fp32 masters, see csrc/gemm_x3.hip)
         self.lp_lo = torch.zeros(self.total, dtype=torch.bfloat16, device=device) if with_lo else None
         self.lp_valid = False
+        self._views: Dict[Tuple[str, str], torch.Tensor] = {}
 
     def view(self, key, which="p"):
-        off, shp, n = self.offsets[key]
-        return getattr(self, which)[off:off + n].view(shp)
+        """[shape] view of one parameter in plane `which` (p | g | lp | lp_lo).  Cached: the planes never move, and the engine asks
+        for the same ~400 views every step (a slice + view costs ~5 us of host time each)."""
+        v = self._views.get((key, which))
+        if v is None:
+            off, shp, n = self.offsets[key]
+            v = self._views[(key, which)] = getattr(self, which)[off:off + n].view(shp)
+        return v
 
     def span(self, first_key, last_key):
         a = self.offsets[first_key][0]

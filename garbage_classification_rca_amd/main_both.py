@@ -215,8 +215,9 @@ def main(argv=None):
         # GPU input path: workers come from a fork SERVER (a fresh interpreter without the GPU runtime), not from a fork of this
         # process -- every fork of a process with registered host memory makes the kernel driver evict and restore its GPU
         # queues; 16 workers cost 25-34 s of stalled GPU per loader start on the MI355X box (tools/input_bench.py)
-        ctx = "forkserver" if (gpu_pre and args.num_workers > 0) else None
-        return torch.utils.data.DataLoader(ds, batch_size=bs, sampler=sampler, num_workers=args.num_workers, pin_memory=True,
+        nw = D.loader_workers(args.num_workers)        # (capped by this rank's CPU slice, distributed.bind_rank_to_cpus)
+        ctx = "forkserver" if (gpu_pre and nw > 0) else None
+        return torch.utils.data.DataLoader(ds, batch_size=bs, sampler=sampler, num_workers=nw, pin_memory=True,
                                            collate_fn=collate_decoded if gpu_pre else None, multiprocessing_context=ctx,
                                            persistent_workers=bool(ctx)), sampler
 

@@ -114,8 +114,11 @@ class GraphedTrainStep:
       * the optimizer -- stays outside (2-4 launches): learning-rate schedules and AdamW's step count are host values;
       * stochastic depth (EfficientNetV2) -- a counter-based draw of the step seed like the dropout masks (mmrca_sd_rowscale).
     Captions run in the padded layout (a packed layout changes launch shapes per batch).  The first `warmup` calls of a shape run
-    eagerly (they allocate the engine's buffers), the next one captures.  With a multi-rank GradSync the step stays eager: the
-    exchange is launched span by span from Python while the backward runs."""
+    eagerly (they allocate the engine's buffers), the next one captures.
+    Data parallel: on RCCL the gradient exchange is captured WITH the step -- the bucketed all-reduces the backward launches span by
+    span (and the wait in front of the optimizer) become graph nodes on RCCL's stream, so an 8-rank node replays eight graphs instead of
+    running eight ~20-ms Python enqueue loops per step; stepping and accumulating micro-batches are different graphs (only the former
+    exchanges).  On gloo (CPU tests), or with MMRCA_GRAPH_DP=0, a multi-rank step stays eager."""
 
     def __init__(self, model, criterion: FusedCrossEntropy, optimizer=None, grad_sync=None, warmup: int = 2):
         self.model, self.criterion, self.optimizer, self.grad_sync, self.warmup = model, criterion, optimizer, grad_sync, int(warmup)
@@ -125,14 +128,20 @@ class GraphedTrainStep:
         self._generation = getattr(model.engine, "buffer_generation", 0)
         L.seed_epoch_set(0)                    # resolves the epoch words' addresses outside any capture
 
+    def _sync_in_graph(self):
+        gs = self.grad_sync
+        return gs is not None and gs.active() and gs.capturable()
+
     def _eager(self):
-        return self.grad_sync is not None and self.grad_sync.world > 1
+        gs = self.grad_sync
+        return gs is not None and gs.active() and not gs.capturable()
 
     def __call__(self, ids, mask, images, labels, do_step: bool = True):
         model, eng = self.model, self.model.engine
         ids, mask, images, _, seed, tt, ti = _prepare_step(model, ids, mask, images, None)
+        in_graph = self._sync_in_graph()
         key = (tuple(ids.shape), tuple(images.shape), images.dtype, labels.dtype, tt, ti, bool(model.training),
-               float(model.drop_ratio), float(model.enc_dropout))
+               float(model.drop_ratio), float(model.enc_dropout), bool(do_step) if in_graph else None)
         if getattr(eng, "buffer_generation", 0) != self._generation:       # engine.release_buffers() freed what the graphs point into
             self._graphs.clear()
             self._eager_left.clear()
@@ -140,7 +149,7 @@ class GraphedTrainStep:
         ent = self._graphs.get(key)
         if ent is None and key not in self._no_graph and not self._eager() and self._eager_left.setdefault(key, self.warmup) <= 0:
             try:
-                ent = self._capture(key, ids, mask, images, labels, seed, tt, ti)
+                ent = self._capture(key, ids, mask, images, labels, seed, tt, ti, do_step)
                 captured_now = True
             except L.MmrcaError:               # a kernel / argument error is an error, not a slowdown
                 raise
@@ -175,7 +184,7 @@ class GraphedTrainStep:
             self.optimizer.zero_grad()
         return loss
 
-    def _capture(self, key, ids, mask, images, labels, seed, tt, ti):
+    def _capture(self, key, ids, mask, images, labels, seed, tt, ti, do_step=True):
         model, eng = self.model, self.model.engine
         eng.refresh_working_copy()
         inputs = [t.clone() for t in (ids, mask, images, labels)]
@@ -193,7 +202,11 @@ class GraphedTrainStep:
             # "global" mode those would invalidate the capture or raise in that thread.  The engine launches from this thread only.
             with torch.cuda.graph(g, capture_error_mode="thread_local"):
                 L.seed_epoch_set(device_value=self._epoch)
-                loss = _enqueue_step(model, inputs[0], inputs[1], inputs[2], inputs[3], self.criterion, None, True, None, seed, tt, ti)
+                gs = self.grad_sync if self._sync_in_graph() else None
+                loss = _enqueue_step(model, inputs[0], inputs[1], inputs[2], inputs[3], self.criterion, gs, do_step if gs is not None else True,
+                                     None, seed, tt, ti)
+                if gs is not None and do_step:
+                    gs.finish()                # RCCL's stream joins the capturing stream: the graph ends with averaged gradients
                 L.seed_epoch_set(0)
         except BaseException:
             # buffers first created inside the dead capture were "zeroed" by a fill that never ran (padding rows are assumed zero by
@@ -207,6 +220,9 @@ class GraphedTrainStep:
                 conv.n_train_forwards, conv.saved = snap["n_fwd"], snap["conv_saved"]
                 if snap["no_arena"]:           # (the BatchNorm arena itself was born in the dead capture)
                     conv._bn_arena, conv._bn_off, conv._bn_used = None, {}, 0
+            if self.grad_sync is not None:     # collectives recorded into the dead capture never ran
+                self.grad_sync.pending.clear()
+                self.grad_sync._acc_lo = self.grad_sync._acc_hi = None
             raise
         print(f"HIP graph captured for the train step of batch shape {key[0]} x {key[1]} (trainable text / image encoder: {tt} / {ti})")
         ent = dict(graph=g, inputs=inputs, loss=loss, seed=seed, replayed=False)

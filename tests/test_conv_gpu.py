@@ -478,7 +478,7 @@ def test_mm_rca_with_conv_backbone_fp32_logits_and_train_step(text_model, image_
         e16 = MMRCAEngine(text_model, image_model, 4, True, 0, torch.bfloat16, image_size=size)
         e16.load_arrays(sd)
         l16 = e16.forward(ids.cuda(), mask.cuda(), images.cuda(), save=False, bn_train=False)
-        assert rel(l16, ref) < 5e-2, rel(l16, ref)         # bf16 bound of this suite
+        assert rel(l16, ref) < 3e-2, rel(l16, ref)         # bf16 bound of this suite
         l16 = e16.forward(ids.cuda(), mask.cuda(), images.cuda(), drop_p=0.6, seed=5, save=True, enc_drop_p=0.1, bn_train=True)
         e16.arena.g.zero_()
         e16.backward(torch.randn(B, 4, device="cuda") * 0.1)

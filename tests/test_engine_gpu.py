@@ -304,7 +304,7 @@ def test_benchmarked_configuration_value_check_b256():
         ref = torch.cat([orc(ids[i:i + 32], mask[i:i + 32], images[i:i + 32], eval=True) for i in range(0, B, 32)])
     e16 = rel(logits, ref)
     print("B=256 bf16 logits relative error vs oracle:", e16)
-    assert torch.isfinite(logits).all() and e16 < 5e-2
+    assert torch.isfinite(logits).all() and e16 < 3e-2
     gen = torch.Generator().manual_seed(1)
     dfeat = (torch.randn(B, 768, generator=gen) * 0.1).cuda()
     dcls = (torch.randn(B, 768, generator=gen) * 0.1).cuda()
@@ -350,7 +350,7 @@ def test_bf16_close_to_oracle_and_to_fp32():
         ref = orc(ids, mask, images, eval=True)
     e = rel(logits, ref)
     print("bf16 logits relative error:", e)
-    assert e < 5e-2          # bf16 storage through 12+6 encoder layers; the 1e-3 bound is met by fp32 mode
+    assert e < 3e-2          # bf16 storage through 12+6 encoder layers (measured 1.5-1.7e-2); the 1e-3 bound is met by bf16x3f / bf16x3 / fp32
     # encoder backward in bf16 vs fp32 for the SAME upstream gradient (the test head's weights are deliberately
     # large, so its d/dfeatures is too sensitive to the 1% feature difference to compare through it)
     gen = torch.Generator().manual_seed(1)
@@ -365,7 +365,7 @@ def test_bf16_close_to_oracle_and_to_fp32():
     eng32 = MMRCAEngine("distilbert", "transformer_B16", 4, True, 0, torch.float32)
     eng32.load_arrays(sd)
     l32 = eng32.forward(ids.cuda(), mask.cuda(), images.cuda())
-    assert rel(logits, l32) < 5e-2
+    assert rel(logits, l32) < 3e-2
     eng32._vision_backward(dfeat, eng32._saved["vision"])
     eng32._text_backward(dcls, eng32._saved["text"])
     worst = 1.0

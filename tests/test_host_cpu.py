@@ -649,6 +649,30 @@ def test_balanced_sampler_weights_draws_and_rank_striding():
     assert len(BalancedShardedSampler([], 0, 1)) == 0 and list(iter(BalancedShardedSampler([], 0, 1))) == []
 
 
+def test_rank_to_cpu_binding_slices_and_worker_cap(monkeypatch):
+    """one process per GPU (replacing nn.DataParallel, main_both.py:386-388) with 16 loader workers each (:476-492) oversubscribes a
+    node unless every rank keeps to its own cores: contiguous, disjoint, equal slices of the allowed CPUs; the worker count follows
+    the slice"""
+    cpus = list(range(4, 68))                                  # 64 allowed CPUs, ids 4..67
+    sl = [D.cpu_slice(r, 8, cpus) for r in range(8)]
+    assert all(len(x) == 8 for x in sl) and sorted(sum(sl, [])) == cpus and sl[0] == list(range(4, 12)) and sl[7] == list(range(60, 68))
+    assert D.cpu_slice(5, 8, [0, 1, 2]) == [2]                 # fewer CPUs than ranks: wrap, never empty
+    assert D.cpu_slice(0, 1, cpus) == cpus
+    before = os.sched_getaffinity(0)
+    try:
+        assert D.bind_rank_to_cpus(0, 1) is None               # one rank per node: untouched
+        monkeypatch.setenv("MMRCA_CPU_BIND", "0")
+        assert D.bind_rank_to_cpus(1, 2) is None and os.sched_getaffinity(0) == before
+        monkeypatch.setenv("MMRCA_CPU_BIND", "1")
+        if len(before) >= 2:
+            got = D.bind_rank_to_cpus(1, 2)
+            assert got == sorted(before)[len(before) // 2: 2 * (len(before) // 2)] and os.sched_getaffinity(0) == set(got)
+            assert D.loader_workers(16) == max(1, min(16, len(got) - 1))
+    finally:
+        os.sched_setaffinity(0, before)
+    assert D.loader_workers(0) == 0 and D.loader_workers(3) == max(1, min(3, len(before) - 1))
+
+
 def _inflight_checker():
     import importlib.util
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))

@@ -540,7 +540,7 @@ def test_layernorm_fwd_bf16_dispatch_branches(D, form):
     torch.cuda.synchronize()
     if use_sum:
         assert torch.equal(s_out.float().cpu(), s_ref)                       # the stored sum: bit-exact
-    assert rel_err(mean, s_ref.mean(1)) < 1e-5 and rel_err(rstd, (s_ref.var(1, unbiased=False) + eps).rsqrt()) < 1e-5
+    assert rel_err(mean.cpu(), s_ref.mean(1)) < 1e-5 and rel_err(rstd.cpu(), (s_ref.var(1, unbiased=False) + eps).rsqrt()) < 1e-5
     d = (y.float().cpu() - y_ref).abs()
     assert float(d.max()) < 0.04 and float(d.mean()) < 2e-3, (float(d.max()), float(d.mean()))     # bf16 rounding of |y| <~ 5
 

@@ -129,3 +129,66 @@ def test_conv_backbone_reports_its_stages_one_by_one(nccl_world1):
     assert sorted(img)[0][0] == img_lo and sorted(img)[-1][1] == img_hi
     assert all(a[1] == b[0] for a, b in zip(sorted(img), sorted(img)[1:]))
     eng.release_buffers()
+
+
+def test_graphed_step_captures_the_rccl_exchange_and_replays_the_eager_step(nccl_world1):
+    """training.GraphedTrainStep with a live exchange (GradSync(force=True) on the world-1 RCCL group): the bucketed all-reduces and
+    the wait in front of the optimizer are captured INSIDE the step's HIP graph; replays compute what the eager step with the same
+    exchange computes (same losses within the eager-vs-eager noise, same parameters), the exchange ran on every replay (a gradient
+    poisoned before a replay comes back averaged = overwritten by the replay's backward, finite), and an accumulating micro-batch
+    (do_step=False: no exchange) is a different graph.  Reference seam: run_one_epoch's per-batch body (main_both.py:95-126) under
+    the data-parallel replacement of nn.DataParallel (:386-388)."""
+    import contextlib, io
+    from garbage_classification_rca_amd.distributed import GradSync
+    from garbage_classification_rca_amd.multimodal_model import MM_RCA
+    from garbage_classification_rca_amd.optim import FlatSGD
+    from garbage_classification_rca_amd.training import FusedCrossEntropy, GraphedTrainStep, hip_train_step
+    from garbage_classification_rca_amd.procedural import synth_captions
+    B, n = 4, 6
+
+    def model():
+        with contextlib.redirect_stdout(io.StringIO()):
+            m = MM_RCA(4, 0.6, 0.0, 0.7, 256, "distilbert", B, True, False, False, image_model_name="transformer_B16", dtype=torch.bfloat16,
+                       device=torch.device("cuda", 0), init_seed=0)
+        m.train()
+        for p in m.parameters():
+            p.requires_grad = True
+        return m
+
+    data = []
+    for k in range(n):
+        ids, mask = (torch.from_numpy(a).cuda() for a in synth_captions(B, 16, seed=50 + k))
+        data.append((ids, mask, torch.randn(B, 3, 224, 224, generator=torch.Generator().manual_seed(60 + k)).cuda(), torch.arange(B).cuda() % 4))
+    ma, mb = model(), model()
+    oa, ob = FlatSGD(ma, lr=2e-3, weight_decay=1e-2), FlatSGD(mb, lr=2e-3, weight_decay=1e-2)
+    crit = FusedCrossEntropy(None, 0.0)
+    sa = GradSync(ma.engine.arena.g, world=1, bucket_bytes=32 << 20, force=True)
+    sb = GradSync(mb.engine.arena.g, world=1, bucket_bytes=32 << 20, force=True)
+    assert sb.active() and sb.capturable()
+    graphed = GraphedTrainStep(mb, crit, ob, grad_sync=sb, warmup=2)
+    la, lb = [], []
+    with contextlib.redirect_stdout(io.StringIO()):
+        for k in range(n):
+            la.append(hip_train_step(ma, *data[k], crit, oa, sa, text_pack=None))
+            lb.append(graphed(*data[k]))
+    torch.cuda.synchronize()
+    la, lb = [float(x) for x in la], [float(x) for x in lb]
+    print("eager + RCCL  ", [round(x, 4) for x in la])
+    print("graphed + RCCL", [round(x, 4) for x in lb])
+    assert graphed.replays == n - 2 and len(graphed._graphs) == 1 and not sb.pending
+    launches_captured = sb.launches
+    assert launches_captured > 2 * 1 and sa.launches > sb.launches          # (the eager twin launches its collectives every step)
+    assert max(abs(a - b) for a, b in zip(la, lb)) < 2e-2, (la, lb)
+    rel = float((ma.engine.arena.p - mb.engine.arena.p).norm() / ma.engine.arena.p.norm())
+    print("parameters after", n, "steps, graphed + RCCL vs eager + RCCL:", rel)
+    assert rel < 2e-4
+    # an accumulating micro-batch exchanges nothing and is its own graph; the stepping one that follows replays the first graph
+    with contextlib.redirect_stdout(io.StringIO()):
+        for k in range(3):
+            graphed(*data[k], do_step=False)
+        assert len(graphed._graphs) == 2 and sb.launches == launches_captured
+        l_last = graphed(*data[0])
+    torch.cuda.synchronize()
+    assert torch.isfinite(l_last) and torch.isfinite(mb.engine.arena.p).all() and len(graphed._graphs) == 2
+    ma.engine.release_buffers()
+    mb.engine.release_buffers()
