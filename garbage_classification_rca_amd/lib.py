@@ -104,6 +104,7 @@ _SIGS = {
     "mmrca_mha_bwd": [_vp] * 6 + [_i32] * 4 + [_f32, _f32, _u64, _vp, _i32, _i32, _vp],
     "mmrca_mha_bwd_colsum": [_vp] * 7 + [_i64] + [_i32] * 4 + [_f32, _f32, _u64, _vp, _i32, _i32, _vp],
     "mmrca_mha_cross_fwd": [_vp, _i64, _vp, _i64, _vp, _i64, _vp, _i64] + [_i32] * 5 + [_f32, _f32, _u64, _i32, _i32, _vp],
+    "mmrca_mha_cross_fwd_x3": [_vp, _i64, _vp, _i64, _vp, _i64, _vp, _vp, _i64] + [_i32] * 5 + [_f32, _f32, _u64, _vp],
     "mmrca_mha_cls_fwd": [_vp] * 4 + [_i32] * 4 + [_f32, _f32, _u64, _vp, _i32, _vp],
     "mmrca_mha_cls_bwd": [_vp] * 6 + [_i32] * 4 + [_f32, _f32, _u64, _vp, _i32, _vp],
     "mmrca_add_layernorm_fwd": [_vp] * 8 + [_i64, _i32, _i64, _i64, _f32, _f32, _u64, _f32, _u64, _i32, _vp],
@@ -396,6 +397,15 @@ def mha_cross_fwd(q, ldq, k, ldk, v, ldv, out, ldo, B, H, Sq, Skv, dh, scale, dt
     _dev(q, "q"); _dev(k, "k"); _dev(v, "v"); _dev(out, "out")
     _check(load().mmrca_mha_cross_fwd(ptr(q), ldq, ptr(k), ldk, ptr(v), ldv, ptr(out), ldo, B, H, Sq, Skv, dh, scale, drop_p,
                                       drop_seed, dtype, impl, stream_ptr()), "mha_cross_fwd")
+
+
+def mha_cross_fwd_x3(q, ldq, k, ldk, v, ldv, out_planes, ldo, B, H, Sq, Skv, dh, scale, drop_p=0.0, drop_seed=0):
+    """bf16x3 attention forward with separate fp32 q / k / v operands; the context as (hi, lo) bf16 planes"""
+    _dev(q, "q"); _dev(k, "k"); _dev(v, "v"); _dev(out_planes[0], "out")
+    if q.dtype != torch.float32 or k.dtype != torch.float32 or v.dtype != torch.float32 or out_planes[0].dtype != torch.bfloat16:
+        raise MmrcaError("mha_cross_fwd_x3: q / k / v must be fp32 and the output planes bf16")
+    _check(load().mmrca_mha_cross_fwd_x3(ptr(q), ldq, ptr(k), ldk, ptr(v), ldv, ptr(out_planes[0]), ptr(out_planes[1]), ldo, B, H, Sq, Skv, dh,
+                                         scale, drop_p, drop_seed, stream_ptr()), "mmrca_mha_cross_fwd_x3")
 
 
 def mha_cls_fwd(qkv, key_mask, out, lse, B, H, S, dh, scale, dtype, drop_p=0.0, drop_seed=0, cu=None):

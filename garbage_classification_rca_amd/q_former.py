@@ -150,9 +150,21 @@ class _FrozenStore:
 class Blip2QFormerEngine:
     """Frozen ViT-g + Q-Former forward and the trainable 4-class classifier of one replica on one GPU."""
 
-    def __init__(self, spec: Blip2Spec = BLIP2_OPT_2_7B, dtype: torch.dtype = torch.bfloat16, device="cuda",
+    def __init__(self, spec: Blip2Spec = BLIP2_OPT_2_7B, dtype=torch.bfloat16, device="cuda",
                  gemm_impl: int = L.IMPL_AUTO, attn_impl: int = L.IMPL_AUTO):
+        """dtype: torch.bfloat16 (fastest; logits ~2e-2 from the reference's fp32 arithmetic at full depth) | torch.float32 (fp32
+        matrix cores / VALU attention: the parity mode) | "bf16x3f" (= "bf16x3" here, the towers are frozen and forward-only): fp32
+        residual stream, LayerNorm and softmax statistics, every nn.Linear AND both attention products as three-pass split-bf16
+        products on the bf16 matrix cores -- the fp32 arithmetic to ~1e-5 on the logits at a third of the bf16 MFMA rate: the fast
+        mode inside the 1e-3 tolerance."""
         L.load()
+        name = dtype.lower() if isinstance(dtype, str) else ""
+        self.x3 = name in ("bf16x3f", "bf16x3")
+        if self.x3:
+            dtype = torch.float32
+        elif isinstance(dtype, str):
+            dtype = {"bf16": torch.bfloat16, "fp32": torch.float32, "f32": torch.float32}[name]
+        self.mode = "bf16x3f" if self.x3 else ("bf16" if dtype == torch.bfloat16 else "fp32")
         self.s, self.dtype, self.device = spec, dtype, torch.device(device)
         self.dt = L.dtype_code(dtype)
         self.gemm_impl, self.attn_impl = gemm_impl, attn_impl
@@ -160,6 +172,10 @@ class Blip2QFormerEngine:
             raise ValueError("hidden sizes must be divisible by their head counts (modeling_blip_2.py:291-295, 540-544)")
         self.entries = blip2_params(spec)
         self.store = _FrozenStore(self.entries, dtype, self.device)
+        # bf16x3f: the fp32 store is the master (LayerNorm weights, biases, the K = 588 patch projection read it); the GEMM operands are
+        # its two bf16 planes hi + lo, rebuilt after every load (2 x 2.2 GB next to the 4.4 GB master for blip2-opt-2.7b)
+        self.w_hi = torch.zeros(self.store.total, dtype=torch.bfloat16, device=self.device) if self.x3 else None
+        self.w_lo = torch.zeros(self.store.total, dtype=torch.bfloat16, device=self.device) if self.x3 else None
         for i in range(spec.q_layers):      # fused operands must be adjacent and unpadded
             p = f"qformer.encoder.layer.{i}.attention.attention."
             o = [self.store.offsets[p + n + ".weight"] for n in ("query", "key", "value")]
@@ -217,6 +233,11 @@ class Blip2QFormerEngine:
             if classifier_sd is not None:
                 self.cls_weight.copy_(torch.as_tensor(classifier_sd["classifier.weight"]).to(self.device, torch.float32))
                 self.cls_bias.copy_(torch.as_tensor(classifier_sd["classifier.bias"]).to(self.device, torch.float32))
+        self._refresh_planes()
+
+    def _refresh_planes(self):
+        if self.x3:
+            L.split_f32(self.store.w, self.w_hi, self.w_lo, self.store.total)
 
     def classifier_state_dict(self) -> Dict[str, "torch.Tensor"]:
         return {"classifier.weight": self.cls_weight.detach().cpu().clone(), "classifier.bias": self.cls_bias.detach().cpu().clone()}
@@ -236,6 +257,7 @@ class Blip2QFormerEngine:
                     v.copy_((torch.randn(shp, generator=g) * 0.02).to(self.dtype))
             bound = 1.0 / math.sqrt(self.s.q_dim)
             self.cls_p.copy_((torch.rand(self.n_cls, generator=g) * 2 - 1) * bound)
+        self._refresh_planes()
 
     def train(self, mode: bool = True):
         self.training = bool(mode)
@@ -263,6 +285,27 @@ class Blip2QFormerEngine:
         b = self.store.view(bkey) if wnumel is None else self.store.flat(bkey, N)
         L.gemm(x, w, out, bias=b, addend=addend, M=M, N=N, K=K, lda=K, ldb=K, ldc=N, a_layout=L.ROWK, b_layout=L.ROWK, act=act,
                dtype=self.dt, impl=self.gemm_impl)
+
+    def pbuf(self, name, rows, cols):
+        """an fp32 [rows, cols] matrix as two bf16 planes (the operand form of the bf16x3 GEMMs)"""
+        return self.buf(name + ".hi", rows, cols, torch.bfloat16), self.buf(name + ".lo", rows, cols, torch.bfloat16)
+
+    def _lin3(self, xp, wkey, bkey, out, M, N, K, act=L.ACT_NONE, addend=None, wnumel=None):
+        """bf16x3 nn.Linear: xp = (hi, lo) planes of the fp32 input; out = an fp32 tensor, or a (hi, lo) pair when only other
+        bf16x3 GEMMs read it; bias / addend fp32"""
+        off = self.store.offsets[wkey][0]
+        n = self.store.offsets[wkey][2] if wnumel is None else wnumel
+        w = (self.w_hi[off:off + n], self.w_lo[off:off + n])
+        b = self.store.view(bkey) if wnumel is None else self.store.flat(bkey, N)
+        planes = isinstance(out, tuple)
+        L.gemm_x3(xp, w, out[0] if planes else out, C_lo=out[1] if planes else None, bias=b, addend=addend, M=M, N=N, K=K, lda=K, ldb=K,
+                  ldc=N, a_layout=L.ROWK, b_layout=L.ROWK, act=act, impl=L.IMPL_AUTO)
+
+    def _ln3(self, x, res, pfx, y, yp, rows, D, eps, in_drop=(0.0, 0), out_drop=(0.0, 0)):
+        """fp32 LayerNorm whose output leaves as two bf16 planes yp (and as fp32 in y when it is also the next residual)"""
+        mean, rstd = self.buf("ln_mean", rows, 1, torch.float32), self.buf("ln_rstd", rows, 1, torch.float32)
+        L.add_layernorm_fwd(x, res, self.store.view(pfx + ".weight"), self.store.view(pfx + ".bias"), None, y, mean, rstd, rows, D,
+                            D, D, eps, L.F32, in_drop=in_drop, out_drop=out_drop, y_planes=yp)
 
     def _ln(self, x, res, pfx, y, rows, D, eps, in_drop=(0.0, 0), out_drop=(0.0, 0), sum_out=None):
         mean, rstd = self.buf("ln_mean", rows, 1, torch.float32), self.buf("ln_rstd", rows, 1, torch.float32)
@@ -292,9 +335,11 @@ class Blip2QFormerEngine:
         x = self.buf("vx", M, D)
         L.vit_assemble_fwd(proj, self.store.view("vision_model.embeddings.class_embedding"),
                            self.store.view("vision_model.embeddings.position_embedding"), x, B, nP, D, self.dt)
+        dh = D // s.v_heads
+        if self.x3:
+            return self._vision_layers_x3(x, B)
         y, qkv, ao, x1 = self.buf("vy", M, D), self.buf("vqkv", M, 3 * D), self.buf("vao", M, D), self.buf("vx1", M, D)
         h = self.buf("vh", M, s.v_mlp)
-        dh = D // s.v_heads
         # GEMMs run over whole 256-row tiles of the (zero-padded) buffers: that is what lets the dispatcher give the
         # persistent 256x256 kernel the shapes it takes (N % 256 == 0: FFN1 and the Q-Former's K|V projection); rows >= M
         # are never read by the attention or the LayerNorms.  The residual adds ride on the GEMM epilogues (addend): moving
@@ -317,10 +362,75 @@ class Blip2QFormerEngine:
         self._ln(x, None, "vision_model.post_layernorm", emb, M, D, s.v_eps)                                               # :521
         return emb
 
+    def _vision_layers_x3(self, x, B):
+        """the 39 layers + post_layernorm of vision_forward in the bf16x3 form: fp32 residual stream x, LayerNorm outputs / attention
+        context / MLP hidden as bf16 plane pairs, q|k|v fp32 (the attention splits them while staging).  Returns image_embeds as a
+        plane pair (its only readers are the Q-Former's K|V projections)."""
+        s = self.s
+        D, T = s.v_dim, s.v_tokens
+        M = B * T
+        Mg = _round_up(M, ROWPAD)
+        dh = D // s.v_heads
+        yp, aop, hp = self.pbuf("vy", M, D), self.pbuf("vao", M, D), self.pbuf("vh", M, s.v_mlp)
+        qkv, x1 = self.buf("vqkv", M, 3 * D), self.buf("vx1", M, D)
+        if Mg > M:
+            x[M:Mg].zero_()
+        for i in range(s.v_layers):
+            p = f"vision_model.encoder.layers.{i}."
+            self._ln3(x, None, p + "layer_norm1", None, yp, M, D, s.v_eps)
+            self._lin3(yp, p + "self_attn.qkv.weight", p + "self_attn.qkv.bias", qkv, Mg, 3 * D, D)
+            L.mha_cross_fwd_x3(qkv, 3 * D, qkv[:, D:], 3 * D, qkv[:, 2 * D:], 3 * D, aop, D, B, s.v_heads, T, T, dh, dh ** -0.5)
+            self._lin3(aop, p + "self_attn.projection.weight", p + "self_attn.projection.bias", x1, Mg, D, D, addend=x)
+            self._ln3(x1, None, p + "layer_norm2", None, yp, M, D, s.v_eps)
+            self._lin3(yp, p + "mlp.fc1.weight", p + "mlp.fc1.bias", hp, Mg, s.v_mlp, D, act=L.ACT_GELU)
+            self._lin3(hp, p + "mlp.fc2.weight", p + "mlp.fc2.bias", x, Mg, D, s.v_mlp, addend=x1)
+        emb = self.pbuf("image_embeds", M, D)
+        self._ln3(x, None, "vision_model.post_layernorm", None, emb, M, D, s.v_eps)
+        return emb
+
+    def _qformer_forward_x3(self, emb, B: int, drop_seed: int):
+        """qformer_forward in the bf16x3 form (emb: the image tokens as a plane pair)"""
+        s = self.s
+        Q, NQ, T, D = s.q_dim, s.n_query, s.v_tokens, s.v_dim
+        M, Mi = B * NQ, B * T
+        hp_, ap = (s.hidden_drop, s.attn_drop) if self.training else (0.0, 0.0)
+        H, dh = s.q_heads, Q // s.q_heads
+        sd = lambda layer, site: self._site_seed(drop_seed, layer, site)
+        qe = self.buf("q_embed", M, Q)
+        qe[:M].view(B, NQ, Q).copy_(self.store.view("query_tokens").expand(B, NQ, Q))
+        hcur, hnext = self.buf("q_h0", M, Q), self.buf("q_h1", M, Q)
+        hcp, hnp = self.pbuf("q_h0p", M, Q), self.pbuf("q_h1p", M, Q)
+        self._ln3(qe, None, "qformer.layernorm", hcur, hcp, M, Q, s.q_eps, out_drop=(hp_, sd(0, 0)))
+        qkv, o, cq, ckv = self.buf("q_qkv", M, 3 * Q), self.buf("q_o", M, Q), self.buf("q_cq", M, Q), self.buf("q_ckv", Mi, 2 * Q)
+        aop, ffp = self.pbuf("q_ao", M, Q), self.pbuf("q_ff", M, s.q_mlp)
+        for i in range(s.q_layers):
+            p = f"qformer.encoder.layer.{i}."
+            self._lin3(hcp, p + "attention.attention.query.weight", p + "attention.attention.query.bias", qkv, M, 3 * Q, Q, wnumel=3 * Q * Q)
+            L.mha_cross_fwd_x3(qkv, 3 * Q, qkv[:, Q:], 3 * Q, qkv[:, 2 * Q:], 3 * Q, aop, Q, B, H, NQ, NQ, dh, dh ** -0.5, drop_p=ap,
+                               drop_seed=sd(i + 1, 1))
+            self._lin3(aop, p + "attention.output.dense.weight", p + "attention.output.dense.bias", o, M, Q, Q)
+            self._ln3(o, hcur, p + "attention.output.LayerNorm", hnext, hnp, M, Q, s.q_eps, in_drop=(hp_, sd(i + 1, 2)))
+            hcur, hnext, hcp, hnp = hnext, hcur, hnp, hcp
+            if i % s.cross_freq == 0:
+                self._lin3(hcp, p + "crossattention.attention.query.weight", p + "crossattention.attention.query.bias", cq, M, Q, Q)
+                self._lin3(emb, p + "crossattention.attention.key.weight", p + "crossattention.attention.key.bias", ckv, _round_up(Mi, ROWPAD),
+                           2 * Q, D, wnumel=2 * Q * D)
+                L.mha_cross_fwd_x3(cq, Q, ckv, 2 * Q, ckv[:, Q:], 2 * Q, aop, Q, B, H, NQ, T, dh, dh ** -0.5, drop_p=ap, drop_seed=sd(i + 1, 3))
+                self._lin3(aop, p + "crossattention.output.dense.weight", p + "crossattention.output.dense.bias", o, M, Q, Q)
+                self._ln3(o, hcur, p + "crossattention.output.LayerNorm", hnext, hnp, M, Q, s.q_eps, in_drop=(hp_, sd(i + 1, 4)))
+                hcur, hnext, hcp, hnp = hnext, hcur, hnp, hcp
+            self._lin3(hcp, p + "intermediate_query.dense.weight", p + "intermediate_query.dense.bias", ffp, M, s.q_mlp, Q, act=L.ACT_GELU)
+            self._lin3(ffp, p + "output_query.dense.weight", p + "output_query.dense.bias", o, M, Q, s.q_mlp)
+            self._ln3(o, hcur, p + "output_query.LayerNorm", hnext, hnp, M, Q, s.q_eps, in_drop=(hp_, sd(i + 1, 5)))
+            hcur, hnext, hcp, hnp = hnext, hcur, hnp, hcp
+        return hcur
+
     def qformer_forward(self, image_embeds: torch.Tensor, B: int, drop_seed: int = 0) -> torch.Tensor:
         """Blip2QFormerModel.forward with query_embeds = query_tokens.expand(B) and an all-ones image mask
         (modeling_blip_2.py:889-950, called at :1633-1639 region of Blip2ForConditionalGeneration.get_image_features).
         Returns last_hidden_state [B*32 (row-padded), 768].  Dropout (hidden 0.1, attention 0.1) is active in train mode."""
+        if self.x3:
+            return self._qformer_forward_x3(image_embeds, B, drop_seed)
         s = self.s
         Q, NQ, T, D = s.q_dim, s.n_query, s.v_tokens, s.v_dim
         M, Mi = B * NQ, B * T

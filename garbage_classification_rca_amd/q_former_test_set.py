@@ -87,7 +87,7 @@ def generate_report_and_image(test_report_dict, test_accuracy, conf_matrix, out_
 def main(argv=None, spec: QF.Blip2Spec = QF.BLIP2_OPT_2_7B, out_dir: str = "."):
     args = args_parser(argv)
     device = torch.device("cuda:0")
-    engine = QF.Blip2QFormerEngine(spec, dtype=torch.bfloat16 if args.dtype == "bf16" else torch.float32, device=device)
+    engine = QF.Blip2QFormerEngine(spec, dtype={"bf16": torch.bfloat16, "fp32": torch.float32}.get(args.dtype, "bf16x3f"), device=device)
     engine.init_parameters(seed=0)
     src = args.blip2_checkpoint or args.model_path
     if src:

@@ -105,7 +105,9 @@ def save_checkpoint(engine: QF.Blip2QFormerEngine, epoch: int, acc: float, out_d
 def main(argv=None, spec: QF.Blip2Spec = QF.BLIP2_OPT_2_7B, out_dir: str = "."):
     args = args_parser(argv)
     device = torch.device("cuda:0")                                                        # :201
-    dtype = torch.bfloat16 if args.dtype == "bf16" else torch.float32
+    # --dtype (options.py): bf16x3f by default = the reference's fp32 arithmetic (q_former_training.py:279-304 runs fp32) to ~1e-5 on the
+    # bf16 matrix cores; bf16 is the opt-in fast mode (logits ~2e-2 off at full depth)
+    dtype = {"bf16": torch.bfloat16, "fp32": torch.float32}.get(args.dtype, "bf16x3f")
     engine = QF.Blip2QFormerEngine(spec, dtype=dtype, device=device)
     if args.blip2_checkpoint:
         engine.init_parameters(seed=0)          # the classifier's nn.Linear default init; the frozen part is overwritten below

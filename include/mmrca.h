@@ -299,6 +299,15 @@ int mmrca_mha_fwd_planes_in(const void* qkv_hi, const void* qkv_lo, const int32_
  * (transformers modeling_distilbert.py:122-203 / torchvision MultiheadAttention under CVPR_code/multimodal_model.py:651-659). */
 int mmrca_mha_fwd_x3(const void* qkv_hi, const void* qkv_lo, const int32_t* key_mask, void* out_hi, void* out_lo, float* lse,
                      int B, int H, int S, int dh, float scale, float drop_p, uint64_t drop_seed, const int32_t* cu_seqlens, void* stream);
+/* The bf16x3 form of mmrca_mha_cross_fwd: q / k / v are fp32 (separate operands, row strides in elements), every product is
+ * three-pass on the bf16 matrix cores with fp32 softmax statistics, the context is written as two bf16 planes out_hi + out_lo (the
+ * operand form of mmrca_gemm_x3).  Any head dim % 8 == 0 <= 128, any S_kv (keys are walked in chunks with running softmax
+ * statistics), S_q <= 384, attention-probability dropout.  The fp32 arithmetic of Blip2Attention (ViT-g: 257 tokens, 16 heads of 88,
+ * transformers modeling_blip_2.py:282-354) and Blip2QFormerMultiHeadAttention (:536-606) under q_former_training.py:279-304, for the
+ * compliant (<= 1e-3) mode of BASELINE configs[4]. */
+int mmrca_mha_cross_fwd_x3(const float* q, int64_t ldq, const float* k, int64_t ldk, const float* v, int64_t ldv, void* out_hi,
+                           void* out_lo, int64_t ldo, int B, int H, int Sq, int Skv, int dh, float scale, float drop_p,
+                           uint64_t drop_seed, void* stream);
 /* mmrca_mha_bwd followed by dqkv_colsum[3*H*dh] (fp32) += column sums of the stored dqkv = the bias gradient of the QKV
  * in-projection (one call; the reduction is a separate HBM pass -- fusing it into the MFMA kernels measured slower).
  * total_rows = number of token rows (B*S padded, cu_seqlens[B] packed). */

@@ -210,4 +210,14 @@ def test_configs4_qformer_full_depth_b2_fp32_against_the_oracle():
     got16 = eng16.eval().forward(torch.from_numpy(px).cuda()).cpu()
     e16 = rel(got16, exp)
     print(f"configs[4] at full depth, bf16 towers (the benchmarked dtype): logits relative error {e16:.2e}")
-    assert e16 < 2e-1          # bf16 storage through 39 + 12 layers of 1408-wide activations; stated, not the compliant mode
+    assert e16 < 5e-2          # bf16 storage through 39 + 12 layers of 1408-wide activations (measured 2.1e-2); stated, not the compliant mode
+    del eng16
+    torch.cuda.empty_cache()
+    # the compliant mode of configs[4] (round 5): the frozen towers in the bf16x3 form -- every nn.Linear and both attention products
+    # three-pass on the bf16 matrix cores, fp32 residual stream / LayerNorm / softmax statistics -- inside north_star's 1e-3
+    eng3 = QF.Blip2QFormerEngine(spec, dtype="bf16x3f", device="cuda")
+    eng3.load_state_dict(sd, cls)
+    got3 = eng3.eval().forward(torch.from_numpy(px).cuda()).cpu()
+    e3 = rel(got3, exp)
+    print(f"configs[4] at full depth, bf16x3f towers (the compliant mode): logits relative error {e3:.2e}")
+    assert e3 < 1e-3, e3

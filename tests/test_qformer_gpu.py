@@ -59,6 +59,30 @@ def test_cross_attention_separate_operands_and_dropout(B, H, Sq, Skv, dh, dtype,
         assert (got - exp).abs().max().item() < tol * max(1.0, exp.abs().max().item()), (p, seed)
 
 
+@pytest.mark.parametrize("B,H,Sq,Skv,dh", [(2, 16, 257, 257, 88), (3, 12, 32, 257, 64), (2, 12, 32, 32, 64), (1, 3, 33, 50, 40), (1, 2, 50, 300, 128),
+                                           (2, 2, 8, 17, 32), (1, 2, 384, 161, 96)])
+def test_cross_attention_x3_matches_fp32_arithmetic(B, H, Sq, Skv, dh):
+    """mmrca_mha_cross_fwd_x3 (fp32 operands, three-pass products on the bf16 matrix cores, keys walked in chunks with running
+    softmax statistics, context as two bf16 planes) against float64 attention of the same fp32 operands: the error of fp32 arithmetic
+    (~1e-6), not of bf16 (~1e-2).  The ViT-g shape (one, two and -- with 160-key chunks -- partially filled chunks), the Q-Former's
+    self- and cross-attention with dropout, ragged tiles, head dims 32 .. 128, three query tiles per wave (S_q = 384)."""
+    g = torch.Generator().manual_seed(Sq * 13 + Skv + dh)
+    D = H * dh
+    q = (torch.randn(B * Sq, D, generator=g) * 0.9).to(DEV)
+    kv = (torch.randn(B * Skv, 2 * D, generator=g) * 0.9).to(DEV)
+    qf, kvf = q.double().cpu().view(B, Sq, D), kv.double().cpu().view(B, Skv, 2 * D)
+    for p, seed in ((0.0, 0), (0.1, 12345)):
+        hi = torch.full((B * Sq, D), float("nan"), dtype=torch.bfloat16, device=DEV)
+        lo = torch.full_like(hi, float("nan"))
+        L.mha_cross_fwd_x3(q, D, kv, 2 * D, kv[:, D:], 2 * D, (hi, lo), D, B, H, Sq, Skv, dh, dh ** -0.5, drop_p=p, drop_seed=seed)
+        torch.cuda.synchronize()
+        got = (hi.float() + lo.float()).cpu().view(B, Sq, D).double()
+        mask = OQ.keep_mask(seed, (B * H, Sq, Skv), p) if p > 0 else None
+        exp = _attn_ref(qf, kvf[..., :D], kvf[..., D:], H, mask)
+        err = (got - exp).abs().max().item() / max(1.0, exp.abs().max().item())
+        assert err < 3e-5, (p, err)           # two bf16 planes carry 16 bits: 1.5e-5 of the largest entry is the output format's own floor
+
+
 def test_cross_attention_rejects_bad_arguments():
     q = torch.zeros(64, 64, dtype=torch.float32, device=DEV)
     with pytest.raises(L.MmrcaError):       # fp32 cannot be forced onto the bf16 MFMA kernel
@@ -131,6 +155,29 @@ def test_engine_eval_logits_match_oracle(spec, B):
     rel16 = (got16 - exp).abs().max().item() / scale
     assert rel16 < 5e-2, rel16                  # bf16 storage of 1408-wide activations through 2 + 2 layers
     assert (got16.argmax(1) == exp.argmax(1)).all() or rel16 < 1e-2
+
+
+def test_engine_bf16x3f_mode_matches_oracle_in_eval_and_train_mode():
+    """the compliant mode of configs[4] (fp32 values as two bf16 planes, three matrix-core passes per product in every nn.Linear and
+    in both attention products): real widths (K = 1408, head dim 88, 257 tokens, 32 queries x 257 keys) at two layers each, eval
+    mode and train mode (the Q-Former's dropout sites with host-rebuilt masks) against the fp32 oracle -- fp32-grade agreement"""
+    spec, B = WIDE, 2
+    sd, cls = _state(spec)
+    px = proc_input("qf_px_%d" % spec.v_dim, (B, 3, spec.image_size, spec.image_size))
+    eng = _engine(spec, "bf16x3f", sd, cls).eval()
+    assert eng.x3 and eng.mode == "bf16x3f" and eng.dtype == torch.float32
+    exp, _ = OQ.forward_logits(sd, cls, torch.from_numpy(px), _cfg(spec), train=False)
+    got = eng.forward(torch.from_numpy(px).to(DEV)).cpu()
+    rel = (got - exp).abs().max().item() / exp.abs().max().item()
+    print("bf16x3f Q-Former path, eval, 2 + 2 layers at real widths: logits vs oracle", rel)
+    assert rel < 1e-4, rel
+    eng.train()
+    got_t = eng.forward(torch.from_numpy(px).to(DEV), drop_seed=77).cpu()
+    exp_t, _ = OQ.forward_logits(sd, cls, torch.from_numpy(px), _cfg(spec), train=True, drop_seed=77)
+    rel_t = (got_t - exp_t).abs().max().item() / exp_t.abs().max().item()
+    assert rel_t < 1e-4, rel_t
+    assert (exp_t - exp).abs().max().item() > 1e-3 * exp.abs().max().item()       # the masks do act
+    eng.release_buffers()
 
 
 def test_engine_train_mode_dropout_matches_oracle_masks():
