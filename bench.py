@@ -198,11 +198,50 @@ def compliant_leg(args, dev, parity, steps=12, warmup=3):
         torch.cuda.synchronize()
         elapsed = time.perf_counter() - t0
         own = parity_check(model, ids, mask, images, others=False)
+        # roofline of THIS leg's GEMMs, measured like the headline's: the same steps replayed on one stream with HIP events around every
+        # matrix-core GEMM launch.  Executed work counts the three passes of a bf16x3 product (3 x 2MNK); useful work is the fp32
+        # product it stands for (2MNK).  The backward of bf16x3f is single-pass bf16: executed = useful there.
+        from garbage_classification_rca_amd import lib as L
+        eng = model.engine
+        saved_streams = (eng._side_v, eng._side_t, eng._side, eng._text_stream)
+        eng._side_v = eng._side_t = eng._side = eng._text_stream = None
+        step(0)
+        torch.cuda.synchronize()
+        L.GEMM_PROFILE = []
+        replay = 2
+        for i in range(replay):
+            step(i)
+        torch.cuda.synchronize()
+        prof, L.GEMM_PROFILE = L.GEMM_PROFILE, None
+        eng._side_v, eng._side_t, eng._side, eng._text_stream = saved_streams
+    g_exec = sum(p[0] for p in prof)
+    g_useful = sum(2.0 * p[4][0] * p[4][1] * p[4][2] for p in prof)
+    g_ms = sum(p[2].elapsed_time(p[3]) for p in prof)
+    x3_ms = sum(p[2].elapsed_time(p[3]) for p in prof if p[0] > 2.5 * p[4][0] * p[4][1] * p[4][2])
+    traffic, traffic_src = None, "no PMC pass of this mode is committed"
+    pmc_json = os.path.join(ROOT, "profiles", "r05_pmc_hbm_traffic_bf16x3f.json")
+    if os.path.exists(pmc_json):
+        with open(pmc_json) as fh:
+            pj = json.load(fh)
+        if pj.get("gemm_sources_sha256") == gemm_sources_sha256():
+            traffic, traffic_src = pj.get("gemm_hbm_bytes_per_launch_mean"), "profiles/r05_pmc_hbm_traffic_bf16x3f.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes, x2 gfx950 fetch correction; this build's GEMM sources)"
+        else:
+            traffic_src = "profiles/r05_pmc_hbm_traffic_bf16x3f.json is STALE (measured on other GEMM sources); not quoted"
+    roof = {"bound": "mfma", "achieved": round(g_exec / (g_ms * 1e-3) / 1e12, 2) if g_ms > 0 else 0.0, "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
+            "frac": round(g_exec / (g_ms * 1e-3) / 1e12 / PEAK_BF16_TFLOPS, 4) if g_ms > 0 else 0.0,
+            "fp32_equivalent_useful_TFLOPs": round(g_useful / (g_ms * 1e-3) / 1e12, 2) if g_ms > 0 else 0.0,
+            "useful_frac": round(g_useful / (g_ms * 1e-3) / 1e12 / PEAK_BF16_TFLOPS, 4) if g_ms > 0 else 0.0,
+            "gemm_ms_per_step": round(g_ms / replay, 3), "three_pass_gemm_ms_per_step": round(x3_ms / replay, 3), "launches_per_step": len(prof) // replay,
+            "traffic": traffic, "traffic_source": traffic_src,
+            "flops_counted": "achieved = executed matrix-core work (3 x 2MNK for the forward's three-pass products, 2MNK for the bf16 backward) / GEMM "
+                             "HIP-event time; fp32_equivalent_useful = 2MNK of every product / the same time",
+            "measured_in": f"single-stream replay of {replay} steps after this leg's timed region"}
     model.engine.release_buffers()
     key = mode + "_logits_rel"
     out = {"dtype": mode, "value": round(B * steps / elapsed, 2), "unit": "samples/s", "ms_per_step": round(elapsed / steps * 1e3, 3), "steps": steps,
            "warmup": warmup, "per_gpu_batch": B, "logits_rel": own[key], "logits_rel_measured_on": f"this leg's weights after its {warmup + steps} steps, 8 pairs vs the oracle",
            "logits_rel_on_headline_weights": parity.get(fwd_of[mode] + "_logits_rel"), "north_star_bound": 1e-3, "final_loss": round(float(loss.item()), 4),
+           "roofline": roof,
            "what": {"bf16x3f": "forward: fp32 residual stream / LayerNorm / attention (fp32 matrix cores), every nn.Linear as a three-pass split-bf16 product "
                                "(the bf16x3 forward, same logits); backward: the bf16 mode's (single-pass bf16 products and bf16 attention backward on the hi planes "
                                "of the saved activations, bf16 gradient buffers, fp32 gradient accumulation and optimizer); a conv image backbone runs its bf16 "
@@ -284,7 +323,7 @@ def bench_qformer(args):
     peak = PEAK_BF16_TFLOPS if (args.dtype == "bf16" or x3) else PEAK_F32_TFLOPS
     # logits of the timed mode against the oracle (full depth, 2 images, eval mode): the number north_star bounds by 1e-3
     parity = None
-    if not args.no_cpu_baseline or os.environ.get("MMRCA_BENCH_QFORMER_PARITY") == "1":
+    if not args.no_cpu_baseline or args.parity:
         parity = qformer_parity(eng, spec, dev)
     T, D_, NQ = spec.v_tokens, spec.v_dim, spec.n_query
     attn_flop = B * (spec.v_layers * 4.0 * T * T * D_ + spec.q_layers * 4.0 * NQ * NQ * spec.q_dim
@@ -393,6 +432,7 @@ def main():
     ap.add_argument("--batch", type=int, default=256, help="per-GPU batch (BASELINE config: 256)")
     ap.add_argument("--seq_len", type=int, default=64)
     ap.add_argument("--no_cpu_baseline", action="store_true")
+    ap.add_argument("--parity", action="store_true", help="measure the logits parity object even with --no_cpu_baseline (secondary lines)")
     ap.add_argument("--no_compliant", action="store_true", help="skip the second timed leg in the fastest mode that meets the 1e-3 logits bound")
     ap.add_argument("--dtype", default="bf16", choices=("bf16", "fp32", "bf16x3", "bf16x3f"),
                     help="bf16 (the benchmarked configuration) | bf16x3: the fast <= 1e-3 mode -- fp32 storage / residual stream / LayerNorm / "
@@ -585,7 +625,7 @@ def main():
         # rocprofv3 --pmc passes over THIS command (tools/pmc_traffic.py) is quoted, next to the algorithmic bytes
         # (operands once + outputs once, from the launch shapes of this run)
         traffic, traffic_src = None, None
-        for pmc_name in ("r04_pmc_hbm_traffic.json", "r03_pmc_hbm_traffic.json", "r02_pmc_hbm_traffic.json", "r01_pmc_hbm_traffic.json"):
+        for pmc_name in ("r05_pmc_hbm_traffic.json", "r04_pmc_hbm_traffic.json", "r03_pmc_hbm_traffic.json", "r02_pmc_hbm_traffic.json", "r01_pmc_hbm_traffic.json"):
             pmc_json = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", pmc_name)
             if os.path.exists(pmc_json):
                 with open(pmc_json) as fh:
@@ -593,7 +633,7 @@ def main():
                 # the summary names the GEMM sources it was measured on (tools/pmc_traffic.py); a kernel edit since then makes it stale
                 if pj.get("gemm_sources_sha256") != gemm_sources_sha256():
                     traffic_src = (f"profiles/{pmc_name} is STALE (measured on other GEMM sources: {str(pj.get('gemm_sources_sha256'))[:12]} vs "
-                                   f"{gemm_sources_sha256()[:12]} now); not quoted -- re-run tools/r04_artifacts.sh")
+                                   f"{gemm_sources_sha256()[:12]} now); not quoted -- re-run tools/r05_artifacts.sh")
                     break
                 traffic = pj.get("gemm_hbm_bytes_per_launch_mean")
                 traffic_src = (f"profiles/{pmc_name} (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes, x2 gfx950 fetch correction; "
@@ -751,9 +791,10 @@ def main():
                 "note": "frac = byte floor / measured step: how far the step is from the roofline that binds it; the MFMA frac above covers the GEMM launches only"}
         if comm is not None:
             out["comm"] = comm
-        if not args.no_cpu_baseline and world == 1:
+        if (not args.no_cpu_baseline or args.parity) and world == 1:
             with contextlib.redirect_stdout(io.StringIO()):
                 out["parity"] = parity_check(model, ids, mask, images)
+        if not args.no_cpu_baseline and world == 1:
             if args.dtype == "bf16" and not args.frozen and not args.no_compliant:
                 eng.release_buffers()
                 out["compliant"] = compliant_leg(args, dev, out["parity"])
