@@ -784,7 +784,7 @@ def main():
             floor_ms = tot_b / 8e12 * 1e3
             out["roofline"]["hbm"] = {
                 "bound": "hbm", "what": "whole train step of the conv image encoder + text encoder: algorithmic HBM bytes of every launch (operands read once + results "
-                                        "written once, per launch arguments; GEMM ms = HIP events of the matrix-core launches, a few small GEMMs excluded) against the 8 TB/s peak",
+                                        "written once, per launch arguments; every launch of every family -- all GEMMs included since round 5 -- timed by HIP events) against the 8 TB/s peak",
                 "algorithmic_GB_per_step": round(tot_b / 1e9, 2), "floor_ms_at_8TBps": round(floor_ms, 2), "floor_ms_at_6.3TBps_achievable": round(tot_b / 6.3e12 * 1e3, 2),
                 "step_ms": round(elapsed / args.steps * 1e3, 2), "achieved_TBps": round(tot_b / (elapsed / args.steps) / 1e12, 3), "peak_TBps": 8.0,
                 "frac": round(floor_ms / (elapsed / args.steps * 1e3), 4), "families": table,

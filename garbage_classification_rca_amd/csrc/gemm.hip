@@ -638,9 +638,16 @@ gemm_mfma_k(const bf16_t* __restrict__ A, const bf16_t* __restrict__ B, void* __
 // shift = the layer's running mean keeps s2 - s1^2 / n free of cancellation.
 struct BnStat { const float* shift; float* s1; float* s2; };
 
-template <bool KROW>
+// 16 zero bytes in global memory: the source of a B chunk past the end of the contraction (see stage_tile32's EDGE forms)
+__device__ __attribute__((aligned(16))) static const unsigned int mmrca_zero_chunk[4] = {0u, 0u, 0u, 0u};
+
+// EDGE (round 5): the last 32-deep step of a contraction that is a multiple of 8 but not of 32 (EfficientNetV2-M's channel counts:
+// 80, 176, 304 -- the reference's default image model put 35 + 33 of its 1x1 convolutions on the general kernel at ~65 TFLOP/s for
+// that).  LDS-DMA cannot write zeros, so the chunks past `kend` are FETCHED as zeros on the B side (one 16-byte zero chunk in
+// global memory) and as a duplicate of a valid chunk on the A side: finite x 0 contributes nothing.  0: no edge, 1: A, 2: B.
+template <bool KROW, int EDGE = 0>
 __device__ __forceinline__ void stage_tile32(const bf16_t* __restrict__ base, int64_t ld, int64_t row0, int64_t rows_total,
-                                             int64_t k0, char* lds_tile, int wave, int lane) {
+                                             int64_t k0, char* lds_tile, int wave, int lane, int64_t kend = 0) {
 #pragma unroll
   for (int ii = 0; ii < 2; ++ii) {
     const int i = wave * 2 + ii;                  // 8 wave-instructions of 1 KiB per operand tile
@@ -650,14 +657,20 @@ __device__ __forceinline__ void stage_tile32(const bf16_t* __restrict__ base, in
       const int c = (lane & 3) ^ ((4 - (r >> 2)) & 3);
       int64_t gr = row0 + r;
       if (gr > rows_total - 1) gr = rows_total - 1;
-      src = base + gr * ld + k0 + c * 8;
+      int64_t kc = k0 + c * 8;
+      if (EDGE == 1 && kc >= kend) kc = kend - 8;
+      src = base + gr * ld + kc;
+      if (EDGE == 2 && kc >= kend) src = reinterpret_cast<const bf16_t*>(mmrca_zero_chunk);
     } else {
       const int kr = 4 * i + (lane >> 4);
       const int chp = lane & 15;
       const int c = ((((chp >> 1) ^ krow_f(kr))) << 1) | (chp & 1);
       int64_t col = row0 + c * 8;
       if (col > rows_total - 8) col = rows_total - 8;       // ragged edge (rows_total % 8 == 0): read a valid chunk, results are never stored
-      src = base + (k0 + kr) * ld + col;
+      int64_t kk = k0 + kr;
+      if (EDGE == 1 && kk >= kend) kk = kend - 1;
+      src = base + kk * ld + col;
+      if (EDGE == 2 && kk >= kend) src = reinterpret_cast<const bf16_t*>(mmrca_zero_chunk);
     }
     __builtin_amdgcn_global_load_lds((gbl_void*)src, (lds_void*)(lds_tile + i * 1024), 16, 0, 0);
   }
@@ -725,9 +738,17 @@ gemm_mfma_k32(const bf16_t* __restrict__ A, const bf16_t* __restrict__ B, void* 
   bf16x8 ones;
 #pragma unroll
   for (int e = 0; e < 8; ++e) ones[e] = (bf16_t)1.0f;
+  // a contraction range that ends off a 32-deep step (K % 32 != 0, K % 8 == 0; forward / input gradient only): its last step is
+  // staged with the EDGE forms (B chunks past kend read as zeros)
+  const bool kedge = !ATOMIC_F32 && ((kend - kbeg) & 31) != 0;
   if (nt > 0) {
-    stage_tile32<A_KROW>(A, lda, m_blk, M, kbeg, smem, wave, lane);
-    stage_tile32<B_KROW>(B, ldb, n_blk, N, kbeg, smem + TILE32_BYTES, wave, lane);
+    if (kedge && nt == 1) {
+      stage_tile32<A_KROW, 1>(A, lda, m_blk, M, kbeg, smem, wave, lane, kend);
+      stage_tile32<B_KROW, 2>(B, ldb, n_blk, N, kbeg, smem + TILE32_BYTES, wave, lane, kend);
+    } else {
+      stage_tile32<A_KROW>(A, lda, m_blk, M, kbeg, smem, wave, lane);
+      stage_tile32<B_KROW>(B, ldb, n_blk, N, kbeg, smem + TILE32_BYTES, wave, lane);
+    }
   }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
@@ -735,8 +756,13 @@ gemm_mfma_k32(const bf16_t* __restrict__ A, const bf16_t* __restrict__ B, void* 
     char* cur = smem + (t & 1) * 2 * TILE32_BYTES;
     char* nxt = smem + ((t + 1) & 1) * 2 * TILE32_BYTES;
     if (t + 1 < nt) {
-      stage_tile32<A_KROW>(A, lda, m_blk, M, kbeg + (int64_t)(t + 1) * 32, nxt, wave, lane);
-      stage_tile32<B_KROW>(B, ldb, n_blk, N, kbeg + (int64_t)(t + 1) * 32, nxt + TILE32_BYTES, wave, lane);
+      if (kedge && t + 2 == nt) {
+        stage_tile32<A_KROW, 1>(A, lda, m_blk, M, kbeg + (int64_t)(t + 1) * 32, nxt, wave, lane, kend);
+        stage_tile32<B_KROW, 2>(B, ldb, n_blk, N, kbeg + (int64_t)(t + 1) * 32, nxt + TILE32_BYTES, wave, lane, kend);
+      } else {
+        stage_tile32<A_KROW>(A, lda, m_blk, M, kbeg + (int64_t)(t + 1) * 32, nxt, wave, lane);
+        stage_tile32<B_KROW>(B, ldb, n_blk, N, kbeg + (int64_t)(t + 1) * 32, nxt + TILE32_BYTES, wave, lane);
+      }
     }
     // asm fragment reads (lds_asm.h): the prefetch issued above stays in flight under them and under the 16 MFMAs
     Frag<A_KROW> afr[4];
@@ -1278,7 +1304,11 @@ static int gemm_dispatch(const void* A, const void* B, void* C, const void* bias
   // past the last row.  These shapes used to fall to the general kernel at a fifth of the rate.
   static const bool ragged_on = !(getenv("MMRCA_GEMM_RAGGED") && atoi(getenv("MMRCA_GEMM_RAGGED")) == 0);
   const bool strict_mfma = ok_mfma;
-  if (!ok_mfma && ragged_on && dtype == MMRCA_BF16 && N % 8 == 0 && N >= 8 && K % 32 == 0 && (a_layout == MMRCA_ROWK || (M % 8 == 0 && M >= 8)) &&
+  // (round 5: a contraction that is a multiple of 8 but not of 32 -- EfficientNetV2-M's 80 / 176 / 304 channels -- is taken by the
+  // 32-deep kernel's edge step; forward / input gradient only, MMRCA_GEMM_KEDGE=0 restores the general kernel for them)
+  static const bool kedge_on = !(getenv("MMRCA_GEMM_KEDGE") && atoi(getenv("MMRCA_GEMM_KEDGE")) == 0);
+  const bool k_ok = K % 32 == 0 || (kedge_on && !out_f32_accum && K % 8 == 0 && K >= 32);
+  if (!ok_mfma && ragged_on && dtype == MMRCA_BF16 && N % 8 == 0 && N >= 8 && k_ok && (a_layout == MMRCA_ROWK || (M % 8 == 0 && M >= 8)) &&
       lda % 8 == 0 && ldb % 8 == 0 && ldc % 4 == 0 && aligned16(A) && aligned16(B) && aligned16(C) && (!bias || (aligned16(bias) && !out_f32_accum)) &&
       !addend && !preact && act == MMRCA_ACT_NONE && !colsum_fused && (out_f32_accum ? K % 64 == 0 : true) && M >= 64 &&
       (impl == MMRCA_GEMM_AUTO || impl == MMRCA_GEMM_MFMA_BK32 || impl == MMRCA_GEMM_MFMA_1STAGE))

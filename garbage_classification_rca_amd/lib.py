@@ -242,7 +242,8 @@ def gemm(A, B, Cout, *, bias=None, addend=None, preact=None, M, N, K, lda, ldb, 
         return
     # matrix-core launches: the bf16 MFMA kernels, and in fp32 mode the general kernel on the fp32 matrix cores
     prof = GEMM_PROFILE is not None and (gemm_is_mfma(M, N, K, a_layout, dtype, impl) or (dtype == F32 and impl != IMPL_REF))
-    if prof:
+    timed = prof or CONV_PROFILE is not None      # the conv step's byte table times EVERY GEMM (ragged / general-kernel shapes too)
+    if timed:
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
     if colsum is not None:
@@ -253,13 +254,14 @@ def gemm(A, B, Cout, *, bias=None, addend=None, preact=None, M, N, K, lda, ldb, 
     else:
         _check(load().mmrca_gemm(ptr(A), ptr(B), ptr(Cout), ptr(bias), ptr(addend), ptr(preact), M, N, K, lda, ldb, ldc,
                                  a_layout, b_layout, act, int(accum), dtype, impl, stream_ptr()), "mmrca_gemm")
-    if prof:
+    if timed:
         e1.record()
+    if prof:
         GEMM_PROFILE.append((2.0 * M * N * K, (a_layout, b_layout, int(accum)), e0, e1, (M, N, K, act)))
     if CONV_PROFILE is not None:         # byte accounting of the conv step (every GEMM, matrix-core qualified or not)
         es = _esz(dtype)
         side = (1 if addend is not None else 0) + (1 if preact is not None else 0)
-        CONV_PROFILE.append(("GEMM (1x1 conv / patch matrix / text encoder)", int((M * K + N * K) * es + M * N * ((4 if accum else es) + side * es)), None, None))
+        CONV_PROFILE.append(("GEMM (1x1 conv / patch matrix / text encoder)", int((M * K + N * K) * es + M * N * ((4 if accum else es) + side * es)), e0, e1))
 
 
 SPLITK_WS_BYTES = 64 << 20      # 256 partial tiles of 256x256 fp32: enough for every shape mmrca_gemm_splitk accepts

@@ -230,6 +230,15 @@ def test_gemm_mfma256_layouts_and_epilogues(bl):
     (1344, 224, 1024, 1, 1, True, False),     # weight gradient: A is [K, M] with ragged M, B is [K, N] with ragged N
     (224, 1344, 960, 1, 1, True, False),
     (128, 56, 1344, 0, 0, False, True),       # squeeze-excitation FC (56 output channels)
+    # round 5: contractions that are multiples of 8 but not of 32 -- EfficientNetV2-M (the reference's default image model,
+    # multimodal_model.py:113-126): 80 / 176 / 304 channels -- on the 32-deep kernel's edge step (B chunks past K fetched as zeros)
+    (14400, 1824, 304, 0, 0, False, False),   # stage-6 expand, forward
+    (1000, 1056, 176, 0, 0, False, True),     # stage-5 expand (ragged M)
+    (777, 320, 80, 0, 0, False, False),       # stage-4 expand: 2.5 steps
+    (14400, 1824, 304, 0, 1, False, False),   # input gradient of a 1824 -> 304 projection: B is [K = 304, N = 1824]
+    (900, 960, 176, 0, 1, False, False),
+    (512, 128, 40, 0, 0, False, False),       # one and a quarter steps
+    (512, 128, 40, 0, 1, False, False),
 ])
 def test_gemm_ragged_shapes_run_on_the_mfma_kernels(M, N, K, al, bl, accum, bias):
     """channel counts that are multiples of 8 but not of 128 (and contractions that are multiples of 32 but not of 64) on the
@@ -249,6 +258,16 @@ def test_gemm_ragged_shapes_run_on_the_mfma_kernels(M, N, K, al, bl, accum, bias
     assert float((C[:, N:] - 7.0).abs().max()) == 0.0 and float((C[M:] - 7.0).abs().max()) == 0.0
     ref = (A.float() if al == 0 else A.float().t()) @ (B.float().t() if bl == 0 else B.float())
     assert rel_err(C[:M, :N], ref) < TOL[torch.bfloat16]
+    if K % 32:
+        # the edge step must not depend on what lies behind the last valid chunk: poison the operands' neighbourhood (A as a column
+        # window of a wider NaN-filled buffer, so that a read past K would hit NaN) and compare bit for bit with the clean run
+        if al == 0:
+            Aw = torch.full((M, K + 32), float("nan"), device="cuda", dtype=torch.bfloat16)
+            Aw[:, :K] = A
+            C2 = torch.full((M + 3, ldc), 7.0, device="cuda", dtype=torch.bfloat16)
+            L.gemm(Aw, B, C2, M=M, N=N, K=K, lda=K + 32, ldb=B.shape[1], ldc=ldc, a_layout=al, b_layout=bl, dtype=L.BF16)
+            torch.cuda.synchronize()
+            assert torch.equal(C2, C)
 
 
 @pytest.mark.parametrize("bl", [0, 1])
