@@ -39,6 +39,8 @@ IGEMM = os.environ.get("MMRCA_CONV_IGEMM", "1") == "1"
 FUSE_GEMM_BN = os.environ.get("MMRCA_CONV_FUSE_GEMM_BN", "0") == "1"
 BN_FLAT = os.environ.get("MMRCA_BN_FLAT", "0") == "1"               # flat BatchNorm reductions (csrc/conv.hip, opt-in): need a 16 MiB workspace
 FUSE_SE = os.environ.get("MMRCA_CONV_FUSE_SE", "1") == "1"         # SE backward: dx and the next BatchNorm's backward sums in one pass
+FUSE_SE_MLP = os.environ.get("MMRCA_CONV_FUSE_SE_MLP", "1") == "1"   # squeeze-excitation MLP: one launch forward, two backward
+SE_FUSE_MAX = int(os.environ.get("MMRCA_CONV_SE_FUSE_MAX", "160000"))   # c * sq up to which the fused MLP is used (see ConvEncoder._se_fused)
 FUSE_RES = os.environ.get("MMRCA_CONV_FUSE_RES", "1") == "1"       # residual connection inside the block's last BatchNorm pass
 IGEMM_DGRAD = os.environ.get("MMRCA_CONV_IGEMM_DGRAD", "1") == "1"
 
@@ -462,16 +464,27 @@ class ConvEncoder:
         return dx
 
     # ------------------------------------------------------------------ squeeze-excitation
+    @staticmethod
+    def _se_fused(se: "_SE") -> bool:
+        """the fused squeeze-excitation MLP (one workgroup per sample re-reads both weight matrices) wins while they are small --
+        measured (tools/se_bench.py, B = 64 / 128): 1824 x 76: 40 vs 75 us forward, 48 vs 137 backward; 2304 x 96: 57 vs 43, 76 vs 66 --
+        and whenever the squeeze width is not a multiple of 8 (EfficientNetV2-M: 20 / 44 / 76 -> the general GEMM kernel)"""
+        return FUSE_SE_MLP and se.c % 4 == 0 and se.sq % 4 == 0 and (se.c * se.sq <= SE_FUSE_MAX or se.sq % 8 != 0)
+
     def _se_fwd(self, se: _SE, x, B, HW, tag, save):
         dt = self.cdt
         n = lambda s, r, c: self.buf(tag + s, r, c)
         pooled, h_pre, h = n(".se.pool", B, se.c), n(".se.hpre", B, se.sq), n(".se.h", B, se.sq)
         s_pre, s = n(".se.spre", B, se.c), n(".se.s", B, se.c)
         L.rowpool_mean(x, pooled, B, HW, se.c, dt)
-        L.gemm(pooled, self.W(se.key + ".fc1.weight"), h_pre, M=B, N=se.sq, K=se.c, lda=se.c, ldb=se.c, ldc=se.sq, dtype=dt, impl=self.o.gemm_impl)
-        L.bias_act_fwd(h_pre, self.W(se.key + ".fc1.bias"), h, B, se.sq, L.CONV_SILU, dt)
-        L.gemm(h, self.W(se.key + ".fc2.weight"), s_pre, M=B, N=se.c, K=se.sq, lda=se.sq, ldb=se.sq, ldc=se.c, dtype=dt, impl=self.o.gemm_impl)
-        L.bias_act_fwd(s_pre, self.W(se.key + ".fc2.bias"), s, B, se.c, L.CONV_SIGMOID, dt)
+        if self._se_fused(se):        # fc1 + SiLU + fc2 + sigmoid in one launch (four M = B GEMM-shaped launches otherwise)
+            L.se_mlp_fwd(pooled, self.W(se.key + ".fc1.weight"), self.W(se.key + ".fc1.bias"), self.W(se.key + ".fc2.weight"),
+                         self.W(se.key + ".fc2.bias"), h_pre, h, s_pre, s, B, se.c, se.sq, dt)
+        else:
+            L.gemm(pooled, self.W(se.key + ".fc1.weight"), h_pre, M=B, N=se.sq, K=se.c, lda=se.c, ldb=se.c, ldc=se.sq, dtype=dt, impl=self.o.gemm_impl)
+            L.bias_act_fwd(h_pre, self.W(se.key + ".fc1.bias"), h, B, se.sq, L.CONV_SILU, dt)
+            L.gemm(h, self.W(se.key + ".fc2.weight"), s_pre, M=B, N=se.c, K=se.sq, lda=se.sq, ldb=se.sq, ldc=se.c, dtype=dt, impl=self.o.gemm_impl)
+            L.bias_act_fwd(s_pre, self.W(se.key + ".fc2.bias"), s, B, se.c, L.CONV_SIGMOID, dt)
         y = self.buf(tag + ".se.y", B * HW, se.c)
         L.se_scale_fwd(x, s, y, B, HW, se.c, dt)
         return y, dict(x=x, pooled=pooled, h_pre=h_pre, h=h, s_pre=s_pre, s=s, HW=HW)
@@ -485,21 +498,24 @@ class ConvEncoder:
         dx, ds = self.buf(f"{gp}.se.dx.{se.c}.{B * HW}", B * HW, se.c), g(".ds", B, se.c)
         fused = FUSE_SE and self.cdtype == torch.bfloat16 and se.c % 8 == 0
         L.se_scale_bwd(dy, sv["x"], sv["s"], None if fused else dx, ds, B, HW, se.c, dt)
-        ds_pre = g(".dspre", B, se.c)
-        L.bias_act_bwd(ds, sv["s_pre"], self.W(se.key + ".fc2.bias"), ds_pre, self.G(se.key + ".fc2.bias"), B, se.c, L.CONV_SIGMOID, dt)
-        Bk = _ru(B, 64)
-        L.gemm(ds_pre, sv["h"], self.G(se.key + ".fc2.weight"), M=se.c, N=se.sq, K=Bk, lda=se.c, ldb=se.sq, ldc=se.sq, a_layout=L.KROW,
-               b_layout=L.KROW, accum=True, dtype=dt, impl=self.o.gemm_impl)
-        dh = g(".dh", B, se.sq)
-        L.gemm(ds_pre, self.W(se.key + ".fc2.weight"), dh, M=B, N=se.sq, K=se.c, lda=se.c, ldb=se.sq, ldc=se.sq, a_layout=L.ROWK, b_layout=L.KROW,
-               dtype=dt, impl=self.o.gemm_impl)
-        dh_pre = g(".dhpre", B, se.sq)
-        L.bias_act_bwd(dh, sv["h_pre"], self.W(se.key + ".fc1.bias"), dh_pre, self.G(se.key + ".fc1.bias"), B, se.sq, L.CONV_SILU, dt)
-        L.gemm(dh_pre, sv["pooled"], self.G(se.key + ".fc1.weight"), M=se.sq, N=se.c, K=Bk, lda=se.sq, ldb=se.c, ldc=se.c, a_layout=L.KROW,
-               b_layout=L.KROW, accum=True, dtype=dt, impl=self.o.gemm_impl)
-        dpool = g(".dpool", B, se.c)
-        L.gemm(dh_pre, self.W(se.key + ".fc1.weight"), dpool, M=B, N=se.c, K=se.sq, lda=se.sq, ldb=se.c, ldc=se.c, a_layout=L.ROWK, b_layout=L.KROW,
-               dtype=dt, impl=self.o.gemm_impl)
+        ds_pre, dh_pre, dpool = g(".dspre", B, se.c), g(".dhpre", B, se.sq), g(".dpool", B, se.c)
+        if self._se_fused(se):        # the whole MLP backward: a per-sample chain + one launch for the batch sums (six launches otherwise)
+            L.se_mlp_bwd(ds, sv["pooled"], sv["h_pre"], sv["h"], sv["s_pre"], self.W(se.key + ".fc1.weight"), self.W(se.key + ".fc1.bias"),
+                         self.W(se.key + ".fc2.weight"), self.W(se.key + ".fc2.bias"), ds_pre, dh_pre, dpool, self.G(se.key + ".fc1.weight"),
+                         self.G(se.key + ".fc1.bias"), self.G(se.key + ".fc2.weight"), self.G(se.key + ".fc2.bias"), B, se.c, se.sq, dt)
+        else:
+            L.bias_act_bwd(ds, sv["s_pre"], self.W(se.key + ".fc2.bias"), ds_pre, self.G(se.key + ".fc2.bias"), B, se.c, L.CONV_SIGMOID, dt)
+            Bk = _ru(B, 64)
+            L.gemm(ds_pre, sv["h"], self.G(se.key + ".fc2.weight"), M=se.c, N=se.sq, K=Bk, lda=se.c, ldb=se.sq, ldc=se.sq, a_layout=L.KROW,
+                   b_layout=L.KROW, accum=True, dtype=dt, impl=self.o.gemm_impl)
+            dh = g(".dh", B, se.sq)
+            L.gemm(ds_pre, self.W(se.key + ".fc2.weight"), dh, M=B, N=se.sq, K=se.c, lda=se.c, ldb=se.sq, ldc=se.sq, a_layout=L.ROWK, b_layout=L.KROW,
+                   dtype=dt, impl=self.o.gemm_impl)
+            L.bias_act_bwd(dh, sv["h_pre"], self.W(se.key + ".fc1.bias"), dh_pre, self.G(se.key + ".fc1.bias"), B, se.sq, L.CONV_SILU, dt)
+            L.gemm(dh_pre, sv["pooled"], self.G(se.key + ".fc1.weight"), M=se.sq, N=se.c, K=Bk, lda=se.sq, ldb=se.c, ldc=se.c, a_layout=L.KROW,
+                   b_layout=L.KROW, accum=True, dtype=dt, impl=self.o.gemm_impl)
+            L.gemm(dh_pre, self.W(se.key + ".fc1.weight"), dpool, M=B, N=se.c, K=se.sq, lda=se.sq, ldb=se.c, ldc=se.c, a_layout=L.ROWK, b_layout=L.KROW,
+                   dtype=dt, impl=self.o.gemm_impl)
         if not fused:
             L.rowpool_mean_bwd(dpool, dx, B, HW, se.c, True, dt)
             return dx, False

@@ -2167,6 +2167,219 @@ extern "C" int mmrca_bias_act_bwd(const void* dy, const void* x, const void* bia
   return 0;
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// Squeeze-excitation MLP, fused (round 5).  torchvision SqueezeExcitation inside efficientnet_v2_*'s MBConv blocks (the reference
+// builds them at CVPR_code/multimodal_model.py:113-126): scale = sigmoid(fc2(silu(fc1(avgpool(x))))) on [B, c] -> [B, sq] -> [B, c].
+// As GEMMs these are M = B (64 .. 128) products: four launches forward and six backward per block, each one or two
+// workgroups walking a long contraction -- 212 launches and 11 ms of an 79 ms EfficientNetV2-M step (14 %) for ~0 FLOPs
+// (and sq = 20 / 44 / 76 is not a multiple of 8: the general kernel).  Here ONE workgroup per sample runs the whole chain out of
+// LDS / registers, every weight read coalesced; the weight gradients (sums over the batch) are a second small launch.
+// The tensors the backward reads (pooled, h_pre, h, s_pre, s: pre-activations WITHOUT bias, rounded to T like the GEMM outputs they
+// replace) keep their layout.
+// ---------------------------------------------------------------------------------------------------------------------
+// (every loop below keeps several independent 8 / 16-byte loads in flight and reduces across lanes at most a few times per wave:
+// the first version -- a wave_sum per output and one dependent load per iteration -- ran the chain in ~150 us per block)
+template <typename T>
+__global__ void __launch_bounds__(256)
+se_mlp_fwd_k(const T* __restrict__ pooled, const T* __restrict__ W1, const T* __restrict__ b1, const T* __restrict__ W2,
+             const T* __restrict__ b2, T* __restrict__ h_pre, T* __restrict__ h, T* __restrict__ s_pre, T* __restrict__ s, int c, int sq) {
+  extern __shared__ __attribute__((aligned(16))) float se_sm[];              // pooled [c] | h [sq]
+  float* pf = se_sm;
+  float* hf = se_sm + c;
+  const int b = blockIdx.x, wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  for (int i = threadIdx.x * 4; i < c; i += 1024) {
+    const Vec4<T> v = Vec4<T>::load(pooled + (int64_t)b * c + i);
+#pragma unroll
+    for (int k = 0; k < 4; ++k) pf[i + k] = v.v[k];
+  }
+  __syncthreads();
+  // fc1 (W1 [sq, c]): a wave takes its share of the outputs four at a time, lanes along the contraction; four reductions interleaved
+  const int jw = (sq + 3) / 4, jend = min(sq, (wave + 1) * jw);
+  for (int j0 = wave * jw; j0 < jend; j0 += 4) {
+    const int nj = min(4, jend - j0);
+    float a[4] = {0.f, 0.f, 0.f, 0.f};
+    for (int i = lane * 4; i < c; i += 256) {
+      const float4 p4 = *reinterpret_cast<const float4*>(pf + i);
+#pragma unroll
+      for (int u = 0; u < 4; ++u)
+        if (u < nj) {
+          const Vec4<T> w = Vec4<T>::load(W1 + (int64_t)(j0 + u) * c + i);
+          a[u] += w.v[0] * p4.x + w.v[1] * p4.y + w.v[2] * p4.z + w.v[3] * p4.w;
+        }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1)
+#pragma unroll
+      for (int u = 0; u < 4; ++u) a[u] += __shfl_xor(a[u], o, 64);
+    if (lane == 0)
+      for (int u = 0; u < nj; ++u) {
+        const int j = j0 + u;
+        const T hp = from_f<T>(a[u]);
+        const T hv = from_f<T>(act_f(to_f(hp) + to_f(b1[j]), CONV_ACT_SILU));
+        h_pre[(int64_t)b * sq + j] = hp;
+        h[(int64_t)b * sq + j] = hv;
+        hf[j] = to_f(hv);
+      }
+  }
+  __syncthreads();
+  // fc2 (W2 [c, sq]): a thread per output walks its own (contiguous) row, two rows at a time
+  for (int i0 = threadIdx.x; i0 < c; i0 += 512) {
+    const int i1 = i0 + 256 < c ? i0 + 256 : i0;
+    const T* r0 = W2 + (int64_t)i0 * sq;
+    const T* r1 = W2 + (int64_t)i1 * sq;
+    float a0 = 0.f, a1 = 0.f;
+#pragma unroll 4
+    for (int j = 0; j < sq; j += 4) {
+      const Vec4<T> w0 = Vec4<T>::load(r0 + j), w1 = Vec4<T>::load(r1 + j);
+      const float4 h4 = *reinterpret_cast<const float4*>(hf + j);
+      a0 += w0.v[0] * h4.x + w0.v[1] * h4.y + w0.v[2] * h4.z + w0.v[3] * h4.w;
+      a1 += w1.v[0] * h4.x + w1.v[1] * h4.y + w1.v[2] * h4.z + w1.v[3] * h4.w;
+    }
+    {
+      const T sp = from_f<T>(a0);
+      s_pre[(int64_t)b * c + i0] = sp;
+      s[(int64_t)b * c + i0] = from_f<T>(act_f(to_f(sp) + to_f(b2[i0]), CONV_ACT_SIGMOID));
+    }
+    if (i1 != i0) {
+      const T sp = from_f<T>(a1);
+      s_pre[(int64_t)b * c + i1] = sp;
+      s[(int64_t)b * c + i1] = from_f<T>(act_f(to_f(sp) + to_f(b2[i1]), CONV_ACT_SIGMOID));
+    }
+  }
+}
+
+// backward chain of one sample: ds -> ds_pre (x sigmoid') -> dh = ds_pre . W2 -> dh_pre (x silu') -> dpool = dh_pre . W1; the bias
+// gradients are the batch sums of ds_pre / dh_pre (fp32 atomics, B addends per entry)
+template <typename T>
+__global__ void __launch_bounds__(256)
+se_mlp_bwd_k(const T* __restrict__ ds, const T* __restrict__ s_pre, const T* __restrict__ h_pre, const T* __restrict__ W1,
+             const T* __restrict__ b1, const T* __restrict__ W2, const T* __restrict__ b2, T* __restrict__ ds_pre, T* __restrict__ dh_pre,
+             T* __restrict__ dpool, float* __restrict__ gb1, float* __restrict__ gb2, int c, int sq) {
+  extern __shared__ __attribute__((aligned(16))) float se_sm[];              // ds_pre [c] | partial dh [4][sq] | dh_pre [sq]
+  float* dsp = se_sm;
+  float* part = se_sm + c;
+  float* dhp = part + 4 * sq;
+  const int b = blockIdx.x, wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  for (int i = threadIdx.x; i < c; i += 256) {
+    const float g = to_f(ds[(int64_t)b * c + i]) * act_grad_f(to_f(s_pre[(int64_t)b * c + i]) + to_f(b2[i]), CONV_ACT_SIGMOID);
+    const T gt = from_f<T>(g);
+    ds_pre[(int64_t)b * c + i] = gt;
+    dsp[i] = to_f(gt);
+    atomicAdd(gb2 + i, g);
+  }
+  __syncthreads();
+  // dh[j] = sum_i ds_pre[i] W2[i][j], 32 columns at a time: a thread walks its own rows (contiguous 8 / 16-byte pieces) into 32
+  // private sums, the wave adds them up (32 independent butterflies), the four waves meet in LDS
+  for (int jc = 0; jc < sq; jc += 32) {
+    const int nq = min(8, (sq - jc) >> 2);
+    float acc[32];
+#pragma unroll
+    for (int k = 0; k < 32; ++k) acc[k] = 0.f;
+    for (int i = threadIdx.x; i < c; i += 256) {
+      const float d = dsp[i];
+      const T* r = W2 + (int64_t)i * sq + jc;
+#pragma unroll
+      for (int q = 0; q < 8; ++q)
+        if (q < nq) {
+          const Vec4<T> w = Vec4<T>::load(r + 4 * q);
+#pragma unroll
+          for (int k = 0; k < 4; ++k) acc[4 * q + k] += d * w.v[k];
+        }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1)
+#pragma unroll
+      for (int k = 0; k < 32; ++k) acc[k] += __shfl_xor(acc[k], o, 64);
+    if (lane == 0) {
+#pragma unroll
+      for (int k = 0; k < 32; ++k)
+        if (k < 4 * nq) part[wave * sq + jc + k] = acc[k];
+    }
+  }
+  __syncthreads();
+  for (int j = threadIdx.x; j < sq; j += 256) {
+    const float dh = part[j] + part[sq + j] + part[2 * sq + j] + part[3 * sq + j];
+    const float g = to_f(from_f<T>(dh)) * act_grad_f(to_f(h_pre[(int64_t)b * sq + j]) + to_f(b1[j]), CONV_ACT_SILU);
+    const T gt = from_f<T>(g);
+    dh_pre[(int64_t)b * sq + j] = gt;
+    dhp[j] = to_f(gt);
+    atomicAdd(gb1 + j, g);
+  }
+  __syncthreads();
+  // dpool[i] = sum_j dh_pre[j] W1[j][i]: a thread per four consecutive outputs (coalesced rows of W1 [sq, c])
+  for (int i = threadIdx.x * 4; i < c; i += 1024) {
+    float a[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll 4
+    for (int j = 0; j < sq; ++j) {
+      const Vec4<T> w = Vec4<T>::load(W1 + (int64_t)j * c + i);
+      const float d = dhp[j];
+#pragma unroll
+      for (int k = 0; k < 4; ++k) a[k] += d * w.v[k];
+    }
+    Vec4<T> o;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) o.v[k] = a[k];
+    o.store(dpool + (int64_t)b * c + i);
+  }
+}
+
+// gW2[i][j] += sum_b ds_pre[b][i] h[b][j]   (blocks [0, n2));   gW1[j][i] += sum_b dh_pre[b][j] pooled[b][i]   (the rest)
+template <typename T>
+__global__ void __launch_bounds__(256)
+se_mlp_wgrad_k(const T* __restrict__ ds_pre, const T* __restrict__ h, const T* __restrict__ dh_pre, const T* __restrict__ pooled,
+               float* __restrict__ gW1, float* __restrict__ gW2, int B, int c, int sq, int n2_blocks) {
+  const int64_t n = (int64_t)c * sq;
+  if ((int)blockIdx.x < n2_blocks) {
+    const int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (e >= n) return;
+    const int i = (int)(e / sq), j = (int)(e - (int64_t)i * sq);
+    float a = 0.f;
+#pragma unroll 8
+    for (int b = 0; b < B; ++b) a += to_f(ds_pre[(int64_t)b * c + i]) * to_f(h[(int64_t)b * sq + j]);
+    gW2[e] += a;
+  } else {
+    const int64_t e = (int64_t)((int)blockIdx.x - n2_blocks) * 256 + threadIdx.x;
+    if (e >= n) return;
+    const int j = (int)(e / c), i = (int)(e - (int64_t)j * c);
+    float a = 0.f;
+#pragma unroll 8
+    for (int b = 0; b < B; ++b) a += to_f(dh_pre[(int64_t)b * sq + j]) * to_f(pooled[(int64_t)b * c + i]);
+    gW1[e] += a;
+  }
+}
+
+extern "C" int mmrca_se_mlp_fwd(const void* pooled, const void* w1, const void* b1, const void* w2, const void* b2, void* h_pre, void* h,
+                                void* s_pre, void* s, int B, int c, int sq, int dtype, void* stream) {
+  MMRCA_REQUIRE(pooled && w1 && b1 && w2 && b2 && h_pre && h && s_pre && s, "se_mlp_fwd: null pointer");
+  MMRCA_REQUIRE(B > 0 && c > 0 && sq > 0 && c % 4 == 0 && sq % 4 == 0 && (size_t)(c + sq) * 4 <= 64 * 1024,
+                "se_mlp_fwd: bad shape B=%d c=%d sq=%d (c and sq must be multiples of 4)", B, c, sq);
+  const size_t lds = (size_t)(c + sq) * sizeof(float);
+  MMRCA_DISPATCH_DTYPE(dtype, "se_mlp_fwd",
+    hipLaunchKernelGGL(se_mlp_fwd_k<T>, dim3(B), dim3(256), lds, (hipStream_t)stream, (const T*)pooled, (const T*)w1, (const T*)b1, (const T*)w2,
+                       (const T*)b2, (T*)h_pre, (T*)h, (T*)s_pre, (T*)s, c, sq);)
+  MMRCA_CHECK_LAUNCH("se_mlp_fwd");
+  return 0;
+}
+
+extern "C" int mmrca_se_mlp_bwd(const void* ds, const void* pooled, const void* h_pre, const void* h, const void* s_pre, const void* w1,
+                                const void* b1, const void* w2, const void* b2, void* ds_pre, void* dh_pre, void* dpool, float* gw1,
+                                float* gb1, float* gw2, float* gb2, int B, int c, int sq, int dtype, void* stream) {
+  MMRCA_REQUIRE(ds && pooled && h_pre && h && s_pre && w1 && b1 && w2 && b2 && ds_pre && dh_pre && dpool && gw1 && gb1 && gw2 && gb2,
+                "se_mlp_bwd: null pointer");
+  MMRCA_REQUIRE(B > 0 && c > 0 && sq > 0 && c % 4 == 0 && sq % 4 == 0 && (size_t)(c + 5 * sq) * 4 <= 64 * 1024,
+                "se_mlp_bwd: bad shape B=%d c=%d sq=%d (c and sq must be multiples of 4)", B, c, sq);
+  const size_t lds = (size_t)(c + 5 * sq) * sizeof(float);
+  const int64_t n = (int64_t)c * sq;
+  const int nb = (int)((n + 255) / 256);
+  MMRCA_DISPATCH_DTYPE(dtype, "se_mlp_bwd",
+    hipLaunchKernelGGL(se_mlp_bwd_k<T>, dim3(B), dim3(256), lds, (hipStream_t)stream, (const T*)ds, (const T*)s_pre, (const T*)h_pre,
+                       (const T*)w1, (const T*)b1, (const T*)w2, (const T*)b2, (T*)ds_pre, (T*)dh_pre, (T*)dpool, gb1, gb2, c, sq);
+    hipLaunchKernelGGL(se_mlp_wgrad_k<T>, dim3(2 * nb), dim3(256), 0, (hipStream_t)stream, (const T*)ds_pre, (const T*)h, (const T*)dh_pre,
+                       (const T*)pooled, gw1, gw2, B, c, sq, nb);)
+  MMRCA_CHECK_LAUNCH("se_mlp_bwd");
+  return 0;
+}
+
 // out = a + b * rowscale[sample]   (residual connection with torchvision's "row" stochastic depth; rowscale NULL = 1)
 __global__ void __launch_bounds__(256)
 residual_add_v8_k(const bf16_t* __restrict__ a, const bf16_t* __restrict__ b, const float* __restrict__ rowscale, bf16_t* __restrict__ out,

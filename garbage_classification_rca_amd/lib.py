@@ -81,6 +81,8 @@ _SIGS = {
     "mmrca_rowpool_mean": [_vp, _vp, _i32, _i32, _i32, _i32, _vp],
     "mmrca_rowpool_mean_bwd": [_vp, _vp, _i32, _i32, _i32, _i32, _i32, _vp],
     "mmrca_se_scale_fwd": [_vp, _vp, _vp, _i32, _i32, _i32, _i32, _vp],
+    "mmrca_se_mlp_fwd": [_vp] * 9 + [_i32] * 4 + [_vp],
+    "mmrca_se_mlp_bwd": [_vp] * 16 + [_i32] * 4 + [_vp],
     "mmrca_se_scale_bwd": [_vp] * 5 + [_i32, _i32, _i32, _i32, _vp],
     "mmrca_bias_act_fwd": [_vp, _vp, _vp, _i64, _i32, _i32, _i32, _vp],
     "mmrca_bias_act_bwd": [_vp] * 5 + [_i64, _i32, _i32, _i32, _vp],
@@ -612,6 +614,8 @@ _CONV_BYTES = {
     "mmrca_rowpool_mean": ("pool / squeeze-excitation", lambda a: a[2] * a[3] * a[4] * _esz(a[5])),
     "mmrca_rowpool_mean_bwd": ("pool / squeeze-excitation", lambda a: a[2] * a[3] * a[4] * _esz(a[6]) * (2 if a[5] else 1)),
     "mmrca_se_scale_fwd": ("pool / squeeze-excitation", lambda a: 2 * a[3] * a[4] * a[5] * _esz(a[6])),
+    "mmrca_se_mlp_fwd": ("pool / squeeze-excitation", lambda a: (2 * a[10] * a[11] + 3 * a[9] * (a[10] + a[11])) * _esz(a[12])),
+    "mmrca_se_mlp_bwd": ("pool / squeeze-excitation", lambda a: (2 * a[17] * a[18] + 6 * a[16] * (a[17] + a[18])) * _esz(a[19]) + 2 * a[17] * a[18] * 4),
     "mmrca_se_scale_bwd": ("pool / squeeze-excitation", lambda a: (3 if a[3] else 2) * a[5] * a[6] * a[7] * _esz(a[8])),
     "mmrca_se_dx": ("pool / squeeze-excitation", lambda a: (3 if a[8] else 2) * a[4] * a[5] * a[6] * _esz(a[7])),
     "mmrca_residual_add": ("residual", lambda a: (3 if a[0] else 2) * a[4] * a[5] * _esz(a[6])),
@@ -744,6 +748,20 @@ def rowpool_mean(x, out, B, HW, C, dtype):
 
 def rowpool_mean_bwd(dpool, dx, B, HW, C, accumulate, dtype):
     _c("mmrca_rowpool_mean_bwd", ptr(dpool), ptr(dx), B, HW, C, int(accumulate), dtype)
+
+
+def se_mlp_fwd(pooled, w1, b1, w2, b2, h_pre, h, s_pre, s, B, c, sq, dtype):
+    """the squeeze-excitation MLP in one launch (include/mmrca.h)"""
+    _c("mmrca_se_mlp_fwd", ptr(pooled), ptr(w1), ptr(b1), ptr(w2), ptr(b2), ptr(h_pre), ptr(h), ptr(s_pre), ptr(s), B, c, sq, dtype)
+
+
+def se_mlp_bwd(ds, pooled, h_pre, h, s_pre, w1, b1, w2, b2, ds_pre, dh_pre, dpool, gw1, gb1, gw2, gb2, B, c, sq, dtype):
+    """... and its backward: dpool, and += into the fp32 parameter gradients"""
+    for t in (gw1, gb1, gw2, gb2):
+        if t.dtype != torch.float32:
+            raise MmrcaError("se_mlp_bwd: parameter gradients must be fp32")
+    _c("mmrca_se_mlp_bwd", ptr(ds), ptr(pooled), ptr(h_pre), ptr(h), ptr(s_pre), ptr(w1), ptr(b1), ptr(w2), ptr(b2), ptr(ds_pre), ptr(dh_pre),
+       ptr(dpool), ptr(gw1), ptr(gb1), ptr(gw2), ptr(gb2), B, c, sq, dtype)
 
 
 def se_scale_fwd(x, s, y, B, HW, C, dtype):

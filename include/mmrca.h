@@ -240,6 +240,16 @@ int mmrca_bn_act_bwd_sums(const void* dy, const void* x, const float* mean, cons
 int mmrca_rowpool_mean(const void* x, void* out, int B, int HW, int C, int dtype, void* stream);
 int mmrca_rowpool_mean_bwd(const void* dpool, void* dx, int B, int HW, int C, int accumulate, int dtype, void* stream);
 /* squeeze-excitation scaling y = x * s[b, c] and its backward (dx = dy * s, ds[b, c] = sum_rows dy * x) */
+/* The squeeze-excitation MLP of one MBConv block in one launch (torchvision SqueezeExcitation: fc1 [sq, c] + bias, SiLU, fc2 [c, sq] +
+ * bias, sigmoid; efficientnet_v2_* as built at CVPR_code/multimodal_model.py:113-126): pooled [B, c] -> h_pre, h [B, sq] -> s_pre, s [B, c]
+ * (pre-activations stored WITHOUT bias, as mmrca_bias_act_fwd expects).  One workgroup per sample; (c + sq) * 4 bytes of LDS. */
+int mmrca_se_mlp_fwd(const void* pooled, const void* w1, const void* b1, const void* w2, const void* b2, void* h_pre, void* h,
+                     void* s_pre, void* s, int B, int c, int sq, int dtype, void* stream);
+/* its backward from ds = d loss / d s [B, c]: writes dpool [B, c] (and the workspaces ds_pre [B, c], dh_pre [B, sq]) and ADDS the
+ * parameter gradients to the fp32 gw1 [sq, c], gb1 [sq], gw2 [c, sq], gb2 [c] (two launches: per-sample chain, batch sums). */
+int mmrca_se_mlp_bwd(const void* ds, const void* pooled, const void* h_pre, const void* h, const void* s_pre, const void* w1,
+                     const void* b1, const void* w2, const void* b2, void* ds_pre, void* dh_pre, void* dpool, float* gw1,
+                     float* gb1, float* gw2, float* gb2, int B, int c, int sq, int dtype, void* stream);
 int mmrca_se_scale_fwd(const void* x, const void* s, void* y, int B, int HW, int C, int dtype, void* stream);
 int mmrca_se_scale_bwd(const void* dy, const void* x, const void* s, void* dx, void* ds, int B, int HW, int C, int dtype, void* stream);
 /* Second half of the squeeze-excitation backward in one pass: dx = dy * s[b, c] + dpool[b, c] / HW (mmrca_se_scale_bwd with

@@ -131,6 +131,42 @@ def test_batchnorm_act_fwd_bwd_and_running_stats(dt, act, train):
     assert rel(dx, x.grad) < tol and rel(dg, gam.grad) < tol and rel(db, bet.grad) < tol
 
 
+@pytest.mark.parametrize("dt", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("B,c,sq", [(5, 320, 20), (64, 1824, 76), (3, 3840, 160), (2, 48, 12)])
+def test_fused_squeeze_excitation_mlp_fwd_bwd(dt, B, c, sq):
+    """mmrca_se_mlp_fwd / _bwd (one launch forward, two backward) against torch autograd of torchvision's SqueezeExcitation MLP
+    (fc1 + SiLU + fc2 + sigmoid; multimodal_model.py:113-126 builds it inside efficientnet_v2_m): the scale, the saved
+    pre-activations, dpool and the four parameter gradients (accumulated onto a non-zero start).  EfficientNetV2-M's squeeze widths
+    20 / 76 are not multiples of 8 (these were general-kernel GEMMs); 3,840 / 160 is EfficientNetV2-L's widest block."""
+    g = torch.Generator().manual_seed(B * c + sq)
+    r = lambda *shape, scale=1.0: (torch.randn(*shape, generator=g) * scale).to(dt).float()
+    pooled, w1, b1 = r(B, c, scale=0.5), r(sq, c, scale=c ** -0.5), r(sq, scale=0.2)
+    w2, b2, ds = r(c, sq, scale=sq ** -0.5), r(c, scale=0.2), r(B, c, scale=0.3)
+    P, W1, B1, W2, B2 = (t.clone().requires_grad_(True) for t in (pooled, w1, b1, w2, b2))
+    h_pre_ref = P @ W1.t()
+    h_ref = F.silu(h_pre_ref + B1)
+    s_pre_ref = h_ref @ W2.t()
+    s_ref = torch.sigmoid(s_pre_ref + B2)
+    s_ref.backward(ds)
+    d = lambda t: t.cuda().to(dt)
+    h_pre, h = torch.empty(B, sq, device="cuda", dtype=dt), torch.empty(B, sq, device="cuda", dtype=dt)
+    s_pre, s = torch.empty(B, c, device="cuda", dtype=dt), torch.empty(B, c, device="cuda", dtype=dt)
+    dc = L.dtype_code(dt)
+    L.se_mlp_fwd(d(pooled), d(w1), d(b1), d(w2), d(b2), h_pre, h, s_pre, s, B, c, sq, dc)
+    tol = 1e-5 if dt == torch.float32 else 2e-2
+    assert rel(h_pre, h_pre_ref.detach()) < tol and rel(h, h_ref.detach()) < tol
+    assert rel(s_pre, s_pre_ref.detach()) < tol and rel(s, s_ref.detach()) < tol
+    ds_pre, dh_pre, dpool = torch.empty(B, c, device="cuda", dtype=dt), torch.empty(B, sq, device="cuda", dtype=dt), torch.empty(B, c, device="cuda", dtype=dt)
+    gw1, gb1 = torch.full((sq, c), 0.5, device="cuda"), torch.full((sq,), 0.5, device="cuda")
+    gw2, gb2 = torch.full((c, sq), 0.5, device="cuda"), torch.full((c,), 0.5, device="cuda")
+    L.se_mlp_bwd(d(ds), d(pooled), h_pre, h, s_pre, d(w1), d(b1), d(w2), d(b2), ds_pre, dh_pre, dpool, gw1, gb1, gw2, gb2, B, c, sq, dc)
+    torch.cuda.synchronize()
+    gt = 2e-4 if dt == torch.float32 else 3e-2
+    assert rel(dpool, P.grad) < gt
+    assert rel(gw1 - 0.5, W1.grad) < gt and rel(gb1 - 0.5, B1.grad) < gt
+    assert rel(gw2 - 0.5, W2.grad) < gt and rel(gb2 - 0.5, B2.grad) < gt
+
+
 @pytest.fixture
 def bn_flat_on():
     """both flat forms are opt-in (faster in isolation, no gain in the conv step): switched on for one test through the library's
