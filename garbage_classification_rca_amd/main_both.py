@@ -243,7 +243,10 @@ def main(argv=None):
             sampler.set_epoch(epoch + (1000 if fine_tuning else 0))
             global_model.train()
             st = time.time()
-            use_graph = args.hip_graph == "on" or (args.hip_graph == "auto" and bs <= 16 and world == 1)
+            # auto: the launch-bound corner only -- one GPU, a batch of at most 16 images of at most 224 x 224 (configs[0]: 6.4 vs 18 ms per
+            # step).  Measured at the reference's own launch shape (EfficientNetV2-M @ 480, B = 16) the step is GPU-bound: graph = eager
+            # (469 vs 471 samples/s), and the eager step keeps the packed caption layout
+            use_graph = args.hip_graph == "on" or (args.hip_graph == "auto" and bs <= 16 and world == 1 and bs * WIDTH * HEIGHT <= 16 * 224 * 224)
             _, losses = run_one_epoch(epoch, global_model, dl_tr, len(sampler), device, bs, optimizer, class_weights,
                                       args.balance_weights, acc_steps, args.label_smoothing, grad_sync=sync, verbose=is_main,
                                       image_pipeline=image_pipeline, aug_params=aug_params, hip_graph=(graphs if use_graph else None))

@@ -56,7 +56,7 @@ BUILD_FLAGS = [
     ("seed", _INT, None, "seed torch / numpy"),
     ("image_size", _INT, None, "input side of the conv image backbones (default: 480 for EfficientNetV2-M as in the reference, else 224)"),
     ("blip2_checkpoint", _STR, None, "q_former_training.py: state_dict file (.pth / .safetensors) of Blip2ForConditionalGeneration (no network here: the reference downloads Salesforce/blip2-opt-2.7b); unset = random weights, with a warning"),
-    ("hip_graph", _STR, "auto", "auto | on | off: replay each train step's forward/backward launches from a HIP graph captured once per batch shape (training.GraphedTrainStep); auto = batch size <= 16 on one GPU, where the step is launch-bound"),
+    ("hip_graph", _STR, "auto", "auto | on | off: replay each train step's forward/backward launches from a HIP graph captured once per batch shape (training.GraphedTrainStep); auto = one GPU, batch size <= 16 and images up to 224 x 224, where the step is launch-bound"),
     ("gpu_preprocess", _BOOL, True, "image pipeline (pad / resize / augment / normalise) as one GPU launch per batch instead of per-sample CPU transforms"),
 ]
 

@@ -230,6 +230,22 @@ class GraphedTrainStep:
         return ent
 
 
+def trim_caption_columns(tokens, mask, multiple: int = 16):
+    """Captions as the dataset pads them (CustomImageTextFolder.py:305-333: ``padding='max_length'`` with the text model's maximum, 512)
+    cut down to the columns the batch uses, rounded up to `multiple`: key columns past every caption's end are masked for every query and
+    the class-token pooling never reads their rows, so the logits and gradients are those of the padded batch.  The eager step gets the
+    same effect from the packed layout (engine.TextPack); a HIP-graph replay needs static shapes, so it runs padded rows -- the
+    reference's file-name captions are ~10 tokens: 512 padded columns would be 50x the text encoder's work -- and the trimmed width
+    (16, 32, ...) is part of the graph key: a handful of graphs.  Host tensors in, host views out (no device sync)."""
+    T = int(mask.shape[1])
+    used = (mask != 0).any(0).nonzero()
+    last = int(used.max()) + 1 if used.numel() else 1
+    t_eff = min(T, (last + multiple - 1) // multiple * multiple)
+    if t_eff >= T:
+        return tokens, mask
+    return tokens[:, :t_eff].contiguous(), mask[:, :t_eff].contiguous()
+
+
 def stage_images(raw, hw_device, image_pipeline=None, aug_params=None):
     """Batch images as the DataLoader delivers them -> fp32 [B,3,H,W] in HBM.  A tensor is the per-sample CPU transform's
     output (copied over); decoded uint8 HWC images (a list, or ``collate_decoded``'s packed batch) go through the GPU
@@ -272,8 +288,11 @@ def run_one_epoch(epoch_num, model, data_loader, len_train_data, hw_device, batc
         texts = data['text']
         # the mask is still on the host here: build the packed token layout without a device sync
         pack = make_text_pack(texts['attention_mask'], hw_device) if (fused and graphed is None and PACK_TEXT and not texts['attention_mask'].is_cuda) else None
-        ids = texts['tokens'].to(hw_device, non_blocking=True)
-        mask = texts['attention_mask'].to(hw_device, non_blocking=True)
+        tok, msk = texts['tokens'], texts['attention_mask']
+        if graphed is not None and not msk.is_cuda:
+            tok, msk = trim_caption_columns(tok, msk)
+        ids = tok.to(hw_device, non_blocking=True)
+        mask = msk.to(hw_device, non_blocking=True)
         labels = labels.to(hw_device, non_blocking=True)
         if acc_steps != 0:
             do_step = ((batch_idx + 1) % acc_steps == 0) or (batch_idx + 1 == n_loader)

@@ -78,6 +78,28 @@ def test_text_encoder_at_the_maximum_caption_length(dtype, tol):
     eng.release_buffers()
 
 
+def test_trimmed_caption_columns_give_the_padded_batch_result():
+    """training.trim_caption_columns (graphed steps): captions padded to 512 by the dataset but ~10 tokens long run as a 16-column padded
+    batch -- same class-token features as the 512-column batch (the dropped key columns are masked for every query), in fp32 to 1e-6"""
+    from garbage_classification_rca_amd.training import trim_caption_columns
+    B, S_len = 4, 512
+    ids, mask = synth_captions(B, S_len, seed=9)
+    for b, n in enumerate([9, 3, 14, 1]):
+        mask[b, :n], mask[b, n:] = 1, 0
+        ids[b, n:] = 0
+        ids[b, 0] = 101
+    eng = MMRCAEngine("distilbert", "transformer_B16", dtype=torch.float32)
+    eng.load_arrays(proc_state_for(eng))
+    eng.refresh_working_copy(force=True)
+    full, _ = eng._text_forward(torch.from_numpy(ids).cuda(), torch.from_numpy(mask).cuda(), save=False)
+    full = full.float().cpu().clone()
+    t_ids, t_mask = trim_caption_columns(torch.from_numpy(ids), torch.from_numpy(mask))
+    assert t_ids.shape == (B, 16)
+    cut, _ = eng._text_forward(t_ids.cuda(), t_mask.cuda(), save=False)
+    assert rel(cut, full) < 1e-6, rel(cut, full)
+    eng.release_buffers()
+
+
 def test_head_matches_reference_goldens_and_grads():
     """HIP fused head vs logits/gradients recorded from the reference's MM_RCA (d_img=1280, d_txt=768)."""
     g = np.load(os.path.join(G, "head_goldens.npz"))

@@ -222,6 +222,25 @@ def _loader(n, bs):
     return torch.utils.data.DataLoader(items, batch_size=bs), xs, ys
 
 
+def test_trim_caption_columns_keeps_every_live_token():
+    """graphed steps run padded rows: the dataset's 512-column captions (CustomImageTextFolder.py:305-333, padding='max_length') are cut to
+    the columns the batch uses, rounded up to 16; nothing live is dropped, short or empty batches keep at least one block"""
+    from garbage_classification_rca_amd.training import trim_caption_columns
+    tok = torch.arange(4 * 512).view(4, 512)
+    mask = torch.zeros(4, 512, dtype=torch.int64)
+    for b, n in enumerate((7, 19, 1, 12)):
+        mask[b, :n] = 1
+    t, m = trim_caption_columns(tok, mask)
+    assert t.shape == m.shape == (4, 32) and torch.equal(t, tok[:, :32]) and int(m.sum()) == int(mask.sum()) and t.is_contiguous()
+    mask[1, 19:] = 0; mask[1, :16] = 1; mask[1, 16:] = 0
+    assert trim_caption_columns(tok, mask)[0].shape == (4, 16)
+    assert trim_caption_columns(tok, torch.zeros_like(mask))[0].shape == (4, 16)            # a caption batch zeroed by modality dropout
+    full = torch.ones(4, 512, dtype=torch.int64)
+    t, m = trim_caption_columns(tok, full)
+    assert t is tok and m is full                                                              # nothing to trim: the inputs themselves
+    assert trim_caption_columns(tok[:, :10], mask[:, :10])[0].shape == (4, 10)                # already shorter than a block
+
+
 @pytest.mark.parametrize("acc_steps", [0, 2, 3])
 def test_run_one_epoch_accumulation_semantics(acc_steps):
     """Gradients of the micro-batches are SUMMED (backward before the /acc_steps), the step happens every acc_steps
