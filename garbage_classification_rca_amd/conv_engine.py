@@ -40,7 +40,8 @@ FUSE_GEMM_BN = os.environ.get("MMRCA_CONV_FUSE_GEMM_BN", "0") == "1"
 BN_FLAT = os.environ.get("MMRCA_BN_FLAT", "0") == "1"               # flat BatchNorm reductions (csrc/conv.hip, opt-in): need a 16 MiB workspace
 FUSE_SE = os.environ.get("MMRCA_CONV_FUSE_SE", "1") == "1"         # SE backward: dx and the next BatchNorm's backward sums in one pass
 FUSE_SE_MLP = os.environ.get("MMRCA_CONV_FUSE_SE_MLP", "1") == "1"   # squeeze-excitation MLP: one launch forward, two backward
-SE_FUSE_MAX = int(os.environ.get("MMRCA_CONV_SE_FUSE_MAX", "160000"))   # c * sq up to which the fused MLP is used (see ConvEncoder._se_fused)
+SE_FUSE_MAX = int(os.environ.get("MMRCA_CONV_SE_FUSE_MAX", "160000"))   # c * sq up to which the fused MLP BACKWARD is used (see ConvEncoder._se_fused)
+SE_FUSE_MAX_FWD = int(os.environ.get("MMRCA_CONV_SE_FUSE_MAX_FWD", "300000"))   # ... and the forward (sixteen waves per sample)
 FUSE_RES = os.environ.get("MMRCA_CONV_FUSE_RES", "1") == "1"       # residual connection inside the block's last BatchNorm pass
 IGEMM_DGRAD = os.environ.get("MMRCA_CONV_IGEMM_DGRAD", "1") == "1"
 
@@ -465,11 +466,13 @@ class ConvEncoder:
 
     # ------------------------------------------------------------------ squeeze-excitation
     @staticmethod
-    def _se_fused(se: "_SE") -> bool:
-        """the fused squeeze-excitation MLP (one workgroup per sample re-reads both weight matrices) wins while they are small --
-        measured (tools/se_bench.py, B = 64 / 128): 1824 x 76: 40 vs 75 us forward, 48 vs 137 backward; 2304 x 96: 57 vs 43, 76 vs 66 --
-        and whenever the squeeze width is not a multiple of 8 (EfficientNetV2-M: 20 / 44 / 76 -> the general GEMM kernel)"""
-        return FUSE_SE_MLP and se.c % 4 == 0 and se.sq % 4 == 0 and (se.c * se.sq <= SE_FUSE_MAX or se.sq % 8 != 0)
+    def _se_fused(se: "_SE", limit: int) -> bool:
+        """the fused squeeze-excitation MLP (one workgroup per sample re-reads both weight matrices, and all B <= 128 workgroups run side
+        by side, so a launch lasts as long as one sample) wins while the matrices are small -- and whenever the squeeze width is not a
+        multiple of 8 (EfficientNetV2-M: 20 / 44 / 76 -> the general GEMM kernel).  Measured (tools/se_bench.py, us, fused vs GEMM
+        sequence): forward 1824 x 76: 23 vs 75, 2304 x 96: 32 vs 44, 3072 x 128: 51 vs 46, 3840 x 160: 79 vs 62; backward 1824 x 76: 48 vs 137,
+        2304 x 96: 76 vs 66.  Forward and backward choose independently (both forms save the same tensors)."""
+        return FUSE_SE_MLP and se.c % 4 == 0 and se.sq % 4 == 0 and (se.c * se.sq <= limit or se.sq % 8 != 0)
 
     def _se_fwd(self, se: _SE, x, B, HW, tag, save):
         dt = self.cdt
@@ -477,7 +480,7 @@ class ConvEncoder:
         pooled, h_pre, h = n(".se.pool", B, se.c), n(".se.hpre", B, se.sq), n(".se.h", B, se.sq)
         s_pre, s = n(".se.spre", B, se.c), n(".se.s", B, se.c)
         L.rowpool_mean(x, pooled, B, HW, se.c, dt)
-        if self._se_fused(se):        # fc1 + SiLU + fc2 + sigmoid in one launch (four M = B GEMM-shaped launches otherwise)
+        if self._se_fused(se, SE_FUSE_MAX_FWD):        # fc1 + SiLU + fc2 + sigmoid in one launch (four M = B GEMM-shaped launches otherwise)
             L.se_mlp_fwd(pooled, self.W(se.key + ".fc1.weight"), self.W(se.key + ".fc1.bias"), self.W(se.key + ".fc2.weight"),
                          self.W(se.key + ".fc2.bias"), h_pre, h, s_pre, s, B, se.c, se.sq, dt)
         else:
@@ -499,7 +502,7 @@ class ConvEncoder:
         fused = FUSE_SE and self.cdtype == torch.bfloat16 and se.c % 8 == 0
         L.se_scale_bwd(dy, sv["x"], sv["s"], None if fused else dx, ds, B, HW, se.c, dt)
         ds_pre, dh_pre, dpool = g(".dspre", B, se.c), g(".dhpre", B, se.sq), g(".dpool", B, se.c)
-        if self._se_fused(se):        # the whole MLP backward: a per-sample chain + one launch for the batch sums (six launches otherwise)
+        if self._se_fused(se, SE_FUSE_MAX):        # the whole MLP backward: a per-sample chain + one launch for the batch sums (six launches otherwise)
             L.se_mlp_bwd(ds, sv["pooled"], sv["h_pre"], sv["h"], sv["s_pre"], self.W(se.key + ".fc1.weight"), self.W(se.key + ".fc1.bias"),
                          self.W(se.key + ".fc2.weight"), self.W(se.key + ".fc2.bias"), ds_pre, dh_pre, dpool, self.G(se.key + ".fc1.weight"),
                          self.G(se.key + ".fc1.bias"), self.G(se.key + ".fc2.weight"), self.G(se.key + ".fc2.bias"), B, se.c, se.sq, dt)

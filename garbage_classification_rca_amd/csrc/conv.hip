@@ -2179,22 +2179,23 @@ extern "C" int mmrca_bias_act_bwd(const void* dy, const void* x, const void* bia
 // ---------------------------------------------------------------------------------------------------------------------
 // (every loop below keeps several independent 8 / 16-byte loads in flight and reduces across lanes at most a few times per wave:
 // the first version -- a wave_sum per output and one dependent load per iteration -- ran the chain in ~150 us per block)
-template <typename T>
-__global__ void __launch_bounds__(256)
+template <typename T, int NW>
+__global__ void __launch_bounds__(64 * NW)
 se_mlp_fwd_k(const T* __restrict__ pooled, const T* __restrict__ W1, const T* __restrict__ b1, const T* __restrict__ W2,
              const T* __restrict__ b2, T* __restrict__ h_pre, T* __restrict__ h, T* __restrict__ s_pre, T* __restrict__ s, int c, int sq) {
   extern __shared__ __attribute__((aligned(16))) float se_sm[];              // pooled [c] | h [sq]
   float* pf = se_sm;
   float* hf = se_sm + c;
   const int b = blockIdx.x, wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-  for (int i = threadIdx.x * 4; i < c; i += 1024) {
+  constexpr int NT = 64 * NW;        // sixteen waves per sample: B <= 128 workgroups run side by side, so the launch lasts as long as ONE does
+  for (int i = threadIdx.x * 4; i < c; i += 4 * NT) {
     const Vec4<T> v = Vec4<T>::load(pooled + (int64_t)b * c + i);
 #pragma unroll
     for (int k = 0; k < 4; ++k) pf[i + k] = v.v[k];
   }
   __syncthreads();
   // fc1 (W1 [sq, c]): a wave takes its share of the outputs four at a time, lanes along the contraction; four reductions interleaved
-  const int jw = (sq + 3) / 4, jend = min(sq, (wave + 1) * jw);
+  const int jw = (sq + NW - 1) / NW, jend = min(sq, (wave + 1) * jw);
   for (int j0 = wave * jw; j0 < jend; j0 += 4) {
     const int nj = min(4, jend - j0);
     float a[4] = {0.f, 0.f, 0.f, 0.f};
@@ -2223,8 +2224,8 @@ se_mlp_fwd_k(const T* __restrict__ pooled, const T* __restrict__ W1, const T* __
   }
   __syncthreads();
   // fc2 (W2 [c, sq]): a thread per output walks its own (contiguous) row, two rows at a time
-  for (int i0 = threadIdx.x; i0 < c; i0 += 512) {
-    const int i1 = i0 + 256 < c ? i0 + 256 : i0;
+  for (int i0 = threadIdx.x; i0 < c; i0 += 2 * NT) {
+    const int i1 = i0 + NT < c ? i0 + NT : i0;
     const T* r0 = W2 + (int64_t)i0 * sq;
     const T* r1 = W2 + (int64_t)i1 * sq;
     float a0 = 0.f, a1 = 0.f;
@@ -2250,17 +2251,18 @@ se_mlp_fwd_k(const T* __restrict__ pooled, const T* __restrict__ W1, const T* __
 
 // backward chain of one sample: ds -> ds_pre (x sigmoid') -> dh = ds_pre . W2 -> dh_pre (x silu') -> dpool = dh_pre . W1; the bias
 // gradients are the batch sums of ds_pre / dh_pre (fp32 atomics, B addends per entry)
-template <typename T>
-__global__ void __launch_bounds__(256)
+template <typename T, int NW>
+__global__ void __launch_bounds__(64 * NW)
 se_mlp_bwd_k(const T* __restrict__ ds, const T* __restrict__ s_pre, const T* __restrict__ h_pre, const T* __restrict__ W1,
              const T* __restrict__ b1, const T* __restrict__ W2, const T* __restrict__ b2, T* __restrict__ ds_pre, T* __restrict__ dh_pre,
              T* __restrict__ dpool, float* __restrict__ gb1, float* __restrict__ gb2, int c, int sq) {
-  extern __shared__ __attribute__((aligned(16))) float se_sm[];              // ds_pre [c] | partial dh [4][sq] | dh_pre [sq]
+  extern __shared__ __attribute__((aligned(16))) float se_sm[];              // ds_pre [c] | partial dh [NW][sq] | dh_pre [sq]
+  constexpr int NT = 64 * NW;
   float* dsp = se_sm;
   float* part = se_sm + c;
-  float* dhp = part + 4 * sq;
+  float* dhp = part + NW * sq;
   const int b = blockIdx.x, wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-  for (int i = threadIdx.x; i < c; i += 256) {
+  for (int i = threadIdx.x; i < c; i += NT) {
     const float g = to_f(ds[(int64_t)b * c + i]) * act_grad_f(to_f(s_pre[(int64_t)b * c + i]) + to_f(b2[i]), CONV_ACT_SIGMOID);
     const T gt = from_f<T>(g);
     ds_pre[(int64_t)b * c + i] = gt;
@@ -2275,7 +2277,7 @@ se_mlp_bwd_k(const T* __restrict__ ds, const T* __restrict__ s_pre, const T* __r
     float acc[32];
 #pragma unroll
     for (int k = 0; k < 32; ++k) acc[k] = 0.f;
-    for (int i = threadIdx.x; i < c; i += 256) {
+    for (int i = threadIdx.x; i < c; i += NT) {
       const float d = dsp[i];
       const T* r = W2 + (int64_t)i * sq + jc;
 #pragma unroll
@@ -2297,8 +2299,10 @@ se_mlp_bwd_k(const T* __restrict__ ds, const T* __restrict__ s_pre, const T* __r
     }
   }
   __syncthreads();
-  for (int j = threadIdx.x; j < sq; j += 256) {
-    const float dh = part[j] + part[sq + j] + part[2 * sq + j] + part[3 * sq + j];
+  for (int j = threadIdx.x; j < sq; j += NT) {
+    float dh = 0.f;
+#pragma unroll
+    for (int w = 0; w < NW; ++w) dh += part[w * sq + j];
     const float g = to_f(from_f<T>(dh)) * act_grad_f(to_f(h_pre[(int64_t)b * sq + j]) + to_f(b1[j]), CONV_ACT_SILU);
     const T gt = from_f<T>(g);
     dh_pre[(int64_t)b * sq + j] = gt;
@@ -2307,7 +2311,7 @@ se_mlp_bwd_k(const T* __restrict__ ds, const T* __restrict__ s_pre, const T* __r
   }
   __syncthreads();
   // dpool[i] = sum_j dh_pre[j] W1[j][i]: a thread per four consecutive outputs (coalesced rows of W1 [sq, c])
-  for (int i = threadIdx.x * 4; i < c; i += 1024) {
+  for (int i = threadIdx.x * 4; i < c; i += 4 * NT) {
     float a[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll 4
     for (int j = 0; j < sq; ++j) {
@@ -2355,7 +2359,7 @@ extern "C" int mmrca_se_mlp_fwd(const void* pooled, const void* w1, const void* 
                 "se_mlp_fwd: bad shape B=%d c=%d sq=%d (c and sq must be multiples of 4)", B, c, sq);
   const size_t lds = (size_t)(c + sq) * sizeof(float);
   MMRCA_DISPATCH_DTYPE(dtype, "se_mlp_fwd",
-    hipLaunchKernelGGL(se_mlp_fwd_k<T>, dim3(B), dim3(256), lds, (hipStream_t)stream, (const T*)pooled, (const T*)w1, (const T*)b1, (const T*)w2,
+    hipLaunchKernelGGL((se_mlp_fwd_k<T, 16>), dim3(B), dim3(1024), lds, (hipStream_t)stream, (const T*)pooled, (const T*)w1, (const T*)b1, (const T*)w2,
                        (const T*)b2, (T*)h_pre, (T*)h, (T*)s_pre, (T*)s, c, sq);)
   MMRCA_CHECK_LAUNCH("se_mlp_fwd");
   return 0;
@@ -2372,7 +2376,8 @@ extern "C" int mmrca_se_mlp_bwd(const void* ds, const void* pooled, const void* 
   const int64_t n = (int64_t)c * sq;
   const int nb = (int)((n + 255) / 256);
   MMRCA_DISPATCH_DTYPE(dtype, "se_mlp_bwd",
-    hipLaunchKernelGGL(se_mlp_bwd_k<T>, dim3(B), dim3(256), lds, (hipStream_t)stream, (const T*)ds, (const T*)s_pre, (const T*)h_pre,
+    // (four waves per sample here: with sixteen the 32-value butterflies of the dh stage outweigh the shorter row walk -- measured)
+    hipLaunchKernelGGL((se_mlp_bwd_k<T, 4>), dim3(B), dim3(256), lds, (hipStream_t)stream, (const T*)ds, (const T*)s_pre, (const T*)h_pre,
                        (const T*)w1, (const T*)b1, (const T*)w2, (const T*)b2, (T*)ds_pre, (T*)dh_pre, (T*)dpool, gb1, gb2, c, sq);
     hipLaunchKernelGGL(se_mlp_wgrad_k<T>, dim3(2 * nb), dim3(256), 0, (hipStream_t)stream, (const T*)ds_pre, (const T*)h, (const T*)dh_pre,
                        (const T*)pooled, gw1, gw2, B, c, sq, nb);)
