@@ -20,7 +20,7 @@ import torch
 
 from .CustomImageTextFolder import CustomImageTextFolder
 from .main_both import DecodeOnly, Transforms, collate_decoded
-from .training import stage_images
+from .training import stage_images, trim_caption_columns
 from .multimodal_model import MM_RCA
 from .options import args_parser
 from .training import mode_config_dict
@@ -46,7 +46,10 @@ def calculate_test_accuracy(model, data_loader, len_test_data, hw_device, batch_
         for batch_idx, (data, labels) in enumerate(data_loader):
             texts = data['text']
             images = stage_images(data['image']['raw_image'], hw_device, image_pipeline)
-            ids, mask = texts['tokens'].to(hw_device), texts['attention_mask'].to(hw_device)
+            tok, msk = texts['tokens'], texts['attention_mask']
+            if hasattr(model, "engine") and not msk.is_cuda:      # drop the padding columns no caption of the batch uses (training.py)
+                tok, msk = trim_caption_columns(tok, msk)
+            ids, mask = tok.to(hw_device), msk.to(hw_device)
             labels = labels.to(hw_device)
             outputs = model(_input_ids=ids, _attention_mask=mask, _images=images, eval=eval_mode,
                             remove_text=mode["remove_text"], remove_image=mode["remove_image"])

@@ -329,13 +329,20 @@ def calculate_set_accuracy(model, data_loader, len_data, device, batch_size, mod
     padding that equalises the ranks and would otherwise be counted twice)."""
     n_batches = math.ceil(len_data / batch_size)
     all_labels, all_predictions = [], []
-    correct, seen = 0, 0
+    seen = 0
     with torch.no_grad():
         for batch_idx, (data, labels) in enumerate(data_loader):
             images = stage_images(data['image']['raw_image'], device, image_pipeline, aug_params)
             texts = data['text']
-            ids, mask = texts['tokens'].to(device), texts['attention_mask'].to(device)
-            labels = labels.to(device)
+            tok, msk = texts['tokens'], texts['attention_mask']
+            if hasattr(model, "engine") and not msk.is_cuda:
+                # the dataset pads every caption to the text model's maximum (512, CustomImageTextFolder.py:305-333) while the
+                # captions are file-name stems of ~10 tokens: the columns no caption of the batch uses are dropped on the host --
+                # same logits (masked keys, class-token pooling), a fraction of the text encoder's work in the FOUR evaluation
+                # passes of every epoch (main_both.py:596-646)
+                tok, msk = trim_caption_columns(tok, msk)
+            ids, mask = tok.to(device, non_blocking=True), msk.to(device, non_blocking=True)
+            labels = labels.to(device, non_blocking=True)
             outputs = model(_input_ids=ids, _attention_mask=mask, _images=images, eval=eval_mode,
                             remove_text=mode["remove_text"], remove_image=mode["remove_image"])
             pred = torch.max(outputs, 1)[1].view(-1)
@@ -343,13 +350,17 @@ def calculate_set_accuracy(model, data_loader, len_data, device, batch_size, mod
                 keep = max(0, min(len(labels), n_real - seen))
                 seen += len(labels)
                 pred, labels = pred[:keep], labels[:keep]
-            correct += torch.sum(torch.eq(pred, labels)).item()
             if verbose:
                 print("Batches {}/{} ".format(batch_idx, n_batches))
-            all_labels.append(labels.cpu())
-            all_predictions.append(pred.cpu())
-    labels_flat = [int(x) for t in all_labels for x in t]
-    preds_flat = [int(x) for t in all_predictions for x in t]
+            # (the reference copies the predictions of every batch to the host, :181-189 -- a device sync per batch; they are only read
+            # after the pass, so they stay in HBM until then)
+            all_labels.append(labels)
+            all_predictions.append(pred)
+    lab = torch.cat([t.view(-1) for t in all_labels]).cpu() if all_labels else torch.zeros(0, dtype=torch.int64)
+    prd = torch.cat([t.view(-1) for t in all_predictions]).cpu() if all_predictions else torch.zeros(0, dtype=torch.int64)
+    correct = int((lab == prd).sum().item())
+    labels_flat = [int(x) for x in lab]
+    preds_flat = [int(x) for x in prd]
     count = len_data
     if all_reduce is not None:
         correct, count = all_reduce(correct, len(labels_flat), device)
