@@ -590,10 +590,23 @@ def main():
         cprof = None
         if eng.conv is not None:       # conv image encoder: a third replay with every launch's ALGORITHMIC bytes and HIP-event time
             L.CONV_PROFILE = []
+            if os.environ.get("MMRCA_BENCH_SHAPES") == "1":
+                L.GEMM_SHAPES = []
             for i in range(replay):
                 step(i)
             torch.cuda.synchronize()
             cprof, L.CONV_PROFILE = L.CONV_PROFILE, None
+            if L.GEMM_SHAPES is not None:      # per-shape table of every GEMM of the conv step (stderr), for kernel tuning
+                tab = {}
+                for (Mg, Ng, Kg, al, bl, ac, nb_, e0, e1) in L.GEMM_SHAPES:
+                    d_ = tab.setdefault((Mg, Ng, Kg, al, bl, ac), [0, 0.0, nb_])
+                    d_[0] += 1; d_[1] += e0.elapsed_time(e1)
+                L.GEMM_SHAPES = None
+                print("[bench] GEMMs of the conv step by shape (M, N, K, a_layout, b_layout, accum): calls/step, us/call, ms/step, TB/s, TFLOP/s", file=sys.stderr)
+                for k_, (n_, ms_, nb_) in sorted(tab.items(), key=lambda kv: -kv[1][1])[:60]:
+                    us = ms_ / n_ * 1e3
+                    print(f"[bench]   {k_}: {n_ // replay} x {us:7.1f} us = {ms_ / replay:6.2f} ms   {nb_ / (us * 1e-6) / 1e12:5.2f} TB/s   "
+                          f"{2.0 * k_[0] * k_[1] * k_[2] / (us * 1e-6) / 1e12:6.1f} TFLOP/s", file=sys.stderr)
     prof, L.GEMM_PROFILE = L.GEMM_PROFILE, None
     kprof, L.KERNEL_PROFILE = L.KERNEL_PROFILE, None
     eng._side_v, eng._side_t, eng._side, eng._text_stream = saved_streams

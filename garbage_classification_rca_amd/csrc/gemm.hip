@@ -354,10 +354,15 @@ typedef const __attribute__((address_space(1))) void gbl_void;
 
 __device__ __forceinline__ int krow_f(int row) { return (row & 3) | (((row >> 3) & 1) << 2); }
 
+// 16 zero bytes in global memory: the source of a B chunk past the end of the contraction (the EDGE forms of stage_tile / stage_tile32)
+__device__ __attribute__((aligned(16))) static const unsigned int mmrca_zero_chunk[4] = {0u, 0u, 0u, 0u};
+
 // stage one 128x64 operand tile (16 x 1-KiB wave instructions; this wave issues 4 of them)
-template <bool KROW>
+// EDGE (round 5; see stage_tile32): the last step of a contraction that is a multiple of 8 but not of 64 -- chunks past `kend` are fetched
+// as zeros on the B side (2) and as a duplicate of a valid chunk on the A side (1)
+template <bool KROW, int EDGE = 0>
 __device__ __forceinline__ void stage_tile(const bf16_t* __restrict__ base, int64_t ld, int64_t row0, int64_t rows_total,
-                                           int64_t k0, char* lds_tile, int wave, int lane) {
+                                           int64_t k0, char* lds_tile, int wave, int lane, int64_t kend = 0) {
 #pragma unroll
   for (int ii = 0; ii < 4; ++ii) {
     const int i = wave * 4 + ii;
@@ -367,14 +372,20 @@ __device__ __forceinline__ void stage_tile(const bf16_t* __restrict__ base, int6
       const int c = (lane & 7) ^ ((r >> 1) & 7);
       int64_t gr = row0 + r;
       if (gr > rows_total - 1) gr = rows_total - 1;        // edge rows: read a valid row, results are never stored
-      src = base + gr * ld + k0 + c * 8;
+      int64_t kc = k0 + c * 8;
+      if (EDGE == 1 && kc >= kend) kc = kend - 8;
+      src = base + gr * ld + kc;
+      if (EDGE == 2 && kc >= kend) src = reinterpret_cast<const bf16_t*>(mmrca_zero_chunk);
     } else {
       const int kr = 4 * i + (lane >> 4);
       const int chp = lane & 15;
       const int c = ((((chp >> 1) ^ krow_f(kr))) << 1) | (chp & 1);
       int64_t col = row0 + c * 8;
       if (col > rows_total - 8) col = rows_total - 8;       // ragged edge (rows_total % 8 == 0): read a valid chunk, results are never stored
-      src = base + (k0 + kr) * ld + col;
+      int64_t kk = k0 + kr;
+      if (EDGE == 1 && kk >= kend) kk = kend - 1;
+      src = base + kk * ld + col;
+      if (EDGE == 2 && kk >= kend) src = reinterpret_cast<const bf16_t*>(mmrca_zero_chunk);
     }
     __builtin_amdgcn_global_load_lds((gbl_void*)src, (lds_void*)(lds_tile + i * 1024), 16, 0, 0);
   }
@@ -637,9 +648,6 @@ gemm_mfma_k(const bf16_t* __restrict__ A, const bf16_t* __restrict__ B, void* __
 // valid rows of the ROUNDED outputs, written (not added) to s1 / s2 [tiles_m, N]; mmrca_bn_finish_sums merges the row blocks.
 // shift = the layer's running mean keeps s2 - s1^2 / n free of cancellation.
 struct BnStat { const float* shift; float* s1; float* s2; };
-
-// 16 zero bytes in global memory: the source of a B chunk past the end of the contraction (see stage_tile32's EDGE forms)
-__device__ __attribute__((aligned(16))) static const unsigned int mmrca_zero_chunk[4] = {0u, 0u, 0u, 0u};
 
 // EDGE (round 5): the last 32-deep step of a contraction that is a multiple of 8 but not of 32 (EfficientNetV2-M's channel counts:
 // 80, 176, 304 -- the reference's default image model put 35 + 33 of its 1x1 convolutions on the general kernel at ~65 TFLOP/s for
@@ -960,8 +968,13 @@ gemm_mfma_k1s(const bf16_t* __restrict__ A, const bf16_t* __restrict__ B, void* 
       if (seg == 1) Ap = A_lo;
       if (seg == 2) Bp = B_lo;
     }
-    stage_tile<A_KROW>(Ap, lda, m_blk, M, kbeg + (int64_t)t * GBK, smem, wave, lane);
-    stage_tile<B_KROW>(Bp, ldb, n_blk, N, kbeg + (int64_t)t * GBK, smem + TILE_BYTES, wave, lane);
+    if (!ATOMIC_F32 && !X3 && t == nt - 1 && ((kend - kbeg) & (GBK - 1)) != 0) {      // the contraction ends inside this step (wave-uniform)
+      stage_tile<A_KROW, 1>(Ap, lda, m_blk, M, kbeg + (int64_t)t * GBK, smem, wave, lane, kend);
+      stage_tile<B_KROW, 2>(Bp, ldb, n_blk, N, kbeg + (int64_t)t * GBK, smem + TILE_BYTES, wave, lane, kend);
+    } else {
+      stage_tile<A_KROW>(Ap, lda, m_blk, M, kbeg + (int64_t)t * GBK, smem, wave, lane);
+      stage_tile<B_KROW>(Bp, ldb, n_blk, N, kbeg + (int64_t)t * GBK, smem + TILE_BYTES, wave, lane);
+    }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
 #pragma unroll
@@ -1310,7 +1323,7 @@ static int gemm_dispatch(const void* A, const void* B, void* C, const void* bias
   const bool k_ok = K % 32 == 0 || (kedge_on && !out_f32_accum && K % 8 == 0 && K >= 32);
   if (!ok_mfma && ragged_on && dtype == MMRCA_BF16 && N % 8 == 0 && N >= 8 && k_ok && (a_layout == MMRCA_ROWK || (M % 8 == 0 && M >= 8)) &&
       lda % 8 == 0 && ldb % 8 == 0 && ldc % 4 == 0 && aligned16(A) && aligned16(B) && aligned16(C) && (!bias || (aligned16(bias) && !out_f32_accum)) &&
-      !addend && !preact && act == MMRCA_ACT_NONE && !colsum_fused && (out_f32_accum ? K % 64 == 0 : true) && M >= 64 &&
+      !addend && !preact && act == MMRCA_ACT_NONE && !colsum_fused && (out_f32_accum ? K % 64 == 0 : true) && M >= (out_f32_accum ? 16 : 64) &&
       (impl == MMRCA_GEMM_AUTO || impl == MMRCA_GEMM_MFMA_BK32 || impl == MMRCA_GEMM_MFMA_1STAGE))
     ok_mfma = true;
   const bool ragged = ok_mfma && !strict_mfma;
@@ -1388,12 +1401,18 @@ static int gemm_dispatch(const void* A, const void* B, void* C, const void* bias
     //   forward (ROWK,ROWK) and dgrad (ROWK,KROW): single-stage 128x128x64 (790-910 TFLOP/s vs 680-875 for the two-stage
     //     kernel at two blocks per CU); 64-deep steps keep the ROWK operands' HBM reads in full 128-byte lines;
     //   wgrad (KROW,KROW, fp32 atomics): two-stage 128x128x32 (800-870 vs 680-740), unless there are too few tiles.
-    const bool need32 = K % 64 != 0;                 // (ragged contraction: only the 32-deep kernel takes it)
+    // ragged contraction (K % 64 != 0): the 32-deep kernel takes K % 32 == 0 exactly and anything else through its edge step.  The
+    // single-stage 64-deep kernel has the same edge step (MMRCA_GEMM_KEDGE64=1 sends forward / input gradient AUTO launches with
+    // K % 64 != 0 there: longer steps, half the barriers per flop) -- measured neutral on both conv workloads (EfficientNetV2-M 909.4 vs
+    // 906.9 samples/s, configs[2] 627.1 vs 626.9: these products wait on HBM, not on barriers), so it is off by default.
+    static const int kedge64 = getenv("MMRCA_GEMM_KEDGE64") ? atoi(getenv("MMRCA_GEMM_KEDGE64")) : 0;
+    const bool edge64 = kedge64 && kedge_on && impl == MMRCA_GEMM_AUTO && !out_f32_accum && K % 64 != 0 && K % 8 == 0 && K >= 64;
+    const bool need32 = K % 64 != 0 && !edge64;
     // (experiment, round 4: below this many 128x128 tiles -- an under-filled chip, where the single-stage kernel has no sibling blocks to
     // hide its load -> barrier -> compute sequence -- AUTO takes the two-stage kernel; 0 = never.  Result in DESIGN K2.)
     static const int g_auto_2stage_below = getenv("MMRCA_AUTO_2STAGE_BELOW") ? atoi(getenv("MMRCA_AUTO_2STAGE_BELOW")) : 512;
     const bool auto1s = impl == MMRCA_GEMM_AUTO && !at && !need32 &&
-                        !((int64_t)tiles_m * tiles_n < g_auto_2stage_below && K >= 768 && !colsum_fused && !ragged);
+                        (edge64 || !((int64_t)tiles_m * tiles_n < g_auto_2stage_below && K >= 768 && !colsum_fused && !ragged));
     const bool auto32 = (impl == MMRCA_GEMM_AUTO && at && (int64_t)tiles_m * tiles_n >= 64) || need32;
     if ((impl == MMRCA_GEMM_MFMA_BK32 || auto32) && !(at && bias)) {
 #define L32(AK_, BK_, AT_) launch_mfma32<AK_, BK_, AT_>(A, B, C, bias, addend, preact, M, N, K, lda, ldb, ldc, act, tiles_m, tiles_n, ksplits, ksplit_len, st)

@@ -222,6 +222,7 @@ def _esz(dt):
     return 2 if dt == BF16 else 4
 
 
+GEMM_SHAPES = None      # tools / bench.py (MMRCA_BENCH_SHAPES=1) set this to a list: (M, N, K, a_layout, b_layout, accum, bytes, e0, e1) of EVERY mmrca_gemm launch
 CONV_PROFILE = None     # bench.py sets this to a list: (kernel family, algorithmic HBM bytes, start event, end event) of every conv-path launch
 
 
@@ -263,7 +264,10 @@ def gemm(A, B, Cout, *, bias=None, addend=None, preact=None, M, N, K, lda, ldb, 
     if CONV_PROFILE is not None:         # byte accounting of the conv step (every GEMM, matrix-core qualified or not)
         es = _esz(dtype)
         side = (1 if addend is not None else 0) + (1 if preact is not None else 0)
-        CONV_PROFILE.append(("GEMM (1x1 conv / patch matrix / text encoder)", int((M * K + N * K) * es + M * N * ((4 if accum else es) + side * es)), e0, e1))
+        nbytes = int((M * K + N * K) * es + M * N * ((4 if accum else es) + side * es))
+        CONV_PROFILE.append(("GEMM (1x1 conv / patch matrix / text encoder)", nbytes, e0, e1))
+        if GEMM_SHAPES is not None:
+            GEMM_SHAPES.append((M, N, K, a_layout, b_layout, int(accum), nbytes, e0, e1))
 
 
 SPLITK_WS_BYTES = 64 << 20      # 256 partial tiles of 256x256 fp32: enough for every shape mmrca_gemm_splitk accepts

@@ -239,12 +239,18 @@ def test_gemm_mfma256_layouts_and_epilogues(bl):
     (900, 960, 176, 0, 1, False, False),
     (512, 128, 40, 0, 0, False, False),       # one and a quarter steps
     (512, 128, 40, 0, 1, False, False),
+    (14400, 304, 1824, 0, 1, False, False),   # K = 28.5 steps of 64: the single-stage 64-deep kernel's edge step (AUTO since round 5)
+    (2000, 176, 1056, 0, 0, False, True),
+    (48, 192, 4096, 1, 1, True, False),       # weight gradient of a 192 -> 48 projection: M = 48 rows of output (was the general kernel)
+    (16, 64, 1024, 1, 1, True, False),
 ])
 def test_gemm_ragged_shapes_run_on_the_mfma_kernels(M, N, K, al, bl, accum, bias):
     """channel counts that are multiples of 8 but not of 128 (and contractions that are multiples of 32 but not of 64) on the
     128x128 bf16 MFMA kernels: edge tiles read a clamped chunk and never store it.  AUTO against the fp64 product; the same call
     with MMRCA_GEMM_RAGGED=0 semantics (impl REF) is the checker's checker."""
     _gemm_case(M, N, K, al, bl, torch.bfloat16, L.IMPL_AUTO, bias=bias, accum=accum)
+    if K % 32 and not accum:                  # AUTO takes the 64-deep kernel's edge step; the 32-deep kernel's is kept under test explicitly
+        _gemm_case(M, N, K, al, bl, torch.bfloat16, L.IMPL_MFMA_BK32, bias=bias, accum=accum)
     # the output columns past N and rows past M are untouched: a canary frame around C
     g = torch.Generator().manual_seed(5)
     A = dev(torch.randn((M, K) if al == 0 else (K, M), generator=g) * 0.5, torch.bfloat16)
