@@ -1406,7 +1406,8 @@ static int gemm_dispatch(const void* A, const void* B, void* C, const void* bias
     // K % 64 != 0 there: longer steps, half the barriers per flop) -- measured neutral on both conv workloads (EfficientNetV2-M 909.4 vs
     // 906.9 samples/s, configs[2] 627.1 vs 626.9: these products wait on HBM, not on barriers), so it is off by default.
     static const int kedge64 = getenv("MMRCA_GEMM_KEDGE64") ? atoi(getenv("MMRCA_GEMM_KEDGE64")) : 0;
-    const bool edge64 = kedge64 && kedge_on && impl == MMRCA_GEMM_AUTO && !out_f32_accum && K % 64 != 0 && K % 8 == 0 && K >= 64;
+    const bool edge64 = kedge_on && ((kedge64 && impl == MMRCA_GEMM_AUTO) || impl == MMRCA_GEMM_MFMA_1STAGE) && !out_f32_accum && K % 64 != 0 &&
+                        K % 8 == 0 && K >= 64;      // (an explicit MFMA_1STAGE request always gets it: the tests do that)
     const bool need32 = K % 64 != 0 && !edge64;
     // (experiment, round 4: below this many 128x128 tiles -- an under-filled chip, where the single-stage kernel has no sibling blocks to
     // hide its load -> barrier -> compute sequence -- AUTO takes the two-stage kernel; 0 = never.  Result in DESIGN K2.)

@@ -249,8 +249,10 @@ def test_gemm_ragged_shapes_run_on_the_mfma_kernels(M, N, K, al, bl, accum, bias
     128x128 bf16 MFMA kernels: edge tiles read a clamped chunk and never store it.  AUTO against the fp64 product; the same call
     with MMRCA_GEMM_RAGGED=0 semantics (impl REF) is the checker's checker."""
     _gemm_case(M, N, K, al, bl, torch.bfloat16, L.IMPL_AUTO, bias=bias, accum=accum)
-    if K % 32 and not accum:                  # AUTO takes the 64-deep kernel's edge step; the 32-deep kernel's is kept under test explicitly
+    if K % 32 and not accum:                  # the 32-deep kernel's edge step, explicitly (AUTO takes it too)
         _gemm_case(M, N, K, al, bl, torch.bfloat16, L.IMPL_MFMA_BK32, bias=bias, accum=accum)
+    if K % 64 and K >= 64 and not accum:      # ... and the single-stage 64-deep kernel's (MMRCA_GEMM_KEDGE64, off by default)
+        _gemm_case(M, N, K, al, bl, torch.bfloat16, L.IMPL_MFMA_1STAGE, bias=bias, accum=accum)
     # the output columns past N and rows past M are untouched: a canary frame around C
     g = torch.Generator().manual_seed(5)
     A = dev(torch.randn((M, K) if al == 0 else (K, M), generator=g) * 0.5, torch.bfloat16)

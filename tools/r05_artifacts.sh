@@ -35,3 +35,16 @@ find $O -name "*kernel_trace.csv" -delete; find $O -name "*counter_collection.cs
 python3 bench.py > $O/bench_default.json 2> $O/bench_default.err || exit 1
 python3 bench.py --dtype bf16x3f --steps 24 --warmup 4 --no_cpu_baseline --parity > $O/bench_bf16x3f.json 2> $O/bench_bf16x3f.err || exit 1
 ls -la $O; cat $O/bench_default.json
+# secondary lines (not the headline): configs[0]-shaped, configs[2], configs[3], configs[4] in both modes, the reference's default model, its launch
+# shape, the frozen phase; cfg3 / cfg4 carry `parity`
+python3 bench.py --image_model shuffle_net --batch 4 --steps 16 --warmup 4 --no_cpu_baseline > $O/bench_cfg0.json 2>/dev/null
+python3 bench.py --image_model eff_v2_large --text_model roberta --image_size 480 --batch 128 --steps 3 --warmup 1 --no_cpu_baseline > $O/bench_cfg2.json 2>/dev/null
+python3 bench.py --text_model bert --image_model transformer_L16 --cross_attention_only --seq_len 128 --batch 128 --steps 16 --warmup 4 --no_cpu_baseline --parity > $O/bench_cfg3.json 2>/dev/null
+python3 bench.py --workload qformer --batch 64 --steps 8 --warmup 2 --no_cpu_baseline --parity > $O/bench_cfg4_qformer.json 2>/dev/null
+python3 bench.py --workload qformer --dtype bf16x3f --batch 64 --steps 6 --warmup 2 --no_cpu_baseline --parity > $O/bench_cfg4_qformer_bf16x3f.json 2>/dev/null
+python3 bench.py --image_model eff_v2_medium --image_size 480 --batch 64 --steps 8 --warmup 3 --no_cpu_baseline > $O/bench_effv2m.json 2>/dev/null
+python3 bench.py --image_model eff_v2_medium --image_size 480 --batch 64 --dtype bf16x3f --steps 8 --warmup 3 --no_cpu_baseline --parity > $O/bench_effv2m_bf16x3f.json 2>/dev/null
+python3 bench.py --image_model eff_v2_medium --image_size 480 --batch 16 --seq_len 16 --dtype bf16x3f --graph off --steps 12 --warmup 4 --no_cpu_baseline > $O/bench_reference_launch_shape_b16.json 2>/dev/null
+python3 bench.py --image_model eff_v2_medium --image_size 480 --batch 16 --seq_len 16 --dtype bf16x3f --graph off --frozen --steps 12 --warmup 4 --no_cpu_baseline > $O/bench_reference_launch_shape_b16_frozen.json 2>/dev/null
+python3 bench.py --frozen --no_cpu_baseline > $O/bench_frozen.json 2>/dev/null
+for f in cfg0 cfg2 cfg3 cfg4_qformer cfg4_qformer_bf16x3f effv2m effv2m_bf16x3f reference_launch_shape_b16 reference_launch_shape_b16_frozen frozen; do python3 -c "import json,sys; d=json.load(open('$O/bench_$f.json')); print('$f', d['value'], d['ms_per_step'], d['roofline']['achieved'], (d.get('parity') or {}))"; done
