@@ -35,13 +35,17 @@ def cpu_slice(local_rank: int, local_world: int, cpus=None) -> List[int]:
     return cpus[local_rank * per: (local_rank + 1) * per]
 
 
+MIN_CPUS_PER_RANK = 4
+
+
 def bind_rank_to_cpus(local_rank: int, local_world: int) -> Optional[List[int]]:
     """Pin this process (and the DataLoader workers it will fork) to its rank's CPU slice; MMRCA_CPU_BIND=0 leaves the affinity
-    alone.  Returns the slice, or None when nothing was changed (one rank per node, binding off, or no sched_setaffinity)."""
+    alone.  Returns the slice, or None when nothing was changed (one rank per node, binding off, fewer than MIN_CPUS_PER_RANK cores per
+    rank, or no sched_setaffinity)."""
     if local_world <= 1 or os.environ.get("MMRCA_CPU_BIND", "1") != "1" or not hasattr(os, "sched_setaffinity"):
         return None
     sl = cpu_slice(local_rank, local_world)
-    if not sl:
+    if len(sl) < MIN_CPUS_PER_RANK:        # a rank also runs RCCL's proxy thread and the HIP runtime's helpers: never squeeze it onto < 4 cores
         return None
     try:
         os.sched_setaffinity(0, sl)

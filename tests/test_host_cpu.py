@@ -683,7 +683,9 @@ def test_rank_to_cpu_binding_slices_and_worker_cap(monkeypatch):
         monkeypatch.setenv("MMRCA_CPU_BIND", "0")
         assert D.bind_rank_to_cpus(1, 2) is None and os.sched_getaffinity(0) == before
         monkeypatch.setenv("MMRCA_CPU_BIND", "1")
-        if len(before) >= 2:
+        if len(before) < 2 * D.MIN_CPUS_PER_RANK:
+            assert D.bind_rank_to_cpus(1, 2) is None and os.sched_getaffinity(0) == before      # too few cores per rank: left alone
+        else:
             got = D.bind_rank_to_cpus(1, 2)
             assert got == sorted(before)[len(before) // 2: 2 * (len(before) // 2)] and os.sched_getaffinity(0) == set(got)
             assert D.loader_workers(16) == max(1, min(16, len(got) - 1))
