@@ -561,7 +561,9 @@ def test_end_to_end_training_driver_and_evaluator_on_a_tiny_folder(tmp_path, ima
                 Image.fromarray(arr).save(d / f"{['chip_bag','pizza_box','banana_peel','aa_batteries'][ci]}_{k}.png")
     env = dict(os.environ, PYTHONPATH=root)
     common = ["--late_fusion=MM_RCA", "--reverse", f"--image_model={image_model}", "--text_model=distilbert", "--image_size", "224" if image_model == "transformer_B16" else "64",
-              "--tokens_max_len", "16", "--num_workers", "0", "--dtype", dtype]
+              "--tokens_max_len", "16", "--num_workers", "2" if image_model == "shuffle_net" else "0", "--dtype", dtype]
+    # (shuffle_net runs with DataLoader workers: its step is captured in a HIP graph while the loader's pin-memory thread is alive --
+    # capture_error_mode="thread_local" in training.GraphedTrainStep)
     r = subprocess.run([sys.executable, os.path.join(root, "main_both.py"), *common, "--dataset_folder_name=Train",
                         "--dataset_folder_name_val=Val", "--epochs", "2" if image_model == "shuffle_net" else "1", "--ft_epochs", "1", "--batch_size", "4",
                         "--batch_size_FT", "4", "--acc_steps_FT", "2", "--balance_weights", "--label_smoothing", "0.1", "--seed", "1", "--prob_aug", "0.8",
