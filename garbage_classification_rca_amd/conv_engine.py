@@ -39,6 +39,7 @@ IGEMM = os.environ.get("MMRCA_CONV_IGEMM", "1") == "1"
 FUSE_GEMM_BN = os.environ.get("MMRCA_CONV_FUSE_GEMM_BN", "0") == "1"
 BN_FLAT = os.environ.get("MMRCA_BN_FLAT", "0") == "1"               # flat BatchNorm reductions (csrc/conv.hip, opt-in): need a 16 MiB workspace
 FUSE_SE = os.environ.get("MMRCA_CONV_FUSE_SE", "1") == "1"         # SE backward: dx and the next BatchNorm's backward sums in one pass
+FUSE_BN_FINISH = os.environ.get("MMRCA_CONV_FUSE_BN_FINISH", "1") == "1"   # BatchNorm moments + finish in one launch
 FUSE_SE_MLP = os.environ.get("MMRCA_CONV_FUSE_SE_MLP", "1") == "1"   # squeeze-excitation MLP: one launch forward, two backward
 SE_FUSE_MAX = int(os.environ.get("MMRCA_CONV_SE_FUSE_MAX", "160000"))   # c * sq up to which the fused MLP BACKWARD is used (see ConvEncoder._se_fused)
 SE_FUSE_MAX_FWD = int(os.environ.get("MMRCA_CONV_SE_FUSE_MAX_FWD", "300000"))   # ... and the forward (sixteen waves per sample)
@@ -250,14 +251,19 @@ class ConvEncoder:
         if self._bn_arena is None:
             self._bn_arena = torch.zeros(self.BN_ARENA_FLOATS, dtype=torch.float32, device=self.o.device)
         off = self._bn_off.get(u.bn_key)
+        c = u.cout
+        nt = _ru((c + 63) // 64, 4)                          # tickets of the fused statistics launch (mmrca_bn_stats_fused), cleared with the rest
         if off is None:
             off = self._bn_used
-            self._bn_used += 4 * _ru(u.cout, 4)              # (16-byte aligned slices)
+            self._bn_used += 4 * _ru(c, 4) + nt             # (16-byte aligned slices)
             if self._bn_used > self.BN_ARENA_FLOATS:
                 raise L.MmrcaError("conv_engine: BatchNorm arena exhausted")
             self._bn_off[u.bn_key] = off
-        c = u.cout
         return self._bn_arena[off: off + 2 * c].view(2, c), self._bn_arena[off + 2 * _ru(c, 4): off + 2 * _ru(c, 4) + 2 * c].view(1, 2 * c)
+
+    def _bn_tickets(self, u: "_Unit"):
+        off = self._bn_off[u.bn_key] + 4 * _ru(u.cout, 4)
+        return self._bn_arena[off: off + _ru((u.cout + 63) // 64, 4)].view(torch.int32)
 
     def _bn_scratch(self, u: "_Unit"):
         """the backward sums of u, clear: by forward()'s fill, or -- a second backward over the same forward -- by a fill of its own"""
@@ -387,7 +393,9 @@ class ConvEncoder:
         elif sums is not None:
             L.bn_finish_sums(sums[0], sums[1], rm, sums[2], rows, mean, rstd, rm, rv, u.cout, u.eps, 0.1)
         else:
-            L.bn_stats(z, mean, rstd, rm, rv, rows, u.cout, u.cout, u.eps, 0.1 if train else 0.0, train, dt, ws=self._bn_ws(), prezeroed=True)
+            fuse = FUSE_BN_FINISH and train and self.cdtype == torch.bfloat16 and u.cout % 8 == 0 and not BN_FLAT
+            L.bn_stats(z, mean, rstd, rm, rv, rows, u.cout, u.cout, u.eps, 0.1 if train else 0.0, train, dt, ws=self._bn_ws(), prezeroed=True,
+                       tickets=self._bn_tickets(u) if fuse else None)
         fused_res = res is not None and FUSE_RES and self.cdtype == torch.bfloat16 and u.cout % 8 == 0
         if fused_res:
             y = out

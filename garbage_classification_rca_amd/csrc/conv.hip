@@ -1186,9 +1186,10 @@ __device__ __forceinline__ int64_t bn_shift_row(int k, int64_t rows) {
   return (int64_t)k * seg + (int64_t)((2654435761u * (unsigned)(k + 1)) % (unsigned long long)seg);
 }
 __device__ __forceinline__ float bn_trimmed(float sum, float lo, float hi) { return (sum - lo - hi) * (1.0f / (BN_SHIFT_ROWS - 2)); }
+struct BnFinish { int* counters; float* running_mean; float* running_var; float eps, momentum; };
 __global__ void __launch_bounds__(256)
 col_moment2_v8_k(const bf16_t* __restrict__ x, float* __restrict__ s1, float* __restrict__ s2, int64_t rows, int C, int64_t ld,
-                 int64_t rows_per_block) {
+                 int64_t rows_per_block, BnFinish fin = BnFinish{nullptr, nullptr, nullptr, 0.f, 0.f}) {
   __shared__ float red[4][8][17];
   const int cg = threadIdx.x & 7, rl = threadIdx.x >> 3;
   const int c0 = blockIdx.x * 64 + cg * 8;
@@ -1226,6 +1227,36 @@ col_moment2_v8_k(const bf16_t* __restrict__ x, float* __restrict__ s1, float* __
   }
   float* const outs[2] = {s1, s2};
   col_reduce8<2>(acc, red, outs, blockIdx.x, C);
+  // fin.counters != NULL (round 5): the LAST of the gridDim.y row ranges of this 64-channel block turns the sums into mean / rstd and
+  // updates the running statistics itself -- what bn_finish_shifted_k did in a launch of its own (one per BatchNorm layer and step: 146
+  // of the ~1,900 launches of an EfficientNetV2-M step at the reference's batch size 16).  The atomics above are device-scope
+  // read-modify-writes at L2; the fence orders them before the ticket, and the finishing reads go to L2 as well.
+  if (fin.counters) {
+    __shared__ int last_blk;
+    __threadfence();
+    __syncthreads();
+    if (threadIdx.x == 0) last_blk = atomicAdd(fin.counters + blockIdx.x, 1) == (int)gridDim.y - 1;
+    __syncthreads();
+    if (last_blk && threadIdx.x < 64) {
+      const int c = blockIdx.x * 64 + threadIdx.x;
+      if (c < C) {
+        float shift = 0.f, slo = INFINITY, shi = -INFINITY;
+        for (int k = 0; k < BN_SHIFT_ROWS; ++k) { const float v = (float)x[bn_shift_row(k, rows) * ld + c]; shift += v; slo = fminf(slo, v); shi = fmaxf(shi, v); }
+        shift = bn_trimmed(shift, slo, shi);
+        const float n = (float)rows;
+        const float d1 = __hip_atomic_load(s1 + c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) / n;
+        const float q = __hip_atomic_load(s2 + c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) / n;
+        const float mu = shift + d1;
+        const float var = fmaxf(q - d1 * d1, 0.f);
+        s1[c] = mu;
+        s2[c] = rsqrtf(var + fin.eps);
+        if (fin.running_mean && fin.momentum > 0.f) {
+          fin.running_mean[c] = (1.f - fin.momentum) * fin.running_mean[c] + fin.momentum * mu;
+          fin.running_var[c] = (1.f - fin.momentum) * fin.running_var[c] + fin.momentum * (n > 1.f ? var * n / (n - 1.f) : var);
+        }
+      }
+    }
+  }
 }
 // ---- FLAT column reductions (round 4).  The kernels above give a workgroup a 64-channel slice (128 bytes) of many rows; measured
 // on the MBConv tensors (tools/bn_bench.sh) they stream at 3.1-3.7 TB/s while the element-wise BatchNorm passes next to them, whose
@@ -1469,7 +1500,8 @@ static const bool g_bn_one_pass = !(getenv("MMRCA_BN_ONE_PASS") && atoi(getenv("
 /* mean[C], rstd[C] (fp32) of x[rows, C] (two passes: mean, then centred second moment; the bf16 fast path: one pass of shifted sums); momentum > 0 also updates the running
  * statistics (torch semantics).  train == 0: mean / rstd are derived from the running statistics instead. */
 static int bn_stats_impl(const void* x, float* mean, float* rstd, float* running_mean, float* running_var, int64_t rows, int C,
-                         int64_t ld, float eps, float momentum, int train, int dtype, void* ws, int64_t ws_bytes, int flags, void* stream) {
+                         int64_t ld, float eps, float momentum, int train, int dtype, void* ws, int64_t ws_bytes, int flags, void* stream,
+                         int* counters = nullptr) {
   MMRCA_REQUIRE(mean && rstd && rows > 0 && C > 0 && ld >= C, "bn_stats: bad arguments");
   hipStream_t st = (hipStream_t)stream;
   if (!train) {
@@ -1481,6 +1513,7 @@ static int bn_stats_impl(const void* x, float* mean, float* rstd, float* running
   MMRCA_REQUIRE(x, "bn_stats: null input");
   dim3 grid; int64_t per;
   col_grid(rows, C, &grid, &per);
+  if (counters && !(flags & 1)) (void)hipMemsetAsync(counters, 0, sizeof(int) * ((C + 63) / 64), st);
   if (flags & 1) {                      // the caller zeroed mean / rstd (one fill for every layer of the step: conv_engine's arena)
   } else if (rstd == mean + C) {        // adjacent (one [2, C] buffer): one fill instead of two
     (void)hipMemsetAsync(mean, 0, sizeof(float) * 2 * C, st);
@@ -1497,8 +1530,13 @@ static int bn_stats_impl(const void* x, float* mean, float* rstd, float* running
       if (T) {
         hipLaunchKernelGGL(col_moment2_flat_k, dim3(blocks_for(T, 256)), dim3(256), 0, st, (const bf16_t*)x, (float*)ws, rows, C / 8, T);
         bn_flat_reduce((const float*)ws, T, C / 8, mean, rstd, st);
+      } else if (counters) {        // moments + finish in one launch (caller-zeroed tickets, one per 64 channels)
+        hipLaunchKernelGGL(col_moment2_v8_k, grid, dim3(256), 0, st, (const bf16_t*)x, mean, rstd, rows, C, ld, per,
+                           BnFinish{counters, running_mean, running_var, eps, momentum});
+        MMRCA_CHECK_LAUNCH("bn_stats(one pass, fused finish)");
+        return 0;
       } else
-      hipLaunchKernelGGL(col_moment2_v8_k, grid, dim3(256), 0, st, (const bf16_t*)x, mean, rstd, rows, C, ld, per);
+      hipLaunchKernelGGL(col_moment2_v8_k, grid, dim3(256), 0, st, (const bf16_t*)x, mean, rstd, rows, C, ld, per, BnFinish{nullptr, nullptr, nullptr, 0.f, 0.f});
       hipLaunchKernelGGL(bn_finish_shifted_k, dim3((C + 255) / 256), dim3(256), 0, st, (const bf16_t*)x, mean, rstd, running_mean, running_var, C,
                          (float)rows, eps, momentum, rows, ld);
       MMRCA_CHECK_LAUNCH("bn_stats(one pass)");
@@ -1518,6 +1556,14 @@ static int bn_stats_impl(const void* x, float* mean, float* rstd, float* running
 extern "C" int mmrca_bn_stats(const void* x, float* mean, float* rstd, float* running_mean, float* running_var, int64_t rows, int C,
                               int64_t ld, float eps, float momentum, int train, int dtype, void* stream) {
   return bn_stats_impl(x, mean, rstd, running_mean, running_var, rows, C, ld, eps, momentum, train, dtype, nullptr, 0, 0, stream);
+}
+/* train-mode statistics with the finish step inside the reduction launch: `tickets` = ceil(C / 64) int32 words (zeroed here unless
+ * flags bit 0 says the caller cleared them together with mean / rstd, as in mmrca_bn_stats_ws); bf16, C % 8 == 0 -- other inputs run
+ * the two-launch form */
+extern "C" int mmrca_bn_stats_fused(const void* x, float* mean, float* rstd, float* running_mean, float* running_var, int64_t rows, int C,
+                                    int64_t ld, float eps, float momentum, int dtype, int* tickets, int flags, void* stream) {
+  MMRCA_REQUIRE(tickets, "bn_stats_fused: null tickets");
+  return bn_stats_impl(x, mean, rstd, running_mean, running_var, rows, C, ld, eps, momentum, 1, dtype, nullptr, 0, flags, stream, tickets);
 }
 /* the same with a workspace (fp32, 16-byte aligned, >= 256 KiB; 16 MiB serves every size): large bf16 tensors take the flat streaming pass */
 extern "C" int mmrca_bn_stats_ws(const void* x, float* mean, float* rstd, float* running_mean, float* running_var, int64_t rows, int C,

@@ -75,6 +75,7 @@ _SIGS = {
     "mmrca_bn_act_fwd_res": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i32, _i32, _i64, _i32, _vp],
     "mmrca_bn_stats": [_vp, _vp, _vp, _vp, _vp, _i64, _i32, _i64, _f32, _f32, _i32, _i32, _vp],
     "mmrca_bn_stats_ws": [_vp, _vp, _vp, _vp, _vp, _i64, _i32, _i64, _f32, _f32, _i32, _i32, _vp, _i64, _i32, _vp],
+    "mmrca_bn_stats_fused": [_vp, _vp, _vp, _vp, _vp, _i64, _i32, _i64, _f32, _f32, _i32, _vp, _i32, _vp],
     "mmrca_bn_act_bwd_ws": [_vp] * 10 + [_i64, _i32, _i32, _i32, _i32, _vp, _i64, _i32, _vp],
     "mmrca_bn_act_fwd": [_vp] * 6 + [_i64, _i32, _i32, _i32, _vp],
     "mmrca_bn_act_bwd": [_vp] * 10 + [_i64, _i32, _i32, _i32, _i32, _vp],
@@ -609,6 +610,7 @@ _CONV_BYTES = {
     "mmrca_channel_deinterleave2": ("layout", lambda a: 2 * a[4] * 2 * a[5] * _esz(a[6])),
     "mmrca_bn_stats": ("BatchNorm", lambda a: a[5] * a[6] * _esz(a[11]) if a[10] else 0),
     "mmrca_bn_stats_ws": ("BatchNorm", lambda a: a[5] * a[6] * _esz(a[11]) if a[10] else 0),
+    "mmrca_bn_stats_fused": ("BatchNorm", lambda a: a[5] * a[6] * _esz(a[10])),
     "mmrca_bn_act_fwd": ("BatchNorm", lambda a: 2 * a[6] * a[7] * _esz(a[9])),
     "mmrca_bn_act_fwd_res": ("BatchNorm", lambda a: 3 * a[8] * a[9] * _esz(a[12])),
     # backward with batch statistics: the sums need dy and z once, the apply pass needs them again and writes dx
@@ -720,9 +722,16 @@ def bn_act_fwd_res(x, mean, rstd, gamma, beta, res, rowscale, out, rows, C, act,
        rows_per_sample, dtype)
 
 
-def bn_stats(x, mean, rstd, running_mean, running_var, rows, C, ld, eps, momentum, train, dtype, ws=None, prezeroed=False):
+def bn_stats(x, mean, rstd, running_mean, running_var, rows, C, ld, eps, momentum, train, dtype, ws=None, prezeroed=False, tickets=None):
     """ws: fp32 workspace tensor (the flat streaming reduction of large bf16 tensors, include/mmrca.h); prezeroed: the caller cleared
-    mean / rstd (conv_engine's per-step arena): no fill launch"""
+    mean / rstd (conv_engine's per-step arena): no fill launch; tickets: int32 [ceil(C / 64)] (cleared with them when prezeroed): the
+    finish step runs inside the reduction launch (train mode)"""
+    if tickets is not None and train and ws is None:
+        if tickets.dtype != torch.int32 or tickets.numel() < (C + 63) // 64:
+            raise MmrcaError("bn_stats: tickets must be int32 [ceil(C / 64)]")
+        _c("mmrca_bn_stats_fused", ptr(x), ptr(mean), ptr(rstd), ptr(running_mean), ptr(running_var), rows, C, ld, eps, momentum, dtype,
+           ptr(tickets), int(prezeroed))
+        return
     if ws is not None or prezeroed:
         _c("mmrca_bn_stats_ws", ptr(x), ptr(mean), ptr(rstd), ptr(running_mean), ptr(running_var), rows, C, ld, eps, momentum, int(train), dtype,
            ptr(ws), 0 if ws is None else ws.numel() * ws.element_size(), int(prezeroed))

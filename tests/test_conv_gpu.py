@@ -167,6 +167,34 @@ def test_fused_squeeze_excitation_mlp_fwd_bwd(dt, B, c, sq):
     assert rel(gw2 - 0.5, W2.grad) < gt and rel(gb2 - 0.5, B2.grad) < gt
 
 
+@pytest.mark.parametrize("R,C", [(20000, 72), (300, 8), (9001, 384), (64 * 57600 // 64, 1056), (50, 3840)])
+def test_batchnorm_statistics_with_the_finish_inside_the_reduction_launch(R, C):
+    """mmrca_bn_stats_fused (the last workgroup of a 64-channel block turns the sums into mean / rstd and updates the running statistics)
+    against the two-launch form it replaces: same sums, same finish arithmetic -- mean / rstd / running statistics equal to fp32 rounding,
+    with caller-zeroed buffers (the conv engine's arena) and with the fills done inside; the tickets come back equal to the number of row
+    ranges.  Small and large tensors: one row range, and many."""
+    g = torch.Generator().manual_seed(R + C)
+    x = (torch.randn(R, C, generator=g) * 1.3 + 0.4).bfloat16().cuda()
+    ref = {}
+    for name in ("two launches", "fused, caller-zeroed", "fused, fills inside"):
+        pz = name == "fused, caller-zeroed"
+        stats = torch.zeros(2, C, device="cuda") if pz else torch.full((2, C), 5.0, device="cuda")
+        rm, rv = torch.full((C,), 0.2, device="cuda"), torch.full((C,), 0.8, device="cuda")
+        tickets = None
+        if name != "two launches":
+            tickets = torch.zeros((C + 63) // 64, dtype=torch.int32, device="cuda") if pz else torch.full(((C + 63) // 64,), 9, dtype=torch.int32, device="cuda")
+        L.bn_stats(x, stats[0], stats[1], rm, rv, R, C, C, 1e-3, 0.1, True, L.BF16, prezeroed=pz, tickets=tickets)
+        torch.cuda.synchronize()
+        ref[name] = (stats.clone(), rm.clone(), rv.clone())
+        if tickets is not None:
+            assert int(tickets.min()) == int(tickets.max()) >= 1
+    xf = x.float()
+    assert rel(ref["two launches"][0][0], xf.mean(0)) < 1e-5 and rel(ref["two launches"][0][1], (xf.var(0, unbiased=False) + 1e-3).rsqrt()) < 1e-5
+    for name in ("fused, caller-zeroed", "fused, fills inside"):
+        for a, b in zip(ref["two launches"], ref[name]):
+            assert rel(b, a) < 2e-6, name
+
+
 @pytest.fixture
 def bn_flat_on():
     """both flat forms are opt-in (faster in isolation, no gain in the conv step): switched on for one test through the library's
