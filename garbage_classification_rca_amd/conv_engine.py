@@ -39,7 +39,10 @@ IGEMM = os.environ.get("MMRCA_CONV_IGEMM", "1") == "1"
 FUSE_GEMM_BN = os.environ.get("MMRCA_CONV_FUSE_GEMM_BN", "0") == "1"
 BN_FLAT = os.environ.get("MMRCA_BN_FLAT", "0") == "1"               # flat BatchNorm reductions (csrc/conv.hip, opt-in): need a 16 MiB workspace
 FUSE_SE = os.environ.get("MMRCA_CONV_FUSE_SE", "1") == "1"         # SE backward: dx and the next BatchNorm's backward sums in one pass
-FUSE_BN_FINISH = os.environ.get("MMRCA_CONV_FUSE_BN_FINISH", "1") == "1"   # BatchNorm moments + finish in one launch
+# BatchNorm moments + finish in one launch (mmrca_bn_stats_fused): built, parity-tested, measured SLOWER and off -- the device-scope fence every
+# workgroup needs in front of its ticket waits for its own atomics to complete (they are fire-and-forget otherwise), and the last workgroup's
+# finish is a serial tail: EfficientNetV2-M B = 64 905 -> 692 samples/s, B = 16 482 -> 396, ShuffleNetV2 B = 4 (HIP graph) 655 -> 648
+FUSE_BN_FINISH = os.environ.get("MMRCA_CONV_FUSE_BN_FINISH", "0") == "1"
 FUSE_SE_MLP = os.environ.get("MMRCA_CONV_FUSE_SE_MLP", "1") == "1"   # squeeze-excitation MLP: one launch forward, two backward
 SE_FUSE_MAX = int(os.environ.get("MMRCA_CONV_SE_FUSE_MAX", "160000"))   # c * sq up to which the fused MLP BACKWARD is used (see ConvEncoder._se_fused)
 SE_FUSE_MAX_FWD = int(os.environ.get("MMRCA_CONV_SE_FUSE_MAX_FWD", "300000"))   # ... and the forward (sixteen waves per sample)

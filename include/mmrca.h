@@ -213,7 +213,8 @@ int mmrca_bn_stats(const void* x, float* mean, float* rstd, float* running_mean,
  * per-thread partial sums go to the workspace and a second small launch adds them up (3.8-4.3 TB/s against 3.1-3.7 for the
  * slice-per-workgroup form in isolation; no gain inside the conv step, hence opt-in -- csrc/conv.hip) */
 /* mmrca_bn_stats(train = 1) with the finish step (sums -> mean / rstd, running statistics) done by the last workgroup of the reduction
- * instead of a second launch (round 5: one launch less per BatchNorm layer and step).  tickets: ceil(C / 64) int32 words of scratch;
+ * instead of a second launch (round 5: one launch less per BatchNorm layer and step -- measured slower in the conv step, the engine
+ * does not use it by default; kept, tested, for small tensors outside it).  tickets: ceil(C / 64) int32 words of scratch;
  * flags bit 0: the caller zeroed mean, rstd AND tickets.  bf16 with C % 8 == 0; other inputs take the two-launch form. */
 int mmrca_bn_stats_fused(const void* x, float* mean, float* rstd, float* running_mean, float* running_var, int64_t rows, int C,
                          int64_t ld, float eps, float momentum, int dtype, int* tickets, int flags, void* stream);
