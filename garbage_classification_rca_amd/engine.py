@@ -6,9 +6,9 @@ Data layout in HBM (sized for 288 GB: nothing is recomputed, every saved activat
   ONE flat fp32 gradient arena with the same offsets (data-parallel all-reduce runs over contiguous slices of
   it, no bucket copies) and, in bf16 mode, ONE bf16 working copy refreshed by the fused optimizer kernel.
   q/k/v projection weights of the text encoders sit adjacently, so the fused [3D, D] QKV GEMM needs no copy.
-* activations: row-major [rows, features] in the compute dtype, rows padded to a multiple of 128 with zeros that
-  no kernel ever writes (the weight-gradient GEMM contracts over rows through transposed LDS reads and needs
-  whole 64-row steps).
+* activations: row-major [rows, features] in the compute dtype, rows padded to a multiple of 256 (ROWPAD) with zeros that
+  no kernel ever writes (the persistent 256x256 GEMM streams whole 256-row tiles; the weight-gradient GEMM contracts over
+  rows through transposed LDS reads and needs whole 64-row steps).
 * no torch autograd inside: forward() saves what backward() needs; backward() accumulates (+=) into the gradient
   arena, which is exactly the reference's gradient-accumulation semantic (main_both.py:112-124).
 
