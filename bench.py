@@ -4,6 +4,7 @@
 
     python bench.py --gpus 1 --steps 10 --warmup 3
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
+    python bench.py --gpus N ...          # no launcher: bench.py starts its own N ranks (launch_ranks below) and relays rank 0's line
 
 A step = one pass of the hot path over one batch of synthetic pairs already resident in HBM: forward (text encoder,
 vision encoder, fused RCA head), weighted/smoothed cross entropy, full backward (fine-tuning phase: every parameter
@@ -424,6 +425,41 @@ def cpu_baseline_qformer(spec, batch=2, steps=2):
                       f"full widths, batch {batch}, {steps} timed iterations after 1 warm-up, {n} threads"}
 
 
+def launch_ranks(n: int, cmd=None) -> int:
+    """`python bench.py --gpus N` with no launcher around it (WORLD_SIZE unset): start the N ranks ourselves -- the one-process-per-GPU
+    replacement of the reference's single-process nn.DataParallel (main_both.py:386-388).  This parent has NOT touched the GPU (no HIP
+    call, no torch.cuda call: it must not, a process that has initialised the GPU may neither exec nor be forked from on this pool); it
+    starts N fresh children of this same script with RANK / LOCAL_RANK / WORLD_SIZE / LOCAL_WORLD_SIZE / MASTER_ADDR / MASTER_PORT set
+    (what torch.distributed.run would set), relays rank 0's stdout (the ONE JSON line) and every rank's stderr, and returns non-zero if
+    any child does -- ending the others first, by their PIDs, so that a rank that died before the rendezvous cannot leave the rest waiting."""
+    import socket
+    import subprocess
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as s:      # a free port for the rendezvous
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    base = dict(os.environ, WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    base.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")               # dmabuf IPC: RCCL across processes needs it on this image
+    cmd = cmd or [sys.executable, os.path.abspath(__file__)] + sys.argv[1:]
+    procs = []
+    for r in range(n):
+        env = dict(base, RANK=str(r), LOCAL_RANK=str(r))
+        procs.append(subprocess.Popen(cmd, env=env, stdout=None if r == 0 else subprocess.DEVNULL))      # rank 0 inherits our stdout
+    rc, alive = 0, set(range(n))
+    while alive:
+        for r in sorted(alive):
+            code = procs[r].poll()
+            if code is None:
+                continue
+            alive.discard(r)
+            if code != 0 and rc == 0:
+                rc = code if code > 0 else 1
+                print(f"[bench] rank {r} exited with {code}: stopping the other ranks", file=sys.stderr, flush=True)
+                for o in alive:
+                    procs[o].terminate()
+        time.sleep(0.05)
+    return rc
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -448,6 +484,8 @@ def main():
     ap.add_argument("--workload", default="mmrca", choices=("mmrca", "qformer"),
                     help="mmrca: the headline MM-RCA train step | qformer: BASELINE configs[4], the BLIP-2 Q-Former classifier iteration")
     args = ap.parse_args()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:       # no launcher: be one (before anything below touches the GPU)
+        sys.exit(launch_ranks(args.gpus))
     if args.workload == "qformer":
         return bench_qformer(args)
 

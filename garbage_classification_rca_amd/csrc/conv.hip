@@ -1146,28 +1146,6 @@ __device__ __forceinline__ void col_reduce8(float (&acc)[NV][8], float (*red)[8]
   }
 }
 
-// the same for a block of CGS channel groups (CGS * 8 channels) x (256 / CGS) row lanes (round 5: CGS = 32 -- 256 channels, 512 contiguous
-// bytes of every row per workgroup -- next to the original 8)
-template <int NV, int CGS>
-__device__ __forceinline__ void col_reduce8w(float (&acc)[NV][8], float (*red)[CGS][8 * NV + 1], float* const (&out)[NV], int cblk, int C) {
-  const int cg = threadIdx.x % CGS, wv = threadIdx.x >> 6;
-#pragma unroll
-  for (int k = 0; k < NV; ++k)
-#pragma unroll
-    for (int j = 0; j < 8; ++j) {
-      float v = acc[k][j];
-#pragma unroll
-      for (int o = CGS; o < 64; o <<= 1) v += __shfl_xor(v, o, 64);
-      if ((threadIdx.x & 63) < CGS) red[wv][cg][k * 8 + j] = v;
-    }
-  __syncthreads();
-  for (int e = threadIdx.x; e < CGS * 8 * NV; e += 256) {
-    const int k = e / (CGS * 8), cl = e % (CGS * 8), g = cl >> 3, j = cl & 7;
-    const int c = cblk * (CGS * 8) + cl;
-    if (c < C) atomicAdd(out[k] + c, (red[0][g][k * 8 + j] + red[1][g][k * 8 + j]) + (red[2][g][k * 8 + j] + red[3][g][k * 8 + j]));
-  }
-}
-
 template <bool CENTERED>
 __global__ void __launch_bounds__(256)
 col_moment_v8_k(const bf16_t* __restrict__ x, const float* __restrict__ mean, float* __restrict__ out, int64_t rows, int C, int64_t ld,
@@ -1209,14 +1187,12 @@ __device__ __forceinline__ int64_t bn_shift_row(int k, int64_t rows) {
 }
 __device__ __forceinline__ float bn_trimmed(float sum, float lo, float hi) { return (sum - lo - hi) * (1.0f / (BN_SHIFT_ROWS - 2)); }
 struct BnFinish { int* counters; float* running_mean; float* running_var; float eps, momentum; };
-template <int CGS>      // channel groups per workgroup: 8 (64 channels x 32 row lanes) or 32 (256 channels x 8 row lanes)
 __global__ void __launch_bounds__(256)
 col_moment2_v8_k(const bf16_t* __restrict__ x, float* __restrict__ s1, float* __restrict__ s2, int64_t rows, int C, int64_t ld,
                  int64_t rows_per_block, BnFinish fin = BnFinish{nullptr, nullptr, nullptr, 0.f, 0.f}) {
-  constexpr int RL = 256 / CGS;
-  __shared__ float red[4][CGS][17];
-  const int cg = threadIdx.x % CGS, rl = threadIdx.x / CGS;
-  const int c0 = blockIdx.x * (CGS * 8) + cg * 8;
+  __shared__ float red[4][8][17];
+  const int cg = threadIdx.x & 7, rl = threadIdx.x >> 3;
+  const int c0 = blockIdx.x * 64 + cg * 8;
   const int64_t r0 = (int64_t)blockIdx.y * rows_per_block;
   const int64_t r1 = r0 + rows_per_block < rows ? r0 + rows_per_block : rows;
   float acc[2][8];
@@ -1234,23 +1210,23 @@ col_moment2_v8_k(const bf16_t* __restrict__ x, float* __restrict__ s1, float* __
 #pragma unroll
     for (int j = 0; j < 8; ++j) m[j] = bn_trimmed(m[j], mlo[j], mhi[j]);
     int64_t r = r0 + rl;
-    for (; r + 7 * RL < r1; r += 8 * RL) {             // eight rows in flight per thread (one load per iteration ran at 2.6 TB/s)
+    for (; r + 224 < r1; r += 256) {                   // eight rows in flight per thread (one load per iteration ran at 2.6 TB/s)
       cm_b8 v[8];
 #pragma unroll
-      for (int u = 0; u < 8; ++u) v[u] = *reinterpret_cast<const cm_b8*>(x + (r + RL * u) * ld + c0);
+      for (int u = 0; u < 8; ++u) v[u] = *reinterpret_cast<const cm_b8*>(x + (r + 32 * u) * ld + c0);
 #pragma unroll
       for (int u = 0; u < 8; ++u)
 #pragma unroll
         for (int j = 0; j < 8; ++j) { const float d = (float)v[u][j] - m[j]; acc[0][j] += d; acc[1][j] = fmaf(d, d, acc[1][j]); }
     }
-    for (; r < r1; r += RL) {
+    for (; r < r1; r += 32) {
       const cm_b8 v = *reinterpret_cast<const cm_b8*>(x + r * ld + c0);
 #pragma unroll
       for (int j = 0; j < 8; ++j) { const float d = (float)v[j] - m[j]; acc[0][j] += d; acc[1][j] = fmaf(d, d, acc[1][j]); }
     }
   }
   float* const outs[2] = {s1, s2};
-  col_reduce8w<2, CGS>(acc, red, outs, blockIdx.x, C);
+  col_reduce8<2>(acc, red, outs, blockIdx.x, C);
   // fin.counters != NULL (round 5): the LAST of the gridDim.y row ranges of this 64-channel block turns the sums into mean / rstd and
   // updates the running statistics itself -- what bn_finish_shifted_k did in a launch of its own (one per BatchNorm layer and step: 146
   // of the ~1,900 launches of an EfficientNetV2-M step at the reference's batch size 16).  The atomics above are device-scope
@@ -1261,8 +1237,8 @@ col_moment2_v8_k(const bf16_t* __restrict__ x, float* __restrict__ s1, float* __
     __syncthreads();
     if (threadIdx.x == 0) last_blk = atomicAdd(fin.counters + blockIdx.x, 1) == (int)gridDim.y - 1;
     __syncthreads();
-    if (last_blk && threadIdx.x < CGS * 8) {
-      const int c = blockIdx.x * (CGS * 8) + threadIdx.x;
+    if (last_blk && threadIdx.x < 64) {
+      const int c = blockIdx.x * 64 + threadIdx.x;
       if (c < C) {
         float shift = 0.f, slo = INFINITY, shi = -INFINITY;
         for (int k = 0; k < BN_SHIFT_ROWS; ++k) { const float v = (float)x[bn_shift_row(k, rows) * ld + c]; shift += v; slo = fminf(slo, v); shi = fmaxf(shi, v); }
@@ -1453,15 +1429,13 @@ __global__ void bn_finish_shifted_k(const bf16_t* __restrict__ x, float* __restr
   }
 }
 
-template <int CGS>
 __global__ void __launch_bounds__(256)
 bn_act_bwd_reduce_v8_k(const bf16_t* __restrict__ dy, const bf16_t* __restrict__ x, const float* __restrict__ mean,
                        const float* __restrict__ rstd, const bf16_t* __restrict__ gamma, const bf16_t* __restrict__ beta,
                        float* __restrict__ sum_du, float* __restrict__ sum_duxh, int64_t rows, int C, int act, int64_t rows_per_block) {
-  constexpr int RL = 256 / CGS;
-  __shared__ float red[4][CGS][17];
-  const int cg = threadIdx.x % CGS, rl = threadIdx.x / CGS;
-  const int c0 = blockIdx.x * (CGS * 8) + cg * 8;
+  __shared__ float red[4][8][17];
+  const int cg = threadIdx.x & 7, rl = threadIdx.x >> 3;
+  const int c0 = blockIdx.x * 64 + cg * 8;
   const int64_t r0 = (int64_t)blockIdx.y * rows_per_block;
   const int64_t r1 = r0 + rows_per_block < rows ? r0 + rows_per_block : rows;
   float acc[2][8];
@@ -1472,12 +1446,12 @@ bn_act_bwd_reduce_v8_k(const bf16_t* __restrict__ dy, const bf16_t* __restrict__
 #pragma unroll
     for (int j = 0; j < 8; ++j) { m[j] = mean[c0 + j]; rs[j] = rstd[c0 + j]; g[j] = (float)gamma[c0 + j]; b[j] = (float)beta[c0 + j]; }
     int64_t r = r0 + rl;
-    for (; r + 7 * RL < r1; r += 8 * RL) {             // eight rows of both operands in flight per thread
+    for (; r + 224 < r1; r += 256) {                   // eight rows of both operands in flight per thread
       cm_b8 xv[8], dv[8];
 #pragma unroll
       for (int u = 0; u < 8; ++u) {
-        xv[u] = *reinterpret_cast<const cm_b8*>(x + (r + RL * u) * C + c0);
-        dv[u] = *reinterpret_cast<const cm_b8*>(dy + (r + RL * u) * C + c0);
+        xv[u] = *reinterpret_cast<const cm_b8*>(x + (r + 32 * u) * C + c0);
+        dv[u] = *reinterpret_cast<const cm_b8*>(dy + (r + 32 * u) * C + c0);
       }
 #pragma unroll
       for (int u = 0; u < 8; ++u)
@@ -1488,7 +1462,7 @@ bn_act_bwd_reduce_v8_k(const bf16_t* __restrict__ dy, const bf16_t* __restrict__
           acc[0][j] += du; acc[1][j] = fmaf(du, xh, acc[1][j]);
         }
     }
-    for (; r < r1; r += RL) {
+    for (; r < r1; r += 32) {
       const cm_b8 xv = *reinterpret_cast<const cm_b8*>(x + r * C + c0), dv = *reinterpret_cast<const cm_b8*>(dy + r * C + c0);
 #pragma unroll
       for (int j = 0; j < 8; ++j) {
@@ -1499,19 +1473,13 @@ bn_act_bwd_reduce_v8_k(const bf16_t* __restrict__ dy, const bf16_t* __restrict__
     }
   }
   float* const outs[2] = {sum_du, sum_duxh};
-  col_reduce8w<2, CGS>(acc, red, outs, blockIdx.x, C);
+  col_reduce8<2>(acc, red, outs, blockIdx.x, C);
 }
 
-// BatchNorm's two column reductions (moments, backward sums) in their WIDE form: a workgroup covers 256 channels x 8 row lanes instead of
-// 64 x 32, i.e. 512 contiguous bytes of every row it touches.  Round 5: tools/hbm_probe.py showed that "a read-only pass saturates near
-// 4.2 TB/s on this part" (section 3d, round 4) was a property of these kernels, not of the part -- the library's own mmrca_colsum_accum
-// (256 columns per workgroup) reads the same 1 GiB tensor at 5.55 TB/s, torch's column sum at 5.2, these at 4.5.  MMRCA_BN_WIDE=0: 64.
-static const int g_bn_wide = getenv("MMRCA_BN_WIDE") ? atoi(getenv("MMRCA_BN_WIDE")) : 1;
-static inline bool bn_wide(int C) { return g_bn_wide && C >= 256; }
-static void col_grid(int64_t rows, int C, dim3* grid, int64_t* per, int chans_per_block = 64) {
+static void col_grid(int64_t rows, int C, dim3* grid, int64_t* per) {
   // ~3,000 blocks in all (12 per CU): every block pays a prologue (the moments' shift = 16 sampled rows) and a reduction tail, so
   // 256-row blocks -- 5,000-10,000 of them on the MBConv tensors -- spent most of their time there (moments at 2.6 TB/s)
-  const int64_t slices = (C + chans_per_block - 1) / chans_per_block;
+  const int64_t slices = (C + 63) / 64;
   int64_t cap = 3072 / slices;
   if (cap < 8) cap = 8;
   if (cap > 2048) cap = 2048;
@@ -1525,7 +1493,7 @@ static void col_grid(int64_t rows, int C, dim3* grid, int64_t* per, int chans_pe
   // x = 64-channel slice (fastest), y = row range: the blocks resident at one time then cover WHOLE rows of a row range.  With the
   // row ranges in x, the ~2,000 resident blocks all read the same 128-byte slice of every row (stride 2C bytes) -- one DRAM burst
   // per page: col_moment2 ran at 2.5 TB/s, the depthwise weight gradient at 1.8.
-  *grid = dim3((unsigned)slices, (unsigned)((rows + *per - 1) / *per));
+  *grid = dim3((unsigned)((C + 63) / 64), (unsigned)((rows + *per - 1) / *per));
 }
 
 static const bool g_bn_one_pass = !(getenv("MMRCA_BN_ONE_PASS") && atoi(getenv("MMRCA_BN_ONE_PASS")) == 0);
@@ -1563,16 +1531,12 @@ static int bn_stats_impl(const void* x, float* mean, float* rstd, float* running
         hipLaunchKernelGGL(col_moment2_flat_k, dim3(blocks_for(T, 256)), dim3(256), 0, st, (const bf16_t*)x, (float*)ws, rows, C / 8, T);
         bn_flat_reduce((const float*)ws, T, C / 8, mean, rstd, st);
       } else if (counters) {        // moments + finish in one launch (caller-zeroed tickets, one per 64 channels)
-        hipLaunchKernelGGL(col_moment2_v8_k<8>, grid, dim3(256), 0, st, (const bf16_t*)x, mean, rstd, rows, C, ld, per,
+        hipLaunchKernelGGL(col_moment2_v8_k, grid, dim3(256), 0, st, (const bf16_t*)x, mean, rstd, rows, C, ld, per,
                            BnFinish{counters, running_mean, running_var, eps, momentum});
         MMRCA_CHECK_LAUNCH("bn_stats(one pass, fused finish)");
         return 0;
-      } else if (bn_wide(C)) {
-        dim3 gw; int64_t pw;
-        col_grid(rows, C, &gw, &pw, 256);
-        hipLaunchKernelGGL(col_moment2_v8_k<32>, gw, dim3(256), 0, st, (const bf16_t*)x, mean, rstd, rows, C, ld, pw, BnFinish{nullptr, nullptr, nullptr, 0.f, 0.f});
       } else
-      hipLaunchKernelGGL(col_moment2_v8_k<8>, grid, dim3(256), 0, st, (const bf16_t*)x, mean, rstd, rows, C, ld, per, BnFinish{nullptr, nullptr, nullptr, 0.f, 0.f});
+      hipLaunchKernelGGL(col_moment2_v8_k, grid, dim3(256), 0, st, (const bf16_t*)x, mean, rstd, rows, C, ld, per, BnFinish{nullptr, nullptr, nullptr, 0.f, 0.f});
       hipLaunchKernelGGL(bn_finish_shifted_k, dim3((C + 255) / 256), dim3(256), 0, st, (const bf16_t*)x, mean, rstd, running_mean, running_var, C,
                          (float)rows, eps, momentum, rows, ld);
       MMRCA_CHECK_LAUNCH("bn_stats(one pass)");
@@ -1830,16 +1794,9 @@ static int bn_act_bwd_impl(const void* dy, const void* x, const float* mean, con
                          (const bf16_t*)gamma, (const bf16_t*)beta, (float*)ws, rows, C / 8, act, Tf);
       bn_flat_reduce((const float*)ws, Tf, C / 8, scratch, scratch + C, st);
     }
-    else if (sizeof(T) == 2 && C % 8 == 0 && ((((uintptr_t)dy) | ((uintptr_t)x)) & 15) == 0) {
-      if (bn_wide(C)) {
-        dim3 gw; int64_t pw;
-        col_grid(rows, C, &gw, &pw, 256);
-        hipLaunchKernelGGL(bn_act_bwd_reduce_v8_k<32>, gw, dim3(256), 0, st, (const bf16_t*)dy, (const bf16_t*)x, mean, rstd, (const bf16_t*)gamma,
-                           (const bf16_t*)beta, scratch, scratch + C, rows, C, act, pw);
-      } else
-      hipLaunchKernelGGL(bn_act_bwd_reduce_v8_k<8>, grid, dim3(256), 0, st, (const bf16_t*)dy, (const bf16_t*)x, mean, rstd, (const bf16_t*)gamma,
+    else if (sizeof(T) == 2 && C % 8 == 0 && ((((uintptr_t)dy) | ((uintptr_t)x)) & 15) == 0)
+      hipLaunchKernelGGL(bn_act_bwd_reduce_v8_k, grid, dim3(256), 0, st, (const bf16_t*)dy, (const bf16_t*)x, mean, rstd, (const bf16_t*)gamma,
                          (const bf16_t*)beta, scratch, scratch + C, rows, C, act, per);
-    }
     else
     hipLaunchKernelGGL(bn_act_bwd_reduce_k<T>, grid, dim3(256), 0, st, (const T*)dy, (const T*)x, mean, rstd, (const T*)gamma, (const T*)beta,
                        scratch, scratch + C, rows, C, act, per);

@@ -786,3 +786,29 @@ def test_split_phase_asm_loads_are_not_touched_before_their_wait():
                 else:
                     outside.append(l.strip())
     assert n_asm == 48 and not outside, (n_asm, outside[:3])          # 4 x 3 loads + 36 v_movs behind the wait
+
+
+def test_bench_launches_its_own_ranks_and_reports_a_failed_one(tmp_path, capfd):
+    """bench.launch_ranks (python bench.py --gpus N with no torchrun around it; main_both.py:386-388's multi-GPU entry): every child gets
+    torchrun's environment, rank 0's stdout is the parent's, and one failing rank ends the others and sets the exit code.  The children
+    here are a probe script -- the parent never touches a GPU, so this runs on the CPU box."""
+    import time
+    sys.path.insert(0, ROOT)
+    import bench
+    probe = tmp_path / "probe.py"
+    probe.write_text(
+        "import json, os, sys, time\n"
+        "r = int(os.environ['RANK'])\n"
+        "print(json.dumps({k: os.environ.get(k) for k in ('RANK', 'LOCAL_RANK', 'WORLD_SIZE', 'LOCAL_WORLD_SIZE', 'MASTER_ADDR', 'MASTER_PORT')}), flush=True)\n"
+        "if sys.argv[1] == 'fail':\n"
+        "    if r == 1: sys.exit(3)\n"
+        "    time.sleep(120)\n")
+    capfd.readouterr()
+    assert bench.launch_ranks(3, [sys.executable, str(probe), "ok"]) == 0
+    out = [json.loads(l) for l in capfd.readouterr().out.splitlines() if l.startswith("{")]
+    assert len(out) == 1                          # only rank 0's line reaches stdout
+    assert out[0]["RANK"] == "0" and out[0]["LOCAL_RANK"] == "0" and out[0]["WORLD_SIZE"] == "3" and out[0]["LOCAL_WORLD_SIZE"] == "3"
+    assert out[0]["MASTER_ADDR"] == "127.0.0.1" and int(out[0]["MASTER_PORT"]) > 0
+    t0 = time.time()
+    assert bench.launch_ranks(2, [sys.executable, str(probe), "fail"]) == 3
+    assert time.time() - t0 < 60                  # rank 0 (sleeping) was ended, not waited for
