@@ -783,11 +783,16 @@ def main():
                        "optimizer": "sgd lr=1e-3 wd=1e-2", "random_init": True, "caption_rows_processed": round(live, 3),
                        "dead_row_elimination": {"class_token_tail": bool(E_CLS_TAIL), "packed_captions": bool(PACK_TEXT) and graphed is None,
                                                 "note": "identical logits and gradients; MMRCA_CLS_TAIL=0 MMRCA_PACK_TEXT=0 runs every row"}, "final_loss": round(final_loss, 4),
-                       "host_enqueue_ms_per_step": round(host_idle_ms, 2),
-                       "host_enqueue_note": "host time to enqueue one step onto an EMPTY queue (median of 3, each after a device sync): what the "
-                                            "Python + ctypes + hipLaunchKernel calls cost; host_wall_in_timed_loop_ms_per_step also counts the "
-                                            "time launch calls block on a full queue, i.e. it follows the step time while the host is ahead",
-                       "host_wall_in_timed_loop_ms_per_step": round(host_enqueue / args.steps * 1e3, 2),
+                       # schema 2 (round 6): `host_enqueue_ms_per_step` has its rounds-1..4 meaning again -- host wall time inside
+                       # the timed loop; round 5 had reused the name for the empty-queue measurement, which now has a name of its own
+                       "host_schema": 2,
+                       "host_enqueue_ms_per_step": round(host_enqueue / args.steps * 1e3, 2),
+                       "host_enqueue_idle_queue_ms_per_step": round(host_idle_ms, 2),
+                       "host_enqueue_note": "host_enqueue_idle_queue_ms_per_step: host time to enqueue one step onto an EMPTY queue (median of 3, each "
+                                            "after a device sync) = what the Python + ctypes + hipLaunchKernel calls cost.  host_enqueue_ms_per_step: "
+                                            "host wall time per step inside the timed loop (rounds 1-4's meaning; BENCH_r05 carried the idle-queue "
+                                            "number under this key), which also counts launch calls blocking on a full queue, i.e. it follows the "
+                                            "step time while the host is ahead",
                        "hip_graph": (None if graphed is None else {"replays_in_timed_region": args.steps, "graphs": len(graphed._graphs),
                                                                    "outside_the_graph": "input copies, mask-epoch word, loss copy, SGD step, gradient memset"}),
                        **({"x3_backward_passes": {"weight_gradient": ENG.X3_WGRAD_PASSES, "input_gradient": ENG.X3_DGRAD_PASSES,

@@ -2403,6 +2403,13 @@ extern "C" int mmrca_se_mlp_fwd(const void* pooled, const void* w1, const void* 
   MMRCA_REQUIRE(pooled && w1 && b1 && w2 && b2 && h_pre && h && s_pre && s, "se_mlp_fwd: null pointer");
   MMRCA_REQUIRE(B > 0 && c > 0 && sq > 0 && c % 4 == 0 && sq % 4 == 0 && (size_t)(c + sq) * 4 <= 64 * 1024,
                 "se_mlp_fwd: bad shape B=%d c=%d sq=%d (c and sq must be multiples of 4)", B, c, sq);
+  // every operand is read (and every output written) in 4-element vectors: 8-byte alignment for bf16, 16 for fp32
+  {
+    const uintptr_t al = (dtype == MMRCA_F32 ? 16 : 8) - 1;
+    MMRCA_REQUIRE((((uintptr_t)pooled | (uintptr_t)w1 | (uintptr_t)b1 | (uintptr_t)w2 | (uintptr_t)b2 | (uintptr_t)h_pre | (uintptr_t)h |
+                    (uintptr_t)s_pre | (uintptr_t)s) & al) == 0,
+                  "se_mlp_fwd: every pointer must be %d-byte aligned (4-element vector accesses)", (int)al + 1);
+  }
   const size_t lds = (size_t)(c + sq) * sizeof(float);
   MMRCA_DISPATCH_DTYPE(dtype, "se_mlp_fwd",
     hipLaunchKernelGGL((se_mlp_fwd_k<T, 16>), dim3(B), dim3(1024), lds, (hipStream_t)stream, (const T*)pooled, (const T*)w1, (const T*)b1, (const T*)w2,
@@ -2418,6 +2425,12 @@ extern "C" int mmrca_se_mlp_bwd(const void* ds, const void* pooled, const void* 
                 "se_mlp_bwd: null pointer");
   MMRCA_REQUIRE(B > 0 && c > 0 && sq > 0 && c % 4 == 0 && sq % 4 == 0 && (size_t)(c + 5 * sq) * 4 <= 64 * 1024,
                 "se_mlp_bwd: bad shape B=%d c=%d sq=%d (c and sq must be multiples of 4)", B, c, sq);
+  {
+    const uintptr_t al = (dtype == MMRCA_F32 ? 16 : 8) - 1;
+    MMRCA_REQUIRE((((uintptr_t)ds | (uintptr_t)pooled | (uintptr_t)h_pre | (uintptr_t)h | (uintptr_t)s_pre | (uintptr_t)w1 | (uintptr_t)b1 |
+                    (uintptr_t)w2 | (uintptr_t)b2 | (uintptr_t)ds_pre | (uintptr_t)dh_pre | (uintptr_t)dpool) & al) == 0,
+                  "se_mlp_bwd: every activation / weight pointer must be %d-byte aligned (4-element vector accesses)", (int)al + 1);
+  }
   const size_t lds = (size_t)(c + 5 * sq) * sizeof(float);
   const int64_t n = (int64_t)c * sq;
   const int nb = (int)((n + 255) / 256);

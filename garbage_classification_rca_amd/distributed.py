@@ -12,27 +12,105 @@ from __future__ import annotations
 
 import math
 import os
+import sys
 from typing import Iterator, List, Optional
 
 import torch
 import torch.distributed as dist
 
 
-def cpu_slice(local_rank: int, local_world: int, cpus=None) -> List[int]:
-    """The CPU set of one rank on a node that runs `local_world` ranks: the `local_rank`-th of `local_world` contiguous slices of
-    the CPUs this process may use (sorted ids).  Contiguous, because Linux numbers the cores of a socket contiguously and the GPUs of
-    an MI355X node are split the same way (GPUs 0-3 on socket 0, 4-7 on socket 1): rank r's launch thread and its DataLoader workers
-    then share the socket -- and the L3 -- next to their GPU instead of migrating across the fabric.  Never empty: with fewer CPUs
-    than ranks the slices wrap."""
+def read_cpu_topology(cpus, sysfs: str = "/sys/devices/system") -> Optional[dict]:
+    """{cpu: (numa node, (package, core id))} of the given CPUs from sysfs, or None when any of it cannot be read (then nothing is
+    bound).  NUMA node = the node whose cpulist holds the CPU (a machine without NUMA has the one node0); package / core id from
+    cpu*/topology.  Ids are NOT assumed contiguous: with SMT on, Linux numbers all physical cores first (socket 0, then socket 1) and
+    their siblings after them -- 0-63 / 64-127 / 128-191 / 192-255 on a 2 x 64-core node are socket 0, socket 1, socket 0, socket 1."""
+    def parse_list(text):
+        out = []
+        for part in text.strip().split(","):
+            if not part:
+                continue
+            lo, _, hi = part.partition("-")
+            out.extend(range(int(lo), int(hi or lo) + 1))
+        return out
+    try:
+        node_of = {}
+        node_dir = os.path.join(sysfs, "node")
+        for name in sorted(os.listdir(node_dir)):
+            if name.startswith("node") and name[4:].isdigit():
+                with open(os.path.join(node_dir, name, "cpulist")) as f:
+                    for c in parse_list(f.read()):
+                        node_of[c] = int(name[4:])
+        topo = {}
+        for c in cpus:
+            base = os.path.join(sysfs, "cpu", f"cpu{c}", "topology")
+            with open(os.path.join(base, "physical_package_id")) as f:
+                pkg = int(f.read())
+            with open(os.path.join(base, "core_id")) as f:
+                core = int(f.read())
+            topo[c] = (node_of[c], (pkg, core))
+        return topo
+    except (OSError, ValueError, KeyError):
+        return None
+
+
+def gpu_numa_nodes(n: int, sysfs_pci: str = "/sys/bus/pci/devices") -> Optional[List[int]]:
+    """NUMA node of each of the first n GPUs (device order = LOCAL_RANK order) from /sys/bus/pci/devices/<bdf>/numa_node, or None when
+    it cannot be told (no GPU, fewer than n devices, an unreadable file, a -1 entry: the firmware did not say)."""
+    try:
+        if not torch.cuda.is_available() or torch.cuda.device_count() < n:
+            return None
+        out = []
+        for i in range(n):
+            pr = torch.cuda.get_device_properties(i)
+            bdf = f"{pr.pci_domain_id:04x}:{pr.pci_bus_id:02x}:{pr.pci_device_id:02x}.0"
+            with open(os.path.join(sysfs_pci, bdf, "numa_node")) as f:
+                node = int(f.read())
+            if node < 0:
+                return None
+            out.append(node)
+        return out
+    except (OSError, ValueError, AttributeError, RuntimeError):
+        return None
+
+
+def cpu_slice(local_rank: int, local_world: int, cpus=None, topology=None, gpu_nodes=None) -> List[int]:
+    """The CPU set of one rank on a node that runs `local_world` ranks, built from the machine's TOPOLOGY, not from the order of the
+    CPU ids (contiguous eighths of the sorted ids put ranks 2-3 of a 2-socket SMT node on the wrong socket).
+      * the allowed CPUs are grouped into physical cores (SMT siblings stay together) and the cores into NUMA nodes;
+      * gpu_nodes (the NUMA node of every local rank's GPU, gpu_numa_nodes) known: the ranks whose GPU sits on a node split THAT node's
+        cores among themselves, in rank order -- launch thread, DataLoader workers and pinned staging buffers next to their GPU;
+      * gpu_nodes unknown: the cores, ordered by (node, package, core), are cut into local_world equal runs (ranks 0-3 on the first
+        socket and 4-7 on the second of an 8-GPU node: how MI355X nodes are wired);
+      * the topology unreadable: [] -- the caller then does not bind at all.
+    With fewer cores than ranks the slices wrap (never empty when there is a CPU)."""
     cpus = sorted(os.sched_getaffinity(0) if cpus is None else cpus)
     local_world = max(int(local_world), 1)
-    n = len(cpus)
-    if n == 0:
+    if not cpus:
         return []
-    if n < local_world:
-        return [cpus[local_rank % n]]
-    per = n // local_world
-    return cpus[local_rank * per: (local_rank + 1) * per]
+    if topology is None:
+        topology = read_cpu_topology(cpus)
+    if topology is None or any(c not in topology for c in cpus):
+        return []
+    cores = {}
+    for c in cpus:
+        node, core = topology[c]
+        cores.setdefault((node, core), []).append(c)
+    ordered = sorted(cores)                       # (node, (package, core id))
+    if gpu_nodes is not None and len(gpu_nodes) >= local_world:
+        mine = gpu_nodes[local_rank]
+        peers = [r for r in range(local_world) if gpu_nodes[r] == mine]
+        pool = [k for k in ordered if k[0] == mine]
+        idx, parts = peers.index(local_rank), len(peers)
+        if not pool:
+            return []
+    else:
+        pool, idx, parts = ordered, local_rank, local_world
+    if len(pool) < parts:
+        chosen = [pool[idx % len(pool)]]
+    else:
+        per = len(pool) // parts
+        chosen = pool[idx * per: (idx + 1) * per]
+    return sorted(c for k in chosen for c in cores[k])
 
 
 MIN_CPUS_PER_RANK = 4
@@ -40,11 +118,11 @@ MIN_CPUS_PER_RANK = 4
 
 def bind_rank_to_cpus(local_rank: int, local_world: int) -> Optional[List[int]]:
     """Pin this process (and the DataLoader workers it will fork) to its rank's CPU slice; MMRCA_CPU_BIND=0 leaves the affinity
-    alone.  Returns the slice, or None when nothing was changed (one rank per node, binding off, fewer than MIN_CPUS_PER_RANK cores per
-    rank, or no sched_setaffinity)."""
+    alone.  Returns the slice, or None when nothing was changed (one rank per node or LOCAL_WORLD_SIZE unknown, binding off, the
+    topology unreadable, fewer than MIN_CPUS_PER_RANK CPUs per rank, or no sched_setaffinity)."""
     if local_world <= 1 or os.environ.get("MMRCA_CPU_BIND", "1") != "1" or not hasattr(os, "sched_setaffinity"):
         return None
-    sl = cpu_slice(local_rank, local_world)
+    sl = cpu_slice(local_rank, local_world, gpu_nodes=gpu_numa_nodes(local_world))
     if len(sl) < MIN_CPUS_PER_RANK:        # a rank also runs RCCL's proxy thread and the HIP runtime's helpers: never squeeze it onto < 4 cores
         return None
     try:
@@ -73,9 +151,11 @@ def init_from_env(backend: Optional[str] = None):
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
-    bound = bind_rank_to_cpus(local, int(os.environ.get("LOCAL_WORLD_SIZE", str(world))))
+    # (LOCAL_WORLD_SIZE unset -- a launcher that does not say how many ranks share this node: no binding, not a 1/world guess)
+    bound = bind_rank_to_cpus(local, int(os.environ.get("LOCAL_WORLD_SIZE", "0")))
     if bound is not None and rank == 0:
-        print(f"[mmrca] rank -> CPU binding on: {len(bound)} CPUs per rank (rank 0: {bound[0]}..{bound[-1]}); MMRCA_CPU_BIND=0 disables")
+        print(f"[mmrca] rank -> CPU binding on: {len(bound)} CPUs per rank (rank 0: {bound[0]}..{bound[-1]}); MMRCA_CPU_BIND=0 disables",
+              file=sys.stderr)
     if world > 1 and not dist.is_initialized():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29500")
@@ -200,9 +280,13 @@ class GradSync:
     def capturable(self) -> bool:
         """can the exchange be recorded INSIDE a HIP graph of the train step (training.GraphedTrainStep)?  RCCL collectives can (the
         all-reduces run on RCCL's stream, forked from and joined back into the capturing stream by events: graph nodes like any
-        other); gloo's cannot.  MMRCA_GRAPH_DP=0 keeps multi-rank steps eager."""
+        other); gloo's cannot.  With MORE THAN ONE rank this is OPT-IN (MMRCA_GRAPH_DP=1): the captured exchange has only ever run on
+        the world-1 RCCL group of a one-GPU box (tests/test_rccl_gpu.py), never on two ranks -- until it has, a multi-rank step is
+        launched from Python.  (run_one_epoch makes the ranks agree on the caption width of every batch, agree_caption_width below, so
+        that they key, warm up, capture and replay the same graphs at the same steps.)"""
+        default = "1" if self.world == 1 else "0"
         return (dist.is_initialized() and dist.get_backend() == "nccl" and self.g.is_cuda
-                and os.environ.get("MMRCA_GRAPH_DP", "1") == "1")
+                and os.environ.get("MMRCA_GRAPH_DP", default) == "1")
 
     def span_ready(self, lo: int, hi: int, flush: bool = False):
         """Called by the engine when grads in [lo, hi) are final.  Adjacent ready spans are merged until a bucket is
@@ -248,6 +332,32 @@ class GradSync:
             e1.record()
             self.wait_events.append((e0, e1))
         self.pending.clear()
+
+
+_HOST_GROUP = []
+
+
+def host_group():
+    """A process group for small HOST-side agreements between the ranks (a gloo group next to the RCCL one: all-reducing a CPU integer
+    does not touch the GPU's queue, so the launch thread never waits for the step it has just enqueued).  Created on first use -- a
+    collective call: every rank must reach it at the same point (run_one_epoch's first batch).  None with a single rank."""
+    if not dist.is_initialized() or dist.get_world_size() == 1:
+        return None
+    if not _HOST_GROUP:
+        _HOST_GROUP.append(dist.group.WORLD if dist.get_backend() == "gloo" else dist.new_group(backend="gloo"))
+    return _HOST_GROUP[0]
+
+
+def agree_caption_width(width: int) -> int:
+    """max over the ranks of this batch's trimmed caption width (training.caption_width): the width is part of a HIP graph's key, and
+    ranks that key differently would warm up, capture and replay at different steps.  A wider layout only adds masked key columns
+    (same logits and gradients), so the maximum is safe for every rank."""
+    g = host_group()
+    if g is None:
+        return int(width)
+    t = torch.tensor([int(width)], dtype=torch.int64)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX, group=g)
+    return int(t.item())
 
 
 def broadcast_seed(seed: Optional[int], device="cpu") -> int:

@@ -151,9 +151,12 @@ class GraphedTrainStep:
             try:
                 ent = self._capture(key, ids, mask, images, labels, seed, tt, ti, do_step)
                 captured_now = True
-            except L.MmrcaError:               # a kernel / argument error is an error, not a slowdown
-                raise
             except RuntimeError as e:          # a step that cannot be captured keeps working, launched from Python
+                # ... but a kernel / argument error of the library is an error, not a slowdown -- unless it is the capture itself
+                # speaking through a launch check ("operation not permitted when stream is capturing", "... previous error during
+                # capture"): that one is a capture failure like torch's own
+                if isinstance(e, L.MmrcaError) and "captur" not in str(e).lower():
+                    raise
                 print(f"HIP graph capture failed for batch shape {key[0]} x {key[1]} ({type(e).__name__}: {str(e)[:200]}); this shape stays eager")
                 self._no_graph.add(key)
                 L.seed_epoch_set(0)
@@ -230,20 +233,27 @@ class GraphedTrainStep:
         return ent
 
 
-def trim_caption_columns(tokens, mask, multiple: int = 16):
+def trim_caption_columns(tokens, mask, multiple: int = 16, width=None):
     """Captions as the dataset pads them (CustomImageTextFolder.py:305-333: ``padding='max_length'`` with the text model's maximum, 512)
     cut down to the columns the batch uses, rounded up to `multiple`: key columns past every caption's end are masked for every query and
     the class-token pooling never reads their rows, so the logits and gradients are those of the padded batch.  The eager step gets the
     same effect from the packed layout (engine.TextPack); a HIP-graph replay needs static shapes, so it runs padded rows -- the
     reference's file-name captions are ~10 tokens: 512 padded columns would be 50x the text encoder's work -- and the trimmed width
-    (16, 32, ...) is part of the graph key: a handful of graphs.  Host tensors in, host views out (no device sync)."""
+    (16, 32, ...) is part of the graph key: a handful of graphs.  Host tensors in, host views out (no device sync).
+    width: use this width instead of the batch's own (data parallel: the maximum over the ranks, distributed.agree_caption_width)."""
     T = int(mask.shape[1])
-    used = (mask != 0).any(0).nonzero()
-    last = int(used.max()) + 1 if used.numel() else 1
-    t_eff = min(T, (last + multiple - 1) // multiple * multiple)
+    t_eff = caption_width(mask, multiple) if width is None else min(T, int(width))
     if t_eff >= T:
         return tokens, mask
     return tokens[:, :t_eff].contiguous(), mask[:, :t_eff].contiguous()
+
+
+def caption_width(mask, multiple: int = 16) -> int:
+    """the columns a batch of padded captions uses, rounded up to `multiple` (never more than the padded width)"""
+    T = int(mask.shape[1])
+    used = (mask != 0).any(0).nonzero()
+    last = int(used.max()) + 1 if used.numel() else 1
+    return min(T, (last + multiple - 1) // multiple * multiple)
 
 
 def stage_images(raw, hw_device, image_pipeline=None, aug_params=None):
@@ -290,7 +300,13 @@ def run_one_epoch(epoch_num, model, data_loader, len_train_data, hw_device, batc
         pack = make_text_pack(texts['attention_mask'], hw_device) if (fused and graphed is None and PACK_TEXT and not texts['attention_mask'].is_cuda) else None
         tok, msk = texts['tokens'], texts['attention_mask']
         if graphed is not None and not msk.is_cuda:
-            tok, msk = trim_caption_columns(tok, msk)
+            if grad_sync is not None and grad_sync.world > 1:
+                # every rank runs this batch at the SAME caption width (the maximum of theirs): the width is in the graph key, and
+                # ranks keyed differently would warm up / capture / replay at different steps (host-side gloo all-reduce, no device sync)
+                from .distributed import agree_caption_width
+                tok, msk = trim_caption_columns(tok, msk, width=agree_caption_width(caption_width(msk)))
+            else:
+                tok, msk = trim_caption_columns(tok, msk)
         ids = tok.to(hw_device, non_blocking=True)
         mask = msk.to(hw_device, non_blocking=True)
         labels = labels.to(hw_device, non_blocking=True)

@@ -248,7 +248,9 @@ int mmrca_rowpool_mean_bwd(const void* dpool, void* dx, int B, int HW, int C, in
 /* squeeze-excitation scaling y = x * s[b, c] and its backward (dx = dy * s, ds[b, c] = sum_rows dy * x) */
 /* The squeeze-excitation MLP of one MBConv block in one launch (torchvision SqueezeExcitation: fc1 [sq, c] + bias, SiLU, fc2 [c, sq] +
  * bias, sigmoid; efficientnet_v2_* as built at CVPR_code/multimodal_model.py:113-126): pooled [B, c] -> h_pre, h [B, sq] -> s_pre, s [B, c]
- * (pre-activations stored WITHOUT bias, as mmrca_bias_act_fwd expects).  One workgroup per sample; (c + sq) * 4 bytes of LDS. */
+ * (pre-activations stored WITHOUT bias, as mmrca_bias_act_fwd expects).  One workgroup per sample; (c + sq) * 4 bytes of LDS.
+ * c and sq multiples of 4; every pointer (both entry points; not the fp32 gradient accumulators) aligned to 4 elements -- 8 bytes in
+ * bf16, 16 in fp32 -- or the call is refused (-1). */
 int mmrca_se_mlp_fwd(const void* pooled, const void* w1, const void* b1, const void* w2, const void* b2, void* h_pre, void* h,
                      void* s_pre, void* s, int B, int c, int sq, int dtype, void* stream);
 /* its backward from ds = d loss / d s [B, c]: writes dpool [B, c] (and the workspaces ds_pre [B, c], dh_pre [B, sq]) and ADDS the

@@ -167,3 +167,43 @@ def test_graphed_step_draws_stochastic_depth_inside_the_graph():
         more = [float(graphed(*data[k % 2])) for k in range(3)]
     assert graphed.replays == 7 and len(graphed._graphs) == 1 and all(l == l for l in more), more
     m.engine.release_buffers()
+
+
+def test_a_capture_error_surfaced_by_a_launch_check_falls_back_to_the_eager_step(monkeypatch):
+    """a capture-illegal call that surfaces through MMRCA_CHECK_LAUNCH arrives as an MmrcaError whose message is the HIP
+    capture error; GraphedTrainStep must treat it like torch's own capture failure -- roll the host state back, keep that batch shape
+    eager, and compute the same step -- while any OTHER library error still raises."""
+    from garbage_classification_rca_amd import training as TR
+    from garbage_classification_rca_amd import lib as L
+    from garbage_classification_rca_amd.optim import FlatSGD
+    B, size, n = 4, 224, 4
+    data = _batches(n, B, size)
+    ma, mb = (_model("transformer_B16", B, size) for _ in range(2))
+    oa, ob = (FlatSGD(m, lr=2e-3, weight_decay=1e-2) for m in (ma, mb))
+    crit = TR.FusedCrossEntropy(None, 0.0)
+    graphed = TR.GraphedTrainStep(mb, crit, ob, warmup=1)
+    real = TR._enqueue_step
+    message = ["mmrca_gemm: launch failed: operation not permitted when stream is capturing"]
+
+    def flaky(*a, **k):
+        if torch.cuda.is_current_stream_capturing():
+            raise L.MmrcaError(message[0])
+        return real(*a, **k)
+
+    monkeypatch.setattr(TR, "_enqueue_step", flaky)
+    la, lb = [], []
+    with contextlib.redirect_stdout(io.StringIO()):
+        for k in range(n):
+            la.append(float(TR.hip_train_step(ma, *data[k], crit, oa, None, text_pack=None)))
+            lb.append(float(graphed(*data[k])))
+    assert graphed.replays == 0 and len(graphed._graphs) == 0 and len(graphed._no_graph) == 1
+    assert ma._fwd_count == mb._fwd_count == n and L.seed_epoch_host() == 0
+    assert max(abs(a - b) for a, b in zip(la, lb)) < 5e-3, (la, lb)
+    # any other library error is an error
+    graphed2 = TR.GraphedTrainStep(mb, crit, ob, warmup=0)
+    message[0] = "mmrca_gemm: K must be a multiple of 8"
+    with pytest.raises(L.MmrcaError, match="multiple of 8"), contextlib.redirect_stdout(io.StringIO()):
+        graphed2(*data[0])
+    assert not torch.cuda.is_current_stream_capturing()
+    for m in (ma, mb):
+        m.engine.release_buffers()

@@ -668,26 +668,69 @@ def test_balanced_sampler_weights_draws_and_rank_striding():
     assert len(BalancedShardedSampler([], 0, 1)) == 0 and list(iter(BalancedShardedSampler([], 0, 1))) == []
 
 
-def test_rank_to_cpu_binding_slices_and_worker_cap(monkeypatch):
+def _smt_two_socket_topology():
+    """2 sockets x 32 cores x 2 threads as Linux numbers them: 0-31 socket 0, 32-63 socket 1, 64-95 the siblings of 0-31, 96-127 of 32-63"""
+    return {c: ((c % 64) // 32, ((c % 64) // 32, c % 32)) for c in range(128)}
+
+
+def test_rank_to_cpu_binding_slices_and_worker_cap(monkeypatch, tmp_path):
     """one process per GPU (replacing nn.DataParallel, main_both.py:386-388) with 16 loader workers each (:476-492) oversubscribes a
-    node unless every rank keeps to its own cores: contiguous, disjoint, equal slices of the allowed CPUs; the worker count follows
-    the slice"""
-    cpus = list(range(4, 68))                                  # 64 allowed CPUs, ids 4..67
-    sl = [D.cpu_slice(r, 8, cpus) for r in range(8)]
-    assert all(len(x) == 8 for x in sl) and sorted(sum(sl, [])) == cpus and sl[0] == list(range(4, 12)) and sl[7] == list(range(60, 68))
-    assert D.cpu_slice(5, 8, [0, 1, 2]) == [2]                 # fewer CPUs than ranks: wrap, never empty
-    assert D.cpu_slice(0, 1, cpus) == cpus
+    node unless every rank keeps to its own cores.  ADVICE r5: the slices come from the TOPOLOGY (NUMA node of the rank's GPU, physical
+    cores with their SMT siblings), not from the order of the CPU ids; an unreadable topology or an unknown LOCAL_WORLD_SIZE binds nothing."""
+    topo = _smt_two_socket_topology()
+    cpus = list(range(128))
+    # GPU NUMA nodes known (0-3 on node 0, 4-7 on node 1): every rank on its GPU's socket, whole cores, disjoint, all CPUs used
+    gn = [0, 0, 0, 0, 1, 1, 1, 1]
+    sl = [D.cpu_slice(r, 8, cpus, topo, gn) for r in range(8)]
+    assert sl[0] == list(range(0, 8)) + list(range(64, 72)) and sl[3] == list(range(24, 32)) + list(range(88, 96))
+    assert sl[4] == list(range(32, 40)) + list(range(96, 104))
+    assert all(len(x) == 16 for x in sl) and sorted(sum(sl, [])) == cpus
+    for r in range(8):
+        assert {topo[c][0] for c in sl[r]} == {gn[r]}                           # ranks 2, 3 stay on socket 0 (id-order eighths: socket 1)
+        assert all((c + 64) % 128 in sl[r] for c in sl[r])                      # SMT siblings stay together
+    # an odd wiring (GPUs alternate between the sockets) is followed, not assumed away
+    alt = [D.cpu_slice(r, 4, cpus, topo, [0, 1, 0, 1]) for r in range(4)]
+    assert alt[0] == list(range(0, 16)) + list(range(64, 80)) and alt[2] == list(range(16, 32)) + list(range(80, 96))
+    assert {topo[c][0] for c in alt[1] + alt[3]} == {1}
+    # GPU nodes unknown: equal runs of cores in (node, package, core) order
+    un = [D.cpu_slice(r, 8, cpus, topo, None) for r in range(8)]
+    assert un == sl
+    # a restricted CPU set (container cpuset), fewer cores than ranks, one rank, no topology
+    few = D.cpu_slice(1, 2, [4, 5, 6, 7, 68, 69, 70, 71], topo, None)
+    assert few == [6, 7, 70, 71]
+    assert D.cpu_slice(5, 8, [0, 1, 2], topo, None) == [2]                    # wrap, never empty
+    assert D.cpu_slice(0, 1, cpus, topo, None) == cpus
+    assert D.cpu_slice(0, 2, [0, 1, 500], topo, None) == []                   # a CPU the topology does not know: no slice, no binding
+    assert D.cpu_slice(3, 8, cpus, topo, [0, 0, 0, 2, 1, 1, 1, 1]) == []      # GPU on a node with no allowed CPU
+    # sysfs reader on a fabricated tree (node cpulists with ranges, per-cpu package / core ids); a missing file -> None
+    for n, lst in ((0, "0-1,4-5"), (1, "2-3,6-7")):
+        (tmp_path / "node" / f"node{n}").mkdir(parents=True)
+        (tmp_path / "node" / f"node{n}" / "cpulist").write_text(lst + "\n")
+    (tmp_path / "node" / "possible").write_text("0-1\n")
+    for c in range(8):
+        d = tmp_path / "cpu" / f"cpu{c}" / "topology"
+        d.mkdir(parents=True)
+        (d / "physical_package_id").write_text(f"{(c % 4) // 2}\n")
+        (d / "core_id").write_text(f"{c % 2}\n")
+    got = D.read_cpu_topology(range(8), str(tmp_path))
+    assert got[0] == (0, (0, 0)) and got[5] == (0, (0, 1)) and got[6] == (1, (1, 0)) and len(got) == 8
+    assert D.cpu_slice(1, 2, list(range(8)), got, None) == [2, 3, 6, 7]
+    assert D.read_cpu_topology([0, 9], str(tmp_path)) is None
+    assert D.gpu_numa_nodes(2, str(tmp_path)) is None                           # (no such PCI devices / no GPU here)
     before = os.sched_getaffinity(0)
     try:
         assert D.bind_rank_to_cpus(0, 1) is None               # one rank per node: untouched
+        assert D.bind_rank_to_cpus(0, 0) is None               # LOCAL_WORLD_SIZE unset: untouched
         monkeypatch.setenv("MMRCA_CPU_BIND", "0")
         assert D.bind_rank_to_cpus(1, 2) is None and os.sched_getaffinity(0) == before
         monkeypatch.setenv("MMRCA_CPU_BIND", "1")
-        if len(before) < 2 * D.MIN_CPUS_PER_RANK:
+        want = D.cpu_slice(1, 2)
+        if len(want) < D.MIN_CPUS_PER_RANK:
             assert D.bind_rank_to_cpus(1, 2) is None and os.sched_getaffinity(0) == before      # too few cores per rank: left alone
         else:
             got = D.bind_rank_to_cpus(1, 2)
-            assert got == sorted(before)[len(before) // 2: 2 * (len(before) // 2)] and os.sched_getaffinity(0) == set(got)
+            assert got == want and os.sched_getaffinity(0) == set(got) and set(got) < before
+            assert not set(got) & set(D.cpu_slice(0, 2, sorted(before)))
             assert D.loader_workers(16) == max(1, min(16, len(got) - 1))
     finally:
         os.sched_setaffinity(0, before)
@@ -786,6 +829,11 @@ def test_split_phase_asm_loads_are_not_touched_before_their_wait():
                 else:
                     outside.append(l.strip())
     assert n_asm == 48 and not outside, (n_asm, outside[:3])          # 4 x 3 loads + 36 v_movs behind the wait
+    # ... and the kernel descriptor must ALLOCATE those registers (v216..v251 -> 252 per lane): the compiler counts the asm clobber
+    # list into the allocation today; a toolchain that stopped doing so would hand the wave 216 registers and the loads would land
+    # out of range
+    alloc = mod.allocated_vgprs(texts["attention_mfma.hip"], "_Z18mha_bwd_p_mfma_v_k")
+    assert alloc and all(v >= 252 for v in alloc.values()), alloc
 
 
 def test_bench_launches_its_own_ranks_and_reports_a_failed_one(tmp_path, capfd):
@@ -812,3 +860,40 @@ def test_bench_launches_its_own_ranks_and_reports_a_failed_one(tmp_path, capfd):
     t0 = time.time()
     assert bench.launch_ranks(2, [sys.executable, str(probe), "fail"]) == 3
     assert time.time() - t0 < 60                  # rank 0 (sleeping) was ended, not waited for
+
+
+def _width_worker(rank, world, port, q):
+    """two ranks whose batches use different caption widths end up on the SAME trimmed width (the graph key of a captured train step)"""
+    import torch.distributed as dist
+    from garbage_classification_rca_amd import training as TR
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    out = []
+    for lens in ([5, 9], [20, 3], [3, 40], [64, 64]):
+        n = lens[rank]
+        mask = torch.zeros(4, 64, dtype=torch.int64)
+        mask[:, :n] = 1
+        tok = torch.arange(4 * 64).view(4, 64)
+        own = TR.caption_width(mask)
+        w = D.agree_caption_width(own)
+        t, m = TR.trim_caption_columns(tok, mask, width=w)
+        out.append((own, w, tuple(t.shape), int(m.sum()), bool(torch.equal(t, tok[:, :w]))))
+    sync = D.GradSync(torch.zeros(8), world)
+    out.append(sync.capturable())
+    q.put((rank, out))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_ranks_agree_on_the_caption_width_of_a_graphed_step_world2():
+    """run_one_epoch trims captions per rank and the trimmed width is part of the HIP-graph key -- the ranks now take the
+    maximum over the ranks (host-side gloo all-reduce), so they key alike; and the captured RCCL exchange is opt-in on > 1 rank."""
+    res = dict(_run_world2(_width_worker))
+    for r in (0, 1):
+        own = [x[0] for x in res[r][:4]]
+        assert own == ([16, 32, 16, 64] if r == 0 else [16, 16, 48, 64])
+        assert [x[1] for x in res[r][:4]] == [16, 32, 48, 64]                  # the maximum of the two
+        assert [x[2] for x in res[r][:4]] == [(4, 16), (4, 32), (4, 48), (4, 64)]
+        assert all(x[4] for x in res[r][:4])
+        assert res[r][4] is False                                               # gloo: never capturable
+    assert [x[3] for x in res[0][:4]] == [4 * 5, 4 * 20, 4 * 3, 4 * 64]         # no live token cut off

@@ -137,6 +137,25 @@ def scan(asm_text, prefix=""):
     return n_k, out
 
 
+def allocated_vgprs(asm_text, name_prefix):
+    """{kernel symbol: VGPRs the kernel descriptor allocates per lane (.amdhsa_next_free_vgpr)} for kernels whose symbol starts with
+    name_prefix.  A kernel that lands asm loads in hard-coded registers ABOVE the range it is compiled for (amdgpu_num_vgpr) relies on
+    the compiler counting the asm clobber list into this number: were it not counted, the wave would be given fewer registers than the
+    asm writes -- the caller asserts the allocation covers the highest register named."""
+    out, cur = {}, None
+    for l in asm_text.split("\n"):
+        m = re.match(r"\s*\.amdhsa_kernel\s+(\S+)", l)
+        if m:
+            cur = m.group(1)
+            continue
+        m = re.match(r"\s*\.amdhsa_next_free_vgpr\s+(\d+)", l)
+        if m and cur is not None and cur.startswith(name_prefix):
+            out[cur] = int(m.group(1))
+        if ".end_amdhsa_kernel" in l:
+            cur = None
+    return out
+
+
 def compile_to_asm(src):
     here = os.path.dirname(os.path.abspath(src))
     with tempfile.TemporaryDirectory() as d:
