@@ -34,6 +34,7 @@
 #include "lds_asm.h"
 #include <stdlib.h>
 #include <type_traits>
+#include <mutex>
 
 typedef __attribute__((ext_vector_type(4))) float f32x4;
 typedef __attribute__((address_space(3))) void lds_void;
@@ -368,7 +369,7 @@ gemm_p256_k(const bf16_t* __restrict__ A, const bf16_t* __restrict__ B, bf16_t* 
             const bf16_t* __restrict__ addend, bf16_t* __restrict__ preact, int64_t M, int64_t N, int64_t K,
             int64_t lda, int64_t ldb, int64_t ldc, int tiles_m, int tiles_n, float* __restrict__ colsum, int skew_ticks, int dbg,
             const bf16_t* __restrict__ A_lo = nullptr, const bf16_t* __restrict__ B_lo = nullptr, bf16_t* __restrict__ C_lo = nullptr,
-            int nseg = 3, int pre16 = 0) {
+            int nseg = 3, int pre16 = 0, float* __restrict__ sk_slab = nullptr, unsigned* __restrict__ sk_count = nullptr, int sk_split = 0) {
   // pre16 (X3 only; MMRCA_ACT_GELU_SAVE_GRAD_BF16): gelu' is stored as bf16 -- the form a bf16 backward reads (bf16x3f mode)
   static_assert(!X3 || (!ADD && ACT != MMRCA_ACT_MUL), "the bf16x3 form has no side-operand epilogue");
   static_assert(!F4 || (X3 && !A_KROW && !B_KROW), "the fused four-plane form is the row-major bf16x3 forward product");
@@ -379,7 +380,19 @@ gemm_p256_k(const bf16_t* __restrict__ A, const bf16_t* __restrict__ B, bf16_t* 
   const int ntiles = tiles_m * tiles_n, G = (int)gridDim.x;                  // G % 8 == 0 (host)
   // workgroups that share an XCD (blockIdx % 8, observed round-robin placement: speed only) take consecutive tile ids
   const int slot = ((int)blockIdx.x & 7) * (G >> 3) + ((int)blockIdx.x >> 3);
-  const int my_tiles = (ntiles - slot + G - 1) / G;                           // tile ids slot, slot + G, ...
+  // Stream-K tail (sk_split >= 2; host: launch_p256).  ntiles = R whole rounds of G tiles + L leftover tiles.  The whole rounds
+  // are walked as ever (tile ids slot, slot + G, ...); each leftover tile's K loop is cut into sk_split ranges of >= 2 K steps and
+  // workgroup `slot` < L * sk_split takes ONE (tile, range) unit as its last work item -- the partial round then costs
+  // ~1 / sk_split of a tile on (nearly) every CU instead of a whole tile on L of them.  Every unit leaves its fp32 partial tile in
+  // `sk_slab` (accumulator order, 1 KiB per wave instruction); the unit that arrives LAST at the tile's counter adds the sk_split
+  // partials in the fixed order 0, 1, ... (bitwise reproducible whatever the arrival order), resets the counter and runs the
+  // ordinary epilogue.  Nobody waits for anybody: no spinning, no residency assumption.
+  const bool sk_on = sk_split > 1;
+  const int dp_tiles = sk_on ? (ntiles / G) * G : ntiles;                     // tiles walked whole
+  const int my_dp = dp_tiles > slot ? (dp_tiles - slot + G - 1) / G : 0;      // tile ids slot, slot + G, ...
+  const int sk_left = ntiles - dp_tiles;                                      // L (0 when the tail is off)
+  const bool has_unit = sk_on && slot < sk_left * sk_split;
+  const int my_tiles = my_dp + (has_unit ? 1 : 0);
   if (my_tiles <= 0) return;
   // Desynchronise the workgroups: all tiles take the same time, so without this every CU reaches its epilogue at the same
   // moment and the chip alternates between "every CU stores 128 KiB" (32 MiB burst = the whole L2) and "nobody stores".
@@ -390,6 +403,18 @@ gemm_p256_k(const bf16_t* __restrict__ A, const bf16_t* __restrict__ B, bf16_t* 
     while (__builtin_amdgcn_s_memrealtime() - t0 < wait) __builtin_amdgcn_s_sleep(32);
   }
   const int nt = (int)(K / (F4 ? 32 : 64));                                   // K steps per plane pair (F4: per tile); >= 2 (host-checked)
+  int unit_tile = 0, unit_part = 0, unit_k0 = 0, unit_len = nt;               // this workgroup's (leftover tile, K range)
+  if (has_unit) {
+    unit_tile = slot % sk_left; unit_part = slot / sk_left;                   // consecutive slots (one XCD) -> consecutive tiles
+    const int kbase = nt / sk_split, krem = nt % sk_split;                    // the first krem ranges take one step more
+    unit_k0 = unit_part * kbase + (unit_part < krem ? unit_part : krem);
+    unit_len = kbase + (unit_part < krem ? 1 : 0);                            // >= 2 (host: sk_split <= nt / 2)
+  }
+  // work item idx of this workgroup: (tile id, first K step, K steps)
+  auto work_item = [&](int idx, int& id, int& k0, int& nk) {
+    if (idx < my_dp) { id = slot + idx * G; k0 = 0; nk = nt; }
+    else { id = dp_tiles + unit_tile; k0 = unit_k0; nk = unit_len; }
+  };
   const int GROUP = 4;
   auto tile_origin = [&](int id, int64_t& m_blk, int64_t& n_blk) {
     const int group = id / (GROUP * tiles_n);
@@ -408,7 +433,7 @@ gemm_p256_k(const bf16_t* __restrict__ A, const bf16_t* __restrict__ B, bf16_t* 
   const unsigned a_step = (unsigned)(F4 ? 64 : (A_KROW ? 128 * lda : 128)), b_step = (unsigned)(F4 ? 64 : (B_KROW ? 128 * ldb : 128));
   const int64_t a_half = A_KROW ? 256 : 256 * lda, b_half = B_KROW ? 64 : 64 * ldb;       // bytes
   unsigned oa[2], ob[2];
-  auto stream_to = [&](int id) {
+  auto stream_to = [&](int id, int k0) {
     int64_t mb, nb;
     tile_origin(id, mb, nb);
     if constexpr (F4) {
@@ -424,8 +449,15 @@ gemm_p256_k(const bf16_t* __restrict__ A, const bf16_t* __restrict__ B, bf16_t* 
         ob[ii] = (unsigned)(2 * (piece_src<B_KROW, true>(B, ldb, nb, (int64_t)1 << 40, wave * 2 + ii, lane, 0) - B));
       }
     }
+    oa[0] += (unsigned)k0 * a_step; oa[1] += (unsigned)k0 * a_step;
+    ob[0] += (unsigned)k0 * b_step; ob[1] += (unsigned)k0 * b_step;
   };
-  stream_to(slot);
+  int stream_nt;                               // K steps of the stream's current work item
+  {
+    int id0, k00;
+    work_item(0, id0, k00, stream_nt);
+    stream_to(id0, k00);
+  }
   int stream_kt = 0, stream_tile = 0;          // K-tiles already issued of the stream's current tile; its index in my list
   [[maybe_unused]] int stream_seg = 0;         // X3: which plane pair the stream is in
   const bf16_t* Acur = A;
@@ -444,13 +476,13 @@ gemm_p256_k(const bf16_t* __restrict__ A, const bf16_t* __restrict__ B, bf16_t* 
     else {                                                                                                      \
       stage_half_t<F4>(SRC_A(1, 0), SRC_A(1, 1), my_piece + issue_stage + SLOT_A1 * HT_BYTES); oa[0] += a_step; oa[1] += a_step;  \
       issue_stage ^= STAGE_BYTES;                                                                               \
-      if (++stream_kt == nt) {                                                                                  \
+      if (++stream_kt == stream_nt) {                                                                           \
         stream_kt = 0;                                                                                          \
         if constexpr (X3 && !F4) {                                                                              \
           if (++stream_seg == nseg) { stream_seg = 0; ++stream_tile; }                                             \
           Acur = stream_seg == 1 ? A_lo : A; Bcur = stream_seg == 2 ? B_lo : B;                                 \
         } else ++stream_tile;                                                                                   \
-        if (stream_tile < my_tiles) stream_to(slot + stream_tile * G);                                          \
+        if (stream_tile < my_tiles) { int id_, k0_; work_item(stream_tile, id_, k0_, stream_nt); stream_to(id_, k0_); } \
       }                                                                                                         \
     }                                                                                                           \
   } while (0)
@@ -505,7 +537,9 @@ gemm_p256_k(const bf16_t* __restrict__ A, const bf16_t* __restrict__ B, bf16_t* 
 
   for (int ti = 0; ti < my_tiles; ++ti) {
     int64_t m_blk, n_blk;
-    tile_origin(slot + ti * G, m_blk, n_blk);
+    int tile_id, tile_k0, tile_nk;
+    work_item(ti, tile_id, tile_k0, tile_nk);
+    tile_origin(tile_id, m_blk, n_blk);
 #pragma unroll
     for (int a = 0; a < 2; ++a)
 #pragma unroll
@@ -517,7 +551,7 @@ gemm_p256_k(const bf16_t* __restrict__ A, const bf16_t* __restrict__ B, bf16_t* 
     frag_bases();
     if (wr) BARRIER();                    // group 1 runs one barrier behind
     __builtin_amdgcn_sched_barrier(0);
-    const int ntv = (X3 && !F4) ? nseg * nt : nt;  // K-tiles per output tile (bf16x3: nseg plane pairs; fused: K / 32 steps of all planes)
+    const int ntv = (X3 && !F4) ? nseg * nt : tile_nk;  // K-tiles of this work item (bf16x3: nseg plane pairs; fused: K / 32 steps of all planes)
     if constexpr (F4) {
       if (ti + 1 < my_tiles) {
         for (int t = 0; t < ntv; ++t) K_TILE_G4(ISSUE_P, 1, 1, 1, 1, 8, 8, 10, 8);
@@ -536,6 +570,56 @@ gemm_p256_k(const bf16_t* __restrict__ A, const bf16_t* __restrict__ B, bf16_t* 
     }
     if (!wr) BARRIER();                   // group 0 waits for group 1's last segment: all eight waves aligned
     __builtin_amdgcn_sched_barrier(0);
+
+    // ---- stream-K unit: partial tile out, and the last arrival at the tile's counter sums the partials (see the top)
+    if constexpr (!X3 || F4) {
+      if (ti >= my_dp) {                    // (uniform; a unit is always the workgroup's last work item: nothing is in flight)
+        int lane_s = lane;                  // (opaque: otherwise the 32 slab addresses are computed at kernel entry and spilled)
+        asm volatile("" : "+v"(lane_s));
+        float* const mine = sk_slab + ((int64_t)(unit_tile * sk_split + unit_part) * 65536 + wave * 8192 + lane_s * 4);
+#pragma unroll
+        for (int a = 0; a < 2; ++a)
+#pragma unroll
+          for (int b = 0; b < 2; ++b)
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+              for (int j = 0; j < 2; ++j)
+                *reinterpret_cast<f32x4*>(mine + (((a * 2 + b) * 4 + i) * 2 + j) * 256) = acc[a][b][i][j];
+        __threadfence();                    // release: this workgroup's partial is visible device-wide before its arrival is
+        __syncthreads();
+        volatile unsigned* const flag = reinterpret_cast<volatile unsigned*>(smem + EP_BASE);
+        if (threadIdx.x == 0) {
+          const unsigned arrived = atomicAdd(sk_count + unit_tile, 1u);
+          if (arrived == (unsigned)sk_split - 1u) sk_count[unit_tile] = 0u;      // all sk_split units have arrived: ready for the next launch
+          *flag = arrived;
+        }
+        __syncthreads();
+        const bool last = *flag == (unsigned)sk_split - 1u;
+        __syncthreads();                    // (wave 0's epilogue staging overwrites the flag)
+        if (!last) break;
+        __threadfence();                    // acquire: the other units' partials
+        asm volatile("" : "+v"(lane_s));
+        const float* const all = sk_slab + ((int64_t)(unit_tile * sk_split) * 65536 + wave * 8192 + lane_s * 4);
+        // part 0 lands in the accumulators themselves (they are dead since the store above: 32 loads = this wave's whole 32 KiB in
+        // flight at once); parts 1.. go through 16 temporaries at a time (all 32 at once would spill)
+#pragma unroll
+        for (int f = 0; f < 32; ++f)
+          acc[f >> 4][(f >> 3) & 1][(f >> 1) & 3][f & 1] = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(all + f * 256));
+        for (int part = 1; part < sk_split; ++part) {
+          const float* const src = all + (int64_t)part * 65536;
+#pragma unroll
+          for (int h = 0; h < 2; ++h) {
+            f32x4 t[16];
+#pragma unroll
+            for (int f = 0; f < 16; ++f) t[f] = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(src + (16 * h + f) * 256));
+#pragma unroll
+            for (int f = 0; f < 16; ++f) acc[h][(f >> 3) & 1][(f >> 1) & 3][f & 1] += t[f];
+            __builtin_amdgcn_sched_barrier(0);
+          }
+        }
+      }
+    }
 
     // ---- epilogue (see the header of this kernel).  Its per-lane addresses are derived from an opaque copy of the lane id,
     // so that none of them is kept in a register (or spilled) across the K loop.
@@ -692,17 +776,68 @@ gemm_p256_k(const bf16_t* __restrict__ A, const bf16_t* __restrict__ B, bf16_t* 
 extern int g_mmrca_dbg;
 static int g_num_cus = 0;
 static int g_p256_skew = -1;      // x 10 ns between the four start groups (MMRCA_P256_SKEW; see gemm_p256_k)
-template <bool AK, bool BK2, int ACT, bool ADD, bool X3 = false, bool PLANES = false, bool F4 = false>
-static void launch_p256(const void* A, const void* B, void* C, const void* bias, const void* addend, void* preact, int64_t M,
-                        int64_t N, int64_t K, int64_t lda, int64_t ldb, int64_t ldc, float* colsum, hipStream_t st,
-                        const void* A_lo = nullptr, const void* B_lo = nullptr, void* C_lo = nullptr, int nseg = 3, int pre16 = 0) {
-  const int tiles_m = (int)((M + 255) / 256), tiles_n = (int)(N / 256);
+
+// ---- stream-K tail workspaces: caller-owned, one per stream that launches GEMMs (mmrca_gemm_streamk_workspace, include/mmrca.h)
+#define SK_COUNTER_BYTES 4096          // 1,024 tile counters (at most 255 are used), zero between launches
+#define SK_MAX_UNITS 256               // one unit per CU at most
+struct SkWorkspace { void* stream; char* base; int64_t bytes; };
+static SkWorkspace g_sk_ws[32];
+static int g_sk_ws_n = 0;
+static std::mutex g_sk_mutex;
+extern "C" int64_t mmrca_gemm_streamk_workspace_bytes(void) { return SK_COUNTER_BYTES + (int64_t)SK_MAX_UNITS * 65536 * 4; }
+extern "C" int mmrca_gemm_streamk_workspace(void* workspace, int64_t bytes, void* stream) {
+  MMRCA_REQUIRE(workspace == nullptr || (bytes >= mmrca_gemm_streamk_workspace_bytes() && (((uintptr_t)workspace) & 15) == 0),
+                "gemm_streamk_workspace: needs %lld bytes, 16-byte aligned, zero-filled", (long long)mmrca_gemm_streamk_workspace_bytes());
+  std::lock_guard<std::mutex> lock(g_sk_mutex);
+  for (int i = 0; i < g_sk_ws_n; ++i)
+    if (g_sk_ws[i].stream == stream) {
+      if (workspace) { g_sk_ws[i].base = (char*)workspace; g_sk_ws[i].bytes = bytes; }
+      else g_sk_ws[i] = g_sk_ws[--g_sk_ws_n];
+      return 0;
+    }
+  if (!workspace) return 0;
+  MMRCA_REQUIRE(g_sk_ws_n < 32, "gemm_streamk_workspace: more than 32 streams registered");
+  g_sk_ws[g_sk_ws_n++] = SkWorkspace{stream, (char*)workspace, bytes};
+  return 0;
+}
+static char* sk_workspace_of(void* stream) {
+  std::lock_guard<std::mutex> lock(g_sk_mutex);
+  for (int i = 0; i < g_sk_ws_n; ++i)
+    if (g_sk_ws[i].stream == stream) return g_sk_ws[i].base;
+  return nullptr;
+}
+static int num_cus() {
   if (g_num_cus == 0) {
     int dev = 0, n = 0;
     (void)hipGetDevice(&dev);
     if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n < 8) n = 256;
     g_num_cus = n & ~7;
   }
+  return g_num_cus;
+}
+// how many K ranges the leftover tiles of a launch are cut into (0 / 1 = no stream-K tail): as many as fill the chip once,
+// each at least two K steps long (the stream's pipeline), at most MMRCA_SK_MAX (default 4: the unit that finishes a tile reads
+// all its partials, 256 KiB each, on ONE CU).  MMRCA_SK=0 turns the tail off.
+int mmrca_gemm256_streamk_split(int64_t M, int64_t N, int64_t ksteps, void* stream) {
+  static const int sk_enabled = getenv("MMRCA_SK") ? atoi(getenv("MMRCA_SK")) : 1;
+  static const int sk_max = getenv("MMRCA_SK_MAX") ? atoi(getenv("MMRCA_SK_MAX")) : 4;
+  if (!sk_enabled || !sk_workspace_of(stream)) return 0;
+  const int64_t tiles = ((M + 255) / 256) * (N / 256);
+  const int ncu = num_cus();
+  if (tiles < ncu) return 0;
+  const int64_t left = tiles % ncu;
+  if (left == 0) return 0;
+  int64_t split = ncu / left;
+  if (split > ksteps / 2) split = ksteps / 2;
+  if (split > sk_max) split = sk_max;
+  return split >= 2 ? (int)split : 0;
+}
+template <bool AK, bool BK2, int ACT, bool ADD, bool X3 = false, bool PLANES = false, bool F4 = false>
+static void launch_p256(const void* A, const void* B, void* C, const void* bias, const void* addend, void* preact, int64_t M,
+                        int64_t N, int64_t K, int64_t lda, int64_t ldb, int64_t ldc, float* colsum, hipStream_t st,
+                        const void* A_lo = nullptr, const void* B_lo = nullptr, void* C_lo = nullptr, int nseg = 3, int pre16 = 0) {
+  const int tiles_m = (int)((M + 255) / 256), tiles_n = (int)(N / 256);
+  (void)num_cus();
   if (g_p256_skew < 0) {
     const char* e = getenv("MMRCA_P256_SKEW");
     g_p256_skew = e ? atoi(e) : 0;
@@ -710,11 +845,20 @@ static void launch_p256(const void* A, const void* B, void* C, const void* bias,
   int grid = tiles_m * tiles_n < g_num_cus ? ((tiles_m * tiles_n) & ~7) : g_num_cus;
   if (grid < 8) grid = 8;
   constexpr int LDS_P = 2 * STAGE_BYTES + 32768;       // all 160 KiB of the CU
+  // stream-K tail (bf16 and the fused four-plane form; the three-pass bf16x3 form walks its K loop per plane pair)
+  int sk_split = 0;
+  char* sk_ws = nullptr;
+  if constexpr (!X3 || F4) {
+    sk_split = mmrca_gemm256_streamk_split(M, N, K / (F4 ? 32 : 64), (void*)st);
+    if (sk_split >= 2) sk_ws = sk_workspace_of((void*)st);
+    if (!sk_ws) sk_split = 0;
+  }
   MMRCA_MAX_LDS(LDS_P, gemm_p256_k<AK, BK2, ACT, ADD, X3, PLANES, F4>);
   hipLaunchKernelGGL((gemm_p256_k<AK, BK2, ACT, ADD, X3, PLANES, F4>), dim3(grid), dim3(512), LDS_P, st, (const bf16_t*)A, (const bf16_t*)B,
                      (bf16_t*)C, (const bf16_t*)bias, (const bf16_t*)addend, (bf16_t*)preact, M, N, K, lda, ldb, ldc, tiles_m,
                      tiles_n, colsum, tiles_m * tiles_n >= 2 * g_num_cus ? g_p256_skew : 0, g_mmrca_dbg, (const bf16_t*)A_lo,
-                     (const bf16_t*)B_lo, (bf16_t*)C_lo, nseg, pre16);
+                     (const bf16_t*)B_lo, (bf16_t*)C_lo, nseg, pre16, (float*)(sk_ws ? sk_ws + SK_COUNTER_BYTES : nullptr),
+                     (unsigned*)sk_ws, sk_split);
 }
 
 int g_mmrca_dbg = 0;

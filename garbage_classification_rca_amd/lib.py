@@ -52,6 +52,7 @@ _SIGS = {
     "mmrca_gemm_colsum": [_vp] * 7 + [_i64] * 6 + [_i32] * 5 + [_vp],
     "mmrca_gemm_rows": [_vp] * 7 + [_i64] * 8 + [_i32] * 5 + [_vp],
     "mmrca_gemm_splitk": [_vp] * 4 + [_i64] * 7 + [_i32] * 2 + [_vp],
+    "mmrca_gemm_streamk_workspace": [_vp, _i64, _vp],
     "mmrca_gemm_x3": [_vp] * 10 + [_i64] * 6 + [_i32] * 5 + [_vp],
     "mmrca_gemm_splitk_x3": [_vp] * 6 + [_i64] * 7 + [_i32] * 2 + [_vp],
     "mmrca_split_f32": [_vp, _vp, _vp, _i64, _vp],
@@ -128,7 +129,7 @@ _SIGS = {
     "mmrca_seed_epoch_set": [_vp, _u64, _vp],
     "mmrca_sd_rowscale": [_vp, _vp, _i32, _i32, _u64, _vp],
 }
-EXPORTS = sorted(list(_SIGS) + ["mmrca_last_error", "mmrca_version", "mmrca_debug_set", "mmrca_bn_flat_set", "mmrca_debug_attn_stamps", "mmrca_gemm_splitk_workspace_bytes",
+EXPORTS = sorted(list(_SIGS) + ["mmrca_last_error", "mmrca_version", "mmrca_debug_set", "mmrca_bn_flat_set", "mmrca_debug_attn_stamps", "mmrca_gemm_splitk_workspace_bytes", "mmrca_gemm_streamk_workspace_bytes",
                                   "mmrca_head_bwd_workspace_bytes", "mmrca_conv3x3_stat_slots", "mmrca_gemm_bnstats_slots"])
 
 
@@ -149,6 +150,8 @@ def load(build_if_missing: bool = False):
         fn.restype = C.c_int
     lib.mmrca_gemm_splitk_workspace_bytes.argtypes = [_i64, _i64]
     lib.mmrca_gemm_splitk_workspace_bytes.restype = _i64
+    lib.mmrca_gemm_streamk_workspace_bytes.argtypes = []
+    lib.mmrca_gemm_streamk_workspace_bytes.restype = _i64
     lib.mmrca_conv3x3_stat_slots.argtypes = [_i32, _i32, _i32]
     lib.mmrca_conv3x3_stat_slots.restype = _i64
     lib.mmrca_last_error.restype = C.c_char_p
@@ -227,6 +230,25 @@ GEMM_SHAPES = None      # tools / bench.py (MMRCA_BENCH_SHAPES=1) set this to a 
 CONV_PROFILE = None     # bench.py sets this to a list: (kernel family, algorithmic HBM bytes, start event, end event) of every conv-path launch
 
 
+_STREAMK_WS = {}       # (device index, stream) -> zero-filled workspace registered with mmrca_gemm_streamk_workspace
+STREAMK = os.environ.get("MMRCA_SK", "1") != "0"
+
+
+def streamk_workspace(M, N, device):
+    """The persistent 256x256 GEMM keeps the partial round of a launch inside the launch (stream-K tail, csrc/gemm256.hip) when the
+    stream it runs on has a workspace: one per (device, stream), allocated at the first product that has a full round of tiles."""
+    if not STREAMK or N % 256 or ((M + 255) // 256) * (N // 256) < 256:
+        return
+    st = stream_ptr()
+    key = (device.index if device.index is not None else torch.cuda.current_device(), st)
+    if key in _STREAMK_WS:
+        return
+    need = int(load().mmrca_gemm_streamk_workspace_bytes())
+    ws = torch.zeros(need, dtype=torch.uint8, device=device)
+    _check(load().mmrca_gemm_streamk_workspace(ptr(ws), need, st), "mmrca_gemm_streamk_workspace")
+    _STREAMK_WS[key] = ws
+
+
 def gemm_is_mfma(M, N, K, a_layout, dtype, impl):
     return dtype == BF16 and impl != IMPL_REF and N % 128 == 0 and K % 64 == 0 and (a_layout == ROWK or M % 128 == 0)
 
@@ -237,6 +259,8 @@ def gemm(A, B, Cout, *, bias=None, addend=None, preact=None, M, N, K, lda, ldb, 
     rows_readable = (rows of A, rows of the side operand) that exist in memory: required for impl=IMPL_MFMA256 with a ragged M
     (mmrca_gemm_rows; the 256x256 kernel reads whole 256-row tiles)"""
     _dev(A, "gemm A")
+    if dtype == BF16 and not accum:
+        streamk_workspace(M, N, A.device)
     if rows_readable is not None:
         if accum:
             raise MmrcaError("gemm: rows_readable is not available in accumulate mode")
@@ -299,6 +323,8 @@ def gemm_x3(A, B, Cout, *, C_lo=None, bias=None, addend=None, preact=None, colsu
     """bf16x3 product (csrc/gemm_x3.hip): A and B are (hi, lo) pairs of bf16 planes of fp32 operands; Cout / bias / addend /
     preact are fp32 -- or, with C_lo, the output is written as two bf16 planes (Cout = hi plane)."""
     _dev(A[0], "gemm_x3 A")
+    if not accum:
+        streamk_workspace(M, N, A[0].device)
     prof = GEMM_PROFILE is not None
     if prof:
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)

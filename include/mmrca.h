@@ -118,6 +118,19 @@ int mmrca_gemm_rows(const void* A, const void* B, void* C, const void* bias, con
                     int64_t a_rows_readable, int64_t side_rows_readable, int a_layout, int b_layout, int act, int dtype,
                     int impl, void* stream);
 
+/* Stream-K tail of the persistent 256x256 kernel (round 6).  A launch of T tiles on G CUs is floor(T / G) whole rounds plus
+ * L = T mod G leftover tiles; without a workspace the leftover tiles cost a whole extra round on L CUs (or, from AUTO, a second
+ * launch on the 128x128 kernel).  With a workspace registered for the stream of the call, the K loop of every leftover tile is
+ * cut into min(G / L, K steps / 2, 4) ranges that run as the LAST work item of as many workgroups of the same launch; each leaves
+ * its fp32 partial tile in the workspace and the workgroup that arrives last at the tile's counter adds the partials in the fixed
+ * order 0, 1, ... (bitwise reproducible) and runs the epilogue.  No workgroup waits for another.
+ *   workspace: caller-owned device memory, >= mmrca_gemm_streamk_workspace_bytes() bytes (4 KiB of counters + 256 partial tiles),
+ *   16-byte aligned, ZERO-FILLED by the caller once (every launch leaves the counters at zero again); one per stream that issues
+ *   GEMMs concurrently with another; it must outlive every launch (and captured graph) made on that stream.  workspace == NULL
+ *   removes the stream's entry.  MMRCA_SK=0 (environment) turns the tail off, MMRCA_SK_MAX caps the ranges per tile. */
+int64_t mmrca_gemm_streamk_workspace_bytes(void);
+int mmrca_gemm_streamk_workspace(void* workspace, int64_t bytes, void* stream);
+
 /* Weight gradient on 256x256 tiles with the contraction split over workgroups: C[M,N] (fp32) += A (.) B over K
  * (torch autograd of nn.Linear: dW = dY^T X; same call sites as mmrca_gemm's accumulate mode).  bf16 operands, either
  * layout; M % 256 == 0, N % 256 == 0, K % 64 == 0, at most 256 output tiles.  The per-workgroup fp32 partial tiles go

@@ -465,6 +465,111 @@ def test_gemm_splitk_is_bitwise_reproducible_and_matches_the_atomic_kernel():
     assert torch.equal(a, b)
 
 
+# ---- stream-K tail of the persistent 256x256 kernel (round 6): the leftover tiles' K loops run as ranges on every CU
+def _streamk_ws_counters():
+    key = (torch.cuda.current_device(), L.stream_ptr())
+    ws = L._STREAMK_WS.get(key)
+    return None if ws is None else ws[:4096].view(torch.int32)
+
+
+def _streamk_toggle(on):
+    """(un)register the current stream's workspace with the library: off = the kernel as it was (whole leftover tiles)"""
+    key = (torch.cuda.current_device(), L.stream_ptr())
+    ws = L._STREAMK_WS[key]
+    L._check(L.load().mmrca_gemm_streamk_workspace(L.ptr(ws) if on else None, ws.numel(), L.stream_ptr()), "streamk toggle")
+
+
+@pytest.mark.parametrize("shape", [(22272, 768, 256, 2), (25600, 768, 768, 4), (50432, 768, 768, 3), (32000, 2304, 512, 2), (25500, 768, 1024, 4)])
+@pytest.mark.parametrize("bl", [L.ROWK, L.KROW])
+def test_gemm_streamk_tail_matches_fp64_and_the_whole_tile_walk_and_is_bitwise_reproducible(shape, bl):
+    """M x N = whole rounds of 256 tiles + L leftover tiles whose K loops are cut into `split` ranges (22272 x 768: 261 tiles, L = 5;
+    25600 x 768: 300, L = 44; 50432 x 768 = the ViT's out-projection at B = 256: 591, L = 79; 32000 x 2304: 1125, L = 101 -- two ranges per tile; 25500: a ragged last row tile inside a split tile)"""
+    M, N, K, split = shape
+    g = torch.Generator().manual_seed(M + N + K)
+    Mp = (M + 255) // 256 * 256
+    X = torch.zeros(Mp, K, device="cuda", dtype=torch.bfloat16)
+    X[:M] = dev(torch.randn(M, K, generator=g) * 0.5, torch.bfloat16)
+    W = dev(torch.randn(N, K, generator=g) * 0.1, torch.bfloat16)
+    Wd = W if bl == L.ROWK else W.t().contiguous()
+    bias = dev(torch.randn(N, generator=g) * 0.2, torch.bfloat16)
+    ref = X[:M].double() @ W.double().t() + bias.double()
+
+    def run():
+        Y = torch.zeros(M, N, device="cuda", dtype=torch.bfloat16)
+        L.gemm(X, Wd, Y, bias=bias, M=M, N=N, K=K, lda=K, ldb=Wd.shape[1], ldc=N, b_layout=bl, dtype=L.BF16, impl=L.IMPL_MFMA256,
+               rows_readable=(Mp, 0))
+        return Y
+    a = run()
+    torch.cuda.synchronize()
+    ctr = _streamk_ws_counters()
+    assert ctr is not None and int(ctr.abs().sum()) == 0, "every tile counter is back at zero after the launch"
+    tiles = (Mp // 256) * (N // 256)
+    left = tiles % 256
+    assert split == min(256 // left, K // 64 // 2, 4)           # what the host picks (mmrca_gemm256_streamk_split)
+    assert rel_err(a, ref) < 1e-2
+    for _ in range(3):
+        assert torch.equal(run(), a), "partials are added in a fixed order: bitwise reproducible"
+    _streamk_toggle(False)
+    try:
+        b = run()
+    finally:
+        _streamk_toggle(True)
+    assert rel_err(b, ref) < 1e-2
+    # the two walks add the same fp32 products in a different order: equal to within bf16 rounding of the output
+    assert rel_err(a, b) < 8e-3 and (a != b).float().mean().item() < 0.05
+
+
+def test_gemm_streamk_tail_under_every_epilogue_of_the_persistent_kernel():
+    """GELU + saved gelu', the gelu' factor with the bias-gradient column sums, a residual addend: the unit that finishes a split
+    tile runs the same epilogue code on the summed partials (M = 25,600 = 100 row tiles x 3: 300 tiles, 44 of them split four ways)"""
+    M, N, K = 25600, 768, 1024
+    g = torch.Generator().manual_seed(11)
+    X = dev(torch.randn(M, K, generator=g) * 0.5, torch.bfloat16)
+    W = dev(torch.randn(N, K, generator=g) * 0.05, torch.bfloat16)
+    bias = dev(torch.randn(N, generator=g) * 0.2, torch.bfloat16)
+    h = X.double() @ W.double().t() + bias.double()
+    Y, P = torch.empty(M, N, device="cuda", dtype=torch.bfloat16), torch.empty(M, N, device="cuda", dtype=torch.bfloat16)
+    L.gemm(X, W, Y, bias=bias, preact=P, M=M, N=N, K=K, lda=K, ldb=K, ldc=N, act=L.ACT_GELU_SAVE_GRAD, dtype=L.BF16, impl=L.IMPL_MFMA256)
+    assert rel_err(Y, F.gelu(h)) < 1e-2
+    hh = h.detach().clone().requires_grad_(True)
+    F.gelu(hh).sum().backward()
+    assert rel_err(P, hh.grad) < 1e-2
+    # input gradient x gelu' with the column sums: dH = (dY W2) * gelu'(h), db1 = column sums of dH
+    W2 = dev(torch.randn(K, N, generator=g) * 0.05, torch.bfloat16)          # [K2 = 1024 rows of the contraction][N]  (KROW)
+    dY = dev(torch.randn(M, K, generator=g) * 0.5, torch.bfloat16)
+    dH = torch.empty(M, N, device="cuda", dtype=torch.bfloat16)
+    db = torch.zeros(N, device="cuda")
+    L.gemm(dY, W2, dH, preact=P, M=M, N=N, K=K, lda=K, ldb=N, ldc=N, b_layout=L.KROW, act=L.ACT_MUL, dtype=L.BF16, impl=L.IMPL_MFMA256, colsum=db)
+    ref = (dY.double() @ W2.double()) * P.double()
+    assert rel_err(dH, ref) < 1e-2
+    assert rel_err(db, dH.double().sum(0)) < 1e-3
+    R = dev(torch.randn(M, N, generator=g), torch.bfloat16)
+    Z = torch.empty(M, N, device="cuda", dtype=torch.bfloat16)
+    L.gemm(X, W, Z, bias=bias, addend=R, M=M, N=N, K=K, lda=K, ldb=K, ldc=N, dtype=L.BF16, impl=L.IMPL_MFMA256)
+    assert rel_err(Z, h + R.double()) < 1e-2
+    assert int(_streamk_ws_counters().abs().sum()) == 0
+
+
+def test_gemm_streamk_tail_on_a_side_stream_and_through_auto():
+    """one workspace per stream (two streams run GEMMs concurrently in the engine); AUTO keeps the partial round inside the launch
+    instead of handing it to the 128x128 kernel"""
+    M, N, K = 50432, 768, 768
+    g = torch.Generator().manual_seed(3)
+    X = dev(torch.randn(M, K, generator=g) * 0.5, torch.bfloat16)
+    W = dev(torch.randn(N, K, generator=g) * 0.05, torch.bfloat16)
+    ref = X.double() @ W.double().t()
+    outs = []
+    side = torch.cuda.Stream()
+    for st in (torch.cuda.current_stream(), side):
+        with torch.cuda.stream(st):
+            Y = torch.empty(M, N, device="cuda", dtype=torch.bfloat16)
+            L.gemm(X, W, Y, M=M, N=N, K=K, lda=K, ldb=K, ldc=N, dtype=L.BF16)
+            outs.append(Y)
+    torch.cuda.synchronize()
+    assert len(L._STREAMK_WS) >= 2
+    assert rel_err(outs[0], ref) < 1e-2 and torch.equal(outs[0], outs[1])
+
+
 def test_gemm_at_the_benchmarked_sizes():
     """BASELINE configs[1]: 50,432 token rows (B=256 x 197).  Forward / input-gradient GEMM at M = 50,432 (XCD remap at
     2,364 tiles, grouped rastering) and the weight gradient with a 50,432-row contraction (split-K over every resident
