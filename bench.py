@@ -549,7 +549,7 @@ def main():
 
     pack_in_loop = os.environ.get("MMRCA_BENCH_PACK_IN_LOOP", "1") == "1" and PACK_TEXT
 
-    use_graph = args.graph == "on" or (args.graph == "auto" and B <= 16 and world == 1 and args.dtype == "bf16")
+    use_graph = args.graph == "on" or (args.graph == "auto" and B <= 16 and world == 1 and args.dtype in ("bf16", "bf16x3f"))
     graphed = None
     if use_graph:
         from garbage_classification_rca_amd.training import GraphedTrainStep

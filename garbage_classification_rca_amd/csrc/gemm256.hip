@@ -571,53 +571,63 @@ gemm_p256_k(const bf16_t* __restrict__ A, const bf16_t* __restrict__ B, bf16_t* 
     if (!wr) BARRIER();                   // group 0 waits for group 1's last segment: all eight waves aligned
     __builtin_amdgcn_sched_barrier(0);
 
-    // ---- stream-K unit: partial tile out, and the last arrival at the tile's counter sums the partials (see the top)
+    // ---- stream-K unit: partial tile out, and the last arrival at the tile's counter sums the partials (see the top).
+    // Coherence without cache flushes: the partial tiles are the ONLY data that cross workgroups, so they are written and read
+    // with agent-scope accesses (sc1: coherent across the eight XCDs' L2s by themselves) and ordered by vmcnt(0) -> barrier ->
+    // agent-scope atomic -> barrier -> loads.  A release / acquire FENCE pair instead (`__threadfence()`) writes back and
+    // invalidates whole L2s -- full of this launch's C tiles -- once per unit: measured +100 us per launch.
     if constexpr (!X3 || F4) {
       if (ti >= my_dp) {                    // (uniform; a unit is always the workgroup's last work item: nothing is in flight)
         int lane_s = lane;                  // (opaque: otherwise the 32 slab addresses are computed at kernel entry and spilled)
         asm volatile("" : "+v"(lane_s));
         float* const mine = sk_slab + ((int64_t)(unit_tile * sk_split + unit_part) * 65536 + wave * 8192 + lane_s * 4);
 #pragma unroll
-        for (int a = 0; a < 2; ++a)
-#pragma unroll
-          for (int b = 0; b < 2; ++b)
-#pragma unroll
-            for (int i = 0; i < 4; ++i)
-#pragma unroll
-              for (int j = 0; j < 2; ++j)
-                *reinterpret_cast<f32x4*>(mine + (((a * 2 + b) * 4 + i) * 2 + j) * 256) = acc[a][b][i][j];
-        __threadfence();                    // release: this workgroup's partial is visible device-wide before its arrival is
+        for (int f = 0; f < 32; ++f)
+          asm volatile("global_store_dwordx4 %0, %1, off sc1" :: "v"(mine + f * 256), "v"(acc[f >> 4][(f >> 3) & 1][(f >> 1) & 3][f & 1]) : "memory");
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // every partial of this wave has reached the coherence point
         __syncthreads();
         volatile unsigned* const flag = reinterpret_cast<volatile unsigned*>(smem + EP_BASE);
         if (threadIdx.x == 0) {
-          const unsigned arrived = atomicAdd(sk_count + unit_tile, 1u);
-          if (arrived == (unsigned)sk_split - 1u) sk_count[unit_tile] = 0u;      // all sk_split units have arrived: ready for the next launch
+          const unsigned arrived = __hip_atomic_fetch_add(sk_count + unit_tile, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          if (arrived == (unsigned)sk_split - 1u)            // all sk_split units have arrived: ready for the next launch
+            __hip_atomic_store(sk_count + unit_tile, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
           *flag = arrived;
         }
         __syncthreads();
         const bool last = *flag == (unsigned)sk_split - 1u;
         __syncthreads();                    // (wave 0's epilogue staging overwrites the flag)
         if (!last) break;
-        __threadfence();                    // acquire: the other units' partials
         asm volatile("" : "+v"(lane_s));
         const float* const all = sk_slab + ((int64_t)(unit_tile * sk_split) * 65536 + wave * 8192 + lane_s * 4);
-        // part 0 lands in the accumulators themselves (they are dead since the store above: 32 loads = this wave's whole 32 KiB in
-        // flight at once); parts 1.. go through 16 temporaries at a time (all 32 at once would spill)
-#pragma unroll
-        for (int f = 0; f < 32; ++f)
-          acc[f >> 4][(f >> 3) & 1][(f >> 1) & 3][f & 1] = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(all + f * 256));
-        for (int part = 1; part < sk_split; ++part) {
+        // part 0 lands in the accumulators themselves (dead since the store above); parts 1.. go through 16 temporaries at a time.
+        // An asm statement = 16 loads + the wait for them: the compiler never sees a register with a load in flight.
+#define SK_LD16(R, SRC)                                                                                                       \
+        asm volatile("global_load_dwordx4 %0, %16, off sc1\n\tglobal_load_dwordx4 %1, %16, off offset:1024 sc1\n\t"         \
+                     "global_load_dwordx4 %2, %16, off offset:2048 sc1\n\tglobal_load_dwordx4 %3, %16, off offset:3072 sc1\n\t" \
+                     "global_load_dwordx4 %4, %17, off sc1\n\tglobal_load_dwordx4 %5, %17, off offset:1024 sc1\n\t"         \
+                     "global_load_dwordx4 %6, %17, off offset:2048 sc1\n\tglobal_load_dwordx4 %7, %17, off offset:3072 sc1\n\t" \
+                     "global_load_dwordx4 %8, %18, off sc1\n\tglobal_load_dwordx4 %9, %18, off offset:1024 sc1\n\t"         \
+                     "global_load_dwordx4 %10, %18, off offset:2048 sc1\n\tglobal_load_dwordx4 %11, %18, off offset:3072 sc1\n\t" \
+                     "global_load_dwordx4 %12, %19, off sc1\n\tglobal_load_dwordx4 %13, %19, off offset:1024 sc1\n\t"       \
+                     "global_load_dwordx4 %14, %19, off offset:2048 sc1\n\tglobal_load_dwordx4 %15, %19, off offset:3072 sc1\n\t" \
+                     "s_waitcnt vmcnt(0)"                                                                                     \
+                     : "=&v"(R[0]), "=&v"(R[1]), "=&v"(R[2]), "=&v"(R[3]), "=&v"(R[4]), "=&v"(R[5]), "=&v"(R[6]), "=&v"(R[7]),     \
+                       "=&v"(R[8]), "=&v"(R[9]), "=&v"(R[10]), "=&v"(R[11]), "=&v"(R[12]), "=&v"(R[13]), "=&v"(R[14]), "=&v"(R[15]) \
+                     : "v"((SRC)), "v"((SRC) + 1024), "v"((SRC) + 2048), "v"((SRC) + 3072) : "memory")
+        for (int part = 0; part < sk_split; ++part) {
           const float* const src = all + (int64_t)part * 65536;
 #pragma unroll
           for (int h = 0; h < 2; ++h) {
             f32x4 t[16];
+            SK_LD16(t, src + h * 4096);
 #pragma unroll
-            for (int f = 0; f < 16; ++f) t[f] = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(src + (16 * h + f) * 256));
-#pragma unroll
-            for (int f = 0; f < 16; ++f) acc[h][(f >> 3) & 1][(f >> 1) & 3][f & 1] += t[f];
-            __builtin_amdgcn_sched_barrier(0);
+            for (int f = 0; f < 16; ++f) {
+              f32x4& c = acc[h][(f >> 3) & 1][(f >> 1) & 3][f & 1];
+              c = part == 0 ? t[f] : c + t[f];
+            }
           }
         }
+#undef SK_LD16
       }
     }
 
@@ -817,11 +827,24 @@ static int num_cus() {
 }
 // how many K ranges the leftover tiles of a launch are cut into (0 / 1 = no stream-K tail): as many as fill the chip once,
 // each at least two K steps long (the stream's pipeline), at most MMRCA_SK_MAX (default 4: the unit that finishes a tile reads
-// all its partials, 256 KiB each, on ONE CU).  MMRCA_SK=0 turns the tail off.
+// all its partials, 256 KiB each, on ONE CU).  No workspace registered for the stream = no tail.
+static int g_sk_max = -1, g_sk_min_ksteps = -1;
+static void sk_config_init() {
+  if (g_sk_max < 0) g_sk_max = getenv("MMRCA_SK_MAX") ? atoi(getenv("MMRCA_SK_MAX")) : 4;
+  // (the partial tiles are 2 x 256 KiB of HBM traffic per unit whatever K is: below this many K steps the round-5 split -- whole
+  // rounds here, the rest on the 128x128 kernel -- is faster; tools/streamk_bench.py, profiles/r06_streamk_ab.txt)
+  if (g_sk_min_ksteps < 0) g_sk_min_ksteps = getenv("MMRCA_SK_MIN_KSTEPS") ? atoi(getenv("MMRCA_SK_MIN_KSTEPS")) : 24;
+}
+extern "C" int mmrca_gemm_streamk_config(int max_split, int min_ksteps) {
+  sk_config_init();
+  if (max_split >= 0) g_sk_max = max_split;
+  if (min_ksteps >= 0) g_sk_min_ksteps = min_ksteps;
+  return 0;
+}
 int mmrca_gemm256_streamk_split(int64_t M, int64_t N, int64_t ksteps, void* stream) {
-  static const int sk_enabled = getenv("MMRCA_SK") ? atoi(getenv("MMRCA_SK")) : 1;
-  static const int sk_max = getenv("MMRCA_SK_MAX") ? atoi(getenv("MMRCA_SK_MAX")) : 4;
-  if (!sk_enabled || !sk_workspace_of(stream)) return 0;
+  sk_config_init();
+  const int sk_max = g_sk_max;
+  if (ksteps < g_sk_min_ksteps || !sk_workspace_of(stream)) return 0;
   const int64_t tiles = ((M + 255) / 256) * (N / 256);
   const int ncu = num_cus();
   if (tiles < ncu) return 0;

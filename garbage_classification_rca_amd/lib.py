@@ -53,6 +53,7 @@ _SIGS = {
     "mmrca_gemm_rows": [_vp] * 7 + [_i64] * 8 + [_i32] * 5 + [_vp],
     "mmrca_gemm_splitk": [_vp] * 4 + [_i64] * 7 + [_i32] * 2 + [_vp],
     "mmrca_gemm_streamk_workspace": [_vp, _i64, _vp],
+    "mmrca_gemm_streamk_config": [_i32, _i32],
     "mmrca_gemm_x3": [_vp] * 10 + [_i64] * 6 + [_i32] * 5 + [_vp],
     "mmrca_gemm_splitk_x3": [_vp] * 6 + [_i64] * 7 + [_i32] * 2 + [_vp],
     "mmrca_split_f32": [_vp, _vp, _vp, _i64, _vp],
@@ -231,13 +232,14 @@ CONV_PROFILE = None     # bench.py sets this to a list: (kernel family, algorith
 
 
 _STREAMK_WS = {}       # (device index, stream) -> zero-filled workspace registered with mmrca_gemm_streamk_workspace
-STREAMK = os.environ.get("MMRCA_SK", "1") != "0"
+STREAMK = os.environ.get("MMRCA_SK", "0") != "0"     # opt-in: measured neutral in the step
 
 
-def streamk_workspace(M, N, device):
+def streamk_workspace(M, N, device, force=False):
     """The persistent 256x256 GEMM keeps the partial round of a launch inside the launch (stream-K tail, csrc/gemm256.hip) when the
-    stream it runs on has a workspace: one per (device, stream), allocated at the first product that has a full round of tiles."""
-    if not STREAMK or N % 256 or ((M + 255) // 256) * (N // 256) < 256:
+    stream it runs on has a workspace: one per (device, stream), allocated at the first product that has a full round of tiles.
+    Registering the workspace IS the switch: MMRCA_SK=1 (or force=True: tests, tools/streamk_bench.py) does it."""
+    if not (STREAMK or force) or N % 256 or ((M + 255) // 256) * (N // 256) < 256:
         return
     st = stream_ptr()
     key = (device.index if device.index is not None else torch.cuda.current_device(), st)

@@ -57,7 +57,8 @@ def test_mask_epoch_equals_a_seed_advanced_by_the_step_stride():
 
 
 @pytest.mark.parametrize("image_model,size,dtype", [("shuffle_net", 224, torch.bfloat16), ("transformer_B16", 224, torch.bfloat16),
-                                                   ("transformer_B16", 224, "bf16x3f"), ("eff_v2_medium", 128, torch.bfloat16)])
+                                                   ("transformer_B16", 224, "bf16x3f"), ("eff_v2_medium", 128, torch.bfloat16),
+                                                   ("eff_v2_medium", 128, "bf16x3f")])
 def test_graphed_step_computes_the_eager_step(image_model, size, dtype):
     """two models from the same seed, the same six batches: eager hip_train_step vs GraphedTrainStep (2 eager calls, 1 capture, 3
     replays).  Same losses step by step -- which requires every replay to draw the masks of ITS step (feature dropout 0.6: frozen

@@ -466,6 +466,19 @@ def test_gemm_splitk_is_bitwise_reproducible_and_matches_the_atomic_kernel():
 
 
 # ---- stream-K tail of the persistent 256x256 kernel (round 6): the leftover tiles' K loops run as ranges on every CU
+@pytest.fixture
+def streamk():
+    """register a stream-K workspace for the current stream (the library's opt-in, MMRCA_SK=1 in production) and remove it afterwards"""
+    L.streamk_workspace(65536, 256, torch.device("cuda", torch.cuda.current_device()), force=True)
+    _streamk_toggle(True)
+    L.load().mmrca_gemm_streamk_config(4, 4)          # (production: no tail below 24 K steps)
+    yield
+    L.load().mmrca_gemm_streamk_config(4, 24)
+    for (d, st), ws in list(L._STREAMK_WS.items()):
+        L._check(L.load().mmrca_gemm_streamk_workspace(None, ws.numel(), st), "streamk off")
+    L._STREAMK_WS.clear()
+
+
 def _streamk_ws_counters():
     key = (torch.cuda.current_device(), L.stream_ptr())
     ws = L._STREAMK_WS.get(key)
@@ -481,7 +494,7 @@ def _streamk_toggle(on):
 
 @pytest.mark.parametrize("shape", [(22272, 768, 256, 2), (25600, 768, 768, 4), (50432, 768, 768, 3), (32000, 2304, 512, 2), (25500, 768, 1024, 4)])
 @pytest.mark.parametrize("bl", [L.ROWK, L.KROW])
-def test_gemm_streamk_tail_matches_fp64_and_the_whole_tile_walk_and_is_bitwise_reproducible(shape, bl):
+def test_gemm_streamk_tail_matches_fp64_and_the_whole_tile_walk_and_is_bitwise_reproducible(shape, bl, streamk, monkeypatch):
     """M x N = whole rounds of 256 tiles + L leftover tiles whose K loops are cut into `split` ranges (22272 x 768: 261 tiles, L = 5;
     25600 x 768: 300, L = 44; 50432 x 768 = the ViT's out-projection at B = 256: 591, L = 79; 32000 x 2304: 1125, L = 101 -- two ranges per tile; 25500: a ragged last row tile inside a split tile)"""
     M, N, K, split = shape
@@ -519,7 +532,7 @@ def test_gemm_streamk_tail_matches_fp64_and_the_whole_tile_walk_and_is_bitwise_r
     assert rel_err(a, b) < 8e-3 and (a != b).float().mean().item() < 0.05
 
 
-def test_gemm_streamk_tail_under_every_epilogue_of_the_persistent_kernel():
+def test_gemm_streamk_tail_under_every_epilogue_of_the_persistent_kernel(streamk):
     """GELU + saved gelu', the gelu' factor with the bias-gradient column sums, a residual addend: the unit that finishes a split
     tile runs the same epilogue code on the summed partials (M = 25,600 = 100 row tiles x 3: 300 tiles, 44 of them split four ways)"""
     M, N, K = 25600, 768, 1024
@@ -550,7 +563,8 @@ def test_gemm_streamk_tail_under_every_epilogue_of_the_persistent_kernel():
     assert int(_streamk_ws_counters().abs().sum()) == 0
 
 
-def test_gemm_streamk_tail_on_a_side_stream_and_through_auto():
+def test_gemm_streamk_tail_on_a_side_stream_and_through_auto(streamk, monkeypatch):
+    monkeypatch.setattr(L, "STREAMK", True)
     """one workspace per stream (two streams run GEMMs concurrently in the engine); AUTO keeps the partial round inside the launch
     instead of handing it to the 128x128 kernel"""
     M, N, K = 50432, 768, 768
