@@ -479,6 +479,177 @@ mha_fwd_mfma_p_k(const bf16_t* __restrict__ qkv, bf16_t* __restrict__ out, float
 }
 
 // ------------------------------------------------------------------------------------------------------
+// bf16x3 forward, persistent over heads (round 6; unmasked, no dropout, padded layout, 193 <= S <= 224: the ViT's attention in the
+// bf16x3f mode).  mha_fwd_x3_k above is one workgroup per head and CU -- its four images (K_hi K_lo V_hi V_lo, 112 KiB at S = 197) leave
+// no room for a second workgroup or a second set of images -- so every head waits for its whole staging with nothing to overlap it:
+// ~20 us per head of which the matrix pipe is busy ~4.  Here a 16-wave workgroup (one query tile per wave) walks heads bh =
+// blockIdx.x, + gridDim.x, ... and the K and V image pairs TIME-SHARE the pipeline instead of being doubled: a head is two phases,
+//   A: S^T = K Q^T (three plane pairs) + softmax -- reads the K pair only, while the V pair of the SAME head lands by LDS-DMA;
+//   B: O^T = V^T P^T (three plane pairs)        -- reads the V pair only, while the K pair of the NEXT head lands,
+// each closed by vmcnt(0) + barrier (the pair just read is free, the pair just loaded is complete).  The next head's Q fragments
+// are loaded during phase B into the registers phase A has finished with.  All LDS reads are inline asm (see mha_fwd_mfma_p_k).
+// ------------------------------------------------------------------------------------------------------
+// stage_rows with the lane id passed in (an opaque copy: per-lane source offsets are then recomputed at every call instead of being
+// hoisted out of the head loop and spilled) and 32-bit element offsets from a wave-uniform base
+__device__ __forceinline__ void stage_rows_l(unsigned img_lds, int mode, const bf16_t* __restrict__ src, int ld, int S, int Spad, int wave, int lane, int nw) {
+  for (int j = wave; j < (Spad >> 3); j += nw) {
+    const int row = 8 * j + (lane >> 3), slot = lane & 7;
+    const int c = mode == IMG_ROW ? (slot ^ ((row >> 1) & 7)) : ((((slot >> 1) ^ ((row >> 1) & 3)) << 1) | (slot & 1));
+    const int r = row < S ? row : S - 1;
+    __builtin_amdgcn_global_load_lds((at_gbl_void*)(src + (unsigned)(r * ld + c * 8)), (at_lds_void*)(uintptr_t)(img_lds + j * 1024), 16, 0, 0);
+  }
+}
+
+template <int NKT, int NW>
+__global__ void __launch_bounds__(64 * NW)
+mha_fwd_x3_p_k(const bf16_t* __restrict__ qkv, const bf16_t* __restrict__ qkv_lo, bf16_t* __restrict__ out_hi, bf16_t* __restrict__ out_lo,
+               float* __restrict__ lse, int H, int S, float scale, int nbh) {
+  extern __shared__ __attribute__((aligned(16))) char sm[];
+  constexpr int Spad = NKT * 16, IMG = Spad * 128;        // images: K_hi | K_lo | V_hi | V_lo
+  const unsigned lds0 = (unsigned)(uintptr_t)(at_lds_void*)sm;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
+  const int ld = 3 * H * AT_DH;
+  const float c1 = scale * LOG2E;
+  const int nqt = (S + 15) / 16;
+  const int qt = wave;
+  const bool has_tile = qt < nqt;
+
+  int bh = blockIdx.x;
+  if (bh >= nbh) return;
+  auto head_base = [&](int bh_) { return (int64_t)(bh_ / H) * S * ld + (bh_ % H) * AT_DH; };       // wave-uniform
+  auto stage_k = [&](int bh_) {
+    int lo_ = lane; asm volatile("" : "+v"(lo_));
+    const int64_t o = head_base(bh_) + (int64_t)H * AT_DH;
+    stage_rows_l(lds0, IMG_ROW, qkv + o, ld, S, Spad, wave, lo_, NW);
+    stage_rows_l(lds0 + IMG, IMG_ROW, qkv_lo + o, ld, S, Spad, wave, lo_, NW);
+  };
+  auto stage_v = [&](int bh_) {
+    int lo_ = lane; asm volatile("" : "+v"(lo_));
+    const int64_t o = head_base(bh_) + 2 * (int64_t)H * AT_DH;
+    stage_rows_l(lds0 + 2 * IMG, IMG_TR, qkv + o, ld, S, Spad, wave, lo_, NW);
+    stage_rows_l(lds0 + 3 * IMG, IMG_TR, qkv_lo + o, ld, S, Spad, wave, lo_, NW);
+  };
+  bf16x8 qh0, qh1, ql0, ql1;
+  auto q_frags = [&](int bh_) {
+    int lo_ = lane; asm volatile("" : "+v"(lo_));
+    const int64_t o = head_base(bh_);
+    int r = qt * 16 + (lo_ & 15);
+    if (r > S - 1) r = S - 1;
+    const unsigned e = (unsigned)(r * ld + 8 * (lo_ >> 4));
+    qh0 = *reinterpret_cast<const bf16x8*>(qkv + o + e); qh1 = *reinterpret_cast<const bf16x8*>(qkv + o + e + 32);
+    ql0 = *reinterpret_cast<const bf16x8*>(qkv_lo + o + e); ql1 = *reinterpret_cast<const bf16x8*>(qkv_lo + o + e + 32);
+  };
+  stage_k(bh);
+  if (has_tile) q_frags(bh);
+  for (;;) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();                    // the K pair of head bh is complete; every wave has left the V pair of the previous head
+    stage_v(bh);                        // lands under phase A
+    const int nxt = bh + (int)gridDim.x;
+    f32x4 s[NKT];
+    float m = -INFINITY, l = 0.f;
+    if (has_tile) {
+      // ---- phase A: scores (the small terms first, as in mha_fwd_x3_k) and the softmax numerators
+      int lo_ = lane; asm volatile("" : "+v"(lo_));
+      const int g = lo_ >> 4, l16 = lo_ & 15;
+      const unsigned ksw = (l16 >> 1) & 7;
+      const unsigned kb0 = lds0 + l16 * 128 + (((unsigned)g ^ ksw) << 4), kb1 = lds0 + l16 * 128 + (((unsigned)(4 + g) ^ ksw) << 4);
+      static_for<0, NKT>([&](auto ic) {
+        constexpr int kt = decltype(ic)::value;
+        bf16x8 kh0, kh1, kl0, kl1;
+        AT_DS_B128_OFF(kh0, kb0, kt * 2048);
+        AT_DS_B128_OFF(kh1, kb1, kt * 2048);
+        AT_DS_B128_OFF(kl0, kb0, IMG + kt * 2048);
+        AT_DS_B128_OFF(kl1, kb1, IMG + kt * 2048);
+        asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(kh0), "+v"(kh1), "+v"(kl0), "+v"(kl1));
+        f32x4 a = {0.f, 0.f, 0.f, 0.f};
+        a = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kl0, qh0, a, 0, 0, 0);
+        a = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kl1, qh1, a, 0, 0, 0);
+        a = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kh0, ql0, a, 0, 0, 0);
+        a = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kh1, ql1, a, 0, 0, 0);
+        a = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kh0, qh0, a, 0, 0, 0);
+        a = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kh1, qh1, a, 0, 0, 0);
+        s[kt] = a;
+      });
+#pragma unroll
+      for (int kt = 0; kt < NKT; ++kt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          if (kt >= NKT - 2) s[kt][r] = kt * 16 + 4 * g + r < S ? s[kt][r] : -INFINITY;      // keys past the sequence end are dead
+          m = fmaxf(m, s[kt][r]);
+        }
+      m = colgroup_max(m);              // maximum of the RAW scores (c1 > 0); finite: there is no mask
+      const float mc = -m * c1;
+#pragma unroll
+      for (int kt = 0; kt < NKT; ++kt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) { const float e = __builtin_amdgcn_exp2f(fmaf(s[kt][r], c1, mc)); s[kt][r] = e; l += e; }
+      l = colgroup_sum(l);              // fp32 row sum (>= 1)
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();                    // the V pair of head bh is complete; every wave has left the K pair
+    if (nxt < nbh) stage_k(nxt);        // lands under phase B
+    if (has_tile) {
+      // ---- phase B: O^T = V^T P^T with P = P_hi + P_lo split in registers
+      int lo_ = lane; asm volatile("" : "+v"(lo_));
+      const int g = lo_ >> 4, l16 = lo_ & 15;
+      const int qq = l16 >> 2, pp = l16 & 3, vsw = (2 * g + (qq >> 1)) & 3;
+      const unsigned vimg = lds0 + 2 * IMG + (4 * g + qq) * 128 + 8 * pp;
+      f32x4 o[4];
+#pragma unroll
+      for (int dt = 0; dt < 4; ++dt) o[dt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+      static_for<0, NKT / 2>([&](auto ic) {
+        constexpr int u = decltype(ic)::value;
+        // the next head's Q fragments, into the registers phase A has finished with -- once half of the numerators are consumed
+        if constexpr (u == NKT / 4) { if (nxt < nbh) q_frags(nxt); }
+        const bf16x8 ph = pack_pair(s[2 * u], s[2 * u + 1]);
+        f32x4 ra, rb;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) { ra[r] = s[2 * u][r] - (float)ph[r]; rb[r] = s[2 * u + 1][r] - (float)ph[4 + r]; }
+        const bf16x8 pl = pack_pair(ra, rb);
+#pragma unroll
+        for (int d2 = 0; d2 < 4; d2 += 2) {          // two 16-column slabs of the head dim at a time (registers)
+          bf16x4 hl[2], hh[2], ll_[2], lh[2];
+#pragma unroll
+          for (int e = 0; e < 2; ++e) {
+            const unsigned vb = vimg + (((d2 + e) ^ vsw) << 5);
+            AT_DS_TR_OFF(hl[e], vb, u * 4096); AT_DS_TR_OFF(hh[e], vb, u * 4096 + 2048);
+            AT_DS_TR_OFF(ll_[e], vb, IMG + u * 4096); AT_DS_TR_OFF(lh[e], vb, IMG + u * 4096 + 2048);
+          }
+          asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(hl[0]), "+v"(hh[0]), "+v"(ll_[0]), "+v"(lh[0]), "+v"(hl[1]), "+v"(hh[1]), "+v"(ll_[1]), "+v"(lh[1]));
+#pragma unroll
+          for (int e = 0; e < 2; ++e) {
+            const bf16x8 vh = __builtin_shufflevector(hl[e], hh[e], 0, 1, 2, 3, 4, 5, 6, 7);
+            const bf16x8 vl = __builtin_shufflevector(ll_[e], lh[e], 0, 1, 2, 3, 4, 5, 6, 7);
+            o[d2 + e] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vl, ph, o[d2 + e], 0, 0, 0);
+            o[d2 + e] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vh, pl, o[d2 + e], 0, 0, 0);
+            o[d2 + e] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vh, ph, o[d2 + e], 0, 0, 0);   // O^T[d][q]
+          }
+        }
+      });
+      int lp_ = lane; asm volatile("" : "+v"(lp_));
+      const int gq = lp_ >> 4, q = qt * 16 + (lp_ & 15);
+      if (q < S) {
+        const float inv = 1.f / l;
+        const int64_t hb = (int64_t)(bh / H) * S * (H * AT_DH) + (bh % H) * AT_DH;          // wave-uniform
+        const unsigned off = (unsigned)(q * (H * AT_DH) + 4 * gq);
+#pragma unroll
+        for (int dt = 0; dt < 4; ++dt) {
+          bf16x4 vh, vl;
+#pragma unroll
+          for (int r = 0; r < 4; ++r) { const float v = o[dt][r] * inv; vh[r] = (bf16_t)v; vl[r] = (bf16_t)(v - (float)vh[r]); }
+          *reinterpret_cast<bf16x4*>(out_hi + hb + off + dt * 16) = vh;
+          *reinterpret_cast<bf16x4*>(out_lo + hb + off + dt * 16) = vl;
+        }
+        if (gq == 0) lse[(int64_t)bh * S + q] = m * c1 * LN2 + __logf(l);
+      }
+    }
+    if (nxt >= nbh) break;
+    bh = nxt;
+  }
+}
+
+// ------------------------------------------------------------------------------------------------------
 // backward, dQ: a wave owns 16 queries
 // ------------------------------------------------------------------------------------------------------
 template <int NKT, bool DROP, int NW>
@@ -1687,6 +1858,18 @@ int mmrca_mha_fwd_x3_launch(const void* qkv_hi, const void* qkv_lo, const int32_
   MMRCA_REQUIRE(mmrca_mha_x3_ok(S, dh), "mha_fwd_x3: needs head dim 64 and 1 <= S <= 224 (got S=%d dh=%d)", S, dh);
   MMRCA_REQUIRE(((((uintptr_t)qkv_hi) | ((uintptr_t)qkv_lo)) & 15) == 0 && ((((uintptr_t)out_hi) | ((uintptr_t)out_lo)) & 7) == 0, "mha_fwd_x3: alignment");
   const int nkt = pick_nkt(S);
+  static const int x3_persist = getenv("MMRCA_ATTN_X3_PERSIST") ? atoi(getenv("MMRCA_ATTN_X3_PERSIST")) : 1;
+  if (x3_persist && nkt == 14 && drop_p <= 0.f && !key_mask && !cu && S > 16 * 12) {     // the ViT's attention: 197 tokens, no mask
+    static int ncu = 0;
+    if (ncu == 0) { int d = 0; (void)hipGetDevice(&d); if (hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, d) != hipSuccess || ncu < 1) ncu = 256; }
+    const int ldsb = 4 * 14 * 16 * 128;
+    const int nbh = B * H, grid = nbh < ncu ? nbh : ncu;
+    MMRCA_MAX_LDS(ldsb, mha_fwd_x3_p_k<14, 16>);
+    hipLaunchKernelGGL((mha_fwd_x3_p_k<14, 16>), dim3(grid), dim3(1024), ldsb, st, (const bf16_t*)qkv_hi, (const bf16_t*)qkv_lo, (bf16_t*)out_hi,
+                       (bf16_t*)out_lo, lse, H, S, scale, nbh);
+    MMRCA_CHECK_LAUNCH("mha_fwd_x3(persistent)");
+    return 0;
+  }
 #define LX3(NKT_, DROP_, NW_)                                                                                                      \
   do {                                                                                                                             \
     const int ldsb = 4 * NKT_ * 16 * 128 + BIAS_EXTRA(NKT_);                                                                       \

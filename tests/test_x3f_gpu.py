@@ -114,6 +114,40 @@ def test_attention_forward_from_planes_equals_fp32_input(B, H, S, packed):
     assert float(out["planes"][0].abs().max()) == 0.0          # the fp32 context is optional and was not asked for
 
 
+@pytest.mark.parametrize("B,H,S", [(3, 12, 197), (24, 12, 197), (70, 12, 197), (30, 16, 224), (23, 12, 193)])
+def test_attention_forward_x3_persistent_form_for_the_vit(B, H, S):
+    """mha_fwd_x3_p_k (round 6): no mask, no dropout, padded layout, 193 <= S <= 224 -- a 16-wave workgroup per CU walks heads, the K and
+    V image pairs time-share the staging pipeline (36 heads: one per workgroup; 288 / 840 / 480 / 276: two to four per workgroup, a
+    ragged last round).  Against a float64 softmax(QK^T)V on the values the planes encode: context within 2e-5 of the largest entry,
+    log-sum-exp within 1e-5; and bit-identical when run again (no atomics, no order dependence)."""
+    dh = 64
+    D = H * dh
+    rows = B * S
+    g = torch.Generator(device="cuda").manual_seed(S + B)
+    hi, lo = _planes(torch.randn(rows, 3 * D, device="cuda", generator=g))
+    qkv = hi.float() + lo.float()
+
+    def run():
+        pl = (torch.zeros(rows, D, dtype=torch.bfloat16, device="cuda"), torch.zeros(rows, D, dtype=torch.bfloat16, device="cuda"))
+        lse = torch.zeros(B * H * S, device="cuda")
+        L.mha_fwd_x3((hi, lo), None, pl, lse, B, H, S, dh, dh ** -0.5)
+        return pl, lse
+    pl, lse = run()
+    got = pl[0].float() + pl[1].float()
+    x = qkv.double().view(B, S, 3, H, dh)
+    q, k, v = (x[:, :, i].transpose(1, 2) for i in range(3))
+    sc = (q @ k.transpose(2, 3)) * dh ** -0.5
+    ref = (torch.softmax(sc, -1) @ v).transpose(1, 2).reshape(rows, D).float()
+    lref = torch.logsumexp(sc, -1).reshape(-1).float()           # [B, H, S]
+    torch.cuda.synchronize()
+    e = float((got - ref).abs().max()) / float(ref.abs().max())
+    el = float((lse - lref).abs().max())
+    print(f"bf16x3 persistent attention forward B={B} H={H} S={S}: context error {e:.2e}, lse error {el:.2e}")
+    assert e < 2e-5 and el <= 1e-5 * max(1.0, float(lref.abs().max()))
+    pl2, lse2 = run()
+    assert torch.equal(pl2[0], pl[0]) and torch.equal(pl2[1], pl[1]) and torch.equal(lse2, lse)
+
+
 @pytest.mark.parametrize("B,H,S,packed,drop", [(3, 12, 197, False, 0.0), (5, 12, 64, True, 0.0), (2, 16, 128, False, 0.1), (4, 12, 64, False, 0.1),
                                                (2, 12, 224, False, 0.0), (3, 12, 17, True, 0.0)])
 def test_attention_forward_x3_on_the_bf16_matrix_cores_matches_the_fp32_kernels(B, H, S, packed, drop):

@@ -83,6 +83,11 @@ for name, m, n, k, al, bl, acc in SHAPES:
         Bt = B.t() if bl == 0 else B
         Cy = torch.empty(m, n, device=dev, dtype=torch.bfloat16)
         runs["hipblaslt"] = lambda At=At, Bt=Bt, Cy=Cy: torch.matmul(At, Bt, out=Cy)
+        if not acc:
+            bf = bias.float().bfloat16()
+            runs["hipblaslt+bias"] = lambda At=At, Bt=Bt, Cy=Cy, bf=bf: torch.addmm(bf, At, Bt, out=Cy)
+            if "gelu" in name:                 # the vendor's fused epilogue is the tanh approximation (not the erf GELU the reference computes)
+                runs["hipblaslt+bias+gelu(tanh)"] = lambda At=At, Bt=Bt, bf=bf: torch._addmm_activation(bf, At, Bt, use_gelu=True)
     best = {k2: 1e9 for k2 in runs}
     for k2, fn in runs.items():
         for _ in range(3):
