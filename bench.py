@@ -220,14 +220,16 @@ def compliant_leg(args, dev, parity, steps=12, warmup=3):
     g_ms = sum(p[2].elapsed_time(p[3]) for p in prof)
     x3_ms = sum(p[2].elapsed_time(p[3]) for p in prof if p[0] > 2.5 * p[4][0] * p[4][1] * p[4][2])
     traffic, traffic_src = None, "no PMC pass of this mode is committed"
-    pmc_json = os.path.join(ROOT, "profiles", "r05_pmc_hbm_traffic_bf16x3f.json")
-    if os.path.exists(pmc_json):
+    import glob as _glob
+    pmc_files = sorted(_glob.glob(os.path.join(ROOT, "profiles", "r[0-9][0-9]_pmc_hbm_traffic_bf16x3f.json")), reverse=True)     # newest round first
+    if pmc_files:
+        pmc_json, pmc_name = pmc_files[0], os.path.basename(pmc_files[0])
         with open(pmc_json) as fh:
             pj = json.load(fh)
         if pj.get("gemm_sources_sha256") == gemm_sources_sha256():
-            traffic, traffic_src = pj.get("gemm_hbm_bytes_per_launch_mean"), "profiles/r05_pmc_hbm_traffic_bf16x3f.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes, x2 gfx950 fetch correction; this build's GEMM sources)"
+            traffic, traffic_src = pj.get("gemm_hbm_bytes_per_launch_mean"), f"profiles/{pmc_name} (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes, x2 gfx950 fetch correction; this build's GEMM sources)"
         else:
-            traffic_src = "profiles/r05_pmc_hbm_traffic_bf16x3f.json is STALE (measured on other GEMM sources); not quoted"
+            traffic_src = f"profiles/{pmc_name} is STALE (measured on other GEMM sources); not quoted"
     roof = {"bound": "mfma", "achieved": round(g_exec / (g_ms * 1e-3) / 1e12, 2) if g_ms > 0 else 0.0, "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
             "frac": round(g_exec / (g_ms * 1e-3) / 1e12 / PEAK_BF16_TFLOPS, 4) if g_ms > 0 else 0.0,
             "fp32_equivalent_useful_TFLOPs": round(g_useful / (g_ms * 1e-3) / 1e12, 2) if g_ms > 0 else 0.0,
@@ -676,15 +678,16 @@ def main():
         # rocprofv3 --pmc passes over THIS command (tools/pmc_traffic.py) is quoted, next to the algorithmic bytes
         # (operands once + outputs once, from the launch shapes of this run)
         traffic, traffic_src = None, None
-        for pmc_name in ("r05_pmc_hbm_traffic.json", "r04_pmc_hbm_traffic.json", "r03_pmc_hbm_traffic.json", "r02_pmc_hbm_traffic.json", "r01_pmc_hbm_traffic.json"):
-            pmc_json = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", pmc_name)
+        import glob as _glob
+        for pmc_json in sorted(_glob.glob(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r[0-9][0-9]_pmc_hbm_traffic.json")), reverse=True):
+            pmc_name = os.path.basename(pmc_json)         # newest round first
             if os.path.exists(pmc_json):
                 with open(pmc_json) as fh:
                     pj = json.load(fh)
                 # the summary names the GEMM sources it was measured on (tools/pmc_traffic.py); a kernel edit since then makes it stale
                 if pj.get("gemm_sources_sha256") != gemm_sources_sha256():
                     traffic_src = (f"profiles/{pmc_name} is STALE (measured on other GEMM sources: {str(pj.get('gemm_sources_sha256'))[:12]} vs "
-                                   f"{gemm_sources_sha256()[:12]} now); not quoted -- re-run tools/r05_artifacts.sh")
+                                   f"{gemm_sources_sha256()[:12]} now); not quoted -- re-run tools/r06_artifacts.sh")
                     break
                 traffic = pj.get("gemm_hbm_bytes_per_launch_mean")
                 traffic_src = (f"profiles/{pmc_name} (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes, x2 gfx950 fetch correction; "
