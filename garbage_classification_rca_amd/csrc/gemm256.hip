@@ -930,6 +930,16 @@ bool mmrca_gemm256_x3_ok(int64_t M, int64_t N, int64_t K, int a_layout, int act,
   return act == MMRCA_ACT_NONE || act == MMRCA_ACT_GELU_SAVE_GRAD;
 }
 
+static bool x3_fused_on() {
+  static const int x3_fused = getenv("MMRCA_X3_FUSED") ? atoi(getenv("MMRCA_X3_FUSED")) : 1;
+  return x3_fused != 0;
+}
+// stream-K ranges per leftover tile of a bf16x3 launch (0 = none): only the fused four-plane form walks one K loop per tile
+int mmrca_gemm256_x3_streamk_split(int64_t M, int64_t N, int64_t K, int b_layout, bool has_a_lo, bool has_b_lo, void* stream) {
+  if (!(x3_fused_on() && b_layout != MMRCA_KROW && has_a_lo && has_b_lo && K % 32 == 0 && K >= 64)) return 0;
+  return mmrca_gemm256_streamk_split(M, N, K / 32, stream);
+}
+
 int mmrca_gemm256_x3(const void* A_hi, const void* A_lo, const void* B_hi, const void* B_lo, void* C, void* C_lo, const void* bias,
                      void* preact, int64_t M, int64_t N, int64_t K, int64_t lda, int64_t ldb, int64_t ldc, int b_layout, int act,
                      hipStream_t st, int pre16) {
@@ -937,8 +947,7 @@ int mmrca_gemm256_x3(const void* A_hi, const void* A_lo, const void* B_hi, const
   MMRCA_REQUIRE(M * lda * 2 < (1ll << 32) && (bk ? K * ldb : N * ldb) * 2 < (1ll << 32) && M * ldc * 4 < (1ll << 32),
                 "gemm_x3(mfma256): operands must be smaller than 4 GiB");
   // the fused four-plane form (gemm_p256_k<..., F4>): row-major B, all three plane pairs, K % 32 == 0 (MMRCA_X3_FUSED=0: the three-pass form)
-  static const int x3_fused = getenv("MMRCA_X3_FUSED") ? atoi(getenv("MMRCA_X3_FUSED")) : 1;
-  if (x3_fused && !bk && A_lo && B_lo && K % 32 == 0 && K >= 64) {
+  if (x3_fused_on() && !bk && A_lo && B_lo && K % 32 == 0 && K >= 64) {
 #define L256F(ACT_, PL_) launch_p256<false, false, ACT_, false, true, PL_, true>(A_hi, B_hi, C, bias, nullptr, preact, M, N, K, lda, ldb, ldc, nullptr, st, A_lo, B_lo, C_lo, 3, pre16)
     if (act == MMRCA_ACT_GELU_SAVE_GRAD) { if (C_lo) L256F(MMRCA_ACT_GELU_SAVE_GRAD, true); else L256F(MMRCA_ACT_GELU_SAVE_GRAD, false); }
     else { if (C_lo) L256F(MMRCA_ACT_NONE, true); else L256F(MMRCA_ACT_NONE, false); }

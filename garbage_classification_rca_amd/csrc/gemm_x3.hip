@@ -22,6 +22,7 @@ int mmrca_gemm256_x3(const void* A_hi, const void* A_lo, const void* B_hi, const
                      void* preact, int64_t M, int64_t N, int64_t K, int64_t lda, int64_t ldb, int64_t ldc, int b_layout, int act,
                      hipStream_t st, int pre16);
 
+int mmrca_gemm256_x3_streamk_split(int64_t M, int64_t N, int64_t K, int b_layout, bool has_a_lo, bool has_b_lo, void* stream);
 static bool al16(const void* p) { return (((uintptr_t)p) & 15) == 0; }
 static const int g_x3_tail_pct = getenv("MMRCA_AUTO256_TAIL_PCT") ? atoi(getenv("MMRCA_AUTO256_TAIL_PCT")) : 60;
 
@@ -66,7 +67,9 @@ extern "C" int mmrca_gemm_x3(const void* A_hi, const void* A_lo, const void* B_h
     const int64_t tm = M / 256, tn = N / 256, tiles = tm * tn;
     const int64_t rounds = tiles / ncu, rem = tiles - rounds * ncu;
     const int64_t m_split = rounds * ncu / tn;
-    if (rounds >= 1 && rem * 100 >= 25 * (int64_t)ncu && rem * 100 < (int64_t)g_x3_tail_pct * ncu && m_split >= 1 && m_split < tm) {
+    // (a stream-K workspace on this stream keeps the partial round inside the persistent launch: gemm256.hip, round 6)
+    const bool sk_tail = mmrca_gemm256_x3_streamk_split(M, N, K, b_layout, A_lo != nullptr, B_lo != nullptr, stream) >= 2;
+    if (!sk_tail && rounds >= 1 && rem * 100 >= 25 * (int64_t)ncu && rem * 100 < (int64_t)g_x3_tail_pct * ncu && m_split >= 1 && m_split < tm) {
       const int64_t M1 = m_split * 256;
       if (int rc = mmrca_gemm256_x3(A_hi, A_lo, B_hi, B_lo, C, C_lo, bias, preact, M1, N, K, lda, ldb, ldc, b_layout, act, st, pre16)) return rc;
       const int64_t csz = C_lo ? 2 : 4;

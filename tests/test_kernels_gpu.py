@@ -563,6 +563,42 @@ def test_gemm_streamk_tail_under_every_epilogue_of_the_persistent_kernel(streamk
     assert int(_streamk_ws_counters().abs().sum()) == 0
 
 
+@pytest.mark.parametrize("K,act", [(768, L.ACT_NONE), (3072, L.ACT_NONE), (768, L.ACT_GELU_SAVE_GRAD)])
+def test_gemm_streamk_tail_under_the_fused_bf16x3_form(K, act, streamk, monkeypatch):
+    """the three-pass product in its fused four-plane form (K steps of 32 of all four planes) with the leftover tiles' K loops cut into
+    ranges: fp32-accurate against float64 (1e-5 of the largest entry), bitwise reproducible, and within fp32 rounding of the whole-tile
+    walk; AUTO (mmrca_gemm_x3) keeps the partial round inside the launch when the stream has a workspace"""
+    monkeypatch.setattr(L, "STREAMK", True)
+    M, N = 50432, 768
+    g = torch.Generator(device="cuda").manual_seed(K)
+    X = torch.randn(M, K, device="cuda", generator=g) * 0.5
+    W = torch.randn(N, K, device="cuda", generator=g) * 0.05
+    bias = torch.randn(N, device="cuda", generator=g) * 0.2
+    pl = lambda t: (t.bfloat16(), (t - t.bfloat16().float()).bfloat16())
+    Xp, Wp = pl(X), pl(W)
+    Xv, Wv = Xp[0].double() + Xp[1].double(), Wp[0].double() + Wp[1].double()
+    h = Xv @ Wv.t() + bias.double()
+    ref = F.gelu(h) if act == L.ACT_GELU_SAVE_GRAD else h
+
+    def run():
+        Y = torch.empty(M, N, device="cuda")
+        P = torch.empty(M, N, device="cuda") if act == L.ACT_GELU_SAVE_GRAD else None
+        L.gemm_x3(Xp, Wp, Y, bias=bias, preact=P, M=M, N=N, K=K, lda=K, ldb=K, ldc=N, act=act)
+        return Y
+    a = run()
+    torch.cuda.synchronize()
+    assert int(_streamk_ws_counters().abs().sum()) == 0
+    assert rel_err(a, ref) < 1e-5
+    assert torch.equal(run(), a)
+    _streamk_toggle(False)
+    try:
+        b = run()
+    finally:
+        _streamk_toggle(True)
+    assert rel_err(b, ref) < 1e-5 and rel_err(a, b) < 2e-6
+    assert not torch.equal(a, b), "the two walks add in a different order: identical outputs would mean the tail did not run"
+
+
 def test_gemm_streamk_tail_on_a_side_stream_and_through_auto(streamk, monkeypatch):
     monkeypatch.setattr(L, "STREAMK", True)
     """one workspace per stream (two streams run GEMMs concurrently in the engine); AUTO keeps the partial round inside the launch
