@@ -1275,7 +1275,7 @@ int mmrca_gemm256(const void* A, const void* B, void* C, const void* bias, const
                   int64_t N, int64_t K, int64_t lda, int64_t ldb, int64_t ldc, int a_layout, int b_layout, int act,
                   float* colsum, hipStream_t st);
 
-int mmrca_gemm256_streamk_split(int64_t M, int64_t N, int64_t ksteps, void* stream);
+int mmrca_gemm256_streamk_split(int64_t M, int64_t N, int64_t ksteps, void* stream, bool x3);
 extern int g_mmrca_dbg;
 static const int g_mmrca_auto256_side = getenv("MMRCA_AUTO256_SIDE") ? atoi(getenv("MMRCA_AUTO256_SIDE")) : 0;
 static const bool g_mmrca_auto256_gelu = getenv("MMRCA_AUTO256_GELU") ? atoi(getenv("MMRCA_AUTO256_GELU")) != 0 : true;
@@ -1356,7 +1356,7 @@ static int gemm_dispatch(const void* A, const void* B, void* C, const void* bias
     // Round 6: with a stream-K workspace registered for the stream (mmrca_gemm_streamk_workspace) the partial round stays INSIDE
     // the persistent launch -- the leftover tiles' K loops are cut into ranges across all CUs (gemm256.hip) -- and the split below
     // is not taken.
-    const bool sk_tail = mmrca_gemm256_streamk_split(M, N, K / 64, stream) >= 2;
+    const bool sk_tail = mmrca_gemm256_streamk_split(M, N, K / 64, stream, false) >= 2;
     if (auto256 && !sk_tail && g_mmrca_auto256_tail > 0 && !colsum_fused && a_layout == MMRCA_ROWK) {
       int ncu = 256, devi = 0;
       (void)hipGetDevice(&devi);

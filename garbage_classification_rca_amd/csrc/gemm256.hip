@@ -828,23 +828,27 @@ static int num_cus() {
 // how many K ranges the leftover tiles of a launch are cut into (0 / 1 = no stream-K tail): as many as fill the chip once,
 // each at least two K steps long (the stream's pipeline), at most MMRCA_SK_MAX (default 4: the unit that finishes a tile reads
 // all its partials, 256 KiB each, on ONE CU).  No workspace registered for the stream = no tail.
-static int g_sk_max = -1, g_sk_min_ksteps = -1;
+static int g_sk_max = -1, g_sk_min_ksteps = -1, g_sk_bf16 = -1;
 static void sk_config_init() {
+  // plain bf16 products: measured neutral at K >= 1536 and slower below (profiles/r06_streamk_ab.txt) -> off unless asked for;
+  // the fused bf16x3 form does three times the matrix work per tile for the same partial-tile traffic: +1.3 % on the compliant step
+  if (g_sk_bf16 < 0) g_sk_bf16 = getenv("MMRCA_SK_BF16") ? atoi(getenv("MMRCA_SK_BF16")) : 0;
   if (g_sk_max < 0) g_sk_max = getenv("MMRCA_SK_MAX") ? atoi(getenv("MMRCA_SK_MAX")) : 4;
   // (the partial tiles are 2 x 256 KiB of HBM traffic per unit whatever K is: below this many K steps the round-5 split -- whole
   // rounds here, the rest on the 128x128 kernel -- is faster; tools/streamk_bench.py, profiles/r06_streamk_ab.txt)
   if (g_sk_min_ksteps < 0) g_sk_min_ksteps = getenv("MMRCA_SK_MIN_KSTEPS") ? atoi(getenv("MMRCA_SK_MIN_KSTEPS")) : 24;
 }
-extern "C" int mmrca_gemm_streamk_config(int max_split, int min_ksteps) {
+extern "C" int mmrca_gemm_streamk_config(int max_split, int min_ksteps, int bf16_products) {
   sk_config_init();
   if (max_split >= 0) g_sk_max = max_split;
   if (min_ksteps >= 0) g_sk_min_ksteps = min_ksteps;
+  if (bf16_products >= 0) g_sk_bf16 = bf16_products;
   return 0;
 }
-int mmrca_gemm256_streamk_split(int64_t M, int64_t N, int64_t ksteps, void* stream) {
+int mmrca_gemm256_streamk_split(int64_t M, int64_t N, int64_t ksteps, void* stream, bool x3) {
   sk_config_init();
   const int sk_max = g_sk_max;
-  if (ksteps < g_sk_min_ksteps || !sk_workspace_of(stream)) return 0;
+  if ((!x3 && !g_sk_bf16) || ksteps < g_sk_min_ksteps || !sk_workspace_of(stream)) return 0;
   const int64_t tiles = ((M + 255) / 256) * (N / 256);
   const int ncu = num_cus();
   if (tiles < ncu) return 0;
@@ -872,7 +876,7 @@ static void launch_p256(const void* A, const void* B, void* C, const void* bias,
   int sk_split = 0;
   char* sk_ws = nullptr;
   if constexpr (!X3 || F4) {
-    sk_split = mmrca_gemm256_streamk_split(M, N, K / (F4 ? 32 : 64), (void*)st);
+    sk_split = mmrca_gemm256_streamk_split(M, N, K / (F4 ? 32 : 64), (void*)st, X3);
     if (sk_split >= 2) sk_ws = sk_workspace_of((void*)st);
     if (!sk_ws) sk_split = 0;
   }
@@ -937,7 +941,7 @@ static bool x3_fused_on() {
 // stream-K ranges per leftover tile of a bf16x3 launch (0 = none): only the fused four-plane form walks one K loop per tile
 int mmrca_gemm256_x3_streamk_split(int64_t M, int64_t N, int64_t K, int b_layout, bool has_a_lo, bool has_b_lo, void* stream) {
   if (!(x3_fused_on() && b_layout != MMRCA_KROW && has_a_lo && has_b_lo && K % 32 == 0 && K >= 64)) return 0;
-  return mmrca_gemm256_streamk_split(M, N, K / 32, stream);
+  return mmrca_gemm256_streamk_split(M, N, K / 32, stream, true);
 }
 
 int mmrca_gemm256_x3(const void* A_hi, const void* A_lo, const void* B_hi, const void* B_lo, void* C, void* C_lo, const void* bias,

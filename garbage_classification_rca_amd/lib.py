@@ -53,7 +53,7 @@ _SIGS = {
     "mmrca_gemm_rows": [_vp] * 7 + [_i64] * 8 + [_i32] * 5 + [_vp],
     "mmrca_gemm_splitk": [_vp] * 4 + [_i64] * 7 + [_i32] * 2 + [_vp],
     "mmrca_gemm_streamk_workspace": [_vp, _i64, _vp],
-    "mmrca_gemm_streamk_config": [_i32, _i32],
+    "mmrca_gemm_streamk_config": [_i32, _i32, _i32],
     "mmrca_gemm_x3": [_vp] * 10 + [_i64] * 6 + [_i32] * 5 + [_vp],
     "mmrca_gemm_splitk_x3": [_vp] * 6 + [_i64] * 7 + [_i32] * 2 + [_vp],
     "mmrca_split_f32": [_vp, _vp, _vp, _i64, _vp],
@@ -232,13 +232,14 @@ CONV_PROFILE = None     # bench.py sets this to a list: (kernel family, algorith
 
 
 _STREAMK_WS = {}       # (device index, stream) -> zero-filled workspace registered with mmrca_gemm_streamk_workspace
-STREAMK = os.environ.get("MMRCA_SK", "0") != "0"     # opt-in: measured neutral in the step
+STREAMK = os.environ.get("MMRCA_SK", "1") != "0"     # the library applies it to the fused bf16x3 products only ...
+STREAMK_BF16 = os.environ.get("MMRCA_SK_BF16", "0") == "1"   # ... unless this asks for the plain bf16 products too (measured neutral)
 
 
 def streamk_workspace(M, N, device, force=False):
     """The persistent 256x256 GEMM keeps the partial round of a launch inside the launch (stream-K tail, csrc/gemm256.hip) when the
     stream it runs on has a workspace: one per (device, stream), allocated at the first product that has a full round of tiles.
-    Registering the workspace IS the switch: MMRCA_SK=1 (or force=True: tests, tools/streamk_bench.py) does it."""
+    Without a workspace there is no tail: MMRCA_SK=0 stops the registration (force=True: tests, tools/streamk_bench.py)."""
     if not (STREAMK or force) or N % 256 or ((M + 255) // 256) * (N // 256) < 256:
         return
     st = stream_ptr()
@@ -261,7 +262,7 @@ def gemm(A, B, Cout, *, bias=None, addend=None, preact=None, M, N, K, lda, ldb, 
     rows_readable = (rows of A, rows of the side operand) that exist in memory: required for impl=IMPL_MFMA256 with a ragged M
     (mmrca_gemm_rows; the 256x256 kernel reads whole 256-row tiles)"""
     _dev(A, "gemm A")
-    if dtype == BF16 and not accum:
+    if STREAMK_BF16 and dtype == BF16 and not accum:
         streamk_workspace(M, N, A.device)
     if rows_readable is not None:
         if accum:

@@ -127,13 +127,15 @@ int mmrca_gemm_rows(const void* A, const void* B, void* C, const void* bias, con
  *   workspace: caller-owned device memory, >= mmrca_gemm_streamk_workspace_bytes() bytes (4 KiB of counters + 256 partial tiles),
  *   16-byte aligned, ZERO-FILLED by the caller once (every launch leaves the counters at zero again); one per stream that issues
  *   GEMMs concurrently with another; it must outlive every launch (and captured graph) made on that stream.  workspace == NULL
- *   removes the stream's entry.  Registering a workspace IS the switch (the Python host does it under MMRCA_SK=1; measured
- *   neutral on the configs[1] step, DESIGN.md K2 round 6, so it is opt-in).
- * mmrca_gemm_streamk_config: at most `max_split` ranges per tile (default 4, MMRCA_SK_MAX) and no tail below `min_ksteps` K steps
- *   of 64 (default 24, MMRCA_SK_MIN_KSTEPS: the partial tiles cost 2 x 256 KiB of traffic per range whatever K is); < 0 = keep. */
+ *   removes the stream's entry.  Without a workspace there is no tail (the Python host registers one per stream; MMRCA_SK=0 stops it).
+ * mmrca_gemm_streamk_config: at most `max_split` ranges per tile (default 4, MMRCA_SK_MAX); no tail below `min_ksteps` K steps
+ *   (of 64 columns; of 32 in the fused bf16x3 form; default 24, MMRCA_SK_MIN_KSTEPS: the partial tiles cost 2 x 256 KiB of traffic
+ *   per range whatever K is); bf16_products: 1 = also for plain bf16 products (default 0, MMRCA_SK_BF16: measured neutral at
+ *   K >= 1536 and slower below, profiles/r06_streamk_ab.txt -- the fused bf16x3 products, three times the matrix work per tile,
+ *   gain: +1.3 % on the bf16x3f step).  An argument < 0 keeps the current value. */
 int64_t mmrca_gemm_streamk_workspace_bytes(void);
 int mmrca_gemm_streamk_workspace(void* workspace, int64_t bytes, void* stream);
-int mmrca_gemm_streamk_config(int max_split, int min_ksteps);
+int mmrca_gemm_streamk_config(int max_split, int min_ksteps, int bf16_products);
 
 /* Weight gradient on 256x256 tiles with the contraction split over workgroups: C[M,N] (fp32) += A (.) B over K
  * (torch autograd of nn.Linear: dW = dY^T X; same call sites as mmrca_gemm's accumulate mode).  bf16 operands, either

@@ -13,7 +13,7 @@ SHAPES = [("fwd out", 768, 768, L.ROWK, None), ("fwd ffn2", 768, 3072, L.ROWK, N
           ("dgrad qkv", 768, 2304, L.KROW, None), ("dgrad ffn1", 768, 3072, L.KROW, None),
           ("fwd qkv (9.2 rounds)", 2304, 768, L.ROWK, None), ("fwd ffn1 gelu (9.2 rounds)", 3072, 768, L.ROWK, L.ACT_GELU_SAVE_GRAD)]
 L.load()
-L.load().mmrca_gemm_streamk_config(int(os.environ.get("MMRCA_SK_MAX", "4")), 0)      # every K: the A/B is the point
+L.load().mmrca_gemm_streamk_config(int(os.environ.get("MMRCA_SK_MAX", "4")), 0, 1)      # every K: the A/B is the point
 res = {}
 for name, N, K, bl, act in SHAPES:
     As = [torch.randn(M, K, device="cuda").bfloat16() for _ in range(4)]
