@@ -851,7 +851,8 @@ int mmrca_gemm256_streamk_split(int64_t M, int64_t N, int64_t ksteps, void* stre
   if ((!x3 && !g_sk_bf16) || ksteps < g_sk_min_ksteps || !sk_workspace_of(stream)) return 0;
   const int64_t tiles = ((M + 255) / 256) * (N / 256);
   const int ncu = num_cus();
-  if (tiles < ncu) return 0;
+  if (tiles < ncu) return 0;             // (fewer tiles than CUs, ranges over the whole chip: measured slower than the 128x128 kernels,
+                                         //  profiles/r06_text_gemm_shapes.txt)
   const int64_t left = tiles % ncu;
   if (left == 0) return 0;
   int64_t split = ncu / left;
