@@ -790,7 +790,7 @@ static int g_p256_skew = -1;      // x 10 ns between the four start groups (MMRC
 // ---- stream-K tail workspaces: caller-owned, one per stream that launches GEMMs (mmrca_gemm_streamk_workspace, include/mmrca.h)
 #define SK_COUNTER_BYTES 4096          // 1,024 tile counters (at most 255 are used), zero between launches
 #define SK_MAX_UNITS 256               // one unit per CU at most
-struct SkWorkspace { void* stream; char* base; int64_t bytes; };
+struct SkWorkspace { int device; void* stream; char* base; int64_t bytes; };      // keyed on (device, stream): stream 0 exists on every device
 static SkWorkspace g_sk_ws[32];
 static int g_sk_ws_n = 0;
 static std::mutex g_sk_mutex;
@@ -798,22 +798,27 @@ extern "C" int64_t mmrca_gemm_streamk_workspace_bytes(void) { return SK_COUNTER_
 extern "C" int mmrca_gemm_streamk_workspace(void* workspace, int64_t bytes, void* stream) {
   MMRCA_REQUIRE(workspace == nullptr || (bytes >= mmrca_gemm_streamk_workspace_bytes() && (((uintptr_t)workspace) & 15) == 0),
                 "gemm_streamk_workspace: needs %lld bytes, 16-byte aligned, zero-filled", (long long)mmrca_gemm_streamk_workspace_bytes());
+  int dev = 0;
+  (void)hipGetDevice(&dev);            // the workspace belongs to the CURRENT device (the caller's, as for every launch)
   std::lock_guard<std::mutex> lock(g_sk_mutex);
   for (int i = 0; i < g_sk_ws_n; ++i)
-    if (g_sk_ws[i].stream == stream) {
+    if (g_sk_ws[i].stream == stream && g_sk_ws[i].device == dev) {
       if (workspace) { g_sk_ws[i].base = (char*)workspace; g_sk_ws[i].bytes = bytes; }
       else g_sk_ws[i] = g_sk_ws[--g_sk_ws_n];
       return 0;
     }
   if (!workspace) return 0;
-  MMRCA_REQUIRE(g_sk_ws_n < 32, "gemm_streamk_workspace: more than 32 streams registered");
-  g_sk_ws[g_sk_ws_n++] = SkWorkspace{stream, (char*)workspace, bytes};
+  MMRCA_REQUIRE(g_sk_ws_n < 32, "gemm_streamk_workspace: more than 32 (device, stream) pairs registered");
+  g_sk_ws[g_sk_ws_n++] = SkWorkspace{dev, stream, (char*)workspace, bytes};
   return 0;
 }
 static char* sk_workspace_of(void* stream) {
+  if (g_sk_ws_n == 0) return nullptr;   // (unlocked fast path: nothing was ever registered)
+  int dev = 0;
+  (void)hipGetDevice(&dev);
   std::lock_guard<std::mutex> lock(g_sk_mutex);
   for (int i = 0; i < g_sk_ws_n; ++i)
-    if (g_sk_ws[i].stream == stream) return g_sk_ws[i].base;
+    if (g_sk_ws[i].stream == stream && g_sk_ws[i].device == dev) return g_sk_ws[i].base;
   return nullptr;
 }
 static int num_cus() {

@@ -246,6 +246,8 @@ def streamk_workspace(M, N, device, force=False):
     key = (device.index if device.index is not None else torch.cuda.current_device(), st)
     if key in _STREAMK_WS:
         return
+    if not force and torch.cuda.is_current_stream_capturing():
+        return      # a capture stream meets its first large product: no allocation / fill inside the capture -- it keeps the two-launch split
     need = int(load().mmrca_gemm_streamk_workspace_bytes())
     ws = torch.zeros(need, dtype=torch.uint8, device=device)
     _check(load().mmrca_gemm_streamk_workspace(ptr(ws), need, st), "mmrca_gemm_streamk_workspace")

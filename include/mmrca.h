@@ -125,7 +125,8 @@ int mmrca_gemm_rows(const void* A, const void* B, void* C, const void* bias, con
  * its fp32 partial tile in the workspace and the workgroup that arrives last at the tile's counter adds the partials in the fixed
  * order 0, 1, ... (bitwise reproducible) and runs the epilogue.  No workgroup waits for another.
  *   workspace: caller-owned device memory, >= mmrca_gemm_streamk_workspace_bytes() bytes (4 KiB of counters + 256 partial tiles),
- *   16-byte aligned, ZERO-FILLED by the caller once (every launch leaves the counters at zero again); one per stream that issues
+ *   on the CURRENT device, 16-byte aligned, ZERO-FILLED by the caller once (every launch leaves the counters at zero again); one
+ *   per (device, stream) that issues
  *   GEMMs concurrently with another; it must outlive every launch (and captured graph) made on that stream.  workspace == NULL
  *   removes the stream's entry.  Without a workspace there is no tail (the Python host registers one per stream; MMRCA_SK=0 stops it).
  * mmrca_gemm_streamk_config: at most `max_split` ranges per tile (default 4, MMRCA_SK_MAX); no tail below `min_ksteps` K steps
