@@ -539,35 +539,12 @@ mha_fwd_x3_p_k(const bf16_t* __restrict__ qkv, const bf16_t* __restrict__ qkv_lo
     qh0 = *reinterpret_cast<const bf16x8*>(qkv + o + e); qh1 = *reinterpret_cast<const bf16x8*>(qkv + o + e + 32);
     ql0 = *reinterpret_cast<const bf16x8*>(qkv_lo + o + e); ql1 = *reinterpret_cast<const bf16x8*>(qkv_lo + o + e + 32);
   };
-  // The context of a head is STORED at the top of the next head's phase A (after that phase's DMA is issued): stored right where it
-  // is computed, the vmcnt(0) in front of the next barrier waits ~1-2 us per head for the stores to retire with nothing running.
-  f32x4 po[4];
-  float p_inv = 0.f, p_lse = 0.f;
-  int p_bh = -1;
-  auto write_context = [&]() {
-    int lp_ = lane; asm volatile("" : "+v"(lp_));
-    const int gq = lp_ >> 4, q = qt * 16 + (lp_ & 15);
-    if (q < S) {
-      const int64_t hb = (int64_t)(p_bh / H) * S * (H * AT_DH) + (p_bh % H) * AT_DH;          // wave-uniform
-      const unsigned off = (unsigned)(q * (H * AT_DH) + 4 * gq);
-#pragma unroll
-      for (int dt = 0; dt < 4; ++dt) {
-        bf16x4 vh, vl;
-#pragma unroll
-        for (int r = 0; r < 4; ++r) { const float v = po[dt][r] * p_inv; vh[r] = (bf16_t)v; vl[r] = (bf16_t)(v - (float)vh[r]); }
-        *reinterpret_cast<bf16x4*>(out_hi + hb + off + dt * 16) = vh;
-        *reinterpret_cast<bf16x4*>(out_lo + hb + off + dt * 16) = vl;
-      }
-      if (gq == 0) lse[(int64_t)p_bh * S + q] = p_lse;
-    }
-  };
   stage_k(bh);
   if (has_tile) q_frags(bh);
   for (;;) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();                    // the K pair of head bh is complete; every wave has left the V pair of the previous head
     stage_v(bh);                        // lands under phase A
-    if (has_tile && p_bh >= 0) write_context();      // the previous head's context: retires under phase A
     const int nxt = bh + (int)gridDim.x;
     f32x4 s[NKT];
     float m = -INFINITY, l = 0.f;
@@ -650,14 +627,26 @@ mha_fwd_x3_p_k(const bf16_t* __restrict__ qkv, const bf16_t* __restrict__ qkv_lo
           }
         }
       });
+      int lp_ = lane; asm volatile("" : "+v"(lp_));
+      const int gq = lp_ >> 4, q = qt * 16 + (lp_ & 15);
+      if (q < S) {
+        const float inv = 1.f / l;
+        const int64_t hb = (int64_t)(bh / H) * S * (H * AT_DH) + (bh % H) * AT_DH;          // wave-uniform
+        const unsigned off = (unsigned)(q * (H * AT_DH) + 4 * gq);
 #pragma unroll
-      for (int dt = 0; dt < 4; ++dt) po[dt] = o[dt];
-      p_inv = 1.f / l; p_lse = m * c1 * LN2 + __logf(l); p_bh = bh;
+        for (int dt = 0; dt < 4; ++dt) {
+          bf16x4 vh, vl;
+#pragma unroll
+          for (int r = 0; r < 4; ++r) { const float v = o[dt][r] * inv; vh[r] = (bf16_t)v; vl[r] = (bf16_t)(v - (float)vh[r]); }
+          *reinterpret_cast<bf16x4*>(out_hi + hb + off + dt * 16) = vh;
+          *reinterpret_cast<bf16x4*>(out_lo + hb + off + dt * 16) = vl;
+        }
+        if (gq == 0) lse[(int64_t)bh * S + q] = m * c1 * LN2 + __logf(l);
+      }
     }
     if (nxt >= nbh) break;
     bh = nxt;
   }
-  if (has_tile && p_bh >= 0) write_context();
 }
 
 // ------------------------------------------------------------------------------------------------------
