@@ -925,7 +925,13 @@ static void launch_mfma32(const void* A, const void* B, void* C, const void* bia
 // (A_lo, B_hi), (A_hi, B_lo); lo x lo is below fp32 resolution -- into the same fp32 accumulators, and the epilogue's
 // bias / side operands / outputs are fp32 (biasv / addendv / preactv / Cv point at floats), or, with C_lo given, the output is
 // written as two bf16 planes (Cv = hi plane) for a consumer that is another X3 GEMM.
-template <bool A_KROW, bool B_KROW, bool ATOMIC_F32, int WPE, bool X3 = false, bool BNS = false>
+// F4 (X3, all three plane pairs, round 6): the FUSED form, as in gemm_p256_k<..., F4>.  The plain X3 loop above walks the contraction three
+// times -- (A_hi, B_hi), (A_lo, B_hi), (A_hi, B_lo) -- staging A_hi and B_hi twice: 6 x 16 KiB of LDS-DMA and three barrier pairs per 64
+// columns of K.  Here a K step is 32 columns of ALL FOUR planes (4 x 8 KiB = the same 32 KiB, the 32-deep images of gemm_mfma_k32) and the
+// three products are formed from them: 4 x 16 KiB staged and two barrier pairs per 64 columns for the same 96 MFMAs per wave.  This is the
+// kernel of every bf16x3 product the persistent kernel does not take: the text encoder's ragged-M shapes, the BLIP-2 towers' N = 1,408 /
+// 4,224 / 6,144 products (configs[4] in its compliant mode).
+template <bool A_KROW, bool B_KROW, bool ATOMIC_F32, int WPE, bool X3 = false, bool BNS = false, bool F4 = false>
 __global__ void __launch_bounds__(256, WPE)
 gemm_mfma_k1s(const bf16_t* __restrict__ A, const bf16_t* __restrict__ B, void* __restrict__ Cv, const bf16_t* __restrict__ bias,
               const bf16_t* __restrict__ addend, bf16_t* __restrict__ preact, int64_t M, int64_t N, int64_t K,
@@ -956,6 +962,37 @@ gemm_mfma_k1s(const bf16_t* __restrict__ A, const bf16_t* __restrict__ B, void* 
   for (int i = 0; i < 4; ++i)
 #pragma unroll
     for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  if constexpr (F4) {
+    static_assert(X3 && !ATOMIC_F32, "the fused four-plane form is a bf16x3 product with an epilogue");
+    const int nt32 = (int)((kend - kbeg) / 32);
+    for (int t = 0; t < nt32; ++t) {
+      const int64_t k0 = kbeg + (int64_t)t * 32;
+      stage_tile32<A_KROW>(A, lda, m_blk, M, k0, smem, wave, lane);
+      stage_tile32<A_KROW>(A_lo, lda, m_blk, M, k0, smem + TILE32_BYTES, wave, lane);
+      stage_tile32<B_KROW>(B, ldb, n_blk, N, k0, smem + 2 * TILE32_BYTES, wave, lane);
+      stage_tile32<B_KROW>(B_lo, ldb, n_blk, N, k0, smem + 3 * TILE32_BYTES, wave, lane);
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __syncthreads();
+      bf16x8 ah[4], al[4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        ah[i] = load_frag32<A_KROW>(smem, wr * 64 + i * 16, lane);
+        al[i] = load_frag32<A_KROW>(smem + TILE32_BYTES, wr * 64 + i * 16, lane);
+      }
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const bf16x8 bh = load_frag32<B_KROW>(smem + 2 * TILE32_BYTES, wc * 64 + j * 16, lane);
+        const bf16x8 bl = load_frag32<B_KROW>(smem + 3 * TILE32_BYTES, wc * 64 + j * 16, lane);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {       // the small terms first
+          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bh, al[i], acc[i][j], 0, 0, 0);
+          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bl, ah[i], acc[i][j], 0, 0, 0);
+          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bh, ah[i], acc[i][j], 0, 0, 0);
+        }
+      }
+      __syncthreads();
+    }
+  } else
   for (int tt = 0; tt < (X3 ? nseg : 1) * nt; ++tt) {      // bf16x3: nseg of the plane pairs (A,B), (A_lo,B), (A,B_lo)
     // single LDS stage: load -> wait -> barrier -> 32 MFMAs -> barrier; the load latency of this block is covered by the
     // other three or four blocks resident on the CU (32 KiB of LDS each) instead of by software prefetch
@@ -1225,13 +1262,13 @@ gemm_mfma_k1s(const bf16_t* __restrict__ A, const bf16_t* __restrict__ B, void* 
   }
 }
 
-template <bool AK, bool BK2, bool AT, int WPE, bool X3 = false, bool BNS = false>
+template <bool AK, bool BK2, bool AT, int WPE, bool X3 = false, bool BNS = false, bool F4 = false>
 static void launch_mfma1s(const void* A, const void* B, void* C, const void* bias, const void* addend, void* preact,
                           int64_t M, int64_t N, int64_t K, int64_t lda, int64_t ldb, int64_t ldc, int act, int tiles_m,
                           int tiles_n, int ksplits, int64_t ksplit_len, float* colsum, hipStream_t st,
                           const void* A_lo = nullptr, const void* B_lo = nullptr, void* C_lo = nullptr, int nseg = 3,
                           BnStat bst = BnStat{nullptr, nullptr, nullptr}, int pre16 = 0) {
-  hipLaunchKernelGGL((gemm_mfma_k1s<AK, BK2, AT, WPE, X3, BNS>), dim3(tiles_m * tiles_n, ksplits), dim3(256), 2 * TILE_BYTES, st,
+  hipLaunchKernelGGL((gemm_mfma_k1s<AK, BK2, AT, WPE, X3, BNS, F4>), dim3(tiles_m * tiles_n, ksplits), dim3(256), 2 * TILE_BYTES, st,
                      (const bf16_t*)A, (const bf16_t*)B, C, (const bf16_t*)bias, (const bf16_t*)addend, (bf16_t*)preact,
                      M, N, K, lda, ldb, ldc, act, tiles_m, tiles_n, ksplit_len, colsum, (const bf16_t*)A_lo, (const bf16_t*)B_lo,
                      (bf16_t*)C_lo, nseg, bst, pre16);
@@ -1254,6 +1291,18 @@ int mmrca_gemm_k1s_x3(const void* A_hi, const void* A_lo, const void* B_hi, cons
     ksplits = (int)((ksteps + steps_per - 1) / steps_per);
   }
   const bool ak = a_layout == MMRCA_KROW, bk = b_layout == MMRCA_KROW, at = accum != 0;
+  // the fused four-plane form: all three plane pairs, an epilogue (no accumulate mode), K % 32 == 0 (MMRCA_X3_FUSED_K1S=0: the three-pass loop)
+  static const int fused_k1s = getenv("MMRCA_X3_FUSED_K1S") ? atoi(getenv("MMRCA_X3_FUSED_K1S")) : 1;
+  if (fused_k1s && A_lo && B_lo && !at && K % 32 == 0) {
+#define L1SF(AK_, BK_) launch_mfma1s<AK_, BK_, false, 4, true, false, true>(A_hi, B_hi, C, bias, addend, preact, M, N, K, lda, ldb, ldc, act, tiles_m, tiles_n, 1, K, colsum, st, A_lo, B_lo, C_lo, 3, BnStat{nullptr, nullptr, nullptr}, pre16)
+    if (!ak && !bk) L1SF(false, false);
+    else if (!ak && bk) L1SF(false, true);
+    else if (ak && !bk) L1SF(true, false);
+    else L1SF(true, true);
+#undef L1SF
+    MMRCA_CHECK_LAUNCH("gemm_x3(k1s,fused)");
+    return 0;
+  }
 #define L1SX(AK_, BK_, AT_) launch_mfma1s<AK_, BK_, AT_, 4, true>(A_hi, B_hi, C, bias, addend, preact, M, N, K, lda, ldb, ldc, act, tiles_m, tiles_n, ksplits, ksplit_len, colsum, st, A_lo, B_lo, C_lo, A_lo ? (B_lo ? 3 : 2) : 1, BnStat{nullptr, nullptr, nullptr}, pre16)
   if (!ak && !bk && !at) L1SX(false, false, false);
   else if (!ak && bk && !at) L1SX(false, true, false);
