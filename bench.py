@@ -445,7 +445,17 @@ def launch_ranks(n: int, cmd=None) -> int:
     procs = []
     for r in range(n):
         env = dict(base, RANK=str(r), LOCAL_RANK=str(r))
-        procs.append(subprocess.Popen(cmd, env=env, stdout=None if r == 0 else subprocess.DEVNULL))      # rank 0 inherits our stdout
+        procs.append(subprocess.Popen(cmd, env=env, stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL, text=(r == 0)))
+    # rank 0's stdout is relayed: the JSON line to our stdout, anything else a library printed there (gloo's "[Gloo] Rank 0 is
+    # connected ...") to stderr -- the contract is ONE line on stdout
+    import threading
+
+    def relay(pipe):
+        for line in pipe:
+            (sys.stdout if line.lstrip().startswith("{") else sys.stderr).write(line)
+            sys.stdout.flush()
+    relay_thread = threading.Thread(target=relay, args=(procs[0].stdout,), daemon=True)
+    relay_thread.start()
     rc, alive = 0, set(range(n))
     while alive:
         for r in sorted(alive):
@@ -459,6 +469,7 @@ def launch_ranks(n: int, cmd=None) -> int:
                 for o in alive:
                     procs[o].terminate()
         time.sleep(0.05)
+    relay_thread.join(timeout=10)
     return rc
 
 
