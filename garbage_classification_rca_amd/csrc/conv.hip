@@ -2225,6 +2225,30 @@ extern "C" int mmrca_bias_act_bwd(const void* dy, const void* x, const void* bia
 // ---------------------------------------------------------------------------------------------------------------------
 // (every loop below keeps several independent 8 / 16-byte loads in flight and reduces across lanes at most a few times per wave:
 // the first version -- a wave_sum per output and one dependent load per iteration -- ran the chain in ~150 us per block)
+// Warm-up of the two weight matrices (round 6).  The fused squeeze-excitation MLP is a chain of dependent phases on ~0.1-1.2 MB of weights
+// that nothing has touched since the previous step: in the step it ran at 52 us per launch against 19 us with the weights in L2
+// (tools/se_bench.py) -- four or five cold HBM round trips in a row.  Every thread therefore touches its share of the cache lines of W1
+// and W2 (one 4-byte load per 128-byte line, up to 1 MiB / 768 KiB per matrix) before the first phase: ONE round trip brings both matrices
+// into L2, and the values are only summed at the very end, so nothing waits for them.
+template <int NT, int KW>
+__device__ __forceinline__ void se_warm(const void* W1, const void* W2, size_t bytes, float (&wv)[2 * KW]) {
+  const char* a = reinterpret_cast<const char*>(W1);
+  const char* b = reinterpret_cast<const char*>(W2);
+#pragma unroll
+  for (int k = 0; k < KW; ++k) {
+    const size_t off = ((size_t)k * NT + threadIdx.x) * 128;
+    wv[k] = off + 4 <= bytes ? *reinterpret_cast<const float*>(a + off) : 0.f;
+    wv[KW + k] = off + 4 <= bytes ? *reinterpret_cast<const float*>(b + off) : 0.f;
+  }
+}
+template <int N2>
+__device__ __forceinline__ bool se_warm_done(const float (&wv)[N2]) {
+  float t = 0.f;
+#pragma unroll
+  for (int k = 0; k < N2; ++k) t += wv[k];
+  return t == 1.2345678e-37f;          // (never: keeps the loads alive without a store)
+}
+
 template <typename T, int NW>
 __global__ void __launch_bounds__(64 * NW)
 se_mlp_fwd_k(const T* __restrict__ pooled, const T* __restrict__ W1, const T* __restrict__ b1, const T* __restrict__ W2,
@@ -2234,6 +2258,8 @@ se_mlp_fwd_k(const T* __restrict__ pooled, const T* __restrict__ W1, const T* __
   float* hf = se_sm + c;
   const int b = blockIdx.x, wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   constexpr int NT = 64 * NW;        // sixteen waves per sample: B <= 128 workgroups run side by side, so the launch lasts as long as ONE does
+  float wv[16];
+  se_warm<NT, 8>(W1, W2, (size_t)c * sq * sizeof(T), wv);
   for (int i = threadIdx.x * 4; i < c; i += 4 * NT) {
     const Vec4<T> v = Vec4<T>::load(pooled + (int64_t)b * c + i);
 #pragma unroll
@@ -2293,6 +2319,7 @@ se_mlp_fwd_k(const T* __restrict__ pooled, const T* __restrict__ W1, const T* __
       s[(int64_t)b * c + i1] = from_f<T>(act_f(to_f(sp) + to_f(b2[i1]), CONV_ACT_SIGMOID));
     }
   }
+  if (se_warm_done(wv)) hf[0] = 0.f;
 }
 
 // backward chain of one sample: ds -> ds_pre (x sigmoid') -> dh = ds_pre . W2 -> dh_pre (x silu') -> dpool = dh_pre . W1; the bias
@@ -2308,6 +2335,9 @@ se_mlp_bwd_k(const T* __restrict__ ds, const T* __restrict__ s_pre, const T* __r
   float* part = se_sm + c;
   float* dhp = part + NW * sq;
   const int b = blockIdx.x, wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  constexpr int KW = NT >= 1024 ? 8 : 24;      // 8 x 1,024 or 24 x 256 lines of 128 bytes per matrix
+  float wv[2 * KW];
+  se_warm<NT, KW>(W2, W1, (size_t)c * sq * sizeof(T), wv);
   for (int i = threadIdx.x; i < c; i += NT) {
     const float g = to_f(ds[(int64_t)b * c + i]) * act_grad_f(to_f(s_pre[(int64_t)b * c + i]) + to_f(b2[i]), CONV_ACT_SIGMOID);
     const T gt = from_f<T>(g);
@@ -2371,6 +2401,7 @@ se_mlp_bwd_k(const T* __restrict__ ds, const T* __restrict__ s_pre, const T* __r
     for (int k = 0; k < 4; ++k) o.v[k] = a[k];
     o.store(dpool + (int64_t)b * c + i);
   }
+  if (se_warm_done(wv)) dhp[0] = 0.f;
 }
 
 // gW2[i][j] += sum_b ds_pre[b][i] h[b][j]   (blocks [0, n2));   gW1[j][i] += sum_b dh_pre[b][j] pooled[b][i]   (the rest)
