@@ -2252,14 +2252,14 @@ __device__ __forceinline__ bool se_warm_done(const float (&wv)[N2]) {
 template <typename T, int NW>
 __global__ void __launch_bounds__(64 * NW)
 se_mlp_fwd_k(const T* __restrict__ pooled, const T* __restrict__ W1, const T* __restrict__ b1, const T* __restrict__ W2,
-             const T* __restrict__ b2, T* __restrict__ h_pre, T* __restrict__ h, T* __restrict__ s_pre, T* __restrict__ s, int c, int sq) {
+             const T* __restrict__ b2, T* __restrict__ h_pre, T* __restrict__ h, T* __restrict__ s_pre, T* __restrict__ s, int c, int sq, int warm) {
   extern __shared__ __attribute__((aligned(16))) float se_sm[];              // pooled [c] | h [sq]
   float* pf = se_sm;
   float* hf = se_sm + c;
   const int b = blockIdx.x, wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   constexpr int NT = 64 * NW;        // sixteen waves per sample: B <= 128 workgroups run side by side, so the launch lasts as long as ONE does
   float wv[16];
-  se_warm<NT, 8>(W1, W2, (size_t)c * sq * sizeof(T), wv);
+  se_warm<NT, 8>(W1, W2, warm ? (size_t)c * sq * sizeof(T) : 0, wv);
   for (int i = threadIdx.x * 4; i < c; i += 4 * NT) {
     const Vec4<T> v = Vec4<T>::load(pooled + (int64_t)b * c + i);
 #pragma unroll
@@ -2328,7 +2328,7 @@ template <typename T, int NW>
 __global__ void __launch_bounds__(64 * NW)
 se_mlp_bwd_k(const T* __restrict__ ds, const T* __restrict__ s_pre, const T* __restrict__ h_pre, const T* __restrict__ W1,
              const T* __restrict__ b1, const T* __restrict__ W2, const T* __restrict__ b2, T* __restrict__ ds_pre, T* __restrict__ dh_pre,
-             T* __restrict__ dpool, float* __restrict__ gb1, float* __restrict__ gb2, int c, int sq) {
+             T* __restrict__ dpool, float* __restrict__ gb1, float* __restrict__ gb2, int c, int sq, int warm) {
   extern __shared__ __attribute__((aligned(16))) float se_sm[];              // ds_pre [c] | partial dh [NW][sq] | dh_pre [sq]
   constexpr int NT = 64 * NW;
   float* dsp = se_sm;
@@ -2337,7 +2337,7 @@ se_mlp_bwd_k(const T* __restrict__ ds, const T* __restrict__ s_pre, const T* __r
   const int b = blockIdx.x, wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   constexpr int KW = NT >= 1024 ? 8 : 24;      // 8 x 1,024 or 24 x 256 lines of 128 bytes per matrix
   float wv[2 * KW];
-  se_warm<NT, KW>(W2, W1, (size_t)c * sq * sizeof(T), wv);
+  se_warm<NT, KW>(W2, W1, warm ? (size_t)c * sq * sizeof(T) : 0, wv);
   for (int i = threadIdx.x; i < c; i += NT) {
     const float g = to_f(ds[(int64_t)b * c + i]) * act_grad_f(to_f(s_pre[(int64_t)b * c + i]) + to_f(b2[i]), CONV_ACT_SIGMOID);
     const T gt = from_f<T>(g);
@@ -2429,6 +2429,7 @@ se_mlp_wgrad_k(const T* __restrict__ ds_pre, const T* __restrict__ h, const T* _
   }
 }
 
+static const int g_se_warm = getenv("MMRCA_SE_WARM") ? atoi(getenv("MMRCA_SE_WARM")) : 1;
 extern "C" int mmrca_se_mlp_fwd(const void* pooled, const void* w1, const void* b1, const void* w2, const void* b2, void* h_pre, void* h,
                                 void* s_pre, void* s, int B, int c, int sq, int dtype, void* stream) {
   MMRCA_REQUIRE(pooled && w1 && b1 && w2 && b2 && h_pre && h && s_pre && s, "se_mlp_fwd: null pointer");
@@ -2444,7 +2445,7 @@ extern "C" int mmrca_se_mlp_fwd(const void* pooled, const void* w1, const void* 
   const size_t lds = (size_t)(c + sq) * sizeof(float);
   MMRCA_DISPATCH_DTYPE(dtype, "se_mlp_fwd",
     hipLaunchKernelGGL((se_mlp_fwd_k<T, 16>), dim3(B), dim3(1024), lds, (hipStream_t)stream, (const T*)pooled, (const T*)w1, (const T*)b1, (const T*)w2,
-                       (const T*)b2, (T*)h_pre, (T*)h, (T*)s_pre, (T*)s, c, sq);)
+                       (const T*)b2, (T*)h_pre, (T*)h, (T*)s_pre, (T*)s, c, sq, g_se_warm);)
   MMRCA_CHECK_LAUNCH("se_mlp_fwd");
   return 0;
 }
@@ -2468,7 +2469,7 @@ extern "C" int mmrca_se_mlp_bwd(const void* ds, const void* pooled, const void* 
   MMRCA_DISPATCH_DTYPE(dtype, "se_mlp_bwd",
     // (four waves per sample here: with sixteen the 32-value butterflies of the dh stage outweigh the shorter row walk -- measured)
     hipLaunchKernelGGL((se_mlp_bwd_k<T, 4>), dim3(B), dim3(256), lds, (hipStream_t)stream, (const T*)ds, (const T*)s_pre, (const T*)h_pre,
-                       (const T*)w1, (const T*)b1, (const T*)w2, (const T*)b2, (T*)ds_pre, (T*)dh_pre, (T*)dpool, gb1, gb2, c, sq);
+                       (const T*)w1, (const T*)b1, (const T*)w2, (const T*)b2, (T*)ds_pre, (T*)dh_pre, (T*)dpool, gb1, gb2, c, sq, g_se_warm);
     hipLaunchKernelGGL(se_mlp_wgrad_k<T>, dim3(2 * nb), dim3(256), 0, (hipStream_t)stream, (const T*)ds_pre, (const T*)h, (const T*)dh_pre,
                        (const T*)pooled, gw1, gw2, B, c, sq, nb);)
   MMRCA_CHECK_LAUNCH("se_mlp_bwd");
