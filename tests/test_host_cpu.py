@@ -320,7 +320,9 @@ def _ddp_worker(rank, world, port, q):
     sync.span_ready(32, 40)
     sync.span_ready(0, 32, flush=True)
     sync.finish()
-    q.put((r, flat.clone(), len(sync.pending), sync.bytes_reduced))
+    # (plain numpy through the queue: a torch tensor travels as a file descriptor the parent must fetch from THIS process while it is
+    # still alive -- a race that showed up as ConnectionResetError in the parent)
+    q.put((r, flat.float().numpy().copy(), len(sync.pending), sync.bytes_reduced))
     dist.barrier()
     dist.destroy_process_group()
 
@@ -410,6 +412,7 @@ def test_gradient_sync_world2_equals_full_batch_gradient():
     Wp = W.clone().requires_grad_(True)
     torch.nn.functional.cross_entropy(X @ Wp.t(), Y).backward()        # gradient of the mean loss over the global batch
     for r, flat, pending, nbytes in res:
+        flat = torch.from_numpy(flat)
         assert torch.allclose(flat[8:32], Wp.grad.flatten(), atol=1e-6)
         assert torch.allclose(flat[40:44], torch.full((4,), 1.5))
         assert pending == 0 and nbytes == 64 * 4
@@ -560,7 +563,7 @@ def _ddp_worker2(rank, world, port, q):
         for lo, hi in ((80, 96), (64, 80), (32, 48), (48, 64), (16, 32), (0, 16)):
             sync.span_ready(lo, hi, flush=(lo in (48, 0)))
         sync.finish()
-        out["bf16" if wire else "fp32"] = (flat.clone(), sync.bytes_reduced)
+        out["bf16" if wire else "fp32"] = (flat.float().numpy().copy(), sync.bytes_reduced)      # numpy: see _ddp_worker
     # evaluation counts: 10 samples over 2 ranks of 5, then 7 samples over 2 ranks (rank 1 draws one wrapped duplicate)
     s = D.ShardedSampler(7, rank, world, shuffle=False)
     out["num_real"] = (len(s), s.num_real, D.all_reduce_counts(s.num_real, s.num_real, "cpu"))
@@ -575,9 +578,9 @@ def test_gradient_sync_two_producers_accumulation_and_bf16_wire_world2():
     want = torch.full((96,), (11.0 + 22.0) / 2)            # mean over the two ranks of the ACCUMULATED gradient
     for r in (0, 1):
         flat, nbytes = res[r]["fp32"]
-        assert torch.equal(flat, want) and nbytes == 96 * 4
+        assert torch.equal(torch.from_numpy(flat), want) and nbytes == 96 * 4
         flat16, nbytes16 = res[r]["bf16"]
-        assert torch.allclose(flat16, want, rtol=1e-2) and nbytes16 == 96 * 2      # half the bytes on the wire
+        assert torch.allclose(torch.from_numpy(flat16), want, rtol=1e-2) and nbytes16 == 96 * 2      # half the bytes on the wire
     assert res[0]["num_real"][:2] == (4, 4) and res[1]["num_real"][:2] == (4, 3)
     assert res[0]["num_real"][2] == (7, 7) and res[0]["seed"] == res[1]["seed"]
 
