@@ -588,7 +588,8 @@ def test_gemm_streamk_tail_under_the_fused_bf16x3_form(K, act, streamk, monkeypa
     a = run()
     torch.cuda.synchronize()
     assert int(_streamk_ws_counters().abs().sum()) == 0
-    assert rel_err(a, ref) < 1e-5
+    print(f"fused bf16x3 product with a stream-K tail, K={K} act={act}: {rel_err(a, ref):.2e} of the largest entry from float64")
+    assert rel_err(a, ref) < 2e-5        # (observed 3.0e-6 at K = 3072; a bf16 product sits at ~3e-3)
     assert torch.equal(run(), a)
     _streamk_toggle(False)
     try:
@@ -597,7 +598,7 @@ def test_gemm_streamk_tail_under_the_fused_bf16x3_form(K, act, streamk, monkeypa
         _streamk_toggle(True)
     # the two walks add the same fp32 terms in a different order: observed 2.2e-6 of the largest entry at K = 3072 (each is within
     # 3e-6 of float64); bound = 4x that
-    assert rel_err(b, ref) < 1e-5 and rel_err(a, b) < 1e-5
+    assert rel_err(b, ref) < 2e-5 and rel_err(a, b) < 1e-5
     assert not torch.equal(a, b), "the two walks add in a different order: identical outputs would mean the tail did not run"
 
 
