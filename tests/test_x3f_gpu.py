@@ -118,8 +118,8 @@ def test_attention_forward_from_planes_equals_fp32_input(B, H, S, packed):
 def test_attention_forward_x3_persistent_form_for_the_vit(B, H, S):
     """mha_fwd_x3_p_k (round 6): no mask, no dropout, padded layout, 193 <= S <= 224 -- a 16-wave workgroup per CU walks heads, the K and
     V image pairs time-share the staging pipeline (36 heads: one per workgroup; 288 / 840 / 480 / 276: two to four per workgroup, a
-    ragged last round).  Against a float64 softmax(QK^T)V on the values the planes encode: context within 2e-5 of the largest entry,
-    log-sum-exp within 1e-5; and bit-identical when run again (no atomics, no order dependence)."""
+    ragged last round).  Against a float64 softmax(QK^T)V on the values the planes encode: context within 3e-5 of the largest entry (4x the
+    worst observed), log-sum-exp within 1e-5 relative; and bit-identical when run again (no atomics, no order dependence)."""
     dh = 64
     D = H * dh
     rows = B * S
@@ -143,7 +143,8 @@ def test_attention_forward_x3_persistent_form_for_the_vit(B, H, S):
     e = float((got - ref).abs().max()) / float(ref.abs().max())
     el = float((lse - lref).abs().max())
     print(f"bf16x3 persistent attention forward B={B} H={H} S={S}: context error {e:.2e}, lse error {el:.2e}")
-    assert e < 2e-5 and el <= 1e-5 * max(1.0, float(lref.abs().max()))
+    # observed over the five shapes: context 5.0e-6 .. 7.2e-6, log-sum-exp 1.9e-6 .. 4.3e-6 (seeded inputs, no atomics: repeatable)
+    assert e < 3e-5 and el <= 1e-5 * max(1.0, float(lref.abs().max()))
     pl2, lse2 = run()
     assert torch.equal(pl2[0], pl[0]) and torch.equal(pl2[1], pl[1]) and torch.equal(lse2, lse)
 
