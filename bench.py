@@ -562,7 +562,11 @@ def main():
 
     pack_in_loop = os.environ.get("MMRCA_BENCH_PACK_IN_LOOP", "1") == "1" and PACK_TEXT
 
-    use_graph = args.graph == "on" or (args.graph == "auto" and B <= 16 and world == 1 and args.dtype in ("bf16", "bf16x3f"))
+    # auto = main_both.py's rule (--hip_graph auto): one GPU, batch <= 16 and images up to 224 x 224 -- where the step is launch-bound.  The
+    # reference's own launch shape (EfficientNetV2-M @ 480, B = 16) is NOT: a replay runs it at the eager step's speed (488 vs 492
+    # samples/s), and eager it can put its weight gradients on a side stream (509; conv_engine.SIDE_WGRAD) -- `--graph on` still captures it
+    use_graph = args.graph == "on" or (args.graph == "auto" and B <= 16 and world == 1 and args.dtype in ("bf16", "bf16x3f")
+                                       and B * args.image_size * args.image_size <= 16 * 224 * 224)
     graphed = None
     if use_graph:
         from garbage_classification_rca_amd.training import GraphedTrainStep

@@ -16,6 +16,7 @@ No torch autograd: forward() saves what backward() needs, backward() accumulates
 """
 from __future__ import annotations
 
+import contextlib
 from typing import Dict, List, Optional, Tuple
 
 import torch
@@ -48,6 +49,14 @@ SE_FUSE_MAX = int(os.environ.get("MMRCA_CONV_SE_FUSE_MAX", "160000"))   # c * sq
 SE_FUSE_MAX_FWD = int(os.environ.get("MMRCA_CONV_SE_FUSE_MAX_FWD", "300000"))   # ... and the forward (sixteen waves per sample)
 FUSE_RES = os.environ.get("MMRCA_CONV_FUSE_RES", "1") == "1"       # residual connection inside the block's last BatchNorm pass
 IGEMM_DGRAD = os.environ.get("MMRCA_CONV_IGEMM_DGRAD", "1") == "1"
+# Weight gradients of the 1x1 and the implicit-GEMM 3x3 convolutions on a SIDE stream, concurrent with the input-gradient chain they are
+# not part of (see ConvEncoder._wgrad_stream): "1" always, "0" never, "auto" (default) everywhere but inside a HIP-graph capture --
+# measured (EfficientNetV2-M @ 480, bf16x3f, same box): eager B = 64 901.8 -> 927.6 samples/s; the captured B = 16 step 490.9 -> 460-470
+# (every fork / join becomes a cross-branch edge of the graph, ~110 per step).  MMRCA_CONV_SIDE_MAXROWS: only layers with at most that
+# many output rows (B * Ho * Wo).
+SIDE_WGRAD = os.environ.get("MMRCA_CONV_SIDE_WGRAD", "auto")
+SIDE_WGRAD = {"0": False, "1": True}.get(SIDE_WGRAD, "auto")
+SIDE_MAXROWS = int(os.environ.get("MMRCA_CONV_SIDE_MAXROWS", str(1 << 40)))
 
 ROWPAD = 256
 
@@ -116,6 +125,8 @@ class ConvEncoder:
         self.saved = None
         self._sd_p = None
         self._bn_arena, self._bn_off, self._bn_used, self._bn_bwd_seen = None, {}, 0, set()
+        self._side, self._side_busy = None, False     # the weight gradients' stream (SIDE_WGRAD), created at the first backward on a GPU
+        self._dz_readers: Dict[Tuple, "torch.cuda.Event"] = {}      # dz buffer -> the side-stream launch that read it last
         self.injected_keep = None             # tests: [n_sd_blocks, B] 0/1 keep masks instead of drawing them
         self.n_train_forwards = 0             # = every BatchNorm's num_batches_tracked (written out by sync_buffers())
 
@@ -409,6 +420,41 @@ class ConvEncoder:
             L.bn_act_fwd(z, mean, rstd, self.W(u.bn_key + ".weight"), self.W(u.bn_key + ".bias"), y, rows, u.cout, u.act, dt)
         return y, Ho, Wo, dict(x=x, z=z, mean=mean, rstd=rstd, H=H, W=Wd, Ho=Ho, Wo=Wo, train=train, fused_res=fused_res, ld_x=(ld_in or u.cin))
 
+    # ------------------------------------------------------------------ weight gradients beside the input-gradient chain
+    # A layer's weight gradient reads dz and the saved input and feeds nothing but the optimizer: with SIDE_WGRAD it is launched on a
+    # second stream behind the BatchNorm backward that wrote dz, and the chain (input gradient, next layer's BatchNorm backward, ...)
+    # goes on beside it.  dz buffers are per (block parity, unit, shape): the next WRITER of one (two blocks further down) waits for the
+    # event of its last side-stream reader; the saved inputs live until the next forward.  backward() joins the streams before every
+    # hand-over to the gradient exchange and at its end, so nothing outside this class sees the second stream.  Inside a HIP-graph
+    # capture the fork / join events become graph edges: the replayed step has the same two branches.
+    def _side_on(self, rows: int) -> bool:
+        if not SIDE_WGRAD or rows > SIDE_MAXROWS or torch.device(self.o.device).type != "cuda":
+            return False
+        if SIDE_WGRAD == "auto" and torch.cuda.is_current_stream_capturing():
+            return False
+        if self._side is None:
+            self._side = torch.cuda.Stream(device=self.o.device)
+        return True
+
+    @contextlib.contextmanager
+    def _wgrad_stream(self, dz_key, rows: int):
+        if not self._side_on(rows):
+            yield
+            return
+        self._side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(self._side):
+            yield
+            ev = torch.cuda.Event()
+            ev.record(self._side)
+        self._dz_readers[dz_key] = ev
+        self._side_busy = True
+
+    def _side_join(self):
+        if self._side_busy:
+            torch.cuda.current_stream().wait_stream(self._side)
+            self._dz_readers.clear()
+            self._side_busy = False
+
     def _unit_bwd(self, u: _Unit, dy, sv, B, need_dx=True, tag="g", sums_ready=False, dx_into=None):
         """dy: gradient at the unit's output rows; returns dx rows (or None).  sums_ready: the BatchNorm-backward sums of this unit are
         already in the shared scratch (the squeeze-excitation backward accumulated them while it wrote dy)."""
@@ -416,6 +462,10 @@ class ConvEncoder:
         H, Wd, Ho, Wo = sv["H"], sv["W"], sv["Ho"], sv["Wo"]
         rows = B * Ho * Wo
         dz = self.buf(f"{tag}.dz.{u.cout}", rows, u.cout)
+        dz_key = (f"{tag}.dz.{u.cout}", rows, u.cout)
+        last_reader = self._dz_readers.pop(dz_key, None)
+        if last_reader is not None:                  # a weight gradient on the side stream may still be reading this buffer
+            torch.cuda.current_stream().wait_event(last_reader)
         scratch = self._bn_slices(u)[1] if sums_ready else self._bn_scratch(u)      # this layer's backward sums (clear since forward(), or filled by se_dx)
         L.bn_act_bwd(dy, sv["z"], sv["mean"], sv["rstd"], self.W(u.bn_key + ".weight"), self.W(u.bn_key + ".bias"), dz,
                      self.G(u.bn_key + ".weight"), self.G(u.bn_key + ".bias"), scratch, rows, u.cout, u.act, sv["train"], dt,
@@ -427,8 +477,9 @@ class ConvEncoder:
         if u.dw:
             L.dwconv3x3_bwd(dz, sv["x"], w, dx, gw, B, H, Wd, u.cin, u.stride, dt, ws=self.buf("tmp.dw.ws", 1, 16 << 20, torch.float32))
         elif u.k == 1:
-            L.gemm(dz, sv["x"], gw, M=u.cout, N=u.cin, K=rows_k, lda=u.cout, ldb=sv.get("ld_x", u.cin), ldc=u.cin, a_layout=L.KROW, b_layout=L.KROW,
-                   accum=True, dtype=dt, impl=self.o.gemm_impl)
+            with self._wgrad_stream(dz_key, rows):
+                L.gemm(dz, sv["x"], gw, M=u.cout, N=u.cin, K=rows_k, lda=u.cout, ldb=sv.get("ld_x", u.cin), ldc=u.cin, a_layout=L.KROW,
+                       b_layout=L.KROW, accum=True, dtype=dt, impl=self.o.gemm_impl)
             if need_dx:
                 ldc = u.cin
                 if dx_into is not None:          # (view of a wider row buffer, its row pitch): the input gradient lands in its column window
@@ -437,10 +488,11 @@ class ConvEncoder:
                        impl=self.o.gemm_impl)
         elif self._igemm(u):
             K = 9 * u.cin
-            gwt = self.buf(f"g.wtap.{u.cout}.{K}", u.cout, K, torch.float32)[: u.cout]
-            gwt.zero_()
-            L.conv3x3_wgrad(dz, sv["x"], gwt, B, H, Wd, u.cin, u.cout, dt)
-            gw.view(u.cout, u.cin, 9).add_(gwt.view(u.cout, 9, u.cin).transpose(1, 2))
+            with self._wgrad_stream(dz_key, rows):           # (its scratch is the side stream's own when the stream is in use)
+                gwt = self.buf(("gs" if self._side_on(rows) else "g") + f".wtap.{u.cout}.{K}", u.cout, K, torch.float32)[: u.cout]
+                gwt.zero_()
+                L.conv3x3_wgrad(dz, sv["x"], gwt, B, H, Wd, u.cin, u.cout, dt)
+                gw.view(u.cout, u.cin, 9).add_(gwt.view(u.cout, 9, u.cin).transpose(1, 2))
             if need_dx:
                 if self._igemm_dgrad(u):
                     # dx = conv3x3(dz, w'), w'[ci, tap', co] = w[co, ci, 8 - tap']
@@ -679,7 +731,12 @@ class ConvEncoder:
         dx = self._unit_bwd(self.final, dy, sv["final"], B)
         # the gradients of a stage are final once its first block's backward is queued: hand them to the data-parallel exchange
         # stage by stage (engine._ready -> GradSync.span_ready), so that it overlaps the backward of the stages below
-        ready = getattr(self.o, "_ready", None) or (lambda group: None)      # (a bare owner in the kernel tests has no exchange)
+        ready_ = getattr(self.o, "_ready", None)                             # (a bare owner in the kernel tests has no exchange)
+
+        def ready(group):
+            if ready_ is not None:
+                self._side_join()           # the stage's weight gradients on the side stream are part of what is handed over
+                ready_(group)
         ready("image_stage_" + ("conv5" if self.name == "shuffle_net" else "final_conv"))
         for bi in reversed(range(len(self.blocks))):
             blk, bs = self.blocks[bi], sv["blocks"][bi]
@@ -741,3 +798,4 @@ class ConvEncoder:
             L.maxpool3x3s2_bwd(dx, p["arg"], d, B, p["H"], p["W"], c0, dt)
             dx = d
         self._unit_bwd(self.stem, dx, sv["stem"], B, need_dx=False)
+        self._side_join()

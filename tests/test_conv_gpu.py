@@ -710,3 +710,42 @@ def test_backbone_bf16_tap_major_equals_channel_major_forward_and_backward():
     print("smallest cosine between the two 3x3 weight gradients:", cos)
     assert cos > 0.998          # (0.9990-0.9997 on im2row + GEMM for both; 0.9990 since the default path is the implicit GEMM, whose
                                 # input gradient is a different kernel with a different rounding point)
+
+
+@pytest.mark.parametrize("maxrows", [1 << 40, 200])
+def test_weight_gradients_on_the_side_stream_equal_the_one_stream_backward(maxrows):
+    """MMRCA_CONV_SIDE_WGRAD: the 1x1 / implicit-GEMM 3x3 weight gradients launched on a second stream beside the input-gradient chain
+    (ConvEncoder._wgrad_stream) -- the same kernels on the same operands, so features are bit-identical and every parameter gradient
+    differs from the one-stream backward only by the order in which fp32 atomics land (bound: 1e-4 of the tensor's largest entry; the
+    one-stream backward run twice differs by up to ~2e-6).  Three backwards in a row over the same buffers: the second and third find
+    the dz buffers of the first still registered with their side-stream readers.  maxrows = 200: only the late stages (at this image
+    size) use the stream, the rest stays on the main one."""
+    from garbage_classification_rca_amd import conv_engine as CE
+    images = torch.randn(3, 3, 64, 64, generator=torch.Generator().manual_seed(5)).cuda()
+    out = {}
+    for side in (False, True):
+        CE.SIDE_WGRAD, CE.SIDE_MAXROWS = side, maxrows
+        try:
+            enc, own, _ = _conv_pair("eff_v2_medium", torch.bfloat16, seed=4)
+            grads = []
+            for rep in range(3):
+                for v in own.g.values():
+                    v.zero_()
+                feat = enc.forward(images, save=True, train=False, seed=9)
+                dfeat = (torch.randn(feat.shape, generator=torch.Generator().manual_seed(6)) * 0.1).to(feat.dtype).cuda()
+                enc.backward(dfeat)
+                torch.cuda.synchronize()
+                grads.append({k: v.float().cpu().clone() for k, v in own.g.items()})
+            assert (enc._side is not None) == side and not enc._side_busy
+            out[side] = (feat.float().cpu(), grads)
+            enc.release()
+        finally:
+            CE.SIDE_WGRAD, CE.SIDE_MAXROWS = "auto", 1 << 40
+    assert torch.equal(out[True][0], out[False][0])
+    worst = 0.0
+    for rep in range(3):
+        for k, ref in out[False][1][0].items():
+            if ref.abs().max() > 0:
+                worst = max(worst, rel(out[True][1][rep][k], ref))
+    print("side-stream vs one-stream weight gradients, worst tensor:", worst)
+    assert worst < 1e-4, worst

@@ -58,8 +58,8 @@ def test_mask_epoch_equals_a_seed_advanced_by_the_step_stride():
 
 @pytest.mark.parametrize("image_model,size,dtype", [("shuffle_net", 224, torch.bfloat16), ("transformer_B16", 224, torch.bfloat16),
                                                    ("transformer_B16", 224, "bf16x3f"), ("eff_v2_medium", 128, torch.bfloat16),
-                                                   ("eff_v2_medium", 128, "bf16x3f")])
-def test_graphed_step_computes_the_eager_step(image_model, size, dtype):
+                                                   ("eff_v2_medium", 128, "bf16x3f"), ("eff_v2_medium+side", 128, "bf16x3f")])
+def test_graphed_step_computes_the_eager_step(image_model, size, dtype, monkeypatch):
     """two models from the same seed, the same six batches: eager hip_train_step vs GraphedTrainStep (2 eager calls, 1 capture, 3
     replays).  Same losses step by step -- which requires every replay to draw the masks of ITS step (feature dropout 0.6: frozen
     masks move the loss by tenths) -- same parameters at the end, same host-side step counters; then one more EAGER step on both
@@ -69,6 +69,10 @@ def test_graphed_step_computes_the_eager_step(image_model, size, dtype):
     from garbage_classification_rca_amd import lib as L
     B, n = 4, 6
     data = _batches(n + 1, B, size)
+    if image_model.endswith("+side"):        # the conv weight gradients on their side stream: the capture records the fork / join as graph edges
+        from garbage_classification_rca_amd import conv_engine as CE
+        monkeypatch.setattr(CE, "SIDE_WGRAD", True)
+        image_model = image_model[:-5]
     ma, mb, mc = (_model(image_model, B, size, dtype=dtype) for _ in range(3))
     # (stochastic depth of the EfficientNetV2 blocks is drawn, not injected: its keep masks are counter-based draws of the step seed like
     # the dropout masks -- round 5, mmrca_sd_rowscale -- so the replay of step s and the eager step s keep the same blocks)
