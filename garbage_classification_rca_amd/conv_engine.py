@@ -57,6 +57,7 @@ IGEMM_DGRAD = os.environ.get("MMRCA_CONV_IGEMM_DGRAD", "1") == "1"
 SIDE_WGRAD = os.environ.get("MMRCA_CONV_SIDE_WGRAD", "auto")
 SIDE_WGRAD = {"0": False, "1": True}.get(SIDE_WGRAD, "auto")
 SIDE_MAXROWS = int(os.environ.get("MMRCA_CONV_SIDE_MAXROWS", str(1 << 40)))
+SIDE_DW = os.environ.get("MMRCA_CONV_SIDE_DW", "1") == "1"       # ... and the depthwise convolutions' weight gradients with them
 
 ROWPAD = 256
 
@@ -474,7 +475,12 @@ class ConvEncoder:
         rows_in = B * H * Wd
         dx = self.buf(f"{tag}.dx.{u.cin}.{rows_in}", rows_in, u.cin) if need_dx else None
         rows_k = _ru(rows, 64)                       # the contraction of the weight gradient runs over whole 64-row steps (zero pad rows)
-        if u.dw:
+        if u.dw and SIDE_DW and self._side_on(rows):
+            # (the library runs the input gradient and the weight gradient as separate launches anyway: one call for each)
+            with self._wgrad_stream(dz_key, rows):
+                L.dwconv3x3_bwd(dz, sv["x"], w, None, gw, B, H, Wd, u.cin, u.stride, dt, ws=self.buf("tmp.dw.ws", 1, 16 << 20, torch.float32))
+            L.dwconv3x3_bwd(dz, sv["x"], w, dx, None, B, H, Wd, u.cin, u.stride, dt)
+        elif u.dw:
             L.dwconv3x3_bwd(dz, sv["x"], w, dx, gw, B, H, Wd, u.cin, u.stride, dt, ws=self.buf("tmp.dw.ws", 1, 16 << 20, torch.float32))
         elif u.k == 1:
             with self._wgrad_stream(dz_key, rows):
