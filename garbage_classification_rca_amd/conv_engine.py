@@ -57,6 +57,12 @@ IGEMM_DGRAD = os.environ.get("MMRCA_CONV_IGEMM_DGRAD", "1") == "1"
 SIDE_WGRAD = os.environ.get("MMRCA_CONV_SIDE_WGRAD", "auto")
 SIDE_WGRAD = {"0": False, "1": True}.get(SIDE_WGRAD, "auto")
 SIDE_MAXROWS = int(os.environ.get("MMRCA_CONV_SIDE_MAXROWS", str(1 << 40)))
+# 1x1 weight gradients with at least this many output elements run on the 256x256 split-K slab kernel (mmrca_gemm_splitk on ragged
+# output shapes) instead of 128x128 tiles + fp32 atomics.  Isolated (tools/conv_wgrad_bench.py, us, atomics / slabs, B = 64 | B = 16):
+# 3072 x 512: 98 / 59 | 60 / 34; 512 x 3072: 89 / 59 | 58 / 34; 176 x 1056: 61 / 60 | 29 / 38; 304 x 1824: 46 / 50 | 24 / 32;
+# 160 x 640: 50 / 57 | 26 / 42; 48 x 192 (K = 921,600): 92 / 166 | 33 / 99 -- the slabs pay for whole 256x256 tiles and a second launch,
+# which only the widest layers (EfficientNetV2-M stage 7, -L stages 6-7) win back.  "0" = never.
+WGRAD_SLAB_MIN_ELEMS = int(os.environ.get("MMRCA_CONV_WGRAD_SLAB_MIN", "1000000"))
 SIDE_DW = os.environ.get("MMRCA_CONV_SIDE_DW", "1") == "1"       # ... and the depthwise convolutions' weight gradients with them
 
 ROWPAD = 256
@@ -428,6 +434,15 @@ class ConvEncoder:
     # event of its last side-stream reader; the saved inputs live until the next forward.  backward() joins the streams before every
     # hand-over to the gradient exchange and at its end, so nothing outside this class sees the second stream.  Inside a HIP-graph
     # capture the fork / join events become graph edges: the replayed step has the same two branches.
+    def _wgrad_slab(self, M: int, N: int, K: int, dt) -> bool:
+        """1x1 weight gradient [M = cout, N = cin] over K rows on the split-K slab kernel?  (see WGRAD_SLAB_MIN_ELEMS)"""
+        return (WGRAD_SLAB_MIN_ELEMS > 0 and M * N >= WGRAD_SLAB_MIN_ELEMS and self.o.gemm_impl == L.IMPL_AUTO
+                and L.gemm_splitk_ragged_ok(M, N, K, dt))
+
+    def _splitk_ws(self):
+        """partial-tile workspace of mmrca_gemm_splitk, one per stream that launches weight gradients"""
+        return self.buf(f"tmp.splitk.{torch.cuda.current_stream().cuda_stream}", 1, L.SPLITK_WS_BYTES, torch.uint8)
+
     def _side_on(self, rows: int) -> bool:
         if not SIDE_WGRAD or rows > SIDE_MAXROWS or torch.device(self.o.device).type != "cuda":
             return False
@@ -484,8 +499,13 @@ class ConvEncoder:
             L.dwconv3x3_bwd(dz, sv["x"], w, dx, gw, B, H, Wd, u.cin, u.stride, dt, ws=self.buf("tmp.dw.ws", 1, 16 << 20, torch.float32))
         elif u.k == 1:
             with self._wgrad_stream(dz_key, rows):
-                L.gemm(dz, sv["x"], gw, M=u.cout, N=u.cin, K=rows_k, lda=u.cout, ldb=sv.get("ld_x", u.cin), ldc=u.cin, a_layout=L.KROW,
-                       b_layout=L.KROW, accum=True, dtype=dt, impl=self.o.gemm_impl)
+                if self._wgrad_slab(u.cout, u.cin, rows_k, dt):
+                    # 256x256 tiles, the contraction split over all CUs, fp32 partial tiles through a workspace and a fixed-order
+                    # reduction (the ViT's weight-gradient kernel, csrc/gemm256.hip, on ragged output shapes)
+                    L.gemm_splitk(dz, sv["x"], gw, self._splitk_ws(), M=u.cout, N=u.cin, K=rows_k, lda=u.cout, ldb=sv.get("ld_x", u.cin), ldc=u.cin)
+                else:
+                    L.gemm(dz, sv["x"], gw, M=u.cout, N=u.cin, K=rows_k, lda=u.cout, ldb=sv.get("ld_x", u.cin), ldc=u.cin, a_layout=L.KROW,
+                           b_layout=L.KROW, accum=True, dtype=dt, impl=self.o.gemm_impl)
             if need_dx:
                 ldc = u.cin
                 if dx_into is not None:          # (view of a wider row buffer, its row pitch): the input gradient lands in its column window

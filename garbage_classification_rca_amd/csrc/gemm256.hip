@@ -81,7 +81,12 @@ __device__ __forceinline__ const bf16_t* piece_src(const bf16_t* __restrict__ ba
     const int kr = 4 * i + (lane >> 4);
     const int chp = lane & 15;
     const int c = ((((chp >> 1) ^ krow_f2(kr))) << 1) | (chp & 1);
-    return base + (int64_t)kr * ld + row0 + (STRIPE ? 64 * (c >> 2) + 32 * h + 8 * (c & 3) : c * 8);
+    // ragged tiles (the split-K weight gradients of the conv layers: 176 x 1056, 48 x 192, ...): an 8-column chunk past the
+    // operand's last column is fetched from column 0 of the same row instead -- finite values that only reach output rows /
+    // columns the reduction never stores -- so nothing outside the [K, rows_total] matrix is ever read (rows_total % 8 == 0)
+    int64_t col = row0 + (STRIPE ? 64 * (c >> 2) + 32 * h + 8 * (c & 3) : c * 8);
+    if (col + 8 > rows_total) col = 0;
+    return base + (int64_t)kr * ld + col;
   }
 }
 
@@ -983,7 +988,7 @@ int mmrca_gemm256_x3(const void* A_hi, const void* A_lo, const void* B_hi, const
 // caller-owned workspace.  One block per CU: (M/256)*(N/256) tiles x `splits` K ranges <= 256 blocks.
 // ---------------------------------------------------------------------------------------------------------------------
 __global__ void __launch_bounds__(256)
-splitk_reduce256_k(const float* __restrict__ slab, float* __restrict__ C, int64_t ldc, int ntiles, int tiles_n, int splits) {
+splitk_reduce256_k(const float* __restrict__ slab, float* __restrict__ C, int64_t ldc, int ntiles, int tiles_n, int splits, int64_t M, int64_t N) {
   const int tile = blockIdx.x >> 6;
   const int idx = ((blockIdx.x & 63) << 8) + threadIdx.x;          // which f32x4 of the tile, accumulator order
   const float* src = slab + (int64_t)tile * 65536 + (int64_t)idx * 4;
@@ -997,6 +1002,7 @@ splitk_reduce256_k(const float* __restrict__ slab, float* __restrict__ C, int64_
   const int wr = w >> 2, wc = w & 3, l16 = lane & 15, g = lane >> 4;
   const int row = 128 * a + 64 * wr + 16 * i + l16, col = 128 * b + 32 * wc + 16 * j + 4 * g;
   const int tm = tile / tiles_n, tn = tile % tiles_n;
+  if ((int64_t)tm * 256 + row >= M || (int64_t)tn * 256 + col >= N) return;     // ragged edge tiles (N % 4 == 0: whole float4s)
   float* dst = C + ((int64_t)tm * 256 + row) * ldc + (int64_t)tn * 256 + col;
   f32x4 c = *reinterpret_cast<f32x4*>(dst);
   c += s;
@@ -1004,8 +1010,8 @@ splitk_reduce256_k(const float* __restrict__ slab, float* __restrict__ C, int64_
 }
 
 extern "C" int64_t mmrca_gemm_splitk_workspace_bytes(int64_t M, int64_t N) {
-  if (M <= 0 || N <= 0 || M % 256 || N % 256) return 0;
-  const int64_t tiles = (M / 256) * (N / 256);
+  if (M <= 0 || N <= 0 || M % 8 || N % 8) return 0;
+  const int64_t tiles = ((M + 255) / 256) * ((N + 255) / 256);
   if (tiles > 256) return 0;
   return (256 / tiles) * tiles * 65536 * 4;
 }
@@ -1016,12 +1022,17 @@ static int gemm_splitk_impl(const void* A, const void* A_lo, const void* B, cons
   const bool x3 = A_lo != nullptr;
   const int nseg = x3 ? (B_lo ? 3 : 2) : 1;
   MMRCA_REQUIRE(A && B && C && workspace, "gemm_splitk: null operand");
-  MMRCA_REQUIRE(M > 0 && N > 0 && M % 256 == 0 && N % 256 == 0 && K >= 128 && K % 64 == 0,
-                "gemm_splitk: needs M %% 256 == 0, N %% 256 == 0, K %% 64 == 0, K >= 128 (got M=%lld N=%lld K=%lld)", (long long)M, (long long)N, (long long)K);
+  // M, N: multiples of 256, or -- both operands K-major (the weight-gradient layout), plain bf16 -- any multiples of 8: edge tiles
+  // then fetch the chunks past the last column from column 0 (piece_src) and the reduction skips what lies outside C
+  const bool ragged = M % 256 != 0 || N % 256 != 0;
+  MMRCA_REQUIRE(M > 0 && N > 0 && M % 8 == 0 && N % 8 == 0 && K >= 128 && K % 64 == 0 &&
+                (!ragged || (a_layout == MMRCA_KROW && b_layout == MMRCA_KROW && !A_lo)),
+                "gemm_splitk: needs K %% 64 == 0, K >= 128 and M, N multiples of 256 (K-major bf16 operands: of 8) (got M=%lld N=%lld K=%lld)",
+                (long long)M, (long long)N, (long long)K);
   MMRCA_REQUIRE(lda % 8 == 0 && ldb % 8 == 0 && ldc % 4 == 0 && (((uintptr_t)A | (uintptr_t)B | (uintptr_t)C | (uintptr_t)workspace) & 15) == 0,
                 "gemm_splitk: operands must be 16-byte aligned");
   MMRCA_REQUIRE(lda >= (a_layout == MMRCA_ROWK ? K : M) && ldb >= (b_layout == MMRCA_ROWK ? K : N) && ldc >= N, "gemm_splitk: leading dimension too small");
-  const int tiles_m = (int)(M / 256), tiles_n = (int)(N / 256), tiles = tiles_m * tiles_n;
+  const int tiles_m = (int)((M + 255) / 256), tiles_n = (int)((N + 255) / 256), tiles = tiles_m * tiles_n;
   MMRCA_REQUIRE(tiles <= 256, "gemm_splitk: more than 256 output tiles (use mmrca_gemm)");
   const int64_t ksteps = (int64_t)nseg * (K / 64);   // bf16x3: the virtual contraction [A_hi|A_lo|A_hi] . [B_hi|B_hi|B_lo]
   int64_t splits64 = 256 / tiles;                   // one workgroup per CU
@@ -1053,7 +1064,7 @@ static int gemm_splitk_impl(const void* A, const void* A_lo, const void* B, cons
   }
 #undef LSLAB
   MMRCA_CHECK_LAUNCH("gemm_splitk(mfma256)");
-  hipLaunchKernelGGL(splitk_reduce256_k, dim3(tiles * 64), dim3(256), 0, st, (const float*)workspace, C, ldc, tiles, tiles_n, splits);
+  hipLaunchKernelGGL(splitk_reduce256_k, dim3(tiles * 64), dim3(256), 0, st, (const float*)workspace, C, ldc, tiles, tiles_n, splits, M, N);
   MMRCA_CHECK_LAUNCH("gemm_splitk(reduce)");
   return 0;
 }

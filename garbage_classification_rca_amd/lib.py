@@ -307,6 +307,13 @@ def gemm_splitk_ok(M, N, K, dtype):
     return dtype == BF16 and M % 256 == 0 and N % 256 == 0 and K % 64 == 0 and K >= 128 and (M // 256) * (N // 256) <= 256
 
 
+def gemm_splitk_ragged_ok(M, N, K, dtype):
+    """the same kernel on output shapes that are not multiples of 256 (K-major bf16 operands only: the conv layers' weight gradients,
+    176 x 1056, 48 x 192, ...): edge tiles compute on duplicated columns and the reduction stores only what lies inside C"""
+    return (dtype == BF16 and M % 8 == 0 and N % 8 == 0 and K % 64 == 0 and K >= 128
+            and ((M + 255) // 256) * ((N + 255) // 256) <= 256)
+
+
 def gemm_splitk(A, B, Cout, workspace, *, M, N, K, lda, ldb, ldc, a_layout=KROW, b_layout=KROW):
     """fp32 Cout += A (.) B over K on 256x256 tiles, partial tiles through `workspace` (uint8/any dtype tensor in HBM)"""
     _dev(A, "gemm_splitk A")

@@ -140,7 +140,10 @@ int mmrca_gemm_streamk_config(int max_split, int min_ksteps, int bf16_products);
 
 /* Weight gradient on 256x256 tiles with the contraction split over workgroups: C[M,N] (fp32) += A (.) B over K
  * (torch autograd of nn.Linear: dW = dY^T X; same call sites as mmrca_gemm's accumulate mode).  bf16 operands, either
- * layout; M % 256 == 0, N % 256 == 0, K % 64 == 0, at most 256 output tiles.  The per-workgroup fp32 partial tiles go
+ * layout; M % 256 == 0, N % 256 == 0, K % 64 == 0, at most 256 output tiles -- or, with both operands K-major (MMRCA_KROW: the
+ * weight-gradient layout), any M, N that are multiples of 8 (the conv layers: 176 x 1056, 48 x 192, ...): the edge tiles then
+ * re-read column 0 in place of the columns past the operands' edge (nothing outside [K, M] / [K, N] is read) and the second launch
+ * stores only what lies inside C.  The per-workgroup fp32 partial tiles go
  * through `workspace` (caller-owned, >= mmrca_gemm_splitk_workspace_bytes(M, N) bytes, one per concurrently used
  * stream) with plain stores and a second launch adds them into C -- no atomics, bitwise reproducible. */
 int64_t mmrca_gemm_splitk_workspace_bytes(int64_t M, int64_t N);

@@ -459,6 +459,37 @@ def test_gemm_splitk_256_tiles(layouts):
     _splitk_case(768, 512, 64 * 101, al, bl)
 
 
+@pytest.mark.parametrize("shape", [(176, 1056, 64 * 45), (1056, 176, 64 * 45), (48, 192, 64 * 40), (304, 1824, 64 * 9), (8, 8, 128),
+                                   (264, 256, 192), (256, 520, 64 * 7), (3072, 512, 64 * 3)])
+def test_gemm_splitk_on_output_shapes_that_are_not_multiples_of_256(shape):
+    """the conv layers' weight gradients (both operands K-major): edge tiles fetch column 0 in place of the columns past the operands'
+    edge -- the operands here are EXACT-size allocations, and integer-valued, so any stray read or a stored out-of-range element shows
+    as an inequality (C carries a guard band of rows that must stay untouched)"""
+    M, N, K = shape
+    assert L.gemm_splitk_ragged_ok(M, N, K, L.BF16)
+    _splitk_case(M, N, K, 1, 1, exact=True)
+    _splitk_case(M, N, K, 1, 1)
+    # a wider row pitch for B (a column window of a wider activation: ShuffleNet's in-place split) and for C, guard rows behind C
+    g = torch.Generator().manual_seed(5)
+    A = torch.randint(-2, 3, (K, M), generator=g).float()
+    Bw = torch.randint(-3, 4, (K, N + 24), generator=g).float()
+    Ad, Bd = dev(A, torch.bfloat16), dev(Bw, torch.bfloat16)
+    Cd = torch.full((M + 3, N + 8), 7.0, device="cuda")
+    ws = torch.empty(L.SPLITK_WS_BYTES, dtype=torch.uint8, device="cuda")
+    L.gemm_splitk(Ad, Bd[:, 8:], Cd, ws, M=M, N=N, K=K, lda=M, ldb=N + 24, ldc=N + 8)
+    torch.cuda.synchronize()
+    ref = torch.full((M + 3, N + 8), 7.0, dtype=torch.float64)
+    ref[:M, :N] += A.double().t() @ Bw[:, 8:8 + N].double()
+    assert torch.equal(Cd.cpu().double(), ref)
+
+
+def test_gemm_splitk_rejects_ragged_shapes_in_row_major_layouts():
+    A, B, C = dev(torch.zeros(176, 256), torch.bfloat16), dev(torch.zeros(256, 256), torch.bfloat16), dev(torch.zeros(176, 256))
+    ws = torch.empty(L.SPLITK_WS_BYTES, dtype=torch.uint8, device="cuda")
+    with pytest.raises(L.MmrcaError):
+        L.gemm_splitk(A, B, C, ws, M=176, N=256, K=256, lda=256, ldb=256, ldc=256, a_layout=L.ROWK, b_layout=L.ROWK)
+
+
 def test_gemm_splitk_is_bitwise_reproducible_and_matches_the_atomic_kernel():
     a = _splitk_case(768, 768, 64 * 131)
     b = _splitk_case(768, 768, 64 * 131)
