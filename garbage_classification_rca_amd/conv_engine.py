@@ -439,9 +439,23 @@ class ConvEncoder:
         return (WGRAD_SLAB_MIN_ELEMS > 0 and M * N >= WGRAD_SLAB_MIN_ELEMS and self.o.gemm_impl == L.IMPL_AUTO
                 and L.gemm_splitk_ragged_ok(M, N, K, dt))
 
+    def _scratch(self, name: str, nbytes: int, per_stream: bool = False):
+        """an uninitialised workspace of exactly nbytes (NOT through buf(): its rows are padded to 256, so buf(name, 1, 64 MiB) is a
+        16 GiB tensor and, first requested inside a graph capture, a 16 GiB fill node in every replay)"""
+        key = ("scratch", name, torch.cuda.current_stream().cuda_stream if per_stream else 0)
+        t = self._bufs.get(key)
+        if t is None:
+            t = self._bufs[key] = torch.empty(nbytes, dtype=torch.uint8, device=self.o.device)
+        return t
+
     def _splitk_ws(self):
-        """partial-tile workspace of mmrca_gemm_splitk, one per stream that launches weight gradients"""
-        return self.buf(f"tmp.splitk.{torch.cuda.current_stream().cuda_stream}", 1, L.SPLITK_WS_BYTES, torch.uint8)
+        """partial-tile workspace of mmrca_gemm_splitk, one per stream that launches weight gradients (every partial tile is written
+        before it is read)"""
+        return self._scratch("splitk", L.SPLITK_WS_BYTES, per_stream=True)
+
+    def _dw_ws(self):
+        """partial sums of the depthwise weight gradient (csrc/conv.hip: at most 196,608 threads x 288 B, written before they are read)"""
+        return self._scratch("dw", 64 << 20).view(torch.float32)
 
     def _side_on(self, rows: int) -> bool:
         if not SIDE_WGRAD or rows > SIDE_MAXROWS or torch.device(self.o.device).type != "cuda":
@@ -493,10 +507,10 @@ class ConvEncoder:
         if u.dw and SIDE_DW and self._side_on(rows):
             # (the library runs the input gradient and the weight gradient as separate launches anyway: one call for each)
             with self._wgrad_stream(dz_key, rows):
-                L.dwconv3x3_bwd(dz, sv["x"], w, None, gw, B, H, Wd, u.cin, u.stride, dt, ws=self.buf("tmp.dw.ws", 1, 16 << 20, torch.float32))
+                L.dwconv3x3_bwd(dz, sv["x"], w, None, gw, B, H, Wd, u.cin, u.stride, dt, ws=self._dw_ws())
             L.dwconv3x3_bwd(dz, sv["x"], w, dx, None, B, H, Wd, u.cin, u.stride, dt)
         elif u.dw:
-            L.dwconv3x3_bwd(dz, sv["x"], w, dx, gw, B, H, Wd, u.cin, u.stride, dt, ws=self.buf("tmp.dw.ws", 1, 16 << 20, torch.float32))
+            L.dwconv3x3_bwd(dz, sv["x"], w, dx, gw, B, H, Wd, u.cin, u.stride, dt, ws=self._dw_ws())
         elif u.k == 1:
             with self._wgrad_stream(dz_key, rows):
                 if self._wgrad_slab(u.cout, u.cin, rows_k, dt):
