@@ -435,6 +435,15 @@ class MMRCAEngine:
             self._bufs[key] = t
         return t
 
+    def vec(self, name, n, dtype=torch.float32, layer=0):
+        """a [1, n] vector (per-row statistics, log-sum-exps): NOT a GEMM operand, so no 256-row padding -- through buf() every
+        [1, B*H*S] log-sum-exp buffer of the ViT was a 620 MB tensor"""
+        key = (name, layer, "vec", n, dtype)
+        t = self._bufs.get(key)
+        if t is None:
+            t = self._bufs[key] = torch.zeros(1, n, dtype=dtype, device=self.device)
+        return t
+
     def buf(self, name, rows, cols, dtype=None, layer=0):
         dtype = dtype or self.dtype
         key = (name, layer, rows, cols, dtype)
@@ -660,7 +669,7 @@ class MMRCAEngine:
             first = torch.arange(B, device=ids.device, dtype=torch.int64) * T
             mask32 = mask.to(torch.int32).contiguous()
         fb = lambda name, cols, l=0, dt=None: self.buf("t_" + name, cap, cols, dt, l if save else 0)
-        stat = lambda name, l=0: self.buf("t_" + name, 1, _round_up(cap, ROWPAD), torch.float32, l if save else 0)
+        stat = lambda name, l=0: self.vec("t_" + name, _round_up(cap, ROWPAD), torch.float32, l if save else 0)
         emb = fb("emb", D)
         type_row = self.Wflat(P + "embeddings.token_type_embeddings.weight", D) if s.type_vocab else None
         L.embed_fwd(ids32, pos, self.W(P + "embeddings.word_embeddings.weight"), self.W(P + "embeddings.position_embeddings.weight"),
@@ -676,13 +685,13 @@ class MMRCAEngine:
             K = S.text_layer_keys(s, i)
             last_tail = CLS_TAIL and i == s.layers - 1          # (the class-token attention reads fp32 q|k|v)
             qkv = self.planes_buf("t_qkv", cap, 3 * D, i if save else 0) if (self._qkv_planes_ok(T, dh) and not last_tail) else fb("qkv", 3 * D, i)
-            ctx, lse = fb("ctx", D, i), self.buf("t_lse", 1, _round_up(B * H * T, ROWPAD), torch.float32, i if save else 0)
+            ctx, lse = fb("ctx", D, i), self.vec("t_lse", _round_up(B * H * T, ROWPAD), torch.float32, i if save else 0)
             self._lin_fwd(x, P + K["q"] + ".weight", P + K["q"] + ".bias", qkv, M, 3 * D, D, wnumel=3 * D * D)
             if CLS_TAIL and i == s.layers - 1:
                 # class-token tail: the class-token query's attention, then rows b*T only (see CLS_TAIL above)
                 cb = lambda name, cols, dt=None: self.buf("t_" + name + "_c", B, cols, dt, i if save else 0)
                 ctx_c, x_c = cb("ctx", D), cb("xin", D)
-                lse = self.buf("t_lse_c", 1, _round_up(B * H, ROWPAD), torch.float32, i if save else 0)
+                lse = self.vec("t_lse_c", _round_up(B * H, ROWPAD), torch.float32, i if save else 0)
                 L.mha_cls_fwd(qkv, mask32, ctx_c, lse, B, H, T, dh, dh ** -0.5, self.dt, drop_p=dp, drop_seed=sd(i, 1), cu=cu)
                 x_c[:B].copy_(x.index_select(0, first))
                 att = cb("att", D)
@@ -830,7 +839,7 @@ class MMRCAEngine:
         nP, Tn, D, Fd, H = s.tokens - 1, s.tokens, s.dim, s.ffn, s.heads
         dh, M, Kp = D // H, B * Tn, 3 * s.patch * s.patch
         fb = lambda name, rows, cols, l=0, dt=None: self.buf("v_" + name, rows, cols, dt, l if save else 0)
-        stat = lambda name, l=0: self.buf("v_" + name, 1, _round_up(M, ROWPAD), torch.float32, l if save else 0)
+        stat = lambda name, l=0: self.vec("v_" + name, _round_up(M, ROWPAD), torch.float32, l if save else 0)
         images = images.to(torch.float32).contiguous()
         patches = fb("patches", B * nP, Kp)
         L.patchify_fwd(images, patches, B, 3, s.image, s.image, s.patch, self.dt)
@@ -853,13 +862,13 @@ class MMRCAEngine:
             last_tail = CLS_TAIL and i == s.layers - 1          # (the class-token attention reads fp32 q|k|v)
             qkv = self.planes_buf("v_qkv", M, 3 * D, i if save else 0) if (self._qkv_planes_ok(Tn, dh) and not last_tail) else fb("qkv", M, 3 * D, i)
             ctx = fb("ctx", M, D, i)
-            lse = self.buf("v_lse", 1, _round_up(B * H * Tn, ROWPAD), torch.float32, i if save else 0)
+            lse = self.vec("v_lse", _round_up(B * H * Tn, ROWPAD), torch.float32, i if save else 0)
             self._lin_fwd(y1, Lk + "self_attention.in_proj_weight", Lk + "self_attention.in_proj_bias", qkv, M, 3 * D, D)
             if CLS_TAIL and i == s.layers - 1:
                 # class-token tail: the class-token query's attention, then rows b*Tn only (see CLS_TAIL above)
                 cb = lambda name, cols, dt=None: fb(name + "_c", B, cols, i, dt)
                 ctx_c, x_c = cb("ctx", D), cb("xin", D)
-                lse = self.buf("v_lse_c", 1, _round_up(B * H, ROWPAD), torch.float32, i if save else 0)
+                lse = self.vec("v_lse_c", _round_up(B * H, ROWPAD), torch.float32, i if save else 0)
                 L.mha_cls_fwd(qkv, None, ctx_c, lse, B, H, Tn, dh, dh ** -0.5, self.dt)
                 x_c[:B].copy_(x[:M].view(B, Tn, D)[:, 0])
                 x1 = cb("x1", D)
