@@ -455,7 +455,7 @@ class ConvEncoder:
 
     def _dw_ws(self):
         """partial sums of the depthwise weight gradient (csrc/conv.hip: at most 196,608 threads x 288 B, written before they are read)"""
-        return self._scratch("dw", 64 << 20).view(torch.float32)
+        return self._scratch("dw", 64 << 20, per_stream=True).view(torch.float32)      # (per stream: MMRCA_CONV_SIDE_MAXROWS can leave some layers on the main one)
 
     def _side_on(self, rows: int) -> bool:
         if not SIDE_WGRAD or rows > SIDE_MAXROWS or torch.device(self.o.device).type != "cuda":
