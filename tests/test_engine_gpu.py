@@ -518,24 +518,27 @@ def test_cfg4_vit_l16_bert_cross_attention_only_fp32_logits():
     eng.release_buffers()
 
 
-def test_two_rank_data_parallel_rehearsal_keeps_replicas_identical():
+@pytest.mark.parametrize("extra,batch,port", [([], 8, 29533), (["--image_model", "eff_v2_medium", "--image_size", "128", "--dtype", "bf16x3f"], 4, 29537)])
+def test_two_rank_data_parallel_rehearsal_keeps_replicas_identical(extra, batch, port):
     """N>1 path of bench.py (sharded synthetic data, overlapped gradient all-reduce over the flat arena, fused SGD) with
     two ranks sharing this one GPU and gloo standing in for RCCL: after several steps both replicas hold bit-identical
-    parameters and exactly one arena's worth of gradients was reduced per step."""
+    parameters and exactly one arena's worth of gradients was reduced per step.  Second case: the reference's default image model,
+    whose weight gradients run on a SIDE stream (conv_engine.SIDE_WGRAD): a stage is handed to the exchange only after that stream
+    has been joined -- a weight gradient landing behind its span's all-reduce would leave the replicas different."""
     import subprocess
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     env = dict(os.environ, MMRCA_DIST_BACKEND="gloo", MMRCA_CHECK_REPLICAS="1")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
-           "--master-port", "29533", os.path.join(root, "bench.py"), "--gpus", "2", "--batch", "8", "--steps", "2", "--warmup", "1",
-           "--no_cpu_baseline"]
+           "--master-port", str(port), os.path.join(root, "bench.py"), "--gpus", "2", "--batch", str(batch), "--steps", "2", "--warmup", "1",
+           "--no_cpu_baseline"] + extra
     r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600, cwd=root)
     assert r.returncode == 0, r.stderr[-2000:]
     assert "replicas identical" in r.stderr
     line = [l for l in r.stdout.splitlines() if l.startswith("{")][-1]
     import json
     d = json.loads(line)
-    assert d["n_gpus"] == 2 and d["config"]["global_batch"] == 16 and d["scaling"] == "weak"
+    assert d["n_gpus"] == 2 and d["config"]["global_batch"] == 2 * batch and d["scaling"] == "weak"
 
 
 @pytest.mark.parametrize("image_model,dtype", [("transformer_B16", "bf16"), ("shuffle_net", "bf16"), ("transformer_B16", "bf16x3f"), ("eff_v2_medium", "bf16x3f")])
