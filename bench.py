@@ -631,6 +631,8 @@ def main():
     graph_on[0] = False                        # the per-launch measurements below bracket eager launches with HIP events
     saved_streams = (eng._side_v, eng._side_t, eng._side, eng._text_stream)
     eng._side_v = eng._side_t = eng._side = eng._text_stream = None
+    from garbage_classification_rca_amd import conv_engine as CE
+    saved_conv_side, CE.SIDE_WGRAD = CE.SIDE_WGRAD, False      # (the conv backbones' weight gradients too: ONE stream for the per-launch timings)
     replay = max(2, min(4, args.steps))
     with contextlib.redirect_stdout(io.StringIO()):
         step(0)
@@ -665,6 +667,7 @@ def main():
     prof, L.GEMM_PROFILE = L.GEMM_PROFILE, None
     kprof, L.KERNEL_PROFILE = L.KERNEL_PROFILE, None
     eng._side_v, eng._side_t, eng._side, eng._text_stream = saved_streams
+    CE.SIDE_WGRAD = saved_conv_side
     if world > 1 and os.environ.get("MMRCA_CHECK_REPLICAS") == "1":
         # data-parallel invariant: every rank applied the same averaged gradient, so the replicas are bit-identical
         chk = eng.arena.p.double().sum().view(1)
