@@ -63,6 +63,12 @@ SIDE_MAXROWS = int(os.environ.get("MMRCA_CONV_SIDE_MAXROWS", str(1 << 40)))
 # 160 x 640: 50 / 57 | 26 / 42; 48 x 192 (K = 921,600): 92 / 166 | 33 / 99 -- the slabs pay for whole 256x256 tiles and a second launch,
 # which only the widest layers (EfficientNetV2-M stage 7, -L stages 6-7) win back.  "0" = never.
 WGRAD_SLAB_MIN_ELEMS = int(os.environ.get("MMRCA_CONV_WGRAD_SLAB_MIN", "1000000"))
+# train-mode BatchNorm forward in two launches instead of three: the finish step (sums -> mean / rstd, running statistics) inside the apply
+# pass (mmrca_bn_moments + mmrca_bn_act_fwd_fin; bf16, channel counts that are multiples of 8).  OFF by default: parity-green and measured
+# at +0.1 .. +2.2 % (EfficientNetV2-M B = 16: 517.3 / 509.5 -> 529.0 / 509.9 samples/s; B = 64 938.0 / 943.6 -> 941.8 / 951.8; ShuffleNetV2 B = 4
+# under a HIP graph 654 -> 660; configs[2] 649 -> 647) -- inside the run-to-run noise except for the graph-replayed step: not worth a
+# default-on change to the BatchNorm path in this round (tools/bn_fold_ab.sh)
+BN_FOLD = os.environ.get("MMRCA_CONV_BN_FOLD", "0") == "1"
 SIDE_DW = os.environ.get("MMRCA_CONV_SIDE_DW", "1") == "1"       # ... and the depthwise convolutions' weight gradients with them
 
 ROWPAD = 256
@@ -276,11 +282,18 @@ class ConvEncoder:
         nt = _ru((c + 63) // 64, 4)                          # tickets of the fused statistics launch (mmrca_bn_stats_fused), cleared with the rest
         if off is None:
             off = self._bn_used
-            self._bn_used += 4 * _ru(c, 4) + nt             # (16-byte aligned slices)
+            self._bn_used += 7 * _ru(c, 4) + nt             # (16-byte aligned slices; the last three: s1 | s2 | shift of _bn_sums)
             if self._bn_used > self.BN_ARENA_FLOATS:
                 raise L.MmrcaError("conv_engine: BatchNorm arena exhausted")
             self._bn_off[u.bn_key] = off
         return self._bn_arena[off: off + 2 * c].view(2, c), self._bn_arena[off + 2 * _ru(c, 4): off + 2 * _ru(c, 4) + 2 * c].view(1, 2 * c)
+
+    def _bn_sums(self, u: "_Unit"):
+        """(s1, s2, shift) of the folded forward (BN_FOLD): three fp32 [C] vectors behind the layer's other slices, cleared with them"""
+        self._bn_slices(u)
+        c4 = _ru(u.cout, 4)
+        off = self._bn_off[u.bn_key] + 4 * c4 + _ru((u.cout + 63) // 64, 4)
+        return tuple(self._bn_arena[off + k * c4: off + k * c4 + u.cout] for k in range(3))
 
     def _bn_tickets(self, u: "_Unit"):
         off = self._bn_off[u.bn_key] + 4 * _ru(u.cout, 4)
@@ -375,6 +388,7 @@ class ConvEncoder:
         w = self.W(u.conv_key + ".weight")
         fused_stats = False
         sums = None
+        fold = False
         if u.dw:
             L.dwconv3x3_fwd(x, w, z, B, H, Wd, u.cin, u.stride, dt)
         elif u.k == 1:
@@ -414,11 +428,20 @@ class ConvEncoder:
         elif sums is not None:
             L.bn_finish_sums(sums[0], sums[1], rm, sums[2], rows, mean, rstd, rm, rv, u.cout, u.eps, 0.1)
         else:
-            fuse = FUSE_BN_FINISH and train and self.cdtype == torch.bfloat16 and u.cout % 8 == 0 and not BN_FLAT
-            L.bn_stats(z, mean, rstd, rm, rv, rows, u.cout, u.cout, u.eps, 0.1 if train else 0.0, train, dt, ws=self._bn_ws(), prezeroed=True,
-                       tickets=self._bn_tickets(u) if fuse else None)
+            fold = BN_FOLD and train and not BN_FLAT and not FUSE_BN_FINISH and L.bn_fold_ok(u.cout, u.cout, dt)
+            if fold:
+                s1, s2, shift = self._bn_sums(u)
+                L.bn_moments(z, s1, s2, shift, rows, u.cout, u.cout, dt)
+            else:
+                fuse = FUSE_BN_FINISH and train and self.cdtype == torch.bfloat16 and u.cout % 8 == 0 and not BN_FLAT
+                L.bn_stats(z, mean, rstd, rm, rv, rows, u.cout, u.cout, u.eps, 0.1 if train else 0.0, train, dt, ws=self._bn_ws(), prezeroed=True,
+                           tickets=self._bn_tickets(u) if fuse else None)
         fused_res = res is not None and FUSE_RES and self.cdtype == torch.bfloat16 and u.cout % 8 == 0
-        if fused_res:
+        if fold:
+            y = out if fused_res else self.buf(tag + ".y", rows, u.cout)
+            L.bn_act_fwd_fin(z, s1, s2, shift, self.W(u.bn_key + ".weight"), self.W(u.bn_key + ".bias"), res if fused_res else None,
+                             rowscale if fused_res else None, y, mean, rstd, rm, rv, rows, u.cout, u.act, Ho * Wo, u.eps, 0.1, dt)
+        elif fused_res:
             y = out
             L.bn_act_fwd_res(z, mean, rstd, self.W(u.bn_key + ".weight"), self.W(u.bn_key + ".bias"), res, rowscale, y, rows, u.cout, u.act,
                              Ho * Wo, dt)

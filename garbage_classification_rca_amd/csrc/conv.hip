@@ -1189,7 +1189,7 @@ __device__ __forceinline__ float bn_trimmed(float sum, float lo, float hi) { ret
 struct BnFinish { int* counters; float* running_mean; float* running_var; float eps, momentum; };
 __global__ void __launch_bounds__(256)
 col_moment2_v8_k(const bf16_t* __restrict__ x, float* __restrict__ s1, float* __restrict__ s2, int64_t rows, int C, int64_t ld,
-                 int64_t rows_per_block, BnFinish fin = BnFinish{nullptr, nullptr, nullptr, 0.f, 0.f}) {
+                 int64_t rows_per_block, BnFinish fin = BnFinish{nullptr, nullptr, nullptr, 0.f, 0.f}, float* __restrict__ shift_out = nullptr) {
   __shared__ float red[4][8][17];
   const int cg = threadIdx.x & 7, rl = threadIdx.x >> 3;
   const int c0 = blockIdx.x * 64 + cg * 8;
@@ -1209,6 +1209,12 @@ col_moment2_v8_k(const bf16_t* __restrict__ x, float* __restrict__ s1, float* __
     }
 #pragma unroll
     for (int j = 0; j < 8; ++j) m[j] = bn_trimmed(m[j], mlo[j], mhi[j]);
+    // shift_out (mmrca_bn_moments): the shift this launch subtracted, for a consumer that turns the sums into mean / rstd itself
+    // (bn_act_fwd_fin_v8_k: no bn_finish_shifted_k launch); every row lane of every row range holds the same values
+    if (shift_out && blockIdx.y == 0 && rl == 0) {
+#pragma unroll
+      for (int j = 0; j < 8; ++j) shift_out[c0 + j] = m[j];
+    }
     int64_t r = r0 + rl;
     for (; r + 224 < r1; r += 256) {                   // eight rows in flight per thread (one load per iteration ran at 2.6 TB/s)
       cm_b8 v[8];
@@ -1650,6 +1656,70 @@ bn_act_fwd_res_v8_k(const bf16_t* __restrict__ x, const float* __restrict__ mean
     *reinterpret_cast<bn_b8*>(out + i0 + k * rs8) = o;
   }
 }
+// The forward apply with the FINISH step inside (round 6): the moments launch left (sum d, sum d^2) in s1 / s2 and its shift in `shift`
+// (mmrca_bn_moments); every thread turns the sums of its eight channels into mean / rstd itself -- the arithmetic of bn_finish_shifted_k,
+// operation for operation -- and the threads of the first row group also store them (the backward reads them) and update the running
+// statistics.  One launch less per BatchNorm layer and step (146 of the ~2,000 launches of an EfficientNetV2-M step).  RES: the block's
+// residual connection as in bn_act_fwd_res_v8_k.
+template <bool RES>
+__global__ void __launch_bounds__(256)
+bn_act_fwd_fin_v8_k(const bf16_t* __restrict__ x, const float* __restrict__ s1, const float* __restrict__ s2, const float* __restrict__ shift,
+                    const bf16_t* __restrict__ gamma, const bf16_t* __restrict__ beta, const bf16_t* __restrict__ res,
+                    const float* __restrict__ rowscale, bf16_t* __restrict__ y, float* __restrict__ mean_out, float* __restrict__ rstd_out,
+                    float* __restrict__ running_mean, float* __restrict__ running_var, int64_t rows, int C8, int act, int64_t rows_per_sample,
+                    float n, float eps, float momentum) {
+  const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int64_t r0 = t / C8 * BN_R;
+  if (r0 >= rows) return;
+  const int c0 = (int)(t % C8) * 8;
+  const int64_t i0 = (r0 * C8 + c0 / 8) * 8, rs8 = (int64_t)C8 * 8;
+  bn_b8 xv[BN_R];
+  [[maybe_unused]] bn_b8 rv[BN_R];
+  [[maybe_unused]] float sc[BN_R];
+#pragma unroll
+  for (int k = 0; k < BN_R; ++k) {
+    const int64_t kk = r0 + k < rows ? k : 0;
+    xv[k] = *reinterpret_cast<const bn_b8*>(x + i0 + kk * rs8);
+    if constexpr (RES) {
+      rv[k] = *reinterpret_cast<const bn_b8*>(res + i0 + kk * rs8);
+      sc[k] = rowscale ? rowscale[(r0 + kk) / rows_per_sample] : 1.f;
+    }
+  }
+  float a1[8], a2[8], sh[8], m[8], r[8];
+  bn_load8(s1 + c0, a1); bn_load8(s2 + c0, a2); bn_load8(shift + c0, sh);
+  const bn_b8 g = *reinterpret_cast<const bn_b8*>(gamma + c0), b = *reinterpret_cast<const bn_b8*>(beta + c0);
+  float var[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    const float d1 = a1[j] / n;
+    m[j] = sh[j] + d1;
+    var[j] = fmaxf(a2[j] / n - d1 * d1, 0.f);
+    r[j] = rsqrtf(var[j] + eps);
+  }
+  if (r0 == 0) {                       // (one thread per channel group: t < C8)
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      mean_out[c0 + j] = m[j];
+      rstd_out[c0 + j] = r[j];
+      if (running_mean && momentum > 0.f) {
+        running_mean[c0 + j] = (1.f - momentum) * running_mean[c0 + j] + momentum * m[j];
+        running_var[c0 + j] = (1.f - momentum) * running_var[c0 + j] + momentum * (n > 1.f ? var[j] * n / (n - 1.f) : var[j]);
+      }
+    }
+  }
+#pragma unroll
+  for (int k = 0; k < BN_R; ++k) {
+    if (r0 + k >= rows) break;
+    bn_b8 o;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const float v = act_f(((float)xv[k][j] - m[j]) * r[j] * (float)g[j] + (float)b[j], act);
+      if constexpr (RES) o[j] = (bf16_t)((float)rv[k][j] + sc[k] * v);
+      else o[j] = (bf16_t)v;
+    }
+    *reinterpret_cast<bn_b8*>(y + i0 + k * rs8) = o;
+  }
+}
 __global__ void __launch_bounds__(256)
 bn_act_bwd_apply_v8_k(const bf16_t* __restrict__ dy, const bf16_t* __restrict__ x, const float* __restrict__ mean, const float* __restrict__ rstd,
                       const bf16_t* __restrict__ gamma, const bf16_t* __restrict__ beta, const float* __restrict__ sum_du,
@@ -1721,6 +1791,45 @@ extern "C" int mmrca_bn_act_fwd_res(const void* x, const float* mean, const floa
                      (const bf16_t*)x, mean, rstd, (const bf16_t*)gamma, (const bf16_t*)beta, (const bf16_t*)res, rowscale, (bf16_t*)out, rows,
                      C / 8, act, rows_per_sample);
   MMRCA_CHECK_LAUNCH("bn_act_fwd_res");
+  return 0;
+}
+
+/* BatchNorm forward in TWO launches instead of three (bf16, C % 8 == 0, train mode).  mmrca_bn_moments: the shifted one-pass sums of
+ * x[rows, C] into s1 / s2 (fp32 [C], += : the caller zeroes them) and the shift it used into `shift` (fp32 [C], written); then
+ * mmrca_bn_act_fwd_fin: y = act(bn(x)) (res != NULL: y = res + rowscale[row / rows_per_sample] * act(bn(x))) with the finish step inside --
+ * mean / rstd from (s1, s2, shift) per thread, stored to mean_out / rstd_out (distinct from s1 / s2) for the backward, running statistics
+ * updated (momentum > 0) -- i.e. what mmrca_bn_stats + mmrca_bn_act_fwd(_res) compute, without the bn_finish launch between them.
+ * Other dtypes / channel counts return -3 and the caller takes the three launches. */
+extern "C" int mmrca_bn_moments(const void* x, float* s1, float* s2, float* shift, int64_t rows, int C, int64_t ld, int dtype, void* stream) {
+  MMRCA_REQUIRE(x && s1 && s2 && shift && rows > 0 && C > 0 && ld >= C, "bn_moments: bad arguments");
+  if (!(dtype == MMRCA_BF16 && C % 8 == 0 && ld % 8 == 0 && (((uintptr_t)x) & 15) == 0))
+    return mmrca_fail(-3, "bn_moments: only the bf16 / C %% 8 == 0 / 16-byte aligned case is built");
+  dim3 grid; int64_t per;
+  col_grid(rows, C, &grid, &per);
+  hipLaunchKernelGGL(col_moment2_v8_k, grid, dim3(256), 0, (hipStream_t)stream, (const bf16_t*)x, s1, s2, rows, C, ld, per,
+                     BnFinish{nullptr, nullptr, nullptr, 0.f, 0.f}, shift);
+  MMRCA_CHECK_LAUNCH("bn_moments");
+  return 0;
+}
+extern "C" int mmrca_bn_act_fwd_fin(const void* x, const float* s1, const float* s2, const float* shift, const void* gamma, const void* beta,
+                                    const void* res, const float* rowscale, void* y, float* mean_out, float* rstd_out, float* running_mean,
+                                    float* running_var, int64_t rows, int C, int act, int64_t rows_per_sample, float eps, float momentum,
+                                    int dtype, void* stream) {
+  MMRCA_REQUIRE(x && s1 && s2 && shift && gamma && beta && y && mean_out && rstd_out && rows > 0 && C > 0 && act >= 0 && act <= 3 &&
+                rows_per_sample > 0 && mean_out != s1 && mean_out != s2 && rstd_out != s1 && rstd_out != s2, "bn_act_fwd_fin: bad arguments");
+  if (!(bn_v8_ok(C, dtype, x, y, gamma, beta) &&
+        ((((uintptr_t)s1) | ((uintptr_t)s2) | ((uintptr_t)shift) | ((uintptr_t)res)) & 15) == 0))
+    return mmrca_fail(-3, "bn_act_fwd_fin: only the bf16 / C %% 8 == 0 / 16-byte aligned case is built");
+  const dim3 grid(blocks_for((rows + BN_R - 1) / BN_R * (C / 8), 256));
+  if (res)
+    hipLaunchKernelGGL(bn_act_fwd_fin_v8_k<true>, grid, dim3(256), 0, (hipStream_t)stream, (const bf16_t*)x, s1, s2, shift, (const bf16_t*)gamma,
+                       (const bf16_t*)beta, (const bf16_t*)res, rowscale, (bf16_t*)y, mean_out, rstd_out, running_mean, running_var, rows, C / 8,
+                       act, rows_per_sample, (float)rows, eps, momentum);
+  else
+    hipLaunchKernelGGL(bn_act_fwd_fin_v8_k<false>, grid, dim3(256), 0, (hipStream_t)stream, (const bf16_t*)x, s1, s2, shift, (const bf16_t*)gamma,
+                       (const bf16_t*)beta, (const bf16_t*)nullptr, (const float*)nullptr, (bf16_t*)y, mean_out, rstd_out, running_mean,
+                       running_var, rows, C / 8, act, rows_per_sample, (float)rows, eps, momentum);
+  MMRCA_CHECK_LAUNCH("bn_act_fwd_fin");
   return 0;
 }
 

@@ -75,6 +75,8 @@ _SIGS = {
     "mmrca_bn_act_bwd_sums": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i32, _i32, _i32, _i32, _vp],
     "mmrca_se_dx": [_vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _vp, _vp, _vp, _vp, _vp, _i32, _vp, _vp],
     "mmrca_bn_act_fwd_res": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i32, _i32, _i64, _i32, _vp],
+    "mmrca_bn_moments": [_vp, _vp, _vp, _vp, _i64, _i32, _i64, _i32, _vp],
+    "mmrca_bn_act_fwd_fin": [_vp] * 13 + [_i64, _i32, _i32, _i64, _f32, _f32, _i32, _vp],
     "mmrca_bn_stats": [_vp, _vp, _vp, _vp, _vp, _i64, _i32, _i64, _f32, _f32, _i32, _i32, _vp],
     "mmrca_bn_stats_ws": [_vp, _vp, _vp, _vp, _vp, _i64, _i32, _i64, _f32, _f32, _i32, _i32, _vp, _i64, _i32, _vp],
     "mmrca_bn_stats_fused": [_vp, _vp, _vp, _vp, _vp, _i64, _i32, _i64, _f32, _f32, _i32, _vp, _i32, _vp],
@@ -651,6 +653,8 @@ _CONV_BYTES = {
     "mmrca_bn_stats_fused": ("BatchNorm", lambda a: a[5] * a[6] * _esz(a[10])),
     "mmrca_bn_act_fwd": ("BatchNorm", lambda a: 2 * a[6] * a[7] * _esz(a[9])),
     "mmrca_bn_act_fwd_res": ("BatchNorm", lambda a: 3 * a[8] * a[9] * _esz(a[12])),
+    "mmrca_bn_moments": ("BatchNorm", lambda a: a[4] * a[5] * _esz(a[7])),
+    "mmrca_bn_act_fwd_fin": ("BatchNorm", lambda a: (3 if a[6] else 2) * a[13] * a[14] * _esz(a[19])),
     # backward with batch statistics: the sums need dy and z once, the apply pass needs them again and writes dx
     "mmrca_bn_act_bwd": ("BatchNorm", lambda a: (5 if a[13] else 3) * a[10] * a[11] * _esz(a[14])),
     "mmrca_bn_act_bwd_ws": ("BatchNorm", lambda a: (5 if a[13] else 3) * a[10] * a[11] * _esz(a[14])),
@@ -752,6 +756,23 @@ def gemm_bnstats(A, B, Cout, *, M, N, K, lda, ldb, ldc, dtype, shift, s1, s2):
 def bn_finish_sums(s1, s2, shift, nslots, rows, mean, rstd, running_mean, running_var, C, eps, momentum):
     _c("mmrca_bn_finish_sums", ptr(s1), ptr(s2), ptr(shift), nslots, rows, ptr(mean), ptr(rstd), ptr(running_mean), ptr(running_var), C, eps,
        momentum)
+
+
+def bn_fold_ok(C, ld, dtype):
+    """can the train-mode BatchNorm forward run as mmrca_bn_moments + mmrca_bn_act_fwd_fin (two launches instead of three)?"""
+    return dtype == BF16 and C % 8 == 0 and ld % 8 == 0
+
+
+def bn_moments(x, s1, s2, shift, rows, C, ld, dtype):
+    """shifted one-pass sums of x[rows, C] into s1 / s2 (+=, caller-zeroed) and the shift into `shift`"""
+    _c("mmrca_bn_moments", ptr(x), ptr(s1), ptr(s2), ptr(shift), rows, C, ld, dtype)
+
+
+def bn_act_fwd_fin(x, s1, s2, shift, gamma, beta, res, rowscale, y, mean, rstd, running_mean, running_var, rows, C, act, rows_per_sample,
+                   eps, momentum, dtype):
+    """y = [res + rowscale *] act(bn(x)) with the finish step inside: mean / rstd from (s1, s2, shift) -> mean / rstd, running statistics"""
+    _c("mmrca_bn_act_fwd_fin", ptr(x), ptr(s1), ptr(s2), ptr(shift), ptr(gamma), ptr(beta), ptr(res), ptr(rowscale), ptr(y), ptr(mean), ptr(rstd),
+       ptr(running_mean), ptr(running_var), rows, C, act, rows_per_sample, eps, momentum, dtype)
 
 
 def bn_act_fwd_res(x, mean, rstd, gamma, beta, res, rowscale, out, rows, C, act, rows_per_sample, dtype):

@@ -252,6 +252,17 @@ int mmrca_bn_act_fwd(const void* x, const float* mean, const float* rstd, const 
  * operands; anything else returns -3 and the caller issues the two calls. */
 int mmrca_bn_act_fwd_res(const void* x, const float* mean, const float* rstd, const void* gamma, const void* beta, const void* res,
                          const float* rowscale, void* out, int64_t rows, int C, int act, int64_t rows_per_sample, int dtype, void* stream);
+/* The train-mode forward in TWO launches instead of three (bf16, C % 8 == 0, 16-byte aligned operands; anything else returns -3 and the
+ * caller takes mmrca_bn_stats + mmrca_bn_act_fwd(_res)).  mmrca_bn_moments: the shifted one-pass sums of x[rows, C] into s1 / s2 (fp32
+ * [C], +=: the caller zeroes them) and the shift it subtracted into `shift` (fp32 [C], written).  mmrca_bn_act_fwd_fin: y = act(bn(x)) --
+ * res != NULL: y = res + rowscale[row / rows_per_sample] * act(bn(x)), rowscale NULL = 1 -- with the finish step inside: mean / rstd from
+ * (s1, s2, shift), stored to mean_out / rstd_out (fp32 [C], distinct from s1 / s2; the backward reads them), running statistics
+ * updated when momentum > 0 (torch semantics, as mmrca_bn_stats). */
+int mmrca_bn_moments(const void* x, float* s1, float* s2, float* shift, int64_t rows, int C, int64_t ld, int dtype, void* stream);
+int mmrca_bn_act_fwd_fin(const void* x, const float* s1, const float* s2, const float* shift, const void* gamma, const void* beta,
+                         const void* res, const float* rowscale, void* y, float* mean_out, float* rstd_out, float* running_mean,
+                         float* running_var, int64_t rows, int C, int act, int64_t rows_per_sample, float eps, float momentum, int dtype,
+                         void* stream);
 /* backward of y = act(BN(x)); scratch = fp32 [2C]; dx / dgamma+dbeta (fp32, +=) may be NULL; train as in the forward */
 int mmrca_bn_act_bwd(const void* dy, const void* x, const float* mean, const float* rstd, const void* gamma, const void* beta,
                      void* dx, float* dgamma, float* dbeta, float* scratch, int64_t rows, int C, int act, int train, int dtype,

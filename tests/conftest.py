@@ -28,7 +28,8 @@ FILE_ORDER = [
     "test_augment_gpu.py",      # f1
 ]
 # opt-in / experimental kernels (off by default in the product): collected last of all
-LAST = ("test_flat_streaming_batchnorm_reductions",)
+LAST = ("test_flat_streaming_batchnorm_reductions", "test_batchnorm_forward_with_the_finish_inside_the_apply_pass",
+        "test_backbone_with_the_folded_batchnorm_forward_matches_the_three_launch_form")
 
 
 def pytest_configure(config):

@@ -752,3 +752,82 @@ def test_weight_gradients_on_the_side_stream_equal_the_one_stream_backward(maxro
                 worst = max(worst, rel(out[True][1][rep][k], ref))
     print("side-stream vs one-stream weight gradients, worst tensor:", worst)
     assert worst < 1e-4, worst
+
+
+@pytest.mark.parametrize("R,C", [(9001, 384), (300, 8), (20000, 72), (3600, 1824), (50, 3840)])
+@pytest.mark.parametrize("with_res", [False, True])
+def test_batchnorm_forward_with_the_finish_inside_the_apply_pass(R, C, with_res):
+    """mmrca_bn_moments + mmrca_bn_act_fwd_fin (two launches: the apply pass turns the sums into mean / rstd itself) against torch's
+    train-mode batch_norm in fp64 and against the three-launch form (mmrca_bn_stats + mmrca_bn_act_fwd / _res).  The two forms run the
+    same arithmetic on sums whose fp32 atomics land in another order: mean / rstd / running statistics within 2e-6 (8x the largest
+    difference seen between two runs of ONE form), outputs within one bf16 rounding of each other."""
+    eps, act = 1e-3, L.CONV_SILU
+    g = torch.Generator().manual_seed(R + C)
+    x = (torch.randn(R, C, generator=g) * 2 + torch.randn(C, generator=g) * 3).bfloat16()
+    gam, bet = (torch.rand(C, generator=g) + 0.5).bfloat16(), (torch.randn(C, generator=g) * 0.3).bfloat16()
+    res = torch.randn(R, C, generator=g).bfloat16() if with_res else None
+    rps = 25 if R % 25 == 0 else R
+    rowscale = (torch.rand(R // rps, generator=g) > 0.3).float().cuda() / 0.7 if with_res else None
+    rm0, rv0 = torch.randn(C, generator=g) * 0.1, torch.rand(C, generator=g) + 0.5
+    u = F.batch_norm(x.double(), rm0.double().clone(), rv0.double().clone(), gam.double(), bet.double(), True, 0.1, eps)
+    ref = F.silu(u)
+    if with_res:
+        ref = res.double() + rowscale.cpu().double().repeat_interleave(rps)[:, None] * ref
+    xd, gd, bd = x.cuda(), gam.cuda(), bet.cuda()
+    resd = res.cuda() if with_res else None
+    # three launches
+    mean_a, rstd_a = torch.zeros(C, device="cuda"), torch.zeros(C, device="cuda")
+    rm_a, rv_a = rm0.clone().cuda(), rv0.clone().cuda()
+    L.bn_stats(xd, mean_a, rstd_a, rm_a, rv_a, R, C, C, eps, 0.1, True, L.BF16)
+    y_a = torch.empty(R, C, device="cuda", dtype=torch.bfloat16)
+    if with_res:
+        L.bn_act_fwd_res(xd, mean_a, rstd_a, gd, bd, resd, rowscale, y_a, R, C, act, rps, L.BF16)
+    else:
+        L.bn_act_fwd(xd, mean_a, rstd_a, gd, bd, y_a, R, C, act, L.BF16)
+    # two launches
+    assert L.bn_fold_ok(C, C, L.BF16)
+    sums = torch.zeros(3, C, device="cuda")
+    mean_b, rstd_b = torch.full((C,), 7.0, device="cuda"), torch.full((C,), 7.0, device="cuda")
+    rm_b, rv_b = rm0.clone().cuda(), rv0.clone().cuda()
+    y_b = torch.empty(R, C, device="cuda", dtype=torch.bfloat16)
+    L.bn_moments(xd, sums[0], sums[1], sums[2], R, C, C, L.BF16)
+    L.bn_act_fwd_fin(xd, sums[0], sums[1], sums[2], gd, bd, resd, rowscale, y_b, mean_b, rstd_b, rm_b, rv_b, R, C, act, rps, eps, 0.1, L.BF16)
+    torch.cuda.synchronize()
+    assert rel(y_b, ref) < TOL[torch.bfloat16], rel(y_b, ref)
+    for a, b in ((mean_a, mean_b), (rstd_a, rstd_b), (rm_a, rm_b), (rv_a, rv_b)):
+        assert rel(b, a) < 2e-6, rel(b, a)
+    # outputs: equal up to the bf16 rounding of a value that moved by ~1e-7
+    d = (y_a.float() - y_b.float()).abs()
+    assert float((d > 0).float().mean()) < 2e-2 and float((d / y_a.float().abs().clamp_min(1e-3)).max()) < 2 ** -6
+
+
+def test_backbone_with_the_folded_batchnorm_forward_matches_the_three_launch_form():
+    """EfficientNetV2-M, bf16, TRAIN-mode BatchNorm at 96 x 96 (B = 6: the late stages normalise over 54 rows): features, running
+    statistics and every parameter gradient with MMRCA_CONV_BN_FOLD on against off.  Two runs of EITHER form already differ (the sums'
+    fp32 atomics land in another order, a bf16 activation flips by one rounding, train-mode BatchNorm over few rows amplifies it), so the
+    bound is the distance between two runs of the three-launch form, times three."""
+    from garbage_classification_rca_amd import conv_engine as CE
+    images = torch.randn(6, 3, 96, 96, generator=torch.Generator().manual_seed(5)).cuda()
+
+    def run(fold):
+        CE.BN_FOLD = fold
+        try:
+            enc, own, _ = _conv_pair("eff_v2_medium", torch.bfloat16, seed=4)
+            enc.injected_keep = torch.ones(sum(1 for blk in enc.blocks if blk.get("res") and blk.get("sd", 0.0) > 0.0), 6)     # (no stochastic depth)
+            feat = enc.forward(images, save=True, train=True, seed=9)
+            dfeat = (torch.randn(feat.shape, generator=torch.Generator().manual_seed(6)) * 0.1).to(feat.dtype).cuda()
+            enc.backward(dfeat)
+            enc.sync_buffers()
+            torch.cuda.synchronize()
+            out = (feat.float().cpu(), torch.cat([v.float().flatten().cpu() for k, v in sorted(own.g.items())]),
+                   torch.cat([t.float().flatten().cpu() for k, t in sorted(enc.buffers.items()) if k.endswith(("running_mean", "running_var"))]))
+            enc.release()
+            return out
+        finally:
+            CE.BN_FOLD = False
+    a, a2, b = run(False), run(False), run(True)
+    dist = lambda p, q: float((p - q).norm() / q.norm())
+    for i, name in enumerate(("features", "gradients", "running statistics")):
+        noise, dev_ = dist(a2[i], a[i]), dist(b[i], a[i])
+        print(f"{name}: folded vs three-launch {dev_:.3e}, three-launch vs itself {noise:.3e}")
+        assert dev_ <= 3.0 * noise + 1e-5, (name, dev_, noise)
